@@ -1,0 +1,612 @@
+/*
+ * gemx_oracle.c -- CPU restatement (plain C, IEEE fp64, one env at a time) of the reference's
+ * SCMLSystem.simulate() hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * build, load or call this file.  The product (gym_electric_motor_amd/) never links or imports it and
+ * shares no source with it: the HIP kernels are an independent implementation that this file checks.
+ *
+ * Parity pinning: tests/test_oracle_golden.py checks this restatement against
+ *   - the reference's only golden trajectory, tests/integration_tests/ref_data.npz (via the replayed
+ *     action sequence in tests/golden/refdata_cont_sc_permexdc_dopri5.npz),
+ *   - ~40 trajectories recorded from the live reference by oracle/make_golden.py (Euler / dopri5,
+ *     free-run / episodic, with and without interlocking) for the three configured env ids,
+ *   - converter known-answer tables produced by the reference converter classes,
+ *   - the hand-written KATs in the reference's tests (Euler solver, PolynomialStaticLoad, constraints).
+ *
+ * All file:line citations are relative to /root/reference/src/gym_electric_motor/.
+ *
+ * Third-party arithmetic: the reference's default solver is scipy.integrate.ode('dopri5')
+ * (physical_systems/solvers.py:139-184; scipy 1.15.3 in this image, requirements.txt pins scipy>=1.4.1).
+ * scipy is not part of /root/reference.  ORC_SOLVER_DOPRI5 restates the published algorithm of Hairer's
+ * DOPRI5 (Dormand & Prince 1980 tableau; Hairer/Norsett/Wanner "Solving ODEs I", II.4-II.5: step-size
+ * control with Lund/PI stabilisation and the HINIT starting step) with scipy's settings for this path:
+ * rtol=1e-6, atol=1e-12, safety=0.9, dfactor(fac1)=0.2, ifactor(fac2)=10, beta=0 -> DOPRI5's default 0.04,
+ * nsteps=500, max_step=0 -> hmax = t_end - t, first_step=0 -> HINIT.  The predicted step size survives from
+ * one integrate() call to the next (DOPRI5 stores it back into WORK(7)) and is cleared by set_initial_value()
+ * (= reset).  Usually one accepted step per integrate() call; near the load's kinks steps are rejected and
+ * split.  The golden vectors recorded from the live scipy path pin this restatement to ~1e-12.
+ * ORC_SOLVER_DP5_FIXED is ONE Dormand-Prince step of size (t_end - t), 5th-order solution, no error control
+ * (what the adaptive code does whenever its first trial step is accepted).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+enum { ORC_SYS_DC_PERMEX = 0, ORC_SYS_PMSM = 1, ORC_SYS_SCIM = 2 };
+enum { ORC_CONV_CONT_4QC = 0, ORC_CONV_FINITE_B6 = 1, ORC_CONV_CONT_B6 = 2 };
+enum { ORC_LOAD_CONST_SPEED = 0, ORC_LOAD_POLY_STATIC = 1 };
+enum { ORC_SOLVER_EULER = 0, ORC_SOLVER_RK4 = 1, ORC_SOLVER_DOPRI5 = 2, ORC_SOLVER_DP5_FIXED = 3 };
+
+#define ORC_MAX_ODE 8
+#define ORC_MAX_OUT 16
+
+typedef struct orc_params {
+    int32_t system, converter, load, solver, nsteps;
+    int32_t limit_mask;   /* bit i set: LimitConstraint observes system-state entry i   (constraints.py:55-58) */
+    int32_t squared_mask; /* bit i set: SquaredConstraint sums entry i                   (constraints.py:96-98) */
+    int32_t reserved;
+    double tau, t_il, u_sup;
+    double mp[8]; /* DC: r_a,l_a,psi_e | PMSM: p,l_d,l_q,r_s,psi_p | SCIM: p,l_m,l_sigs,l_sigr,r_s,r_r */
+    double j_total, load_a, load_b, load_c, tau_decay;
+    double limits[ORC_MAX_OUT];
+    double init[ORC_MAX_ODE]; /* initial ODE state [omega, motor states...] */
+} orc_params;
+
+typedef struct orc_env {
+    double y[ORC_MAX_ODE];
+    double t;           /* SCMLSystem._t == solver.t */
+    int32_t k;          /* PhysicalSystem._k */
+    /* converter state (converters.py:40-43, 193-197) */
+    double action_start;
+    double duty[3][2];        /* Cont: per sub-converter clipped duty (ContDynamicallyAveragedConverter.set_action:144-146) */
+    int32_t sw_state[3];      /* FiniteTwoQuadrantConverter._switching_state, NOT cleared by reset() (45-54) */
+    int32_t sw_pattern[3][2]; /* _switching_pattern */
+    int32_t sw_plen[3];
+    /* solver f_params */
+    double u[2];
+    double dp_h; /* dopri5: predicted step size carried between integrate() calls (0 -> HINIT) */
+    /* constants */
+    double C[5][11];
+} orc_env;
+
+static int n_ode(const orc_params *p) { return p->system == ORC_SYS_DC_PERMEX ? 2 : (p->system == ORC_SYS_PMSM ? 4 : 6); }
+static int n_out(const orc_params *p) { return p->system == ORC_SYS_DC_PERMEX ? 5 : 14; }
+
+int orc_n_ode(const orc_params *p) { return n_ode(p); }
+int orc_n_out(const orc_params *p) { return n_out(p); }
+
+/* ---------------------------------------------------------------- model constants -------------- */
+/* dc_permanently_excited_motor.py:71-75; permanent_magnet_synchronous_motor.py:107-119;
+ * induction_motor.py:287-312 */
+void orc_model_constants(const orc_params *p, double C[5][11]) {
+    memset(C, 0, sizeof(double) * 55);
+    const double *mp = p->mp;
+    if (p->system == ORC_SYS_DC_PERMEX) {
+        double r_a = mp[0], l_a = mp[1], psi_e = mp[2];
+        C[0][0] = -psi_e / l_a; C[0][1] = -r_a / l_a; C[0][2] = 1.0 / l_a;
+    } else if (p->system == ORC_SYS_PMSM) {
+        double pp = mp[0], l_d = mp[1], l_q = mp[2], r_s = mp[3], psi_p = mp[4];
+        /*            omega,         i_d,   i_q, u_d, u_q, omega*i_d,  omega*i_q */
+        double M[3][7] = {{0, -r_s, 0, 1, 0, 0, l_q * pp},
+                          {-psi_p * pp, 0, -r_s, 0, 1, -l_d * pp, 0},
+                          {pp, 0, 0, 0, 0, 0, 0}};
+        for (int j = 0; j < 7; ++j) { C[0][j] = M[0][j] / l_d; C[1][j] = M[1][j] / l_q; C[2][j] = M[2][j]; }
+    } else {
+        double pp = mp[0], l_m = mp[1], l_sigs = mp[2], l_sigr = mp[3], r_s = mp[4], r_r = mp[5];
+        double l_s = l_m + l_sigs, l_r = l_m + l_sigr;
+        double sigma = (l_s * l_r - l_m * l_m) / (l_s * l_r);
+        double tau_r = l_r / r_r;
+        double tau_sig = sigma * l_s / (r_s + r_r * (l_m * l_m) / (l_r * l_r));
+        /* omega, i_a, i_b, psi_a, psi_b, omega*psi_a, omega*psi_b, u_sa, u_sb, u_ra, u_rb */
+        C[0][1] = -1 / tau_sig; C[0][3] = l_m * r_r / (sigma * l_s * l_r * l_r);
+        C[0][6] = l_m * pp / (sigma * l_r * l_s); C[0][7] = 1 / (sigma * l_s); C[0][9] = -l_m / (sigma * l_r * l_s);
+        C[1][2] = -1 / tau_sig; C[1][4] = l_m * r_r / (sigma * l_s * l_r * l_r);
+        C[1][5] = -l_m * pp / (sigma * l_r * l_s); C[1][8] = 1 / (sigma * l_s); C[1][10] = -l_m / (sigma * l_r * l_s);
+        C[2][1] = l_m / tau_r; C[2][3] = -1 / tau_r; C[2][6] = -pp; C[2][9] = 1;
+        C[3][2] = l_m / tau_r; C[3][4] = -1 / tau_r; C[3][5] = pp; C[3][10] = 1;
+        C[4][0] = pp;
+    }
+}
+
+/* ---------------------------------------------------------------- motor ------------------------ */
+/* torque: dc_permanently_excited_motor.py:67-69; permanent_magnet_synchronous_motor.py:134-139;
+ * induction_motor.py:236-248.  `ms` = motor part of the ODE state. */
+static double motor_torque(const orc_params *p, const double *ms) {
+    const double *mp = p->mp;
+    if (p->system == ORC_SYS_DC_PERMEX) return mp[2] * ms[0];
+    if (p->system == ORC_SYS_PMSM) return 1.5 * mp[0] * (mp[4] + (mp[1] - mp[2]) * ms[0]) * ms[1];
+    return 1.5 * mp[0] * mp[1] / (mp[1] + mp[3]) * (ms[2] * ms[1] - ms[3] * ms[0]);
+}
+
+/* electrical_ode = constant matrix x feature vector: dc_permanently_excited_motor.py:81-84;
+ * synchronous_motor.py:143-168; induction_motor.py:187-217 + squirrel_cage_induction_motor.py:121-129 */
+static void electrical_ode(const orc_params *p, const orc_env *e, const double *ms, const double *u, double omega,
+                           double *out) {
+    double f[11];
+    int nf, nr;
+    if (p->system == ORC_SYS_DC_PERMEX) {
+        f[0] = omega; f[1] = ms[0]; f[2] = u[0]; nf = 3; nr = 1;
+    } else if (p->system == ORC_SYS_PMSM) {
+        f[0] = omega; f[1] = ms[0]; f[2] = ms[1]; f[3] = u[0]; f[4] = u[1]; f[5] = omega * ms[0]; f[6] = omega * ms[1];
+        nf = 7; nr = 3;
+    } else {
+        f[0] = omega; f[1] = ms[0]; f[2] = ms[1]; f[3] = ms[2]; f[4] = ms[3]; f[5] = omega * ms[2]; f[6] = omega * ms[3];
+        f[7] = u[0]; f[8] = u[1]; f[9] = 0.0; f[10] = 0.0; /* SCIM: zero rotor voltage */
+        nf = 11; nr = 5;
+    }
+    for (int r = 0; r < nr; ++r) {
+        double acc = 0.0;
+        for (int j = 0; j < nf; ++j) acc += e->C[r][j] * f[j];
+        out[r] = acc;
+    }
+}
+
+/* ---------------------------------------------------------------- load ------------------------- */
+/* constant_speed_load.py:40-42 ; polynomial_static_load.py:62-66, 87-99 */
+static double mechanical_ode(const orc_params *p, double omega, double torque) {
+    if (p->load == ORC_LOAD_CONST_SPEED) return 0.0;
+    double omega_linear_factor = p->j_total / p->tau_decay;
+    double omega_lim = p->load_a / p->j_total * p->tau_decay;
+    double sign = omega > 0 ? 1.0 : (omega < -0.0 ? -1.0 : 0.0);
+    double a = fabs(omega) > omega_lim ? sign * p->load_a : omega_linear_factor * omega;
+    double static_torque = sign * p->load_c * omega * omega + p->load_b * omega + a;
+    return (torque - static_torque) / p->j_total;
+}
+
+/* SCMLSystem._system_equation, physical_systems.py:205-236: [load derivative, motor derivative] */
+static void system_equation(const orc_params *p, const orc_env *e, const double *y, double *dy) {
+    const double *ms = y + 1;
+    dy[0] = mechanical_ode(p, y[0], motor_torque(p, ms));
+    electrical_ode(p, e, ms, e->u, y[0], dy + 1);
+}
+
+/* ---------------------------------------------------------------- solvers ---------------------- */
+
+/* One Dormand-Prince stage sweep from (y, k1) with step h: fills y1 (5th order), k2 := f(y1) (FSAL),
+ * err vector in k4 (scaled by h), ysti unused.  Coefficients: Hairer CDOPRI. */
+static void dp5_stages(const orc_params *p, const orc_env *e, int n, const double *y, double h, double *k1, double *k2,
+                       double *k3, double *k4, double *k5, double *k6, double *y1) {
+    double yt[ORC_MAX_ODE];
+    for (int i = 0; i < n; ++i) yt[i] = y[i] + h * (1.0 / 5.0) * k1[i];
+    system_equation(p, e, yt, k2);
+    for (int i = 0; i < n; ++i) yt[i] = y[i] + h * (3.0 / 40.0 * k1[i] + 9.0 / 40.0 * k2[i]);
+    system_equation(p, e, yt, k3);
+    for (int i = 0; i < n; ++i) yt[i] = y[i] + h * (44.0 / 45.0 * k1[i] - 56.0 / 15.0 * k2[i] + 32.0 / 9.0 * k3[i]);
+    system_equation(p, e, yt, k4);
+    for (int i = 0; i < n; ++i)
+        yt[i] = y[i] + h * (19372.0 / 6561.0 * k1[i] - 25360.0 / 2187.0 * k2[i] + 64448.0 / 6561.0 * k3[i] -
+                            212.0 / 729.0 * k4[i]);
+    system_equation(p, e, yt, k5);
+    for (int i = 0; i < n; ++i)
+        yt[i] = y[i] + h * (9017.0 / 3168.0 * k1[i] - 355.0 / 33.0 * k2[i] + 46732.0 / 5247.0 * k3[i] +
+                            49.0 / 176.0 * k4[i] - 5103.0 / 18656.0 * k5[i]);
+    system_equation(p, e, yt, k6);
+    for (int i = 0; i < n; ++i)
+        y1[i] = y[i] + h * (35.0 / 384.0 * k1[i] + 500.0 / 1113.0 * k3[i] + 125.0 / 192.0 * k4[i] -
+                            2187.0 / 6784.0 * k5[i] + 11.0 / 84.0 * k6[i]);
+    system_equation(p, e, y1, k2);
+    for (int i = 0; i < n; ++i)
+        k4[i] = (71.0 / 57600.0 * k1[i] - 71.0 / 16695.0 * k3[i] + 71.0 / 1920.0 * k4[i] - 17253.0 / 339200.0 * k5[i] +
+                 22.0 / 525.0 * k6[i] - 1.0 / 40.0 * k2[i]) * h;
+}
+
+/* scipy.integrate.ode('dopri5').integrate(t_end) as used by ScipyOdeSolver (solvers.py:139-184). */
+static void dopri5_adaptive(const orc_params *p, orc_env *e, double t_end) {
+    const double RTOL = 1e-6, ATOL = 1e-12, SAFE = 0.9, FAC1 = 0.2, FAC2 = 10.0, BETA = 0.04, UROUND = 2.3e-16;
+    const int NMAX = 500;
+    int n = n_ode(p);
+    double k1[ORC_MAX_ODE], k2[ORC_MAX_ODE], k3[ORC_MAX_ODE], k4[ORC_MAX_ODE], k5[ORC_MAX_ODE], k6[ORC_MAX_ODE],
+        y1[ORC_MAX_ODE];
+    double x = e->t, xend = t_end;
+    if (xend == x) return;
+    double posneg = xend >= x ? 1.0 : -1.0;
+    double facold = 1e-4, expo1 = 0.2 - BETA * 0.75, facc1 = 1.0 / FAC1, facc2 = 1.0 / FAC2;
+    double hmax = fabs(xend - x);
+    double h = e->dp_h;
+    int last = 0, reject = 0, nstep = 0;
+    system_equation(p, e, e->y, k1);
+    if (h == 0.0) { /* HINIT */
+        double dnf = 0.0, dny = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double sk = ATOL + RTOL * fabs(e->y[i]);
+            dnf += (k1[i] / sk) * (k1[i] / sk);
+            dny += (e->y[i] / sk) * (e->y[i] / sk);
+        }
+        h = (dnf <= 1e-10 || dny <= 1e-10) ? 1e-6 : sqrt(dny / dnf) * 0.01;
+        h = fmin(h, hmax) * posneg;
+        for (int i = 0; i < n; ++i) y1[i] = e->y[i] + h * k1[i];
+        system_equation(p, e, y1, k2);
+        double der2 = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double sk = ATOL + RTOL * fabs(e->y[i]);
+            der2 += ((k2[i] - k1[i]) / sk) * ((k2[i] - k1[i]) / sk);
+        }
+        der2 = sqrt(der2) / h;
+        double der12 = fmax(fabs(der2), sqrt(dnf));
+        double h1 = der12 <= 1e-15 ? fmax(1e-6, fabs(h) * 1e-3) : pow(0.01 / der12, 1.0 / 5.0);
+        h = fmin(fmin(100.0 * fabs(h), h1), hmax) * posneg;
+    }
+    for (;;) {
+        if (nstep > NMAX) break;                       /* scipy would warn "larger nsteps is needed" */
+        if (0.1 * fabs(h) <= fabs(x) * UROUND) break;  /* step size too small */
+        if ((x + 1.01 * h - xend) * posneg > 0.0) { h = xend - x; last = 1; }
+        nstep++;
+        dp5_stages(p, e, n, e->y, h, k1, k2, k3, k4, k5, k6, y1);
+        double err = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double sk = ATOL + RTOL * fmax(fabs(e->y[i]), fabs(y1[i]));
+            err += (k4[i] / sk) * (k4[i] / sk);
+        }
+        err = sqrt(err / n);
+        double fac11 = pow(err, expo1);
+        double fac = fac11 / pow(facold, BETA);
+        fac = fmax(facc2, fmin(facc1, fac / SAFE));
+        double hnew = h / fac;
+        if (err <= 1.0) {
+            facold = fmax(err, 1e-4);
+            for (int i = 0; i < n; ++i) { k1[i] = k2[i]; e->y[i] = y1[i]; }
+            x = x + h;
+            if (last) { h = hnew; break; }
+            if (fabs(hnew) > hmax) hnew = posneg * hmax;
+            if (reject) hnew = posneg * fmin(fabs(hnew), fabs(h));
+            reject = 0;
+        } else {
+            hnew = h / fmin(facc1, fac11 / SAFE);
+            reject = 1;
+            last = 0;
+        }
+        h = hnew;
+    }
+    e->dp_h = h;
+    e->t = last ? t_end : x;
+}
+
+static void integrate(const orc_params *p, orc_env *e, double t_end) {
+    int n = n_ode(p);
+    if (p->solver == ORC_SOLVER_DOPRI5) { dopri5_adaptive(p, e, t_end); return; }
+    double k1[ORC_MAX_ODE], k2[ORC_MAX_ODE], k3[ORC_MAX_ODE], k4[ORC_MAX_ODE], k5[ORC_MAX_ODE], k6[ORC_MAX_ODE],
+        yt[ORC_MAX_ODE];
+    if (p->solver == ORC_SOLVER_EULER) {
+        if (p->nsteps <= 1) { /* solvers.py:124-136 */
+            system_equation(p, e, e->y, k1);
+            double h = t_end - e->t;
+            for (int i = 0; i < n; ++i) e->y[i] = e->y[i] + k1[i] * h;
+        } else { /* solvers.py:103-122 */
+            double h = (t_end - e->t) / p->nsteps;
+            for (int s = 0; s < p->nsteps; ++s) {
+                system_equation(p, e, e->y, k1);
+                for (int i = 0; i < n; ++i) e->y[i] = e->y[i] + k1[i] * h;
+            }
+        }
+    } else if (p->solver == ORC_SOLVER_RK4) { /* classical RK4; the reference has none */
+        double h = t_end - e->t;
+        system_equation(p, e, e->y, k1);
+        for (int i = 0; i < n; ++i) yt[i] = e->y[i] + 0.5 * h * k1[i];
+        system_equation(p, e, yt, k2);
+        for (int i = 0; i < n; ++i) yt[i] = e->y[i] + 0.5 * h * k2[i];
+        system_equation(p, e, yt, k3);
+        for (int i = 0; i < n; ++i) yt[i] = e->y[i] + h * k3[i];
+        system_equation(p, e, yt, k4);
+        for (int i = 0; i < n; ++i) e->y[i] = e->y[i] + h / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+    } else { /* ORC_SOLVER_DP5_FIXED: one Dormand-Prince step, 5th-order solution, no error control */
+        double h = t_end - e->t;
+        system_equation(p, e, e->y, k1);
+        for (int i = 0; i < n; ++i) yt[i] = e->y[i] + h * (1.0 / 5.0) * k1[i];
+        system_equation(p, e, yt, k2);
+        for (int i = 0; i < n; ++i) yt[i] = e->y[i] + h * (3.0 / 40.0 * k1[i] + 9.0 / 40.0 * k2[i]);
+        system_equation(p, e, yt, k3);
+        for (int i = 0; i < n; ++i) yt[i] = e->y[i] + h * (44.0 / 45.0 * k1[i] - 56.0 / 15.0 * k2[i] + 32.0 / 9.0 * k3[i]);
+        system_equation(p, e, yt, k4);
+        for (int i = 0; i < n; ++i)
+            yt[i] = e->y[i] + h * (19372.0 / 6561.0 * k1[i] - 25360.0 / 2187.0 * k2[i] + 64448.0 / 6561.0 * k3[i] -
+                                   212.0 / 729.0 * k4[i]);
+        system_equation(p, e, yt, k5);
+        for (int i = 0; i < n; ++i)
+            yt[i] = e->y[i] + h * (9017.0 / 3168.0 * k1[i] - 355.0 / 33.0 * k2[i] + 46732.0 / 5247.0 * k3[i] +
+                                   49.0 / 176.0 * k4[i] - 5103.0 / 18656.0 * k5[i]);
+        system_equation(p, e, yt, k6);
+        for (int i = 0; i < n; ++i)
+            e->y[i] = e->y[i] + h * (35.0 / 384.0 * k1[i] + 500.0 / 1113.0 * k3[i] + 125.0 / 192.0 * k4[i] -
+                                     2187.0 / 6784.0 * k5[i] + 11.0 / 84.0 * k6[i]);
+    }
+    e->t = t_end;
+}
+
+/* ---------------------------------------------------------------- transforms ------------------- */
+/* three_phase_motor.py:18-28 (matrices), 31-88 (t_23, t_32, q, q_inv) */
+static void t_23(const double *abc, double *ab) {
+    const double s = 0.5 * sqrt(3.0);
+    ab[0] = 2.0 / 3.0 * (abc[0] - 0.5 * abc[1] - 0.5 * abc[2]);
+    ab[1] = 2.0 / 3.0 * (s * abc[1] - s * abc[2]);
+}
+static void t_32(const double *ab, double *abc) {
+    const double s = 0.5 * sqrt(3.0);
+    abc[0] = ab[0];
+    abc[1] = -0.5 * ab[0] + s * ab[1];
+    abc[2] = -0.5 * ab[0] - s * ab[1];
+}
+static void q_rot(const double *x, double eps, double *out) {
+    double c = cos(eps), s = sin(eps);
+    double o0 = c * x[0] - s * x[1], o1 = s * x[0] + c * x[1];
+    out[0] = o0; out[1] = o1;
+}
+static void dq_to_abc(const double *dq, double eps, double *abc) { double ab[2]; q_rot(dq, eps, ab); t_32(ab, abc); }
+static void abc_to_dq(const double *abc, double eps, double *dq) { double ab[2]; t_23(abc, ab); q_rot(ab, -eps, dq); }
+
+/* ---------------------------------------------------------------- converters ------------------- */
+static double clip(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+static double sgn(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0); } /* np.sign */
+
+/* ContTwoQuadrantConverter via ContDynamicallyAveragedConverter: set_action clips to action_space [0,1]
+ * (converters.py:144-146), convert = clip(duty - sign(i)/tau*t_il, 0, 1) (148-158, 177-184, 425-427). */
+static double cont2qc_convert(const orc_params *p, double duty, double i) {
+    return clip(duty - sgn(i) / p->tau * p->t_il, 0.0, 1.0);
+}
+
+/* FiniteTwoQuadrantConverter._set_switching_pattern, converters.py:300-310.  Returns #segments (1|2). */
+static int fin2qc_set_action(const orc_params *p, orc_env *e, int leg, int action) {
+    if (action == 0 || e->sw_state[leg] == 0 || action == e->sw_state[leg] || p->t_il == 0.0) {
+        e->sw_pattern[leg][0] = action; e->sw_plen[leg] = 1;
+        return 1;
+    }
+    e->sw_pattern[leg][0] = 0; e->sw_pattern[leg][1] = action; e->sw_plen[leg] = 2;
+    return 2;
+}
+/* FiniteTwoQuadrantConverter.convert, converters.py:270-287 */
+static double fin2qc_convert(const orc_params *p, orc_env *e, int leg, double i, double t) {
+    if (t - p->tau / 1000.0 > e->action_start + p->t_il)
+        e->sw_state[leg] = e->sw_pattern[leg][e->sw_plen[leg] - 1];
+    else
+        e->sw_state[leg] = e->sw_pattern[leg][0];
+    if (e->sw_state[leg] == 0) return i < 0 ? 1.0 : 0.0;
+    if (e->sw_state[leg] == 1) return 1.0;
+    return 0.0;
+}
+
+static const int B6_SUBACTIONS[8][3] = {{2, 2, 2}, {2, 2, 1}, {2, 1, 2}, {2, 1, 1},
+                                        {1, 2, 2}, {1, 2, 1}, {1, 1, 2}, {1, 1, 1}}; /* converters.py:788-797 */
+
+/* converter.set_action: returns the number of integration segments; seg_end[] = absolute switching times */
+static int conv_set_action(const orc_params *p, orc_env *e, const double *action, double t, double *seg_end) {
+    e->action_start = t; /* converters.py:67 */
+    if (p->converter == ORC_CONV_CONT_4QC) { /* converters.py:485-491 */
+        e->duty[0][0] = clip(0.5 * (action[0] + 1.0), 0.0, 1.0);
+        e->duty[0][1] = clip(-0.5 * (action[0] - 1.0), 0.0, 1.0);
+        seg_end[0] = t + p->tau;
+        return 1;
+    }
+    if (p->converter == ORC_CONV_CONT_B6) { /* converters.py:897-903 */
+        for (int l = 0; l < 3; ++l) e->duty[l][0] = clip(0.5 * (action[l] + 1.0), 0.0, 1.0);
+        seg_end[0] = t + p->tau;
+        return 1;
+    }
+    /* Finite-B6C, converters.py:825-835: union of the legs' switching times, sorted */
+    int a = (int)action[0];
+    int two = 0;
+    for (int l = 0; l < 3; ++l)
+        if (fin2qc_set_action(p, e, l, B6_SUBACTIONS[a][l]) == 2) two = 1;
+    if (two) { seg_end[0] = t + p->t_il; seg_end[1] = t + p->tau; return 2; }
+    seg_end[0] = t + p->tau;
+    return 1;
+}
+
+/* converter.convert(i_out, t): normalised output voltages (1 for DC, 3 for B6) */
+static void conv_convert(const orc_params *p, orc_env *e, const double *i_in, double t, double *u) {
+    if (p->converter == ORC_CONV_CONT_4QC) { /* converters.py:481-483: both sub-converters see the SAME i_out */
+        u[0] = cont2qc_convert(p, e->duty[0][0], i_in[0]) - cont2qc_convert(p, e->duty[0][1], i_in[0]);
+    } else if (p->converter == ORC_CONV_CONT_B6) { /* converters.py:888-895 */
+        for (int l = 0; l < 3; ++l) u[l] = cont2qc_convert(p, e->duty[l][0], i_in[l]) - 0.5;
+    } else { /* converters.py:816-823 */
+        for (int l = 0; l < 3; ++l) u[l] = fin2qc_convert(p, e, l, i_in[l], t) - 0.5;
+    }
+}
+
+static void conv_reset(const orc_params *p, orc_env *e, double *u) {
+    e->action_start = 0.0; /* converters.py:45-54; switching state/pattern intentionally untouched */
+    if (p->converter == ORC_CONV_CONT_4QC) u[0] = 0.0;
+    else { u[0] = u[1] = u[2] = -0.5; } /* converters.py:808-814, 880-886 */
+}
+
+/* ---------------------------------------------------------------- simulate --------------------- */
+static double wrap_eps(double eps) { /* physical_systems.py:520-522 / 809-811 */
+    eps = fmod(eps, 2.0 * M_PI);
+    if (eps < 0) eps += 2.0 * M_PI; /* python % is non-negative for positive modulus */
+    if (eps > M_PI) eps -= 2.0 * M_PI;
+    return eps;
+}
+
+static void normalise(const orc_params *p, double *obs) {
+    int n = n_out(p);
+    for (int i = 0; i < n; ++i) obs[i] = obs[i] / p->limits[i];
+}
+
+/* SCMLSystem.simulate (DC), physical_systems.py:171-203 */
+static void simulate_dc(const orc_params *p, orc_env *e, const double *action, double *obs) {
+    double seg_end[2], i_in[1], u_n[1], u_in[1];
+    double u_sup = p->u_sup; /* IdealVoltageSupply.get_voltage, voltage_supplies.py:70-72 */
+    i_in[0] = e->y[1];
+    int nseg = conv_set_action(p, e, action, e->t, seg_end);
+    double t0 = e->t;
+    for (int s = 0; s < nseg; ++s) {
+        conv_convert(p, e, i_in, e->t, u_n);
+        u_in[0] = u_n[0] * u_sup;
+        e->u[0] = u_in[0];
+        integrate(p, e, s == nseg - 1 ? t0 + p->tau : seg_end[s]);
+        i_in[0] = e->y[1];
+    }
+    e->k += 1;
+    obs[0] = e->y[0]; obs[1] = motor_torque(p, e->y + 1); obs[2] = e->y[1]; obs[3] = u_in[0]; obs[4] = u_sup;
+    normalise(p, obs);
+}
+
+/* SynchronousMotorSystem.simulate, physical_systems.py:487-525 (control_space == 'abc') */
+static void simulate_pmsm(const orc_params *p, orc_env *e, const double *action, double *obs) {
+    double seg_end[2], i_in[3], u_n[3], u_in[3], u_dq[2], i_abc[3];
+    double u_sup = p->u_sup;
+    double eps = e->y[3];
+    dq_to_abc(e->y + 1, eps, i_in);
+    int nseg = conv_set_action(p, e, action, e->t, seg_end);
+    double t0 = e->t;
+    for (int s = 0; s < nseg; ++s) {
+        conv_convert(p, e, i_in, e->t, u_n);
+        for (int l = 0; l < 3; ++l) u_in[l] = u_n[l] * u_sup;
+        abc_to_dq(u_in, eps, u_dq);
+        e->u[0] = u_dq[0]; e->u[1] = u_dq[1];
+        integrate(p, e, s == nseg - 1 ? t0 + p->tau : seg_end[s]);
+        if (s < nseg - 1) { eps = e->y[3]; dq_to_abc(e->y + 1, eps, i_in); }
+    }
+    e->k += 1;
+    double torque = motor_torque(p, e->y + 1);
+    dq_to_abc(e->y + 1, eps, i_abc); /* eps of the LAST segment start (line 519) */
+    obs[0] = e->y[0]; obs[1] = torque;
+    obs[2] = i_abc[0]; obs[3] = i_abc[1]; obs[4] = i_abc[2]; obs[5] = e->y[1]; obs[6] = e->y[2];
+    obs[7] = u_in[0]; obs[8] = u_in[1]; obs[9] = u_in[2]; obs[10] = u_dq[0]; obs[11] = u_dq[1];
+    obs[12] = wrap_eps(e->y[3]); obs[13] = u_sup;
+    normalise(p, obs);
+}
+
+/* SquirrelCageInductionMotorSystem.simulate, physical_systems.py:771-814 (control_space == 'abc') */
+static void simulate_scim(const orc_params *p, orc_env *e, const double *action, double *obs) {
+    double seg_end[2], i_in[3], u_n[3], u_in[3], u_dq[2], u_ab[2], i_dq[2], i_abc[3];
+    double u_sup = p->u_sup;
+    double eps_fs = atan2(e->y[4], e->y[3]); /* calculate_field_angle, 765-769 */
+    t_32(e->y + 1, i_in);
+    int nseg = conv_set_action(p, e, action, e->t, seg_end);
+    double t0 = e->t;
+    for (int s = 0; s < nseg; ++s) {
+        conv_convert(p, e, i_in, e->t, u_n);
+        for (int l = 0; l < 3; ++l) u_in[l] = u_n[l] * u_sup;
+        abc_to_dq(u_in, eps_fs, u_dq);
+        t_23(u_in, u_ab);
+        e->u[0] = u_ab[0]; e->u[1] = u_ab[1];
+        integrate(p, e, s == nseg - 1 ? t0 + p->tau : seg_end[s]);
+        if (s < nseg - 1) { eps_fs = atan2(e->y[4], e->y[3]); t_32(e->y + 1, i_in); }
+    }
+    e->k += 1;
+    double torque = motor_torque(p, e->y + 1);
+    q_rot(e->y + 1, -eps_fs, i_dq);  /* stale field angle, line 806 */
+    dq_to_abc(i_dq, eps_fs, i_abc);  /* line 807 */
+    obs[0] = e->y[0]; obs[1] = torque;
+    obs[2] = i_abc[0]; obs[3] = i_abc[1]; obs[4] = i_abc[2]; obs[5] = i_dq[0]; obs[6] = i_dq[1];
+    obs[7] = u_in[0]; obs[8] = u_in[1]; obs[9] = u_in[2]; obs[10] = u_dq[0]; obs[11] = u_dq[1];
+    obs[12] = wrap_eps(e->y[5]); obs[13] = u_sup;
+    normalise(p, obs);
+}
+
+/* ---------------------------------------------------------------- public API ------------------- */
+void orc_init(const orc_params *p, orc_env *e) {
+    memset(e, 0, sizeof(*e));
+    orc_model_constants(p, e->C);
+}
+
+/* SCMLSystem.reset 256-287 / SynchronousMotorSystem.reset 527-561 / SquirrelCage...reset 816-847,
+ * with constant initialisers (electric_motor.py:270-285, mechanical_load.py:169-186). */
+void orc_reset(const orc_params *p, orc_env *e, double *obs) {
+    int n = n_ode(p);
+    for (int i = 0; i < n; ++i) e->y[i] = p->init[i];
+    e->t = 0.0; e->k = 0;
+    e->dp_h = 0.0; /* ode.set_initial_value() re-creates the integrator work array */
+    double u_n[3], u_abc[3], u_dq[2], i_abc[3], i_dq[2];
+    double u_sup = p->u_sup;
+    conv_reset(p, e, u_n);
+    double torque = motor_torque(p, e->y + 1);
+    if (p->system == ORC_SYS_DC_PERMEX) {
+        obs[0] = e->y[0]; obs[1] = torque; obs[2] = e->y[1]; obs[3] = u_n[0] * u_sup; obs[4] = u_sup;
+    } else if (p->system == ORC_SYS_PMSM) {
+        double eps = e->y[3];
+        if (eps > M_PI) eps -= 2.0 * M_PI;
+        for (int l = 0; l < 3; ++l) u_abc[l] = u_n[l] * u_sup;
+        abc_to_dq(u_abc, eps, u_dq);
+        dq_to_abc(e->y + 1, eps, i_abc);
+        obs[0] = e->y[0]; obs[1] = torque; obs[2] = i_abc[0]; obs[3] = i_abc[1]; obs[4] = i_abc[2];
+        obs[5] = e->y[1]; obs[6] = e->y[2]; obs[7] = u_abc[0]; obs[8] = u_abc[1]; obs[9] = u_abc[2];
+        obs[10] = u_dq[0]; obs[11] = u_dq[1]; obs[12] = eps; obs[13] = u_sup;
+    } else {
+        double eps = e->y[5];
+        double eps_fs = atan2(e->y[4], e->y[3]);
+        if (eps > M_PI) eps -= 2.0 * M_PI;
+        for (int l = 0; l < 3; ++l) u_abc[l] = u_n[l] * u_sup;
+        abc_to_dq(u_abc, eps_fs, u_dq);
+        q_rot(e->y + 1, -eps_fs, i_dq);
+        dq_to_abc(i_dq, eps_fs, i_abc);
+        obs[0] = e->y[0]; obs[1] = torque; obs[2] = i_abc[0]; obs[3] = i_abc[1]; obs[4] = i_abc[2];
+        obs[5] = i_dq[0]; obs[6] = i_dq[1]; obs[7] = u_abc[0]; obs[8] = u_abc[1]; obs[9] = u_abc[2];
+        obs[10] = u_dq[0]; obs[11] = u_dq[1]; obs[12] = eps; obs[13] = u_sup;
+    }
+    normalise(p, obs);
+}
+
+void orc_step(const orc_params *p, orc_env *e, const double *action, double *obs) {
+    if (p->system == ORC_SYS_DC_PERMEX) simulate_dc(p, e, action, obs);
+    else if (p->system == ORC_SYS_PMSM) simulate_pmsm(p, e, action, obs);
+    else simulate_scim(p, e, action, obs);
+}
+
+/* ConstraintMonitor.check_constraints core.py:834-844 (merge 'max'), LimitConstraint constraints.py:55-58,
+ * SquaredConstraint 96-98, terminated = violation >= 1.0 core.py:350 */
+int orc_done(const orc_params *p, const double *obs) {
+    int n = n_out(p), viol = 0;
+    double sq = 0.0;
+    for (int i = 0; i < n; ++i) {
+        if ((p->limit_mask >> i) & 1) viol |= fabs(obs[i]) > 1.0;
+        if ((p->squared_mask >> i) & 1) sq += obs[i] * obs[i];
+    }
+    if (p->squared_mask) viol |= sq > 1.0;
+    return viol;
+}
+
+/* K steps of one env.  actions: [K][A] doubles (A = 1 | 3; discrete action stored as double).
+ * auto_reset: mirror `if terminated: env.reset()` of the reference's usage loop. */
+void orc_rollout(const orc_params *p, orc_env *e, const double *actions, int n_act, int K, int auto_reset,
+                 double *obs_out, uint8_t *done_out) {
+    int no = n_out(p);
+    double scratch[ORC_MAX_OUT];
+    for (int k = 0; k < K; ++k) {
+        double *obs = obs_out + (size_t)k * no;
+        orc_step(p, e, actions + (size_t)k * n_act, obs);
+        int d = orc_done(p, obs);
+        if (done_out) done_out[k] = (uint8_t)d;
+        if (d && auto_reset) orc_reset(p, e, scratch);
+    }
+}
+
+/* Throughput helper for bench.py's cpu_baseline ("port"): n_env independent envs, K steps each, same
+ * action stream layout [K][n_env][A]; only the last observation per env is kept. */
+void orc_rollout_many(const orc_params *p, int n_env, const double *actions, int n_act, int K, int auto_reset,
+                      double *last_obs, int64_t *n_done) {
+    int no = n_out(p);
+    double scratch[ORC_MAX_OUT];
+    int64_t nd = 0;
+    for (int j = 0; j < n_env; ++j) {
+        orc_env e;
+        orc_init(p, &e);
+        orc_reset(p, &e, scratch);
+        double *obs = last_obs + (size_t)j * no;
+        for (int k = 0; k < K; ++k) {
+            orc_step(p, &e, actions + ((size_t)k * n_env + j) * n_act, obs);
+            if (orc_done(p, obs)) { nd++; if (auto_reset) orc_reset(p, &e, scratch); }
+        }
+    }
+    if (n_done) *n_done = nd;
+}
+
+/* Bare pieces exported for known-answer tests */
+double orc_kat_poly_load(const orc_params *p, double omega, double torque) { return mechanical_ode(p, omega, torque); }
+size_t orc_sizeof_params(void) { return sizeof(orc_params); }
+size_t orc_sizeof_env(void) { return sizeof(orc_env); }
+
+/* Converter known-answer hook: set_action(action, t) then convert(i_seg, t_segment_start) for each segment,
+ * exactly as *.simulate() drives the converter.  currents/volt: [2][3].  Returns the number of segments. */
+int orc_kat_converter(const orc_params *p, orc_env *e, const double *action, double t, const double *currents,
+                      double *volt) {
+    double seg_end[2];
+    int nseg = conv_set_action(p, e, action, t, seg_end);
+    double t_seg = t;
+    for (int s = 0; s < nseg; ++s) {
+        conv_convert(p, e, currents + 3 * s, t_seg, volt + 3 * s);
+        t_seg = seg_end[s];
+    }
+    return nseg;
+}
+void orc_kat_converter_reset(const orc_params *p, orc_env *e, double *u) { conv_reset(p, e, u); }

@@ -1,0 +1,298 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by executing the UNMODIFIED reference (gym-electric-motor 3.0.2).
+
+TEST / ORACLE INFRASTRUCTURE ONLY -- never imported by the product package.
+
+Run in the build container (where /root/reference exists):
+
+    MPLBACKEND=Agg python oracle/make_golden.py
+
+It puts `oracle/gymnasium_standin` (gymnasium is not installed, no network) and
+`/root/reference/src` on sys.path, drives the reference envs with seeded action
+tensors and writes small `.npz` fixtures to `tests/golden/`.  The GPU box has no
+/root/reference; tests there only read the committed fixtures.
+
+Every fixture stores: the actions, the normalised states the reference returned
+(`env.step(...)[0][0]`, i.e. `SCMLSystem.simulate()/limits`,
+physical_systems.py:203/525/814), the terminated flags, the reset state and a
+JSON `meta` blob with every parameter needed to rebuild the case without the
+reference (motor/load parameters, limits, tau, interlocking time, model constants).
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = os.environ.get("GEM_REFERENCE", "/root/reference")
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.path.insert(0, os.path.join(HERE, "gymnasium_standin"))
+sys.path.insert(0, os.path.join(REF, "src"))
+
+import numpy as np  # noqa: E402
+
+import gym_electric_motor as gem  # noqa: E402
+from gym_electric_motor import physical_systems as ps  # noqa: E402
+from gym_electric_motor.physical_systems import solvers as ref_solvers  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def make_solver(name):
+    if name == "euler":
+        return ref_solvers.EulerSolver()
+    if name == "euler4":
+        return ref_solvers.EulerSolver(nsteps=4)
+    if name == "dopri5":
+        return ref_solvers.ScipyOdeSolver()  # the default of all 54 envs
+    if name == "ivp_tight":
+        return ref_solvers.ScipySolveIvpSolver(rtol=1e-10, atol=1e-12)
+    raise KeyError(name)
+
+
+def gen_actions(space_kind, K, seed, mode):
+    """uniform: iid every step.  held: piecewise-constant for random dwell times."""
+    rng = np.random.default_rng(seed)
+    if space_kind == "box1":
+        shape, disc = (K, 1), False
+    elif space_kind == "box3":
+        shape, disc = (K, 3), False
+    elif space_kind == "disc8":
+        shape, disc = (K,), True
+    else:
+        raise KeyError(space_kind)
+    if mode == "uniform":
+        return rng.integers(0, 8, shape).astype(np.int64) if disc else rng.uniform(-1, 1, shape)
+    # held
+    out = np.zeros(shape, dtype=np.int64 if disc else np.float64)
+    k = 0
+    while k < K:
+        dwell = int(rng.integers(1, 40))
+        if disc:
+            v = rng.integers(0, 8)
+        else:
+            v = rng.uniform(-1, 1, shape[1:]) * rng.uniform(0.0, 1.0)
+        out[k : k + dwell] = v
+        k += dwell
+    return out
+
+
+def describe(env):
+    """Everything a restatement needs, read from the live reference objects."""
+    psys = env.physical_system.unwrapped
+    motor, load, conv, sup = psys.electrical_motor, psys.mechanical_load, psys.converter, psys.supply
+    meta = dict(
+        system=type(psys).__name__,
+        motor=type(motor).__name__,
+        load=type(load).__name__,
+        converter=type(conv).__name__,
+        supply=type(sup).__name__,
+        state_names=list(psys.state_names),
+        limits=[float(x) for x in psys.limits],
+        nominal_state=[float(x) for x in psys.nominal_state],
+        tau=float(psys.tau),
+        interlocking_time=float(conv._interlocking_time),
+        u_nominal=float(sup.u_nominal),
+        motor_parameter={k: float(v) for k, v in motor.motor_parameter.items()},
+        model_constants=np.asarray(motor._model_constants, dtype=float).tolist(),
+        j_total=float(load.j_total),
+    )
+    if isinstance(load, ps.PolynomialStaticLoad):
+        meta["load_parameter"] = {k: float(v) for k, v in load.load_parameter.items()}
+        meta["tau_decay"] = float(load.tau_decay)
+    if isinstance(load, ps.ConstantSpeedLoad):
+        meta["omega_fixed"] = float(load.omega_fixed)
+    return meta
+
+
+def run_case(name, env_id, solver, K, seed, mode, episodic, space_kind, every=1, **make_kwargs):
+    kw = dict(make_kwargs)
+    kw["ode_solver"] = make_solver(solver)
+    if not episodic:
+        kw["constraints"] = ()
+    env = gem.make(env_id, **kw)
+    (s0, _), _ = env.reset(seed=0)
+    actions = gen_actions(space_kind, K, seed, mode)
+    states = np.zeros((K, len(s0)))
+    term = np.zeros(K, dtype=bool)
+    for k in range(K):
+        a = actions[k]
+        if space_kind == "disc8":
+            a = int(a)
+        (s, _), _, terminated, _, _ = env.step(a)
+        states[k] = s
+        term[k] = terminated
+        if terminated:
+            env.reset()
+    meta = describe(env)
+    meta.update(name=name, env_id=env_id, solver=solver, K=K, seed=seed, mode=mode, episodic=bool(episodic),
+                every=every, constraints=("default" if episodic else "none"))
+    idx = np.arange(K)
+    keep = idx[(idx % every == every - 1)] if every > 1 else idx
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"),
+        actions=actions.astype(np.uint8) if space_kind == "disc8" else actions,
+        states=states[keep],
+        state_index=keep.astype(np.int64),
+        terminated=term,
+        reset_state=np.asarray(s0, dtype=float),
+        meta=np.array(json.dumps(meta)),
+    )
+    print(f"{name:48s} K={K} terminated={int(term.sum()):5d} max|x|={np.abs(states).max():.3f}")
+
+
+def replay_ref_data():
+    """The reference's only golden trajectory: tests/integration_tests/test_integration.py:18-97
+    (Cont-SC-PermExDc-v0, PI cascade, seed 1337, 2001 steps) -> ref_data.npz.  We re-run it to record
+    the ACTIONS the controller emitted (ref_data.npz holds states only), check we reproduce the stored
+    states, and save actions + the stored states as a fixture the C oracle can be pinned against."""
+    sys.path.insert(0, os.path.join(REF, "examples", "classic_controllers"))
+    from classic_controllers import Controller
+    from gym_electric_motor.reference_generators import SinusoidalReferenceGenerator
+
+    ref = np.load(os.path.join(REF, "tests", "integration_tests", "ref_data.npz"))
+    gen = SinusoidalReferenceGenerator(amplitude_range=(1, 1), frequency_range=(5, 5), offset_range=(0, 0),
+                                       episode_lengths=(10001, 10001))
+    env = gem.make("Cont-SC-PermExDc-v0", reference_generator=gen)
+    controller = Controller.make(env)
+    (state, reference), _ = env.reset(seed=1337)
+    s0 = np.array(state, dtype=float)
+    acts, states, terms = [], [], []
+    for _ in range(2001):
+        action = controller.control(state, reference)
+        acts.append(np.array(action, dtype=float).reshape(-1))
+        (state, reference), _, terminated, _, _ = env.step(action)
+        states.append(state)
+        terms.append(terminated)
+        if terminated:
+            env.reset()
+            controller.reset()
+    states = np.asarray(states)
+    err = np.abs(states - ref["states"]).max()
+    assert err < 1e-12, err
+    assert np.array_equal(np.asarray(terms), ref["terminations"])
+    meta = describe(env)
+    meta.update(name="refdata_cont_sc_permexdc_dopri5", env_id="Cont-SC-PermExDc-v0", solver="dopri5", K=2001,
+                episodic=True, every=1, constraints="default", repro_err=float(err),
+                source="reference tests/integration_tests/ref_data.npz (states, terminations)")
+    np.savez_compressed(
+        os.path.join(OUT, "refdata_cont_sc_permexdc_dopri5.npz"),
+        actions=np.asarray(acts),
+        states=ref["states"],
+        state_index=np.arange(2001),
+        terminated=ref["terminations"],
+        reset_state=s0,
+        meta=np.array(json.dumps(meta)),
+    )
+    print(f"ref_data.npz replay: reproduced with max|d|={err:.2e}; terminated={int(np.sum(terms))}")
+
+
+def converter_kats():
+    """Known-answer tables for the converters on the path, produced by the reference classes
+    (converters.py:404-495 Cont-4QC, 743-839 Finite-B6C, 842-911 Cont-B6C), with and without interlocking."""
+    rng = np.random.default_rng(7)
+    out = {}
+    # Cont-4QC: convert(i, t) for grids of action x current sign
+    acts = np.concatenate([np.linspace(-1.5, 1.5, 31), rng.uniform(-1, 1, 20)])
+    curr = np.array([-3.0, 0.0, 2.5])
+    for t_il in (0.0, 1e-6, 5e-6):
+        conv = ps.ContFourQuadrantConverter(tau=1e-4, interlocking_time=t_il)
+        tab = np.zeros((len(acts), len(curr)))
+        for i, a in enumerate(acts):
+            conv.reset()
+            conv.set_action(np.array([a]), 0.0)
+            for j, c in enumerate(curr):
+                tab[i, j] = conv.convert([c], 0.0)[0]
+        out[f"c4qc_til{t_il:g}"] = tab
+        out["c4qc_actions"] = acts
+        out["c4qc_currents"] = curr
+    # Cont-B6C
+    acts = rng.uniform(-1.3, 1.3, (40, 3))
+    curr = rng.uniform(-1, 1, (40, 3))
+    curr[:5] = 0.0
+    for t_il in (0.0, 1e-6):
+        conv = ps.ContB6BridgeConverter(tau=1e-4, interlocking_time=t_il)
+        tab = np.zeros((40, 3))
+        for i in range(40):
+            conv.reset()
+            conv.set_action(acts[i], 0.0)
+            tab[i] = conv.convert(curr[i], 0.0)
+        out[f"cb6_til{t_il:g}"] = tab
+        out["cb6_actions"] = acts
+        out["cb6_currents"] = curr
+    # Finite-B6C: a persistent converter driven as SynchronousMotorSystem.simulate does
+    # (physical_systems.py:494-511): set_action(a, t); for each switching time: convert(i, t_segment_start).
+    acts = rng.integers(0, 8, 200)
+    curr = rng.uniform(-1, 1, (200, 2, 3))
+    for t_il in (0.0, 1e-6):
+        tau = 1e-5
+        conv = ps.FiniteB6BridgeConverter(tau=tau, interlocking_time=t_il)
+        conv.reset()
+        nseg = np.zeros(200, dtype=np.int64)
+        volt = np.zeros((200, 2, 3))
+        t = 0.0
+        for k in range(200):
+            times = conv.set_action(int(acts[k]), t)
+            nseg[k] = len(times)
+            t_seg = t
+            for s, t_sw in enumerate(times):
+                volt[k, s] = conv.convert(curr[k, s], t_seg)
+                t_seg = t_sw
+            t = t + tau
+            if k == 100:
+                conv.reset()  # switching state must survive reset() (converters.py:45-54)
+        out[f"fb6_til{t_il:g}_nseg"] = nseg
+        out[f"fb6_til{t_il:g}_volt"] = volt
+        out["fb6_actions"] = acts
+        out["fb6_currents"] = curr
+    np.savez_compressed(os.path.join(OUT, "converter_kats.npz"), **out)
+    print("converter KATs written")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    replay_ref_data()
+    converter_kats()
+    dc, pmsm, scim = "Cont-CC-PermExDc-v0", "Finite-CC-PMSM-v0", "Cont-SC-SCIM-v0"
+    K = 2000
+    # --- config 1/2: Cont-CC-PermExDc-v0 -------------------------------------------------------------
+    for solver in ("euler", "dopri5"):
+        run_case(f"permexdc_free_uniform_{solver}", dc, solver, K, 1234, "uniform", False, "box1")
+        run_case(f"permexdc_free_held_{solver}", dc, solver, K, 1235, "held", False, "box1")
+        run_case(f"permexdc_epi_held_{solver}", dc, solver, K, 1236, "held", True, "box1")
+    run_case("permexdc_epi_uniform_euler", dc, "euler", K, 1234, "uniform", True, "box1")
+    run_case("permexdc_free_held_euler4", dc, "euler4", K, 1235, "held", False, "box1")
+    run_case("permexdc_free_held_til_euler", dc, "euler", K, 1235, "held", False, "box1",
+             converter=dict(interlocking_time=2e-6))
+    run_case("permexdc_free_uniform_10k_euler", dc, "euler", 10000, 1234, "uniform", False, "box1", every=10)
+    run_case("permexdc_free_uniform_10k_dopri5", dc, "dopri5", 10000, 1234, "uniform", False, "box1", every=10)
+    # Cont-SC-PermExDc (PolynomialStaticLoad) -- the env of ref_data.npz
+    run_case("permexdc_sc_free_held_dopri5", "Cont-SC-PermExDc-v0", "dopri5", K, 1237, "held", False, "box1")
+    run_case("permexdc_sc_free_held_euler", "Cont-SC-PermExDc-v0", "euler", K, 1237, "held", False, "box1")
+    # --- config 3: Finite-CC-PMSM-v0 -----------------------------------------------------------------
+    for solver in ("euler", "dopri5"):
+        run_case(f"pmsm_free_uniform_{solver}", pmsm, solver, K, 1234, "uniform", False, "disc8")
+        run_case(f"pmsm_free_held_{solver}", pmsm, solver, K, 1235, "held", False, "disc8")
+        run_case(f"pmsm_free_uniform_tau1e-4_{solver}", pmsm, solver, K, 1234, "uniform", False, "disc8", tau=1e-4)
+        run_case(f"pmsm_free_held_til_{solver}", pmsm, solver, K, 1235, "held", False, "disc8",
+                 converter=dict(interlocking_time=1e-6))
+        run_case(f"pmsm_free_uniform_til_{solver}", pmsm, solver, K, 1234, "uniform", False, "disc8",
+                 converter=dict(interlocking_time=1e-6))
+        run_case(f"pmsm_epi_held_tau1e-4_{solver}", pmsm, solver, 4000, 1238, "held", True, "disc8", tau=1e-4)
+    run_case("pmsm_free_uniform_10k_dopri5", pmsm, "dopri5", 10000, 1234, "uniform", False, "disc8", every=10)
+    run_case("pmsm_free_uniform_10k_euler", pmsm, "euler", 10000, 1234, "uniform", False, "disc8", every=10)
+    run_case("pmsm_sc_free_held_dopri5", "Finite-SC-PMSM-v0", "dopri5", K, 1239, "held", False, "disc8")
+    # --- config 4: Cont-SC-SCIM-v0 -------------------------------------------------------------------
+    for solver in ("euler", "dopri5"):
+        run_case(f"scim_free_uniform_{solver}", scim, solver, K, 1234, "uniform", False, "box3")
+        run_case(f"scim_free_held_{solver}", scim, solver, K, 1235, "held", False, "box3")
+        run_case(f"scim_epi_uniform_{solver}", scim, solver, K, 1234, "uniform", True, "box3")
+        run_case(f"scim_constspeed_free_held_{solver}", scim, solver, K, 1235, "held", False, "box3",
+                 load=ps.ConstantSpeedLoad(omega_fixed=100.0))
+    run_case("scim_free_held_til_euler", scim, "euler", K, 1235, "held", False, "box3",
+             converter=dict(interlocking_time=2e-6))
+    run_case("scim_free_uniform_10k_dopri5", scim, "dopri5", 10000, 1234, "uniform", False, "box3", every=10)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,182 @@
+"""ctypes wrapper around oracle/libgemx_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (gym_electric_motor_amd) never does.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgemx_oracle.so")
+
+SYS_DC, SYS_PMSM, SYS_SCIM = 0, 1, 2
+CONV_C4QC, CONV_FB6, CONV_CB6 = 0, 1, 2
+LOAD_CONST, LOAD_POLY = 0, 1
+SOLVER_EULER, SOLVER_RK4, SOLVER_DOPRI5, SOLVER_DP5_FIXED = 0, 1, 2, 3
+
+MAX_ODE, MAX_OUT = 8, 16
+
+
+class OrcParams(C.Structure):
+    _fields_ = [
+        ("system", C.c_int32), ("converter", C.c_int32), ("load", C.c_int32), ("solver", C.c_int32),
+        ("nsteps", C.c_int32), ("limit_mask", C.c_int32), ("squared_mask", C.c_int32), ("reserved", C.c_int32),
+        ("tau", C.c_double), ("t_il", C.c_double), ("u_sup", C.c_double),
+        ("mp", C.c_double * 8),
+        ("j_total", C.c_double), ("load_a", C.c_double), ("load_b", C.c_double), ("load_c", C.c_double),
+        ("tau_decay", C.c_double),
+        ("limits", C.c_double * MAX_OUT),
+        ("init", C.c_double * MAX_ODE),
+    ]
+
+
+def build():
+    """(Re)build the oracle library with gcc if it is missing or stale."""
+    src = os.path.join(HERE, "gemx_oracle.c")
+    if not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "-s"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        assert L.orc_sizeof_params() == C.sizeof(OrcParams)
+        L.orc_sizeof_env.restype = C.c_size_t
+        L.orc_kat_poly_load.restype = C.c_double
+        L.orc_kat_poly_load.argtypes = [C.POINTER(OrcParams), C.c_double, C.c_double]
+        _lib = L
+    return _lib
+
+
+_SYS = {"DcMotorSystem": SYS_DC, "SynchronousMotorSystem": SYS_PMSM, "SquirrelCageInductionMotorSystem": SYS_SCIM}
+_CONV = {"ContFourQuadrantConverter": CONV_C4QC, "FiniteB6BridgeConverter": CONV_FB6, "ContB6BridgeConverter": CONV_CB6}
+_LOAD = {"ConstantSpeedLoad": LOAD_CONST, "PolynomialStaticLoad": LOAD_POLY}
+_SOLVER = {"euler": (SOLVER_EULER, 1), "euler4": (SOLVER_EULER, 4), "rk4": (SOLVER_RK4, 1),
+           "dopri5": (SOLVER_DOPRI5, 1), "ivp_tight": (SOLVER_DOPRI5, 1), "dp5_fixed": (SOLVER_DP5_FIXED, 1)}
+_MP_KEYS = {SYS_DC: ("r_a", "l_a", "psi_e"), SYS_PMSM: ("p", "l_d", "l_q", "r_s", "psi_p"),
+            SYS_SCIM: ("p", "l_m", "l_sigs", "l_sigr", "r_s", "r_r")}
+
+
+def default_masks(meta):
+    """Default constraints of the configured envs: LimitConstraint('i') for Cont-CC-PermExDc-v0
+    (cont_cc_permex_dc_env.py:104), SquaredConstraint(('i_sq','i_sd')) for PMSM / SCIM
+    (finite_cc_pmsm_env.py:106, cont_sc_scim_env.py:111)."""
+    names = meta["state_names"]
+    if meta["system"] == "DcMotorSystem":
+        return 1 << names.index("i"), 0
+    return 0, (1 << names.index("i_sd")) | (1 << names.index("i_sq"))
+
+
+def params_from_meta(meta, solver=None, episodic=None):
+    """Build OrcParams from a golden fixture's meta blob (see oracle/make_golden.py:describe)."""
+    if isinstance(meta, (str, bytes, np.ndarray)):
+        meta = json.loads(str(meta))
+    p = OrcParams()
+    p.system = _SYS[meta["system"]]
+    p.converter = _CONV[meta["converter"]]
+    p.load = _LOAD[meta["load"]]
+    p.solver, p.nsteps = _SOLVER[solver or meta["solver"]]
+    epi = meta.get("episodic", False) if episodic is None else episodic
+    if epi:
+        p.limit_mask, p.squared_mask = default_masks(meta)
+    p.tau, p.t_il, p.u_sup = meta["tau"], meta["interlocking_time"], meta["u_nominal"]
+    for i, k in enumerate(_MP_KEYS[p.system]):
+        p.mp[i] = meta["motor_parameter"][k]
+    p.j_total = meta["j_total"]
+    lp = meta.get("load_parameter", {})
+    p.load_a, p.load_b, p.load_c = lp.get("a", 0.0), lp.get("b", 0.0), lp.get("c", 0.0)
+    p.tau_decay = meta.get("tau_decay", 1e-3)
+    for i, v in enumerate(meta["limits"]):
+        p.limits[i] = v
+    p.init[0] = meta.get("omega_fixed", 0.0)  # default initialisers: omega_fixed | 0, motor states 0
+    return p
+
+
+class OracleEnv:
+    """One fp64 reference-restatement env."""
+
+    def __init__(self, params):
+        self.p = params
+        self.L = lib()
+        self._env = C.create_string_buffer(self.L.orc_sizeof_env())
+        self.L.orc_init(C.byref(self.p), self._env)
+        self.n_out = self.L.orc_n_out(C.byref(self.p))
+        self.n_ode = self.L.orc_n_ode(C.byref(self.p))
+        self.n_act = 3 if self.p.converter == CONV_CB6 else 1
+
+    def reset(self):
+        obs = np.zeros(self.n_out)
+        self.L.orc_reset(C.byref(self.p), self._env, obs.ctypes.data_as(C.c_void_p))
+        return obs
+
+    def step(self, action):
+        a = np.ascontiguousarray(np.atleast_1d(action), dtype=np.float64)
+        obs = np.zeros(self.n_out)
+        self.L.orc_step(C.byref(self.p), self._env, a.ctypes.data_as(C.c_void_p), obs.ctypes.data_as(C.c_void_p))
+        return obs
+
+    def rollout(self, actions, auto_reset=True):
+        a = np.ascontiguousarray(np.asarray(actions, dtype=np.float64).reshape(len(actions), -1))
+        K = a.shape[0]
+        obs = np.zeros((K, self.n_out))
+        done = np.zeros(K, dtype=np.uint8)
+        self.L.orc_rollout(C.byref(self.p), self._env, a.ctypes.data_as(C.c_void_p), C.c_int(a.shape[1]), C.c_int(K),
+                           C.c_int(int(auto_reset)), obs.ctypes.data_as(C.c_void_p), done.ctypes.data_as(C.c_void_p))
+        return obs, done.astype(bool)
+
+    def done(self, obs):
+        o = np.ascontiguousarray(obs, dtype=np.float64)
+        full = np.zeros(MAX_OUT)
+        full[: len(o)] = o
+        return bool(self.L.orc_done(C.byref(self.p), full.ctypes.data_as(C.c_void_p)))
+
+    def kat_converter(self, action, t, currents):
+        """set_action + per-segment convert; currents [2,3] -> (nseg, volt [2,3])."""
+        a = np.ascontiguousarray(np.atleast_1d(action), dtype=np.float64)
+        cur = np.ascontiguousarray(currents, dtype=np.float64).reshape(2, 3)
+        volt = np.zeros((2, 3))
+        nseg = self.L.orc_kat_converter(C.byref(self.p), self._env, a.ctypes.data_as(C.c_void_p), C.c_double(t),
+                                        cur.ctypes.data_as(C.c_void_p), volt.ctypes.data_as(C.c_void_p))
+        return nseg, volt
+
+    def kat_converter_reset(self):
+        u = np.zeros(3)
+        self.L.orc_kat_converter_reset(C.byref(self.p), self._env, u.ctypes.data_as(C.c_void_p))
+        return u
+
+    def model_constants(self):
+        Cm = np.zeros((5, 11))
+        self.L.orc_model_constants(C.byref(self.p), Cm.ctypes.data_as(C.c_void_p))
+        return Cm
+
+
+def rollout_many(params, actions, auto_reset=True):
+    """actions [K, n_env, A] -> (last_obs [n_env, S_out], n_done).  Single-threaded; used as cpu_baseline 'port'."""
+    a = np.ascontiguousarray(actions, dtype=np.float64)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    K, n_env, A = a.shape
+    L = lib()
+    n_out = L.orc_n_out(C.byref(params))
+    last = np.zeros((n_env, n_out))
+    nd = C.c_int64(0)
+    L.orc_rollout_many(C.byref(params), C.c_int(n_env), a.ctypes.data_as(C.c_void_p), C.c_int(A), C.c_int(K),
+                       C.c_int(int(auto_reset)), last.ctypes.data_as(C.c_void_p), C.byref(nd))
+    return last, nd.value
+
+
+def load_golden(name, golden_dir=None):
+    golden_dir = golden_dir or os.path.join(os.path.dirname(HERE), "tests", "golden")
+    d = np.load(os.path.join(golden_dir, name + ".npz"))
+    meta = json.loads(str(d["meta"]))
+    return d, meta

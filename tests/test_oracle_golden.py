@@ -1,0 +1,168 @@
+"""CPU-only: pin the oracle (oracle/gemx_oracle.c) against the reference.
+
+* every golden trajectory recorded from the live reference by oracle/make_golden.py, including the
+  reference's own tests/integration_tests/ref_data.npz (replayed PI-controller actions);
+* converter known-answer tables produced by the reference converter classes;
+* the hand-written KATs of the reference's unit tests (cited below).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz")) if "converter_kats" not in f)
+
+
+def test_fixture_inventory():
+    assert len(CASES) >= 35
+    assert "refdata_cont_sc_permexdc_dopri5" in CASES
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_reference_trajectory(name):
+    """Same solver as the reference run (Euler <-> EulerSolver, dopri5 <-> scipy.ode('dopri5')), fp64 both sides:
+    tolerance 1e-10 absolute on normalised states (observed <= 1e-12), done masks bit-exact."""
+    d, meta = orc.load_golden(name)
+    env = orc.OracleEnv(orc.params_from_meta(meta))
+    r = env.reset()
+    assert np.abs(r - d["reset_state"]).max() < 1e-14
+    obs, done = env.rollout(d["actions"], auto_reset=True)
+    err = np.abs(obs[d["state_index"]] - d["states"]).max()
+    assert err < 1e-10, err
+    assert np.array_equal(done, d["terminated"])
+
+
+def test_reference_ref_data_npz():
+    """reference tests/integration_tests/test_integration.py:88-97 compares with np.allclose; we hold 1e-12."""
+    d, meta = orc.load_golden("refdata_cont_sc_permexdc_dopri5")
+    assert meta["repro_err"] < 1e-12  # the generating run itself reproduced ref_data.npz
+    env = orc.OracleEnv(orc.params_from_meta(meta))
+    env.reset()
+    obs, done = env.rollout(d["actions"])
+    assert np.abs(obs - d["states"]).max() < 1e-12
+    assert not done.any()
+
+
+@pytest.mark.parametrize("name", [c for c in CASES if c.endswith("dopri5")])
+def test_fixed_step_rk4_close_to_reference_default_solver(name):
+    """The reference has no RK4; classical RK4 must stay within the 1e-4 relative contract of the
+    reference's default dopri5 path (observed <= 8e-5, worst case SCIM + PolynomialStaticLoad kinks)."""
+    d, meta = orc.load_golden(name)
+    env = orc.OracleEnv(orc.params_from_meta(meta, solver="rk4", episodic=False))
+    if meta["episodic"]:
+        pytest.skip("episodic runs compared solver-for-solver only")
+    env.reset()
+    obs, _ = env.rollout(d["actions"])
+    ref = d["states"]
+    got = obs[d["state_index"]]
+    eps_idx = meta["state_names"].index("epsilon") if "epsilon" in meta["state_names"] else None
+    diff = np.abs(got - ref)
+    if eps_idx is not None:  # angle: circular distance in normalised units (2.0 == 2*pi)
+        diff[:, eps_idx] = np.minimum(diff[:, eps_idx], 2.0 - diff[:, eps_idx])
+    rel = (diff.max(axis=0) / np.maximum(np.abs(ref).max(axis=0), 1e-9)).max()
+    assert rel < 1e-4, rel
+
+
+def test_model_constants_and_limits_match_reference():
+    for name in ("permexdc_free_held_euler", "pmsm_free_held_euler", "scim_free_held_euler"):
+        d, meta = orc.load_golden(name)
+        env = orc.OracleEnv(orc.params_from_meta(meta))
+        ref = np.asarray(meta["model_constants"])
+        got = env.model_constants()[: ref.shape[0], : ref.shape[1]]
+        assert np.allclose(got, ref, rtol=1e-14, atol=0)
+    # PermExDc C = [-8684.21, -842.105, 52631.58]
+    d, meta = orc.load_golden("permexdc_free_held_euler")
+    assert np.allclose(np.asarray(meta["model_constants"])[0], [-8684.2105263, -842.1052632, 52631.5789474])
+    assert meta["limits"] == [400.0, 38.0, 210.0, 60.0, 60.0]
+
+
+@pytest.mark.parametrize("omega, expected", [(-3, 23400), (0, 20000), (5, 11400)])
+def test_polynomial_static_load_kat(omega, expected):
+    """reference tests/test_physical_systems/test_mechanical_loads.py:191-211 (j_load=1e-4,a=.01,b=.02,c=.03,T=2)."""
+    p = orc.OrcParams()
+    p.load = orc.LOAD_POLY
+    p.j_total, p.load_a, p.load_b, p.load_c, p.tau_decay = 1e-4, 0.01, 0.02, 0.03, 1e-3
+    assert abs(orc.lib().orc_kat_poly_load(p, float(omega), 2.0) - expected) < 1e-6
+
+
+@pytest.mark.parametrize(
+    "mask, state, expected",
+    [  # reference tests/test_constraints/test_limit_constraint.py:28-66
+        (0b11, [0.0, 1.1], 1), (0b11, [0.0, 0.9], 0), (0b11, [0.0, 1.0], 0), (0b11, [-1.1, 0.9], 1),
+        (0b11, [-0.1, 0.9], 0), (0b11, [-1.1, 1.1], 1), (0b11, [-1.0, 1.0], 0),
+        (0b101, [0.0, 1.1, 0.0], 0), (0b101, [-1.0, 1.1, 0.0], 0), (0b101, [-1.1, 1.1, 0.0], 1),
+    ],
+)
+def test_limit_constraint_kat(mask, state, expected):
+    p = orc.OrcParams()
+    p.system = orc.SYS_DC
+    p.limit_mask = mask
+    assert orc.OracleEnv(p).done(state) == bool(expected)
+
+
+@pytest.mark.parametrize(
+    "mask, state, expected",
+    [  # reference tests/test_constraints/test_squared_constraint.py:24-100
+        (0b11, [0.8, 0.8], 1), (0b11, [0.0, 0.9], 0), (0b11, [0.0, 1.0], 0), (0b11, [-0.1, 1.0], 1),
+        (0b11, [-1.1, 0.9], 1), (0b11, [-0.1, 0.9], 0), (0b11, [-1.1, 1.1], 1), (0b11, [-1.0, 1.0], 1),
+        (0b101, [0.5, 1.1, 0.5], 0), (0b101, [-1.0, 1.1, 0.1], 1), (0b101, [-1.1, 1.1, 0.0], 1),
+    ],
+)
+def test_squared_constraint_kat(mask, state, expected):
+    p = orc.OrcParams()
+    p.system = orc.SYS_DC
+    p.squared_mask = mask
+    assert orc.OracleEnv(p).done(state) == bool(expected)
+
+
+def _conv_env(kind, tau, t_il):
+    p = orc.OrcParams()
+    p.system = orc.SYS_DC if kind == orc.CONV_C4QC else orc.SYS_PMSM
+    p.converter = kind
+    p.tau, p.t_il = tau, t_il
+    return orc.OracleEnv(p)
+
+
+def test_converter_kats_cont_4qc():
+    k = np.load(os.path.join(GOLDEN, "converter_kats.npz"))
+    for t_il in (0.0, 1e-6, 5e-6):
+        env = _conv_env(orc.CONV_C4QC, 1e-4, t_il)
+        tab = k[f"c4qc_til{t_il:g}"]
+        for i, a in enumerate(k["c4qc_actions"]):
+            for j, c in enumerate(k["c4qc_currents"]):
+                nseg, v = env.kat_converter([a], 0.0, [[c, 0, 0], [0, 0, 0]])
+                assert nseg == 1 and abs(v[0, 0] - tab[i, j]) < 1e-15
+
+
+def test_converter_kats_cont_b6():
+    k = np.load(os.path.join(GOLDEN, "converter_kats.npz"))
+    for t_il in (0.0, 1e-6):
+        env = _conv_env(orc.CONV_CB6, 1e-4, t_il)
+        for i in range(len(k["cb6_actions"])):
+            nseg, v = env.kat_converter(k["cb6_actions"][i], 0.0, [k["cb6_currents"][i], [0, 0, 0]])
+            assert nseg == 1 and np.abs(v[0] - k[f"cb6_til{t_il:g}"][i]).max() < 1e-15
+
+
+def test_converter_kats_finite_b6_interlocking_and_reset_quirk():
+    """FiniteB6BridgeConverter incl. dead-time segments and the switching state surviving reset()
+    (reference converters.py:45-54, 270-310, 825-835; cf. tests/test_physical_systems/test_converters.py:592-697)."""
+    k = np.load(os.path.join(GOLDEN, "converter_kats.npz"))
+    for t_il in (0.0, 1e-6):
+        env = _conv_env(orc.CONV_FB6, 1e-5, t_il)
+        env.kat_converter_reset()
+        t = 0.0
+        nsegs = k[f"fb6_til{t_il:g}_nseg"]
+        volt = k[f"fb6_til{t_il:g}_volt"]
+        for i, a in enumerate(k["fb6_actions"]):
+            nseg, v = env.kat_converter([float(a)], t, k["fb6_currents"][i])
+            assert nseg == nsegs[i]
+            assert np.array_equal(v[:nseg], volt[i, :nseg])
+            t += 1e-5
+            if i == 100:
+                env.kat_converter_reset()
+        if t_il > 0:
+            assert (nsegs == 2).sum() > 20  # the dead-time path is really exercised
