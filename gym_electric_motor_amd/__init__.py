@@ -1,0 +1,31 @@
+"""gym_electric_motor_amd -- MI355X-native batched physical-system stepper for gym-electric-motor (GEM).
+
+One hot path only: `SCMLSystem.simulate()` / `reset()` for N independent env instances, in hand-written HIP
+kernels behind GEM's `PhysicalSystem` plugin surface (include/gemx.h).
+"""
+from . import _lib  # noqa: F401
+from .components import (  # noqa: F401
+    ConstantSpeedLoad,
+    ContB6BridgeConverter,
+    ContFourQuadrantConverter,
+    DcPermanentlyExcitedMotor,
+    DormandPrince5Solver,
+    EulerSolver,
+    FiniteB6BridgeConverter,
+    IdealVoltageSupply,
+    PermanentMagnetSynchronousMotor,
+    PolynomialStaticLoad,
+    RK4Solver,
+    SquirrelCageInductionMotor,
+)
+from .envs import BatchedElectricMotorEnv, make  # noqa: F401
+from .physical_systems import (  # noqa: F401
+    BatchedDcMotorSystem,
+    BatchedSCMLSystem,
+    BatchedSquirrelCageInductionMotorSystem,
+    BatchedSynchronousMotorSystem,
+    LimitConstraint,
+    SquaredConstraint,
+)
+
+__version__ = "0.1.0"

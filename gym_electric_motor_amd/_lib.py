@@ -1,0 +1,95 @@
+"""ctypes binding of include/gemx.h.  The product path has NO fallback: if `libgemx.so` is missing or no
+HIP device is visible, creating a system raises."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+MAX_ODE, MAX_OUT, MODEL_ROWS, MODEL_COLS = 8, 16, 5, 11
+ABI_VERSION = 1
+
+SYS_DC_PERMEX, SYS_SYNC, SYS_SCIM = 0, 1, 2
+CONV_CONT_4QC, CONV_FINITE_B6, CONV_CONT_B6 = 0, 1, 2
+LOAD_CONST_SPEED, LOAD_POLY_STATIC = 0, 1
+SOLVER_EULER, SOLVER_RK4, SOLVER_DP5 = 0, 1, 2
+F32, F64 = 0, 1
+OBS_AOS, OBS_SOA = 0, 1
+
+
+class GemxConfig(C.Structure):
+    """Mirror of `gemx_config` (include/gemx.h)."""
+
+    _fields_ = [
+        ("struct_size", C.c_int32), ("abi_version", C.c_int32),
+        ("system_kind", C.c_int32), ("converter_kind", C.c_int32), ("load_kind", C.c_int32),
+        ("solver_kind", C.c_int32), ("solver_nsteps", C.c_int32),
+        ("dtype", C.c_int32), ("obs_layout", C.c_int32), ("auto_reset", C.c_int32),
+        ("limit_mask", C.c_uint32), ("squared_mask", C.c_uint32),
+        ("tau", C.c_double), ("interlocking_time", C.c_double), ("u_nominal", C.c_double),
+        ("model", C.c_double * (MODEL_ROWS * MODEL_COLS)),
+        ("torque_coef", C.c_double * 4),
+        ("j_total", C.c_double), ("load_a", C.c_double), ("load_b", C.c_double), ("load_c", C.c_double),
+        ("tau_decay", C.c_double),
+        ("limits", C.c_double * MAX_OUT),
+        ("init_state", C.c_double * MAX_ODE),
+    ]
+
+
+class GemxError(RuntimeError):
+    pass
+
+
+_lib = None
+
+EXPORTS = (
+    "gemx_abi_version", "gemx_sizeof_config", "gemx_last_error", "gemx_device_count", "gemx_create", "gemx_destroy",
+    "gemx_n_envs", "gemx_n_ode", "gemx_n_out", "gemx_n_action", "gemx_action_itemsize", "gemx_reset_observation",
+    "gemx_reset", "gemx_step", "gemx_rollout", "gemx_get_state", "gemx_set_state", "gemx_get_switch_state",
+    "gemx_set_switch_state", "gemx_error_flags",
+)
+
+
+def library_path():
+    return _build.LIB
+
+
+def load():
+    """Load libgemx.so (built in-tree by `__graft_entry__.build()` / `gym_electric_motor_amd.build.build_library()`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise GemxError(
+            f"{path} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    L = C.CDLL(path)
+    L.gemx_last_error.restype = C.c_char_p
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.gemx_create.argtypes = [C.POINTER(GemxConfig), i64, C.c_int, C.POINTER(vp)]
+    L.gemx_destroy.argtypes = [vp]
+    L.gemx_n_envs.argtypes = [vp, C.POINTER(i64)]
+    for f in ("gemx_n_ode", "gemx_n_out", "gemx_n_action", "gemx_action_itemsize"):
+        getattr(L, f).argtypes = [vp]
+    L.gemx_reset_observation.argtypes = [vp, C.POINTER(C.c_double)]
+    L.gemx_reset.argtypes = [vp, vp, vp, vp]
+    L.gemx_step.argtypes = [vp, vp, vp, vp, vp]
+    L.gemx_rollout.argtypes = [vp, vp, i32, vp, vp, i32, vp]
+    L.gemx_get_state.argtypes = [vp, vp, vp]
+    L.gemx_set_state.argtypes = [vp, vp, vp]
+    L.gemx_get_switch_state.argtypes = [vp, vp, vp]
+    L.gemx_set_switch_state.argtypes = [vp, vp, vp]
+    L.gemx_error_flags.argtypes = [vp, C.POINTER(C.c_uint32), vp]
+    if L.gemx_abi_version() != ABI_VERSION or L.gemx_sizeof_config() != C.sizeof(GemxConfig):
+        raise GemxError("libgemx.so ABI does not match gym_electric_motor_amd._lib.GemxConfig; rebuild the library")
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().gemx_last_error().decode()
+        if rc == -1:
+            raise ValueError(msg)
+        raise GemxError(msg)

@@ -1,0 +1,370 @@
+"""Parameter-holder mirrors of the reference components that sit on the accelerated path.
+
+These classes keep the reference's names, constructor arguments, default parameters and the derivation of
+limits / nominal values / model constants, so that `BatchedSCMLSystem(converter=..., motor=..., load=...,
+supply=..., ode_solver=...)` reads like `SCMLSystem(...)` (reference physical_systems/physical_systems.py:54).
+They contain NO physics: the right-hand sides, converters, solvers and constraints run only in the HIP kernels
+(csrc/gemx.hip).  Instances of the reference's own component classes are accepted as well -- the batched system
+reads the same attributes from either (`motor_parameter`, `limits`, `nominal_values`, `_model_constants`,
+`j_total`, `load_parameter`, `omega_fixed`, `_interlocking_time`, `u_nominal`, `_nsteps`).
+
+Citations are relative to /root/reference/src/gym_electric_motor/physical_systems/.
+"""
+import math
+
+import numpy as np
+
+from .spaces import Box, Discrete
+
+
+def update_parameter_dict(source, update):
+    """utils.py:73-94 -- unknown keys raise KeyError."""
+    for key in update:
+        if key not in source:
+            raise KeyError(f'Cannot update_dict the source_dict. The key "{key}" is not available.')
+    out = dict(source)
+    out.update(update)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- supply
+class IdealVoltageSupply:
+    """voltage_supplies.py:60-72: constant u_nominal."""
+
+    voltage_len = 1
+
+    def __init__(self, u_nominal=600.0):
+        self._u_nominal = float(u_nominal)
+        self.supply_range = (u_nominal, u_nominal)
+
+    @property
+    def u_nominal(self):
+        return self._u_nominal
+
+
+# ------------------------------------------------------------------------------------------------- converters
+class _Converter:
+    """converters.py:5-111 (tau, interlocking_time)."""
+
+    voltages = currents = action_space = None
+
+    def __init__(self, tau, interlocking_time=0.0):
+        self._tau = float(tau)
+        self._interlocking_time = float(interlocking_time)
+
+    @property
+    def tau(self):
+        return self._tau
+
+    @tau.setter
+    def tau(self, value):
+        self._tau = float(value)
+
+
+class ContFourQuadrantConverter(_Converter):
+    """Key 'Cont-4QC', converters.py:438-495."""
+
+    voltages = Box(-1, 1, shape=(1,), dtype=np.float64)
+    currents = Box(-1, 1, shape=(1,), dtype=np.float64)
+    action_space = Box(-1, 1, shape=(1,), dtype=np.float64)
+
+    def __init__(self, tau=1e-4, interlocking_time=0.0):
+        super().__init__(tau, interlocking_time)
+
+
+class ContB6BridgeConverter(_Converter):
+    """Key 'Cont-B6C', converters.py:842-911."""
+
+    voltages = Box(-1, 1, shape=(3,), dtype=np.float64)
+    currents = Box(-1, 1, shape=(3,), dtype=np.float64)
+    action_space = Box(-1, 1, shape=(3,), dtype=np.float64)
+
+    def __init__(self, tau=1e-4, interlocking_time=0.0):
+        super().__init__(tau, interlocking_time)
+
+
+class FiniteB6BridgeConverter(_Converter):
+    """Key 'Finite-B6C', converters.py:743-839."""
+
+    voltages = Box(-1, 1, shape=(3,), dtype=np.float64)
+    currents = Box(-1, 1, shape=(3,), dtype=np.float64)
+    action_space = Discrete(8)
+
+    def __init__(self, tau=1e-5, interlocking_time=0.0):
+        super().__init__(tau, interlocking_time)
+
+
+# ------------------------------------------------------------------------------------------------- solvers
+class EulerSolver:
+    """solvers.py:79-136."""
+
+    def __init__(self, nsteps=1):
+        self._nsteps = int(nsteps)
+
+
+class RK4Solver:
+    """Classical 4th-order Runge-Kutta with `nsteps` sub-steps per integration segment.  The reference has no
+    RK4; its like-for-like CPU counterpart is the default scipy dopri5 path."""
+
+    def __init__(self, nsteps=1):
+        self._nsteps = int(nsteps)
+
+
+class DormandPrince5Solver:
+    """One fixed Dormand-Prince 5th-order step per sub-step: what the reference's default
+    scipy.integrate.ode('dopri5') (solvers.py:139-184) computes whenever its trial step is accepted."""
+
+    def __init__(self, nsteps=1):
+        self._nsteps = int(nsteps)
+
+
+# ------------------------------------------------------------------------------------------------- motors
+class _ElectricMotor:
+    """electric_motors/electric_motor.py:9-325 (parameter / limit / nominal bookkeeping only)."""
+
+    CURRENTS = []
+    VOLTAGES = []
+    _default_motor_parameter = {}
+    _default_nominal_values = {}
+    _default_limits = {}
+    _default_initializer = {"states": {}, "interval": None, "random_init": None, "random_params": None}
+
+    def __init__(self, motor_parameter=None, nominal_values=None, limit_values=None, motor_initializer=None):
+        self._motor_parameter = update_parameter_dict(self._default_motor_parameter, motor_parameter or {})
+        self._limits = update_parameter_dict(self._default_limits, limit_values or {})
+        self._nominal_values = update_parameter_dict(self._default_nominal_values, nominal_values or {})
+        self._initializer = update_parameter_dict(self._default_initializer, motor_initializer or {})
+        if self._initializer.get("random_init") is not None:
+            raise NotImplementedError("random motor initialisers are not on the accelerated path yet (SURVEY.md 8f rank 4)")
+        self._initial_states = dict(self._initializer["states"] or {})
+
+    motor_parameter = property(lambda self: self._motor_parameter)
+    limits = property(lambda self: self._limits)
+    nominal_values = property(lambda self: self._nominal_values)
+    initializer = property(lambda self: self._initializer)
+
+    def _update_limits(self, limits_d=None, nominal_d=None):
+        """electric_motor.py:296-317: replace missing (0) limits / nominal values."""
+        limits_d = dict(limits_d or {})
+        nominal_d = dict(nominal_d or {})
+        limits_d.update(dict(omega=self._default_limits["omega"]))
+        for qty, lim in limits_d.items():
+            if self._limits.get(qty, 0) == 0:
+                self._limits[qty] = lim
+        for entry in self._limits.keys():
+            if self._nominal_values.get(entry, 0) == 0:
+                self._nominal_values[entry] = nominal_d.get(entry, self._limits[entry])
+
+
+class DcPermanentlyExcitedMotor(_ElectricMotor):
+    """electric_motors/dc_permanently_excited_motor.py:6-120 (PMG-132 defaults, lines 49-63)."""
+
+    CURRENTS = ["i"]
+    VOLTAGES = ["u"]
+    _default_motor_parameter = {"r_a": 16e-3, "l_a": 19e-6, "psi_e": 0.165, "j_rotor": 0.025}
+    _default_nominal_values = dict(omega=300, torque=16.0, i=97, u=60)
+    _default_limits = dict(omega=400, torque=38.0, i=210, u=60)
+    _default_initializer = {"states": {"i": 0.0}, "interval": None, "random_init": None, "random_params": (None, None)}
+
+    def __init__(self, motor_parameter=None, nominal_values=None, limit_values=None, motor_initializer=None):
+        super().__init__(motor_parameter, nominal_values, limit_values, motor_initializer)
+        mp = self._motor_parameter
+        # _update_model, lines 71-75
+        self._model_constants = np.array([[-mp["psi_e"], -mp["r_a"], 1.0]]) / mp["l_a"]
+        # _update_limits, lines 95-105 + DcMotor._update_limits (dc_motor.py:153-160)
+        r_a = 1 if mp["r_a"] == 0 else mp["r_a"]
+        agenda = {"u": self._default_limits["u"], "i": self._limits["u"] / r_a}
+        agenda["torque"] = mp["psi_e"] * self._limits["i"]
+        self._update_limits(agenda)
+
+    def torque_coefficients(self):
+        return [self._motor_parameter["psi_e"], 0.0]
+
+    def initial_motor_state(self):
+        return [float(self._initial_states.get("i", 0.0))]
+
+
+class _ThreePhaseMotor(_ElectricMotor):
+    IO_VOLTAGES = []
+    IO_CURRENTS = []
+
+    def _three_phase_limits(self):
+        """synchronous_motor.py:173-189 / squirrel_cage_induction_motor.py:131-144 + three_phase_motor.py:125-131."""
+        voltage_limit = 0.5 * self._limits["u"]
+        voltage_nominal = 0.5 * self._nominal_values["u"]
+        limits_agenda, nominal_agenda = {}, {}
+        r_s = self._motor_parameter["r_s"]
+        for u, i in zip(self.IO_VOLTAGES, self.IO_CURRENTS):
+            limits_agenda[u] = voltage_limit
+            nominal_agenda[u] = voltage_nominal
+            limits_agenda[i] = self._limits.get("i", None) or self._limits[u] / r_s
+            nominal_agenda[i] = self._nominal_values.get("i", None) or self._nominal_values[u] / r_s
+        self._update_limits(limits_agenda, nominal_agenda)
+        self._update_limits(dict(torque=self._torque_limit()))
+
+
+class PermanentMagnetSynchronousMotor(_ThreePhaseMotor):
+    """electric_motors/permanent_magnet_synchronous_motor.py:8-173 (defaults lines 86-103)."""
+
+    CURRENTS = ["i_sd", "i_sq"]
+    VOLTAGES = ["u_sd", "u_sq"]
+    IO_VOLTAGES = ["u_a", "u_b", "u_c", "u_sd", "u_sq"]
+    IO_CURRENTS = ["i_a", "i_b", "i_c", "i_sd", "i_sq"]
+    _default_motor_parameter = {"p": 3, "l_d": 0.37e-3, "l_q": 1.2e-3, "j_rotor": 0.03883, "r_s": 18e-3, "psi_p": 66e-3}
+    _default_limits = dict(omega=4e3 * np.pi / 30, torque=0.0, i=400, epsilon=math.pi, u=300)
+    _default_nominal_values = dict(omega=3e3 * np.pi / 30, torque=0.0, i=240, epsilon=math.pi, u=300)
+    # NOTE the key order i_sq, i_sd, epsilon of the reference (line 98): reset() returns the VALUES in dict
+    # order into the ODE slots [i_sd, i_sq, epsilon], i.e. user-supplied i_sd / i_sq are swapped.  Reproduced.
+    _default_initializer = {"states": {"i_sq": 0.0, "i_sd": 0.0, "epsilon": 0.0}, "interval": None,
+                            "random_init": None, "random_params": (None, None)}
+
+    def __init__(self, motor_parameter=None, nominal_values=None, limit_values=None, motor_initializer=None):
+        super().__init__(motor_parameter, nominal_values, limit_values, motor_initializer)
+        mp = self._motor_parameter
+        # _update_model, lines 107-119
+        m = np.array([
+            [0, -mp["r_s"], 0, 1, 0, 0, mp["l_q"] * mp["p"]],
+            [-mp["psi_p"] * mp["p"], 0, -mp["r_s"], 0, 1, -mp["l_d"] * mp["p"], 0],
+            [mp["p"], 0, 0, 0, 0, 0, 0],
+        ], dtype=float)
+        m[0] = m[0] / mp["l_d"]
+        m[1] = m[1] / mp["l_q"]
+        self._model_constants = m
+        self._three_phase_limits()
+
+    def torque(self, currents):
+        mp = self._motor_parameter
+        return 1.5 * mp["p"] * (mp["psi_p"] + (mp["l_d"] - mp["l_q"]) * currents[0]) * currents[1]
+
+    def _torque_limit(self):
+        """lines 121-132."""
+        mp = self._motor_parameter
+        if mp["l_d"] == mp["l_q"]:
+            return self.torque([0, self._limits["i_sq"], 0])
+        i_n = self._nominal_values["i"]
+        _p = mp["psi_p"] / (2 * (mp["l_d"] - mp["l_q"]))
+        _q = -(i_n**2) / 2
+        i_d_opt = -_p / 2 - np.sqrt((_p / 2) ** 2 - _q)
+        i_q_opt = np.sqrt(i_n**2 - i_d_opt**2)
+        return self.torque([i_d_opt, i_q_opt, 0])
+
+    def torque_coefficients(self):
+        mp = self._motor_parameter
+        return [1.5 * mp["p"] * mp["psi_p"], 1.5 * mp["p"] * (mp["l_d"] - mp["l_q"])]
+
+    def initial_motor_state(self):
+        # synchronous_motor.py:125-131: np.asarray(list(self._initial_states.values())) -> dict ORDER, not names
+        vals = [float(v) for v in self._initial_states.values()]
+        return vals if len(vals) == 3 else [0.0, 0.0, 0.0]
+
+
+class SquirrelCageInductionMotor(_ThreePhaseMotor):
+    """electric_motors/squirrel_cage_induction_motor.py:8-157 over induction_motor.py:7-364."""
+
+    CURRENTS = ["i_salpha", "i_sbeta"]
+    FLUXES = ["psi_ralpha", "psi_rbeta"]
+    IO_VOLTAGES = ["u_sa", "u_sb", "u_sc", "u_salpha", "u_sbeta", "u_sd", "u_sq"]
+    IO_CURRENTS = ["i_sa", "i_sb", "i_sc", "i_salpha", "i_sbeta", "i_sd", "i_sq"]
+    _default_motor_parameter = {"p": 2, "l_m": 143.75e-3, "l_sigs": 5.87e-3, "l_sigr": 5.87e-3, "j_rotor": 1.1e-3,
+                                "r_s": 2.9338, "r_r": 1.355}
+    _default_limits = dict(omega=4e3 * np.pi / 30, torque=0.0, i=5.5, epsilon=math.pi, u=560)
+    _default_nominal_values = dict(omega=3e3 * np.pi / 30, torque=0.0, i=3.9, epsilon=math.pi, u=560)
+    _default_initializer = {"states": {"i_salpha": 0.0, "i_sbeta": 0.0, "psi_ralpha": 0.0, "psi_rbeta": 0.0, "epsilon": 0.0},
+                            "interval": None, "random_init": None, "random_params": (None, None)}
+
+    def __init__(self, motor_parameter=None, nominal_values=None, limit_values=None, motor_initializer=None):
+        super().__init__(motor_parameter, nominal_values, limit_values, motor_initializer)
+        mp = self._motor_parameter
+        # InductionMotor._update_model, induction_motor.py:287-312
+        l_s = mp["l_m"] + mp["l_sigs"]
+        l_r = mp["l_m"] + mp["l_sigr"]
+        sigma = (l_s * l_r - mp["l_m"] ** 2) / (l_s * l_r)
+        tau_r = l_r / mp["r_r"]
+        tau_sig = sigma * l_s / (mp["r_s"] + mp["r_r"] * (mp["l_m"] ** 2) / (l_r**2))
+        k = mp["l_m"] / (sigma * l_r * l_s)
+        g = mp["l_m"] * mp["r_r"] / (sigma * l_s * l_r**2)
+        self._model_constants = np.array([
+            [0, -1 / tau_sig, 0, g, 0, 0, +k * mp["p"], 1 / (sigma * l_s), 0, -k, 0],
+            [0, 0, -1 / tau_sig, 0, g, -k * mp["p"], 0, 0, 1 / (sigma * l_s), 0, -k],
+            [0, mp["l_m"] / tau_r, 0, -1 / tau_r, 0, 0, -mp["p"], 0, 0, 1, 0],
+            [0, 0, mp["l_m"] / tau_r, 0, -1 / tau_r, mp["p"], 0, 0, 0, 0, 1],
+            [mp["p"], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+        ], dtype=float)
+        self._three_phase_limits()
+
+    def _torque_limit(self):
+        """induction_motor.py:223-234."""
+        mp = self._motor_parameter
+        return 1.5 * mp["p"] * mp["l_m"] ** 2 / (mp["l_m"] + mp["l_sigr"]) * self._limits["i_sd"] * self._limits["i_sq"] / 2
+
+    def torque_coefficients(self):
+        mp = self._motor_parameter
+        return [1.5 * mp["p"] * mp["l_m"] / (mp["l_m"] + mp["l_sigr"]), 0.0]
+
+    def initial_motor_state(self):
+        vals = [float(v) for v in self._initial_states.values()]
+        return vals if len(vals) == 5 else [0.0] * 5
+
+
+# ------------------------------------------------------------------------------------------------- loads
+class _MechanicalLoad:
+    """mechanical_loads/mechanical_load.py:9-236 (bookkeeping only)."""
+
+    _default_initializer = {}
+
+    def __init__(self, j_load=0.0, load_initializer=None):
+        self._j_total = self._j_load = float(j_load)
+        self._state_names = ["omega"]
+        self._limits = {}
+        self._nominal_values = {}
+        self._initializer = dict(self._default_initializer)
+        self._initializer.update(load_initializer or {})
+        if self._initializer.get("random_init") is not None:
+            raise NotImplementedError("random load initialisers are not on the accelerated path yet (SURVEY.md 8f rank 4)")
+        self._initial_states = dict(self._initializer.get("states", {"omega": 0.0}))
+
+    j_total = property(lambda self: self._j_total)
+    state_names = property(lambda self: self._state_names)
+    limits = property(lambda self: self._limits)
+    nominal_values = property(lambda self: self._nominal_values)
+    initializer = property(lambda self: self._initializer)
+
+    def set_j_rotor(self, j_rotor):
+        self._j_total = self._j_load + float(j_rotor)
+
+    def initial_omega(self):
+        return float(self._initial_states.get("omega", 0.0))
+
+
+class ConstantSpeedLoad(_MechanicalLoad):
+    """mechanical_loads/constant_speed_load.py:6-46."""
+
+    _default_initializer = {"states": {"omega": 0.0}, "interval": None, "random_init": None, "random_params": (None, None)}
+
+    def __init__(self, omega_fixed=0, load_initializer=None, **kwargs):
+        super().__init__(load_initializer=load_initializer, **kwargs)
+        self._initial_states = dict(self._initial_states)
+        self._omega = omega_fixed or self._initial_states["omega"]
+        if omega_fixed != 0:
+            self._initial_states["omega"] = omega_fixed
+
+    @property
+    def omega_fixed(self):
+        return self._omega
+
+
+class PolynomialStaticLoad(_MechanicalLoad):
+    """mechanical_loads/polynomial_static_load.py:8-107."""
+
+    _load_parameter = dict(a=0.0, b=0.0, c=0.0, j_load=1e-5)
+    _default_initializer = {"states": {"omega": 0.0}, "interval": None, "random_init": None, "random_params": (None, None)}
+    tau_decay = 1e-3
+
+    def __init__(self, load_parameter=None, limits=None, load_initializer=None):
+        self._load_parameter = update_parameter_dict(self._load_parameter, load_parameter or {})
+        super().__init__(j_load=self._load_parameter["j_load"], load_initializer=load_initializer)
+        self._limits.update(limits or {})
+
+    @property
+    def load_parameter(self):
+        return self._load_parameter

@@ -1,0 +1,88 @@
+"""Multi-GPU: env instances are independent, so the path shards with NO data-path collective.
+
+Rank r of W (one process per GPU, torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for
+the tests) owns the contiguous env range `shard_range(n_total, r, W)`, with its own SoA state on its own GPU; the
+(few hundred bytes of) parameters are replicated.  The only collective is on the batched-return path, when a
+caller wants every rank's observations in one place: `gather_observations` = ONE all-gather of the
+`[n_local, S_out]` shards (+ the `[n_local]` done bytes).  On the 8-GPU xGMI mesh every shard travels once over
+each direct link (no ring all-reduce anywhere), so gather per K-step chunk, not per step, when the policy is not
+co-located (DESIGN.md section "Multi-GPU").
+"""
+import os
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous, balanced partition of env indices: the first n_total % world ranks get one extra env."""
+    base, rem = divmod(int(n_total), int(world))
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def shard_sizes(n_total, world):
+    return [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def gather_observations(obs_local, done_local=None, n_total=None, group=None):
+    """All-gather the per-rank observation shards into `[n_total, S_out]` (and done into `[n_total]`) on every rank.
+
+    Shards may differ by one env (unbalanced tail); they are padded to the largest shard for the collective
+    and trimmed afterwards.  Works for CPU tensors with gloo and device tensors with RCCL."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return obs_local, done_local
+    world = dist.get_world_size(group)
+    n_local = obs_local.shape[0]
+    if n_total is None:
+        sizes_t = torch.tensor([n_local], device=obs_local.device, dtype=torch.int64)
+        all_sizes = [torch.zeros_like(sizes_t) for _ in range(world)]
+        dist.all_gather(all_sizes, sizes_t, group=group)
+        sizes = [int(s.item()) for s in all_sizes]
+    else:
+        sizes = shard_sizes(n_total, world)
+    n_max = max(sizes)
+
+    def _gather(x):
+        if x.shape[0] < n_max:
+            pad = torch.zeros((n_max - x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+            x = torch.cat([x, pad], dim=0)
+        x = x.contiguous()
+        out = torch.empty((world * n_max,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=group)
+        parts = [out[r * n_max : r * n_max + sizes[r]] for r in range(world)]
+        return torch.cat(parts, dim=0) if any(s != n_max for s in sizes) else out
+
+    obs_all = _gather(obs_local)
+    done_all = _gather(done_local) if done_local is not None else None
+    return obs_all, done_all
+
+
+def make_sharded(env_id, n_envs_total, rank, world, device, **kwargs):
+    """This rank's shard of a `n_envs_total`-env batched environment."""
+    from .envs import make
+
+    lo, hi = shard_range(n_envs_total, rank, world)
+    env = make(env_id, n_envs=hi - lo, device=device, **kwargs)
+    env.shard = (lo, hi)
+    env.n_envs_total = n_envs_total
+    return env

@@ -1,0 +1,548 @@
+"""Batched SCML physical systems behind GEM's `PhysicalSystem` plugin surface.
+
+`BatchedSCMLSystem` keeps the constructor and the property/method surface of the reference's `SCMLSystem`
+(physical_systems/physical_systems.py:13-287) and of `gym_electric_motor.core.PhysicalSystem`
+(core.py:589-705): `simulate(action)`, `reset()`, `tau`, `k`, `state_names`, `state_positions`,
+`action_space`, `state_space`, `limits`, `nominal_state`, `unwrapped`, `close()`, `supply`, `converter`,
+`electrical_motor`, `mechanical_load`, the `*_IDX` tables and the abc/alphabeta/dq helper transforms.
+All physics runs in the HIP kernels of `libgemx.so` through the C ABI in include/gemx.h -- there is no CPU path.
+
+* `n_envs == 1`: `simulate(action)` / `reset()` take and return 1-D numpy arrays exactly like the reference,
+  so the instance drops into the unmodified `ElectricMotorEnvironment(physical_system=...)` and its wrappers.
+* `n_envs > 1`: `simulate(actions[N, A])` returns a device tensor `[N, S_out]`; `done` holds the constraint
+  mask of the last step; `rollout(actions[K, N, A])` runs K fused steps in one launch.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from . import components as comp
+from .spaces import Box
+
+try:  # derive from the reference's plugin base when GEM is importable, so isinstance() checks hold
+    from gym_electric_motor.core import PhysicalSystem as _PhysicalSystemBase  # pragma: no cover
+except Exception:
+
+    class _PhysicalSystemBase:
+        """Stand-alone equivalent of gym_electric_motor.core.PhysicalSystem (core.py:589-705)."""
+
+        def __init__(self, action_space, state_space, state_names, tau):
+            self._action_space = action_space
+            self._state_space = state_space
+            self._state_names = state_names
+            self._state_positions = {key: index for index, key in enumerate(self._state_names)}
+            self._tau = tau
+            self._k = 0
+
+        tau = property(lambda self: self._tau)
+        unwrapped = property(lambda self: self)
+        k = property(lambda self: self._k)
+        state_names = property(lambda self: self._state_names)
+        state_positions = property(lambda self: self._state_positions)
+        action_space = property(lambda self: self._action_space)
+        state_space = property(lambda self: self._state_space)
+
+        def close(self):
+            pass
+
+
+def _is_a(obj, *names):
+    """Duck typing across this package's and the reference's component classes (by class name in the MRO)."""
+    mro = {c.__name__ for c in type(obj).__mro__}
+    return any(n in mro for n in names)
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+class LimitConstraint:
+    """constraints.py:31-68: violation if any observed |state| > 1 (normalised)."""
+
+    def __init__(self, observed_state_names="all_states"):
+        self.observed_state_names = observed_state_names
+
+
+class SquaredConstraint:
+    """constraints.py:71-98: violation if the sum of squares of the normalised states > 1."""
+
+    def __init__(self, states=()):
+        self.states = tuple(states)
+
+
+class BatchedSCMLSystem(_PhysicalSystemBase):
+    """N independent Supply-Converter-Motor-Load systems stepped in lockstep on one MI355X."""
+
+    OMEGA_IDX = 0
+    TORQUE_IDX = 1
+    CURRENTS_IDX = []
+    VOLTAGES_IDX = []
+    U_SUP_IDX = -1
+
+    _SYSTEM_KIND = None
+
+    def __init__(self, converter, motor, load, supply, ode_solver, tau=1e-4, calc_jacobian=None, n_envs=1, device=0,
+                 dtype="float32", constraints=(), auto_reset=None, obs_layout="aos", control_space="abc", _defer_create=False):
+        """
+        Args (first six as in SCMLSystem.__init__, physical_systems.py:54-65):
+            converter, motor, load, supply: component instances (this package's or the reference's).
+            ode_solver: EulerSolver(nsteps) | RK4Solver(nsteps) | DormandPrince5Solver(); scipy-backed reference
+                solvers are refused (they are the CPU oracle path).
+            tau(float): control step.
+            calc_jacobian: accepted and ignored (explicit solvers need no Jacobian).
+            n_envs(int): number of env instances advanced in lockstep.
+            device(int): HIP device ordinal.
+            dtype: 'float32' (product path) | 'float64' (diagnostic).
+            constraints: iterable of state names (LimitConstraint), LimitConstraint / SquaredConstraint objects
+                (this package's or the reference's).  They are evaluated in-kernel into the `done` mask.
+            auto_reset(bool): restart an env from its initial state on the step after `done`.
+                Default: True when n_envs > 1 and constraints are given, else False.
+            obs_layout: 'aos' -> observations [N, S_out] (reference contract); 'soa' -> [S_out, N].
+        """
+        if control_space != "abc":
+            raise NotImplementedError("control_space='dq' is not on the accelerated path yet (SURVEY.md 8f rank 1)")
+        self._converter = converter
+        self._electrical_motor = motor
+        self._mechanical_load = load
+        self._supply = supply
+        self._ode_solver = ode_solver
+        self.control_space = control_space
+        self._n_envs = int(n_envs)
+        self._device = int(device)
+        self._dtype_name = {"float32": "float32", "float64": "float64", "f32": "float32", "f64": "float64"}[str(dtype).replace("torch.", "")]
+        self._obs_layout = obs_layout
+        self._mechanical_load.set_j_rotor(self._electrical_motor.motor_parameter["j_rotor"])  # line 83
+        state_names = self._build_state_names()
+        self._set_indices()
+        # PhysicalSystem.__init__ (core.py:662-676)
+        _PhysicalSystemBase.__init__(self, self._converter.action_space, None, state_names, tau)
+        self._state_space = self._build_state_space(state_names)
+        self._limits = np.zeros(len(state_names), dtype=float)
+        self._nominal_state = np.zeros(len(state_names), dtype=float)
+        self._set_limits()
+        self._set_nominal_state()
+        self._converter.tau = self.tau  # line 103
+        self._constraints = tuple(constraints)
+        limit_mask, squared_mask = self._constraint_masks(self._constraints)
+        if auto_reset is None:
+            auto_reset = self._n_envs > 1 and bool(limit_mask or squared_mask)
+        self._auto_reset = bool(auto_reset)
+        self._cfg = self._build_config(limit_mask, squared_mask)
+        self._handle = None
+        if not _defer_create:  # (_defer_create: host-side config only, used by the CPU unit tests)
+            self._create()
+
+    # ------------------------------------------------------------------ reference-compatible metadata
+    limits = property(lambda self: self._limits)
+    nominal_state = property(lambda self: self._nominal_state)
+    supply = property(lambda self: self._supply)
+    converter = property(lambda self: self._converter)
+    electrical_motor = property(lambda self: self._electrical_motor)
+    mechanical_load = property(lambda self: self._mechanical_load)
+    n_envs = property(lambda self: self._n_envs)
+    device = property(lambda self: self._device)
+
+    def _set_limits(self):
+        """physical_systems.py:105-113."""
+        for ind, state in enumerate(self._state_names):
+            motor_lim = self._electrical_motor.limits.get(state, np.inf)
+            mechanical_lim = self._mechanical_load.limits.get(state, np.inf)
+            self._limits[ind] = min(motor_lim, mechanical_lim)
+        self._limits[self._state_positions["u_sup"]] = self.supply.u_nominal
+
+    def _set_nominal_state(self):
+        """physical_systems.py:115-123."""
+        for ind, state in enumerate(self._state_names):
+            motor_nom = self._electrical_motor.nominal_values.get(state, np.inf)
+            mechanical_nom = self._mechanical_load.nominal_values.get(state, np.inf)
+            self._nominal_state[ind] = min(motor_nom, mechanical_nom)
+        self._nominal_state[self._state_positions["u_sup"]] = self.supply.u_nominal
+
+    def _build_state_names(self):
+        raise NotImplementedError
+
+    def _build_state_space(self, state_names):
+        raise NotImplementedError
+
+    def _set_indices(self):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ config extraction
+    def _constraint_masks(self, constraints):
+        """Map the env's `constraints` argument (core.py:256-262) onto bit masks over the system state."""
+        pos = {n: i for i, n in enumerate(self._build_state_names())}
+        limit_mask = squared_mask = 0
+        for c in constraints:
+            if isinstance(c, str):
+                names = list(pos) if c == "all_states" else [c]
+                for n in names:
+                    limit_mask |= 1 << pos[n]
+            elif _is_a(c, "LimitConstraint"):
+                names = getattr(c, "observed_state_names", None)
+                if names is None:
+                    names = getattr(c, "_observed_state_names", [])
+                if isinstance(names, str):
+                    names = [names]
+                if "all_states" in names:
+                    names = list(pos)
+                for n in names:
+                    limit_mask |= 1 << pos[n]
+            elif _is_a(c, "SquaredConstraint"):
+                if squared_mask:
+                    raise ValueError("only one SquaredConstraint is supported in-kernel")
+                names = getattr(c, "states", None) or getattr(c, "_states", ())
+                for n in names:
+                    squared_mask |= 1 << pos[n]
+            else:
+                raise ValueError(f"constraint {c!r} cannot be evaluated in-kernel (supported: state names, "
+                                 "LimitConstraint, SquaredConstraint)")
+        return limit_mask, squared_mask
+
+    def _converter_kind(self):
+        c = self._converter
+        if _is_a(c, "ContFourQuadrantConverter"):
+            return _lib.CONV_CONT_4QC
+        if _is_a(c, "FiniteB6BridgeConverter"):
+            return _lib.CONV_FINITE_B6
+        if _is_a(c, "ContB6BridgeConverter"):
+            return _lib.CONV_CONT_B6
+        raise ValueError(f"converter {type(c).__name__} is not on the accelerated path "
+                         "(supported: ContFourQuadrantConverter, FiniteB6BridgeConverter, ContB6BridgeConverter)")
+
+    def _solver_kind(self):
+        s = self._ode_solver
+        nsteps = int(getattr(s, "_nsteps", 1))
+        if _is_a(s, "EulerSolver"):
+            return _lib.SOLVER_EULER, nsteps
+        if _is_a(s, "RK4Solver"):
+            return _lib.SOLVER_RK4, nsteps
+        if _is_a(s, "DormandPrince5Solver"):
+            return _lib.SOLVER_DP5, nsteps
+        raise ValueError(f"ode_solver {type(s).__name__} is a CPU (scipy) solver; the GPU path takes EulerSolver, "
+                         "RK4Solver or DormandPrince5Solver")
+
+    def _load_params(self):
+        ld = self._mechanical_load
+        if _is_a(ld, "ConstantSpeedLoad"):
+            return _lib.LOAD_CONST_SPEED, 0.0, 0.0, 0.0, 1e-3, float(ld.omega_fixed)
+        if _is_a(ld, "PolynomialStaticLoad"):
+            lp = ld.load_parameter
+            init = getattr(ld, "initializer", {}) or {}
+            omega0 = float((init.get("states") or {}).get("omega", 0.0))
+            return _lib.LOAD_POLY_STATIC, float(lp["a"]), float(lp["b"]), float(lp["c"]), float(ld.tau_decay), omega0
+        raise ValueError(f"load {type(ld).__name__} is not on the accelerated path (supported: ConstantSpeedLoad, PolynomialStaticLoad)")
+
+    def _torque_coefficients(self):
+        m = self._electrical_motor
+        mp = m.motor_parameter
+        if _is_a(m, "DcPermanentlyExcitedMotor"):
+            return [mp["psi_e"], 0.0]
+        if _is_a(m, "PermanentMagnetSynchronousMotor"):
+            return [1.5 * mp["p"] * mp["psi_p"], 1.5 * mp["p"] * (mp["l_d"] - mp["l_q"])]
+        if _is_a(m, "SynchronousReluctanceMotor"):
+            return [0.0, 1.5 * mp["p"] * (mp["l_d"] - mp["l_q"])]
+        if _is_a(m, "SquirrelCageInductionMotor"):
+            return [1.5 * mp["p"] * mp["l_m"] / (mp["l_m"] + mp["l_sigr"]), 0.0]
+        raise ValueError(f"motor {type(m).__name__} is not on the accelerated path")
+
+    def _initial_motor_state(self):
+        m = self._electrical_motor
+        if hasattr(m, "initial_motor_state"):
+            return m.initial_motor_state()
+        init = getattr(m, "initializer", None) or {}
+        states = init.get("states") or {}
+        n_motor = self._n_ode - 1
+        vals = [float(v) for v in states.values()]
+        return vals if len(vals) == n_motor else [0.0] * n_motor
+
+    def _build_config(self, limit_mask, squared_mask):
+        cfg = _lib.GemxConfig()
+        cfg.struct_size = C.sizeof(_lib.GemxConfig)
+        cfg.abi_version = _lib.ABI_VERSION
+        cfg.system_kind = self._SYSTEM_KIND
+        cfg.converter_kind = self._converter_kind()
+        cfg.solver_kind, cfg.solver_nsteps = self._solver_kind()
+        cfg.dtype = _lib.F64 if self._dtype_name == "float64" else _lib.F32
+        cfg.obs_layout = {"aos": _lib.OBS_AOS, "soa": _lib.OBS_SOA}[self._obs_layout]
+        cfg.auto_reset = int(self._auto_reset)
+        cfg.limit_mask, cfg.squared_mask = limit_mask, squared_mask
+        cfg.tau = float(self.tau)
+        cfg.interlocking_time = float(getattr(self._converter, "_interlocking_time", 0.0))
+        cfg.u_nominal = float(self._supply.u_nominal)
+        model = np.zeros((_lib.MODEL_ROWS, _lib.MODEL_COLS))
+        mc = np.asarray(self._electrical_motor._model_constants, dtype=float)
+        model[: mc.shape[0], : mc.shape[1]] = mc
+        for i, v in enumerate(model.ravel()):
+            cfg.model[i] = v
+        for i, v in enumerate(self._torque_coefficients()):
+            cfg.torque_coef[i] = v
+        kind, a, b, c_, tau_decay, omega0 = self._load_params()
+        cfg.load_kind = kind
+        cfg.j_total = float(self._mechanical_load.j_total)
+        cfg.load_a, cfg.load_b, cfg.load_c, cfg.tau_decay = a, b, c_, tau_decay
+        for i, v in enumerate(self._limits):
+            cfg.limits[i] = float(v)
+        init = [omega0] + list(self._initial_motor_state())
+        assert len(init) == self._n_ode
+        for i, v in enumerate(init):
+            cfg.init_state[i] = float(v)
+        return cfg
+
+    # ------------------------------------------------------------------ device plumbing (torch = memory + streams)
+    def _create(self):
+        torch = _torch()
+        L = _lib.load()
+        if L.gemx_device_count() <= 0 or not torch.cuda.is_available():
+            raise _lib.GemxError("no HIP device visible: gym_electric_motor_amd has no CPU fallback "
+                                 "(the CPU restatement under oracle/ is test infrastructure, not a product path)")
+        h = C.c_void_p()
+        _lib.check(L.gemx_create(C.byref(self._cfg), self._n_envs, self._device, C.byref(h)))
+        self._handle = h
+        self._L = L
+        self._tdev = torch.device("cuda", self._device)
+        self._tdtype = torch.float64 if self._dtype_name == "float64" else torch.float32
+        self._n_out = L.gemx_n_out(h)
+        self._n_act = L.gemx_n_action(h)
+        self._discrete = L.gemx_action_itemsize(h) == 1
+        shape = (self._n_envs, self._n_out) if self._obs_layout == "aos" else (self._n_out, self._n_envs)
+        self._obs = torch.empty(shape, dtype=self._tdtype, device=self._tdev)
+        self._done = torch.zeros(self._n_envs, dtype=torch.uint8, device=self._tdev)
+        ro = (C.c_double * _lib.MAX_OUT)()
+        _lib.check(L.gemx_reset_observation(h, ro))
+        self._reset_obs = np.array(ro[: self._n_out], dtype=float)
+
+    def _stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self._tdev).cuda_stream)
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None:
+            self._L.gemx_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _actions_to_device(self, actions, leading):
+        """-> contiguous device tensor of shape leading + (A,) (float R) or leading (uint8)."""
+        torch = _torch()
+        if self._discrete:
+            if not torch.is_tensor(actions):
+                arr = np.asarray(actions)
+                if arr.size and (arr.min() < 0 or arr.max() > 7):
+                    bad = arr.ravel()[(arr.ravel() < 0) | (arr.ravel() > 7)][0]
+                    raise AssertionError(f"The selected action {bad} is not a valid element of the action space {self.action_space}.")
+                actions = torch.as_tensor(arr.astype(np.uint8))
+            t = actions.to(device=self._tdev, dtype=torch.uint8).reshape(leading).contiguous()
+        else:
+            if not torch.is_tensor(actions):
+                actions = torch.as_tensor(np.asarray(actions, dtype=np.float64))
+            t = actions.to(device=self._tdev, dtype=self._tdtype).reshape(leading + (self._n_act,)).contiguous()
+        return t
+
+    # ------------------------------------------------------------------ the plugin surface
+    @property
+    def done(self):
+        """uint8 device tensor [N]: constraint violation (`terminated`, core.py:350) of the last simulate()."""
+        return self._done
+
+    @property
+    def reset_observation(self):
+        """Normalised state every env shows right after a reset (constant initialiser), numpy [S_out]."""
+        return self._reset_obs.copy()
+
+    def simulate(self, action, *_, **__):
+        """One control step.  n_envs == 1: 1-D numpy in / out (reference contract, physical_systems.py:171-203).
+        Otherwise `action` is [N, A] (float) or [N] (discrete) and the returned device tensor ([N, S_out]) is an
+        internal buffer that the next call overwrites."""
+        single = self._n_envs == 1 and not _torch().is_tensor(action)
+        if single and self._discrete:
+            assert self.action_space.contains(action), (  # converters.py:204-206
+                f"The selected action {action} is not a valid element of the action space {self.action_space}.")
+        a = self._actions_to_device(action, (self._n_envs,))
+        _lib.check(self._L.gemx_step(self._handle, C.c_void_p(a.data_ptr()), C.c_void_p(self._obs.data_ptr()),
+                                     C.c_void_p(self._done.data_ptr()), self._stream()))
+        self._k += 1
+        if single:
+            return self._obs.reshape(-1).double().cpu().numpy()
+        return self._obs
+
+    def rollout(self, actions, obs_out=None, done_out=None, last_only=False):
+        """K fused control steps in one launch.  actions: [K, N, A] / [K, N]; returns (obs [K, N, S_out], done [K, N])
+        device tensors (or the last step's [N, S_out], [N] with last_only=True)."""
+        torch = _torch()
+        K = int(actions.shape[0])
+        a = self._actions_to_device(actions, (K, self._n_envs))
+        if last_only:
+            oshape, dshape = tuple(self._obs.shape), (self._n_envs,)
+        else:
+            oshape = (K,) + tuple(self._obs.shape)
+            dshape = (K, self._n_envs)
+        if obs_out is None:
+            obs_out = torch.empty(oshape, dtype=self._tdtype, device=self._tdev)
+        if done_out is None:
+            done_out = torch.empty(dshape, dtype=torch.uint8, device=self._tdev)
+        assert tuple(obs_out.shape) == oshape and obs_out.is_contiguous() and obs_out.dtype == self._tdtype
+        assert tuple(done_out.shape) == dshape and done_out.is_contiguous() and done_out.dtype == torch.uint8
+        _lib.check(self._L.gemx_rollout(self._handle, C.c_void_p(a.data_ptr()), K, C.c_void_p(obs_out.data_ptr()),
+                                        C.c_void_p(done_out.data_ptr()), 0 if last_only else 1, self._stream()))
+        self._k += K
+        return obs_out, done_out
+
+    def reset(self, mask=None, *_):
+        """PhysicalSystem.reset (core.py:678-685).  mask: optional [N] bool/uint8 selecting the envs to reset."""
+        torch = _torch()
+        m = None
+        if mask is not None and not (self._n_envs == 1 and not torch.is_tensor(mask) and np.ndim(mask) == 0):
+            m = torch.as_tensor(mask).to(device=self._tdev, dtype=torch.uint8).contiguous()
+        _lib.check(self._L.gemx_reset(self._handle, C.c_void_p(m.data_ptr()) if m is not None else None,
+                                      C.c_void_p(self._obs.data_ptr()) if m is None else None, self._stream()))
+        if m is None:
+            self._k = 0
+        if self._n_envs == 1:
+            return self._reset_obs.copy()
+        return self._obs
+
+    def check_errors(self):
+        """Synchronises.  Raises like the reference (converters.py:204-206) if a discrete action left 0..7."""
+        flags = C.c_uint32(0)
+        _lib.check(self._L.gemx_error_flags(self._handle, C.byref(flags), self._stream()))
+        if flags.value & 1:
+            raise AssertionError(f"An action outside the action space {self.action_space} was passed to simulate()/rollout().")
+
+    # ------------------------------------------------------------------ checkpoint / parity access
+    def get_state(self):
+        """ODE state [S_ode, N] (physical units, angle in rad) as a new device tensor."""
+        torch = _torch()
+        out = torch.empty((self._n_ode, self._n_envs), dtype=self._tdtype, device=self._tdev)
+        _lib.check(self._L.gemx_get_state(self._handle, C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def set_state(self, state):
+        torch = _torch()
+        s = torch.as_tensor(state).to(device=self._tdev, dtype=self._tdtype).reshape(self._n_ode, self._n_envs).contiguous()
+        _lib.check(self._L.gemx_set_state(self._handle, C.c_void_p(s.data_ptr()), self._stream()))
+        torch.cuda.current_stream(self._tdev).synchronize()
+
+    def get_switch_state(self):
+        torch = _torch()
+        out = torch.empty(self._n_envs, dtype=torch.uint8, device=self._tdev)
+        _lib.check(self._L.gemx_get_switch_state(self._handle, C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def set_switch_state(self, sw):
+        torch = _torch()
+        s = torch.as_tensor(sw).to(device=self._tdev, dtype=torch.uint8).contiguous()
+        _lib.check(self._L.gemx_set_switch_state(self._handle, C.c_void_p(s.data_ptr()), self._stream()))
+        torch.cuda.current_stream(self._tdev).synchronize()
+
+
+class BatchedDcMotorSystem(BatchedSCMLSystem):
+    """DcMotorSystem (physical_systems.py:290-318) for N envs."""
+
+    _SYSTEM_KIND = _lib.SYS_DC_PERMEX
+    _n_ode = 2
+
+    def _build_state_names(self):
+        return self._mechanical_load.state_names + ["torque"] + list(self._electrical_motor.CURRENTS) + list(self._electrical_motor.VOLTAGES) + ["u_sup"]
+
+    def _set_indices(self):
+        """physical_systems.py:141-162."""
+        n_c, n_v = len(self._electrical_motor.CURRENTS), len(self._electrical_motor.VOLTAGES)
+        self.OMEGA_IDX = 0
+        self.TORQUE_IDX = 1
+        self.CURRENTS_IDX = list(range(2, 2 + n_c))
+        self.VOLTAGES_IDX = list(range(2 + n_c, 2 + n_c + n_v))
+        self.U_SUP_IDX = [2 + n_c + n_v]
+
+    def _build_state_space(self, state_names):
+        """physical_systems.py:305-318 with DcPermanentlyExcitedMotor.get_state_space (dc_permanently_excited_motor.py:107-120)."""
+        cur_low, vol_low = self._converter.currents.low[0], self._converter.voltages.low[0]
+        low = {"omega": -1 if vol_low == -1 else 0, "torque": -1 if cur_low == -1 else 0, "i": -1 if cur_low == -1 else 0,
+               "u": -1 if vol_low == -1 else 0, "u_sup": 0}
+        high = {"omega": 1, "torque": 1, "i": 1, "u": 1, "u_sup": self._supply.supply_range[1] / self._supply.u_nominal}
+        if self._supply.supply_range[0] != self._supply.supply_range[1]:
+            low["u_sup"] = self._supply.supply_range[0] / self._supply.u_nominal
+        return Box(np.array([low[n] for n in state_names], dtype=float), np.array([high[n] for n in state_names], dtype=float), dtype=np.float64)
+
+
+class _BatchedThreePhaseMotorSystem(BatchedSCMLSystem):
+    """ThreePhaseMotorSystem helper transforms (physical_systems.py:321-415), host-side numpy, for user code."""
+
+    _T23 = 2 / 3 * np.array([[1, -0.5, -0.5], [0, 0.5 * np.sqrt(3), -0.5 * np.sqrt(3)]])
+    _T32 = np.array([[1, 0], [-0.5, 0.5 * np.sqrt(3)], [-0.5, -0.5 * np.sqrt(3)]])
+
+    @staticmethod
+    def _q(quantities, epsilon):
+        c, s = math.cos(epsilon), math.sin(epsilon)
+        return c * quantities[0] - s * quantities[1], s * quantities[0] + c * quantities[1]
+
+    def abc_to_alphabeta_space(self, abc_quantities):
+        return np.matmul(self._T23, abc_quantities)
+
+    def alphabeta_to_abc_space(self, alphabeta_quantities):
+        return np.matmul(self._T32, alphabeta_quantities)
+
+    def abc_to_dq_space(self, abc_quantities, epsilon_el, normed_epsilon=False):
+        if normed_epsilon:
+            epsilon_el *= np.pi
+        return self._q(np.matmul(self._T23, abc_quantities), -epsilon_el)
+
+    def dq_to_abc_space(self, dq_quantities, epsilon_el, normed_epsilon=False):
+        if normed_epsilon:
+            epsilon_el *= np.pi
+        return np.matmul(self._T32, self._q(dq_quantities, epsilon_el))
+
+    def alphabeta_to_dq_space(self, alphabeta_quantities, epsilon_el, normed_epsilon=False):
+        if normed_epsilon:
+            epsilon_el *= np.pi
+        return self._q(alphabeta_quantities, -epsilon_el)
+
+    def dq_to_alphabeta_space(self, dq_quantities, epsilon_el, normed_epsilon=False):
+        if normed_epsilon:
+            epsilon_el *= np.pi
+        return self._q(dq_quantities, epsilon_el)
+
+    def _set_indices(self):
+        """physical_systems.py:462-485 / 737-763."""
+        self.OMEGA_IDX = 0
+        self.TORQUE_IDX = 1
+        self.CURRENTS_IDX = list(range(2, 7))
+        self.VOLTAGES_IDX = list(range(7, 12))
+        self.EPSILON_IDX = 12
+        self.U_SUP_IDX = [13]
+
+    def _build_state_space(self, state_names):
+        """physical_systems.py:437-442 / 712-717."""
+        low = -1 * np.ones(len(state_names), dtype=float)
+        low[self.U_SUP_IDX] = 0.0
+        high = np.ones(len(state_names), dtype=float)
+        return Box(low, high, dtype=np.float64)
+
+
+class BatchedSynchronousMotorSystem(_BatchedThreePhaseMotorSystem):
+    """SynchronousMotorSystem (physical_systems.py:418-561) for N envs (PMSM, SynRM)."""
+
+    _SYSTEM_KIND = _lib.SYS_SYNC
+    _n_ode = 4
+
+    def _build_state_names(self):
+        return self._mechanical_load.state_names + ["torque", "i_a", "i_b", "i_c", "i_sd", "i_sq", "u_a", "u_b", "u_c",
+                                                    "u_sd", "u_sq", "epsilon", "u_sup"]
+
+
+class BatchedSquirrelCageInductionMotorSystem(_BatchedThreePhaseMotorSystem):
+    """SquirrelCageInductionMotorSystem (physical_systems.py:696-847) for N envs."""
+
+    _SYSTEM_KIND = _lib.SYS_SCIM
+    _n_ode = 6
+
+    def _build_state_names(self):
+        return self._mechanical_load.state_names + ["torque", "i_sa", "i_sb", "i_sc", "i_sd", "i_sq", "u_sa", "u_sb", "u_sc",
+                                                    "u_sd", "u_sq", "epsilon", "u_sup"]

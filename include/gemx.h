@@ -1,0 +1,137 @@
+/*
+ * gemx.h -- C ABI of the MI355X-native batched physical-system stepper for gym-electric-motor (GEM).
+ *
+ * The reference (upb-lea/gym-electric-motor 3.0.2) is pure Python and has no FFI: its replaceable seam is
+ * the plugin base class gym_electric_motor.core.PhysicalSystem (core.py:589-705) whose two hot methods are
+ *     simulate(action) -> state / limits        (core.py:687-698; SCMLSystem.simulate physical_systems.py:171-203,
+ *                                                SynchronousMotorSystem.simulate 487-525,
+ *                                                SquirrelCageInductionMotorSystem.simulate 771-814)
+ *     reset()          -> state / limits        (core.py:678-685; physical_systems.py:256-287, 527-561, 816-847)
+ * This library is what a GEM maintainer binds with ctypes behind that seam (INTEGRATION.md shows the stub):
+ * one handle = N independent SCML systems (supply -> converter -> motor ODE + load ODE -> normalised state,
+ * constraint-violation done flag) advanced in lockstep by hand-written gfx950 kernels.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all `*_dev` pointers are DEVICE pointers owned by the caller
+ *    (e.g. torch.Tensor.data_ptr()); `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *  - every call returns GEMX_OK (0) or a negative gemx_status; the message is in gemx_last_error().
+ *    Nothing throws across the boundary.  Calls on one handle are not thread-safe; launches are asynchronous.
+ *  - real type R = float (dtype GEMX_F32, default; the product path) or double (GEMX_F64, diagnostic).
+ *  - there is NO CPU fallback: without a HIP device gemx_create() fails with GEMX_ERR_DEVICE.
+ */
+#ifndef GEMX_H
+#define GEMX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GEMX_ABI_VERSION 1
+#define GEMX_MAX_ODE 8  /* ODE state length incl. omega and the angle      */
+#define GEMX_MAX_OUT 16 /* system-state (observation) length               */
+#define GEMX_MODEL_ROWS 5
+#define GEMX_MODEL_COLS 11
+
+typedef enum gemx_status {
+    GEMX_OK = 0,
+    GEMX_ERR_ARG = -1,     /* invalid argument / unsupported configuration (cf. reference asserts, converters.py:204-206) */
+    GEMX_ERR_DEVICE = -2,  /* no HIP device / HIP runtime error                                                        */
+    GEMX_ERR_ALLOC = -3
+} gemx_status;
+
+/* SCML system class: DcMotorSystem / SynchronousMotorSystem / SquirrelCageInductionMotorSystem */
+typedef enum { GEMX_SYS_DC_PERMEX = 0, GEMX_SYS_SYNC = 1, GEMX_SYS_SCIM = 2 } gemx_system_kind;
+/* ContFourQuadrantConverter (converters.py:438-495), FiniteB6BridgeConverter (743-839), ContB6BridgeConverter (842-911) */
+typedef enum { GEMX_CONV_CONT_4QC = 0, GEMX_CONV_FINITE_B6 = 1, GEMX_CONV_CONT_B6 = 2 } gemx_converter_kind;
+/* ConstantSpeedLoad (constant_speed_load.py), PolynomialStaticLoad (polynomial_static_load.py) */
+typedef enum { GEMX_LOAD_CONST_SPEED = 0, GEMX_LOAD_POLY_STATIC = 1 } gemx_load_kind;
+/* EulerSolver(nsteps) (solvers.py:79-136); classical RK4 (not in the reference); one fixed Dormand-Prince-5
+ * step per segment (what the reference's default scipy dopri5 does whenever its trial step is accepted) */
+typedef enum { GEMX_SOLVER_EULER = 0, GEMX_SOLVER_RK4 = 1, GEMX_SOLVER_DP5 = 2 } gemx_solver_kind;
+typedef enum { GEMX_F32 = 0, GEMX_F64 = 1 } gemx_dtype;
+/* observation layout: [N, S_out] rows per env (the reference contract) or [S_out, N] */
+typedef enum { GEMX_OBS_AOS = 0, GEMX_OBS_SOA = 1 } gemx_obs_layout;
+
+/* Flat description of ONE SCML system shared by all N envs of a handle (parameters are uniform across envs:
+ * they travel as kernel arguments -> SGPRs, 0 bytes of HBM traffic per env). */
+typedef struct gemx_config {
+    int32_t struct_size; /* = sizeof(gemx_config), ABI check */
+    int32_t abi_version; /* = GEMX_ABI_VERSION */
+    int32_t system_kind, converter_kind, load_kind;
+    int32_t solver_kind, solver_nsteps; /* nsteps: sub-steps per integration segment (EulerSolver(nsteps)); >= 1 */
+    int32_t dtype, obs_layout;
+    int32_t auto_reset;    /* 1: an env whose step ended `done` restarts from init_state on its next step */
+    uint32_t limit_mask;   /* LimitConstraint:   done if any |obs[i]| > 1      over set bits (constraints.py:55-58) */
+    uint32_t squared_mask; /* SquaredConstraint: done if sum obs[i]^2 > 1      over set bits (constraints.py:96-98) */
+    double tau;               /* control step, PhysicalSystem.tau */
+    double interlocking_time; /* converter dead time, converters.py:35-41; must be < tau */
+    double u_nominal;         /* IdealVoltageSupply.u_nominal, voltage_supplies.py:60-72 */
+    /* motor._model_constants zero-padded to 5x11, row-major; feature order as in the reference:
+     * DC    (1x3) [omega, i, u]                                  dc_permanently_excited_motor.py:71-84
+     * SYNC  (3x7) [omega, i_d, i_q, u_d, u_q, omega*i_d, omega*i_q]  synchronous_motor.py:143-168
+     * SCIM  (5x11)[omega, i_a, i_b, psi_a, psi_b, omega*psi_a, omega*psi_b, u_sa, u_sb, u_ra, u_rb] induction_motor.py:187-217 */
+    double model[GEMX_MODEL_ROWS * GEMX_MODEL_COLS];
+    /* torque: DC T = tc[0]*i ; SYNC T = (tc[0] + tc[1]*i_d)*i_q ; SCIM T = tc[0]*(psi_a*i_b - psi_b*i_a) */
+    double torque_coef[4];
+    double j_total;                    /* load.j_total (j_load + j_rotor), mechanical_load.py:35-41 */
+    double load_a, load_b, load_c;     /* PolynomialStaticLoad parameters */
+    double tau_decay;                  /* PolynomialStaticLoad.tau_decay (1e-3) */
+    double limits[GEMX_MAX_OUT];       /* PhysicalSystem.limits, physical_systems.py:105-113 */
+    double init_state[GEMX_MAX_ODE];   /* ODE state after reset: [omega, motor states..., epsilon] */
+} gemx_config;
+
+typedef struct gemx_handle gemx_handle;
+
+int gemx_abi_version(void);
+int gemx_sizeof_config(void);
+const char *gemx_last_error(void);
+/* number of visible HIP devices (0 => the library cannot run; callers must fail loudly) */
+int gemx_device_count(void);
+
+/* Create N envs on `device`, all at the reset state.  Replaces SCMLSystem.__init__ (physical_systems.py:54-103). */
+int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle **out);
+int gemx_destroy(gemx_handle *h);
+
+int gemx_n_envs(const gemx_handle *h, int64_t *n);
+int gemx_n_ode(const gemx_handle *h);    /* S_ode: 2 | 4 | 6 */
+int gemx_n_out(const gemx_handle *h);    /* S_out: 5 | 14    */
+int gemx_n_action(const gemx_handle *h); /* A: 1 | 3         */
+int gemx_action_itemsize(const gemx_handle *h); /* 1 (uint8 discrete) | sizeof(R) */
+/* normalised state returned by reset() for the configured constant initialiser, host doubles [S_out] */
+int gemx_reset_observation(const gemx_handle *h, double *obs_host);
+
+/* PhysicalSystem.reset(): envs with mask[i] != 0 (all if mask_dev == NULL) go back to init_state, their step
+ * counter to 0; the converter switching state survives, as in the reference (converters.py:45-54).
+ * obs_out_dev (optional, layout per config) receives the reset observation for the reset envs. */
+int gemx_reset(gemx_handle *h, const uint8_t *mask_dev, void *obs_out_dev, void *stream);
+
+/* PhysicalSystem.simulate() for all N envs: one control step.
+ *   actions_dev : [N, A] R for continuous converters, [N] uint8 in 0..7 for Finite-B6C
+ *   obs_out_dev : [N, S_out] R (AoS) or [S_out, N] R (SoA); 16-byte aligned
+ *   done_out_dev: [N] uint8 (may be NULL when no constraint is configured)                                    */
+int gemx_step(gemx_handle *h, const void *actions_dev, void *obs_out_dev, uint8_t *done_out_dev, void *stream);
+
+/* K fused control steps in ONE launch (ODE state stays in registers between steps).
+ *   actions_dev [K, N, A]; obs_out_dev [K, N, S_out] (or [K, S_out, N]); done_out_dev [K, N].
+ *   obs_every: 1 = write every step; 0 = write only the last step (obs_out_dev [N,S_out], done_out_dev [N] =
+ *   OR over the K steps).                                                                                     */
+int gemx_rollout(gemx_handle *h, const void *actions_dev, int32_t K, void *obs_out_dev, uint8_t *done_out_dev,
+                 int32_t obs_every, void *stream);
+
+/* Checkpoint / parity access to the ODE state, SoA [S_ode, N] of R in physical units (angle in rad), plus the
+ * per-env packed converter switching state [N] uint8 (2 bits per leg) and step counters are not exported. */
+int gemx_get_state(gemx_handle *h, void *soa_out_dev, void *stream);
+int gemx_set_state(gemx_handle *h, const void *soa_in_dev, void *stream);
+int gemx_get_switch_state(gemx_handle *h, uint8_t *out_dev, void *stream);
+int gemx_set_switch_state(gemx_handle *h, const uint8_t *in_dev, void *stream);
+
+/* Sticky device error word (synchronises `stream`): bit 0 = a discrete action outside 0..7 was seen (the
+ * reference asserts action_space.contains(action), converters.py:204-206; the kernel masks it to 0..7). */
+int gemx_error_flags(gemx_handle *h, uint32_t *flags_host, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEMX_H */

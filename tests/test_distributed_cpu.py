@@ -1,0 +1,57 @@
+"""world_size-2 gloo test of the N>1 path (sharding + the one gather collective) on CPU."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from gym_electric_motor_amd import distributed as gd
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions_exactly():
+    for n in (1, 7, 8, 262144, 262147):
+        for w in (1, 2, 4, 8):
+            edges = [gd.shard_range(n, r, w) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
+            sizes = gd.shard_sizes(n, w)
+            assert sum(sizes) == n and max(sizes) - min(sizes) <= 1
+    assert gd.shard_range(262144, 3, 8) == (98304, 131072)  # BASELINE config 5: 8 x 32768
+
+
+def _worker(rank, world, port, n_total, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    from gym_electric_motor_amd import distributed as gdd
+
+    r, w, _ = gdd.init_from_env(backend="gloo")
+    lo, hi = gdd.shard_range(n_total, r, w)
+    # stand-in for this rank's observation shard: row i of the global batch is filled with i
+    obs = torch.arange(lo, hi, dtype=torch.float32).reshape(-1, 1).repeat(1, 14)
+    done = (torch.arange(lo, hi) % 3 == 0).to(torch.uint8)
+    all_obs, all_done = gdd.gather_observations(obs, done, n_total=n_total)
+    all_obs2, _ = gdd.gather_observations(obs, None)  # sizes discovered by a collective
+    torch.save((all_obs, all_done, all_obs2), os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [64, 101])
+def test_gather_observations_gloo_world2(tmp_path, n_total):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, n_total, str(tmp_path)), nprocs=2, join=True)
+    expect = torch.arange(n_total, dtype=torch.float32).reshape(-1, 1).repeat(1, 14)
+    for r in range(2):
+        all_obs, all_done, all_obs2 = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
+        assert torch.equal(all_obs, expect) and torch.equal(all_obs2, expect)
+        assert torch.equal(all_done, (torch.arange(n_total) % 3 == 0).to(torch.uint8))

@@ -1,0 +1,135 @@
+"""CPU-only tests of the product's host side: parameter extraction vs the reference (via golden meta), the C-ABI
+library loading with every symbol of include/gemx.h, loud failure without a GPU, error behaviour."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import gym_electric_motor_amd as ga
+from gym_electric_motor_amd import _lib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+
+def _meta(name):
+    return json.loads(str(np.load(os.path.join(HERE, "golden", name + ".npz"))["meta"]))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    import __graft_entry__ as g
+
+    g.build()
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, "include", "gemx.h")).read()
+    declared = set(re.findall(r"\b(gemx_[a-z_0-9]+)\s*\(", header))
+    declared -= {"gemx_config", "gemx_handle"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    L = _lib.load()
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    assert L.gemx_abi_version() == _lib.ABI_VERSION
+    assert L.gemx_sizeof_config() == C.sizeof(_lib.GemxConfig)
+
+
+@pytest.mark.parametrize("env_id, golden", [
+    ("Cont-CC-PermExDc-v0", "permexdc_free_held_euler"),
+    ("Cont-SC-PermExDc-v0", "permexdc_sc_free_held_euler"),
+    ("Finite-CC-PMSM-v0", "pmsm_free_held_euler"),
+    ("Finite-SC-PMSM-v0", "pmsm_sc_free_held_dopri5"),
+    ("Cont-SC-SCIM-v0", "scim_free_held_euler"),
+])
+def test_host_metadata_matches_reference(env_id, golden):
+    """limits / nominal_state / model constants / names / j_total as the live reference reported them."""
+    meta = _meta(golden)
+    ps = ga.make(env_id, n_envs=8, _defer_create=True).physical_system
+    assert list(ps.state_names) == meta["state_names"]
+    assert np.allclose(ps.limits, meta["limits"], rtol=1e-15, atol=0)
+    assert np.allclose(ps.nominal_state, meta["nominal_state"], rtol=1e-15, atol=0)
+    assert np.allclose(np.asarray(ps.electrical_motor._model_constants), np.asarray(meta["model_constants"]), rtol=1e-15, atol=0)
+    assert ps.mechanical_load.j_total == pytest.approx(meta["j_total"], rel=1e-15)
+    assert ps.tau == meta["tau"] and ps.supply.u_nominal == meta["u_nominal"]
+    assert ps.state_positions == {n: i for i, n in enumerate(meta["state_names"])}
+    assert ps.state_space.low.shape == (len(meta["state_names"]),)
+    cfg = ps._cfg
+    assert cfg.struct_size == C.sizeof(_lib.GemxConfig)
+    assert list(cfg.limits)[: len(meta["limits"])] == meta["limits"]
+
+
+def test_default_constraints_become_masks():
+    dc = ga.make("Cont-CC-PermExDc-v0", n_envs=2, _defer_create=True).physical_system
+    assert dc._cfg.limit_mask == 1 << dc.state_positions["i"] and dc._cfg.squared_mask == 0 and dc._cfg.auto_reset == 1
+    pm = ga.make("Finite-CC-PMSM-v0", n_envs=2, _defer_create=True).physical_system
+    assert pm._cfg.squared_mask == (1 << pm.state_positions["i_sd"]) | (1 << pm.state_positions["i_sq"])
+    one = ga.make("Finite-CC-PMSM-v0", n_envs=1, _defer_create=True).physical_system
+    assert one._cfg.auto_reset == 0  # n_envs == 1: the reference env shell decides when to reset
+    allc = ga.make("Cont-CC-PermExDc-v0", n_envs=2, constraints=("all_states",), _defer_create=True).physical_system
+    assert allc._cfg.limit_mask == 0b11111
+
+
+def test_pmsm_initialiser_dict_order_quirk():
+    """Reference quirk (permanent_magnet_synchronous_motor.py:98 + synchronous_motor.py:125-131): the VALUES of the
+    initialiser dict go into [i_sd, i_sq, epsilon] in dict order."""
+    m = ga.PermanentMagnetSynchronousMotor(motor_initializer={"states": {"i_sq": 1.0, "i_sd": 2.0, "epsilon": 0.5}})
+    ps = ga.make("Finite-CC-PMSM-v0", n_envs=2, motor=m, _defer_create=True).physical_system
+    assert list(ps._cfg.init_state)[:4] == [100.0, 1.0, 2.0, 0.5]
+
+
+def test_unsupported_pieces_raise():
+    with pytest.raises(KeyError):
+        ga.make("Finite-CC-PermExDc-v0", n_envs=2, _defer_create=True)
+    with pytest.raises(KeyError):
+        ga.make("Cont-CC-SeriesDc-v0", n_envs=2, _defer_create=True)
+
+    class ScipyOdeSolver:  # stands for the reference's scipy-backed solver classes
+        pass
+
+    with pytest.raises(ValueError):
+        ga.make("Cont-CC-PermExDc-v0", n_envs=2, ode_solver=ScipyOdeSolver(), _defer_create=True)
+    with pytest.raises(KeyError):  # update_parameter_dict semantics, utils.py:73-94
+        ga.DcPermanentlyExcitedMotor(motor_parameter=dict(r_x=1.0))
+    with pytest.raises(NotImplementedError):
+        ga.make("Cont-CC-PMSM-v0", n_envs=2, control_space="dq", _defer_create=True)
+
+
+def test_c_abi_argument_validation_without_gpu():
+    """gemx_create validates before touching the device; error text through gemx_last_error()."""
+    L = _lib.load()
+    ps = ga.make("Cont-CC-PermExDc-v0", n_envs=2, _defer_create=True).physical_system
+    h = C.c_void_p()
+    cfg = ps._cfg
+    bad = _lib.GemxConfig.from_buffer_copy(cfg)
+    bad.struct_size = 12
+    assert L.gemx_create(C.byref(bad), 4, 0, C.byref(h)) == -1 and b"ABI" in L.gemx_last_error()
+    bad = _lib.GemxConfig.from_buffer_copy(cfg)
+    bad.interlocking_time = 1.0
+    assert L.gemx_create(C.byref(bad), 4, 0, C.byref(h)) == -1 and b"interlocking" in L.gemx_last_error()
+    bad = _lib.GemxConfig.from_buffer_copy(cfg)
+    bad.model[5] = 1.0  # outside the DC sparsity pattern
+    assert L.gemx_create(C.byref(bad), 4, 0, C.byref(h)) == -1 and b"sparsity" in L.gemx_last_error()
+    assert L.gemx_create(C.byref(cfg), 0, 0, C.byref(h)) == -1
+    assert L.gemx_destroy(None) == 0
+
+
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.GemxError, match="no CPU fallback"):
+        ga.make("Cont-CC-PermExDc-v0", n_envs=4)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(REPO, "gym_electric_motor_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp")):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "gemx_oracle" not in src, f
