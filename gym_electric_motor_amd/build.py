@@ -28,7 +28,7 @@ def build_library(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> gym_electric_motor_amd/libgemx.so (cross-compiles without a GPU)."""
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(REPO, "include"),
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-I" + os.path.join(REPO, "include"),
            "-shared", "-fPIC", "-o", LIB, SRC]
     if verbose:
         print(" ".join(cmd))

@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <type_traits>
@@ -65,11 +66,13 @@ template <class R> struct DevParams {
     R u_sup;      // IdealVoltageSupply
     R il_ratio;   // interlocking_time / tau (continuous converters)
     R tau, t_il;  // control step, dead time
+    R inv_ns;     // 1 / solver_nsteps
     R inv_lim[GEMX_MAX_OUT];
-    R init[GEMX_MAX_ODE];  // [omega, motor states...]; the angle entry is also given in init_angle
-    double init_angle;     // rad
-    int32_t load_kind, solver, nsteps, has_il, auto_reset, obs_layout;
-    uint32_t limit_mask, squared_mask;
+    R init[GEMX_MAX_ODE];  // [omega, motor states...] (angle separately)
+    const R *cw;           // device array [2][GEMX_MAX_OUT]: generic constraint path 0/1 weights (limit | squared)
+    int64_t init_angle_rep; // initial angle in Angle<R>::T representation (bit pattern)
+    int32_t solver, nsteps, has_il, auto_reset, obs_layout;
+    int32_t constr_kind;    // 0 none, 1 the system's default constraint (fast path), 2 generic weights
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -87,6 +90,8 @@ template <> struct Angle<float> {
         long long c = llrint(t * 4294967296.0);
         return (T)(uint32_t)(unsigned long long)c;
     }
+    static __host__ __device__ T from_bits(int64_t b) { return (T)(int32_t)b; }
+    static __host__ int64_t to_bits(T a) { return (int64_t)a; }
     static __device__ __forceinline__ T advance(T a, float d_rad) {
         int32_t inc = __float2int_rn(d_rad * kCountsPerRad);
         return (T)((uint32_t)a + (uint32_t)inc);
@@ -114,6 +119,8 @@ template <> struct Angle<float> {
 template <> struct Angle<double> {
     using T = double;  // unwrapped radians, exactly as the reference integrates it
     static __host__ __device__ T from_rad(double a) { return a; }
+    static __host__ __device__ T from_bits(int64_t b) { T r; memcpy(&r, &b, 8); return r; }
+    static __host__ int64_t to_bits(T a) { int64_t b; memcpy(&b, &a, 8); return b; }
     static __device__ __forceinline__ T advance(T a, double d) { return a + d; }
     static __device__ __forceinline__ double wrapped(T a) {  // physical_systems.py:520-522
         double e = fmod(a, kTwoPi);
@@ -146,8 +153,8 @@ template <class R> __device__ __forceinline__ void t32(R al, R be, R &a, R &b, R
 // ------------------------------------------------------------------------------------------------
 // load: dω/dt (constant_speed_load.py:40-42; polynomial_static_load.py:62-66, 87-99)
 // ------------------------------------------------------------------------------------------------
-template <class R> __device__ __forceinline__ R load_ode(const DevParams<R> &P, R omega, R torque) {
-    if (P.load_kind == GEMX_LOAD_CONST_SPEED) return R(0);  // uniform branch (SGPR condition)
+template <int LOAD, class R> __device__ __forceinline__ R load_ode(const DevParams<R> &P, R omega, R torque) {
+    if (LOAD == GEMX_LOAD_CONST_SPEED) return R(0);
     R sign = sgn(omega);
     R a = fabs(omega) > P.omega_lim ? sign * P.la : P.lin_factor * omega;
     R tl = sign * P.lc * omega * omega + P.lb * omega + a;
@@ -159,29 +166,29 @@ template <class R> __device__ __forceinline__ R load_ode(const DevParams<R> &P, 
 // The reference evaluates matmul(model_constants, feature_vector); here only the structurally non-zero
 // entries are used (pack_model() rejects a matrix with any other non-zero entry).
 // ------------------------------------------------------------------------------------------------
-template <int SYS, class R> struct Motor;
+template <int SYS, int LOAD, class R> struct Motor;
 
-template <class R> struct Motor<GEMX_SYS_DC_PERMEX, R> {  // dc_permanently_excited_motor.py:67-84
+template <int LOAD, class R> struct Motor<GEMX_SYS_DC_PERMEX, LOAD, R> {  // dc_permanently_excited_motor.py:67-84
     static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&y)[2]) { return P.tc0 * y[1]; }
     static __device__ __forceinline__ void rhs(const DevParams<R> &P, const R (&y)[2], const R (&u)[2], R (&dy)[2]) {
-        dy[0] = load_ode(P, y[0], torque(P, y));
+        dy[0] = load_ode<LOAD, R>(P, y[0], torque(P, y));
         dy[1] = P.m[0] * y[0] + P.m[1] * y[1] + P.m[2] * u[0];
     }
 };
-template <class R> struct Motor<GEMX_SYS_SYNC, R> {  // synchronous_motor.py:143-168, permanent_magnet_synchronous_motor.py:107-139
+template <int LOAD, class R> struct Motor<GEMX_SYS_SYNC, LOAD, R> {  // synchronous_motor.py:143-168, permanent_magnet_synchronous_motor.py:107-139
     static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&y)[3]) { return (P.tc0 + P.tc1 * y[1]) * y[2]; }
     static __device__ __forceinline__ void rhs(const DevParams<R> &P, const R (&y)[3], const R (&u)[2], R (&dy)[3]) {
         const R w = y[0], id = y[1], iq = y[2];
-        dy[0] = load_ode(P, w, torque(P, y));
+        dy[0] = load_ode<LOAD, R>(P, w, torque(P, y));
         dy[1] = P.m[0] * id + P.m[1] * u[0] + P.m[2] * (w * iq);
         dy[2] = P.m[3] * w + P.m[4] * iq + P.m[5] * u[1] + P.m[6] * (w * id);
     }
 };
-template <class R> struct Motor<GEMX_SYS_SCIM, R> {  // induction_motor.py:187-217, 236-248, 287-312; squirrel_cage_induction_motor.py:121-129
+template <int LOAD, class R> struct Motor<GEMX_SYS_SCIM, LOAD, R> {  // induction_motor.py:187-217, 236-248, 287-312; squirrel_cage_induction_motor.py:121-129
     static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&y)[5]) { return P.tc0 * (y[3] * y[2] - y[4] * y[1]); }
     static __device__ __forceinline__ void rhs(const DevParams<R> &P, const R (&y)[5], const R (&u)[2], R (&dy)[5]) {
         const R w = y[0], ia = y[1], ib = y[2], pa = y[3], pb = y[4];
-        dy[0] = load_ode(P, w, torque(P, y));
+        dy[0] = load_ode<LOAD, R>(P, w, torque(P, y));
         dy[1] = P.m[0] * ia + P.m[1] * pa + P.m[2] * (w * pb) + P.m[3] * u[0];
         dy[2] = P.m[4] * ib + P.m[5] * pb + P.m[6] * (w * pa) + P.m[7] * u[1];
         dy[3] = P.m[8] * ia + P.m[9] * pa + P.m[10] * (w * pb);
@@ -191,14 +198,15 @@ template <class R> struct Motor<GEMX_SYS_SCIM, R> {  // induction_motor.py:187-2
 
 // ------------------------------------------------------------------------------------------------
 // integrate one segment of length h; returns the angle increment  ∫ pole*omega dt  of the scheme
-// (solvers.py:103-136 Euler; classical RK4; Dormand-Prince 5th-order weights)
+// (solvers.py:103-136 Euler; classical RK4; Dormand-Prince 5th-order weights).  The solver kind and the
+// sub-step count are wave-uniform run-time values (scalar branches).
 // ------------------------------------------------------------------------------------------------
-template <int SYS, class R>
+template <int SYS, int LOAD, class R>
 __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<SYS>::ND], const R (&u)[2], R h) {
     constexpr int ND = SysTraits<SYS>::ND;
-    using M = Motor<SYS, R>;
+    using M = Motor<SYS, LOAD, R>;
     const int ns = P.nsteps;
-    const R hs = ns == 1 ? h : h / R(ns);
+    const R hs = h * P.inv_ns;
     R wsum = R(0);  // sum over sub-steps of the omega quadrature
     for (int s = 0; s < ns; ++s) {
         R k1[ND], k2[ND], k3[ND], k4[ND], yt[ND];
@@ -209,12 +217,13 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
             for (int i = 0; i < ND; ++i) y[i] = y[i] + k1[i] * hs;
         } else if (P.solver == GEMX_SOLVER_RK4) {
             R wq = y[0];
+            const R hh = R(0.5) * hs;
 #pragma unroll
-            for (int i = 0; i < ND; ++i) yt[i] = y[i] + R(0.5) * hs * k1[i];
+            for (int i = 0; i < ND; ++i) yt[i] = y[i] + hh * k1[i];
             M::rhs(P, yt, u, k2);
             wq += R(2) * yt[0];
 #pragma unroll
-            for (int i = 0; i < ND; ++i) yt[i] = y[i] + R(0.5) * hs * k2[i];
+            for (int i = 0; i < ND; ++i) yt[i] = y[i] + hh * k2[i];
             M::rhs(P, yt, u, k3);
             wq += R(2) * yt[0];
 #pragma unroll
@@ -222,8 +231,9 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
             M::rhs(P, yt, u, k4);
             wq += yt[0];
             wsum += wq * R(1.0 / 6.0);
+            const R h6 = hs * R(1.0 / 6.0);
 #pragma unroll
-            for (int i = 0; i < ND; ++i) y[i] = y[i] + (hs * R(1.0 / 6.0)) * (k1[i] + R(2) * k2[i] + R(2) * k3[i] + k4[i]);
+            for (int i = 0; i < ND; ++i) y[i] = y[i] + h6 * (k1[i] + R(2) * (k2[i] + k3[i]) + k4[i]);
         } else {  // GEMX_SOLVER_DP5: one Dormand-Prince step, 5th-order solution, no error control
             R k5[ND], k6[ND];
             R wq = R(35.0 / 384.0) * y[0];
@@ -269,32 +279,11 @@ template <class R> __device__ __forceinline__ R cont_leg(const DevParams<R> &P, 
     return clip01(duty - sgn(i) * P.il_ratio);
 }
 // FiniteTwoQuadrantConverter.convert (converters.py:277-285): leg state 1 -> 1, 2 -> 0, 0 (dead) -> freewheeling diode
-template <class R> __device__ __forceinline__ R fin_leg(uint32_t st, R i) {
-    return st == 1u ? R(1) : (st == 2u ? R(0) : (i < R(0) ? R(1) : R(0)));
+// (conducts to the upper rail while i < 0).  Branch-free: returns +-0.5 * u_sup directly.
+template <class R> __device__ __forceinline__ R fin_leg_u(uint32_t st, R i, R half_us) {
+    const bool upper = (st == 1u) | ((st == 0u) & (i < R(0)));
+    return upper ? half_us : -half_us;
 }
-
-// ------------------------------------------------------------------------------------------------
-// one control step of one env.  Returns done.
-// ------------------------------------------------------------------------------------------------
-template <int SYS, int CONV, class R> struct Stepper;
-
-// ---- DcMotorSystem + Cont-4QC (physical_systems.py:171-203; converters.py:481-491) --------------------------
-template <class R> struct Stepper<GEMX_SYS_DC_PERMEX, GEMX_CONV_CONT_4QC, R> {
-    using AngT = typename Angle<R>::T;
-    static __device__ __forceinline__ void step(const DevParams<R> &P, R (&y)[2], AngT &, uint32_t &, const R (&act)[3],
-                                                uint32_t, R (&obs)[5]) {
-        const R d0 = clip01(R(0.5) * (act[0] + R(1)));
-        const R d1 = clip01(R(-0.5) * (act[0] - R(1)));
-        const R un = cont_leg(P, d0, y[1]) - cont_leg(P, d1, y[1]);  // both sub-converters see the same i (line 483)
-        R u[2] = {un * P.u_sup, R(0)};
-        integrate<GEMX_SYS_DC_PERMEX, R>(P, y, u, P.tau);
-        obs[0] = y[0] * P.inv_lim[0];
-        obs[1] = Motor<GEMX_SYS_DC_PERMEX, R>::torque(P, y) * P.inv_lim[1];
-        obs[2] = y[1] * P.inv_lim[2];
-        obs[3] = u[0] * P.inv_lim[3];
-        obs[4] = P.u_sup * P.inv_lim[4];
-    }
-};
 
 // phase voltages of the B6 bridges for one segment
 template <int CONV, class R>
@@ -305,9 +294,10 @@ __device__ __forceinline__ void b6_voltages(const DevParams<R> &P, const R (&act
         ub = (cont_leg(P, clip01(R(0.5) * (act[1] + R(1))), ib) - R(0.5)) * P.u_sup;
         uc = (cont_leg(P, clip01(R(0.5) * (act[2] + R(1))), ic) - R(0.5)) * P.u_sup;
     } else {  // converters.py:816-823; leg_state: 2 bits per leg, leg 0 in bits 0-1
-        ua = (fin_leg<R>(leg_state & 3u, ia) - R(0.5)) * P.u_sup;
-        ub = (fin_leg<R>((leg_state >> 2) & 3u, ib) - R(0.5)) * P.u_sup;
-        uc = (fin_leg<R>((leg_state >> 4) & 3u, ic) - R(0.5)) * P.u_sup;
+        const R hu = R(0.5) * P.u_sup;
+        ua = fin_leg_u<R>(leg_state & 3u, ia, hu);
+        ub = fin_leg_u<R>((leg_state >> 2) & 3u, ib, hu);
+        uc = fin_leg_u<R>((leg_state >> 4) & 3u, ic, hu);
     }
 }
 
@@ -332,8 +322,33 @@ __device__ __forceinline__ uint32_t b6_interlock(uint32_t prev, uint32_t want, b
     return used;
 }
 
+// ------------------------------------------------------------------------------------------------
+// one control step of one env: advances (y, ang, sw) and fills the normalised observation row.
+// ------------------------------------------------------------------------------------------------
+template <int SYS, int CONV, int LOAD, class R> struct Stepper;
+
+// ---- DcMotorSystem + Cont-4QC (physical_systems.py:171-203; converters.py:481-491) --------------------------
+template <int LOAD, class R> struct Stepper<GEMX_SYS_DC_PERMEX, GEMX_CONV_CONT_4QC, LOAD, R> {
+    using AngT = typename Angle<R>::T;
+    static __device__ __forceinline__ void step(const DevParams<R> &P, R (&y)[2], AngT &, uint32_t &, const R (&act)[3],
+                                                uint32_t, R (&obs)[5]) {
+        const R d0 = clip01(R(0.5) * (act[0] + R(1)));
+        const R d1 = clip01(R(-0.5) * (act[0] - R(1)));
+        const R un = cont_leg(P, d0, y[1]) - cont_leg(P, d1, y[1]);  // both sub-converters see the same i (line 483)
+        R u[2] = {un * P.u_sup, R(0)};
+        integrate<GEMX_SYS_DC_PERMEX, LOAD, R>(P, y, u, P.tau);
+        obs[0] = y[0] * P.inv_lim[0];
+        obs[1] = Motor<GEMX_SYS_DC_PERMEX, LOAD, R>::torque(P, y) * P.inv_lim[1];
+        obs[2] = y[1] * P.inv_lim[2];
+        obs[3] = u[0] * P.inv_lim[3];
+        obs[4] = P.u_sup * P.inv_lim[4];
+    }
+    // default constraint of the DC envs: LimitConstraint('i') (cont_cc_permex_dc_env.py:104)
+    static __device__ __forceinline__ bool default_done(const R (&obs)[5]) { return fabs(obs[2]) > R(1); }
+};
+
 // ---- SynchronousMotorSystem (physical_systems.py:487-525), control_space 'abc' ---------------------------------
-template <int CONV, class R> struct Stepper<GEMX_SYS_SYNC, CONV, R> {
+template <int CONV, int LOAD, class R> struct Stepper<GEMX_SYS_SYNC, CONV, LOAD, R> {
     using AngT = typename Angle<R>::T;
     static __device__ __forceinline__ void step(const DevParams<R> &P, R (&y)[3], AngT &ang, uint32_t &sw, const R (&act)[3],
                                                 uint32_t dact, R (&obs)[14]) {
@@ -355,7 +370,7 @@ template <int CONV, class R> struct Stepper<GEMX_SYS_SYNC, CONV, R> {
             t23(ua, ub, uc, ual, ube);
             u[0] = c * ual + s * ube;  // Q^-1(., eps): u_dq frozen at the segment-start angle (line 501/511)
             u[1] = -s * ual + c * ube;
-            R deps = integrate<GEMX_SYS_SYNC, R>(P, y, u, h);
+            R deps = integrate<GEMX_SYS_SYNC, LOAD, R>(P, y, u, h);
             ang = Angle<R>::advance(ang, deps);
         };
         segment(two ? P.t_il : P.tau);
@@ -367,7 +382,7 @@ template <int CONV, class R> struct Stepper<GEMX_SYS_SYNC, CONV, R> {
         R ial = c * y[1] - s * y[2], ibe = s * y[1] + c * y[2], ia, ib, ic;
         t32(ial, ibe, ia, ib, ic);
         obs[0] = y[0] * P.inv_lim[0];
-        obs[1] = Motor<GEMX_SYS_SYNC, R>::torque(P, y) * P.inv_lim[1];
+        obs[1] = Motor<GEMX_SYS_SYNC, LOAD, R>::torque(P, y) * P.inv_lim[1];
         obs[2] = ia * P.inv_lim[2];
         obs[3] = ib * P.inv_lim[3];
         obs[4] = ic * P.inv_lim[4];
@@ -381,10 +396,12 @@ template <int CONV, class R> struct Stepper<GEMX_SYS_SYNC, CONV, R> {
         obs[12] = Angle<R>::wrapped(ang) * P.inv_lim[12];
         obs[13] = P.u_sup * P.inv_lim[13];
     }
+    // default constraint: SquaredConstraint(('i_sq','i_sd')) (finite_cc_pmsm_env.py:106)
+    static __device__ __forceinline__ bool default_done(const R (&obs)[14]) { return obs[5] * obs[5] + obs[6] * obs[6] > R(1); }
 };
 
 // ---- SquirrelCageInductionMotorSystem (physical_systems.py:771-814), control_space 'abc' -----------------------
-template <int CONV, class R> struct Stepper<GEMX_SYS_SCIM, CONV, R> {
+template <int CONV, int LOAD, class R> struct Stepper<GEMX_SYS_SCIM, CONV, LOAD, R> {
     using AngT = typename Angle<R>::T;
     // cos/sin of the rotor-flux angle eps_fs = atan2(psi_b, psi_a) (calculate_field_angle, 765-769) without atan2
     static __device__ __forceinline__ void field_angle(R pa, R pb, R &s, R &c) {
@@ -415,7 +432,7 @@ template <int CONV, class R> struct Stepper<GEMX_SYS_SCIM, CONV, R> {
             t32(y[1], y[2], ia, ib, ic);  // i_in = T32(i_alphabeta) (line 780/792)
             b6_voltages<CONV, R>(P, act, legs, ia, ib, ic, ua, ub, uc);
             t23(ua, ub, uc, u[0], u[1]);  // u_alphabeta constant over the segment (line 788/799)
-            R deps = integrate<GEMX_SYS_SCIM, R>(P, y, u, h);
+            R deps = integrate<GEMX_SYS_SCIM, LOAD, R>(P, y, u, h);
             ang = Angle<R>::advance(ang, deps);
         };
         segment(two ? P.t_il : P.tau);
@@ -428,7 +445,7 @@ template <int CONV, class R> struct Stepper<GEMX_SYS_SCIM, CONV, R> {
         R ia, ib, ic;
         t32(y[1], y[2], ia, ib, ic);
         obs[0] = y[0] * P.inv_lim[0];
-        obs[1] = Motor<GEMX_SYS_SCIM, R>::torque(P, y) * P.inv_lim[1];
+        obs[1] = Motor<GEMX_SYS_SCIM, LOAD, R>::torque(P, y) * P.inv_lim[1];
         obs[2] = ia * P.inv_lim[2];
         obs[3] = ib * P.inv_lim[3];
         obs[4] = ic * P.inv_lim[4];
@@ -442,19 +459,23 @@ template <int CONV, class R> struct Stepper<GEMX_SYS_SCIM, CONV, R> {
         obs[12] = Angle<R>::wrapped(ang) * P.inv_lim[12];
         obs[13] = P.u_sup * P.inv_lim[13];
     }
+    // default constraint: SquaredConstraint(('i_sq','i_sd')) (cont_sc_scim_env.py:111)
+    static __device__ __forceinline__ bool default_done(const R (&obs)[14]) { return obs[5] * obs[5] + obs[6] * obs[6] > R(1); }
 };
 
 // ConstraintMonitor with merge 'max' over LimitConstraint / SquaredConstraint; terminated = violation >= 1
-// (core.py:350, 834-844; constraints.py:55-58, 96-98)
-template <int NOUT, class R> __device__ __forceinline__ bool constraint_done(const DevParams<R> &P, const R (&obs)[NOUT]) {
-    bool viol = false;
-    R sq = R(0);
+// (core.py:350, 834-844; constraints.py:55-58, 96-98).  constr_kind is wave-uniform: 0 none, 1 the env's default
+// constraint (3 VALU ops), 2 arbitrary masks as 0/1 weights (branch-free).
+template <class ST, int NOUT, class R> __device__ __forceinline__ bool constraint_done(const DevParams<R> &P, const R (&obs)[NOUT]) {
+    if (P.constr_kind == 0) return false;
+    if (P.constr_kind == 1) return ST::default_done(obs);
+    R lim = R(0), sq = R(0);
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) {
-        if ((P.limit_mask >> i) & 1u) viol |= fabs(obs[i]) > R(1);
-        if ((P.squared_mask >> i) & 1u) sq += obs[i] * obs[i];
+        lim = fmax(lim, P.cw[i] * fabs(obs[i]));
+        sq += (P.cw[GEMX_MAX_OUT + i] * obs[i]) * obs[i];
     }
-    return viol | (sq > R(1));
+    return (lim > R(1)) | (sq > R(1));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -465,44 +486,108 @@ template <class R> struct KArgs {
     R *state;                       // [ND][N]
     typename Angle<R>::T *angle;    // [N] (systems with an angle)
     uint8_t *sw;                    // [N] packed leg states (Finite-B6C with interlocking)
-    const void *actions;            // [K][N][A] R  |  [K][N] uint8
+    const unsigned char *actions;   // [K][N][A] R  |  [K][N] uint8
     R *obs;                         // [K][N][NOUT] | [K][NOUT][N]  (or a single step's worth if !obs_every)
     uint8_t *done;                  // [K][N] | [N]
     uint32_t *err;                  // device error word (bit 0: discrete action out of range)
     int64_t N;
     int32_t K, obs_every;
+    int32_t S;                      // control steps per I/O block (LDS ring depth)
+    int32_t coop;                   // 1: action rows / done rows of full blocks are 16-byte aligned -> cooperative staging
+    int32_t obs_vec;                // 1: observation rows of full blocks are 16-byte aligned -> 16-byte stores
 };
 
-// Row-per-env observation store: transpose through LDS so the wave writes its contiguous span with
-// 16-byte-per-lane stores.  `rows` = number of valid envs of this workgroup.
-template <int NOUT, class R>
-__device__ __forceinline__ void store_obs_rows(R *lds, R *gbase, const R (&obs)[NOUT], int tid, int rows) {
-    __syncthreads();  // previous step's LDS reads are complete
+extern __shared__ __attribute__((aligned(16))) unsigned char gemx_smem[];
+
+constexpr int MAX_ACT_CHUNKS = 12;  // upper bound of 16-byte chunks of staged actions per lane and I/O block
+constexpr int MAX_STEPS_PER_BLOCK = 32;
+// chunks per lane needed to stage MAX_STEPS_PER_BLOCK steps of a row made of `cpr` 16-byte chunks
+__host__ __device__ constexpr int act_chunks(int cpr) {
+    return (MAX_STEPS_PER_BLOCK * cpr + BLOCK - 1) / BLOCK < MAX_ACT_CHUNKS ? (MAX_STEPS_PER_BLOCK * cpr + BLOCK - 1) / BLOCK : MAX_ACT_CHUNKS;
+}
+
+// S control steps of one I/O block.  COOP: actions come from the LDS tile (no global memory access at all in
+// this loop); otherwise straight from global memory (K == 1, tail workgroup, unaligned tensors).  The two variants
+// are separate instantiations on purpose: a pointer that may be LDS or global would compile to FLAT loads, whose
+// s_waitcnt covers vmcnt as well and would wait for every outstanding observation store.
+template <bool COOP, int SYS, int CONV, int LOAD, class R>
+__device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTraits<SYS>::ND], typename Angle<R>::T &ang, uint32_t &sw,
+                                              R (&obs)[SysTraits<SYS>::NOUT], uint32_t &done_or, uint32_t &bad_action, R *ring,
+                                              const unsigned char *atile, unsigned char *donebuf, int k0, int sb, int tid,
+                                              int64_t e, typename Angle<R>::T init_ang) {
+    constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
+    constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
+    constexpr int ABYTES = DISCRETE ? 1 : NACT * (int)sizeof(R);
+    constexpr int ROWB = BLOCK * ABYTES;
+    using ST = Stepper<SYS, CONV, LOAD, R>;
+    const DevParams<R> &P = a.P;
+    for (int s = 0; s < sb; ++s) {
+        R act[3] = {R(0), R(0), R(0)};
+        uint32_t dact = 0;
+        if (COOP) {
+            if (DISCRETE) dact = atile[s * ROWB + tid];
+            else {
 #pragma unroll
-    for (int j = 0; j < NOUT; ++j) lds[tid * NOUT + j] = obs[j];
-    __syncthreads();
-    constexpr int VEC = 16 / sizeof(R);
-    using V = typename std::conditional<sizeof(R) == 4, float4, double2>::type;
-    const int total = rows * NOUT;
-    const int nvec = total / VEC;
-    const V *lv = reinterpret_cast<const V *>(lds);
-    V *gv = reinterpret_cast<V *>(gbase);
+                for (int i = 0; i < NACT; ++i) act[i] = reinterpret_cast<const R *>(atile + s * ROWB)[tid * NACT + i];
+            }
+        } else {
+            const unsigned char *g = a.actions + ((int64_t)(k0 + s) * a.N + e) * ABYTES;
+            if (DISCRETE) dact = *g;
+            else {
 #pragma unroll
-    for (int i = 0; i < (BLOCK * NOUT / VEC + BLOCK - 1) / BLOCK; ++i) {
-        int idx = tid + i * BLOCK;
-        if (idx < nvec) gv[idx] = lv[idx];
+                for (int i = 0; i < NACT; ++i) act[i] = reinterpret_cast<const R *>(g)[i];
+            }
+        }
+        if (DISCRETE) { bad_action |= dact > 7u; dact &= 7u; }
+        ST::step(P, y, ang, sw, act, dact, obs);
+        const bool done = constraint_done<ST, NOUT, R>(P, obs);
+        done_or |= done ? 1u : 0u;
+        if (a.obs_every) {
+            if (P.obs_layout == GEMX_OBS_AOS) {
+#pragma unroll
+                for (int j = 0; j < NOUT; ++j) ring[(s * BLOCK + tid) * NOUT + j] = obs[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < NOUT; ++j) ring[(s * NOUT + j) * BLOCK + tid] = obs[j];
+            }
+            donebuf[s * BLOCK + tid] = done ? 1 : 0;
+        }
+        if (done && P.auto_reset) {  // `if terminated: env.reset()`; switching state survives (converters.py:45-54)
+#pragma unroll
+            for (int j = 0; j < ND; ++j) y[j] = P.init[j];
+            ang = init_ang;
+        }
     }
-    for (int idx = nvec * VEC + tid; idx < total; idx += BLOCK) gbase[idx] = lds[idx];
 }
 
 // ------------------------------------------------------------------------------------------------
 // THE kernel: K control steps of N envs (K = 1 is the single-step path of gemx_step()).
+//
+// I/O is blocked in groups of S control steps, because on gfx950 loads AND stores retire through the same
+// in-order vmcnt counter: waiting for the next action right after issuing this step's observation stores would
+// expose the HBM store latency (~2 us) on every step.  Per block of S steps:
+//   1. issue the global loads of the NEXT block's action tile (S rows x 64 envs, contiguous per row) as 16-byte
+//      per-lane loads into registers (no wait);
+//   2. S control steps, reading this block's actions from LDS and writing observation rows / done bytes to an
+//      LDS ring (no global memory traffic at all inside the compute loop);
+//   3. park the prefetched action tile in the other half of the LDS action buffer (its loads had S steps of
+//      arithmetic to land);
+//   4. flush the ring: each 64-env row is a contiguous 64*S_out*sizeof(R) span of the [K, N, S_out] output, written
+//      with 16-byte-per-lane stores; the stores drain while the next block computes.
 // ------------------------------------------------------------------------------------------------
-template <int SYS, int CONV, class R>
+template <int SYS, int CONV, int LOAD, class R>
 __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
     constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
+    constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
+    constexpr int ABYTES = DISCRETE ? 1 : NACT * (int)sizeof(R);  // action bytes per env and step
+    constexpr int ROWB = BLOCK * ABYTES;                           // action bytes per 64-env row
+    constexpr int CPR = ROWB / 16;                                 // 16-byte chunks per action row
+    constexpr int VEC = 16 / sizeof(R);
+    constexpr int ROWV = BLOCK * NOUT / VEC;                       // 16-byte chunks per observation row
+    constexpr int NCH = act_chunks(CPR);                           // 16-byte action chunks per lane and I/O block
     using AngT = typename Angle<R>::T;
-    __shared__ __attribute__((aligned(16))) R lds[BLOCK * NOUT];
+    using ST = Stepper<SYS, CONV, LOAD, R>;
+    using V = typename std::conditional<sizeof(R) == 4, float4, double2>::type;
 
     const DevParams<R> &P = a.P;
     const int tid = threadIdx.x;
@@ -512,6 +597,15 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
     const bool valid = env < N;
     const int64_t e = valid ? env : N - 1;  // clamp loads of the tail lanes; their stores are masked
     const int rows = (int)((N - blk0) < BLOCK ? (N - blk0) : BLOCK);
+    const bool full = rows == BLOCK;
+    const int S = a.S;
+    const int K = a.K;
+
+    // LDS carve-up: observation ring [S][64*NOUT] R | action tiles [2][S*ROWB] bytes | done ring [S][64] bytes
+    R *ring = reinterpret_cast<R *>(gemx_smem);
+    unsigned char *actbuf = gemx_smem + (size_t)S * BLOCK * NOUT * sizeof(R);
+    unsigned char *donebuf = actbuf + 2 * (size_t)S * ROWB;
+    const bool coop = a.coop && full && K > 1;   // cooperative action staging for this workgroup (uniform)
 
     R y[ND];
 #pragma unroll
@@ -521,56 +615,120 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
     uint32_t sw = 0;
     const bool use_sw = (CONV == GEMX_CONV_FINITE_B6) && P.has_il;
     if (use_sw) sw = a.sw[e];
+    const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
 
-    const R *act_r = static_cast<const R *>(a.actions);
-    const uint8_t *act_u8 = static_cast<const uint8_t *>(a.actions);
-    R act[3] = {R(0), R(0), R(0)};
-    uint32_t dact = 0;
-    auto load_action = [&](int k, R (&dst)[3], uint32_t &ddst) {
-        if (ConvTraits<CONV>::DISCRETE) {
-            ddst = act_u8[(int64_t)k * N + e];
-        } else {
+    // per-lane 16-byte loads of one action tile (steps [k0, k0+sb)) into registers: tile_load / tile_park below
+    V tile[NCH];
 #pragma unroll
-            for (int i = 0; i < NACT; ++i) dst[i] = act_r[((int64_t)k * N + e) * NACT + i];
-        }
-    };
-    load_action(0, act, dact);
+    for (int c = 0; c < NCH; ++c) tile[c] = V{};
+    const unsigned char *act_blk = a.actions + blk0 * ABYTES;  // this workgroup's column of the action tensor
+    const int64_t act_row_stride = N * ABYTES;
+#define GEMX_TILE_LOAD(k0_, sb_)                                                                                      \
+    do {                                                                                                              \
+        const int nchunk_ = (sb_) * CPR;                                                                              \
+        _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                                             \
+            const int idx = c * BLOCK + tid;                                                                          \
+            if (idx < nchunk_) {                                                                                      \
+                const int row = idx / CPR, col = idx - row * CPR;                                                     \
+                tile[c] = *reinterpret_cast<const V *>(act_blk + (int64_t)((k0_) + row) * act_row_stride + col * 16); \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+#define GEMX_TILE_PARK(half_, sb_)                                                                                    \
+    do {                                                                                                              \
+        const int nchunk_ = (sb_) * CPR;                                                                              \
+        V *dst_ = reinterpret_cast<V *>(actbuf + (size_t)(half_) * S * ROWB);                                         \
+        _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                                             \
+            const int idx = c * BLOCK + tid;                                                                          \
+            if (idx < nchunk_) dst_[idx] = tile[c];                                                                   \
+        }                                                                                                             \
+    } while (0)
 
-    const AngT init_ang = Angle<R>::from_rad(P.init_angle);
-    uint32_t done_or = 0;
-    uint32_t bad_action = 0;
+    if (coop) {
+        GEMX_TILE_LOAD(0, S < K ? S : K);
+        GEMX_TILE_PARK(0, S < K ? S : K);
+    }
+    // Drain the prologue loads (state, angle, first action tile) HERE, once.  Otherwise the compiler parks a
+    // conservative `s_waitcnt vmcnt(0)` at the first use inside the step loop, and since stores retire through the
+    // same counter every I/O block would wait for the previous block's whole flush burst instead of overlapping it.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // gfx9 encoding: vmcnt(0), expcnt/lgkmcnt untouched
+    __syncthreads();
 
-    for (int k = 0; k < a.K; ++k) {
-        // prefetch the next step's action so its HBM latency hides under this step's arithmetic
-        R nact[3] = {R(0), R(0), R(0)};
-        uint32_t ndact = 0;
-        if (k + 1 < a.K) load_action(k + 1, nact, ndact);
+    uint32_t done_or = 0, bad_action = 0;
+    R obs[NOUT];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) obs[j] = R(0);
+    int half = 0;
+    for (int k0 = 0; k0 < K; k0 += S) {
+        const int sb = (K - k0) < S ? (K - k0) : S;
+        const int k1 = k0 + sb;
+        const int sb_next = (K - k1) < S ? (K - k1) : S;
+        if (coop && sb_next > 0) GEMX_TILE_LOAD(k1, sb_next);  // 1. prefetch (no wait)
 
-        if (ConvTraits<CONV>::DISCRETE) { bad_action |= dact > 7u; dact &= 7u; }
-        R obs[NOUT];
-        Stepper<SYS, CONV, R>::step(P, y, ang, sw, act, dact, obs);
-        const bool done = constraint_done<NOUT, R>(P, obs);
-        done_or |= done ? 1u : 0u;
+        // 2. compute: no global memory traffic in here when coop
+        const unsigned char *atile = actbuf + (size_t)half * S * ROWB;
+        if (coop) compute_block<true, SYS, CONV, LOAD, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang);
+        else compute_block<false, SYS, CONV, LOAD, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang);
+        __syncthreads();
 
-        const bool last = (k == a.K - 1);
-        if (a.obs_every || last) {
-            const int64_t kk = a.obs_every ? k : 0;
+        // 3. park the prefetched tile
+        if (coop && sb_next > 0) GEMX_TILE_PARK(half ^ 1, sb_next);
+
+        // 4. flush the rings
+        if (a.obs_every) {
             if (P.obs_layout == GEMX_OBS_AOS) {
-                store_obs_rows<NOUT, R>(lds, a.obs + (kk * N + blk0) * NOUT, obs, tid, rows);
+                if (a.obs_vec) {
+                    const int nvec = rows * NOUT / VEC;  // == ROWV for full blocks
+                    for (int s = 0; s < sb; ++s) {
+                        V *gv = reinterpret_cast<V *>(a.obs + ((int64_t)(k0 + s) * N + blk0) * NOUT);
+                        const V *lv = reinterpret_cast<const V *>(ring + (size_t)s * BLOCK * NOUT);
+#pragma unroll
+                        for (int i = 0; i < (ROWV + BLOCK - 1) / BLOCK; ++i) {
+                            const int idx = tid + i * BLOCK;
+                            if (idx < nvec) gv[idx] = lv[idx];
+                        }
+                        for (int idx = nvec * VEC + tid; idx < rows * NOUT; idx += BLOCK)
+                            a.obs[((int64_t)(k0 + s) * N + blk0) * NOUT + idx] = ring[(size_t)s * BLOCK * NOUT + idx];
+                    }
+                } else {
+                    for (int s = 0; s < sb; ++s)
+                        for (int idx = tid; idx < rows * NOUT; idx += BLOCK)
+                            a.obs[((int64_t)(k0 + s) * N + blk0) * NOUT + idx] = ring[(size_t)s * BLOCK * NOUT + idx];
+                }
             } else if (valid) {
+                for (int s = 0; s < sb; ++s) {
 #pragma unroll
-                for (int j = 0; j < NOUT; ++j) a.obs[(kk * NOUT + j) * N + env] = obs[j];
+                    for (int j = 0; j < NOUT; ++j) a.obs[((int64_t)(k0 + s) * NOUT + j) * N + env] = ring[(s * NOUT + j) * BLOCK + tid];
+                }
             }
-            if (a.done != nullptr && valid) a.done[kk * N + env] = (uint8_t)(a.obs_every ? (done ? 1u : 0u) : done_or);
+            if (a.done != nullptr) {
+                if (a.coop && full) {  // done rows are 64 contiguous bytes: 4 x 16-byte chunks per row
+                    const int nchunk = sb * (BLOCK / 16);
+                    for (int idx = tid; idx < nchunk; idx += BLOCK) {
+                        const int row = idx >> 2, col = idx & 3;
+                        *reinterpret_cast<uint4 *>(a.done + (int64_t)(k0 + row) * N + blk0 + col * 16) =
+                            *reinterpret_cast<const uint4 *>(donebuf + row * BLOCK + col * 16);
+                    }
+                } else if (valid) {
+                    for (int s = 0; s < sb; ++s) a.done[(int64_t)(k0 + s) * N + env] = donebuf[s * BLOCK + tid];
+                }
+            }
         }
-        if (done && P.auto_reset) {  // `if terminated: env.reset()`; switching state survives (converters.py:45-54)
+        __syncthreads();
+        half ^= 1;
+    }
+
+    if (!a.obs_every) {  // last-step-only mode: one row through ring slot 0
+        if (P.obs_layout == GEMX_OBS_AOS) {
 #pragma unroll
-            for (int j = 0; j < ND; ++j) y[j] = P.init[j];
-            ang = init_ang;
+            for (int j = 0; j < NOUT; ++j) ring[tid * NOUT + j] = obs[j];
+            __syncthreads();
+            for (int idx = tid; idx < rows * NOUT; idx += BLOCK) a.obs[blk0 * NOUT + idx] = ring[idx];
+        } else if (valid) {
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) a.obs[(int64_t)j * N + env] = obs[j];
         }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) act[i] = nact[i];
-        dact = ndact;
+        if (a.done != nullptr && valid) a.done[env] = (uint8_t)done_or;
     }
 
     if (valid) {
@@ -580,6 +738,8 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
         if (use_sw) a.sw[env] = (uint8_t)sw;
     }
     if (bad_action && valid) atomicOr(a.err, 1u);
+#undef GEMX_TILE_LOAD
+#undef GEMX_TILE_PARK
 }
 
 // reset: masked envs back to the initial ODE state; optional broadcast of the reset observation
@@ -590,7 +750,7 @@ __global__ void reset_kernel(R *state, typename Angle<R>::T *angle, const uint8_
     if (env >= N) return;
     if (mask != nullptr && mask[env] == 0) return;
     for (int j = 0; j < nd; ++j) state[(int64_t)j * N + env] = P.init[j];
-    if (has_angle) angle[env] = Angle<R>::from_rad(P.init_angle);
+    if (has_angle) angle[env] = Angle<R>::from_bits(P.init_angle_rep);
     if (obs != nullptr) {
         for (int j = 0; j < nout; ++j) {
             if (obs_layout == GEMX_OBS_AOS) obs[env * nout + j] = reset_obs[j];
@@ -647,7 +807,11 @@ struct gemx_handle {
     uint8_t *sw = nullptr;   // [n]
     uint32_t *err = nullptr;
     void *reset_obs_dev = nullptr;  // [nout] R
+    void *cw_dev = nullptr;         // [2][GEMX_MAX_OUT] R constraint weights
     double reset_obs[GEMX_MAX_OUT];
+    int n_cu = 256;
+    size_t lds_max = 160 * 1024;
+    int steps_per_block = 0;  // 0 = heuristic
 };
 
 template <class R> static const DevParams<R> &params_of(const gemx_handle *h);
@@ -704,17 +868,24 @@ template <class R> static void fill_params(const gemx_handle &h, const double *m
     P.il_ratio = (R)(c.interlocking_time / c.tau);
     P.tau = (R)c.tau;
     P.t_il = (R)c.interlocking_time;
-    for (int i = 0; i < GEMX_MAX_OUT; ++i) P.inv_lim[i] = (R)(i < h.nout ? 1.0 / c.limits[i] : 0.0);
+    P.inv_ns = (R)(1.0 / c.solver_nsteps);
+    for (int i = 0; i < GEMX_MAX_OUT; ++i) {
+        P.inv_lim[i] = (R)(i < h.nout ? 1.0 / c.limits[i] : 0.0);
+    }
+    P.cw = (const R *)h.cw_dev;
     for (int i = 0; i < h.nd; ++i) P.init[i] = (R)c.init_state[i];
-    P.init_angle = h.has_angle ? c.init_state[h.nd] : 0.0;
-    P.load_kind = c.load_kind;
+    P.init_angle_rep = Angle<R>::to_bits(Angle<R>::from_rad(h.has_angle ? c.init_state[h.nd] : 0.0));
     P.solver = c.solver_kind;
     P.nsteps = c.solver_nsteps;
     P.has_il = (c.converter_kind == GEMX_CONV_FINITE_B6 && c.interlocking_time > 0.0) ? 1 : 0;
     P.auto_reset = c.auto_reset;
     P.obs_layout = c.obs_layout;
-    P.limit_mask = c.limit_mask;
-    P.squared_mask = c.squared_mask;
+    // the env's default constraint gets the 3-instruction fast path (Stepper::default_done)
+    const uint32_t def_limit = c.system_kind == GEMX_SYS_DC_PERMEX ? (1u << 2) : 0u;
+    const uint32_t def_sq = c.system_kind == GEMX_SYS_DC_PERMEX ? 0u : ((1u << 5) | (1u << 6));
+    if (c.limit_mask == 0 && c.squared_mask == 0) P.constr_kind = 0;
+    else if (c.limit_mask == def_limit && c.squared_mask == def_sq) P.constr_kind = 1;
+    else P.constr_kind = 2;
 }
 
 // reset observation in fp64 on the host (SCMLSystem.reset 256-287, SynchronousMotorSystem.reset 527-561,
@@ -770,34 +941,79 @@ template <class R> static int launch_reset(gemx_handle *h, const uint8_t *mask, 
     return GEMX_OK;
 }
 
-template <int SYS, int CONV, class R>
+// I/O block depth S (control steps staged in LDS between global-memory bursts): as deep as the LDS allows for the
+// number of workgroups that should be co-resident per CU, capped by the per-lane action-prefetch registers.
+static int choose_steps_per_block(const gemx_handle *h, int K, int es, int abytes) {
+    if (K <= 1) return 1;
+    const size_t per_step = (size_t)BLOCK * h->nout * es + 2 * (size_t)BLOCK * abytes + BLOCK;
+    int S = h->steps_per_block;
+    if (S <= 0) {
+        const int64_t nblocks = (h->n + BLOCK - 1) / BLOCK;
+        int64_t per_cu = (nblocks + h->n_cu - 1) / h->n_cu;
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 8) per_cu = 8;
+        S = (int)((h->lds_max - 1024) / per_cu / per_step);
+        if (S > MAX_STEPS_PER_BLOCK) S = MAX_STEPS_PER_BLOCK;
+    }
+    const int cpr = BLOCK * abytes / 16;
+    const int s_regs = act_chunks(cpr) * BLOCK / cpr;  // steps whose action rows fit the per-lane prefetch registers
+    if (S > s_regs) S = s_regs;
+    const int s_lds = (int)((h->lds_max - 256) / per_step);
+    if (S > s_lds) S = s_lds;
+    if (S > K) S = K;
+    if (S < 1) S = 1;
+    return S;
+}
+
+template <int SYS, int CONV, int LOAD, class R>
 static int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint8_t *done, int obs_every, hipStream_t st) {
+    constexpr int ABYTES = ConvTraits<CONV>::DISCRETE ? 1 : ConvTraits<CONV>::NACT * (int)sizeof(R);
     KArgs<R> a;
     a.P = params_of<R>(h);
     a.state = (R *)h->state;
     a.angle = (typename Angle<R>::T *)h->angle;
     a.sw = h->sw;
-    a.actions = actions;
+    a.actions = (const unsigned char *)actions;
     a.obs = (R *)obs;
     a.done = done;
     a.err = h->err;
     a.N = h->n;
     a.K = K;
     a.obs_every = obs_every;
+    a.S = choose_steps_per_block(h, K, (int)sizeof(R), ABYTES);
+    // 16-byte alignment of every full block's rows: row starts are (k*N + blk0) * bytes_per_env with blk0 % 64 == 0
+    a.coop = (((uintptr_t)actions & 15u) == 0 && ((size_t)h->n * ABYTES) % 16 == 0 &&
+              (done == nullptr || (((uintptr_t)done & 15u) == 0 && (size_t)h->n % 16 == 0))) ? 1 : 0;
+    a.obs_vec = (((size_t)h->n * h->nout * sizeof(R)) % 16 == 0) ? 1 : 0;
+    size_t smem = (size_t)a.S * BLOCK * h->nout * sizeof(R) + 2 * (size_t)a.S * BLOCK * ABYTES + (size_t)a.S * BLOCK;
+    smem = (smem + 15) & ~(size_t)15;
+    auto kern = advance_kernel<SYS, CONV, LOAD, R>;
+    static size_t attr_set = 0;  // per instantiation: largest dynamic-LDS size enabled so far
+    if (smem > attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max));
+        attr_set = h->lds_max;
+    }
     int64_t blocks = (h->n + BLOCK - 1) / BLOCK;
-    hipLaunchKernelGGL((advance_kernel<SYS, CONV, R>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), smem, st, a);
     HIP_TRY(hipGetLastError());
     return GEMX_OK;
+}
+
+template <int SYS, int CONV, class R>
+static int launch_advance_l(gemx_handle *h, const void *actions, int K, void *obs, uint8_t *done, int obs_every, hipStream_t st) {
+    if (h->cfg.load_kind == GEMX_LOAD_CONST_SPEED)
+        return launch_advance_t<SYS, CONV, GEMX_LOAD_CONST_SPEED, R>(h, actions, K, obs, done, obs_every, st);
+    return launch_advance_t<SYS, CONV, GEMX_LOAD_POLY_STATIC, R>(h, actions, K, obs, done, obs_every, st);
 }
 
 template <class R>
 static int launch_advance(gemx_handle *h, const void *actions, int K, void *obs, uint8_t *done, int obs_every, hipStream_t st) {
     const int s = h->cfg.system_kind, c = h->cfg.converter_kind;
-    if (s == GEMX_SYS_DC_PERMEX && c == GEMX_CONV_CONT_4QC) return launch_advance_t<GEMX_SYS_DC_PERMEX, GEMX_CONV_CONT_4QC, R>(h, actions, K, obs, done, obs_every, st);
-    if (s == GEMX_SYS_SYNC && c == GEMX_CONV_FINITE_B6) return launch_advance_t<GEMX_SYS_SYNC, GEMX_CONV_FINITE_B6, R>(h, actions, K, obs, done, obs_every, st);
-    if (s == GEMX_SYS_SYNC && c == GEMX_CONV_CONT_B6) return launch_advance_t<GEMX_SYS_SYNC, GEMX_CONV_CONT_B6, R>(h, actions, K, obs, done, obs_every, st);
-    if (s == GEMX_SYS_SCIM && c == GEMX_CONV_FINITE_B6) return launch_advance_t<GEMX_SYS_SCIM, GEMX_CONV_FINITE_B6, R>(h, actions, K, obs, done, obs_every, st);
-    if (s == GEMX_SYS_SCIM && c == GEMX_CONV_CONT_B6) return launch_advance_t<GEMX_SYS_SCIM, GEMX_CONV_CONT_B6, R>(h, actions, K, obs, done, obs_every, st);
+    if (s == GEMX_SYS_DC_PERMEX && c == GEMX_CONV_CONT_4QC) return launch_advance_l<GEMX_SYS_DC_PERMEX, GEMX_CONV_CONT_4QC, R>(h, actions, K, obs, done, obs_every, st);
+    if (s == GEMX_SYS_SYNC && c == GEMX_CONV_FINITE_B6) return launch_advance_l<GEMX_SYS_SYNC, GEMX_CONV_FINITE_B6, R>(h, actions, K, obs, done, obs_every, st);
+    if (s == GEMX_SYS_SYNC && c == GEMX_CONV_CONT_B6) return launch_advance_l<GEMX_SYS_SYNC, GEMX_CONV_CONT_B6, R>(h, actions, K, obs, done, obs_every, st);
+    if (s == GEMX_SYS_SCIM && c == GEMX_CONV_FINITE_B6) return launch_advance_l<GEMX_SYS_SCIM, GEMX_CONV_FINITE_B6, R>(h, actions, K, obs, done, obs_every, st);
+    if (s == GEMX_SYS_SCIM && c == GEMX_CONV_CONT_B6) return launch_advance_l<GEMX_SYS_SCIM, GEMX_CONV_CONT_B6, R>(h, actions, K, obs, done, obs_every, st);
     return fail(GEMX_ERR_ARG, "unsupported system/converter combination %d/%d", s, c);
 }
 
@@ -862,8 +1078,15 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
     }
     if (device < 0 || device >= ndev) { delete h; return fail(GEMX_ERR_ARG, "device %d out of range (0..%d)", device, ndev - 1); }
     if (hipSetDevice(device) != hipSuccess) { delete h; return fail(GEMX_ERR_DEVICE, "hipSetDevice(%d) failed", device); }
-    fill_params<float>(*h, m, pole, h->pf);
-    fill_params<double>(*h, m, pole, h->pd);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+            if (prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
+            if (prop.sharedMemPerBlock >= 64 * 1024) h->lds_max = prop.sharedMemPerBlock;
+        }
+        const char *ev = getenv("GEMX_STEPS_PER_BLOCK");
+        if (ev) h->steps_per_block = atoi(ev);
+    }
     host_reset_obs(*h, m);
 
     const size_t es = (size_t)elem_size(h);
@@ -874,6 +1097,22 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
     if (hipMalloc((void **)&h->sw, (size_t)h->n) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(sw) failed"));
     if (hipMalloc((void **)&h->err, sizeof(uint32_t)) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(err) failed"));
     if (hipMalloc(&h->reset_obs_dev, es * GEMX_MAX_OUT) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(reset_obs) failed"));
+    if (hipMalloc(&h->cw_dev, es * 2 * GEMX_MAX_OUT) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(cw) failed"));
+    {
+        double wd[2 * GEMX_MAX_OUT];
+        float wf[2 * GEMX_MAX_OUT];
+        for (int i = 0; i < GEMX_MAX_OUT; ++i) {
+            wd[i] = (double)((cfg->limit_mask >> i) & 1u);
+            wd[GEMX_MAX_OUT + i] = (double)((cfg->squared_mask >> i) & 1u);
+            wf[i] = (float)wd[i];
+            wf[GEMX_MAX_OUT + i] = (float)wd[GEMX_MAX_OUT + i];
+        }
+        const void *src = cfg->dtype == GEMX_F64 ? (const void *)wd : (const void *)wf;
+        if (hipMemcpy(h->cw_dev, src, es * 2 * GEMX_MAX_OUT, hipMemcpyHostToDevice) != hipSuccess)
+            return cleanup(fail(GEMX_ERR_DEVICE, "hipMemcpy failed"));
+    }
+    fill_params<float>(*h, m, pole, h->pf);
+    fill_params<double>(*h, m, pole, h->pd);
     if (hipMemset(h->sw, 0, (size_t)h->n) != hipSuccess || hipMemset(h->err, 0, sizeof(uint32_t)) != hipSuccess)
         return cleanup(fail(GEMX_ERR_DEVICE, "hipMemset failed"));
     if (cfg->dtype == GEMX_F64) {
@@ -900,6 +1139,7 @@ int gemx_destroy(gemx_handle *h) {
     if (h->sw) (void)hipFree(h->sw);
     if (h->err) (void)hipFree(h->err);
     if (h->reset_obs_dev) (void)hipFree(h->reset_obs_dev);
+    if (h->cw_dev) (void)hipFree(h->cw_dev);
     delete h;
     return GEMX_OK;
 }
@@ -977,6 +1217,11 @@ int gemx_get_switch_state(gemx_handle *h, uint8_t *out_dev, void *stream) {
 int gemx_set_switch_state(gemx_handle *h, const uint8_t *in_dev, void *stream) {
     if (!h || !in_dev) return fail(GEMX_ERR_ARG, "null argument");
     HIP_TRY(hipMemcpyAsync(h->sw, in_dev, (size_t)h->n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return GEMX_OK;
+}
+int gemx_set_steps_per_block(gemx_handle *h, int32_t steps) {
+    if (!h || steps < 0) return fail(GEMX_ERR_ARG, "invalid argument");
+    h->steps_per_block = steps;
     return GEMX_OK;
 }
 int gemx_error_flags(gemx_handle *h, uint32_t *flags_host, void *stream) {

@@ -127,6 +127,10 @@ int gemx_set_state(gemx_handle *h, const void *soa_in_dev, void *stream);
 int gemx_get_switch_state(gemx_handle *h, uint8_t *out_dev, void *stream);
 int gemx_set_switch_state(gemx_handle *h, const uint8_t *in_dev, void *stream);
 
+/* Tuning: number of control steps whose observations are staged in LDS between global-memory bursts inside
+ * gemx_rollout (0 = heuristic from N, S_out and the LDS size; also settable with env GEMX_STEPS_PER_BLOCK). */
+int gemx_set_steps_per_block(gemx_handle *h, int32_t steps);
+
 /* Sticky device error word (synchronises `stream`): bit 0 = a discrete action outside 0..7 was seen (the
  * reference asserts action_space.contains(action), converters.py:204-206; the kernel masks it to 0..7). */
 int gemx_error_flags(gemx_handle *h, uint32_t *flags_host, void *stream);
