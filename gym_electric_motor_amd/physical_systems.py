@@ -115,7 +115,12 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         self._device = int(device)
         self._dtype_name = {"float32": "float32", "float64": "float64", "f32": "float32", "f64": "float64"}[str(dtype).replace("torch.", "")]
         self._obs_layout = obs_layout
-        self._mechanical_load.set_j_rotor(self._electrical_motor.motor_parameter["j_rotor"])  # line 83
+        # line 83: load.set_j_rotor(j_rotor).  The reference's set_j_rotor ADDS to j_total (mechanical_load.py:188-193),
+        # so a load instance that already served another SCMLSystem must not be bumped a second time.
+        j_rotor = self._electrical_motor.motor_parameter["j_rotor"]
+        j_load = getattr(self._mechanical_load, "_j_load", None)
+        if j_load is None or abs(self._mechanical_load.j_total - (j_load + j_rotor)) > 1e-15 * max(1.0, abs(j_load + j_rotor)):
+            self._mechanical_load.set_j_rotor(j_rotor)
         state_names = self._build_state_names()
         self._set_indices()
         # PhysicalSystem.__init__ (core.py:662-676)

@@ -133,3 +133,57 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp")):
                 src = open(os.path.join(root, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "gemx_oracle" not in src, f
+
+
+REF_SRC = "/root/reference/src"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="reference tree only exists in the build container")
+def test_drops_into_unmodified_reference_env_shell_with_reference_components():
+    """reference component INSTANCES + the reference's ElectricMotorEnvironment around the batched
+    system (host-side wiring only here: the build container has no GPU, the GPU box has no reference).  Runs in a
+    subprocess so the reference / gymnasium stand-in imports do not leak into this test session."""
+    import subprocess
+    import sys
+
+    code = r'''
+import os, sys
+os.environ["MPLBACKEND"] = "Agg"
+sys.path[:0] = [%r, %r, %r]
+import numpy as np
+import gym_electric_motor as gem
+from gym_electric_motor.core import ElectricMotorEnvironment, PhysicalSystem
+from gym_electric_motor import physical_systems as ps, reference_generators as rg, reward_functions as rf
+from gym_electric_motor.constraints import SquaredConstraint
+import gym_electric_motor_amd as ga
+
+ref_sys = ps.SynchronousMotorSystem(converter=ps.FiniteB6BridgeConverter(), motor=ps.PermanentMagnetSynchronousMotor(),
+    load=ps.ConstantSpeedLoad(omega_fixed=100.0), supply=ps.IdealVoltageSupply(u_nominal=420.0), ode_solver=ps.EulerSolver(), tau=1e-5)
+system = ga.BatchedSynchronousMotorSystem(converter=ps.FiniteB6BridgeConverter(interlocking_time=1e-6),
+    motor=ps.PermanentMagnetSynchronousMotor(), load=ps.ConstantSpeedLoad(omega_fixed=100.0),
+    supply=ps.IdealVoltageSupply(u_nominal=420.0), ode_solver=ps.EulerSolver(nsteps=2), tau=1e-5, n_envs=1, _defer_create=True)
+assert isinstance(system, PhysicalSystem)
+env = ElectricMotorEnvironment(physical_system=system,
+    reference_generator=rg.WienerProcessReferenceGenerator(reference_state="i_sq"),
+    reward_function=rf.WeightedSumOfErrors(reward_weights=dict(i_sq=1.0)),
+    constraints=(SquaredConstraint(("i_sq", "i_sd")),), visualization=())
+assert env.physical_system is system and env.action_space == ref_sys.action_space
+assert list(system.state_names) == list(ref_sys.state_names)
+assert np.array_equal(system.limits, ref_sys.limits) and np.array_equal(system.nominal_state, ref_sys.nominal_state)
+assert np.array_equal(system.state_space.low, ref_sys.state_space.low) and np.array_equal(system.state_space.high, ref_sys.state_space.high)
+cfg = system._cfg
+assert cfg.solver_kind == 0 and cfg.solver_nsteps == 2 and cfg.interlocking_time == 1e-6 and cfg.converter_kind == 1
+assert np.allclose(np.array(cfg.model).reshape(5, 11)[:3, :7], ref_sys.electrical_motor._model_constants)
+# the three configured ids built from REFERENCE components give the same config as from this package's mirrors
+for eid in ("Cont-CC-PermExDc-v0", "Finite-CC-PMSM-v0", "Cont-SC-SCIM-v0"):
+    renv = gem.make(eid, ode_solver=ps.EulerSolver())
+    rs = renv.physical_system
+    mine = ga.make(eid, n_envs=1, ode_solver=ga.EulerSolver(), _defer_create=True).physical_system
+    cls = type(mine)
+    theirs = cls(converter=rs.converter, motor=rs.electrical_motor, load=rs.mechanical_load, supply=rs.supply,
+                 ode_solver=ps.EulerSolver(), tau=rs.tau, n_envs=1, constraints=mine._constraints, _defer_create=True)
+    assert bytes(theirs._cfg) == bytes(mine._cfg), eid
+print("OK")
+''' % (os.path.join(REPO, "oracle", "gymnasium_standin"), REF_SRC, REPO)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-3000:]
