@@ -1,13 +1,29 @@
-"""Build the in-tree HIP library `libgemx.so` for gfx950 (explicit hipcc, no JIT cache)."""
+"""Build the in-tree HIP library `libgemx.so` for gfx950 (explicit hipcc, no JIT cache).
+
+Sources (gym_electric_motor_amd/csrc):
+    gemx_common.hpp, gemx_kernels.hpp   device templates
+    gemx_inst.hip                       ONE instantiation unit, compiled once per (system, converter, dtype)
+    gemx_capi.hip                       C ABI (include/gemx.h), validation, small kernels, dispatch
+The ten instantiation units + the C-ABI unit are compiled in parallel and linked with `hipcc -shared`.
+"""
+import concurrent.futures as cf
+import hashlib
 import os
 import shutil
 import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG_DIR)
-SRC = os.path.join(PKG_DIR, "csrc", "gemx.hip")
+CSRC = os.path.join(PKG_DIR, "csrc")
+SOURCES = [os.path.join(CSRC, f) for f in ("gemx_common.hpp", "gemx_kernels.hpp", "gemx_inst.hip", "gemx_capi.hip")]
 HEADER = os.path.join(REPO, "include", "gemx.h")
 LIB = os.path.join(PKG_DIR, "libgemx.so")
+OBJ_DIR = os.path.join(PKG_DIR, "build")
+STAMP = os.path.join(OBJ_DIR, "sources.sha256")
+
+# (system_kind, converter_kind) pairs on the accelerated path; each for fp32 (0) and fp64 (1)
+UNITS = [(0, 0), (1, 1), (1, 2), (2, 1), (2, 2)]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC"]
 
 
 def hipcc_path():
@@ -17,20 +33,45 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: cannot build gym_electric_motor_amd/libgemx.so")
 
 
+def _digest():
+    h = hashlib.sha256()
+    for p in SOURCES + [HEADER]:
+        h.update(open(p, "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def is_stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in (SRC, HEADER))
+    return open(STAMP).read().strip() != _digest()
 
 
-def build_library(force=False, verbose=False):
+def build_library(force=False, verbose=False, jobs=None):
     """hipcc --offload-arch=gfx950 -> gym_electric_motor_amd/libgemx.so (cross-compiles without a GPU)."""
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-I" + os.path.join(REPO, "include"),
-           "-shared", "-fPIC", "-o", LIB, SRC]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    hipcc = hipcc_path()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    inc = ["-I" + os.path.join(REPO, "include"), "-I" + CSRC]
+    cmds = []
+    for s, c in UNITS:
+        for f64 in (0, 1):
+            obj = os.path.join(OBJ_DIR, f"gemx_inst_{s}_{c}_{f64}.o")
+            cmds.append((obj, [hipcc] + FLAGS + inc + [f"-DGEMX_INST_SYS={s}", f"-DGEMX_INST_CONV={c}", f"-DGEMX_INST_F64={f64}",
+                                                      "-c", os.path.join(CSRC, "gemx_inst.hip"), "-o", obj]))
+    capi_obj = os.path.join(OBJ_DIR, "gemx_capi.o")
+    cmds.append((capi_obj, [hipcc] + FLAGS + inc + ["-c", os.path.join(CSRC, "gemx_capi.hip"), "-o", capi_obj]))
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    jobs = jobs or min(len(cmds), os.cpu_count() or 4)
+    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+        list(ex.map(lambda oc: run(oc[1]), cmds))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [o for o, _ in cmds])
+    with open(STAMP, "w") as fh:
+        fh.write(_digest())
     return LIB

@@ -1,0 +1,418 @@
+// gemx_capi.hip -- C ABI of libgemx.so (include/gemx.h): handle management, validation, reset / state access
+// kernels, dispatch to the kernel instantiation units (gemx_inst.hip).  No CPU fallback.
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <new>
+
+#include "gemx_common.hpp"
+
+namespace gemx {
+
+// reset: masked envs back to the initial ODE state; optional broadcast of the reset observation
+template <class R>
+__global__ void reset_kernel(R *state, typename Angle<R>::T *angle, const uint8_t *mask, R *obs, int64_t N, int nd, int nout,
+                             int has_angle, int obs_layout, DevParams<R> P, const R *reset_obs) {
+    int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    if (mask != nullptr && mask[env] == 0) return;
+    for (int j = 0; j < nd; ++j) state[(int64_t)j * N + env] = P.init[j];
+    if (has_angle) angle[env] = Angle<R>::from_bits(P.init_angle_rep);
+    if (obs != nullptr) {
+        for (int j = 0; j < nout; ++j) {
+            if (obs_layout == GEMX_OBS_AOS) obs[env * nout + j] = reset_obs[j];
+            else obs[(int64_t)j * N + env] = reset_obs[j];
+        }
+    }
+}
+
+template <class R>
+__global__ void get_state_kernel(const R *state, const typename Angle<R>::T *angle, R *out, int64_t N, int nd, int has_angle) {
+    int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    for (int j = 0; j < nd; ++j) out[(int64_t)j * N + env] = state[(int64_t)j * N + env];
+    if (has_angle) out[(int64_t)nd * N + env] = Angle<R>::to_rad(angle[env]);
+}
+template <class R>
+__global__ void set_state_kernel(R *state, typename Angle<R>::T *angle, const R *in, int64_t N, int nd, int has_angle) {
+    int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    for (int j = 0; j < nd; ++j) state[(int64_t)j * N + env] = in[(int64_t)j * N + env];
+    if (has_angle) angle[env] = Angle<R>::from_rad((double)in[(int64_t)nd * N + env]);
+}
+
+}  // namespace gemx
+
+// =================================================================================================
+// host side: handle, validation, launch
+// =================================================================================================
+using namespace gemx;
+
+static thread_local char g_err[512] = "";
+namespace gemx {
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace gemx
+#define HIP_TRY(x) GEMX_HIP_TRY(x)
+
+// which entries of the reference's model-constant matrix each system uses, in the order of DevParams::m
+static const int DC_IDX[][2] = {{0, 0}, {0, 1}, {0, 2}};
+static const int SYNC_IDX[][2] = {{0, 1}, {0, 3}, {0, 6}, {1, 0}, {1, 2}, {1, 4}, {1, 5}};
+static const int SCIM_IDX[][2] = {{0, 1}, {0, 3}, {0, 6}, {0, 7}, {1, 2}, {1, 4}, {1, 5}, {1, 8},
+                                  {2, 1}, {2, 3}, {2, 6}, {3, 2}, {3, 4}, {3, 5}};
+
+static int pack_model(const gemx_config &c, double *m, double *pole) {
+    const int(*idx)[2];
+    int n, pole_row, rows, cols;
+    switch (c.system_kind) {
+        case GEMX_SYS_DC_PERMEX: idx = DC_IDX; n = 3; pole_row = -1; rows = 1; cols = 3; break;
+        case GEMX_SYS_SYNC: idx = SYNC_IDX; n = 7; pole_row = 2; rows = 3; cols = 7; break;
+        case GEMX_SYS_SCIM: idx = SCIM_IDX; n = 14; pole_row = 4; rows = 5; cols = 9; break;  // u_r columns: zero rotor voltage
+        default: return fail(GEMX_ERR_ARG, "unknown system_kind %d", c.system_kind);
+    }
+    bool used[GEMX_MODEL_ROWS][GEMX_MODEL_COLS] = {};
+    for (int i = 0; i < n; ++i) {
+        m[i] = c.model[idx[i][0] * GEMX_MODEL_COLS + idx[i][1]];
+        used[idx[i][0]][idx[i][1]] = true;
+    }
+    *pole = 0.0;
+    if (pole_row >= 0) {
+        *pole = c.model[pole_row * GEMX_MODEL_COLS + 0];
+        used[pole_row][0] = true;
+    }
+    (void)rows;
+    for (int r = 0; r < GEMX_MODEL_ROWS; ++r)
+        for (int k = 0; k < GEMX_MODEL_COLS; ++k)
+            if (!used[r][k] && !(k >= cols && c.system_kind == GEMX_SYS_SCIM) && c.model[r * GEMX_MODEL_COLS + k] != 0.0)
+                return fail(GEMX_ERR_ARG, "model[%d][%d] = %g is outside the sparsity pattern supported for system_kind %d", r, k,
+                            c.model[r * GEMX_MODEL_COLS + k], c.system_kind);
+    return GEMX_OK;
+}
+
+template <class R> static void fill_params(const gemx_handle &h, const double *m, double pole, DevParams<R> &P) {
+    const gemx_config &c = h.cfg;
+    memset(&P, 0, sizeof(P));
+    for (int i = 0; i < 16; ++i) P.m[i] = (R)m[i];
+    P.tc0 = (R)c.torque_coef[0];
+    P.tc1 = (R)c.torque_coef[1];
+    P.pole = (R)pole;
+    P.inv_j = (R)(c.j_total > 0 ? 1.0 / c.j_total : 0.0);
+    P.la = (R)c.load_a; P.lb = (R)c.load_b; P.lc = (R)c.load_c;
+    // PolynomialStaticLoad.set_j_rotor, polynomial_static_load.py:62-66
+    P.omega_lim = (R)(c.j_total > 0 ? c.load_a / c.j_total * c.tau_decay : 0.0);
+    P.lin_factor = (R)(c.tau_decay > 0 ? c.j_total / c.tau_decay : 0.0);
+    P.u_sup = (R)c.u_nominal;
+    P.il_ratio = (R)(c.interlocking_time / c.tau);
+    P.tau = (R)c.tau;
+    P.t_il = (R)c.interlocking_time;
+    P.inv_ns = (R)(1.0 / c.solver_nsteps);
+    for (int i = 0; i < GEMX_MAX_OUT; ++i) {
+        P.inv_lim[i] = (R)(i < h.nout ? 1.0 / c.limits[i] : 0.0);
+    }
+    P.cw = (const R *)h.cw_dev;
+    for (int i = 0; i < h.nd; ++i) P.init[i] = (R)c.init_state[i];
+    P.init_angle_rep = Angle<R>::to_bits(Angle<R>::from_rad(h.has_angle ? c.init_state[h.nd] : 0.0));
+    P.nsteps = c.solver_nsteps;
+    P.auto_reset = c.auto_reset;
+    P.obs_layout = c.obs_layout;
+    // the env's default constraint gets the 3-instruction fast path (Stepper::default_done)
+    const uint32_t def_limit = c.system_kind == GEMX_SYS_DC_PERMEX ? (1u << 2) : 0u;
+    const uint32_t def_sq = c.system_kind == GEMX_SYS_DC_PERMEX ? 0u : ((1u << 5) | (1u << 6));
+    if (c.limit_mask == 0 && c.squared_mask == 0) P.constr_kind = 0;
+    else if (c.limit_mask == def_limit && c.squared_mask == def_sq) P.constr_kind = 1;
+    else P.constr_kind = 2;
+}
+
+// reset observation in fp64 on the host (SCMLSystem.reset 256-287, SynchronousMotorSystem.reset 527-561,
+// SquirrelCageInductionMotorSystem.reset 816-847) for the constant initial state
+static void host_reset_obs(gemx_handle &h, const double *m) {
+    (void)m;
+    const gemx_config &c = h.cfg;
+    double *o = h.reset_obs;
+    const double *y = c.init_state;
+    const double us = c.u_nominal;
+    memset(o, 0, sizeof(double) * GEMX_MAX_OUT);
+    auto T32 = [](double al, double be, double *abc) {
+        abc[0] = al; abc[1] = -0.5 * al + 0.5 * sqrt(3.0) * be; abc[2] = -0.5 * al - 0.5 * sqrt(3.0) * be;
+    };
+    auto T23 = [](const double *abc, double *ab) {
+        ab[0] = 2.0 / 3.0 * (abc[0] - 0.5 * abc[1] - 0.5 * abc[2]);
+        ab[1] = 2.0 / 3.0 * (0.5 * sqrt(3.0) * abc[1] - 0.5 * sqrt(3.0) * abc[2]);
+    };
+    if (c.system_kind == GEMX_SYS_DC_PERMEX) {
+        o[0] = y[0]; o[1] = c.torque_coef[0] * y[1]; o[2] = y[1]; o[3] = 0.0 * us; o[4] = us;
+    } else {
+        double uabc[3] = {-0.5 * us, -0.5 * us, -0.5 * us}, uab[2], iabc[3], idq[2], udq[2], eps, torque, cs, sn;
+        T23(uabc, uab);
+        if (c.system_kind == GEMX_SYS_SYNC) {
+            eps = y[3];
+            cs = cos(eps); sn = sin(eps);
+            torque = (c.torque_coef[0] + c.torque_coef[1] * y[1]) * y[2];
+            idq[0] = y[1]; idq[1] = y[2];
+            T32(cs * y[1] - sn * y[2], sn * y[1] + cs * y[2], iabc);
+        } else {
+            eps = y[5];
+            double efs = atan2(y[4], y[3]);
+            cs = cos(efs); sn = sin(efs);
+            torque = c.torque_coef[0] * (y[3] * y[2] - y[4] * y[1]);
+            idq[0] = cs * y[1] + sn * y[2]; idq[1] = -sn * y[1] + cs * y[2];
+            T32(y[1], y[2], iabc);
+        }
+        udq[0] = cs * uab[0] + sn * uab[1]; udq[1] = -sn * uab[0] + cs * uab[1];
+        if (eps > kPi) eps -= kTwoPi;
+        o[0] = y[0]; o[1] = torque; o[2] = iabc[0]; o[3] = iabc[1]; o[4] = iabc[2]; o[5] = idq[0]; o[6] = idq[1];
+        o[7] = uabc[0]; o[8] = uabc[1]; o[9] = uabc[2]; o[10] = udq[0]; o[11] = udq[1]; o[12] = eps; o[13] = us;
+    }
+    for (int i = 0; i < h.nout; ++i) o[i] /= c.limits[i];
+}
+
+template <class R> static int launch_reset(gemx_handle *h, const uint8_t *mask, void *obs, hipStream_t st) {
+    using AngT = typename Angle<R>::T;
+    const DevParams<R> &P = params_of<R>(h);
+    int64_t blocks = (h->n + 255) / 256;
+    hipLaunchKernelGGL(reset_kernel<R>, dim3((unsigned)blocks), dim3(256), 0, st, (R *)h->state, (AngT *)h->angle, mask, (R *)obs, h->n,
+                       h->nd, h->nout, h->has_angle, h->cfg.obs_layout, P, (const R *)h->reset_obs_dev);
+    HIP_TRY(hipGetLastError());
+    return GEMX_OK;
+}
+
+namespace gemx {
+#define GEMX_DECL_UNIT(S, C, F) int launch_unit_##S##_##C##_##F(gemx_handle *, const void *, int, void *, uint8_t *, int, hipStream_t);
+GEMX_DECL_UNIT(0, 0, 0) GEMX_DECL_UNIT(0, 0, 1)
+GEMX_DECL_UNIT(1, 1, 0) GEMX_DECL_UNIT(1, 1, 1)
+GEMX_DECL_UNIT(1, 2, 0) GEMX_DECL_UNIT(1, 2, 1)
+GEMX_DECL_UNIT(2, 1, 0) GEMX_DECL_UNIT(2, 1, 1)
+GEMX_DECL_UNIT(2, 2, 0) GEMX_DECL_UNIT(2, 2, 1)
+#undef GEMX_DECL_UNIT
+}  // namespace gemx
+
+static int launch_advance(gemx_handle *h, const void *actions, int K, void *obs, uint8_t *done, int obs_every, hipStream_t st) {
+    const int s = h->cfg.system_kind, c = h->cfg.converter_kind, f = h->cfg.dtype == GEMX_F64;
+#define GEMX_UNIT(S, C)                                                                                     \
+    if (s == S && c == C)                                                                                   \
+        return f ? gemx::launch_unit_##S##_##C##_1(h, actions, K, obs, done, obs_every, st)                 \
+                 : gemx::launch_unit_##S##_##C##_0(h, actions, K, obs, done, obs_every, st);
+    GEMX_UNIT(0, 0) GEMX_UNIT(1, 1) GEMX_UNIT(1, 2) GEMX_UNIT(2, 1) GEMX_UNIT(2, 2)
+#undef GEMX_UNIT
+    return fail(GEMX_ERR_ARG, "unsupported system/converter combination %d/%d", s, c);
+}
+
+static int elem_size(const gemx_handle *h) { return h->cfg.dtype == GEMX_F64 ? 8 : 4; }
+
+extern "C" {
+
+int gemx_abi_version(void) { return GEMX_ABI_VERSION; }
+int gemx_sizeof_config(void) { return (int)sizeof(gemx_config); }
+const char *gemx_last_error(void) { return g_err; }
+
+int gemx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle **out) {
+    if (!cfg || !out) return fail(GEMX_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(gemx_config) || cfg->abi_version != GEMX_ABI_VERSION)
+        return fail(GEMX_ERR_ARG, "gemx_config ABI mismatch (struct_size %d vs %d, abi %d vs %d)", cfg->struct_size,
+                    (int)sizeof(gemx_config), cfg->abi_version, GEMX_ABI_VERSION);
+    if (n_envs <= 0) return fail(GEMX_ERR_ARG, "n_envs must be positive");
+    if (!(cfg->tau > 0)) return fail(GEMX_ERR_ARG, "tau must be positive");
+    if (cfg->interlocking_time < 0 || cfg->interlocking_time >= cfg->tau)
+        return fail(GEMX_ERR_ARG, "interlocking_time must be in [0, tau)");
+    if (cfg->solver_kind < GEMX_SOLVER_EULER || cfg->solver_kind > GEMX_SOLVER_DP5) return fail(GEMX_ERR_ARG, "unknown solver_kind");
+    if (cfg->solver_nsteps < 1 || cfg->solver_nsteps > 1024) return fail(GEMX_ERR_ARG, "solver_nsteps must be in [1, 1024]");
+    if (cfg->dtype != GEMX_F32 && cfg->dtype != GEMX_F64) return fail(GEMX_ERR_ARG, "unknown dtype");
+    if (cfg->obs_layout != GEMX_OBS_AOS && cfg->obs_layout != GEMX_OBS_SOA) return fail(GEMX_ERR_ARG, "unknown obs_layout");
+    if (cfg->load_kind != GEMX_LOAD_CONST_SPEED && cfg->load_kind != GEMX_LOAD_POLY_STATIC) return fail(GEMX_ERR_ARG, "unknown load_kind");
+    if (cfg->load_kind == GEMX_LOAD_POLY_STATIC && !(cfg->j_total > 0 && cfg->tau_decay > 0))
+        return fail(GEMX_ERR_ARG, "PolynomialStaticLoad needs j_total > 0 and tau_decay > 0");
+    const int s = cfg->system_kind, c = cfg->converter_kind;
+    const bool combo = (s == GEMX_SYS_DC_PERMEX && c == GEMX_CONV_CONT_4QC) ||
+                       ((s == GEMX_SYS_SYNC || s == GEMX_SYS_SCIM) && (c == GEMX_CONV_FINITE_B6 || c == GEMX_CONV_CONT_B6));
+    if (!combo) return fail(GEMX_ERR_ARG, "unsupported system/converter combination %d/%d", s, c);
+
+    gemx_handle *h = new (std::nothrow) gemx_handle();
+    if (!h) return fail(GEMX_ERR_ALLOC, "out of host memory");
+    h->cfg = *cfg;
+    h->n = n_envs;
+    h->device = device;
+    h->nd = s == GEMX_SYS_DC_PERMEX ? 2 : (s == GEMX_SYS_SYNC ? 3 : 5);
+    h->nout = s == GEMX_SYS_DC_PERMEX ? 5 : 14;
+    h->has_angle = s != GEMX_SYS_DC_PERMEX;
+    h->nact = c == GEMX_CONV_CONT_B6 ? 3 : 1;
+    for (int i = 0; i < h->nout; ++i)
+        if (!(cfg->limits[i] > 0)) { delete h; return fail(GEMX_ERR_ARG, "limits[%d] must be positive", i); }
+    if ((cfg->limit_mask | cfg->squared_mask) >> h->nout) { delete h; return fail(GEMX_ERR_ARG, "constraint mask has bits beyond S_out=%d", h->nout); }
+
+    double m[16] = {0}, pole = 0;
+    int rc = pack_model(*cfg, m, &pole);
+    if (rc != GEMX_OK) { delete h; return rc; }
+
+    // all argument validation is done; from here on a device is required
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        delete h;
+        return fail(GEMX_ERR_DEVICE, "no HIP device visible: the gemx stepper has no CPU fallback");
+    }
+    if (device < 0 || device >= ndev) { delete h; return fail(GEMX_ERR_ARG, "device %d out of range (0..%d)", device, ndev - 1); }
+    if (hipSetDevice(device) != hipSuccess) { delete h; return fail(GEMX_ERR_DEVICE, "hipSetDevice(%d) failed", device); }
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+            if (prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
+            if (prop.sharedMemPerBlock >= 64 * 1024) h->lds_max = prop.sharedMemPerBlock;
+        }
+        const char *ev = getenv("GEMX_STEPS_PER_BLOCK");
+        if (ev) h->steps_per_block = atoi(ev);
+    }
+    host_reset_obs(*h, m);
+
+    const size_t es = (size_t)elem_size(h);
+    auto cleanup = [&](int code) { gemx_destroy(h); return code; };
+    if (hipMalloc(&h->state, es * h->nd * (size_t)h->n) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(state) failed"));
+    if (h->has_angle && hipMalloc(&h->angle, (cfg->dtype == GEMX_F64 ? 8 : 4) * (size_t)h->n) != hipSuccess)
+        return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(angle) failed"));
+    if (hipMalloc((void **)&h->sw, (size_t)h->n) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(sw) failed"));
+    if (hipMalloc((void **)&h->err, sizeof(uint32_t)) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(err) failed"));
+    if (hipMalloc(&h->reset_obs_dev, es * GEMX_MAX_OUT) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(reset_obs) failed"));
+    if (hipMalloc(&h->cw_dev, es * 2 * GEMX_MAX_OUT) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(cw) failed"));
+    {
+        double wd[2 * GEMX_MAX_OUT];
+        float wf[2 * GEMX_MAX_OUT];
+        for (int i = 0; i < GEMX_MAX_OUT; ++i) {
+            wd[i] = (double)((cfg->limit_mask >> i) & 1u);
+            wd[GEMX_MAX_OUT + i] = (double)((cfg->squared_mask >> i) & 1u);
+            wf[i] = (float)wd[i];
+            wf[GEMX_MAX_OUT + i] = (float)wd[GEMX_MAX_OUT + i];
+        }
+        const void *src = cfg->dtype == GEMX_F64 ? (const void *)wd : (const void *)wf;
+        if (hipMemcpy(h->cw_dev, src, es * 2 * GEMX_MAX_OUT, hipMemcpyHostToDevice) != hipSuccess)
+            return cleanup(fail(GEMX_ERR_DEVICE, "hipMemcpy failed"));
+    }
+    fill_params<float>(*h, m, pole, h->pf);
+    fill_params<double>(*h, m, pole, h->pd);
+    if (hipMemset(h->sw, 0, (size_t)h->n) != hipSuccess || hipMemset(h->err, 0, sizeof(uint32_t)) != hipSuccess)
+        return cleanup(fail(GEMX_ERR_DEVICE, "hipMemset failed"));
+    if (cfg->dtype == GEMX_F64) {
+        if (hipMemcpy(h->reset_obs_dev, h->reset_obs, sizeof(double) * GEMX_MAX_OUT, hipMemcpyHostToDevice) != hipSuccess)
+            return cleanup(fail(GEMX_ERR_DEVICE, "hipMemcpy failed"));
+    } else {
+        float tmp[GEMX_MAX_OUT];
+        for (int i = 0; i < GEMX_MAX_OUT; ++i) tmp[i] = (float)h->reset_obs[i];
+        if (hipMemcpy(h->reset_obs_dev, tmp, sizeof(tmp), hipMemcpyHostToDevice) != hipSuccess)
+            return cleanup(fail(GEMX_ERR_DEVICE, "hipMemcpy failed"));
+    }
+    rc = gemx_reset(h, nullptr, nullptr, nullptr);
+    if (rc != GEMX_OK) return cleanup(rc);
+    if (hipDeviceSynchronize() != hipSuccess) return cleanup(fail(GEMX_ERR_DEVICE, "hipDeviceSynchronize failed"));
+    *out = h;
+    return GEMX_OK;
+}
+
+int gemx_destroy(gemx_handle *h) {
+    if (!h) return GEMX_OK;
+    (void)hipSetDevice(h->device);
+    if (h->state) (void)hipFree(h->state);
+    if (h->angle) (void)hipFree(h->angle);
+    if (h->sw) (void)hipFree(h->sw);
+    if (h->err) (void)hipFree(h->err);
+    if (h->reset_obs_dev) (void)hipFree(h->reset_obs_dev);
+    if (h->cw_dev) (void)hipFree(h->cw_dev);
+    delete h;
+    return GEMX_OK;
+}
+
+int gemx_n_envs(const gemx_handle *h, int64_t *n) {
+    if (!h || !n) return fail(GEMX_ERR_ARG, "null argument");
+    *n = h->n;
+    return GEMX_OK;
+}
+int gemx_n_ode(const gemx_handle *h) { return h ? h->nd + h->has_angle : GEMX_ERR_ARG; }
+int gemx_n_out(const gemx_handle *h) { return h ? h->nout : GEMX_ERR_ARG; }
+int gemx_n_action(const gemx_handle *h) { return h ? h->nact : GEMX_ERR_ARG; }
+int gemx_action_itemsize(const gemx_handle *h) {
+    if (!h) return GEMX_ERR_ARG;
+    return h->cfg.converter_kind == GEMX_CONV_FINITE_B6 ? 1 : elem_size(h);
+}
+int gemx_reset_observation(const gemx_handle *h, double *obs_host) {
+    if (!h || !obs_host) return fail(GEMX_ERR_ARG, "null argument");
+    memcpy(obs_host, h->reset_obs, sizeof(double) * h->nout);
+    return GEMX_OK;
+}
+
+int gemx_reset(gemx_handle *h, const uint8_t *mask_dev, void *obs_out_dev, void *stream) {
+    if (!h) return fail(GEMX_ERR_ARG, "null handle");
+    hipStream_t st = (hipStream_t)stream;
+    return h->cfg.dtype == GEMX_F64 ? launch_reset<double>(h, mask_dev, obs_out_dev, st) : launch_reset<float>(h, mask_dev, obs_out_dev, st);
+}
+
+int gemx_rollout(gemx_handle *h, const void *actions_dev, int32_t K, void *obs_out_dev, uint8_t *done_out_dev, int32_t obs_every,
+                 void *stream) {
+    if (!h) return fail(GEMX_ERR_ARG, "null handle");
+    if (!actions_dev || !obs_out_dev) return fail(GEMX_ERR_ARG, "actions_dev and obs_out_dev must not be null");
+    if (K < 1) return fail(GEMX_ERR_ARG, "K must be >= 1");
+    if (((uintptr_t)obs_out_dev & 15u) != 0) return fail(GEMX_ERR_ARG, "obs_out_dev must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    return launch_advance(h, actions_dev, K, obs_out_dev, done_out_dev, obs_every ? 1 : 0, st);
+}
+
+int gemx_step(gemx_handle *h, const void *actions_dev, void *obs_out_dev, uint8_t *done_out_dev, void *stream) {
+    return gemx_rollout(h, actions_dev, 1, obs_out_dev, done_out_dev, 1, stream);
+}
+
+int gemx_get_state(gemx_handle *h, void *soa_out_dev, void *stream) {
+    if (!h || !soa_out_dev) return fail(GEMX_ERR_ARG, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t blocks = (h->n + 255) / 256;
+    if (h->cfg.dtype == GEMX_F64)
+        hipLaunchKernelGGL(get_state_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st, (const double *)h->state, (const double *)h->angle,
+                           (double *)soa_out_dev, h->n, h->nd, h->has_angle);
+    else
+        hipLaunchKernelGGL(get_state_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)h->state, (const int32_t *)h->angle,
+                           (float *)soa_out_dev, h->n, h->nd, h->has_angle);
+    HIP_TRY(hipGetLastError());
+    return GEMX_OK;
+}
+int gemx_set_state(gemx_handle *h, const void *soa_in_dev, void *stream) {
+    if (!h || !soa_in_dev) return fail(GEMX_ERR_ARG, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t blocks = (h->n + 255) / 256;
+    if (h->cfg.dtype == GEMX_F64)
+        hipLaunchKernelGGL(set_state_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st, (double *)h->state, (double *)h->angle,
+                           (const double *)soa_in_dev, h->n, h->nd, h->has_angle);
+    else
+        hipLaunchKernelGGL(set_state_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (float *)h->state, (int32_t *)h->angle,
+                           (const float *)soa_in_dev, h->n, h->nd, h->has_angle);
+    HIP_TRY(hipGetLastError());
+    return GEMX_OK;
+}
+int gemx_get_switch_state(gemx_handle *h, uint8_t *out_dev, void *stream) {
+    if (!h || !out_dev) return fail(GEMX_ERR_ARG, "null argument");
+    HIP_TRY(hipMemcpyAsync(out_dev, h->sw, (size_t)h->n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return GEMX_OK;
+}
+int gemx_set_switch_state(gemx_handle *h, const uint8_t *in_dev, void *stream) {
+    if (!h || !in_dev) return fail(GEMX_ERR_ARG, "null argument");
+    HIP_TRY(hipMemcpyAsync(h->sw, in_dev, (size_t)h->n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return GEMX_OK;
+}
+int gemx_set_steps_per_block(gemx_handle *h, int32_t steps) {
+    if (!h || steps < 0) return fail(GEMX_ERR_ARG, "invalid argument");
+    h->steps_per_block = steps;
+    return GEMX_OK;
+}
+int gemx_error_flags(gemx_handle *h, uint32_t *flags_host, void *stream) {
+    if (!h || !flags_host) return fail(GEMX_ERR_ARG, "null argument");
+    HIP_TRY(hipMemcpyAsync(flags_host, h->err, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return GEMX_OK;
+}
+
+}  // extern "C"

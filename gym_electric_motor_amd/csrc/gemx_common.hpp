@@ -1,0 +1,193 @@
+// gemx_common.hpp -- types shared by the kernel instantiation units and the C-ABI unit of libgemx.so.
+// See gemx_kernels.hpp for the design notes.  gfx950 only; no CPU fallback anywhere in the product.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <type_traits>
+
+#include "gemx.h"
+
+namespace gemx {
+
+constexpr int BLOCK = 64;  // one wavefront per workgroup (gfx950 wave64)
+constexpr double kTwoPi = 6.283185307179586476925286766559;
+constexpr double kPi = 3.141592653589793238462643383279;
+
+// ------------------------------------------------------------------------------------------------
+// compile-time system traits
+// ------------------------------------------------------------------------------------------------
+template <int SYS> struct SysTraits;
+template <> struct SysTraits<GEMX_SYS_DC_PERMEX> { static constexpr int ND = 2, NOUT = 5, HAS_ANGLE = 0; };   // omega, i
+template <> struct SysTraits<GEMX_SYS_SYNC>      { static constexpr int ND = 3, NOUT = 14, HAS_ANGLE = 1; };  // omega, i_sd, i_sq (+eps)
+template <> struct SysTraits<GEMX_SYS_SCIM>      { static constexpr int ND = 5, NOUT = 14, HAS_ANGLE = 1; };  // omega, i_sa, i_sb, psi_ra, psi_rb (+eps)
+
+template <int CONV> struct ConvTraits;
+template <> struct ConvTraits<GEMX_CONV_CONT_4QC>  { static constexpr int NACT = 1, DISCRETE = 0; };
+template <> struct ConvTraits<GEMX_CONV_FINITE_B6> { static constexpr int NACT = 1, DISCRETE = 1; };
+template <> struct ConvTraits<GEMX_CONV_CONT_B6>   { static constexpr int NACT = 3, DISCRETE = 0; };
+
+// ------------------------------------------------------------------------------------------------
+// uniform parameters (kernel argument, by value -> SGPRs)
+// ------------------------------------------------------------------------------------------------
+template <class R> struct DevParams {
+    R m[16];      // non-zero entries of motor._model_constants, see pack_model()
+    R tc0, tc1;   // torque coefficients
+    R pole;       // d(eps)/dt = pole * omega
+    R inv_j, la, lb, lc, omega_lim, lin_factor;  // PolynomialStaticLoad
+    R u_sup;      // IdealVoltageSupply
+    R il_ratio;   // interlocking_time / tau (continuous converters)
+    R tau, t_il;  // control step, dead time
+    R inv_ns;     // 1 / solver_nsteps
+    R inv_lim[GEMX_MAX_OUT];
+    R init[GEMX_MAX_ODE];  // [omega, motor states...] (angle separately)
+    const R *cw;           // device array [2][GEMX_MAX_OUT]: generic constraint path 0/1 weights (limit | squared)
+    int64_t init_angle_rep; // initial angle in Angle<R>::T representation (bit pattern)
+    int32_t nsteps, auto_reset, obs_layout;
+    int32_t constr_kind;    // 0 none, 1 the system's default constraint (fast path), 2 generic weights
+};
+
+// ------------------------------------------------------------------------------------------------
+// angle representation
+// ------------------------------------------------------------------------------------------------
+template <class R> struct Angle;
+
+template <> struct Angle<float> {
+    using T = int32_t;  // 2*pi / 2^32 rad per count, wraps by integer overflow
+    static constexpr float kCountsPerRad = 683565275.57643158978229477811f;  // 2^32 / (2 pi)
+    static constexpr float kRadPerCount = 1.4629180792671596e-9f;            // 2 pi / 2^32
+    static __host__ __device__ T from_rad(double a) {
+        double t = a / kTwoPi;
+        t -= floor(t + 0.5);  // [-0.5, 0.5)
+        long long c = llrint(t * 4294967296.0);
+        return (T)(uint32_t)(unsigned long long)c;
+    }
+    static __host__ __device__ T from_bits(int64_t b) { return (T)(int32_t)b; }
+    static __host__ int64_t to_bits(T a) { return (int64_t)a; }
+    static __device__ __forceinline__ T advance(T a, float d_rad) {
+        int32_t inc = __float2int_rn(d_rad * kCountsPerRad);
+        return (T)((uint32_t)a + (uint32_t)inc);
+    }
+    static __device__ __forceinline__ float wrapped(T a) { return (float)a * kRadPerCount; }  // [-pi, pi]
+    static __device__ __forceinline__ float to_rad(T a) { return wrapped(a); }
+    // sin/cos of a fixed-point angle: quadrant from the top bits, Cephes single-precision minimax
+    // polynomials on [-pi/4, pi/4] (abs error < 1.2e-7); ~20 VALU ops for both, no range-reduction branches.
+    static __device__ __forceinline__ void sincos(T a, float &s, float &c) {
+        uint32_t ua = (uint32_t)a + 0x20000000u;                    // + 1/8 turn
+        uint32_t q = ua >> 30;                                      // quadrant 0..3
+        int32_t r = (int32_t)(ua & 0x3FFFFFFFu) - 0x20000000;       // [-2^29, 2^29) counts == [-pi/4, pi/4)
+        float x = (float)r * kRadPerCount;
+        float z = x * x;
+        float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, x, x);
+        float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                        fmaf(-0.5f, z, 1.0f));
+        float s1 = (q & 1u) ? cp : sp;
+        float c1 = (q & 1u) ? sp : cp;
+        s = (q & 2u) ? -s1 : s1;
+        c = ((q + 1u) & 2u) ? -c1 : c1;
+    }
+};
+
+template <> struct Angle<double> {
+    using T = double;  // unwrapped radians, exactly as the reference integrates it
+    static __host__ __device__ T from_rad(double a) { return a; }
+    static __host__ __device__ T from_bits(int64_t b) { T r; memcpy(&r, &b, 8); return r; }
+    static __host__ int64_t to_bits(T a) { int64_t b; memcpy(&b, &a, 8); return b; }
+    static __device__ __forceinline__ T advance(T a, double d) { return a + d; }
+    static __device__ __forceinline__ double wrapped(T a) {  // physical_systems.py:520-522
+        double e = fmod(a, kTwoPi);
+        if (e < 0) e += kTwoPi;
+        if (e > kPi) e -= kTwoPi;
+        return e;
+    }
+    static __device__ __forceinline__ double to_rad(T a) { return a; }
+    static __device__ __forceinline__ void sincos(T a, double &s, double &c) { ::sincos(a, &s, &c); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// small math helpers
+// ------------------------------------------------------------------------------------------------
+template <class R> __device__ __forceinline__ R clip01(R x) { return fmin(fmax(x, R(0)), R(1)); }
+template <class R> __device__ __forceinline__ R sgn(R x) { return x > R(0) ? R(1) : (x < R(0) ? R(-1) : R(0)); }  // np.sign
+
+// Clarke / inverse Clarke (three_phase_motor.py:18-28, 31-54) and Park rotation (56-88)
+template <class R> __device__ __forceinline__ void t23(R a, R b, R c, R &al, R &be) {
+    al = R(2.0 / 3.0) * (a - R(0.5) * b - R(0.5) * c);
+    be = R(0.57735026918962576451) * (b - c);  // 2/3 * sqrt(3)/2
+}
+template <class R> __device__ __forceinline__ void t32(R al, R be, R &a, R &b, R &c) {
+    const R h = R(0.86602540378443864676) * be;
+    a = al;
+    b = R(-0.5) * al + h;
+    c = R(-0.5) * al - h;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// kernel arguments
+// ------------------------------------------------------------------------------------------------
+template <class R> struct KArgs {
+    DevParams<R> P;
+    R *state;                       // [ND][N]
+    typename Angle<R>::T *angle;    // [N] (systems with an angle)
+    uint8_t *sw;                    // [N] packed leg states (Finite-B6C with interlocking)
+    const unsigned char *actions;   // [K][N][A] R  |  [K][N] uint8
+    R *obs;                         // [K][N][NOUT] | [K][NOUT][N]  (or a single step's worth if !obs_every)
+    uint8_t *done;                  // [K][N] | [N]
+    uint32_t *err;                  // device error word (bit 0: discrete action out of range)
+    int64_t N;
+    int32_t K, obs_every;
+    int32_t S;                      // control steps per I/O block (LDS ring depth)
+    int32_t coop;                   // 1: action rows / done rows of full blocks are 16-byte aligned -> cooperative staging
+    int32_t obs_vec;                // 1: observation rows of full blocks are 16-byte aligned -> 16-byte stores
+};
+
+constexpr int MAX_ACT_CHUNKS = 12;  // upper bound of 16-byte chunks of staged actions per lane and I/O block
+constexpr int MAX_STEPS_PER_BLOCK = 32;
+// chunks per lane needed to stage MAX_STEPS_PER_BLOCK steps of a row made of `cpr` 16-byte chunks
+__host__ __device__ constexpr int act_chunks(int cpr) {
+    return (MAX_STEPS_PER_BLOCK * cpr + BLOCK - 1) / BLOCK < MAX_ACT_CHUNKS ? (MAX_STEPS_PER_BLOCK * cpr + BLOCK - 1) / BLOCK : MAX_ACT_CHUNKS;
+}
+
+}  // namespace gemx
+
+// ------------------------------------------------------------------------------------------------
+// host-side handle (shared by gemx_capi.hip and the instantiation units)
+// ------------------------------------------------------------------------------------------------
+struct gemx_handle {
+    gemx_config cfg;
+    int64_t n;
+    int device;
+    int nd, nout, nact, has_angle;
+    gemx::DevParams<float> pf;
+    gemx::DevParams<double> pd;
+    void *state = nullptr;   // [nd][n] R
+    void *angle = nullptr;   // [n] int32 | double
+    uint8_t *sw = nullptr;   // [n]
+    uint32_t *err = nullptr;
+    void *reset_obs_dev = nullptr;  // [nout] R
+    void *cw_dev = nullptr;         // [2][GEMX_MAX_OUT] R constraint weights
+    double reset_obs[GEMX_MAX_OUT];
+    int n_cu = 256;
+    size_t lds_max = 160 * 1024;
+    int steps_per_block = 0;  // 0 = heuristic
+};
+
+namespace gemx {
+template <class R> inline const DevParams<R> &params_of(const gemx_handle *h);
+template <> inline const DevParams<float> &params_of<float>(const gemx_handle *h) { return h->pf; }
+template <> inline const DevParams<double> &params_of<double>(const gemx_handle *h) { return h->pd; }
+
+int fail(int code, const char *fmt, ...);  // sets gemx_last_error(); defined in gemx_capi.hip
+
+// one launcher per (system, converter, dtype) instantiation unit; dispatches on load / solver / interlocking
+typedef int (*advance_fn)(gemx_handle *h, const void *actions, int K, void *obs, uint8_t *done, int obs_every, hipStream_t st);
+}  // namespace gemx
+
+#define GEMX_HIP_TRY(x)                                                                                              \
+    do {                                                                                                             \
+        hipError_t _e = (x);                                                                                         \
+        if (_e != hipSuccess) return gemx::fail(GEMX_ERR_DEVICE, "%s failed: %s", #x, hipGetErrorString(_e));        \
+    } while (0)

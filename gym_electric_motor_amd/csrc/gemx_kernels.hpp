@@ -1,0 +1,756 @@
+// gemx_kernels.hpp -- the MI355X (gfx950 / CDNA4) batched SCML physical-system stepper.
+//
+// What it replaces (reference = upb-lea/gym-electric-motor 3.0.2, paths relative to src/gym_electric_motor/):
+//   SCMLSystem.simulate                          physical_systems/physical_systems.py:171-203
+//   SynchronousMotorSystem.simulate              physical_systems/physical_systems.py:487-525
+//   SquirrelCageInductionMotorSystem.simulate    physical_systems/physical_systems.py:771-814
+//   converters / motors / loads / solvers / constraints on that path (cited at each device function).
+//
+// Design (MI355X-first, not a translation of the Python):
+//   * one lane = one env; one 64-lane wavefront = one workgroup; N envs advance in lockstep.
+//   * ODE state lives in HBM as SoA rows [S_ode][N]; in the fused K-step launch it stays in VGPRs between steps,
+//     so a step moves only action-in + observation-out + done.
+//   * all motor/load/converter/limit parameters are uniform across envs -> kernel arguments -> SGPRs (0 HBM bytes
+//     per env, no LDS needed for them).
+//   * LDS is spent where lanes exchange data: observation rows are staged in an LDS ring and flushed in bursts of
+//     16-byte-per-lane stores; the next block's action tile is prefetched cooperatively (see advance_kernel).
+//   * the electrical angle is a 32-bit fixed-point fraction of a turn in the fp32 path (exact wrap, constant
+//     resolution however long the rollout is).
+//   * compile-time specialisation <SYS, CONV, LOAD, SOLVER, IL, R>: a constant-speed load removes the omega
+//     dynamics (per-segment pre-multiplied coefficients, 4 FMAs per PMSM right-hand side); IL = false (no converter
+//     dead time, the default of every reference env) removes the current-sign logic and the second segment.
+//   * no MFMA: ~100-250 VALU ops and 25-117 bytes per env-step; the path is HBM / issue bound.
+#pragma once
+#include "gemx_common.hpp"
+
+namespace gemx {
+
+// ------------------------------------------------------------------------------------------------
+// load: d(omega)/dt (constant_speed_load.py:40-42; polynomial_static_load.py:62-66, 87-99)
+// ------------------------------------------------------------------------------------------------
+template <class R> __device__ __forceinline__ R poly_load_ode(const DevParams<R> &P, R omega, R torque) {
+    R sign = sgn(omega);
+    R a = fabs(omega) > P.omega_lim ? sign * P.la : P.lin_factor * omega;
+    R tl = sign * P.lc * omega * omega + P.lb * omega + a;
+    return (torque - tl) * P.inv_j;
+}
+
+// ------------------------------------------------------------------------------------------------
+// electrical sub-system.  x = motor states without the angle, u = segment-constant input voltage.
+// The reference evaluates matmul(model_constants, feature_vector) (dc_permanently_excited_motor.py:81-84,
+// synchronous_motor.py:143-168, induction_motor.py:187-217 + squirrel_cage_induction_motor.py:121-129); here only
+// the structurally non-zero entries are used (pack_model() rejects a matrix with any other non-zero entry), and
+// everything that depends only on (omega, u) is multiplied out once per call of prep().
+// ------------------------------------------------------------------------------------------------
+template <int SYS, class R> struct Elec;
+
+template <class R> struct Elec<GEMX_SYS_DC_PERMEX, R> {
+    static constexpr int NM = 1;
+    struct Pre { R b; };
+    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[2]) { return Pre{P.m[0] * w + P.m[2] * u[0]}; }
+    static __device__ __forceinline__ void f(const DevParams<R> &P, const Pre &p, const R (&x)[1], R (&dx)[1]) { dx[0] = p.b + P.m[1] * x[0]; }
+    static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[1]) { return P.tc0 * x[0]; }  // line 67-69
+};
+template <class R> struct Elec<GEMX_SYS_SYNC, R> {  // permanent_magnet_synchronous_motor.py:107-119, 134-139
+    static constexpr int NM = 2;
+    struct Pre { R bd, bq, wdq, wqd; };
+    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[2]) {
+        return Pre{P.m[1] * u[0], P.m[3] * w + P.m[5] * u[1], P.m[2] * w, P.m[6] * w};
+    }
+    static __device__ __forceinline__ void f(const DevParams<R> &P, const Pre &p, const R (&x)[2], R (&dx)[2]) {
+        dx[0] = p.bd + P.m[0] * x[0] + p.wdq * x[1];
+        dx[1] = p.bq + P.m[4] * x[1] + p.wqd * x[0];
+    }
+    static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[2]) { return (P.tc0 + P.tc1 * x[0]) * x[1]; }
+};
+template <class R> struct Elec<GEMX_SYS_SCIM, R> {  // induction_motor.py:236-248, 287-312
+    static constexpr int NM = 4;
+    struct Pre { R ba, bb, w2, w6, w10, w13; };
+    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[2]) {
+        return Pre{P.m[3] * u[0], P.m[7] * u[1], P.m[2] * w, P.m[6] * w, P.m[10] * w, P.m[13] * w};
+    }
+    static __device__ __forceinline__ void f(const DevParams<R> &P, const Pre &p, const R (&x)[4], R (&dx)[4]) {
+        dx[0] = p.ba + P.m[0] * x[0] + P.m[1] * x[2] + p.w2 * x[3];
+        dx[1] = p.bb + P.m[4] * x[1] + P.m[5] * x[3] + p.w6 * x[2];
+        dx[2] = P.m[8] * x[0] + P.m[9] * x[2] + p.w10 * x[3];
+        dx[3] = P.m[11] * x[1] + P.m[12] * x[3] + p.w13 * x[2];
+    }
+    static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[4]) { return P.tc0 * (x[2] * x[1] - x[3] * x[0]); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// one explicit Runge-Kutta step of size h for  z' = F(z),  z in R^NZ.  Returns the scheme's quadrature of z[0]
+// (used for the angle when omega = z[0] is dynamic).  SOLVER: Euler (solvers.py:124-136), classical RK4,
+// Dormand-Prince 5th-order solution without error control.
+// ------------------------------------------------------------------------------------------------
+template <int SOLVER, int NZ, class R, class F>
+__device__ __forceinline__ R rk_step(R (&z)[NZ], R h, F &&rhs) {
+    R k1[NZ], zt[NZ];
+    rhs(z, k1);
+    if (SOLVER == GEMX_SOLVER_EULER) {
+        const R q = z[0];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) z[i] = z[i] + k1[i] * h;
+        return q;
+    } else if (SOLVER == GEMX_SOLVER_RK4) {
+        R k2[NZ], k3[NZ], k4[NZ];
+        R q = z[0];
+        const R hh = R(0.5) * h;
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) zt[i] = z[i] + hh * k1[i];
+        rhs(zt, k2);
+        q += R(2) * zt[0];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) zt[i] = z[i] + hh * k2[i];
+        rhs(zt, k3);
+        q += R(2) * zt[0];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) zt[i] = z[i] + h * k3[i];
+        rhs(zt, k4);
+        q += zt[0];
+        const R h6 = h * R(1.0 / 6.0);
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) z[i] = z[i] + h6 * (k1[i] + R(2) * (k2[i] + k3[i]) + k4[i]);
+        return q * R(1.0 / 6.0);
+    } else {
+        R k2[NZ], k3[NZ], k4[NZ], k5[NZ], k6[NZ];
+        R q = R(35.0 / 384.0) * z[0];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) zt[i] = z[i] + h * (R(1.0 / 5.0) * k1[i]);
+        rhs(zt, k2);
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) zt[i] = z[i] + h * (R(3.0 / 40.0) * k1[i] + R(9.0 / 40.0) * k2[i]);
+        rhs(zt, k3);
+        q += R(500.0 / 1113.0) * zt[0];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) zt[i] = z[i] + h * (R(44.0 / 45.0) * k1[i] - R(56.0 / 15.0) * k2[i] + R(32.0 / 9.0) * k3[i]);
+        rhs(zt, k4);
+        q += R(125.0 / 192.0) * zt[0];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i)
+            zt[i] = z[i] + h * (R(19372.0 / 6561.0) * k1[i] - R(25360.0 / 2187.0) * k2[i] + R(64448.0 / 6561.0) * k3[i] -
+                                R(212.0 / 729.0) * k4[i]);
+        rhs(zt, k5);
+        q -= R(2187.0 / 6784.0) * zt[0];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i)
+            zt[i] = z[i] + h * (R(9017.0 / 3168.0) * k1[i] - R(355.0 / 33.0) * k2[i] + R(46732.0 / 5247.0) * k3[i] +
+                                R(49.0 / 176.0) * k4[i] - R(5103.0 / 18656.0) * k5[i]);
+        rhs(zt, k6);
+        q += R(11.0 / 84.0) * zt[0];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i)
+            z[i] = z[i] + h * (R(35.0 / 384.0) * k1[i] + R(500.0 / 1113.0) * k3[i] + R(125.0 / 192.0) * k4[i] -
+                               R(2187.0 / 6784.0) * k5[i] + R(11.0 / 84.0) * k6[i]);
+        return q;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// integrate one segment of length h with `nsteps` sub-steps (EulerSolver(nsteps), solvers.py:103-122).
+// y = [omega, motor states].  Returns the angle increment  pole * int(omega dt)  of the scheme.
+// ------------------------------------------------------------------------------------------------
+template <int SYS, int LOAD, int SOLVER, class R>
+__device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<SYS>::ND], const R (&u)[2], R h) {
+    using E = Elec<SYS, R>;
+    constexpr int NM = E::NM;
+    const int ns = P.nsteps;
+    const R hs = h * P.inv_ns;
+    if (LOAD == GEMX_LOAD_CONST_SPEED) {
+        // omega is constant (constant_speed_load.py:40-42): integrate the electrical states only; every scheme's
+        // quadrature weights sum to one, so the angle increment is exactly pole * omega * h.
+        const typename E::Pre pre = E::prep(P, y[0], u);
+        R x[NM];
+#pragma unroll
+        for (int i = 0; i < NM; ++i) x[i] = y[1 + i];
+        auto rhs = [&](const R (&xx)[NM], R (&dx)[NM]) { E::f(P, pre, xx, dx); };
+        if (ns == 1) {
+            rk_step<SOLVER, NM, R>(x, hs, rhs);
+        } else {
+            for (int s = 0; s < ns; ++s) rk_step<SOLVER, NM, R>(x, hs, rhs);
+        }
+#pragma unroll
+        for (int i = 0; i < NM; ++i) y[1 + i] = x[i];
+        return P.pole * y[0] * h;
+    } else {
+        // SCMLSystem._system_equation (physical_systems.py:205-236): [load derivative, motor derivative]
+        auto rhs = [&](const R (&z)[NM + 1], R (&dz)[NM + 1]) {
+            R x[NM], dx[NM];
+#pragma unroll
+            for (int i = 0; i < NM; ++i) x[i] = z[1 + i];
+            const typename E::Pre pre = E::prep(P, z[0], u);
+            E::f(P, pre, x, dx);
+            dz[0] = poly_load_ode(P, z[0], E::torque(P, x));
+#pragma unroll
+            for (int i = 0; i < NM; ++i) dz[1 + i] = dx[i];
+        };
+        R wsum = R(0);
+        if (ns == 1) {
+            wsum = rk_step<SOLVER, NM + 1, R>(y, hs, rhs);
+        } else {
+            for (int s = 0; s < ns; ++s) wsum += rk_step<SOLVER, NM + 1, R>(y, hs, rhs);
+        }
+        return P.pole * hs * wsum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// converters: phase voltages for one segment
+// ------------------------------------------------------------------------------------------------
+// ContTwoQuadrantConverter via ContDynamicallyAveragedConverter (converters.py:144-158, 177-184, 425-427):
+// clip(duty - sign(i) * t_il / tau, 0, 1).  IL = false: t_il == 0, the current is irrelevant.
+template <bool IL, class R> __device__ __forceinline__ R cont_leg(const DevParams<R> &P, R duty, R i) {
+    if (!IL) return duty;  // duty is already clipped to [0, 1]
+    return clip01(duty - sgn(i) * P.il_ratio);
+}
+// FiniteTwoQuadrantConverter.convert (converters.py:277-285): leg state 1 -> upper rail, 2 -> lower rail, 0 (dead)
+// -> freewheeling diode (upper rail while i < 0).  Branch-free; returns +-0.5 * u_sup.
+template <class R> __device__ __forceinline__ R fin_leg_u(uint32_t st, R i, R half_us) {
+    const bool upper = (st == 1u) | ((st == 0u) & (i < R(0)));
+    return upper ? half_us : -half_us;
+}
+// Finite-B6C action -> per-leg sub-action (1 = upper, 2 = lower), converters.py:788-797, packed 2 bits per leg.
+__device__ __forceinline__ uint32_t b6_subactions(uint32_t a) {
+    return ((a & 4u) ? 1u : 2u) | (((a & 2u) ? 1u : 2u) << 2) | (((a & 1u) ? 1u : 2u) << 4);
+}
+// Interlocking (FiniteTwoQuadrantConverter._set_switching_pattern 300-310 + convert 270-276 as driven by
+// *.simulate(), which passes the segment START time): a leg that changes between upper and lower goes to the
+// dead state 0 for the WHOLE step (two segments [t, t+t_il], [t+t_il, t+tau]) and takes the new state on the
+// next step.  Returns the leg states used during this step; `two` = this env integrates two segments.
+__device__ __forceinline__ uint32_t b6_interlock(uint32_t prev, uint32_t want, bool &two) {
+    uint32_t used = 0;
+    two = false;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        uint32_t s = (prev >> (2 * l)) & 3u, a = (want >> (2 * l)) & 3u;
+        bool trans = (s != 0u) && (a != s);
+        two |= trans;
+        used |= (trans ? 0u : a) << (2 * l);
+    }
+    return used;
+}
+
+// B6 bridges: phase voltages u_a, u_b, u_c [V].  `legs` only matters for Finite-B6C with IL.
+template <int CONV, bool IL, class R>
+__device__ __forceinline__ void b6_voltages(const DevParams<R> &P, const R (&act)[3], uint32_t dact, uint32_t legs, R ia, R ib, R ic,
+                                            R &ua, R &ub, R &uc) {
+    if (CONV == GEMX_CONV_CONT_B6) {  // converters.py:888-903
+        ua = (cont_leg<IL, R>(P, clip01(R(0.5) * (act[0] + R(1))), ia) - R(0.5)) * P.u_sup;
+        ub = (cont_leg<IL, R>(P, clip01(R(0.5) * (act[1] + R(1))), ib) - R(0.5)) * P.u_sup;
+        uc = (cont_leg<IL, R>(P, clip01(R(0.5) * (act[2] + R(1))), ic) - R(0.5)) * P.u_sup;
+    } else {  // converters.py:816-823
+        const R hu = R(0.5) * P.u_sup;
+        if (!IL) {  // every leg follows its sub-action immediately: upper rail iff the action bit is set
+            ua = (dact & 4u) ? hu : -hu;
+            ub = (dact & 2u) ? hu : -hu;
+            uc = (dact & 1u) ? hu : -hu;
+        } else {
+            ua = fin_leg_u<R>(legs & 3u, ia, hu);
+            ub = fin_leg_u<R>((legs >> 2) & 3u, ib, hu);
+            uc = fin_leg_u<R>((legs >> 4) & 3u, ic, hu);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// one control step of one env: advances (y, ang, sw) and fills the normalised observation row.
+// ------------------------------------------------------------------------------------------------
+template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper;
+
+// ---- DcMotorSystem + Cont-4QC (physical_systems.py:171-203; converters.py:481-491) --------------------------
+template <int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_DC_PERMEX, GEMX_CONV_CONT_4QC, LOAD, SOLVER, IL, R> {
+    using AngT = typename Angle<R>::T;
+    static __device__ __forceinline__ void step(const DevParams<R> &P, R (&y)[2], AngT &, uint32_t &, const R (&act)[3],
+                                                uint32_t, R (&obs)[5]) {
+        const R d0 = clip01(R(0.5) * (act[0] + R(1)));
+        const R d1 = clip01(R(-0.5) * (act[0] - R(1)));
+        const R un = cont_leg<IL, R>(P, d0, y[1]) - cont_leg<IL, R>(P, d1, y[1]);  // both sub-converters see the same i (line 483)
+        R u[2] = {un * P.u_sup, R(0)};
+        integrate<GEMX_SYS_DC_PERMEX, LOAD, SOLVER, R>(P, y, u, P.tau);
+        const R x[1] = {y[1]};
+        obs[0] = y[0] * P.inv_lim[0];
+        obs[1] = Elec<GEMX_SYS_DC_PERMEX, R>::torque(P, x) * P.inv_lim[1];
+        obs[2] = y[1] * P.inv_lim[2];
+        obs[3] = u[0] * P.inv_lim[3];
+        obs[4] = P.u_sup * P.inv_lim[4];
+    }
+    // default constraint of the DC envs: LimitConstraint('i') (cont_cc_permex_dc_env.py:104)
+    static __device__ __forceinline__ bool default_done(const R (&obs)[5]) { return fabs(obs[2]) > R(1); }
+};
+
+// ---- SynchronousMotorSystem (physical_systems.py:487-525), control_space 'abc' ---------------------------------
+template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_SYNC, CONV, LOAD, SOLVER, IL, R> {
+    using AngT = typename Angle<R>::T;
+    static __device__ __forceinline__ void step(const DevParams<R> &P, R (&y)[3], AngT &ang, uint32_t &sw, const R (&act)[3],
+                                                uint32_t dact, R (&obs)[14]) {
+        R s, c;
+        Angle<R>::sincos(ang, s, c);
+        uint32_t legs = 0;
+        bool two = false;
+        if (IL && CONV == GEMX_CONV_FINITE_B6) {
+            legs = b6_subactions(dact);
+            if (P.t_il > R(0)) legs = b6_interlock(sw, legs, two);  // converters.py:302: no dead time -> pattern [action]
+            sw = legs;
+        }
+        R ua, ub, uc, u[2];
+        auto segment = [&](R h) {
+            R ia = R(0), ib = R(0), ic = R(0);
+            if (IL) {  // i_in = T32(Q(i_dq, eps)) (line 493/505); only its sign matters (dead legs / cont. interlocking)
+                const R ial = c * y[1] - s * y[2], ibe = s * y[1] + c * y[2];
+                t32(ial, ibe, ia, ib, ic);
+            }
+            b6_voltages<CONV, IL, R>(P, act, dact, legs, ia, ib, ic, ua, ub, uc);
+            R ual, ube;
+            t23(ua, ub, uc, ual, ube);
+            u[0] = c * ual + s * ube;  // Q^-1(., eps): u_dq frozen at the segment-start angle (line 501/511)
+            u[1] = -s * ual + c * ube;
+            const R deps = integrate<GEMX_SYS_SYNC, LOAD, SOLVER, R>(P, y, u, h);
+            ang = Angle<R>::advance(ang, deps);
+        };
+        if (IL) {
+            segment(two ? P.t_il : P.tau);
+            if (two) {  // exec-masked; the whole wave skips it when no lane switches (s_cbranch_execz)
+                Angle<R>::sincos(ang, s, c);  // eps / i_in refreshed at the switching instant (lines 504-505)
+                segment(P.tau - P.t_il);
+            }
+        } else {
+            segment(P.tau);
+        }
+        // outputs: i_abc from the NEW i_dq with the angle of the last segment start (line 519, reference quirk)
+        const R ial = c * y[1] - s * y[2], ibe = s * y[1] + c * y[2];
+        R ia, ib, ic;
+        t32(ial, ibe, ia, ib, ic);
+        const R x[2] = {y[1], y[2]};
+        obs[0] = y[0] * P.inv_lim[0];
+        obs[1] = Elec<GEMX_SYS_SYNC, R>::torque(P, x) * P.inv_lim[1];
+        obs[2] = ia * P.inv_lim[2];
+        obs[3] = ib * P.inv_lim[3];
+        obs[4] = ic * P.inv_lim[4];
+        obs[5] = y[1] * P.inv_lim[5];
+        obs[6] = y[2] * P.inv_lim[6];
+        obs[7] = ua * P.inv_lim[7];
+        obs[8] = ub * P.inv_lim[8];
+        obs[9] = uc * P.inv_lim[9];
+        obs[10] = u[0] * P.inv_lim[10];
+        obs[11] = u[1] * P.inv_lim[11];
+        obs[12] = Angle<R>::wrapped(ang) * P.inv_lim[12];
+        obs[13] = P.u_sup * P.inv_lim[13];
+    }
+    // default constraint: SquaredConstraint(('i_sq','i_sd')) (finite_cc_pmsm_env.py:106)
+    static __device__ __forceinline__ bool default_done(const R (&obs)[14]) { return obs[5] * obs[5] + obs[6] * obs[6] > R(1); }
+};
+
+// ---- SquirrelCageInductionMotorSystem (physical_systems.py:771-814), control_space 'abc' -----------------------
+template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_SCIM, CONV, LOAD, SOLVER, IL, R> {
+    using AngT = typename Angle<R>::T;
+    // cos/sin of the rotor-flux angle eps_fs = atan2(psi_b, psi_a) (calculate_field_angle, 765-769) without atan2
+    static __device__ __forceinline__ void field_angle(R pa, R pb, R &s, R &c) {
+        R n2 = pa * pa + pb * pb;
+        if (n2 < R(1e-30)) { pa *= R(1e18); pb *= R(1e18); n2 = pa * pa + pb * pb; }
+        const R rn = n2 > R(0) ? R(1) / sqrt(n2) : R(0);
+        c = n2 > R(0) ? pa * rn : R(1);  // atan2(0, 0) = 0
+        s = pb * rn;
+    }
+    static __device__ __forceinline__ void step(const DevParams<R> &P, R (&y)[5], AngT &ang, uint32_t &sw, const R (&act)[3],
+                                                uint32_t dact, R (&obs)[14]) {
+        R s, c;
+        field_angle(y[3], y[4], s, c);
+        uint32_t legs = 0;
+        bool two = false;
+        if (IL && CONV == GEMX_CONV_FINITE_B6) {
+            legs = b6_subactions(dact);
+            if (P.t_il > R(0)) legs = b6_interlock(sw, legs, two);  // converters.py:302: no dead time -> pattern [action]
+            sw = legs;
+        }
+        R ua, ub, uc, u[2];
+        auto segment = [&](R h) {
+            R ia = R(0), ib = R(0), ic = R(0);
+            if (IL) t32(y[1], y[2], ia, ib, ic);  // i_in = T32(i_alphabeta) (line 780/792)
+            b6_voltages<CONV, IL, R>(P, act, dact, legs, ia, ib, ic, ua, ub, uc);
+            t23(ua, ub, uc, u[0], u[1]);  // u_alphabeta constant over the segment (line 788/799)
+            const R deps = integrate<GEMX_SYS_SCIM, LOAD, SOLVER, R>(P, y, u, h);
+            ang = Angle<R>::advance(ang, deps);
+        };
+        if (IL) {
+            segment(two ? P.t_il : P.tau);
+            if (two) {
+                field_angle(y[3], y[4], s, c);  // line 791
+                segment(P.tau - P.t_il);
+            }
+        } else {
+            segment(P.tau);
+        }
+        // i_dq = Q^-1(i_alphabeta_new, eps_fs of the last segment start) (line 806, reference quirk);
+        // i_abc = T32(Q(i_dq, eps_fs)) == T32(i_alphabeta_new) (line 807); u_dq = Q^-1(u_alphabeta, eps_fs) (798)
+        R ia, ib, ic;
+        t32(y[1], y[2], ia, ib, ic);
+        const R x[4] = {y[1], y[2], y[3], y[4]};
+        obs[0] = y[0] * P.inv_lim[0];
+        obs[1] = Elec<GEMX_SYS_SCIM, R>::torque(P, x) * P.inv_lim[1];
+        obs[2] = ia * P.inv_lim[2];
+        obs[3] = ib * P.inv_lim[3];
+        obs[4] = ic * P.inv_lim[4];
+        obs[5] = (c * y[1] + s * y[2]) * P.inv_lim[5];
+        obs[6] = (-s * y[1] + c * y[2]) * P.inv_lim[6];
+        obs[7] = ua * P.inv_lim[7];
+        obs[8] = ub * P.inv_lim[8];
+        obs[9] = uc * P.inv_lim[9];
+        obs[10] = (c * u[0] + s * u[1]) * P.inv_lim[10];
+        obs[11] = (-s * u[0] + c * u[1]) * P.inv_lim[11];
+        obs[12] = Angle<R>::wrapped(ang) * P.inv_lim[12];
+        obs[13] = P.u_sup * P.inv_lim[13];
+    }
+    // default constraint: SquaredConstraint(('i_sq','i_sd')) (cont_sc_scim_env.py:111)
+    static __device__ __forceinline__ bool default_done(const R (&obs)[14]) { return obs[5] * obs[5] + obs[6] * obs[6] > R(1); }
+};
+
+// ConstraintMonitor with merge 'max' over LimitConstraint / SquaredConstraint; terminated = violation >= 1
+// (core.py:350, 834-844; constraints.py:55-58, 96-98).  constr_kind is wave-uniform: 0 none, 1 the env's default
+// constraint (3 VALU ops), 2 arbitrary masks as 0/1 weights (branch-free).
+template <class ST, int NOUT, class R> __device__ __forceinline__ bool constraint_done(const DevParams<R> &P, const R (&obs)[NOUT]) {
+    if (P.constr_kind == 0) return false;
+    if (P.constr_kind == 1) return ST::default_done(obs);
+    R lim = R(0), sq = R(0);
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) {
+        lim = fmax(lim, P.cw[i] * fabs(obs[i]));
+        sq += (P.cw[GEMX_MAX_OUT + i] * obs[i]) * obs[i];
+    }
+    return (lim > R(1)) | (sq > R(1));
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char gemx_smem[];
+
+// S control steps of one I/O block.  COOP: actions come from the LDS tile (no global memory access at all in
+// this loop); otherwise straight from global memory (K == 1, tail workgroup, unaligned tensors).  The two variants
+// are separate instantiations on purpose: a pointer that may be LDS or global would compile to FLAT loads, whose
+// s_waitcnt covers vmcnt as well and would wait for every outstanding observation store.
+template <bool COOP, int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R>
+__device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTraits<SYS>::ND], typename Angle<R>::T &ang, uint32_t &sw,
+                                              R (&obs)[SysTraits<SYS>::NOUT], uint32_t &done_or, uint32_t &bad_action, R *ring,
+                                              const unsigned char *atile, unsigned char *donebuf, int k0, int sb, int tid,
+                                              int64_t e, typename Angle<R>::T init_ang) {
+    constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
+    constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
+    constexpr int ABYTES = DISCRETE ? 1 : NACT * (int)sizeof(R);
+    constexpr int ROWB = BLOCK * ABYTES;
+    using ST = Stepper<SYS, CONV, LOAD, SOLVER, IL, R>;
+    const DevParams<R> &P = a.P;
+    // Software pipeline (COOP): the action of step s+1 is read from LDS while step s computes, and the observation
+    // row of step s is written to the ring at the top of iteration s+1, so the only LDS wait of an iteration (for the
+    // action it is about to use) finds a read that was issued a whole step earlier.
+    auto read_action = [&](int s, R (&dst)[3], uint32_t &ddst) {
+        if (COOP) {
+            if (DISCRETE) ddst = atile[s * ROWB + tid];
+            else {
+#pragma unroll
+                for (int i = 0; i < NACT; ++i) dst[i] = reinterpret_cast<const R *>(atile + s * ROWB)[tid * NACT + i];
+            }
+        } else {
+            const unsigned char *g = a.actions + ((int64_t)(k0 + s) * a.N + e) * ABYTES;
+            if (DISCRETE) ddst = *g;
+            else {
+#pragma unroll
+                for (int i = 0; i < NACT; ++i) dst[i] = reinterpret_cast<const R *>(g)[i];
+            }
+        }
+    };
+    auto write_ring = [&](int s, bool dn) {
+        if (P.obs_layout == GEMX_OBS_AOS) {
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) ring[(s * BLOCK + tid) * NOUT + j] = obs[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) ring[(s * NOUT + j) * BLOCK + tid] = obs[j];
+        }
+        donebuf[s * BLOCK + tid] = dn ? 1 : 0;
+    };
+    R nact[3] = {R(0), R(0), R(0)};
+    uint32_t ndact = 0;
+    read_action(0, nact, ndact);
+    bool pdone = false;
+    for (int s = 0; s < sb; ++s) {
+        R act[3] = {nact[0], nact[1], nact[2]};
+        uint32_t dact = ndact;
+        if (a.obs_every && s > 0) write_ring(s - 1, pdone);       // row of the previous step (obs still holds it)
+        if (COOP && s + 1 < sb) read_action(s + 1, nact, ndact);   // prefetch (LDS only; global loads would add vmcnt waits)
+        if (DISCRETE) { bad_action |= dact > 7u; dact &= 7u; }
+        ST::step(P, y, ang, sw, act, dact, obs);
+        const bool done = constraint_done<ST, NOUT, R>(P, obs);
+        done_or |= done ? 1u : 0u;
+        pdone = done;
+        if (done && P.auto_reset) {  // `if terminated: env.reset()`; switching state survives (converters.py:45-54)
+#pragma unroll
+            for (int j = 0; j < ND; ++j) y[j] = P.init[j];
+            ang = init_ang;
+        }
+        if (!COOP && s + 1 < sb) read_action(s + 1, nact, ndact);
+    }
+    if (a.obs_every) write_ring(sb - 1, pdone);
+}
+
+// ------------------------------------------------------------------------------------------------
+// THE kernel: K control steps of N envs (K = 1 is the single-step path of gemx_step()).
+//
+// I/O is blocked in groups of S control steps, because on gfx950 loads AND stores retire through the same
+// in-order vmcnt counter: waiting for the next action right after issuing this step's observation stores would
+// expose the HBM store latency (~2 us) on every step.  Per block of S steps:
+//   1. issue the global loads of the NEXT block's action tile (S rows x 64 envs, contiguous per row) as 16-byte
+//      per-lane loads into registers (no wait);
+//   2. S control steps, reading this block's actions from LDS and writing observation rows / done bytes to an
+//      LDS ring (no global memory traffic at all inside the compute loop);
+//   3. park the prefetched action tile in the other half of the LDS action buffer (its loads had S steps of
+//      arithmetic to land);
+//   4. flush the ring: each 64-env row is a contiguous 64*S_out*sizeof(R) span of the [K, N, S_out] output, written
+//      with 16-byte-per-lane stores; the stores drain while the next block computes.
+// ------------------------------------------------------------------------------------------------
+template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R>
+__global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
+    constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
+    constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
+    constexpr int ABYTES = DISCRETE ? 1 : NACT * (int)sizeof(R);  // action bytes per env and step
+    constexpr int ROWB = BLOCK * ABYTES;                           // action bytes per 64-env row
+    constexpr int CPR = ROWB / 16;                                 // 16-byte chunks per action row
+    constexpr int VEC = 16 / sizeof(R);
+    constexpr int ROWV = BLOCK * NOUT / VEC;                       // 16-byte chunks per observation row
+    constexpr int NCH = act_chunks(CPR);                           // 16-byte action chunks per lane and I/O block
+    using AngT = typename Angle<R>::T;
+    using V = typename std::conditional<sizeof(R) == 4, float4, double2>::type;
+
+    const DevParams<R> &P = a.P;
+    const int tid = threadIdx.x;
+    const int64_t blk0 = (int64_t)blockIdx.x * BLOCK;
+    const int64_t env = blk0 + tid;
+    const int64_t N = a.N;
+    const bool valid = env < N;
+    const int64_t e = valid ? env : N - 1;  // clamp loads of the tail lanes; their stores are masked
+    const int rows = (int)((N - blk0) < BLOCK ? (N - blk0) : BLOCK);
+    const bool full = rows == BLOCK;
+    const int S = a.S;
+    const int K = a.K;
+
+    // LDS carve-up: observation ring [S][64*NOUT] R | action tiles [2][S*ROWB] bytes | done ring [S][64] bytes
+    R *ring = reinterpret_cast<R *>(gemx_smem);
+    unsigned char *actbuf = gemx_smem + (size_t)S * BLOCK * NOUT * sizeof(R);
+    unsigned char *donebuf = actbuf + 2 * (size_t)S * ROWB;
+    const bool coop = a.coop && full && K > 1;   // cooperative action staging for this workgroup (uniform)
+
+    R y[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) y[j] = a.state[(int64_t)j * N + e];
+    AngT ang = AngT(0);
+    if (SysTraits<SYS>::HAS_ANGLE) ang = a.angle[e];
+    uint32_t sw = 0;
+    constexpr bool USE_SW = (CONV == GEMX_CONV_FINITE_B6) && IL;
+    if (USE_SW) sw = a.sw[e];
+    const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
+
+    // per-lane 16-byte loads of one action tile (steps [k0, k0+sb)) into registers: tile_load / tile_park below
+    V tile[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) tile[c] = V{};
+    const unsigned char *act_blk = a.actions + blk0 * ABYTES;  // this workgroup's column of the action tensor
+    const int64_t act_row_stride = N * ABYTES;
+#define GEMX_TILE_LOAD(k0_, sb_)                                                                                      \
+    do {                                                                                                              \
+        const int nchunk_ = (sb_) * CPR;                                                                              \
+        _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                                             \
+            const int idx = c * BLOCK + tid;                                                                          \
+            if (idx < nchunk_) {                                                                                      \
+                const int row = idx / CPR, col = idx - row * CPR;                                                     \
+                tile[c] = *reinterpret_cast<const V *>(act_blk + (int64_t)((k0_) + row) * act_row_stride + col * 16); \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+#define GEMX_TILE_PARK(half_, sb_)                                                                                    \
+    do {                                                                                                              \
+        const int nchunk_ = (sb_) * CPR;                                                                              \
+        V *dst_ = reinterpret_cast<V *>(actbuf + (size_t)(half_) * S * ROWB);                                         \
+        _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                                             \
+            const int idx = c * BLOCK + tid;                                                                          \
+            if (idx < nchunk_) dst_[idx] = tile[c];                                                                   \
+        }                                                                                                             \
+    } while (0)
+
+    if (coop) {
+        GEMX_TILE_LOAD(0, S < K ? S : K);
+        GEMX_TILE_PARK(0, S < K ? S : K);
+    }
+    // Drain the prologue loads (state, angle, first action tile) HERE, once.  Otherwise the compiler parks a
+    // conservative `s_waitcnt vmcnt(0)` at the first use inside the step loop, and since stores retire through the
+    // same counter every I/O block would wait for the previous block's whole flush burst instead of overlapping it.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // gfx9 encoding: vmcnt(0), expcnt/lgkmcnt untouched
+    __syncthreads();
+
+    uint32_t done_or = 0, bad_action = 0;
+    R obs[NOUT];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) obs[j] = R(0);
+    int half = 0;
+    for (int k0 = 0; k0 < K; k0 += S) {
+        const int sb = (K - k0) < S ? (K - k0) : S;
+        const int k1 = k0 + sb;
+        const int sb_next = (K - k1) < S ? (K - k1) : S;
+        if (coop && sb_next > 0) GEMX_TILE_LOAD(k1, sb_next);  // 1. prefetch (no wait)
+
+        // 2. compute: no global memory traffic in here when coop
+        const unsigned char *atile = actbuf + (size_t)half * S * ROWB;
+        if (coop) compute_block<true, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang);
+        else compute_block<false, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang);
+        __syncthreads();
+
+        // 3. park the prefetched tile
+        if (coop && sb_next > 0) GEMX_TILE_PARK(half ^ 1, sb_next);
+
+        // 4. flush the rings
+        if (a.obs_every) {
+            if (P.obs_layout == GEMX_OBS_AOS) {
+                if (a.obs_vec) {
+                    const int nvec = rows * NOUT / VEC;  // == ROWV for full blocks
+#pragma unroll 2
+                    for (int s = 0; s < sb; ++s) {
+                        V *gv = reinterpret_cast<V *>(a.obs + ((int64_t)(k0 + s) * N + blk0) * NOUT);
+                        const V *lv = reinterpret_cast<const V *>(ring + (size_t)s * BLOCK * NOUT);
+#pragma unroll
+                        for (int i = 0; i < (ROWV + BLOCK - 1) / BLOCK; ++i) {
+                            const int idx = tid + i * BLOCK;
+                            if (idx < nvec) gv[idx] = lv[idx];
+                        }
+                        for (int idx = nvec * VEC + tid; idx < rows * NOUT; idx += BLOCK)
+                            a.obs[((int64_t)(k0 + s) * N + blk0) * NOUT + idx] = ring[(size_t)s * BLOCK * NOUT + idx];
+                    }
+                } else {
+                    for (int s = 0; s < sb; ++s)
+                        for (int idx = tid; idx < rows * NOUT; idx += BLOCK)
+                            a.obs[((int64_t)(k0 + s) * N + blk0) * NOUT + idx] = ring[(size_t)s * BLOCK * NOUT + idx];
+                }
+            } else if (valid) {
+                for (int s = 0; s < sb; ++s) {
+#pragma unroll
+                    for (int j = 0; j < NOUT; ++j) a.obs[((int64_t)(k0 + s) * NOUT + j) * N + env] = ring[(s * NOUT + j) * BLOCK + tid];
+                }
+            }
+            if (a.done != nullptr) {
+                if (a.coop && full) {  // done rows are 64 contiguous bytes: 4 x 16-byte chunks per row
+                    const int nchunk = sb * (BLOCK / 16);
+                    for (int idx = tid; idx < nchunk; idx += BLOCK) {
+                        const int row = idx >> 2, col = idx & 3;
+                        *reinterpret_cast<uint4 *>(a.done + (int64_t)(k0 + row) * N + blk0 + col * 16) =
+                            *reinterpret_cast<const uint4 *>(donebuf + row * BLOCK + col * 16);
+                    }
+                } else if (valid) {
+                    for (int s = 0; s < sb; ++s) a.done[(int64_t)(k0 + s) * N + env] = donebuf[s * BLOCK + tid];
+                }
+            }
+        }
+        __syncthreads();
+        half ^= 1;
+    }
+
+    if (!a.obs_every) {  // last-step-only mode: one row through ring slot 0
+        if (P.obs_layout == GEMX_OBS_AOS) {
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) ring[tid * NOUT + j] = obs[j];
+            __syncthreads();
+            for (int idx = tid; idx < rows * NOUT; idx += BLOCK) a.obs[blk0 * NOUT + idx] = ring[idx];
+        } else if (valid) {
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) a.obs[(int64_t)j * N + env] = obs[j];
+        }
+        if (a.done != nullptr && valid) a.done[env] = (uint8_t)done_or;
+    }
+
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < ND; ++j) a.state[(int64_t)j * N + env] = y[j];
+        if (SysTraits<SYS>::HAS_ANGLE) a.angle[env] = ang;
+        if (USE_SW) a.sw[env] = (uint8_t)sw;
+    }
+    if (bad_action && valid) atomicOr(a.err, 1u);
+#undef GEMX_TILE_LOAD
+#undef GEMX_TILE_PARK
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launcher
+// ------------------------------------------------------------------------------------------------
+// I/O block depth S (control steps staged in LDS between global-memory bursts): as deep as the LDS allows for the
+// number of workgroups that should be co-resident per CU, capped by the per-lane action-prefetch registers.
+inline int choose_steps_per_block(const gemx_handle *h, int K, int es, int abytes) {
+    if (K <= 1) return 1;
+    const size_t per_step = (size_t)BLOCK * h->nout * es + 2 * (size_t)BLOCK * abytes + BLOCK;
+    int S = h->steps_per_block;
+    if (S <= 0) {
+        const int64_t nblocks = (h->n + BLOCK - 1) / BLOCK;
+        int64_t per_cu = (nblocks + h->n_cu - 1) / h->n_cu;
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 16) per_cu = 16;
+        S = (int)((h->lds_max - 1024) / per_cu / per_step);
+        if (S > MAX_STEPS_PER_BLOCK) S = MAX_STEPS_PER_BLOCK;
+    }
+    const int cpr = BLOCK * abytes / 16;
+    const int s_regs = act_chunks(cpr) * BLOCK / cpr;  // steps whose action rows fit the per-lane prefetch registers
+    if (S > s_regs) S = s_regs;
+    const int s_lds = (int)((h->lds_max - 256) / per_step);
+    if (S > s_lds) S = s_lds;
+    if (S > K) S = K;
+    if (S < 1) S = 1;
+    return S;
+}
+
+template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R>
+int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint8_t *done, int obs_every, hipStream_t st) {
+    constexpr int ABYTES = ConvTraits<CONV>::DISCRETE ? 1 : ConvTraits<CONV>::NACT * (int)sizeof(R);
+    KArgs<R> a;
+    a.P = params_of<R>(h);
+    a.state = (R *)h->state;
+    a.angle = (typename Angle<R>::T *)h->angle;
+    a.sw = h->sw;
+    a.actions = (const unsigned char *)actions;
+    a.obs = (R *)obs;
+    a.done = done;
+    a.err = h->err;
+    a.N = h->n;
+    a.K = K;
+    a.obs_every = obs_every;
+    a.S = choose_steps_per_block(h, K, (int)sizeof(R), ABYTES);
+    // 16-byte alignment of every full block's rows: row starts are (k*N + blk0) * bytes_per_env with blk0 % 64 == 0
+    a.coop = (((uintptr_t)actions & 15u) == 0 && ((size_t)h->n * ABYTES) % 16 == 0 &&
+              (done == nullptr || (((uintptr_t)done & 15u) == 0 && (size_t)h->n % 16 == 0))) ? 1 : 0;
+    a.obs_vec = (((size_t)h->n * h->nout * sizeof(R)) % 16 == 0) ? 1 : 0;
+    size_t smem = (size_t)a.S * BLOCK * h->nout * sizeof(R) + 2 * (size_t)a.S * BLOCK * ABYTES + (size_t)a.S * BLOCK;
+    smem = (smem + 15) & ~(size_t)15;
+    auto kern = advance_kernel<SYS, CONV, LOAD, SOLVER, IL, R>;
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        GEMX_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max));
+        attr_set = true;
+    }
+    int64_t blocks = (h->n + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), smem, st, a);
+    GEMX_HIP_TRY(hipGetLastError());
+    return GEMX_OK;
+}
+
+// run-time -> compile-time dispatch on (load, solver, interlocking) for one (system, converter, dtype) unit.
+// IL = false only exists for fp32 (the product path); the fp64 diagnostic build always takes the general code.
+template <int SYS, int CONV, class R>
+int launch_advance_unit(gemx_handle *h, const void *actions, int K, void *obs, uint8_t *done, int obs_every, hipStream_t st) {
+    const bool il = sizeof(R) == 8 || h->cfg.interlocking_time > 0.0;
+    const int ld = h->cfg.load_kind, sv = h->cfg.solver_kind;
+#define GEMX_CASE(LD, SV)                                                                                                  \
+    if (ld == LD && sv == SV) {                                                                                            \
+        if (il) return launch_advance_t<SYS, CONV, LD, SV, true, R>(h, actions, K, obs, done, obs_every, st);              \
+        if constexpr (sizeof(R) == 4) return launch_advance_t<SYS, CONV, LD, SV, false, R>(h, actions, K, obs, done, obs_every, st); \
+    }
+    GEMX_CASE(GEMX_LOAD_CONST_SPEED, GEMX_SOLVER_EULER)
+    GEMX_CASE(GEMX_LOAD_CONST_SPEED, GEMX_SOLVER_RK4)
+    GEMX_CASE(GEMX_LOAD_CONST_SPEED, GEMX_SOLVER_DP5)
+    GEMX_CASE(GEMX_LOAD_POLY_STATIC, GEMX_SOLVER_EULER)
+    GEMX_CASE(GEMX_LOAD_POLY_STATIC, GEMX_SOLVER_RK4)
+    GEMX_CASE(GEMX_LOAD_POLY_STATIC, GEMX_SOLVER_DP5)
+#undef GEMX_CASE
+    return fail(GEMX_ERR_ARG, "unsupported load/solver combination %d/%d", ld, sv);
+}
+
+}  // namespace gemx
