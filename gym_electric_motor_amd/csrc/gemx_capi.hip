@@ -271,6 +271,9 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         }
         const char *ev = getenv("GEMX_STEPS_PER_BLOCK");
         if (ev) h->steps_per_block = atoi(ev);
+        ev = getenv("GEMX_PIPE");
+        if (ev) h->use_pipe = atoi(ev);
+
     }
     host_reset_obs(*h, m);
 

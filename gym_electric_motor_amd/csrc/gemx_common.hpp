@@ -140,12 +140,15 @@ template <class R> struct KArgs {
     int64_t N;
     int32_t K, obs_every;
     int32_t S;                      // control steps per I/O block (LDS ring depth)
+    int32_t D;                      // pipelined kernel: control steps per hand-off block (one barrier per D steps)
     int32_t coop;                   // 1: action rows / done rows of full blocks are 16-byte aligned -> cooperative staging
     int32_t obs_vec;                // 1: observation rows of full blocks are 16-byte aligned -> 16-byte stores
 };
 
 constexpr int MAX_ACT_CHUNKS = 12;  // upper bound of 16-byte chunks of staged actions per lane and I/O block
 constexpr int MAX_STEPS_PER_BLOCK = 32;
+constexpr int PIPE_D = 8;           // pipelined kernel: control steps per hand-off block (one barrier per block)
+constexpr int PIPE_MAX_S = 8;       // pipelined kernel: max observation-ring depth
 // chunks per lane needed to stage MAX_STEPS_PER_BLOCK steps of a row made of `cpr` 16-byte chunks
 __host__ __device__ constexpr int act_chunks(int cpr) {
     return (MAX_STEPS_PER_BLOCK * cpr + BLOCK - 1) / BLOCK < MAX_ACT_CHUNKS ? (MAX_STEPS_PER_BLOCK * cpr + BLOCK - 1) / BLOCK : MAX_ACT_CHUNKS;
@@ -173,6 +176,7 @@ struct gemx_handle {
     int n_cu = 256;
     size_t lds_max = 160 * 1024;
     int steps_per_block = 0;  // 0 = heuristic
+    int use_pipe = -1;        // two-wave pipelined kernel: -1 auto (small N only), 0 never, 1 whenever eligible
 };
 
 namespace gemx {

@@ -150,12 +150,12 @@ __device__ __forceinline__ R rk_step(R (&z)[NZ], R h, F &&rhs) {
 // integrate one segment of length h with `nsteps` sub-steps (EulerSolver(nsteps), solvers.py:103-122).
 // y = [omega, motor states].  Returns the angle increment  pole * int(omega dt)  of the scheme.
 // ------------------------------------------------------------------------------------------------
-template <int SYS, int LOAD, int SOLVER, class R>
+template <int SYS, int LOAD, int SOLVER, class R, bool NS1 = false>
 __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<SYS>::ND], const R (&u)[2], R h) {
     using E = Elec<SYS, R>;
     constexpr int NM = E::NM;
-    const int ns = P.nsteps;
-    const R hs = h * P.inv_ns;
+    const int ns = NS1 ? 1 : P.nsteps;     // NS1: the caller guarantees solver_nsteps == 1 (branch-free code)
+    const R hs = NS1 ? h : h * P.inv_ns;
     if (LOAD == GEMX_LOAD_CONST_SPEED) {
         // omega is constant (constant_speed_load.py:40-42): integrate the electrical states only; every scheme's
         // quadrature weights sum to one, so the angle increment is exactly pole * omega * h.
@@ -164,7 +164,7 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
 #pragma unroll
         for (int i = 0; i < NM; ++i) x[i] = y[1 + i];
         auto rhs = [&](const R (&xx)[NM], R (&dx)[NM]) { E::f(P, pre, xx, dx); };
-        if (ns == 1) {
+        if (NS1 || ns == 1) {
             rk_step<SOLVER, NM, R>(x, hs, rhs);
         } else {
             for (int s = 0; s < ns; ++s) rk_step<SOLVER, NM, R>(x, hs, rhs);
@@ -185,7 +185,7 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
             for (int i = 0; i < NM; ++i) dz[1 + i] = dx[i];
         };
         R wsum = R(0);
-        if (ns == 1) {
+        if (NS1 || ns == 1) {
             wsum = rk_step<SOLVER, NM + 1, R>(y, hs, rhs);
         } else {
             for (int s = 0; s < ns; ++s) wsum += rk_step<SOLVER, NM + 1, R>(y, hs, rhs);
@@ -253,36 +253,50 @@ __device__ __forceinline__ void b6_voltages(const DevParams<R> &P, const R (&act
 }
 
 // ------------------------------------------------------------------------------------------------
-// one control step of one env: advances (y, ang, sw) and fills the normalised observation row.
+// one control step of one env, in two halves so that they can run in different waves (advance_pipe_kernel):
+//   advance(): converter -> voltages -> ODE integration -> new (y, ang, sw); leaves in ho[] what observe() needs
+//   observe(): normalised observation row from (y, ang, ho)
+//   state_done(): the env's DEFAULT constraint evaluated from (y, ho) with the same arithmetic as on the row
+// step() = advance() + observe() (single-wave kernel).
 // ------------------------------------------------------------------------------------------------
 template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper;
 
 // ---- DcMotorSystem + Cont-4QC (physical_systems.py:171-203; converters.py:481-491) --------------------------
 template <int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_DC_PERMEX, GEMX_CONV_CONT_4QC, LOAD, SOLVER, IL, R> {
     using AngT = typename Angle<R>::T;
-    static __device__ __forceinline__ void step(const DevParams<R> &P, R (&y)[2], AngT &, uint32_t &, const R (&act)[3],
-                                                uint32_t, R (&obs)[5]) {
+    static constexpr int NH = 1;  // ho: u [V]
+    template <bool NS1 = false>
+    static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[2], AngT &, uint32_t &, const R (&act)[3], uint32_t,
+                                                   R (&ho)[NH]) {
         const R d0 = clip01(R(0.5) * (act[0] + R(1)));
         const R d1 = clip01(R(-0.5) * (act[0] - R(1)));
         const R un = cont_leg<IL, R>(P, d0, y[1]) - cont_leg<IL, R>(P, d1, y[1]);  // both sub-converters see the same i (line 483)
         R u[2] = {un * P.u_sup, R(0)};
-        integrate<GEMX_SYS_DC_PERMEX, LOAD, SOLVER, R>(P, y, u, P.tau);
+        integrate<GEMX_SYS_DC_PERMEX, LOAD, SOLVER, R, NS1>(P, y, u, P.tau);
+        ho[0] = u[0];
+    }
+    static __device__ __forceinline__ void observe(const DevParams<R> &P, const R (&y)[2], AngT, const R (&ho)[NH], R (&obs)[5]) {
         const R x[1] = {y[1]};
         obs[0] = y[0] * P.inv_lim[0];
         obs[1] = Elec<GEMX_SYS_DC_PERMEX, R>::torque(P, x) * P.inv_lim[1];
         obs[2] = y[1] * P.inv_lim[2];
-        obs[3] = u[0] * P.inv_lim[3];
+        obs[3] = ho[0] * P.inv_lim[3];
         obs[4] = P.u_sup * P.inv_lim[4];
     }
     // default constraint of the DC envs: LimitConstraint('i') (cont_cc_permex_dc_env.py:104)
     static __device__ __forceinline__ bool default_done(const R (&obs)[5]) { return fabs(obs[2]) > R(1); }
+    static __device__ __forceinline__ bool state_done(const DevParams<R> &P, const R (&y)[2], const R (&)[NH]) {
+        return fabs(y[1] * P.inv_lim[2]) > R(1);
+    }
 };
 
 // ---- SynchronousMotorSystem (physical_systems.py:487-525), control_space 'abc' ---------------------------------
 template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_SYNC, CONV, LOAD, SOLVER, IL, R> {
     using AngT = typename Angle<R>::T;
-    static __device__ __forceinline__ void step(const DevParams<R> &P, R (&y)[3], AngT &ang, uint32_t &sw, const R (&act)[3],
-                                                uint32_t dact, R (&obs)[14]) {
+    static constexpr int NH = 7;  // ho: sin, cos of the last segment-start angle, u_a, u_b, u_c, u_sd, u_sq
+    template <bool NS1 = false>
+    static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[3], AngT &ang, uint32_t &sw, const R (&act)[3],
+                                                   uint32_t dact, R (&ho)[NH]) {
         R s, c;
         Angle<R>::sincos(ang, s, c);
         uint32_t legs = 0;
@@ -304,7 +318,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             t23(ua, ub, uc, ual, ube);
             u[0] = c * ual + s * ube;  // Q^-1(., eps): u_dq frozen at the segment-start angle (line 501/511)
             u[1] = -s * ual + c * ube;
-            const R deps = integrate<GEMX_SYS_SYNC, LOAD, SOLVER, R>(P, y, u, h);
+            const R deps = integrate<GEMX_SYS_SYNC, LOAD, SOLVER, R, NS1>(P, y, u, h);
             ang = Angle<R>::advance(ang, deps);
         };
         if (IL) {
@@ -316,7 +330,11 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
         } else {
             segment(P.tau);
         }
-        // outputs: i_abc from the NEW i_dq with the angle of the last segment start (line 519, reference quirk)
+        ho[0] = s; ho[1] = c; ho[2] = ua; ho[3] = ub; ho[4] = uc; ho[5] = u[0]; ho[6] = u[1];
+    }
+    static __device__ __forceinline__ void observe(const DevParams<R> &P, const R (&y)[3], AngT ang, const R (&ho)[NH], R (&obs)[14]) {
+        // i_abc from the NEW i_dq with the angle of the last segment start (line 519, reference quirk)
+        const R s = ho[0], c = ho[1];
         const R ial = c * y[1] - s * y[2], ibe = s * y[1] + c * y[2];
         R ia, ib, ic;
         t32(ial, ibe, ia, ib, ic);
@@ -328,21 +346,26 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
         obs[4] = ic * P.inv_lim[4];
         obs[5] = y[1] * P.inv_lim[5];
         obs[6] = y[2] * P.inv_lim[6];
-        obs[7] = ua * P.inv_lim[7];
-        obs[8] = ub * P.inv_lim[8];
-        obs[9] = uc * P.inv_lim[9];
-        obs[10] = u[0] * P.inv_lim[10];
-        obs[11] = u[1] * P.inv_lim[11];
+        obs[7] = ho[2] * P.inv_lim[7];
+        obs[8] = ho[3] * P.inv_lim[8];
+        obs[9] = ho[4] * P.inv_lim[9];
+        obs[10] = ho[5] * P.inv_lim[10];
+        obs[11] = ho[6] * P.inv_lim[11];
         obs[12] = Angle<R>::wrapped(ang) * P.inv_lim[12];
         obs[13] = P.u_sup * P.inv_lim[13];
     }
     // default constraint: SquaredConstraint(('i_sq','i_sd')) (finite_cc_pmsm_env.py:106)
     static __device__ __forceinline__ bool default_done(const R (&obs)[14]) { return obs[5] * obs[5] + obs[6] * obs[6] > R(1); }
+    static __device__ __forceinline__ bool state_done(const DevParams<R> &P, const R (&y)[3], const R (&)[NH]) {
+        const R o5 = y[1] * P.inv_lim[5], o6 = y[2] * P.inv_lim[6];
+        return o5 * o5 + o6 * o6 > R(1);
+    }
 };
 
 // ---- SquirrelCageInductionMotorSystem (physical_systems.py:771-814), control_space 'abc' -----------------------
 template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_SCIM, CONV, LOAD, SOLVER, IL, R> {
     using AngT = typename Angle<R>::T;
+    static constexpr int NH = 7;  // ho: sin, cos of the last segment-start field angle, u_a, u_b, u_c, u_alpha, u_beta
     // cos/sin of the rotor-flux angle eps_fs = atan2(psi_b, psi_a) (calculate_field_angle, 765-769) without atan2
     static __device__ __forceinline__ void field_angle(R pa, R pb, R &s, R &c) {
         R n2 = pa * pa + pb * pb;
@@ -351,15 +374,16 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
         c = n2 > R(0) ? pa * rn : R(1);  // atan2(0, 0) = 0
         s = pb * rn;
     }
-    static __device__ __forceinline__ void step(const DevParams<R> &P, R (&y)[5], AngT &ang, uint32_t &sw, const R (&act)[3],
-                                                uint32_t dact, R (&obs)[14]) {
+    template <bool NS1 = false>
+    static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[5], AngT &ang, uint32_t &sw, const R (&act)[3],
+                                                   uint32_t dact, R (&ho)[NH]) {
         R s, c;
         field_angle(y[3], y[4], s, c);
         uint32_t legs = 0;
         bool two = false;
         if (IL && CONV == GEMX_CONV_FINITE_B6) {
             legs = b6_subactions(dact);
-            if (P.t_il > R(0)) legs = b6_interlock(sw, legs, two);  // converters.py:302: no dead time -> pattern [action]
+            if (P.t_il > R(0)) legs = b6_interlock(sw, legs, two);
             sw = legs;
         }
         R ua, ub, uc, u[2];
@@ -368,7 +392,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             if (IL) t32(y[1], y[2], ia, ib, ic);  // i_in = T32(i_alphabeta) (line 780/792)
             b6_voltages<CONV, IL, R>(P, act, dact, legs, ia, ib, ic, ua, ub, uc);
             t23(ua, ub, uc, u[0], u[1]);  // u_alphabeta constant over the segment (line 788/799)
-            const R deps = integrate<GEMX_SYS_SCIM, LOAD, SOLVER, R>(P, y, u, h);
+            const R deps = integrate<GEMX_SYS_SCIM, LOAD, SOLVER, R, NS1>(P, y, u, h);
             ang = Angle<R>::advance(ang, deps);
         };
         if (IL) {
@@ -380,8 +404,12 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
         } else {
             segment(P.tau);
         }
+        ho[0] = s; ho[1] = c; ho[2] = ua; ho[3] = ub; ho[4] = uc; ho[5] = u[0]; ho[6] = u[1];
+    }
+    static __device__ __forceinline__ void observe(const DevParams<R> &P, const R (&y)[5], AngT ang, const R (&ho)[NH], R (&obs)[14]) {
         // i_dq = Q^-1(i_alphabeta_new, eps_fs of the last segment start) (line 806, reference quirk);
         // i_abc = T32(Q(i_dq, eps_fs)) == T32(i_alphabeta_new) (line 807); u_dq = Q^-1(u_alphabeta, eps_fs) (798)
+        const R s = ho[0], c = ho[1];
         R ia, ib, ic;
         t32(y[1], y[2], ia, ib, ic);
         const R x[4] = {y[1], y[2], y[3], y[4]};
@@ -392,17 +420,31 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
         obs[4] = ic * P.inv_lim[4];
         obs[5] = (c * y[1] + s * y[2]) * P.inv_lim[5];
         obs[6] = (-s * y[1] + c * y[2]) * P.inv_lim[6];
-        obs[7] = ua * P.inv_lim[7];
-        obs[8] = ub * P.inv_lim[8];
-        obs[9] = uc * P.inv_lim[9];
-        obs[10] = (c * u[0] + s * u[1]) * P.inv_lim[10];
-        obs[11] = (-s * u[0] + c * u[1]) * P.inv_lim[11];
+        obs[7] = ho[2] * P.inv_lim[7];
+        obs[8] = ho[3] * P.inv_lim[8];
+        obs[9] = ho[4] * P.inv_lim[9];
+        obs[10] = (c * ho[5] + s * ho[6]) * P.inv_lim[10];
+        obs[11] = (-s * ho[5] + c * ho[6]) * P.inv_lim[11];
         obs[12] = Angle<R>::wrapped(ang) * P.inv_lim[12];
         obs[13] = P.u_sup * P.inv_lim[13];
     }
     // default constraint: SquaredConstraint(('i_sq','i_sd')) (cont_sc_scim_env.py:111)
     static __device__ __forceinline__ bool default_done(const R (&obs)[14]) { return obs[5] * obs[5] + obs[6] * obs[6] > R(1); }
+    static __device__ __forceinline__ bool state_done(const DevParams<R> &P, const R (&y)[5], const R (&ho)[NH]) {
+        const R s = ho[0], c = ho[1];
+        const R o5 = (c * y[1] + s * y[2]) * P.inv_lim[5], o6 = (-s * y[1] + c * y[2]) * P.inv_lim[6];
+        return o5 * o5 + o6 * o6 > R(1);
+    }
 };
+
+// step() for the single-wave kernel
+template <class ST, int ND, int NOUT, class R>
+__device__ __forceinline__ void full_step(const DevParams<R> &P, R (&y)[ND], typename Angle<R>::T &ang, uint32_t &sw, const R (&act)[3],
+                                          uint32_t dact, R (&obs)[NOUT]) {
+    R ho[ST::NH];
+    ST::advance(P, y, ang, sw, act, dact, ho);
+    ST::observe(P, y, ang, ho, obs);
+}
 
 // ConstraintMonitor with merge 'max' over LimitConstraint / SquaredConstraint; terminated = violation >= 1
 // (core.py:350, 834-844; constraints.py:55-58, 96-98).  constr_kind is wave-uniform: 0 none, 1 the env's default
@@ -420,6 +462,55 @@ template <class ST, int NOUT, class R> __device__ __forceinline__ bool constrain
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char gemx_smem[];
+
+// Flush `sb` observation rows / done rows (control steps k0 .. k0+sb-1) of one 64-env workgroup from the LDS rings to
+// the caller's tensors: 16-byte-per-lane stores over each row's contiguous span (AoS) or coalesced dword stores (SoA).
+template <int NOUT, class R>
+__device__ __forceinline__ void flush_rings(const KArgs<R> &a, const R *ring, const unsigned char *donebuf, int k0, int sb, int tid,
+                                            int64_t blk0, int rows, bool full, bool valid, int64_t env) {
+    constexpr int VEC = 16 / sizeof(R);
+    constexpr int ROWV = BLOCK * NOUT / VEC;
+    using V = typename std::conditional<sizeof(R) == 4, float4, double2>::type;
+    const int64_t N = a.N;
+    if (a.P.obs_layout == GEMX_OBS_AOS) {
+        if (a.obs_vec) {
+            const int nvec = rows * NOUT / VEC;  // == ROWV for full blocks
+#pragma unroll 2
+            for (int s = 0; s < sb; ++s) {
+                V *gv = reinterpret_cast<V *>(a.obs + ((int64_t)(k0 + s) * N + blk0) * NOUT);
+                const V *lv = reinterpret_cast<const V *>(ring + (size_t)s * BLOCK * NOUT);
+#pragma unroll
+                for (int i = 0; i < (ROWV + BLOCK - 1) / BLOCK; ++i) {
+                    const int idx = tid + i * BLOCK;
+                    if (idx < nvec) gv[idx] = lv[idx];
+                }
+                for (int idx = nvec * VEC + tid; idx < rows * NOUT; idx += BLOCK)
+                    a.obs[((int64_t)(k0 + s) * N + blk0) * NOUT + idx] = ring[(size_t)s * BLOCK * NOUT + idx];
+            }
+        } else {
+            for (int s = 0; s < sb; ++s)
+                for (int idx = tid; idx < rows * NOUT; idx += BLOCK)
+                    a.obs[((int64_t)(k0 + s) * N + blk0) * NOUT + idx] = ring[(size_t)s * BLOCK * NOUT + idx];
+        }
+    } else if (valid) {
+        for (int s = 0; s < sb; ++s) {
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) a.obs[((int64_t)(k0 + s) * NOUT + j) * N + env] = ring[(s * NOUT + j) * BLOCK + tid];
+        }
+    }
+    if (a.done != nullptr) {
+        if (a.coop && full) {  // done rows are 64 contiguous bytes: 4 x 16-byte chunks per row
+            const int nchunk = sb * (BLOCK / 16);
+            for (int idx = tid; idx < nchunk; idx += BLOCK) {
+                const int row = idx >> 2, col = idx & 3;
+                *reinterpret_cast<uint4 *>(a.done + (int64_t)(k0 + row) * N + blk0 + col * 16) =
+                    *reinterpret_cast<const uint4 *>(donebuf + row * BLOCK + col * 16);
+            }
+        } else if (valid) {
+            for (int s = 0; s < sb; ++s) a.done[(int64_t)(k0 + s) * N + env] = donebuf[s * BLOCK + tid];
+        }
+    }
+}
 
 // S control steps of one I/O block.  COOP: actions come from the LDS tile (no global memory access at all in
 // this loop); otherwise straight from global memory (K == 1, tail workgroup, unaligned tensors).  The two variants
@@ -475,7 +566,7 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
         if (a.obs_every && s > 0) write_ring(s - 1, pdone);       // row of the previous step (obs still holds it)
         if (COOP && s + 1 < sb) read_action(s + 1, nact, ndact);   // prefetch (LDS only; global loads would add vmcnt waits)
         if (DISCRETE) { bad_action |= dact > 7u; dact &= 7u; }
-        ST::step(P, y, ang, sw, act, dact, obs);
+        full_step<ST, ND, NOUT, R>(P, y, ang, sw, act, dact, obs);
         const bool done = constraint_done<ST, NOUT, R>(P, obs);
         done_or |= done ? 1u : 0u;
         pdone = done;
@@ -603,46 +694,7 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
         if (coop && sb_next > 0) GEMX_TILE_PARK(half ^ 1, sb_next);
 
         // 4. flush the rings
-        if (a.obs_every) {
-            if (P.obs_layout == GEMX_OBS_AOS) {
-                if (a.obs_vec) {
-                    const int nvec = rows * NOUT / VEC;  // == ROWV for full blocks
-#pragma unroll 2
-                    for (int s = 0; s < sb; ++s) {
-                        V *gv = reinterpret_cast<V *>(a.obs + ((int64_t)(k0 + s) * N + blk0) * NOUT);
-                        const V *lv = reinterpret_cast<const V *>(ring + (size_t)s * BLOCK * NOUT);
-#pragma unroll
-                        for (int i = 0; i < (ROWV + BLOCK - 1) / BLOCK; ++i) {
-                            const int idx = tid + i * BLOCK;
-                            if (idx < nvec) gv[idx] = lv[idx];
-                        }
-                        for (int idx = nvec * VEC + tid; idx < rows * NOUT; idx += BLOCK)
-                            a.obs[((int64_t)(k0 + s) * N + blk0) * NOUT + idx] = ring[(size_t)s * BLOCK * NOUT + idx];
-                    }
-                } else {
-                    for (int s = 0; s < sb; ++s)
-                        for (int idx = tid; idx < rows * NOUT; idx += BLOCK)
-                            a.obs[((int64_t)(k0 + s) * N + blk0) * NOUT + idx] = ring[(size_t)s * BLOCK * NOUT + idx];
-                }
-            } else if (valid) {
-                for (int s = 0; s < sb; ++s) {
-#pragma unroll
-                    for (int j = 0; j < NOUT; ++j) a.obs[((int64_t)(k0 + s) * NOUT + j) * N + env] = ring[(s * NOUT + j) * BLOCK + tid];
-                }
-            }
-            if (a.done != nullptr) {
-                if (a.coop && full) {  // done rows are 64 contiguous bytes: 4 x 16-byte chunks per row
-                    const int nchunk = sb * (BLOCK / 16);
-                    for (int idx = tid; idx < nchunk; idx += BLOCK) {
-                        const int row = idx >> 2, col = idx & 3;
-                        *reinterpret_cast<uint4 *>(a.done + (int64_t)(k0 + row) * N + blk0 + col * 16) =
-                            *reinterpret_cast<const uint4 *>(donebuf + row * BLOCK + col * 16);
-                    }
-                } else if (valid) {
-                    for (int s = 0; s < sb; ++s) a.done[(int64_t)(k0 + s) * N + env] = donebuf[s * BLOCK + tid];
-                }
-            }
-        }
+        if (a.obs_every) flush_rings<NOUT, R>(a, ring, donebuf, k0, sb, tid, blk0, rows, full, valid, env);
         __syncthreads();
         half ^= 1;
     }
@@ -669,6 +721,202 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
     if (bad_action && valid) atomicOr(a.err, 1u);
 #undef GEMX_TILE_LOAD
 #undef GEMX_TILE_PARK
+}
+
+// ------------------------------------------------------------------------------------------------
+// Two-wave pipelined variant for small N (<= 2 workgroups per CU), where a single wave per SIMD is bound by its own
+// instruction issue rate (~4.7 cycles per instruction, PMC): the control step is split across the two waves of a
+// 128-thread workgroup that serve the SAME 64 envs,
+//   wave 0 (integrator): actions (global -> registers, one block ahead) -> converter -> ODE integration -> default
+//                        constraint -> auto-reset -> hand-off row to LDS.  It issues no stores before its epilogue, so
+//                        its vmcnt waits only cover action loads issued a whole block earlier, and it never READS LDS.
+//   wave 1 (output):     hand-off row -> observation row -> LDS ring -> 16-byte stores to HBM.  It issues no global
+//                        loads, so it never waits on vmcnt: its stores are fire-and-forget.
+// They meet at ONE s_barrier per block of D = PIPE_D control steps; the hand-off buffer is double-buffered so wave 1
+// works on block b-1 while wave 0 integrates block b.  Full blocks are completely unrolled and branch-free in both
+// waves (one long basic block for the scheduler).
+// Preconditions (checked by the launcher): full 64-env workgroups, 16-byte aligned tensors (coop), obs_every, K >= 2,
+// constraint kind none/default, S a multiple of PIPE_D.
+// ------------------------------------------------------------------------------------------------
+template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R>
+__global__ __launch_bounds__(2 * BLOCK) void advance_pipe_kernel(const KArgs<R> a) {
+    constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
+    constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
+    constexpr bool HAS_ANGLE = SysTraits<SYS>::HAS_ANGLE;
+    constexpr int D = PIPE_D;
+    using AngT = typename Angle<R>::T;
+    using ST = Stepper<SYS, CONV, LOAD, SOLVER, IL, R>;
+    constexpr int NH = ST::NH;
+    constexpr int NHT = ND + (HAS_ANGLE ? 1 : 0) + NH + 1;  // hand-off row: y, angle bits, ho, done
+
+    const DevParams<R> &P = a.P;
+    const int wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x & (BLOCK - 1);
+    const int64_t blk0 = (int64_t)blockIdx.x * BLOCK;
+    const int64_t env = blk0 + tid;
+    const int64_t N = a.N;
+    const int S = a.S, K = a.K;
+    const int nb = (K + D - 1) / D;   // hand-off blocks
+    const int RB = S / D;             // hand-off blocks per ring flush
+
+    // LDS: observation ring [S][64*NOUT] R | done ring [S][64] | hand-off [2][D][64][NHT] R
+    R *ring = reinterpret_cast<R *>(gemx_smem);
+    unsigned char *donebuf = gemx_smem + (size_t)S * BLOCK * NOUT * sizeof(R);
+    R *hand = reinterpret_cast<R *>(donebuf + (size_t)S * BLOCK);
+    auto steps_of = [&](int b) { return (K - b * D) < D ? (K - b * D) : D; };
+
+    if (wave == 0) {
+        // ------------------------------------------------------------------ integrator
+        R y[ND];
+#pragma unroll
+        for (int j = 0; j < ND; ++j) y[j] = a.state[(int64_t)j * N + env];
+        AngT ang = AngT(0);
+        if (HAS_ANGLE) ang = a.angle[env];
+        uint32_t sw = 0;
+        constexpr bool USE_SW = (CONV == GEMX_CONV_FINITE_B6) && IL;
+        if (USE_SW) sw = a.sw[env];
+        const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
+        const bool check_default = P.constr_kind == 1;
+        const bool auto_reset = P.auto_reset != 0;
+        uint32_t bad_action = 0;
+
+        // this lane's actions of one block, in registers
+        R pre[D][NACT];
+        uint32_t dpre[D];
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            dpre[s] = 0;
+#pragma unroll
+            for (int i = 0; i < NACT; ++i) pre[s][i] = R(0);
+        }
+        const R *act_r = reinterpret_cast<const R *>(a.actions);
+        auto load_actions = [&](int b) {  // coalesced: 64 lanes read 64 consecutive envs of row k
+            const int sb = steps_of(b);
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                if (s < sb) {
+                    const int64_t k = (int64_t)b * D + s;
+                    if (DISCRETE) dpre[s] = a.actions[k * N + env];
+                    else {
+#pragma unroll
+                        for (int i = 0; i < NACT; ++i) pre[s][i] = act_r[(k * N + env) * NACT + i];
+                    }
+                }
+            }
+        };
+        auto one_step = [&](const R (&act_in)[NACT], uint32_t dact, R *row) {
+            R act[3] = {R(0), R(0), R(0)};
+#pragma unroll
+            for (int i = 0; i < NACT; ++i) act[i] = act_in[i];
+            if (DISCRETE) { bad_action |= dact > 7u; dact &= 7u; }
+            R ho[NH];
+            ST::template advance<true>(P, y, ang, sw, act, dact, ho);  // launcher guarantees solver_nsteps == 1
+            const bool done = ST::state_done(P, y, ho) & check_default;
+#pragma unroll
+            for (int j = 0; j < ND; ++j) row[j] = y[j];
+            if (HAS_ANGLE) {
+                R bits;
+                memcpy(&bits, &ang, sizeof(R));
+                row[ND] = bits;
+            }
+#pragma unroll
+            for (int j = 0; j < NH; ++j) row[ND + (HAS_ANGLE ? 1 : 0) + j] = ho[j];
+            row[NHT - 1] = done ? R(1) : R(0);
+            const bool rs = done & auto_reset;  // `if terminated: env.reset()`; switching state survives
+#pragma unroll
+            for (int j = 0; j < ND; ++j) y[j] = rs ? P.init[j] : y[j];
+            ang = rs ? init_ang : ang;
+        };
+        load_actions(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): state + first block of actions have landed
+        for (int b = 0; b < nb; ++b) {
+            const int sb = steps_of(b);
+            R *hb = hand + (size_t)(b & 1) * D * BLOCK * NHT + (size_t)tid * NHT;
+            R cur[D][NACT];
+            uint32_t dcur[D];
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                dcur[s] = dpre[s];
+#pragma unroll
+                for (int i = 0; i < NACT; ++i) cur[s][i] = pre[s][i];
+            }
+            if (b + 1 < nb) load_actions(b + 1);  // prefetch: lands while this block integrates
+            if (sb == D) {
+#pragma unroll
+                for (int s = 0; s < D; ++s) one_step(cur[s], dcur[s], hb + (size_t)s * BLOCK * NHT);
+            } else {
+#pragma unroll
+                for (int s = 0; s < D; ++s)
+                    if (s < sb) one_step(cur[s], dcur[s], hb + (size_t)s * BLOCK * NHT);
+            }
+            __syncthreads();  // publishes hand-off block b; wave 1 is done reading block b-1 (other half)
+        }
+#pragma unroll
+        for (int j = 0; j < ND; ++j) a.state[(int64_t)j * N + env] = y[j];
+        if (HAS_ANGLE) a.angle[env] = ang;
+        if (USE_SW) a.sw[env] = (uint8_t)sw;
+        if (bad_action) atomicOr(a.err, 1u);
+    } else {
+        // ------------------------------------------------------------------ output + stores
+        const bool aos = P.obs_layout == GEMX_OBS_AOS;
+        auto one_row = [&](const R (&row)[NHT], int rs) {
+            R y[ND], ho[NH], obs[NOUT];
+#pragma unroll
+            for (int j = 0; j < ND; ++j) y[j] = row[j];
+            AngT ang = AngT(0);
+            if (HAS_ANGLE) {
+                const R bits = row[ND];
+                memcpy(&ang, &bits, sizeof(R));
+            }
+#pragma unroll
+            for (int j = 0; j < NH; ++j) ho[j] = row[ND + (HAS_ANGLE ? 1 : 0) + j];
+            const R dn = row[NHT - 1];
+            ST::observe(P, y, ang, ho, obs);
+            if (aos) {
+#pragma unroll
+                for (int j = 0; j < NOUT; ++j) ring[(rs * BLOCK + tid) * NOUT + j] = obs[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < NOUT; ++j) ring[(rs * NOUT + j) * BLOCK + tid] = obs[j];
+            }
+            donebuf[rs * BLOCK + tid] = dn != R(0) ? 1 : 0;
+        };
+        auto load_row = [&](const R *src, R (&row)[NHT]) {
+#pragma unroll
+            for (int j = 0; j < NHT; ++j) row[j] = src[j];
+        };
+        auto process = [&](int pb) {  // observation rows of hand-off block pb -> ring; flush when the ring is full
+            const int sb = steps_of(pb);
+            const int slot0 = (pb % RB) * D;
+            const R *hb = hand + (size_t)(pb & 1) * D * BLOCK * NHT + (size_t)tid * NHT;
+            R rows[2][NHT];
+            load_row(hb, rows[0]);
+            if (sb == D) {
+#pragma unroll
+                for (int s = 0; s < D; ++s) {  // the next row's LDS reads are issued BEFORE this row's ring writes
+                    if (s + 1 < D) load_row(hb + (size_t)(s + 1) * BLOCK * NHT, rows[(s + 1) & 1]);
+                    one_row(rows[s & 1], slot0 + s);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < D; ++s) {
+                    if (s < sb) {
+                        if (s + 1 < sb) load_row(hb + (size_t)(s + 1) * BLOCK * NHT, rows[(s + 1) & 1]);
+                        one_row(rows[s & 1], slot0 + s);
+                    }
+                }
+            }
+            if ((pb % RB) == RB - 1 || pb == nb - 1) {
+                const int kbase = (pb - pb % RB) * D;
+                flush_rings<NOUT, R>(a, ring, donebuf, kbase, slot0 + sb, tid, blk0, BLOCK, true, true, env);
+            }
+        };
+        for (int b = 0; b < nb; ++b) {
+            if (b >= 1) process(b - 1);
+            __syncthreads();
+        }
+        process(nb - 1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -714,19 +962,51 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     a.K = K;
     a.obs_every = obs_every;
     a.S = choose_steps_per_block(h, K, (int)sizeof(R), ABYTES);
+    a.D = 1;
     // 16-byte alignment of every full block's rows: row starts are (k*N + blk0) * bytes_per_env with blk0 % 64 == 0
     a.coop = (((uintptr_t)actions & 15u) == 0 && ((size_t)h->n * ABYTES) % 16 == 0 &&
               (done == nullptr || (((uintptr_t)done & 15u) == 0 && (size_t)h->n % 16 == 0))) ? 1 : 0;
     a.obs_vec = (((size_t)h->n * h->nout * sizeof(R)) % 16 == 0) ? 1 : 0;
     size_t smem = (size_t)a.S * BLOCK * h->nout * sizeof(R) + 2 * (size_t)a.S * BLOCK * ABYTES + (size_t)a.S * BLOCK;
     smem = (smem + 15) & ~(size_t)15;
+    const int64_t blocks = (h->n + BLOCK - 1) / BLOCK;
+    // two-wave pipelined kernel for small N (the chip is not full: a single wave per SIMD is issue-bound)
+    const bool pipe_ok = h->use_pipe != 0 && K >= 2 && obs_every && a.coop && a.obs_vec && (h->n % BLOCK) == 0 &&
+                         params_of<R>(h).constr_kind <= 1 && h->cfg.solver_nsteps == 1 && (h->use_pipe > 0 || blocks <= 2 * (int64_t)h->n_cu);
+    if (pipe_ok) {
+        using ST = Stepper<SYS, CONV, LOAD, SOLVER, IL, R>;
+        constexpr int NHT = SysTraits<SYS>::ND + (SysTraits<SYS>::HAS_ANGLE ? 1 : 0) + ST::NH + 1;
+        const int64_t per_cu = blocks > h->n_cu ? 2 : 1;
+        const size_t budget = (h->lds_max - 512) / per_cu;
+        constexpr int D = PIPE_D;
+        const size_t fixed = 2 * (size_t)D * BLOCK * NHT * sizeof(R);
+        const size_t per_step = (size_t)BLOCK * h->nout * sizeof(R) + BLOCK;
+        int S = budget > fixed ? (int)((budget - fixed) / per_step) : 0;
+        if (h->steps_per_block > 0 && h->steps_per_block < S) S = h->steps_per_block;
+        if (S > PIPE_MAX_S) S = PIPE_MAX_S;
+        S = (S / D) * D;
+        if (S >= D) {
+            a.S = S;
+            a.D = D;
+            size_t psmem = (size_t)S * per_step + fixed;
+            psmem = (psmem + 15) & ~(size_t)15;
+            auto pkern = advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R>;
+            static bool pattr_set = false;
+            if (!pattr_set) {
+                GEMX_HIP_TRY(hipFuncSetAttribute((const void *)pkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max));
+                pattr_set = true;
+            }
+            hipLaunchKernelGGL(pkern, dim3((unsigned)blocks), dim3(2 * BLOCK), psmem, st, a);
+            GEMX_HIP_TRY(hipGetLastError());
+            return GEMX_OK;
+        }
+    }
     auto kern = advance_kernel<SYS, CONV, LOAD, SOLVER, IL, R>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         GEMX_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max));
         attr_set = true;
     }
-    int64_t blocks = (h->n + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), smem, st, a);
     GEMX_HIP_TRY(hipGetLastError());
     return GEMX_OK;

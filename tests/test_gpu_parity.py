@@ -185,6 +185,24 @@ def test_full_size_configs_against_oracle(env_id, n_envs, solver):
     assert worst < 1e-4, worst
 
 
+@pytest.mark.parametrize("name", ["pmsm_free_uniform_euler", "pmsm_epi_held_tau1e-4_euler", "pmsm_free_held_til_euler",
+                                  "scim_epi_uniform_euler", "scim_free_held_til_euler", "permexdc_epi_held_euler",
+                                  "permexdc_free_held_til_euler", "pmsm_free_uniform_10k_euler"])
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_two_wave_pipelined_kernel_matches_reference_and_single_wave_kernel(name, dtype, monkeypatch):
+    """n_envs = 128 (full 64-env workgroups) takes the two-wave pipelined kernel; it must agree with the reference AND be
+    bit-identical to the single-wave kernel (GEMX_PIPE=0) on the same inputs."""
+    monkeypatch.setenv("GEMX_PIPE", "1")
+    d, meta, obs_p, done_p = _run_golden(name, dtype, n_envs=128)
+    monkeypatch.setenv("GEMX_PIPE", "0")
+    _, _, obs_s, done_s = _run_golden(name, dtype, n_envs=128)
+    assert np.array_equal(obs_p, obs_s) and np.array_equal(done_p, done_s)
+    rel, ab = _rel_err(obs_p[d["state_index"]], d["states"], meta["state_names"])
+    assert (rel < 1e-4) if dtype == "float32" else (ab < 1e-9)
+    if meta["episodic"]:
+        _check_done(meta, d, done_p)
+
+
 def test_obs_layouts_agree_and_tail_block():
     import torch
 
