@@ -145,7 +145,7 @@ def cpu_baseline(w, budget_s=12.0):
     meta = dict(meta, tau=w["tau"])
     p = orc.params_from_meta(meta, solver=w["solver"], episodic=True)
     rng = np.random.default_rng(1234)
-    n_env, K = 64, 2000
+    n_env, K = 64, 1000
 
     def acts(n_env, K):
         if w["a_bytes"] == 1:
@@ -157,7 +157,7 @@ def cpu_baseline(w, budget_s=12.0):
     orc.rollout_many(p, a)
     t_probe = time.perf_counter() - t0
     scale = max(1, int(budget_s / max(t_probe, 1e-3)))
-    n_env2 = min(n_env * scale, 4096)
+    n_env2 = min(n_env * scale, 65536)
     a = acts(n_env2, K)
     t0 = time.perf_counter()
     orc.rollout_many(p, a)
@@ -244,8 +244,8 @@ def main():
                                   "device_ms_per_step": ms1, "achieved_GBps": n_local * b1 / (ms1 * 1e-3) / 1e9,
                                   "bytes_per_env_step": b1, "note": "one gemx_step launch per control step (launch-bound at this N)"}
             # the same kernel with the chip full
-            n_big = 2 ** 21
-            c_big = 50
+            n_big = 2 ** 20
+            c_big = 100
             envb = make_env(ga, w, n_big, local_rank)
             dtb, msb, c_big = measure(torch, dist, envb, w, n_big, 2 * c_big, c_big, c_big, device, 1, seed=7)
             envb.close()

@@ -148,7 +148,7 @@ template <class R> struct KArgs {
 constexpr int MAX_ACT_CHUNKS = 12;  // upper bound of 16-byte chunks of staged actions per lane and I/O block
 constexpr int MAX_STEPS_PER_BLOCK = 32;
 constexpr int PIPE_D = 8;           // pipelined kernel: control steps per hand-off block (one barrier per block)
-constexpr int PIPE_MAX_S = 8;       // pipelined kernel: max observation-ring depth
+constexpr int PIPE_OUT_WAVES = 2;   // pipelined kernel: output/store waves per workgroup (each owns PIPE_D / PIPE_OUT_WAVES rows)      // pipelined kernel: max observation-ring depth
 // chunks per lane needed to stage MAX_STEPS_PER_BLOCK steps of a row made of `cpr` 16-byte chunks
 __host__ __device__ constexpr int act_chunks(int cpr) {
     return (MAX_STEPS_PER_BLOCK * cpr + BLOCK - 1) / BLOCK < MAX_ACT_CHUNKS ? (MAX_STEPS_PER_BLOCK * cpr + BLOCK - 1) / BLOCK : MAX_ACT_CHUNKS;

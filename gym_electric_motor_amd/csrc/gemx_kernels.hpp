@@ -738,12 +738,11 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
 // Preconditions (checked by the launcher): full 64-env workgroups, 16-byte aligned tensors (coop), obs_every, K >= 2,
 // constraint kind none/default, S a multiple of PIPE_D.
 // ------------------------------------------------------------------------------------------------
-template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R>
-__global__ __launch_bounds__(2 * BLOCK) void advance_pipe_kernel(const KArgs<R> a) {
+template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R, int D>
+__global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_kernel(const KArgs<R> a) {
     constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
     constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
     constexpr bool HAS_ANGLE = SysTraits<SYS>::HAS_ANGLE;
-    constexpr int D = PIPE_D;
     using AngT = typename Angle<R>::T;
     using ST = Stepper<SYS, CONV, LOAD, SOLVER, IL, R>;
     constexpr int NH = ST::NH;
@@ -755,9 +754,9 @@ __global__ __launch_bounds__(2 * BLOCK) void advance_pipe_kernel(const KArgs<R> 
     const int64_t blk0 = (int64_t)blockIdx.x * BLOCK;
     const int64_t env = blk0 + tid;
     const int64_t N = a.N;
-    const int S = a.S, K = a.K;
+    const int K = a.K;
+    constexpr int S = D;              // the observation ring holds exactly one hand-off block
     const int nb = (K + D - 1) / D;   // hand-off blocks
-    const int RB = S / D;             // hand-off blocks per ring flush
 
     // LDS: observation ring [S][64*NOUT] R | done ring [S][64] | hand-off [2][D][64][NHT] R
     R *ring = reinterpret_cast<R *>(gemx_smem);
@@ -885,31 +884,36 @@ __global__ __launch_bounds__(2 * BLOCK) void advance_pipe_kernel(const KArgs<R> 
 #pragma unroll
             for (int j = 0; j < NHT; ++j) row[j] = src[j];
         };
-        auto process = [&](int pb) {  // observation rows of hand-off block pb -> ring; flush when the ring is full
+        // output wave `ow` of PIPE_OUT_WAVES owns rows [ow*RPW, (ow+1)*RPW) of every hand-off block: it turns them into
+        // observation rows in ITS part of the ring and flushes them itself -- the output waves never synchronise with
+        // each other, only with the integrator at the block barrier.
+        constexpr int RPW = D / PIPE_OUT_WAVES;
+        const int ow = wave - 1;
+        const int r0 = ow * RPW;
+        auto process = [&](int pb) {
             const int sb = steps_of(pb);
-            const int slot0 = (pb % RB) * D;
-            const R *hb = hand + (size_t)(pb & 1) * D * BLOCK * NHT + (size_t)tid * NHT;
+            const int nr = sb - r0 < RPW ? sb - r0 : RPW;  // rows of this wave in this block (may be <= 0 in the tail block)
+            if (nr <= 0) return;
+            const R *hb = hand + (size_t)(pb & 1) * D * BLOCK * NHT + (size_t)r0 * BLOCK * NHT + (size_t)tid * NHT;
             R rows[2][NHT];
             load_row(hb, rows[0]);
-            if (sb == D) {
+            if (nr == RPW) {
 #pragma unroll
-                for (int s = 0; s < D; ++s) {  // the next row's LDS reads are issued BEFORE this row's ring writes
-                    if (s + 1 < D) load_row(hb + (size_t)(s + 1) * BLOCK * NHT, rows[(s + 1) & 1]);
-                    one_row(rows[s & 1], slot0 + s);
+                for (int s = 0; s < RPW; ++s) {  // the next row's LDS reads are issued BEFORE this row's ring writes
+                    if (s + 1 < RPW) load_row(hb + (size_t)(s + 1) * BLOCK * NHT, rows[(s + 1) & 1]);
+                    one_row(rows[s & 1], r0 + s);
                 }
             } else {
 #pragma unroll
-                for (int s = 0; s < D; ++s) {
-                    if (s < sb) {
-                        if (s + 1 < sb) load_row(hb + (size_t)(s + 1) * BLOCK * NHT, rows[(s + 1) & 1]);
-                        one_row(rows[s & 1], slot0 + s);
+                for (int s = 0; s < RPW; ++s) {
+                    if (s < nr) {
+                        if (s + 1 < nr) load_row(hb + (size_t)(s + 1) * BLOCK * NHT, rows[(s + 1) & 1]);
+                        one_row(rows[s & 1], r0 + s);
                     }
                 }
             }
-            if ((pb % RB) == RB - 1 || pb == nb - 1) {
-                const int kbase = (pb - pb % RB) * D;
-                flush_rings<NOUT, R>(a, ring, donebuf, kbase, slot0 + sb, tid, blk0, BLOCK, true, true, env);
-            }
+            flush_rings<NOUT, R>(a, ring + (size_t)r0 * BLOCK * NOUT, donebuf + (size_t)r0 * BLOCK, pb * D + r0, nr, tid, blk0, BLOCK, true,
+                                 true, env);
         };
         for (int b = 0; b < nb; ++b) {
             if (b >= 1) process(b - 1);
@@ -972,31 +976,34 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     const int64_t blocks = (h->n + BLOCK - 1) / BLOCK;
     // two-wave pipelined kernel for small N (the chip is not full: a single wave per SIMD is issue-bound)
     const bool pipe_ok = h->use_pipe != 0 && K >= 2 && obs_every && a.coop && a.obs_vec && (h->n % BLOCK) == 0 &&
-                         params_of<R>(h).constr_kind <= 1 && h->cfg.solver_nsteps == 1 && (h->use_pipe > 0 || blocks <= 2 * (int64_t)h->n_cu);
+                         params_of<R>(h).constr_kind <= 1 && h->cfg.solver_nsteps == 1;
     if (pipe_ok) {
         using ST = Stepper<SYS, CONV, LOAD, SOLVER, IL, R>;
         constexpr int NHT = SysTraits<SYS>::ND + (SysTraits<SYS>::HAS_ANGLE ? 1 : 0) + ST::NH + 1;
-        const int64_t per_cu = blocks > h->n_cu ? 2 : 1;
-        const size_t budget = (h->lds_max - 512) / per_cu;
-        constexpr int D = PIPE_D;
-        const size_t fixed = 2 * (size_t)D * BLOCK * NHT * sizeof(R);
-        const size_t per_step = (size_t)BLOCK * h->nout * sizeof(R) + BLOCK;
-        int S = budget > fixed ? (int)((budget - fixed) / per_step) : 0;
-        if (h->steps_per_block > 0 && h->steps_per_block < S) S = h->steps_per_block;
-        if (S > PIPE_MAX_S) S = PIPE_MAX_S;
-        S = (S / D) * D;
-        if (S >= D) {
-            a.S = S;
+        // hand-off depth: 8 steps per barrier when one resident round of workgroups covers N, else 4 (half the LDS ->
+        // twice the resident workgroups).  Small-N regime only: at most two rounds of resident workgroups.
+        auto smem_of = [&](int D) {
+            size_t b = (size_t)D * BLOCK * h->nout * sizeof(R) + (size_t)D * BLOCK + 2 * (size_t)D * BLOCK * NHT * sizeof(R);
+            return (b + 15) & ~(size_t)15;
+        };
+        auto resident = [&](int D) {
+            int64_t w = (int64_t)(h->lds_max / smem_of(D));
+            const int64_t wmax = 32 / (1 + PIPE_OUT_WAVES);
+            return (w > wmax ? wmax : w) * (int64_t)h->n_cu;
+        };
+        const int D = (blocks <= resident(PIPE_D) || resident(PIPE_D / 2) == resident(PIPE_D)) ? PIPE_D : PIPE_D / 2;
+        if (smem_of(D) <= h->lds_max && (h->use_pipe > 0 || blocks <= 2 * resident(D))) {
+            a.S = D;
             a.D = D;
-            size_t psmem = (size_t)S * per_step + fixed;
-            psmem = (psmem + 15) & ~(size_t)15;
-            auto pkern = advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R>;
-            static bool pattr_set = false;
-            if (!pattr_set) {
+            const size_t psmem = smem_of(D);
+            auto pkern = D == PIPE_D ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D>
+                                     : advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D / 2>;
+            static bool pattr_set[2] = {false, false};
+            if (!pattr_set[D == PIPE_D]) {
                 GEMX_HIP_TRY(hipFuncSetAttribute((const void *)pkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max));
-                pattr_set = true;
+                pattr_set[D == PIPE_D] = true;
             }
-            hipLaunchKernelGGL(pkern, dim3((unsigned)blocks), dim3(2 * BLOCK), psmem, st, a);
+            hipLaunchKernelGGL(pkern, dim3((unsigned)blocks), dim3((1 + PIPE_OUT_WAVES) * BLOCK), psmem, st, a);
             GEMX_HIP_TRY(hipGetLastError());
             return GEMX_OK;
         }
