@@ -198,6 +198,7 @@ def main():
 
     env = make_env(ga, w, n_local, local_rank)
     dt, launch_ms, chunk = measure(torch, dist, env, w, n_local, K, W, args.chunk, device, world, seed=1234 + rank)
+    kernel_desc = env.physical_system.last_launch()
     env.close()
 
     if rank == 0:
@@ -229,7 +230,7 @@ def main():
                        "env_id": w["env_id"], "envs_per_gpu": n_local, "solver": w["solver"], "tau": w["tau"],
                        "steps_per_launch": chunk, "parallelism": f"env-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "kernel": "gemx::advance_kernel", "launch_ms": launch_ms,
+                         "traffic": traffic, "kernel": kernel_desc, "launch_ms": launch_ms,
                          "algorithmic_bytes_per_launch": launch_bytes, "bytes_per_env_step": b_step},
         }
         if not args.no_extras and world == 1:

@@ -45,7 +45,7 @@ EXPORTS = (
     "gemx_abi_version", "gemx_sizeof_config", "gemx_last_error", "gemx_device_count", "gemx_create", "gemx_destroy",
     "gemx_n_envs", "gemx_n_ode", "gemx_n_out", "gemx_n_action", "gemx_action_itemsize", "gemx_reset_observation",
     "gemx_reset", "gemx_step", "gemx_rollout", "gemx_get_state", "gemx_set_state", "gemx_get_switch_state",
-    "gemx_set_switch_state", "gemx_set_steps_per_block", "gemx_error_flags",
+    "gemx_set_switch_state", "gemx_set_steps_per_block", "gemx_last_launch", "gemx_error_flags",
 )
 
 
@@ -85,6 +85,8 @@ def load():
     L.gemx_get_switch_state.argtypes = [vp, vp, vp]
     L.gemx_set_switch_state.argtypes = [vp, vp, vp]
     L.gemx_set_steps_per_block.argtypes = [vp, i32]
+    L.gemx_last_launch.argtypes = [vp]
+    L.gemx_last_launch.restype = C.c_char_p
     L.gemx_error_flags.argtypes = [vp, C.POINTER(C.c_uint32), vp]
     if L.gemx_abi_version() != ABI_VERSION or L.gemx_sizeof_config() != C.sizeof(GemxConfig):
         raise GemxError("libgemx.so ABI does not match gym_electric_motor_amd._lib.GemxConfig; rebuild the library")

@@ -406,6 +406,7 @@ int gemx_set_switch_state(gemx_handle *h, const uint8_t *in_dev, void *stream) {
     HIP_TRY(hipMemcpyAsync(h->sw, in_dev, (size_t)h->n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return GEMX_OK;
 }
+const char *gemx_last_launch(const gemx_handle *h) { return h ? h->last_launch : ""; }
 int gemx_set_steps_per_block(gemx_handle *h, int32_t steps) {
     if (!h || steps < 0) return fail(GEMX_ERR_ARG, "invalid argument");
     h->steps_per_block = steps;

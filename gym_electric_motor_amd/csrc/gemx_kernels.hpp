@@ -21,6 +21,8 @@
 //     dead time, the default of every reference env) removes the current-sign logic and the second segment.
 //   * no MFMA: ~100-250 VALU ops and 25-117 bytes per env-step; the path is HBM / issue bound.
 #pragma once
+#include <cstdio>
+
 #include "gemx_common.hpp"
 
 namespace gemx {
@@ -1005,6 +1007,9 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             }
             hipLaunchKernelGGL(pkern, dim3((unsigned)blocks), dim3((1 + PIPE_OUT_WAVES) * BLOCK), psmem, st, a);
             GEMX_HIP_TRY(hipGetLastError());
+            snprintf(h->last_launch, sizeof(h->last_launch),
+                     "gemx::advance_pipe_kernel<sys=%d,conv=%d,load=%d,solver=%d,il=%d,%s,D=%d> grid=%lld x %d threads, lds=%zu B, K=%d",
+                     SYS, CONV, LOAD, SOLVER, (int)IL, sizeof(R) == 4 ? "f32" : "f64", D, (long long)blocks, (1 + PIPE_OUT_WAVES) * BLOCK, psmem, K);
             return GEMX_OK;
         }
     }
@@ -1016,6 +1021,9 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), smem, st, a);
     GEMX_HIP_TRY(hipGetLastError());
+    snprintf(h->last_launch, sizeof(h->last_launch),
+             "gemx::advance_kernel<sys=%d,conv=%d,load=%d,solver=%d,il=%d,%s> grid=%lld x %d threads, lds=%zu B, K=%d, S=%d", SYS, CONV, LOAD,
+             SOLVER, (int)IL, sizeof(R) == 4 ? "f32" : "f64", (long long)blocks, BLOCK, smem, K, a.S);
     return GEMX_OK;
 }
 

@@ -414,6 +414,10 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             return self._reset_obs.copy()
         return self._obs
 
+    def last_launch(self):
+        """Description of the kernel instantiation / geometry the last simulate() / rollout() launched."""
+        return self._L.gemx_last_launch(self._handle).decode()
+
     def check_errors(self):
         """Synchronises.  Raises like the reference (converters.py:204-206) if a discrete action left 0..7."""
         flags = C.c_uint32(0)

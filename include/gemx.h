@@ -131,6 +131,10 @@ int gemx_set_switch_state(gemx_handle *h, const uint8_t *in_dev, void *stream);
  * gemx_rollout (0 = heuristic from N, S_out and the LDS size; also settable with env GEMX_STEPS_PER_BLOCK). */
 int gemx_set_steps_per_block(gemx_handle *h, int32_t steps);
 
+/* Which kernel instantiation / geometry the most recent gemx_step / gemx_rollout on this handle launched (for
+ * profiling reports): e.g. "gemx::advance_pipe_kernel<sys=1,conv=1,load=0,solver=1,il=0,f32,D=8> grid=256 x 192 ...". */
+const char *gemx_last_launch(const gemx_handle *h);
+
 /* Sticky device error word (synchronises `stream`): bit 0 = a discrete action outside 0..7 was seen (the
  * reference asserts action_space.contains(action), converters.py:204-206; the kernel masks it to 0..7). */
 int gemx_error_flags(gemx_handle *h, uint32_t *flags_host, void *stream);
