@@ -406,7 +406,19 @@ int gemx_set_switch_state(gemx_handle *h, const uint8_t *in_dev, void *stream) {
     HIP_TRY(hipMemcpyAsync(h->sw, in_dev, (size_t)h->n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return GEMX_OK;
 }
-const char *gemx_last_launch(const gemx_handle *h) { return h ? h->last_launch : ""; }
+const char *gemx_last_launch(const gemx_handle *h) {
+    if (!h) return "";
+    const auto &l = h->ll;
+    if (l.pipe)
+        snprintf(h->last_launch, sizeof(h->last_launch),
+                 "gemx::advance_pipe_kernel<sys=%d,conv=%d,load=%d,solver=%d,il=%d,%s,D=%d> grid=%lld x %d threads, lds=%zu B, K=%d", l.sys,
+                 l.conv, l.load, l.solver, l.il, l.real_size == 4 ? "f32" : "f64", l.d, l.blocks, l.threads, l.lds, l.k);
+    else
+        snprintf(h->last_launch, sizeof(h->last_launch),
+                 "gemx::advance_kernel<sys=%d,conv=%d,load=%d,solver=%d,il=%d,%s> grid=%lld x %d threads, lds=%zu B, K=%d, S=%d", l.sys, l.conv,
+                 l.load, l.solver, l.il, l.real_size == 4 ? "f32" : "f64", l.blocks, l.threads, l.lds, l.k, l.s);
+    return h->last_launch;
+}
 int gemx_set_steps_per_block(gemx_handle *h, int32_t steps) {
     if (!h || steps < 0) return fail(GEMX_ERR_ARG, "invalid argument");
     h->steps_per_block = steps;

@@ -176,7 +176,9 @@ struct gemx_handle {
     int n_cu = 256;
     size_t lds_max = 160 * 1024;
     int steps_per_block = 0;  // 0 = heuristic
-    char last_launch[256] = "";  // description of the most recent advance launch (gemx_last_launch)
+    struct LastLaunch { int pipe, sys, conv, load, solver, il, real_size, d, threads, k, s; long long blocks; size_t lds; };
+    LastLaunch ll = {};            // most recent advance launch (formatted lazily by gemx_last_launch)
+    mutable char last_launch[256] = "";
     int use_pipe = -1;        // two-wave pipelined kernel: -1 auto (small N only), 0 never, 1 whenever eligible
 };
 

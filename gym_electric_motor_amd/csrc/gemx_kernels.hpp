@@ -1007,9 +1007,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             }
             hipLaunchKernelGGL(pkern, dim3((unsigned)blocks), dim3((1 + PIPE_OUT_WAVES) * BLOCK), psmem, st, a);
             GEMX_HIP_TRY(hipGetLastError());
-            snprintf(h->last_launch, sizeof(h->last_launch),
-                     "gemx::advance_pipe_kernel<sys=%d,conv=%d,load=%d,solver=%d,il=%d,%s,D=%d> grid=%lld x %d threads, lds=%zu B, K=%d",
-                     SYS, CONV, LOAD, SOLVER, (int)IL, sizeof(R) == 4 ? "f32" : "f64", D, (long long)blocks, (1 + PIPE_OUT_WAVES) * BLOCK, psmem, K);
+            h->ll = {1, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), D, (1 + PIPE_OUT_WAVES) * BLOCK, K, D, (long long)blocks, psmem};
             return GEMX_OK;
         }
     }
@@ -1021,9 +1019,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), smem, st, a);
     GEMX_HIP_TRY(hipGetLastError());
-    snprintf(h->last_launch, sizeof(h->last_launch),
-             "gemx::advance_kernel<sys=%d,conv=%d,load=%d,solver=%d,il=%d,%s> grid=%lld x %d threads, lds=%zu B, K=%d, S=%d", SYS, CONV, LOAD,
-             SOLVER, (int)IL, sizeof(R) == 4 ? "f32" : "f64", (long long)blocks, BLOCK, smem, K, a.S);
+    h->ll = {0, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), 0, BLOCK, K, a.S, (long long)blocks, smem};
     return GEMX_OK;
 }
 

@@ -316,6 +316,7 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         shape = (self._n_envs, self._n_out) if self._obs_layout == "aos" else (self._n_out, self._n_envs)
         self._obs = torch.empty(shape, dtype=self._tdtype, device=self._tdev)
         self._done = torch.zeros(self._n_envs, dtype=torch.uint8, device=self._tdev)
+        self._obs_ptr, self._done_ptr = self._obs.data_ptr(), self._done.data_ptr()
         ro = (C.c_double * _lib.MAX_OUT)()
         _lib.check(L.gemx_reset_observation(h, ro))
         self._reset_obs = np.array(ro[: self._n_out], dtype=float)
@@ -337,6 +338,13 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
     def _actions_to_device(self, actions, leading):
         """-> contiguous device tensor of shape leading + (A,) (float R) or leading (uint8)."""
         torch = _torch()
+        want_dtype = torch.uint8 if self._discrete else self._tdtype
+        if torch.is_tensor(actions) and actions.dtype == want_dtype and actions.device == self._tdev and actions.is_contiguous():
+            n = 1
+            for d in leading:
+                n *= d
+            if actions.numel() == n * (1 if self._discrete else self._n_act):
+                return actions  # fast path: already what the kernel reads (no torch ops on the hot path)
         if self._discrete:
             if not torch.is_tensor(actions):
                 arr = np.asarray(actions)
@@ -371,8 +379,10 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             assert self.action_space.contains(action), (  # converters.py:204-206
                 f"The selected action {action} is not a valid element of the action space {self.action_space}.")
         a = self._actions_to_device(action, (self._n_envs,))
-        _lib.check(self._L.gemx_step(self._handle, C.c_void_p(a.data_ptr()), C.c_void_p(self._obs.data_ptr()),
-                                     C.c_void_p(self._done.data_ptr()), self._stream()))
+        rc = self._L.gemx_step(self._handle, a.data_ptr(), self._obs_ptr, self._done_ptr,
+                               _torch().cuda.current_stream(self._tdev).cuda_stream)
+        if rc:
+            _lib.check(rc)
         self._k += 1
         if single:
             return self._obs.reshape(-1).double().cpu().numpy()
