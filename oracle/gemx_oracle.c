@@ -33,8 +33,9 @@
 #include <stdint.h>
 #include <string.h>
 
-enum { ORC_SYS_DC_PERMEX = 0, ORC_SYS_PMSM = 1, ORC_SYS_SCIM = 2 };
-enum { ORC_CONV_CONT_4QC = 0, ORC_CONV_FINITE_B6 = 1, ORC_CONV_CONT_B6 = 2 };
+enum { ORC_SYS_DC_PERMEX = 0, ORC_SYS_PMSM = 1, ORC_SYS_SCIM = 2, ORC_SYS_DC_SERIES = 3, ORC_SYS_DC_SHUNT = 4 };
+enum { ORC_CONV_CONT_4QC = 0, ORC_CONV_FINITE_B6 = 1, ORC_CONV_CONT_B6 = 2, ORC_CONV_FINITE_4QC = 3 };
+#define ORC_IS_DC(s) ((s) == ORC_SYS_DC_PERMEX || (s) == ORC_SYS_DC_SERIES || (s) == ORC_SYS_DC_SHUNT)
 enum { ORC_LOAD_CONST_SPEED = 0, ORC_LOAD_POLY_STATIC = 1 };
 enum { ORC_SOLVER_EULER = 0, ORC_SOLVER_RK4 = 1, ORC_SOLVER_DOPRI5 = 2, ORC_SOLVER_DP5_FIXED = 3 };
 
@@ -47,7 +48,8 @@ typedef struct orc_params {
     int32_t squared_mask; /* bit i set: SquaredConstraint sums entry i                   (constraints.py:96-98) */
     int32_t reserved;
     double tau, t_il, u_sup;
-    double mp[8]; /* DC: r_a,l_a,psi_e | PMSM: p,l_d,l_q,r_s,psi_p | SCIM: p,l_m,l_sigs,l_sigr,r_s,r_r */
+    double mp[8]; /* DC permex: r_a,l_a,psi_e | PMSM/SynRM: p,l_d,l_q,r_s,psi_p(0 for SynRM) | SCIM: p,l_m,l_sigs,l_sigr,r_s,r_r
+                   * DC series / shunt: r_a,r_e,l_a,l_e,l_e_prime */
     double j_total, load_a, load_b, load_c, tau_decay;
     double limits[ORC_MAX_OUT];
     double init[ORC_MAX_ODE]; /* initial ODE state [omega, motor states...] */
@@ -70,8 +72,16 @@ typedef struct orc_env {
     double C[5][11];
 } orc_env;
 
-static int n_ode(const orc_params *p) { return p->system == ORC_SYS_DC_PERMEX ? 2 : (p->system == ORC_SYS_PMSM ? 4 : 6); }
-static int n_out(const orc_params *p) { return p->system == ORC_SYS_DC_PERMEX ? 5 : 14; }
+static int n_ode(const orc_params *p) {
+    switch (p->system) {
+        case ORC_SYS_DC_PERMEX: case ORC_SYS_DC_SERIES: return 2;
+        case ORC_SYS_DC_SHUNT: return 3;
+        case ORC_SYS_PMSM: return 4;
+        default: return 6;
+    }
+}
+/* state names: DcMotorSystem._build_state_names (physical_systems.py:295-303): [omega, torque] + CURRENTS + VOLTAGES + [u_sup] */
+static int n_out(const orc_params *p) { return p->system == ORC_SYS_DC_SHUNT ? 6 : (ORC_IS_DC(p->system) ? 5 : 14); }
 
 int orc_n_ode(const orc_params *p) { return n_ode(p); }
 int orc_n_out(const orc_params *p) { return n_out(p); }
@@ -85,6 +95,13 @@ void orc_model_constants(const orc_params *p, double C[5][11]) {
     if (p->system == ORC_SYS_DC_PERMEX) {
         double r_a = mp[0], l_a = mp[1], psi_e = mp[2];
         C[0][0] = -psi_e / l_a; C[0][1] = -r_a / l_a; C[0][2] = 1.0 / l_a;
+    } else if (p->system == ORC_SYS_DC_SERIES) { /* dc_series_motor.py:68-72, features [i, omega*i, u] */
+        double r_a = mp[0], r_e = mp[1], l_a = mp[2], l_e = mp[3], lep = mp[4];
+        C[0][0] = (-r_a - r_e) / (l_a + l_e); C[0][1] = -lep / (l_a + l_e); C[0][2] = 1.0 / (l_a + l_e);
+    } else if (p->system == ORC_SYS_DC_SHUNT) { /* dc_motor.py:96-104, features [i_a, i_e, omega*i_e, u_a, u_e] */
+        double r_a = mp[0], r_e = mp[1], l_a = mp[2], l_e = mp[3], lep = mp[4];
+        C[0][0] = -r_a / l_a; C[0][2] = -lep / l_a; C[0][3] = 1.0 / l_a;
+        C[1][1] = -r_e / l_e; C[1][4] = 1.0 / l_e;
     } else if (p->system == ORC_SYS_PMSM) {
         double pp = mp[0], l_d = mp[1], l_q = mp[2], r_s = mp[3], psi_p = mp[4];
         /*            omega,         i_d,   i_q, u_d, u_q, omega*i_d,  omega*i_q */
@@ -115,6 +132,8 @@ void orc_model_constants(const orc_params *p, double C[5][11]) {
 static double motor_torque(const orc_params *p, const double *ms) {
     const double *mp = p->mp;
     if (p->system == ORC_SYS_DC_PERMEX) return mp[2] * ms[0];
+    if (p->system == ORC_SYS_DC_SERIES) return mp[4] * ms[0] * ms[0]; /* dc_series_motor.py:74-76 -> dc_motor.py:106-108 */
+    if (p->system == ORC_SYS_DC_SHUNT) return mp[4] * ms[0] * ms[1];  /* dc_motor.py:106-108 */
     if (p->system == ORC_SYS_PMSM) return 1.5 * mp[0] * (mp[4] + (mp[1] - mp[2]) * ms[0]) * ms[1];
     return 1.5 * mp[0] * mp[1] / (mp[1] + mp[3]) * (ms[2] * ms[1] - ms[3] * ms[0]);
 }
@@ -127,6 +146,10 @@ static void electrical_ode(const orc_params *p, const orc_env *e, const double *
     int nf, nr;
     if (p->system == ORC_SYS_DC_PERMEX) {
         f[0] = omega; f[1] = ms[0]; f[2] = u[0]; nf = 3; nr = 1;
+    } else if (p->system == ORC_SYS_DC_SERIES) { /* dc_series_motor.py:78-83 */
+        f[0] = ms[0]; f[1] = omega * ms[0]; f[2] = u[0]; nf = 3; nr = 1;
+    } else if (p->system == ORC_SYS_DC_SHUNT) { /* dc_shunt_motor.py:72-74: u_a = u_e = u; dc_motor.py:114-127 */
+        f[0] = ms[0]; f[1] = ms[1]; f[2] = omega * ms[1]; f[3] = u[0]; f[4] = u[0]; nf = 5; nr = 2;
     } else if (p->system == ORC_SYS_PMSM) {
         f[0] = omega; f[1] = ms[0]; f[2] = ms[1]; f[3] = u[0]; f[4] = u[1]; f[5] = omega * ms[0]; f[6] = omega * ms[1];
         nf = 7; nr = 3;
@@ -279,8 +302,10 @@ static void integrate(const orc_params *p, orc_env *e, double t_end) {
                 for (int i = 0; i < n; ++i) e->y[i] = e->y[i] + k1[i] * h;
             }
         }
-    } else if (p->solver == ORC_SOLVER_RK4) { /* classical RK4; the reference has none */
-        double h = t_end - e->t;
+    } else if (p->solver == ORC_SOLVER_RK4) { /* classical RK4 with nsteps sub-steps; the reference has none */
+        int ns = p->nsteps > 1 ? p->nsteps : 1;
+        double h = (t_end - e->t) / ns;
+        for (int sub = 0; sub < ns; ++sub) {
         system_equation(p, e, e->y, k1);
         for (int i = 0; i < n; ++i) yt[i] = e->y[i] + 0.5 * h * k1[i];
         system_equation(p, e, yt, k2);
@@ -289,6 +314,7 @@ static void integrate(const orc_params *p, orc_env *e, double t_end) {
         for (int i = 0; i < n; ++i) yt[i] = e->y[i] + h * k3[i];
         system_equation(p, e, yt, k4);
         for (int i = 0; i < n; ++i) e->y[i] = e->y[i] + h / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+        }
     } else { /* ORC_SOLVER_DP5_FIXED: one Dormand-Prince step, 5th-order solution, no error control */
         double h = t_end - e->t;
         system_equation(p, e, e->y, k1);
@@ -381,6 +407,16 @@ static int conv_set_action(const orc_params *p, orc_env *e, const double *action
         seg_end[0] = t + p->tau;
         return 1;
     }
+    if (p->converter == ORC_CONV_FINITE_4QC) { /* FiniteFourQuadrantConverter.set_action, converters.py:354-364 */
+        static const int A0[4] = {1, 1, 2, 2}, A1[4] = {1, 2, 1, 2};
+        int a4 = (int)action[0];
+        int two4 = 0;
+        if (fin2qc_set_action(p, e, 0, A0[a4]) == 2) two4 = 1;
+        if (fin2qc_set_action(p, e, 1, A1[a4]) == 2) two4 = 1;
+        if (two4) { seg_end[0] = t + p->t_il; seg_end[1] = t + p->tau; return 2; }
+        seg_end[0] = t + p->tau;
+        return 1;
+    }
     /* Finite-B6C, converters.py:825-835: union of the legs' switching times, sorted */
     int a = (int)action[0];
     int two = 0;
@@ -397,6 +433,8 @@ static void conv_convert(const orc_params *p, orc_env *e, const double *i_in, do
         u[0] = cont2qc_convert(p, e->duty[0][0], i_in[0]) - cont2qc_convert(p, e->duty[0][1], i_in[0]);
     } else if (p->converter == ORC_CONV_CONT_B6) { /* converters.py:888-895 */
         for (int l = 0; l < 3; ++l) u[l] = cont2qc_convert(p, e->duty[l][0], i_in[l]) - 0.5;
+    } else if (p->converter == ORC_CONV_FINITE_4QC) { /* converters.py:350-352: second leg sees -i_out */
+        u[0] = fin2qc_convert(p, e, 0, i_in[0], t) - fin2qc_convert(p, e, 1, -i_in[0], t);
     } else { /* converters.py:816-823 */
         for (int l = 0; l < 3; ++l) u[l] = fin2qc_convert(p, e, l, i_in[l], t) - 0.5;
     }
@@ -404,7 +442,7 @@ static void conv_convert(const orc_params *p, orc_env *e, const double *i_in, do
 
 static void conv_reset(const orc_params *p, orc_env *e, double *u) {
     e->action_start = 0.0; /* converters.py:45-54; switching state/pattern intentionally untouched */
-    if (p->converter == ORC_CONV_CONT_4QC) u[0] = 0.0;
+    if (p->converter == ORC_CONV_CONT_4QC || p->converter == ORC_CONV_FINITE_4QC) u[0] = 0.0; /* converters.py:344-348, 475-479 */
     else { u[0] = u[1] = u[2] = -0.5; } /* converters.py:808-814, 880-886 */
 }
 
@@ -421,11 +459,15 @@ static void normalise(const orc_params *p, double *obs) {
     for (int i = 0; i < n; ++i) obs[i] = obs[i] / p->limits[i];
 }
 
-/* SCMLSystem.simulate (DC), physical_systems.py:171-203 */
+/* SCMLSystem.simulate (DC motors), physical_systems.py:171-203.  i_in = motor.i_in(currents): the current itself
+ * (dc_permanently_excited_motor.py:77-79, dc_series_motor.py:85-87) or i_a + i_e (dc_shunt_motor.py:68-70). */
+static double dc_i_in(const orc_params *p, const orc_env *e) {
+    return p->system == ORC_SYS_DC_SHUNT ? e->y[1] + e->y[2] : e->y[1];
+}
 static void simulate_dc(const orc_params *p, orc_env *e, const double *action, double *obs) {
     double seg_end[2], i_in[1], u_n[1], u_in[1];
     double u_sup = p->u_sup; /* IdealVoltageSupply.get_voltage, voltage_supplies.py:70-72 */
-    i_in[0] = e->y[1];
+    i_in[0] = dc_i_in(p, e);
     int nseg = conv_set_action(p, e, action, e->t, seg_end);
     double t0 = e->t;
     for (int s = 0; s < nseg; ++s) {
@@ -433,10 +475,13 @@ static void simulate_dc(const orc_params *p, orc_env *e, const double *action, d
         u_in[0] = u_n[0] * u_sup;
         e->u[0] = u_in[0];
         integrate(p, e, s == nseg - 1 ? t0 + p->tau : seg_end[s]);
-        i_in[0] = e->y[1];
+        i_in[0] = dc_i_in(p, e);
     }
     e->k += 1;
-    obs[0] = e->y[0]; obs[1] = motor_torque(p, e->y + 1); obs[2] = e->y[1]; obs[3] = u_in[0]; obs[4] = u_sup;
+    int nc = n_ode(p) - 1;
+    obs[0] = e->y[0]; obs[1] = motor_torque(p, e->y + 1);
+    for (int c = 0; c < nc; ++c) obs[2 + c] = e->y[1 + c];
+    obs[2 + nc] = u_in[0]; obs[3 + nc] = u_sup;
     normalise(p, obs);
 }
 
@@ -511,8 +556,11 @@ void orc_reset(const orc_params *p, orc_env *e, double *obs) {
     double u_sup = p->u_sup;
     conv_reset(p, e, u_n);
     double torque = motor_torque(p, e->y + 1);
-    if (p->system == ORC_SYS_DC_PERMEX) {
-        obs[0] = e->y[0]; obs[1] = torque; obs[2] = e->y[1]; obs[3] = u_n[0] * u_sup; obs[4] = u_sup;
+    if (ORC_IS_DC(p->system)) {
+        int nc = n - 1;
+        obs[0] = e->y[0]; obs[1] = torque;
+        for (int c = 0; c < nc; ++c) obs[2 + c] = e->y[1 + c];
+        obs[2 + nc] = u_n[0] * u_sup; obs[3 + nc] = u_sup;
     } else if (p->system == ORC_SYS_PMSM) {
         double eps = e->y[3];
         if (eps > M_PI) eps -= 2.0 * M_PI;
@@ -538,7 +586,7 @@ void orc_reset(const orc_params *p, orc_env *e, double *obs) {
 }
 
 void orc_step(const orc_params *p, orc_env *e, const double *action, double *obs) {
-    if (p->system == ORC_SYS_DC_PERMEX) simulate_dc(p, e, action, obs);
+    if (ORC_IS_DC(p->system)) simulate_dc(p, e, action, obs);
     else if (p->system == ORC_SYS_PMSM) simulate_pmsm(p, e, action, obs);
     else simulate_scim(p, e, action, obs);
 }

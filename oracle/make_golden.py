@@ -57,19 +57,20 @@ def gen_actions(space_kind, K, seed, mode):
         shape, disc = (K, 1), False
     elif space_kind == "box3":
         shape, disc = (K, 3), False
-    elif space_kind == "disc8":
+    elif space_kind in ("disc8", "disc4"):
         shape, disc = (K,), True
     else:
         raise KeyError(space_kind)
+    nact = 4 if space_kind == "disc4" else 8
     if mode == "uniform":
-        return rng.integers(0, 8, shape).astype(np.int64) if disc else rng.uniform(-1, 1, shape)
+        return rng.integers(0, nact, shape).astype(np.int64) if disc else rng.uniform(-1, 1, shape)
     # held
     out = np.zeros(shape, dtype=np.int64 if disc else np.float64)
     k = 0
     while k < K:
         dwell = int(rng.integers(1, 40))
         if disc:
-            v = rng.integers(0, 8)
+            v = rng.integers(0, nact)
         else:
             v = rng.uniform(-1, 1, shape[1:]) * rng.uniform(0.0, 1.0)
         out[k : k + dwell] = v
@@ -112,15 +113,19 @@ def run_case(name, env_id, solver, K, seed, mode, episodic, space_kind, every=1,
         kw["constraints"] = ()
     env = gem.make(env_id, **kw)
     (s0, _), _ = env.reset(seed=0)
+    # physical-system wrappers that only post-process the observation (e.g. the shunt envs' CurrentSumProcessor, which
+    # appends 'i_sum') are outside the path: keep the columns of the unwrapped physical system
+    n_keep = len(env.physical_system.unwrapped.state_names)
+    s0 = s0[:n_keep]
     actions = gen_actions(space_kind, K, seed, mode)
     states = np.zeros((K, len(s0)))
     term = np.zeros(K, dtype=bool)
     for k in range(K):
         a = actions[k]
-        if space_kind == "disc8":
+        if space_kind.startswith("disc"):
             a = int(a)
         (s, _), _, terminated, _, _ = env.step(a)
-        states[k] = s
+        states[k] = s[:n_keep]
         term[k] = terminated
         if terminated:
             env.reset()
@@ -131,7 +136,7 @@ def run_case(name, env_id, solver, K, seed, mode, episodic, space_kind, every=1,
     keep = idx[(idx % every == every - 1)] if every > 1 else idx
     np.savez_compressed(
         os.path.join(OUT, name + ".npz"),
-        actions=actions.astype(np.uint8) if space_kind == "disc8" else actions,
+        actions=actions.astype(np.uint8) if space_kind.startswith("disc") else actions,
         states=states[keep],
         state_index=keep.astype(np.int64),
         terminated=term,
@@ -245,6 +250,30 @@ def converter_kats():
         out[f"fb6_til{t_il:g}_volt"] = volt
         out["fb6_actions"] = acts
         out["fb6_currents"] = curr
+    # Finite-4QC (converters.py:313-368) driven as SCMLSystem.simulate does, incl. dead time and reset()
+    acts4 = rng.integers(0, 4, 200)
+    curr4 = rng.uniform(-1, 1, (200, 2))
+    for t_il in (0.0, 1e-6):
+        tau = 1e-5
+        conv = ps.FiniteFourQuadrantConverter(tau=tau, interlocking_time=t_il)
+        conv.reset()
+        nseg = np.zeros(200, dtype=np.int64)
+        volt = np.zeros((200, 2))
+        t = 0.0
+        for k in range(200):
+            times = conv.set_action(int(acts4[k]), t)
+            nseg[k] = len(times)
+            t_seg = t
+            for sgm, t_sw in enumerate(times):
+                volt[k, sgm] = conv.convert([curr4[k, sgm]], t_seg)[0]
+                t_seg = t_sw
+            t = t + tau
+            if k == 100:
+                conv.reset()
+        out[f"f4qc_til{t_il:g}_nseg"] = nseg
+        out[f"f4qc_til{t_il:g}_volt"] = volt
+    out["f4qc_actions"] = acts4
+    out["f4qc_currents"] = curr4
     np.savez_compressed(os.path.join(OUT, "converter_kats.npz"), **out)
     print("converter KATs written")
 
@@ -292,6 +321,31 @@ def main():
     run_case("scim_free_held_til_euler", scim, "euler", K, 1235, "held", False, "box3",
              converter=dict(interlocking_time=2e-6))
     run_case("scim_free_uniform_10k_dopri5", scim, "dopri5", 10000, 1234, "uniform", False, "box3", every=10)
+    # --- further motors / converters on the same kernel skeleton ----------------------
+    for solver in ("euler", "dopri5"):
+        run_case(f"synrm_fin_free_held_{solver}", "Finite-CC-SynRM-v0", solver, K, 1240, "held", False, "disc8")
+        run_case(f"synrm_cont_sc_free_held_{solver}", "Cont-SC-SynRM-v0", solver, K, 1241, "held", False, "box3")
+        run_case(f"permexdc_fin_free_held_{solver}", "Finite-CC-PermExDc-v0", solver, K, 1242, "held", False, "disc4")
+        run_case(f"series_cont_free_held_{solver}", "Cont-CC-SeriesDc-v0", solver, K, 1243, "held", False, "box1")
+        run_case(f"series_cont_sc_free_held_{solver}", "Cont-SC-SeriesDc-v0", solver, K, 1244, "held", False, "box1")
+        run_case(f"shunt_cont_free_held_{solver}", "Cont-CC-ShuntDc-v0", solver, K, 1245, "held", False, "box1")
+        run_case(f"shunt_cont_sc_free_held_{solver}", "Cont-SC-ShuntDc-v0", solver, K, 1246, "held", False, "box1")
+    run_case("synrm_fin_epi_held_tau1e-4_euler", "Finite-CC-SynRM-v0", "euler", 4000, 1247, "held", True, "disc8", tau=1e-4)
+    # uniform actions: with "held" actions the run starts with a long zero-vector phase at exactly zero current, where the
+    # reference's freewheeling-diode direction in the dead state is decided by ~1e-18 A of matmul rounding noise
+    run_case("synrm_fin_free_uniform_til_euler", "Finite-CC-SynRM-v0", "euler", K, 1240, "uniform", False, "disc8",
+             converter=dict(interlocking_time=1e-6))
+    run_case("permexdc_fin_free_held_til_euler", "Finite-CC-PermExDc-v0", "euler", K, 1242, "held", False, "disc4",
+             converter=dict(interlocking_time=1e-6))
+    run_case("permexdc_fin_free_uniform_til_euler", "Finite-CC-PermExDc-v0", "euler", K, 1248, "uniform", False, "disc4",
+             converter=dict(interlocking_time=1e-6))
+    run_case("permexdc_fin_epi_held_euler", "Finite-CC-PermExDc-v0", "euler", K, 1249, "held", True, "disc4")
+    run_case("series_fin_free_held_til_euler", "Finite-CC-SeriesDc-v0", "euler", K, 1250, "held", False, "disc4",
+             converter=dict(interlocking_time=1e-6))
+    run_case("series_cont_epi_held_euler", "Cont-CC-SeriesDc-v0", "euler", K, 1251, "held", True, "box1")
+    run_case("shunt_fin_free_held_til_euler", "Finite-CC-ShuntDc-v0", "euler", K, 1252, "held", False, "disc4",
+             converter=dict(interlocking_time=1e-6))
+    run_case("shunt_cont_epi_held_euler", "Cont-CC-ShuntDc-v0", "euler", K, 1253, "held", True, "box1")
 
 
 if __name__ == "__main__":

@@ -13,8 +13,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgemx_oracle.so")
 
-SYS_DC, SYS_PMSM, SYS_SCIM = 0, 1, 2
-CONV_C4QC, CONV_FB6, CONV_CB6 = 0, 1, 2
+SYS_DC, SYS_PMSM, SYS_SCIM, SYS_DC_SERIES, SYS_DC_SHUNT = 0, 1, 2, 3, 4
+CONV_C4QC, CONV_FB6, CONV_CB6, CONV_F4QC = 0, 1, 2, 3
 LOAD_CONST, LOAD_POLY = 0, 1
 SOLVER_EULER, SOLVER_RK4, SOLVER_DOPRI5, SOLVER_DP5_FIXED = 0, 1, 2, 3
 
@@ -59,12 +59,15 @@ def lib():
 
 
 _SYS = {"DcMotorSystem": SYS_DC, "SynchronousMotorSystem": SYS_PMSM, "SquirrelCageInductionMotorSystem": SYS_SCIM}
-_CONV = {"ContFourQuadrantConverter": CONV_C4QC, "FiniteB6BridgeConverter": CONV_FB6, "ContB6BridgeConverter": CONV_CB6}
+_CONV = {"ContFourQuadrantConverter": CONV_C4QC, "FiniteB6BridgeConverter": CONV_FB6, "ContB6BridgeConverter": CONV_CB6,
+         "FiniteFourQuadrantConverter": CONV_F4QC}
+_DC_MOTOR_SYS = {"DcPermanentlyExcitedMotor": SYS_DC, "DcSeriesMotor": SYS_DC_SERIES, "DcShuntMotor": SYS_DC_SHUNT}
 _LOAD = {"ConstantSpeedLoad": LOAD_CONST, "PolynomialStaticLoad": LOAD_POLY}
-_SOLVER = {"euler": (SOLVER_EULER, 1), "euler4": (SOLVER_EULER, 4), "rk4": (SOLVER_RK4, 1),
+_SOLVER = {"euler": (SOLVER_EULER, 1), "euler4": (SOLVER_EULER, 4), "rk4": (SOLVER_RK4, 1), "rk4x4": (SOLVER_RK4, 4), "rk4x8": (SOLVER_RK4, 8),
            "dopri5": (SOLVER_DOPRI5, 1), "ivp_tight": (SOLVER_DOPRI5, 1), "dp5_fixed": (SOLVER_DP5_FIXED, 1)}
 _MP_KEYS = {SYS_DC: ("r_a", "l_a", "psi_e"), SYS_PMSM: ("p", "l_d", "l_q", "r_s", "psi_p"),
-            SYS_SCIM: ("p", "l_m", "l_sigs", "l_sigr", "r_s", "r_r")}
+            SYS_SCIM: ("p", "l_m", "l_sigs", "l_sigr", "r_s", "r_r"),
+            SYS_DC_SERIES: ("r_a", "r_e", "l_a", "l_e", "l_e_prime"), SYS_DC_SHUNT: ("r_a", "r_e", "l_a", "l_e", "l_e_prime")}
 
 
 def default_masks(meta):
@@ -73,6 +76,8 @@ def default_masks(meta):
     (finite_cc_pmsm_env.py:106, cont_sc_scim_env.py:111)."""
     names = meta["state_names"]
     if meta["system"] == "DcMotorSystem":
+        if meta["motor"] == "DcShuntMotor":  # constraints=("i_a", "i_e"), cont_cc_shunt_dc_env.py:103
+            return (1 << names.index("i_a")) | (1 << names.index("i_e")), 0
         return 1 << names.index("i"), 0
     return 0, (1 << names.index("i_sd")) | (1 << names.index("i_sq"))
 
@@ -83,6 +88,8 @@ def params_from_meta(meta, solver=None, episodic=None):
         meta = json.loads(str(meta))
     p = OrcParams()
     p.system = _SYS[meta["system"]]
+    if meta["system"] == "DcMotorSystem":
+        p.system = _DC_MOTOR_SYS[meta["motor"]]
     p.converter = _CONV[meta["converter"]]
     p.load = _LOAD[meta["load"]]
     p.solver, p.nsteps = _SOLVER[solver or meta["solver"]]
@@ -91,7 +98,7 @@ def params_from_meta(meta, solver=None, episodic=None):
         p.limit_mask, p.squared_mask = default_masks(meta)
     p.tau, p.t_il, p.u_sup = meta["tau"], meta["interlocking_time"], meta["u_nominal"]
     for i, k in enumerate(_MP_KEYS[p.system]):
-        p.mp[i] = meta["motor_parameter"][k]
+        p.mp[i] = meta["motor_parameter"].get(k, 0.0)  # SynchronousReluctanceMotor has no psi_p (-> 0)
     p.j_total = meta["j_total"]
     lp = meta.get("load_parameter", {})
     p.load_a, p.load_b, p.load_c = lp.get("a", 0.0), lp.get("b", 0.0), lp.get("c", 0.0)
