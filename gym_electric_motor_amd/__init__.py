@@ -9,14 +9,18 @@ from .components import (  # noqa: F401
     ContB6BridgeConverter,
     ContFourQuadrantConverter,
     DcPermanentlyExcitedMotor,
+    DcSeriesMotor,
+    DcShuntMotor,
     DormandPrince5Solver,
     EulerSolver,
     FiniteB6BridgeConverter,
+    FiniteFourQuadrantConverter,
     IdealVoltageSupply,
     PermanentMagnetSynchronousMotor,
     PolynomialStaticLoad,
     RK4Solver,
     SquirrelCageInductionMotor,
+    SynchronousReluctanceMotor,
 )
 from .envs import BatchedElectricMotorEnv, make  # noqa: F401
 from .physical_systems import (  # noqa: F401

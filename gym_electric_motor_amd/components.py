@@ -94,6 +94,17 @@ class FiniteB6BridgeConverter(_Converter):
         super().__init__(tau, interlocking_time)
 
 
+class FiniteFourQuadrantConverter(_Converter):
+    """Key 'Finite-4QC', converters.py:313-368 (actions 0..3: T2T4 / T1T4 / T2T3 / T1T3)."""
+
+    voltages = Box(-1, 1, shape=(1,), dtype=np.float64)
+    currents = Box(-1, 1, shape=(1,), dtype=np.float64)
+    action_space = Discrete(4)
+
+    def __init__(self, tau=1e-5, interlocking_time=0.0):
+        super().__init__(tau, interlocking_time)
+
+
 # ------------------------------------------------------------------------------------------------- solvers
 class EulerSolver:
     """solvers.py:79-136."""
@@ -183,6 +194,84 @@ class DcPermanentlyExcitedMotor(_ElectricMotor):
     def initial_motor_state(self):
         return [float(self._initial_states.get("i", 0.0))]
 
+    def get_state_space(self, input_currents, input_voltages):
+        """dc_permanently_excited_motor.py:107-120."""
+        lc, lv = input_currents.low[0] == -1, input_voltages.low[0] == -1
+        low = {"omega": -1 if lv else 0, "torque": -1 if lc else 0, "i": -1 if lc else 0, "u": -1 if lv else 0}
+        return low, {"omega": 1, "torque": 1, "i": 1, "u": 1}
+
+
+class DcSeriesMotor(_ElectricMotor):
+    """electric_motors/dc_series_motor.py:6-140: one circuit, di/dt = (-(r_a + r_e) i - l_e' omega i + u) / (l_a + l_e)."""
+
+    CURRENTS = ["i"]
+    VOLTAGES = ["u"]
+    _default_motor_parameter = {"r_a": 16e-3, "r_e": 48e-3, "l_a": 19e-6, "l_e_prime": 1.7e-3, "l_e": 5.4e-3, "j_rotor": 0.0025}
+    _default_nominal_values = dict(omega=300, torque=16.0, i=97, i_a=97, i_e=97, u=60, u_a=60, u_e=60)
+    _default_limits = dict(omega=400, torque=38.0, i=210, i_a=210, i_e=210, u=60, u_a=60, u_e=60)
+    _default_initializer = {"states": {"i": 0.0}, "interval": None, "random_init": None, "random_params": (None, None)}
+
+    def __init__(self, motor_parameter=None, nominal_values=None, limit_values=None, motor_initializer=None):
+        super().__init__(motor_parameter, nominal_values, limit_values, motor_initializer)
+        mp = self._motor_parameter
+        # _update_model, lines 68-72: features [i, omega * i, u]
+        self._model_constants = np.array([[-mp["r_a"] - mp["r_e"], -mp["l_e_prime"], 1.0]]) / (mp["l_a"] + mp["l_e"])
+        # _update_limits, lines 89-99 + DcMotor._update_limits (dc_motor.py:153-160)
+        r_a = 1 if mp["r_a"] == 0 else mp["r_a"]
+        agenda = {"u": self._default_limits["u"], "i": self._limits["u"] / (r_a + mp["r_e"])}
+        agenda["torque"] = mp["l_e_prime"] * self._limits["i"] * self._limits["i"]
+        self._update_limits(agenda)
+
+    def torque_coefficients(self):
+        return [self._motor_parameter["l_e_prime"], 0.0]
+
+    def initial_motor_state(self):
+        return [float(self._initial_states.get("i", 0.0))]
+
+    def get_state_space(self, input_currents, input_voltages):
+        """dc_series_motor.py:101-116."""
+        low = {"omega": 0, "torque": 0, "i": -1 if input_currents.low[0] == -1 else 0, "u": -1 if input_voltages.low[0] == -1 else 0}
+        return low, {"omega": 1, "torque": 1, "i": 1, "u": 1}
+
+
+class DcShuntMotor(_ElectricMotor):
+    """electric_motors/dc_shunt_motor.py:6-150 over dc_motor.py: armature and exciting circuit fed by the SAME voltage."""
+
+    CURRENTS = ["i_a", "i_e"]
+    VOLTAGES = ["u"]
+    _default_motor_parameter = {"r_a": 16e-3, "r_e": 4e-1, "l_a": 19e-6, "l_e_prime": 1.7e-3, "l_e": 5.4e-3, "j_rotor": 0.0025}
+    _default_nominal_values = dict(omega=300, torque=16.0, i=97, i_a=97, i_e=97, u=60, u_a=60, u_e=60)
+    _default_limits = dict(omega=400, torque=38.0, i=210, i_a=210, i_e=210, u=60, u_a=60, u_e=60)
+    _default_initializer = {"states": {"i_a": 0.0, "i_e": 0.0}, "interval": None, "random_init": None, "random_params": (None, None)}
+
+    def __init__(self, motor_parameter=None, nominal_values=None, limit_values=None, motor_initializer=None):
+        super().__init__(motor_parameter, nominal_values, limit_values, motor_initializer)
+        mp = self._motor_parameter
+        # DcMotor._update_model, dc_motor.py:96-104: features [i_a, i_e, omega * i_e, u_a, u_e]
+        self._model_constants = np.array([[-mp["r_a"], 0, -mp["l_e_prime"], 1, 0], [0, -mp["r_e"], 0, 0, 1]], dtype=float)
+        self._model_constants[0] = self._model_constants[0] / mp["l_a"]
+        self._model_constants[1] = self._model_constants[1] / mp["l_e"]
+        # _update_limits, dc_shunt_motor.py:137-150 + dc_motor.py:153-160
+        r_a = 1 if mp["r_a"] == 0 else mp["r_a"]
+        agenda = {"u": self._default_limits["u"], "i_a": self._limits.get("i", None) or self._limits["u"] / r_a,
+                  "i_e": self._limits.get("i", None) or self._limits["u"] / mp["r_e"]}
+        agenda["torque"] = mp["l_e_prime"] * self._limits["i_a"] * self._limits["i_e"]
+        self._update_limits(agenda)
+
+    def torque_coefficients(self):
+        return [self._motor_parameter["l_e_prime"], 0.0]
+
+    def initial_motor_state(self):
+        vals = [float(v) for v in self._initial_states.values()]
+        return vals if len(vals) == 2 else [0.0, 0.0]
+
+    def get_state_space(self, input_currents, input_voltages):
+        """dc_shunt_motor.py:104-135."""
+        lc = input_currents.low[0] == -1
+        low = {"omega": 0, "torque": -1 if lc else 0, "i_a": -1 if lc else 0, "i_e": -1 if lc else 0,
+               "u": -1 if input_voltages.low[0] == -1 else 0}
+        return low, {"omega": 1, "torque": 1, "i_a": 1, "i_e": 1, "u": 1}
+
 
 class _ThreePhaseMotor(_ElectricMotor):
     IO_VOLTAGES = []
@@ -254,6 +343,50 @@ class PermanentMagnetSynchronousMotor(_ThreePhaseMotor):
 
     def initial_motor_state(self):
         # synchronous_motor.py:125-131: np.asarray(list(self._initial_states.values())) -> dict ORDER, not names
+        vals = [float(v) for v in self._initial_states.values()]
+        return vals if len(vals) == 3 else [0.0, 0.0, 0.0]
+
+
+class SynchronousReluctanceMotor(_ThreePhaseMotor):
+    """electric_motors/synchronous_reluctance_motor.py:8-190 (defaults lines 85-113): a synchronous motor without magnets."""
+
+    CURRENTS = ["i_sd", "i_sq"]
+    VOLTAGES = ["u_sd", "u_sq"]
+    IO_VOLTAGES = ["u_a", "u_b", "u_c", "u_sd", "u_sq"]
+    IO_CURRENTS = ["i_a", "i_b", "i_c", "i_sd", "i_sq"]
+    _default_motor_parameter = {"p": 4, "l_d": 10.1e-3, "l_q": 4.1e-3, "j_rotor": 0.8e-3, "r_s": 0.57}
+    _default_nominal_values = {"i": 10, "torque": 0, "omega": 3e3 * np.pi / 30, "epsilon": np.pi, "u": 80}
+    _default_limits = {"i": 18, "torque": 0, "omega": 4.3e3 * np.pi / 30, "epsilon": np.pi, "u": 80}
+    _default_initializer = {"states": {"i_sq": 0.0, "i_sd": 0.0, "epsilon": 0.0}, "interval": None,
+                            "random_init": None, "random_params": (None, None)}
+
+    def __init__(self, motor_parameter=None, nominal_values=None, limit_values=None, motor_initializer=None):
+        super().__init__(motor_parameter, nominal_values, limit_values, motor_initializer)
+        mp = self._motor_parameter
+        # _update_model, lines 117-129
+        m = np.array([
+            [0, -mp["r_s"], 0, 1, 0, 0, mp["l_q"] * mp["p"]],
+            [0, 0, -mp["r_s"], 0, 1, -mp["l_d"] * mp["p"], 0],
+            [mp["p"], 0, 0, 0, 0, 0, 0],
+        ], dtype=float)
+        m[0] = m[0] / mp["l_d"]
+        m[1] = m[1] / mp["l_q"]
+        self._model_constants = m
+        self._three_phase_limits()
+
+    def torque(self, currents):
+        mp = self._motor_parameter
+        return 1.5 * mp["p"] * ((mp["l_d"] - mp["l_q"]) * currents[0]) * currents[1]
+
+    def _torque_limit(self):
+        """lines 131-133."""
+        return self.torque([self._limits["i_sd"] / np.sqrt(2), self._limits["i_sq"] / np.sqrt(2), 0])
+
+    def torque_coefficients(self):
+        mp = self._motor_parameter
+        return [0.0, 1.5 * mp["p"] * (mp["l_d"] - mp["l_q"])]
+
+    def initial_motor_state(self):
         vals = [float(v) for v in self._initial_states.values()]
         return vals if len(vals) == 3 else [0.0, 0.0, 0.0]
 
@@ -334,6 +467,10 @@ class _MechanicalLoad:
 
     def initial_omega(self):
         return float(self._initial_states.get("omega", 0.0))
+
+    def get_state_space(self, omega_range):
+        """mechanical_load.py:225-236."""
+        return {"omega": omega_range[0]}, {"omega": omega_range[1]}
 
 
 class ConstantSpeedLoad(_MechanicalLoad):

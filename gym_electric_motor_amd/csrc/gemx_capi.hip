@@ -62,6 +62,8 @@ int fail(int code, const char *fmt, ...) {
 
 // which entries of the reference's model-constant matrix each system uses, in the order of DevParams::m
 static const int DC_IDX[][2] = {{0, 0}, {0, 1}, {0, 2}};
+static const int SERIES_IDX[][2] = {{0, 0}, {0, 1}, {0, 2}};
+static const int SHUNT_IDX[][2] = {{0, 0}, {0, 2}, {0, 3}, {1, 1}, {1, 4}};
 static const int SYNC_IDX[][2] = {{0, 1}, {0, 3}, {0, 6}, {1, 0}, {1, 2}, {1, 4}, {1, 5}};
 static const int SCIM_IDX[][2] = {{0, 1}, {0, 3}, {0, 6}, {0, 7}, {1, 2}, {1, 4}, {1, 5}, {1, 8},
                                   {2, 1}, {2, 3}, {2, 6}, {3, 2}, {3, 4}, {3, 5}};
@@ -71,6 +73,8 @@ static int pack_model(const gemx_config &c, double *m, double *pole) {
     int n, pole_row, rows, cols;
     switch (c.system_kind) {
         case GEMX_SYS_DC_PERMEX: idx = DC_IDX; n = 3; pole_row = -1; rows = 1; cols = 3; break;
+        case GEMX_SYS_DC_SERIES: idx = SERIES_IDX; n = 3; pole_row = -1; rows = 1; cols = 3; break;
+        case GEMX_SYS_DC_SHUNT: idx = SHUNT_IDX; n = 5; pole_row = -1; rows = 2; cols = 5; break;
         case GEMX_SYS_SYNC: idx = SYNC_IDX; n = 7; pole_row = 2; rows = 3; cols = 7; break;
         case GEMX_SYS_SCIM: idx = SCIM_IDX; n = 14; pole_row = 4; rows = 5; cols = 9; break;  // u_r columns: zero rotor voltage
         default: return fail(GEMX_ERR_ARG, "unknown system_kind %d", c.system_kind);
@@ -121,8 +125,9 @@ template <class R> static void fill_params(const gemx_handle &h, const double *m
     P.auto_reset = c.auto_reset;
     P.obs_layout = c.obs_layout;
     // the env's default constraint gets the 3-instruction fast path (Stepper::default_done)
-    const uint32_t def_limit = c.system_kind == GEMX_SYS_DC_PERMEX ? (1u << 2) : 0u;
-    const uint32_t def_sq = c.system_kind == GEMX_SYS_DC_PERMEX ? 0u : ((1u << 5) | (1u << 6));
+    const bool is_dc = c.system_kind == GEMX_SYS_DC_PERMEX || c.system_kind == GEMX_SYS_DC_SERIES || c.system_kind == GEMX_SYS_DC_SHUNT;
+    const uint32_t def_limit = !is_dc ? 0u : (c.system_kind == GEMX_SYS_DC_SHUNT ? ((1u << 2) | (1u << 3)) : (1u << 2));
+    const uint32_t def_sq = is_dc ? 0u : ((1u << 5) | (1u << 6));
     if (c.limit_mask == 0 && c.squared_mask == 0) P.constr_kind = 0;
     else if (c.limit_mask == def_limit && c.squared_mask == def_sq) P.constr_kind = 1;
     else P.constr_kind = 2;
@@ -144,8 +149,14 @@ static void host_reset_obs(gemx_handle &h, const double *m) {
         ab[0] = 2.0 / 3.0 * (abc[0] - 0.5 * abc[1] - 0.5 * abc[2]);
         ab[1] = 2.0 / 3.0 * (0.5 * sqrt(3.0) * abc[1] - 0.5 * sqrt(3.0) * abc[2]);
     };
-    if (c.system_kind == GEMX_SYS_DC_PERMEX) {
-        o[0] = y[0]; o[1] = c.torque_coef[0] * y[1]; o[2] = y[1]; o[3] = 0.0 * us; o[4] = us;
+    if (!h.has_angle) {  // DC motors: [omega, torque, currents..., u, u_sup]
+        const int nc = h.nd - 1;
+        double torque = c.torque_coef[0] * y[1];
+        if (c.system_kind == GEMX_SYS_DC_SERIES) torque = c.torque_coef[0] * y[1] * y[1];
+        if (c.system_kind == GEMX_SYS_DC_SHUNT) torque = c.torque_coef[0] * y[1] * y[2];
+        o[0] = y[0]; o[1] = torque;
+        for (int i = 0; i < nc; ++i) o[2 + i] = y[1 + i];
+        o[2 + nc] = 0.0 * us; o[3 + nc] = us;
     } else {
         double uabc[3] = {-0.5 * us, -0.5 * us, -0.5 * us}, uab[2], iabc[3], idq[2], udq[2], eps, torque, cs, sn;
         T23(uabc, uab);
@@ -188,6 +199,11 @@ GEMX_DECL_UNIT(1, 1, 0) GEMX_DECL_UNIT(1, 1, 1)
 GEMX_DECL_UNIT(1, 2, 0) GEMX_DECL_UNIT(1, 2, 1)
 GEMX_DECL_UNIT(2, 1, 0) GEMX_DECL_UNIT(2, 1, 1)
 GEMX_DECL_UNIT(2, 2, 0) GEMX_DECL_UNIT(2, 2, 1)
+GEMX_DECL_UNIT(0, 3, 0) GEMX_DECL_UNIT(0, 3, 1)
+GEMX_DECL_UNIT(3, 0, 0) GEMX_DECL_UNIT(3, 0, 1)
+GEMX_DECL_UNIT(3, 3, 0) GEMX_DECL_UNIT(3, 3, 1)
+GEMX_DECL_UNIT(4, 0, 0) GEMX_DECL_UNIT(4, 0, 1)
+GEMX_DECL_UNIT(4, 3, 0) GEMX_DECL_UNIT(4, 3, 1)
 #undef GEMX_DECL_UNIT
 }  // namespace gemx
 
@@ -198,6 +214,7 @@ static int launch_advance(gemx_handle *h, const void *actions, int K, void *obs,
         return f ? gemx::launch_unit_##S##_##C##_1(h, actions, K, obs, done, obs_every, st)                 \
                  : gemx::launch_unit_##S##_##C##_0(h, actions, K, obs, done, obs_every, st);
     GEMX_UNIT(0, 0) GEMX_UNIT(1, 1) GEMX_UNIT(1, 2) GEMX_UNIT(2, 1) GEMX_UNIT(2, 2)
+    GEMX_UNIT(0, 3) GEMX_UNIT(3, 0) GEMX_UNIT(3, 3) GEMX_UNIT(4, 0) GEMX_UNIT(4, 3)
 #undef GEMX_UNIT
     return fail(GEMX_ERR_ARG, "unsupported system/converter combination %d/%d", s, c);
 }
@@ -234,7 +251,8 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
     if (cfg->load_kind == GEMX_LOAD_POLY_STATIC && !(cfg->j_total > 0 && cfg->tau_decay > 0))
         return fail(GEMX_ERR_ARG, "PolynomialStaticLoad needs j_total > 0 and tau_decay > 0");
     const int s = cfg->system_kind, c = cfg->converter_kind;
-    const bool combo = (s == GEMX_SYS_DC_PERMEX && c == GEMX_CONV_CONT_4QC) ||
+    const bool dc_sys = s == GEMX_SYS_DC_PERMEX || s == GEMX_SYS_DC_SERIES || s == GEMX_SYS_DC_SHUNT;
+    const bool combo = (dc_sys && (c == GEMX_CONV_CONT_4QC || c == GEMX_CONV_FINITE_4QC)) ||
                        ((s == GEMX_SYS_SYNC || s == GEMX_SYS_SCIM) && (c == GEMX_CONV_FINITE_B6 || c == GEMX_CONV_CONT_B6));
     if (!combo) return fail(GEMX_ERR_ARG, "unsupported system/converter combination %d/%d", s, c);
 
@@ -243,9 +261,9 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
     h->cfg = *cfg;
     h->n = n_envs;
     h->device = device;
-    h->nd = s == GEMX_SYS_DC_PERMEX ? 2 : (s == GEMX_SYS_SYNC ? 3 : 5);
-    h->nout = s == GEMX_SYS_DC_PERMEX ? 5 : 14;
-    h->has_angle = s != GEMX_SYS_DC_PERMEX;
+    h->nd = (s == GEMX_SYS_DC_PERMEX || s == GEMX_SYS_DC_SERIES) ? 2 : ((s == GEMX_SYS_SYNC || s == GEMX_SYS_DC_SHUNT) ? 3 : 5);
+    h->nout = s == GEMX_SYS_DC_SHUNT ? 6 : (dc_sys ? 5 : 14);
+    h->has_angle = !dc_sys;
     h->nact = c == GEMX_CONV_CONT_B6 ? 3 : 1;
     for (int i = 0; i < h->nout; ++i)
         if (!(cfg->limits[i] > 0)) { delete h; return fail(GEMX_ERR_ARG, "limits[%d] must be positive", i); }
@@ -342,7 +360,7 @@ int gemx_n_out(const gemx_handle *h) { return h ? h->nout : GEMX_ERR_ARG; }
 int gemx_n_action(const gemx_handle *h) { return h ? h->nact : GEMX_ERR_ARG; }
 int gemx_action_itemsize(const gemx_handle *h) {
     if (!h) return GEMX_ERR_ARG;
-    return h->cfg.converter_kind == GEMX_CONV_FINITE_B6 ? 1 : elem_size(h);
+    return (h->cfg.converter_kind == GEMX_CONV_FINITE_B6 || h->cfg.converter_kind == GEMX_CONV_FINITE_4QC) ? 1 : elem_size(h);
 }
 int gemx_reset_observation(const gemx_handle *h, double *obs_host) {
     if (!h || !obs_host) return fail(GEMX_ERR_ARG, "null argument");

@@ -23,11 +23,14 @@ template <int SYS> struct SysTraits;
 template <> struct SysTraits<GEMX_SYS_DC_PERMEX> { static constexpr int ND = 2, NOUT = 5, HAS_ANGLE = 0; };   // omega, i
 template <> struct SysTraits<GEMX_SYS_SYNC>      { static constexpr int ND = 3, NOUT = 14, HAS_ANGLE = 1; };  // omega, i_sd, i_sq (+eps)
 template <> struct SysTraits<GEMX_SYS_SCIM>      { static constexpr int ND = 5, NOUT = 14, HAS_ANGLE = 1; };  // omega, i_sa, i_sb, psi_ra, psi_rb (+eps)
+template <> struct SysTraits<GEMX_SYS_DC_SERIES> { static constexpr int ND = 2, NOUT = 5, HAS_ANGLE = 0; };   // omega, i
+template <> struct SysTraits<GEMX_SYS_DC_SHUNT>  { static constexpr int ND = 3, NOUT = 6, HAS_ANGLE = 0; };   // omega, i_a, i_e
 
 template <int CONV> struct ConvTraits;
-template <> struct ConvTraits<GEMX_CONV_CONT_4QC>  { static constexpr int NACT = 1, DISCRETE = 0; };
-template <> struct ConvTraits<GEMX_CONV_FINITE_B6> { static constexpr int NACT = 1, DISCRETE = 1; };
-template <> struct ConvTraits<GEMX_CONV_CONT_B6>   { static constexpr int NACT = 3, DISCRETE = 0; };
+template <> struct ConvTraits<GEMX_CONV_CONT_4QC>   { static constexpr int NACT = 1, DISCRETE = 0, NACTIONS = 0; };
+template <> struct ConvTraits<GEMX_CONV_FINITE_B6>  { static constexpr int NACT = 1, DISCRETE = 1, NACTIONS = 8; };
+template <> struct ConvTraits<GEMX_CONV_CONT_B6>    { static constexpr int NACT = 3, DISCRETE = 0, NACTIONS = 0; };
+template <> struct ConvTraits<GEMX_CONV_FINITE_4QC> { static constexpr int NACT = 1, DISCRETE = 1, NACTIONS = 4; };
 
 // ------------------------------------------------------------------------------------------------
 // uniform parameters (kernel argument, by value -> SGPRs)

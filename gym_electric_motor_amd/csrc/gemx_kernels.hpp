@@ -53,6 +53,23 @@ template <class R> struct Elec<GEMX_SYS_DC_PERMEX, R> {
     static __device__ __forceinline__ void f(const DevParams<R> &P, const Pre &p, const R (&x)[1], R (&dx)[1]) { dx[0] = p.b + P.m[1] * x[0]; }
     static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[1]) { return P.tc0 * x[0]; }  // line 67-69
 };
+template <class R> struct Elec<GEMX_SYS_DC_SERIES, R> {  // dc_series_motor.py:68-83: di = (-(r_a+r_e) i - l_e' omega i + u) / (l_a+l_e)
+    static constexpr int NM = 1;
+    struct Pre { R a, b; };
+    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[2]) { return Pre{P.m[0] + P.m[1] * w, P.m[2] * u[0]}; }
+    static __device__ __forceinline__ void f(const DevParams<R> &, const Pre &p, const R (&x)[1], R (&dx)[1]) { dx[0] = p.b + p.a * x[0]; }
+    static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[1]) { return P.tc0 * x[0] * x[0]; }  // line 74-76
+};
+template <class R> struct Elec<GEMX_SYS_DC_SHUNT, R> {  // dc_motor.py:96-127 with u_a = u_e = u (dc_shunt_motor.py:72-74)
+    static constexpr int NM = 2;
+    struct Pre { R ba, be, w1; };
+    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[2]) { return Pre{P.m[2] * u[0], P.m[4] * u[0], P.m[1] * w}; }
+    static __device__ __forceinline__ void f(const DevParams<R> &P, const Pre &p, const R (&x)[2], R (&dx)[2]) {
+        dx[0] = p.ba + P.m[0] * x[0] + p.w1 * x[1];
+        dx[1] = p.be + P.m[3] * x[1];
+    }
+    static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[2]) { return P.tc0 * x[0] * x[1]; }  // dc_motor.py:106-108
+};
 template <class R> struct Elec<GEMX_SYS_SYNC, R> {  // permanent_magnet_synchronous_motor.py:107-119, 134-139
     static constexpr int NM = 2;
     struct Pre { R bd, bq, wdq, wqd; };
@@ -219,11 +236,11 @@ __device__ __forceinline__ uint32_t b6_subactions(uint32_t a) {
 // *.simulate(), which passes the segment START time): a leg that changes between upper and lower goes to the
 // dead state 0 for the WHOLE step (two segments [t, t+t_il], [t+t_il, t+tau]) and takes the new state on the
 // next step.  Returns the leg states used during this step; `two` = this env integrates two segments.
-__device__ __forceinline__ uint32_t b6_interlock(uint32_t prev, uint32_t want, bool &two) {
+template <int NLEG = 3> __device__ __forceinline__ uint32_t b6_interlock(uint32_t prev, uint32_t want, bool &two) {
     uint32_t used = 0;
     two = false;
 #pragma unroll
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < NLEG; ++l) {
         uint32_t s = (prev >> (2 * l)) & 3u, a = (want >> (2 * l)) & 3u;
         bool trans = (s != 0u) && (a != s);
         two |= trans;
@@ -263,34 +280,87 @@ __device__ __forceinline__ void b6_voltages(const DevParams<R> &P, const R (&act
 // ------------------------------------------------------------------------------------------------
 template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper;
 
-// ---- DcMotorSystem + Cont-4QC (physical_systems.py:171-203; converters.py:481-491) --------------------------
-template <int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_DC_PERMEX, GEMX_CONV_CONT_4QC, LOAD, SOLVER, IL, R> {
+// ---- DcMotorSystem (physical_systems.py:171-203, 290-318) for the DC motors with ONE converter voltage:
+// permanently excited, series, shunt; Cont-4QC (converters.py:438-495) or Finite-4QC (313-368) -----------------------
+template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcStepper {
     using AngT = typename Angle<R>::T;
+    static constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NC = ND - 1;
     static constexpr int NH = 1;  // ho: u [V]
+    // i_in = motor.i_in(currents): the current (dc_permanently_excited_motor.py:77-79, dc_series_motor.py:85-87) or
+    // i_a + i_e for the shunt motor (dc_shunt_motor.py:68-70)
+    static __device__ __forceinline__ R i_in(const R (&y)[ND]) { return SYS == GEMX_SYS_DC_SHUNT ? y[1] + y[ND - 1] : y[1]; }
     template <bool NS1 = false>
-    static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[2], AngT &, uint32_t &, const R (&act)[3], uint32_t,
+    static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[ND], AngT &, uint32_t &sw, const R (&act)[3], uint32_t dact,
                                                    R (&ho)[NH]) {
-        const R d0 = clip01(R(0.5) * (act[0] + R(1)));
-        const R d1 = clip01(R(-0.5) * (act[0] - R(1)));
-        const R un = cont_leg<IL, R>(P, d0, y[1]) - cont_leg<IL, R>(P, d1, y[1]);  // both sub-converters see the same i (line 483)
-        R u[2] = {un * P.u_sup, R(0)};
-        integrate<GEMX_SYS_DC_PERMEX, LOAD, SOLVER, R, NS1>(P, y, u, P.tau);
+        R u[2] = {R(0), R(0)};
+        if (CONV == GEMX_CONV_CONT_4QC) {
+            const R d0 = clip01(R(0.5) * (act[0] + R(1)));
+            const R d1 = clip01(R(-0.5) * (act[0] - R(1)));
+            const R i = i_in(y);
+            u[0] = (cont_leg<IL, R>(P, d0, i) - cont_leg<IL, R>(P, d1, i)) * P.u_sup;  // both sub-converters see the same i (line 483)
+            integrate<SYS, LOAD, SOLVER, R, NS1>(P, y, u, P.tau);
+        } else {  // Finite-4QC: action -> (leg0, leg1) sub-actions [1,1,2,2] / [1,2,1,2] (converters.py:360-361)
+            uint32_t legs = ((dact & 2u) ? 2u : 1u) | (((dact & 1u) ? 2u : 1u) << 2);
+            bool two = false;
+            if (IL) {
+                if (P.t_il > R(0)) legs = b6_interlock<2>(sw, legs, two);
+                sw = legs;
+            }
+            auto segment = [&](R h) {
+                R v0, v1;
+                if (!IL) {
+                    v0 = (legs & 3u) == 1u ? R(1) : R(0);
+                    v1 = ((legs >> 2) & 3u) == 1u ? R(1) : R(0);
+                } else {  // converters.py:350-352: leg 1 sees -i_out; dead leg -> freewheeling diode (277-285)
+                    const R i = i_in(y);
+                    const uint32_t s0 = legs & 3u, s1 = (legs >> 2) & 3u;
+                    v0 = ((s0 == 1u) | ((s0 == 0u) & (i < R(0)))) ? R(1) : R(0);
+                    v1 = ((s1 == 1u) | ((s1 == 0u) & (-i < R(0)))) ? R(1) : R(0);
+                }
+                u[0] = (v0 - v1) * P.u_sup;
+                integrate<SYS, LOAD, SOLVER, R, NS1>(P, y, u, h);
+            };
+            if (IL) {
+                segment(two ? P.t_il : P.tau);
+                if (two) segment(P.tau - P.t_il);
+            } else {
+                segment(P.tau);
+            }
+        }
         ho[0] = u[0];
     }
-    static __device__ __forceinline__ void observe(const DevParams<R> &P, const R (&y)[2], AngT, const R (&ho)[NH], R (&obs)[5]) {
-        const R x[1] = {y[1]};
+    static __device__ __forceinline__ void observe(const DevParams<R> &P, const R (&y)[ND], AngT, const R (&ho)[NH], R (&obs)[NOUT]) {
+        R x[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) x[c] = y[1 + c];
         obs[0] = y[0] * P.inv_lim[0];
-        obs[1] = Elec<GEMX_SYS_DC_PERMEX, R>::torque(P, x) * P.inv_lim[1];
-        obs[2] = y[1] * P.inv_lim[2];
-        obs[3] = ho[0] * P.inv_lim[3];
-        obs[4] = P.u_sup * P.inv_lim[4];
+        obs[1] = Elec<SYS, R>::torque(P, x) * P.inv_lim[1];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) obs[2 + c] = y[1 + c] * P.inv_lim[2 + c];
+        obs[2 + NC] = ho[0] * P.inv_lim[2 + NC];
+        obs[3 + NC] = P.u_sup * P.inv_lim[3 + NC];
     }
-    // default constraint of the DC envs: LimitConstraint('i') (cont_cc_permex_dc_env.py:104)
-    static __device__ __forceinline__ bool default_done(const R (&obs)[5]) { return fabs(obs[2]) > R(1); }
-    static __device__ __forceinline__ bool state_done(const DevParams<R> &P, const R (&y)[2], const R (&)[NH]) {
-        return fabs(y[1] * P.inv_lim[2]) > R(1);
+    // default constraints of the DC envs: LimitConstraint on the current(s): ('i',) (cont_cc_permex_dc_env.py:104,
+    // cont_cc_series_dc_env.py:102) / ('i_a', 'i_e') (cont_cc_shunt_dc_env.py:103)
+    static __device__ __forceinline__ bool default_done(const R (&obs)[NOUT]) {
+        bool d = false;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) d |= fabs(obs[2 + c]) > R(1);
+        return d;
+    }
+    static __device__ __forceinline__ bool state_done(const DevParams<R> &P, const R (&y)[ND], const R (&)[NH]) {
+        bool d = false;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) d |= fabs(y[1 + c] * P.inv_lim[2 + c]) > R(1);
+        return d;
     }
 };
+template <int CONV, int LOAD, int SOLVER, bool IL, class R>
+struct Stepper<GEMX_SYS_DC_PERMEX, CONV, LOAD, SOLVER, IL, R> : DcStepper<GEMX_SYS_DC_PERMEX, CONV, LOAD, SOLVER, IL, R> {};
+template <int CONV, int LOAD, int SOLVER, bool IL, class R>
+struct Stepper<GEMX_SYS_DC_SERIES, CONV, LOAD, SOLVER, IL, R> : DcStepper<GEMX_SYS_DC_SERIES, CONV, LOAD, SOLVER, IL, R> {};
+template <int CONV, int LOAD, int SOLVER, bool IL, class R>
+struct Stepper<GEMX_SYS_DC_SHUNT, CONV, LOAD, SOLVER, IL, R> : DcStepper<GEMX_SYS_DC_SHUNT, CONV, LOAD, SOLVER, IL, R> {};
 
 // ---- SynchronousMotorSystem (physical_systems.py:487-525), control_space 'abc' ---------------------------------
 template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_SYNC, CONV, LOAD, SOLVER, IL, R> {
@@ -567,7 +637,7 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
         uint32_t dact = ndact;
         if (a.obs_every && s > 0) write_ring(s - 1, pdone);       // row of the previous step (obs still holds it)
         if (COOP && s + 1 < sb) read_action(s + 1, nact, ndact);   // prefetch (LDS only; global loads would add vmcnt waits)
-        if (DISCRETE) { bad_action |= dact > 7u; dact &= 7u; }
+        if (DISCRETE) { bad_action |= dact >= (uint32_t)ConvTraits<CONV>::NACTIONS; dact &= (uint32_t)(ConvTraits<CONV>::NACTIONS - 1); }
         full_step<ST, ND, NOUT, R>(P, y, ang, sw, act, dact, obs);
         const bool done = constraint_done<ST, NOUT, R>(P, obs);
         done_or |= done ? 1u : 0u;
@@ -634,7 +704,7 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
     AngT ang = AngT(0);
     if (SysTraits<SYS>::HAS_ANGLE) ang = a.angle[e];
     uint32_t sw = 0;
-    constexpr bool USE_SW = (CONV == GEMX_CONV_FINITE_B6) && IL;
+    constexpr bool USE_SW = (CONV == GEMX_CONV_FINITE_B6 || CONV == GEMX_CONV_FINITE_4QC) && IL;
     if (USE_SW) sw = a.sw[e];
     const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
 
@@ -774,7 +844,7 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
         AngT ang = AngT(0);
         if (HAS_ANGLE) ang = a.angle[env];
         uint32_t sw = 0;
-        constexpr bool USE_SW = (CONV == GEMX_CONV_FINITE_B6) && IL;
+        constexpr bool USE_SW = (CONV == GEMX_CONV_FINITE_B6 || CONV == GEMX_CONV_FINITE_4QC) && IL;
         if (USE_SW) sw = a.sw[env];
         const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
         const bool check_default = P.constr_kind == 1;
@@ -809,7 +879,7 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
             R act[3] = {R(0), R(0), R(0)};
 #pragma unroll
             for (int i = 0; i < NACT; ++i) act[i] = act_in[i];
-            if (DISCRETE) { bad_action |= dact > 7u; dact &= 7u; }
+            if (DISCRETE) { bad_action |= dact >= (uint32_t)ConvTraits<CONV>::NACTIONS; dact &= (uint32_t)(ConvTraits<CONV>::NACTIONS - 1); }
             R ho[NH];
             ST::template advance<true>(P, y, ang, sw, act, dact, ho);  // launcher guarantees solver_nsteps == 1
             const bool done = ST::state_done(P, y, ho) & check_default;

@@ -4,9 +4,10 @@
 for the env ids whose physical system is built from supported components, with the same per-id defaults as the
 reference env classes (supply voltage, converter, motor, load, tau, constraints):
 
-    Cont-{CC,TC,SC}-PermExDc-v0   envs/gym_dcm/permex_dc_motor_env/cont_*_permex_dc_env.py
-    {Finite,Cont}-{CC,TC,SC}-PMSM-v0   envs/gym_pmsm/*.py
-    {Finite,Cont}-{CC,TC,SC}-SCIM-v0   envs/gym_im/squirrel_cage_induction_motor_envs/*.py
+    {Finite,Cont}-{CC,TC,SC}-{PermExDc,SeriesDc,ShuntDc}-v0   envs/gym_dcm/{permex,series,shunt}_dc_motor_env/*.py
+    {Finite,Cont}-{CC,TC,SC}-{PMSM,SynRM}-v0                  envs/gym_pmsm/*.py, envs/gym_synrm/*.py
+    {Finite,Cont}-{CC,TC,SC}-SCIM-v0                          envs/gym_im/squirrel_cage_induction_motor_envs/*.py
+(36 of the reference's 54 env ids; the rest need the multi-converter systems: ExtExDc, EESM, DFIM.)
 
 Only the physical system + constraint monitor (done mask) are device-resident.  Reference generators, reward
 functions and visualisation are outside the accelerated path: `step()` returns
@@ -18,7 +19,7 @@ import re
 from . import components as comp
 from . import physical_systems as bps
 
-_ID = re.compile(r"^(Finite|Cont)-(CC|TC|SC)-(PermExDc|PMSM|SCIM)-v0$")
+_ID = re.compile(r"^(Finite|Cont)-(CC|TC|SC)-(PermExDc|SeriesDc|ShuntDc|PMSM|SynRM|SCIM)-v0$")
 
 
 def _initialize(arg, default_class, default_args):
@@ -36,34 +37,47 @@ def _initialize(arg, default_class, default_args):
     return arg
 
 
+# speed-control (SC) envs: PolynomialStaticLoad parameters per env class (e.g. cont_sc_permex_dc_env.py:159,
+# finite_sc_permex_dc_env.py:160, cont_sc_series_dc_env.py:157, finite_sc_series_dc_env.py:157, cont_sc_shunt_dc_env.py:159,
+# cont_sc_pmsm_env.py:153, cont_sc_synrm_env.py:153, cont_sc_scim_env.py:161)
+_SC_LOAD = {
+    ("Cont", "PermExDc"): dict(a=0.0, b=0.0, c=0.0, j_load=1e-4), ("Finite", "PermExDc"): dict(a=0.0, b=0.0, c=0.0, j_load=1e-3),
+    ("Cont", "SeriesDc"): dict(a=0.01, b=0.05, c=0.0, j_load=1e-4), ("Finite", "SeriesDc"): dict(a=0.15, b=0.05, c=0.0, j_load=1e-4),
+    ("Cont", "ShuntDc"): dict(a=0.05, b=0.01, c=0.0, j_load=1e-4), ("Finite", "ShuntDc"): dict(a=0.05, b=0.01, c=0.0, j_load=1e-4),
+}
+# supply voltages that differ from the family default (60 V DC motors, 420 V three-phase)
+_U_NOMINAL = {"Cont-CC-PMSM-v0": 300.0, "Finite-CC-SeriesDc-v0": 420.0, "Finite-TC-SeriesDc-v0": 420.0}
+
+
 def default_components(env_id):
     """Per-id defaults, read off the reference env classes (e.g. cont_cc_permex_dc_env.py:146-160,
-    finite_cc_pmsm_env.py:148-166, cont_sc_scim_env.py:153-170)."""
+    finite_cc_pmsm_env.py:148-166, cont_sc_scim_env.py:153-170, cont_cc_series_dc_env.py:144-160,
+    cont_cc_shunt_dc_env.py:145-161, cont_cc_synrm_env.py:152-160)."""
     m = _ID.match(env_id)
     if not m:
-        raise KeyError(f"{env_id!r} is not on the accelerated path; supported: (Finite|Cont)-(CC|TC|SC)-(PermExDc|PMSM|SCIM)-v0 "
-                       "(Finite-*-PermExDc needs the Finite-4QC converter, not built yet)")
+        raise KeyError(f"{env_id!r} is not on the accelerated path; supported: "
+                       "(Finite|Cont)-(CC|TC|SC)-(PermExDc|SeriesDc|ShuntDc|PMSM|SynRM|SCIM)-v0")
     action, control, motor = m.groups()
     finite = action == "Finite"
-    speed_control = control == "SC"
-    if motor == "PermExDc":
-        if finite:
-            raise KeyError("Finite-*-PermExDc-v0 uses FiniteFourQuadrantConverter, which is not on the accelerated path yet")
-        d = dict(system=bps.BatchedDcMotorSystem, supply=dict(u_nominal=60.0), converter=comp.ContFourQuadrantConverter,
-                 motor=comp.DcPermanentlyExcitedMotor, constraints=("i",))
+    dc = motor.endswith("Dc")
+    if dc:
+        motor_cls = {"PermExDc": comp.DcPermanentlyExcitedMotor, "SeriesDc": comp.DcSeriesMotor, "ShuntDc": comp.DcShuntMotor}[motor]
+        d = dict(system=bps.BatchedDcMotorSystem, supply=dict(u_nominal=60.0), motor=motor_cls,
+                 converter=comp.FiniteFourQuadrantConverter if finite else comp.ContFourQuadrantConverter,
+                 constraints=("i_a", "i_e") if motor == "ShuntDc" else ("i",))
+        # NOTE: the reference's shunt envs additionally wrap the system in a CurrentSumProcessor ('i_sum' observation):
+        # observation post-processing, outside the accelerated path
     else:
-        conv = comp.FiniteB6BridgeConverter if finite else comp.ContB6BridgeConverter
-        d = dict(supply=dict(u_nominal=420.0), converter=conv, constraints=(bps.SquaredConstraint(("i_sq", "i_sd")),))
-        if motor == "PMSM":
-            d.update(system=bps.BatchedSynchronousMotorSystem, motor=comp.PermanentMagnetSynchronousMotor)
-        else:
-            d.update(system=bps.BatchedSquirrelCageInductionMotorSystem, motor=comp.SquirrelCageInductionMotor)
-    if env_id == "Cont-CC-PMSM-v0":
-        d["supply"] = dict(u_nominal=300.0)  # cont_cc_pmsm_env.py:154 (all other PMSM/SCIM ids: 420 V)
-    if speed_control and motor == "PermExDc":
-        d["load"] = (comp.PolynomialStaticLoad, dict(load_parameter=dict(a=0.0, b=0.0, c=0.0, j_load=1e-4)))  # cont_sc_permex_dc_env.py:159
-    elif speed_control:
-        d["load"] = (comp.PolynomialStaticLoad, dict(load_parameter=dict(a=0.01, b=0.01, c=0.0)))
+        motor_cls = {"PMSM": comp.PermanentMagnetSynchronousMotor, "SynRM": comp.SynchronousReluctanceMotor,
+                     "SCIM": comp.SquirrelCageInductionMotor}[motor]
+        system = bps.BatchedSquirrelCageInductionMotorSystem if motor == "SCIM" else bps.BatchedSynchronousMotorSystem
+        d = dict(system=system, supply=dict(u_nominal=420.0), motor=motor_cls,
+                 converter=comp.FiniteB6BridgeConverter if finite else comp.ContB6BridgeConverter,
+                 constraints=(bps.SquaredConstraint(("i_sq", "i_sd")),))
+    if env_id in _U_NOMINAL:
+        d["supply"] = dict(u_nominal=_U_NOMINAL[env_id])
+    if control == "SC":
+        d["load"] = (comp.PolynomialStaticLoad, dict(load_parameter=_SC_LOAD.get((action, motor), dict(a=0.01, b=0.01, c=0.0))))
     else:
         d["load"] = (comp.ConstantSpeedLoad, dict(omega_fixed=100.0))
     d["tau"] = 1e-5 if finite else 1e-4

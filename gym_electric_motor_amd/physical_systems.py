@@ -213,10 +213,12 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             return _lib.CONV_CONT_4QC
         if _is_a(c, "FiniteB6BridgeConverter"):
             return _lib.CONV_FINITE_B6
+        if _is_a(c, "FiniteFourQuadrantConverter"):
+            return _lib.CONV_FINITE_4QC
         if _is_a(c, "ContB6BridgeConverter"):
             return _lib.CONV_CONT_B6
         raise ValueError(f"converter {type(c).__name__} is not on the accelerated path "
-                         "(supported: ContFourQuadrantConverter, FiniteB6BridgeConverter, ContB6BridgeConverter)")
+                         "(supported: ContFourQuadrantConverter, FiniteFourQuadrantConverter, FiniteB6BridgeConverter, ContB6BridgeConverter)")
 
     def _solver_kind(self):
         s = self._ode_solver
@@ -246,6 +248,8 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         mp = m.motor_parameter
         if _is_a(m, "DcPermanentlyExcitedMotor"):
             return [mp["psi_e"], 0.0]
+        if _is_a(m, "DcSeriesMotor", "DcShuntMotor"):
+            return [mp["l_e_prime"], 0.0]
         if _is_a(m, "PermanentMagnetSynchronousMotor"):
             return [1.5 * mp["p"] * mp["psi_p"], 1.5 * mp["p"] * (mp["l_d"] - mp["l_q"])]
         if _is_a(m, "SynchronousReluctanceMotor"):
@@ -348,8 +352,9 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         if self._discrete:
             if not torch.is_tensor(actions):
                 arr = np.asarray(actions)
-                if arr.size and (arr.min() < 0 or arr.max() > 7):
-                    bad = arr.ravel()[(arr.ravel() < 0) | (arr.ravel() > 7)][0]
+                nmax = int(self.action_space.n) - 1
+                if arr.size and (arr.min() < 0 or arr.max() > nmax):
+                    bad = arr.ravel()[(arr.ravel() < 0) | (arr.ravel() > nmax)][0]
                     raise AssertionError(f"The selected action {bad} is not a valid element of the action space {self.action_space}.")
                 actions = torch.as_tensor(arr.astype(np.uint8))
             t = actions.to(device=self._tdev, dtype=torch.uint8).reshape(leading).contiguous()
@@ -463,10 +468,21 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
 
 
 class BatchedDcMotorSystem(BatchedSCMLSystem):
-    """DcMotorSystem (physical_systems.py:290-318) for N envs."""
+    """DcMotorSystem (physical_systems.py:290-318) for N envs: permanently excited, series and shunt DC motors
+    (one converter voltage) with Cont-4QC or Finite-4QC."""
 
-    _SYSTEM_KIND = _lib.SYS_DC_PERMEX
-    _n_ode = 2
+    def __init__(self, converter, motor, *args, **kwargs):
+        if _is_a(motor, "DcSeriesMotor"):
+            self._SYSTEM_KIND = _lib.SYS_DC_SERIES
+        elif _is_a(motor, "DcShuntMotor"):
+            self._SYSTEM_KIND = _lib.SYS_DC_SHUNT
+        elif _is_a(motor, "DcPermanentlyExcitedMotor"):
+            self._SYSTEM_KIND = _lib.SYS_DC_PERMEX
+        else:
+            raise ValueError(f"motor {type(motor).__name__} is not on the accelerated path for DcMotorSystem "
+                             "(supported: DcPermanentlyExcitedMotor, DcSeriesMotor, DcShuntMotor)")
+        self._n_ode = 1 + len(motor.CURRENTS)
+        super().__init__(converter, motor, *args, **kwargs)
 
     def _build_state_names(self):
         return self._mechanical_load.state_names + ["torque"] + list(self._electrical_motor.CURRENTS) + list(self._electrical_motor.VOLTAGES) + ["u_sup"]
@@ -481,13 +497,17 @@ class BatchedDcMotorSystem(BatchedSCMLSystem):
         self.U_SUP_IDX = [2 + n_c + n_v]
 
     def _build_state_space(self, state_names):
-        """physical_systems.py:305-318 with DcPermanentlyExcitedMotor.get_state_space (dc_permanently_excited_motor.py:107-120)."""
-        cur_low, vol_low = self._converter.currents.low[0], self._converter.voltages.low[0]
-        low = {"omega": -1 if vol_low == -1 else 0, "torque": -1 if cur_low == -1 else 0, "i": -1 if cur_low == -1 else 0,
-               "u": -1 if vol_low == -1 else 0, "u_sup": 0}
-        high = {"omega": 1, "torque": 1, "i": 1, "u": 1, "u_sup": self._supply.supply_range[1] / self._supply.u_nominal}
+        """physical_systems.py:305-318."""
+        low, high = self._electrical_motor.get_state_space(self._converter.currents, self._converter.voltages)
+        low_mech, high_mech = self._mechanical_load.get_state_space((low["omega"], high["omega"]))
+        low, high = dict(low), dict(high)
+        low.update(low_mech)
+        high.update(high_mech)
+        high["u_sup"] = self._supply.supply_range[1] / self._supply.u_nominal
         if self._supply.supply_range[0] != self._supply.supply_range[1]:
             low["u_sup"] = self._supply.supply_range[0] / self._supply.u_nominal
+        else:
+            low["u_sup"] = 0
         return Box(np.array([low[n] for n in state_names], dtype=float), np.array([high[n] for n in state_names], dtype=float), dtype=np.float64)
 
 

@@ -42,9 +42,16 @@ typedef enum gemx_status {
 } gemx_status;
 
 /* SCML system class: DcMotorSystem / SynchronousMotorSystem / SquirrelCageInductionMotorSystem */
-typedef enum { GEMX_SYS_DC_PERMEX = 0, GEMX_SYS_SYNC = 1, GEMX_SYS_SCIM = 2 } gemx_system_kind;
-/* ContFourQuadrantConverter (converters.py:438-495), FiniteB6BridgeConverter (743-839), ContB6BridgeConverter (842-911) */
-typedef enum { GEMX_CONV_CONT_4QC = 0, GEMX_CONV_FINITE_B6 = 1, GEMX_CONV_CONT_B6 = 2 } gemx_converter_kind;
+typedef enum {
+    GEMX_SYS_DC_PERMEX = 0, /* DcMotorSystem + DcPermanentlyExcitedMotor                                   */
+    GEMX_SYS_SYNC = 1,      /* SynchronousMotorSystem (PMSM, SynRM)                                         */
+    GEMX_SYS_SCIM = 2,      /* SquirrelCageInductionMotorSystem                                             */
+    GEMX_SYS_DC_SERIES = 3, /* DcMotorSystem + DcSeriesMotor (electric_motors/dc_series_motor.py)           */
+    GEMX_SYS_DC_SHUNT = 4   /* DcMotorSystem + DcShuntMotor  (electric_motors/dc_shunt_motor.py)            */
+} gemx_system_kind;
+/* ContFourQuadrantConverter (converters.py:438-495), FiniteB6BridgeConverter (743-839), ContB6BridgeConverter (842-911),
+ * FiniteFourQuadrantConverter (313-368; DC systems, actions 0..3) */
+typedef enum { GEMX_CONV_CONT_4QC = 0, GEMX_CONV_FINITE_B6 = 1, GEMX_CONV_CONT_B6 = 2, GEMX_CONV_FINITE_4QC = 3 } gemx_converter_kind;
 /* ConstantSpeedLoad (constant_speed_load.py), PolynomialStaticLoad (polynomial_static_load.py) */
 typedef enum { GEMX_LOAD_CONST_SPEED = 0, GEMX_LOAD_POLY_STATIC = 1 } gemx_load_kind;
 /* EulerSolver(nsteps) (solvers.py:79-136); classical RK4 (not in the reference); one fixed Dormand-Prince-5
@@ -70,10 +77,13 @@ typedef struct gemx_config {
     double u_nominal;         /* IdealVoltageSupply.u_nominal, voltage_supplies.py:60-72 */
     /* motor._model_constants zero-padded to 5x11, row-major; feature order as in the reference:
      * DC    (1x3) [omega, i, u]                                  dc_permanently_excited_motor.py:71-84
+     * SERIES(1x3) [i, omega*i, u]                                dc_series_motor.py:68-83
+     * SHUNT (2x5) [i_a, i_e, omega*i_e, u_a, u_e] (u_a = u_e = u) dc_motor.py:96-127, dc_shunt_motor.py:72-74
      * SYNC  (3x7) [omega, i_d, i_q, u_d, u_q, omega*i_d, omega*i_q]  synchronous_motor.py:143-168
      * SCIM  (5x11)[omega, i_a, i_b, psi_a, psi_b, omega*psi_a, omega*psi_b, u_sa, u_sb, u_ra, u_rb] induction_motor.py:187-217 */
     double model[GEMX_MODEL_ROWS * GEMX_MODEL_COLS];
-    /* torque: DC T = tc[0]*i ; SYNC T = (tc[0] + tc[1]*i_d)*i_q ; SCIM T = tc[0]*(psi_a*i_b - psi_b*i_a) */
+    /* torque: DC T = tc[0]*i ; SYNC T = (tc[0] + tc[1]*i_d)*i_q ; SCIM T = tc[0]*(psi_a*i_b - psi_b*i_a) ;
+     * SERIES T = tc[0]*i*i ; SHUNT T = tc[0]*i_a*i_e */
     double torque_coef[4];
     double j_total;                    /* load.j_total (j_load + j_rotor), mechanical_load.py:35-41 */
     double load_a, load_b, load_c;     /* PolynomialStaticLoad parameters */
@@ -95,8 +105,8 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
 int gemx_destroy(gemx_handle *h);
 
 int gemx_n_envs(const gemx_handle *h, int64_t *n);
-int gemx_n_ode(const gemx_handle *h);    /* S_ode: 2 | 4 | 6 */
-int gemx_n_out(const gemx_handle *h);    /* S_out: 5 | 14    */
+int gemx_n_ode(const gemx_handle *h);    /* S_ode: 2 | 3 | 4 | 6 */
+int gemx_n_out(const gemx_handle *h);    /* S_out: 5 | 6 | 14    */
 int gemx_n_action(const gemx_handle *h); /* A: 1 | 3         */
 int gemx_action_itemsize(const gemx_handle *h); /* 1 (uint8 discrete) | sizeof(R) */
 /* normalised state returned by reset() for the configured constant initialiser, host doubles [S_out] */
@@ -108,7 +118,7 @@ int gemx_reset_observation(const gemx_handle *h, double *obs_host);
 int gemx_reset(gemx_handle *h, const uint8_t *mask_dev, void *obs_out_dev, void *stream);
 
 /* PhysicalSystem.simulate() for all N envs: one control step.
- *   actions_dev : [N, A] R for continuous converters, [N] uint8 in 0..7 for Finite-B6C
+ *   actions_dev : [N, A] R for continuous converters, [N] uint8 for finite ones (0..7 Finite-B6C, 0..3 Finite-4QC)
  *   obs_out_dev : [N, S_out] R (AoS) or [S_out, N] R (SoA); 16-byte aligned
  *   done_out_dev: [N] uint8 (may be NULL when no constraint is configured)                                    */
 int gemx_step(gemx_handle *h, const void *actions_dev, void *obs_out_dev, uint8_t *done_out_dev, void *stream);

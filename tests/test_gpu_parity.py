@@ -31,6 +31,7 @@ def _make_from_meta(meta, n_envs, solver=None, dtype="float32", episodic=None, o
 
     solver = solver or meta["solver"]
     sol = {"euler": ga.EulerSolver(), "euler4": ga.EulerSolver(nsteps=4), "rk4": ga.RK4Solver(), "rk4x4": ga.RK4Solver(nsteps=4),
+           "rk4x8": ga.RK4Solver(nsteps=8), "dp5x8": ga.DormandPrince5Solver(nsteps=8),
            "dopri5": ga.DormandPrince5Solver(), "dp5": ga.DormandPrince5Solver()}[solver]
     kw = dict(n_envs=n_envs, ode_solver=sol, tau=meta["tau"], dtype=dtype, obs_layout=obs_layout, auto_reset=auto_reset)
     kw["converter"] = dict(interlocking_time=meta["interlocking_time"])
@@ -83,7 +84,9 @@ def _check_done(meta, d, got_done, ref_states_full=None):
     assert meta["every"] == 1
     s = d["states"]
     names = meta["state_names"]
-    if meta["system"] == "DcMotorSystem":
+    if meta["system"] == "DcMotorSystem" and meta["motor"] == "DcShuntMotor":
+        margin = np.minimum(np.abs(np.abs(s[:, names.index("i_a")]) - 1.0), np.abs(np.abs(s[:, names.index("i_e")]) - 1.0))
+    elif meta["system"] == "DcMotorSystem":
         margin = np.abs(np.abs(s[:, names.index("i")]) - 1.0)
     else:
         margin = np.abs(s[:, names.index("i_sd")] ** 2 + s[:, names.index("i_sq")] ** 2 - 1.0)
@@ -116,6 +119,9 @@ def test_fp64_euler_matches_reference_euler(name):
 @pytest.mark.parametrize("name", DOPRI)
 @pytest.mark.parametrize("solver", ["rk4", "dp5"])
 def test_fp32_fixed_step_matches_reference_default_dopri5(name, solver):
+    _, meta0 = _load(name)
+    if meta0["env_id"].endswith("SC-SynRM-v0"):
+        solver += "x8"  # tiny inertia: one step per tau is 1e-3 off the adaptive reference solver, 8 sub-steps restore 1e-4
     d, meta, obs, done = _run_golden(name, "float32", solver=solver)
     if meta["episodic"]:
         # after the first termination mismatch trajectories legitimately diverge; compare up to the first done

@@ -44,6 +44,15 @@ def test_library_exports_every_declared_symbol():
     ("Finite-CC-PMSM-v0", "pmsm_free_held_euler"),
     ("Finite-SC-PMSM-v0", "pmsm_sc_free_held_dopri5"),
     ("Cont-SC-SCIM-v0", "scim_free_held_euler"),
+    ("Finite-CC-SynRM-v0", "synrm_fin_free_held_euler"),
+    ("Cont-SC-SynRM-v0", "synrm_cont_sc_epi_held_euler"),
+    ("Finite-CC-PermExDc-v0", "permexdc_fin_free_held_euler"),
+    ("Cont-CC-SeriesDc-v0", "series_cont_free_held_euler"),
+    ("Cont-SC-SeriesDc-v0", "series_cont_sc_free_held_euler"),
+    ("Finite-CC-SeriesDc-v0", "series_fin_free_held_til_euler"),
+    ("Cont-CC-ShuntDc-v0", "shunt_cont_free_held_euler"),
+    ("Cont-SC-ShuntDc-v0", "shunt_cont_sc_free_held_euler"),
+    ("Finite-CC-ShuntDc-v0", "shunt_fin_free_held_til_euler"),
 ])
 def test_host_metadata_matches_reference(env_id, golden):
     """limits / nominal_state / model constants / names / j_total as the live reference reported them."""
@@ -71,6 +80,9 @@ def test_default_constraints_become_masks():
     assert one._cfg.auto_reset == 0  # n_envs == 1: the reference env shell decides when to reset
     allc = ga.make("Cont-CC-PermExDc-v0", n_envs=2, constraints=("all_states",), _defer_create=True).physical_system
     assert allc._cfg.limit_mask == 0b11111
+    sh = ga.make("Finite-CC-ShuntDc-v0", n_envs=2, _defer_create=True).physical_system
+    assert sh._cfg.limit_mask == 0b1100 and sh._cfg.system_kind == 4 and sh._cfg.converter_kind == 3 and sh.action_space.n == 4
+    assert list(sh._cfg.init_state)[:3] == [100.0, 0.0, 0.0] and sh.state_names == ["omega", "torque", "i_a", "i_e", "u", "u_sup"]
 
 
 def test_pmsm_initialiser_dict_order_quirk():
@@ -83,9 +95,13 @@ def test_pmsm_initialiser_dict_order_quirk():
 
 def test_unsupported_pieces_raise():
     with pytest.raises(KeyError):
-        ga.make("Finite-CC-PermExDc-v0", n_envs=2, _defer_create=True)
+        ga.make("Cont-CC-ExtExDc-v0", n_envs=2, _defer_create=True)   # needs the multi-converter system
     with pytest.raises(KeyError):
-        ga.make("Cont-CC-SeriesDc-v0", n_envs=2, _defer_create=True)
+        ga.make("Finite-CC-EESM-v0", n_envs=2, _defer_create=True)
+    with pytest.raises(ValueError):  # a DC system needs a one-voltage DC motor
+        ga.BatchedDcMotorSystem(converter=ga.ContFourQuadrantConverter(), motor=ga.PermanentMagnetSynchronousMotor(),
+                                load=ga.ConstantSpeedLoad(100.0), supply=ga.IdealVoltageSupply(60.0), ode_solver=ga.EulerSolver(),
+                                _defer_create=True)
 
     class ScipyOdeSolver:  # stands for the reference's scipy-backed solver classes
         pass
