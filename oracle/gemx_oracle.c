@@ -33,9 +33,13 @@
 #include <stdint.h>
 #include <string.h>
 
-enum { ORC_SYS_DC_PERMEX = 0, ORC_SYS_PMSM = 1, ORC_SYS_SCIM = 2, ORC_SYS_DC_SERIES = 3, ORC_SYS_DC_SHUNT = 4 };
-enum { ORC_CONV_CONT_4QC = 0, ORC_CONV_FINITE_B6 = 1, ORC_CONV_CONT_B6 = 2, ORC_CONV_FINITE_4QC = 3 };
-#define ORC_IS_DC(s) ((s) == ORC_SYS_DC_PERMEX || (s) == ORC_SYS_DC_SERIES || (s) == ORC_SYS_DC_SHUNT)
+enum { ORC_SYS_DC_PERMEX = 0, ORC_SYS_PMSM = 1, ORC_SYS_SCIM = 2, ORC_SYS_DC_SERIES = 3, ORC_SYS_DC_SHUNT = 4,
+       ORC_SYS_DC_EXTEX = 5, ORC_SYS_EESM = 6 };
+/* 4..7: Cont/FiniteMultiConverter (converters.py:498-740) of exactly two sub-converters:
+ * 2 x 4QC (the ExtExDc envs) and B6 + 4QC (the EESM envs) */
+enum { ORC_CONV_CONT_4QC = 0, ORC_CONV_FINITE_B6 = 1, ORC_CONV_CONT_B6 = 2, ORC_CONV_FINITE_4QC = 3,
+       ORC_CONV_CONT_2X4QC = 4, ORC_CONV_FINITE_2X4QC = 5, ORC_CONV_CONT_B6_4QC = 6, ORC_CONV_FINITE_B6_4QC = 7 };
+#define ORC_IS_DC(s) ((s) == ORC_SYS_DC_PERMEX || (s) == ORC_SYS_DC_SERIES || (s) == ORC_SYS_DC_SHUNT || (s) == ORC_SYS_DC_EXTEX)
 enum { ORC_LOAD_CONST_SPEED = 0, ORC_LOAD_POLY_STATIC = 1 };
 enum { ORC_SOLVER_EULER = 0, ORC_SOLVER_RK4 = 1, ORC_SOLVER_DOPRI5 = 2, ORC_SOLVER_DP5_FIXED = 3 };
 
@@ -49,7 +53,7 @@ typedef struct orc_params {
     int32_t reserved;
     double tau, t_il, u_sup;
     double mp[8]; /* DC permex: r_a,l_a,psi_e | PMSM/SynRM: p,l_d,l_q,r_s,psi_p(0 for SynRM) | SCIM: p,l_m,l_sigs,l_sigr,r_s,r_r
-                   * DC series / shunt: r_a,r_e,l_a,l_e,l_e_prime */
+                   * DC series / shunt / extex: r_a,r_e,l_a,l_e,l_e_prime | EESM: p,l_d,l_q,l_m,l_e,r_s,r_e,k */
     double j_total, load_a, load_b, load_c, tau_decay;
     double limits[ORC_MAX_OUT];
     double init[ORC_MAX_ODE]; /* initial ODE state [omega, motor states...] */
@@ -61,12 +65,12 @@ typedef struct orc_env {
     int32_t k;          /* PhysicalSystem._k */
     /* converter state (converters.py:40-43, 193-197) */
     double action_start;
-    double duty[3][2];        /* Cont: per sub-converter clipped duty (ContDynamicallyAveragedConverter.set_action:144-146) */
-    int32_t sw_state[3];      /* FiniteTwoQuadrantConverter._switching_state, NOT cleared by reset() (45-54) */
-    int32_t sw_pattern[3][2]; /* _switching_pattern */
-    int32_t sw_plen[3];
+    double duty[5][2];        /* Cont: per sub-converter clipped duty (ContDynamicallyAveragedConverter.set_action:144-146) */
+    int32_t sw_state[5];      /* FiniteTwoQuadrantConverter._switching_state, NOT cleared by reset() (45-54) */
+    int32_t sw_pattern[5][2]; /* _switching_pattern */
+    int32_t sw_plen[5];
     /* solver f_params */
-    double u[2];
+    double u[3];
     double dp_h; /* dopri5: predicted step size carried between integrate() calls (0 -> HINIT) */
     /* constants */
     double C[5][11];
@@ -75,13 +79,18 @@ typedef struct orc_env {
 static int n_ode(const orc_params *p) {
     switch (p->system) {
         case ORC_SYS_DC_PERMEX: case ORC_SYS_DC_SERIES: return 2;
-        case ORC_SYS_DC_SHUNT: return 3;
+        case ORC_SYS_DC_SHUNT: case ORC_SYS_DC_EXTEX: return 3;
         case ORC_SYS_PMSM: return 4;
+        case ORC_SYS_EESM: return 5; /* [omega, i_sd, i_sq, i_e, epsilon] */
         default: return 6;
     }
 }
 /* state names: DcMotorSystem._build_state_names (physical_systems.py:295-303): [omega, torque] + CURRENTS + VOLTAGES + [u_sup] */
-static int n_out(const orc_params *p) { return p->system == ORC_SYS_DC_SHUNT ? 6 : (ORC_IS_DC(p->system) ? 5 : 14); }
+static int n_out(const orc_params *p) {
+    if (p->system == ORC_SYS_DC_EXTEX) return 7;  /* [omega, torque, i_a, i_e, u_a, u_e, u_sup] */
+    if (p->system == ORC_SYS_EESM) return 16;     /* physical_systems.py:575-593 */
+    return p->system == ORC_SYS_DC_SHUNT ? 6 : (ORC_IS_DC(p->system) ? 5 : 14);
+}
 
 int orc_n_ode(const orc_params *p) { return n_ode(p); }
 int orc_n_out(const orc_params *p) { return n_out(p); }
@@ -98,10 +107,24 @@ void orc_model_constants(const orc_params *p, double C[5][11]) {
     } else if (p->system == ORC_SYS_DC_SERIES) { /* dc_series_motor.py:68-72, features [i, omega*i, u] */
         double r_a = mp[0], r_e = mp[1], l_a = mp[2], l_e = mp[3], lep = mp[4];
         C[0][0] = (-r_a - r_e) / (l_a + l_e); C[0][1] = -lep / (l_a + l_e); C[0][2] = 1.0 / (l_a + l_e);
-    } else if (p->system == ORC_SYS_DC_SHUNT) { /* dc_motor.py:96-104, features [i_a, i_e, omega*i_e, u_a, u_e] */
+    } else if (p->system == ORC_SYS_DC_SHUNT || p->system == ORC_SYS_DC_EXTEX) { /* dc_motor.py:96-104, features [i_a, i_e, omega*i_e, u_a, u_e] */
         double r_a = mp[0], r_e = mp[1], l_a = mp[2], l_e = mp[3], lep = mp[4];
         C[0][0] = -r_a / l_a; C[0][2] = -lep / l_a; C[0][3] = 1.0 / l_a;
         C[1][1] = -r_e / l_e; C[1][4] = 1.0 / l_e;
+    } else if (p->system == ORC_SYS_EESM) { /* externally_excited_synchronous_motor.py:69-93 */
+        double pp = mp[0], l_d = mp[1], l_q = mp[2], l_m = mp[3], l_e = mp[4], r_s = mp[5], r_e = mp[6], k = mp[7];
+        double r_E = k * k * 3 / 2 * r_e, l_M = k * 3 / 2 * l_m, l_E = k * k * 3 / 2 * l_e, ik = 2.0 / 3 / k;
+        double sigma = 1 - l_M * l_M / (l_d * l_E);
+        /* omega, i_d, i_q, i_e, u_d, u_q, u_e, omega*i_d, omega*i_q, omega*i_e */
+        double M[4][10] = {
+            {0, -r_s / sigma, 0, l_M * r_E / (sigma * l_E) * ik, 1 / sigma, 0, -l_M * k / (sigma * l_E), 0, l_q * pp / sigma, 0},
+            {0, 0, -r_s, 0, 0, 1, 0, -l_d * pp, 0, -pp * l_M * ik},
+            {0, l_M * r_s / (sigma * l_d), 0, -r_E / sigma * ik, -l_M / (sigma * l_d), 0, k / sigma, 0,
+             -pp * l_M * l_q / (sigma * l_d), 0},
+            {pp, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+        for (int j = 0; j < 10; ++j) {
+            C[0][j] = M[0][j] / l_d; C[1][j] = M[1][j] / l_q; C[2][j] = M[2][j] / l_E / ik; C[3][j] = M[3][j];
+        }
     } else if (p->system == ORC_SYS_PMSM) {
         double pp = mp[0], l_d = mp[1], l_q = mp[2], r_s = mp[3], psi_p = mp[4];
         /*            omega,         i_d,   i_q, u_d, u_q, omega*i_d,  omega*i_q */
@@ -133,7 +156,11 @@ static double motor_torque(const orc_params *p, const double *ms) {
     const double *mp = p->mp;
     if (p->system == ORC_SYS_DC_PERMEX) return mp[2] * ms[0];
     if (p->system == ORC_SYS_DC_SERIES) return mp[4] * ms[0] * ms[0]; /* dc_series_motor.py:74-76 -> dc_motor.py:106-108 */
-    if (p->system == ORC_SYS_DC_SHUNT) return mp[4] * ms[0] * ms[1];  /* dc_motor.py:106-108 */
+    if (p->system == ORC_SYS_DC_SHUNT || p->system == ORC_SYS_DC_EXTEX) return mp[4] * ms[0] * ms[1]; /* dc_motor.py:106-108 */
+    if (p->system == ORC_SYS_EESM) { /* externally_excited_synchronous_motor.py:133-136 */
+        double l_M = mp[7] * 3 / 2 * mp[3], ik = 2.0 / 3 / mp[7];
+        return 1.5 * mp[0] * (l_M * ms[2] * ik + (mp[1] - mp[2]) * ms[0]) * ms[1];
+    }
     if (p->system == ORC_SYS_PMSM) return 1.5 * mp[0] * (mp[4] + (mp[1] - mp[2]) * ms[0]) * ms[1];
     return 1.5 * mp[0] * mp[1] / (mp[1] + mp[3]) * (ms[2] * ms[1] - ms[3] * ms[0]);
 }
@@ -150,6 +177,11 @@ static void electrical_ode(const orc_params *p, const orc_env *e, const double *
         f[0] = ms[0]; f[1] = omega * ms[0]; f[2] = u[0]; nf = 3; nr = 1;
     } else if (p->system == ORC_SYS_DC_SHUNT) { /* dc_shunt_motor.py:72-74: u_a = u_e = u; dc_motor.py:114-127 */
         f[0] = ms[0]; f[1] = ms[1]; f[2] = omega * ms[1]; f[3] = u[0]; f[4] = u[0]; nf = 5; nr = 2;
+    } else if (p->system == ORC_SYS_DC_EXTEX) { /* dc_motor.py:114-127 with separate u_a, u_e */
+        f[0] = ms[0]; f[1] = ms[1]; f[2] = omega * ms[1]; f[3] = u[0]; f[4] = u[1]; nf = 5; nr = 2;
+    } else if (p->system == ORC_SYS_EESM) { /* externally_excited_synchronous_motor.py:95-113 */
+        f[0] = omega; f[1] = ms[0]; f[2] = ms[1]; f[3] = ms[2]; f[4] = u[0]; f[5] = u[1]; f[6] = u[2];
+        f[7] = omega * ms[0]; f[8] = omega * ms[1]; f[9] = omega * ms[2]; nf = 10; nr = 4;
     } else if (p->system == ORC_SYS_PMSM) {
         f[0] = omega; f[1] = ms[0]; f[2] = ms[1]; f[3] = u[0]; f[4] = u[1]; f[5] = omega * ms[0]; f[6] = omega * ms[1];
         nf = 7; nr = 3;
@@ -393,57 +425,106 @@ static double fin2qc_convert(const orc_params *p, orc_env *e, int leg, double i,
 static const int B6_SUBACTIONS[8][3] = {{2, 2, 2}, {2, 2, 1}, {2, 1, 2}, {2, 1, 1},
                                         {1, 2, 2}, {1, 2, 1}, {1, 1, 2}, {1, 1, 1}}; /* converters.py:788-797 */
 
-/* converter.set_action: returns the number of integration segments; seg_end[] = absolute switching times */
-static int conv_set_action(const orc_params *p, orc_env *e, const double *action, double t, double *seg_end) {
-    e->action_start = t; /* converters.py:67 */
-    if (p->converter == ORC_CONV_CONT_4QC) { /* converters.py:485-491 */
-        e->duty[0][0] = clip(0.5 * (action[0] + 1.0), 0.0, 1.0);
-        e->duty[0][1] = clip(-0.5 * (action[0] - 1.0), 0.0, 1.0);
-        seg_end[0] = t + p->tau;
+/* One plain converter `kind` (0..3) whose first half-bridge / duty slot is `leg0`.  Returns the length of the
+ * switching-time list the reference's set_action() returns (1: [t+tau], 2: [t+t_il, t+tau]). */
+static int sub_set_action(const orc_params *p, orc_env *e, int kind, int leg0, const double *action) {
+    if (kind == ORC_CONV_CONT_4QC) { /* converters.py:485-491 */
+        e->duty[leg0][0] = clip(0.5 * (action[0] + 1.0), 0.0, 1.0);
+        e->duty[leg0][1] = clip(-0.5 * (action[0] - 1.0), 0.0, 1.0);
         return 1;
     }
-    if (p->converter == ORC_CONV_CONT_B6) { /* converters.py:897-903 */
-        for (int l = 0; l < 3; ++l) e->duty[l][0] = clip(0.5 * (action[l] + 1.0), 0.0, 1.0);
-        seg_end[0] = t + p->tau;
+    if (kind == ORC_CONV_CONT_B6) { /* converters.py:897-903 */
+        for (int l = 0; l < 3; ++l) e->duty[leg0 + l][0] = clip(0.5 * (action[l] + 1.0), 0.0, 1.0);
         return 1;
     }
-    if (p->converter == ORC_CONV_FINITE_4QC) { /* FiniteFourQuadrantConverter.set_action, converters.py:354-364 */
+    int two = 0;
+    if (kind == ORC_CONV_FINITE_4QC) { /* FiniteFourQuadrantConverter.set_action, converters.py:354-364 */
         static const int A0[4] = {1, 1, 2, 2}, A1[4] = {1, 2, 1, 2};
         int a4 = (int)action[0];
-        int two4 = 0;
-        if (fin2qc_set_action(p, e, 0, A0[a4]) == 2) two4 = 1;
-        if (fin2qc_set_action(p, e, 1, A1[a4]) == 2) two4 = 1;
-        if (two4) { seg_end[0] = t + p->t_il; seg_end[1] = t + p->tau; return 2; }
-        seg_end[0] = t + p->tau;
-        return 1;
+        if (fin2qc_set_action(p, e, leg0, A0[a4]) == 2) two = 1;
+        if (fin2qc_set_action(p, e, leg0 + 1, A1[a4]) == 2) two = 1;
+    } else { /* Finite-B6C, converters.py:825-835: union of the legs' switching times, sorted */
+        int a = (int)action[0];
+        for (int l = 0; l < 3; ++l)
+            if (fin2qc_set_action(p, e, leg0 + l, B6_SUBACTIONS[a][l]) == 2) two = 1;
     }
-    /* Finite-B6C, converters.py:825-835: union of the legs' switching times, sorted */
-    int a = (int)action[0];
-    int two = 0;
-    for (int l = 0; l < 3; ++l)
-        if (fin2qc_set_action(p, e, l, B6_SUBACTIONS[a][l]) == 2) two = 1;
+    return two ? 2 : 1;
+}
+
+/* convert(i_out, t) of one plain converter: normalised output voltages (1 for 4QC, 3 for B6) */
+static void sub_convert(const orc_params *p, orc_env *e, int kind, int leg0, const double *i_in, double t, double *u) {
+    if (kind == ORC_CONV_CONT_4QC) { /* converters.py:481-483: both sub-converters see the SAME i_out */
+        u[0] = cont2qc_convert(p, e->duty[leg0][0], i_in[0]) - cont2qc_convert(p, e->duty[leg0][1], i_in[0]);
+    } else if (kind == ORC_CONV_CONT_B6) { /* converters.py:888-895 */
+        for (int l = 0; l < 3; ++l) u[l] = cont2qc_convert(p, e->duty[leg0 + l][0], i_in[l]) - 0.5;
+    } else if (kind == ORC_CONV_FINITE_4QC) { /* converters.py:350-352: second leg sees -i_out */
+        u[0] = fin2qc_convert(p, e, leg0, i_in[0], t) - fin2qc_convert(p, e, leg0 + 1, -i_in[0], t);
+    } else { /* converters.py:816-823 */
+        for (int l = 0; l < 3; ++l) u[l] = fin2qc_convert(p, e, leg0 + l, i_in[l], t) - 0.5;
+    }
+}
+
+static int sub_nsig(int kind) { return (kind == ORC_CONV_CONT_B6 || kind == ORC_CONV_FINITE_B6) ? 3 : 1; }
+static int sub_nact(int kind) { return kind == ORC_CONV_CONT_B6 ? 3 : 1; }
+static int sub_nleg(int kind) { return kind == ORC_CONV_CONT_4QC ? 1 : (kind == ORC_CONV_FINITE_4QC ? 2 : 3); }
+
+/* Decompose a converter kind into its plain sub-converters (MultiConverter: converters.py:519-548 / 640-676) */
+static int conv_subs(const orc_params *p, int *kinds) {
+    switch (p->converter) {
+        case ORC_CONV_CONT_2X4QC: kinds[0] = kinds[1] = ORC_CONV_CONT_4QC; return 2;
+        case ORC_CONV_FINITE_2X4QC: kinds[0] = kinds[1] = ORC_CONV_FINITE_4QC; return 2;
+        case ORC_CONV_CONT_B6_4QC: kinds[0] = ORC_CONV_CONT_B6; kinds[1] = ORC_CONV_CONT_4QC; return 2;
+        case ORC_CONV_FINITE_B6_4QC: kinds[0] = ORC_CONV_FINITE_B6; kinds[1] = ORC_CONV_FINITE_4QC; return 2;
+        default: kinds[0] = p->converter; return 1;
+    }
+}
+static int conv_nsig(const orc_params *p) {
+    int kinds[2], n = conv_subs(p, kinds), tot = 0;
+    for (int i = 0; i < n; ++i) tot += sub_nsig(kinds[i]);
+    return tot;
+}
+static int conv_nact(const orc_params *p) {
+    int kinds[2], n = conv_subs(p, kinds), tot = 0;
+    for (int i = 0; i < n; ++i) tot += sub_nact(kinds[i]);
+    return tot;
+}
+int orc_n_act(const orc_params *p) { return conv_nact(p); }
+
+/* converter.set_action: returns the number of integration segments; seg_end[] = absolute switching times.
+ * MultiConverter.set_action (converters.py:566-570 / 678-685): the action is split per sub-converter and the
+ * switching times are the sorted UNION of the sub-converters' lists, so one dead-time transition anywhere makes
+ * [t + t_il, t + tau] (all sub-converters share tau; the restatement assumes they share t_il as well). */
+static int conv_set_action(const orc_params *p, orc_env *e, const double *action, double t, double *seg_end) {
+    e->action_start = t; /* converters.py:67 */
+    int kinds[2], n = conv_subs(p, kinds), leg0 = 0, two = 0;
+    for (int i = 0; i < n; ++i) {
+        if (sub_set_action(p, e, kinds[i], leg0, action) == 2) two = 1;
+        action += sub_nact(kinds[i]);
+        leg0 += sub_nleg(kinds[i]);
+    }
     if (two) { seg_end[0] = t + p->t_il; seg_end[1] = t + p->tau; return 2; }
     seg_end[0] = t + p->tau;
     return 1;
 }
 
-/* converter.convert(i_out, t): normalised output voltages (1 for DC, 3 for B6) */
+/* converter.convert(i_out, t); MultiConverter.convert slices i_out by the sub-converters' signal widths
+ * (converters.py:550-558 / 693-701) */
 static void conv_convert(const orc_params *p, orc_env *e, const double *i_in, double t, double *u) {
-    if (p->converter == ORC_CONV_CONT_4QC) { /* converters.py:481-483: both sub-converters see the SAME i_out */
-        u[0] = cont2qc_convert(p, e->duty[0][0], i_in[0]) - cont2qc_convert(p, e->duty[0][1], i_in[0]);
-    } else if (p->converter == ORC_CONV_CONT_B6) { /* converters.py:888-895 */
-        for (int l = 0; l < 3; ++l) u[l] = cont2qc_convert(p, e->duty[l][0], i_in[l]) - 0.5;
-    } else if (p->converter == ORC_CONV_FINITE_4QC) { /* converters.py:350-352: second leg sees -i_out */
-        u[0] = fin2qc_convert(p, e, 0, i_in[0], t) - fin2qc_convert(p, e, 1, -i_in[0], t);
-    } else { /* converters.py:816-823 */
-        for (int l = 0; l < 3; ++l) u[l] = fin2qc_convert(p, e, l, i_in[l], t) - 0.5;
+    int kinds[2], n = conv_subs(p, kinds), leg0 = 0;
+    for (int i = 0; i < n; ++i) {
+        sub_convert(p, e, kinds[i], leg0, i_in, t, u);
+        i_in += sub_nsig(kinds[i]); u += sub_nsig(kinds[i]);
+        leg0 += sub_nleg(kinds[i]);
     }
 }
 
 static void conv_reset(const orc_params *p, orc_env *e, double *u) {
     e->action_start = 0.0; /* converters.py:45-54; switching state/pattern intentionally untouched */
-    if (p->converter == ORC_CONV_CONT_4QC || p->converter == ORC_CONV_FINITE_4QC) u[0] = 0.0; /* converters.py:344-348, 475-479 */
-    else { u[0] = u[1] = u[2] = -0.5; } /* converters.py:808-814, 880-886 */
+    int kinds[2], n = conv_subs(p, kinds);
+    for (int i = 0; i < n; ++i) {
+        if (sub_nsig(kinds[i]) == 1) *u++ = 0.0;                /* converters.py:344-348, 475-479 */
+        else { u[0] = u[1] = u[2] = -0.5; u += 3; }            /* converters.py:808-814, 880-886 */
+    }
 }
 
 /* ---------------------------------------------------------------- simulate --------------------- */
@@ -460,34 +541,62 @@ static void normalise(const orc_params *p, double *obs) {
 }
 
 /* SCMLSystem.simulate (DC motors), physical_systems.py:171-203.  i_in = motor.i_in(currents): the current itself
- * (dc_permanently_excited_motor.py:77-79, dc_series_motor.py:85-87) or i_a + i_e (dc_shunt_motor.py:68-70). */
-static double dc_i_in(const orc_params *p, const orc_env *e) {
-    return p->system == ORC_SYS_DC_SHUNT ? e->y[1] + e->y[2] : e->y[1];
+ * (dc_permanently_excited_motor.py:77-79, dc_series_motor.py:85-87), i_a + i_e (dc_shunt_motor.py:68-70) or the
+ * list [i_a, i_e] (externally excited: DcMotor.i_in). */
+static void dc_i_in(const orc_params *p, const orc_env *e, double *i_in) {
+    if (p->system == ORC_SYS_DC_SHUNT) i_in[0] = e->y[1] + e->y[2];
+    else if (p->system == ORC_SYS_DC_EXTEX) { i_in[0] = e->y[1]; i_in[1] = e->y[2]; } /* dc_motor.py:110-112 */
+    else i_in[0] = e->y[1];
 }
 static void simulate_dc(const orc_params *p, orc_env *e, const double *action, double *obs) {
-    double seg_end[2], i_in[1], u_n[1], u_in[1];
+    double seg_end[2], i_in[2], u_n[2], u_in[2] = {0};
     double u_sup = p->u_sup; /* IdealVoltageSupply.get_voltage, voltage_supplies.py:70-72 */
-    i_in[0] = dc_i_in(p, e);
+    int nu = conv_nsig(p);
+    dc_i_in(p, e, i_in);
     int nseg = conv_set_action(p, e, action, e->t, seg_end);
     double t0 = e->t;
     for (int s = 0; s < nseg; ++s) {
         conv_convert(p, e, i_in, e->t, u_n);
-        u_in[0] = u_n[0] * u_sup;
-        e->u[0] = u_in[0];
+        for (int j = 0; j < nu; ++j) { u_in[j] = u_n[j] * u_sup; e->u[j] = u_in[j]; }
         integrate(p, e, s == nseg - 1 ? t0 + p->tau : seg_end[s]);
-        i_in[0] = dc_i_in(p, e);
+        dc_i_in(p, e, i_in);
     }
     e->k += 1;
     int nc = n_ode(p) - 1;
     obs[0] = e->y[0]; obs[1] = motor_torque(p, e->y + 1);
     for (int c = 0; c < nc; ++c) obs[2 + c] = e->y[1 + c];
-    obs[2 + nc] = u_in[0]; obs[3 + nc] = u_sup;
+    for (int j = 0; j < nu; ++j) obs[2 + nc + j] = u_in[j];
+    obs[2 + nc + nu] = u_sup;
+    normalise(p, obs);
+}
+
+/* ExternallyExcitedSynchronousMotorSystem.simulate, physical_systems.py:619-652.  The reference's dead-time loop
+ * (lines 628-638) calls abc_to_dq_space(u_in[:2], eps) and cannot run; only the single-segment path exists. */
+static void simulate_eesm(const orc_params *p, orc_env *e, const double *action, double *obs) {
+    double seg_end[2], i_in[4], u_n[4], u_in[4], u_dq[2], i_abc[3];
+    double u_sup = p->u_sup;
+    double eps = e->y[4];
+    dq_to_abc(e->y + 1, eps, i_in);
+    i_in[3] = e->y[3];
+    conv_set_action(p, e, action, e->t, seg_end);
+    conv_convert(p, e, i_in, e->t, u_n);
+    for (int l = 0; l < 4; ++l) u_in[l] = u_n[l] * u_sup;
+    abc_to_dq(u_in, eps, u_dq);
+    e->u[0] = u_dq[0]; e->u[1] = u_dq[1]; e->u[2] = u_in[3];
+    integrate(p, e, e->t + p->tau);
+    e->k += 1;
+    double torque = motor_torque(p, e->y + 1);
+    dq_to_abc(e->y + 1, eps, i_abc); /* eps of the step start (line 646) */
+    obs[0] = e->y[0]; obs[1] = torque;
+    obs[2] = i_abc[0]; obs[3] = i_abc[1]; obs[4] = i_abc[2]; obs[5] = e->y[1]; obs[6] = e->y[2]; obs[7] = e->y[3];
+    obs[8] = u_in[0]; obs[9] = u_in[1]; obs[10] = u_in[2]; obs[11] = u_dq[0]; obs[12] = u_dq[1]; obs[13] = u_in[3];
+    obs[14] = wrap_eps(e->y[4]); obs[15] = u_sup;
     normalise(p, obs);
 }
 
 /* SynchronousMotorSystem.simulate, physical_systems.py:487-525 (control_space == 'abc') */
 static void simulate_pmsm(const orc_params *p, orc_env *e, const double *action, double *obs) {
-    double seg_end[2], i_in[3], u_n[3], u_in[3], u_dq[2], i_abc[3];
+    double seg_end[2], i_in[3], u_n[3], u_in[3] = {0}, u_dq[2] = {0}, i_abc[3];
     double u_sup = p->u_sup;
     double eps = e->y[3];
     dq_to_abc(e->y + 1, eps, i_in);
@@ -513,7 +622,7 @@ static void simulate_pmsm(const orc_params *p, orc_env *e, const double *action,
 
 /* SquirrelCageInductionMotorSystem.simulate, physical_systems.py:771-814 (control_space == 'abc') */
 static void simulate_scim(const orc_params *p, orc_env *e, const double *action, double *obs) {
-    double seg_end[2], i_in[3], u_n[3], u_in[3], u_dq[2], u_ab[2], i_dq[2], i_abc[3];
+    double seg_end[2], i_in[3], u_n[3], u_in[3] = {0}, u_dq[2] = {0}, u_ab[2], i_dq[2], i_abc[3];
     double u_sup = p->u_sup;
     double eps_fs = atan2(e->y[4], e->y[3]); /* calculate_field_angle, 765-769 */
     t_32(e->y + 1, i_in);
@@ -552,15 +661,28 @@ void orc_reset(const orc_params *p, orc_env *e, double *obs) {
     for (int i = 0; i < n; ++i) e->y[i] = p->init[i];
     e->t = 0.0; e->k = 0;
     e->dp_h = 0.0; /* ode.set_initial_value() re-creates the integrator work array */
-    double u_n[3], u_abc[3], u_dq[2], i_abc[3], i_dq[2];
+    double u_n[4], u_abc[4], u_dq[2], i_abc[3], i_dq[2];
     double u_sup = p->u_sup;
     conv_reset(p, e, u_n);
     double torque = motor_torque(p, e->y + 1);
     if (ORC_IS_DC(p->system)) {
-        int nc = n - 1;
+        int nc = n - 1, nu = conv_nsig(p);
         obs[0] = e->y[0]; obs[1] = torque;
         for (int c = 0; c < nc; ++c) obs[2 + c] = e->y[1 + c];
-        obs[2 + nc] = u_n[0] * u_sup; obs[3 + nc] = u_sup;
+        for (int j = 0; j < nu; ++j) obs[2 + nc + j] = u_n[j] * u_sup;
+        obs[2 + nc + nu] = u_sup;
+    } else if (p->system == ORC_SYS_EESM) { /* physical_systems.py:654-691 */
+        double eps = e->y[4];
+        if (eps > M_PI) eps -= 2.0 * M_PI;
+        for (int l = 0; l < 4; ++l) u_abc[l] = u_n[l] * u_sup;
+        abc_to_dq(u_abc, eps, u_dq);
+        dq_to_abc(e->y + 1, eps, i_abc);
+        obs[0] = e->y[0]; obs[1] = torque; obs[2] = i_abc[0]; obs[3] = i_abc[1]; obs[4] = i_abc[2];
+        obs[5] = e->y[1]; obs[6] = e->y[2]; obs[7] = e->y[3];
+        /* the reference concatenates (u_a,u_b,u_c,u_e) then (u_sd,u_sq) here -- NOT the state_names order
+         * (lines 679-690); with the converter's reset voltages (u_e = 0, u_sd ~ u_sq ~ 0) this is invisible */
+        obs[8] = u_abc[0]; obs[9] = u_abc[1]; obs[10] = u_abc[2]; obs[11] = u_abc[3]; obs[12] = u_dq[0]; obs[13] = u_dq[1];
+        obs[14] = eps; obs[15] = u_sup;
     } else if (p->system == ORC_SYS_PMSM) {
         double eps = e->y[3];
         if (eps > M_PI) eps -= 2.0 * M_PI;
@@ -588,6 +710,7 @@ void orc_reset(const orc_params *p, orc_env *e, double *obs) {
 void orc_step(const orc_params *p, orc_env *e, const double *action, double *obs) {
     if (ORC_IS_DC(p->system)) simulate_dc(p, e, action, obs);
     else if (p->system == ORC_SYS_PMSM) simulate_pmsm(p, e, action, obs);
+    else if (p->system == ORC_SYS_EESM) simulate_eesm(p, e, action, obs);
     else simulate_scim(p, e, action, obs);
 }
 
@@ -646,15 +769,19 @@ size_t orc_sizeof_env(void) { return sizeof(orc_env); }
 
 /* Converter known-answer hook: set_action(action, t) then convert(i_seg, t_segment_start) for each segment,
  * exactly as *.simulate() drives the converter.  currents/volt: [2][3].  Returns the number of segments. */
-int orc_kat_converter(const orc_params *p, orc_env *e, const double *action, double t, const double *currents,
-                      double *volt) {
+int orc_kat_converter_n(const orc_params *p, orc_env *e, const double *action, double t, const double *currents,
+                        double *volt, int stride) {
     double seg_end[2];
     int nseg = conv_set_action(p, e, action, t, seg_end);
     double t_seg = t;
     for (int s = 0; s < nseg; ++s) {
-        conv_convert(p, e, currents + 3 * s, t_seg, volt + 3 * s);
+        conv_convert(p, e, currents + stride * s, t_seg, volt + stride * s);
         t_seg = seg_end[s];
     }
     return nseg;
+}
+int orc_kat_converter(const orc_params *p, orc_env *e, const double *action, double t, const double *currents,
+                      double *volt) {
+    return orc_kat_converter_n(p, e, action, t, currents, volt, 3);
 }
 void orc_kat_converter_reset(const orc_params *p, orc_env *e, double *u) { conv_reset(p, e, u); }

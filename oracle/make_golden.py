@@ -57,11 +57,19 @@ def gen_actions(space_kind, K, seed, mode):
         shape, disc = (K, 1), False
     elif space_kind == "box3":
         shape, disc = (K, 3), False
+    elif space_kind == "box2":
+        shape, disc = (K, 2), False
+    elif space_kind == "box4":
+        shape, disc = (K, 4), False
     elif space_kind in ("disc8", "disc4"):
         shape, disc = (K,), True
+    elif space_kind in ("mdisc44", "mdisc84"):  # MultiDiscrete of a FiniteMultiConverter (converters.py:546)
+        shape, disc = (K, 2), True
     else:
         raise KeyError(space_kind)
     nact = 4 if space_kind == "disc4" else 8
+    if space_kind.startswith("mdisc"):
+        nact = np.array([int(space_kind[5]), int(space_kind[6])])
     if mode == "uniform":
         return rng.integers(0, nact, shape).astype(np.int64) if disc else rng.uniform(-1, 1, shape)
     # held
@@ -70,7 +78,7 @@ def gen_actions(space_kind, K, seed, mode):
     while k < K:
         dwell = int(rng.integers(1, 40))
         if disc:
-            v = rng.integers(0, nact)
+            v = rng.integers(0, nact)  # array-valued `nact` -> one draw per sub-converter
         else:
             v = rng.uniform(-1, 1, shape[1:]) * rng.uniform(0.0, 1.0)
         out[k : k + dwell] = v
@@ -92,12 +100,19 @@ def describe(env):
         limits=[float(x) for x in psys.limits],
         nominal_state=[float(x) for x in psys.nominal_state],
         tau=float(psys.tau),
-        interlocking_time=float(conv._interlocking_time),
+        interlocking_time=float(conv._interlocking_time),  # multi converters: overwritten below
         u_nominal=float(sup.u_nominal),
         motor_parameter={k: float(v) for k, v in motor.motor_parameter.items()},
         model_constants=np.asarray(motor._model_constants, dtype=float).tolist(),
         j_total=float(load.j_total),
     )
+    subs = getattr(conv, "_sub_converters", None)
+    if subs is not None:
+        # Cont/FiniteMultiConverter: the holder's own interlocking time is never used; the sub-converters' are
+        meta["converter"] += "[" + ",".join(type(sc).__name__ for sc in subs) + "]"
+        tils = {float(sc._interlocking_time) for sc in subs}
+        assert len(tils) == 1, tils
+        meta["interlocking_time"] = tils.pop()
     if isinstance(load, ps.PolynomialStaticLoad):
         meta["load_parameter"] = {k: float(v) for k, v in load.load_parameter.items()}
         meta["tau_decay"] = float(load.tau_decay)
@@ -124,6 +139,8 @@ def run_case(name, env_id, solver, K, seed, mode, episodic, space_kind, every=1,
         a = actions[k]
         if space_kind.startswith("disc"):
             a = int(a)
+        elif space_kind.startswith("mdisc"):
+            a = np.array(a, dtype=np.int64)
         (s, _), _, terminated, _, _ = env.step(a)
         states[k] = s[:n_keep]
         term[k] = terminated
@@ -136,7 +153,7 @@ def run_case(name, env_id, solver, K, seed, mode, episodic, space_kind, every=1,
     keep = idx[(idx % every == every - 1)] if every > 1 else idx
     np.savez_compressed(
         os.path.join(OUT, name + ".npz"),
-        actions=actions.astype(np.uint8) if space_kind.startswith("disc") else actions,
+        actions=actions.astype(np.uint8) if "disc" in space_kind else actions,
         states=states[keep],
         state_index=keep.astype(np.int64),
         terminated=term,
@@ -278,8 +295,15 @@ def converter_kats():
     print("converter KATs written")
 
 
-def main():
+def main(only=None):
+    """`only`: optional set of groups to (re)generate -- {"multi"}; default: everything."""
     os.makedirs(OUT, exist_ok=True)
+    if not only:
+        main_base()
+    main_multi(only)
+
+
+def main_base():
     replay_ref_data()
     converter_kats()
     dc, pmsm, scim = "Cont-CC-PermExDc-v0", "Finite-CC-PMSM-v0", "Cont-SC-SCIM-v0"
@@ -350,5 +374,38 @@ def main():
     run_case("shunt_cont_epi_held_euler", "Cont-CC-ShuntDc-v0", "euler", K, 1253, "held", True, "box1")
 
 
+def main_multi(only=None):
+    """Multi-converter systems: ExtExDc = 2 x 4QC, EESM = B6 + 4QC."""
+    K = 2000
+    xc, xf = "Cont-CC-ExtExDc-v0", "Finite-CC-ExtExDc-v0"
+    for solver in ("euler", "dopri5"):
+        run_case(f"extex_cont_free_held_{solver}", xc, solver, K, 1260, "held", False, "box2")
+        run_case(f"extex_cont_sc_free_held_{solver}", "Cont-SC-ExtExDc-v0", solver, K, 1261, "held", False, "box2")
+        run_case(f"extex_fin_free_held_{solver}", xf, solver, K, 1262, "held", False, "mdisc44")
+        run_case(f"eesm_cont_free_held_{solver}", "Cont-CC-EESM-v0", solver, K, 1270, "held", False, "box4")
+        # episodic: the default EESM parameter set has sigma < 0 (an exponentially unstable d/e-axis pair), a free run
+        # of the speed-control env overflows
+        run_case(f"eesm_cont_sc_epi_held_{solver}", "Cont-SC-EESM-v0", solver, K, 1271, "held", True, "box4")
+        run_case(f"eesm_fin_free_held_{solver}", "Finite-CC-EESM-v0", solver, K, 1272, "held", False, "mdisc84")
+    run_case("extex_cont_free_uniform_euler", xc, "euler", K, 1263, "uniform", False, "box2")
+    run_case("extex_cont_epi_held_euler", xc, "euler", K, 1264, "held", True, "box2")
+    run_case("extex_fin_epi_held_euler", xf, "euler", K, 1265, "held", True, "mdisc44")
+    run_case("extex_fin_free_uniform_euler", xf, "euler", K, 1266, "uniform", False, "mdisc44")
+    # dead time: `converter=dict(interlocking_time=...)` only reaches the holder, so build the sub-converters by hand
+    run_case("extex_fin_free_held_til_euler", xf, "euler", K, 1267, "held", False, "mdisc44",
+             converter=ps.FiniteMultiConverter(subconverters=[ps.FiniteFourQuadrantConverter(interlocking_time=1e-6),
+                                                              ps.FiniteFourQuadrantConverter(interlocking_time=1e-6)]))
+    run_case("extex_fin_free_uniform_til_euler", xf, "euler", K, 1268, "uniform", False, "mdisc44",
+             converter=ps.FiniteMultiConverter(subconverters=[ps.FiniteFourQuadrantConverter(interlocking_time=1e-6),
+                                                              ps.FiniteFourQuadrantConverter(interlocking_time=1e-6)]))
+    run_case("extex_cont_free_held_til_euler", xc, "euler", K, 1269, "held", False, "box2",
+             converter=ps.ContMultiConverter(subconverters=[ps.ContFourQuadrantConverter(interlocking_time=2e-6),
+                                                            ps.ContFourQuadrantConverter(interlocking_time=2e-6)]))
+    run_case("eesm_cont_free_uniform_euler", "Cont-CC-EESM-v0", "euler", K, 1273, "uniform", False, "box4")
+    run_case("eesm_cont_epi_held_euler", "Cont-CC-EESM-v0", "euler", 4000, 1274, "held", True, "box4")
+    run_case("eesm_fin_epi_held_tau1e-4_euler", "Finite-CC-EESM-v0", "euler", 4000, 1275, "held", True, "mdisc84", tau=1e-4)
+    run_case("eesm_fin_free_uniform_euler", "Finite-CC-EESM-v0", "euler", K, 1276, "uniform", False, "mdisc84")
+
+
 if __name__ == "__main__":
-    main()
+    main(set(sys.argv[1:]))

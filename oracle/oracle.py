@@ -13,8 +13,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgemx_oracle.so")
 
-SYS_DC, SYS_PMSM, SYS_SCIM, SYS_DC_SERIES, SYS_DC_SHUNT = 0, 1, 2, 3, 4
+SYS_DC, SYS_PMSM, SYS_SCIM, SYS_DC_SERIES, SYS_DC_SHUNT, SYS_DC_EXTEX, SYS_EESM = 0, 1, 2, 3, 4, 5, 6
 CONV_C4QC, CONV_FB6, CONV_CB6, CONV_F4QC = 0, 1, 2, 3
+CONV_C2X4QC, CONV_F2X4QC, CONV_CB6_4QC, CONV_FB6_4QC = 4, 5, 6, 7  # Cont/FiniteMultiConverter of two sub-converters
 LOAD_CONST, LOAD_POLY = 0, 1
 SOLVER_EULER, SOLVER_RK4, SOLVER_DOPRI5, SOLVER_DP5_FIXED = 0, 1, 2, 3
 
@@ -58,16 +59,25 @@ def lib():
     return _lib
 
 
-_SYS = {"DcMotorSystem": SYS_DC, "SynchronousMotorSystem": SYS_PMSM, "SquirrelCageInductionMotorSystem": SYS_SCIM}
+_SYS = {"DcMotorSystem": SYS_DC, "SynchronousMotorSystem": SYS_PMSM, "SquirrelCageInductionMotorSystem": SYS_SCIM,
+        "ExternallyExcitedSynchronousMotorSystem": SYS_EESM}
 _CONV = {"ContFourQuadrantConverter": CONV_C4QC, "FiniteB6BridgeConverter": CONV_FB6, "ContB6BridgeConverter": CONV_CB6,
-         "FiniteFourQuadrantConverter": CONV_F4QC}
-_DC_MOTOR_SYS = {"DcPermanentlyExcitedMotor": SYS_DC, "DcSeriesMotor": SYS_DC_SERIES, "DcShuntMotor": SYS_DC_SHUNT}
+         "FiniteFourQuadrantConverter": CONV_F4QC,
+         # multi converters: make_golden.describe() appends the sub-converter class names
+         "ContMultiConverter[ContFourQuadrantConverter,ContFourQuadrantConverter]": CONV_C2X4QC,
+         "FiniteMultiConverter[FiniteFourQuadrantConverter,FiniteFourQuadrantConverter]": CONV_F2X4QC,
+         "ContMultiConverter[ContB6BridgeConverter,ContFourQuadrantConverter]": CONV_CB6_4QC,
+         "FiniteMultiConverter[FiniteB6BridgeConverter,FiniteFourQuadrantConverter]": CONV_FB6_4QC}
+_DC_MOTOR_SYS = {"DcPermanentlyExcitedMotor": SYS_DC, "DcSeriesMotor": SYS_DC_SERIES, "DcShuntMotor": SYS_DC_SHUNT,
+                 "DcExternallyExcitedMotor": SYS_DC_EXTEX}
 _LOAD = {"ConstantSpeedLoad": LOAD_CONST, "PolynomialStaticLoad": LOAD_POLY}
 _SOLVER = {"euler": (SOLVER_EULER, 1), "euler4": (SOLVER_EULER, 4), "rk4": (SOLVER_RK4, 1), "rk4x4": (SOLVER_RK4, 4), "rk4x8": (SOLVER_RK4, 8),
            "dopri5": (SOLVER_DOPRI5, 1), "ivp_tight": (SOLVER_DOPRI5, 1), "dp5_fixed": (SOLVER_DP5_FIXED, 1)}
 _MP_KEYS = {SYS_DC: ("r_a", "l_a", "psi_e"), SYS_PMSM: ("p", "l_d", "l_q", "r_s", "psi_p"),
             SYS_SCIM: ("p", "l_m", "l_sigs", "l_sigr", "r_s", "r_r"),
-            SYS_DC_SERIES: ("r_a", "r_e", "l_a", "l_e", "l_e_prime"), SYS_DC_SHUNT: ("r_a", "r_e", "l_a", "l_e", "l_e_prime")}
+            SYS_DC_SERIES: ("r_a", "r_e", "l_a", "l_e", "l_e_prime"), SYS_DC_SHUNT: ("r_a", "r_e", "l_a", "l_e", "l_e_prime"),
+            SYS_DC_EXTEX: ("r_a", "r_e", "l_a", "l_e", "l_e_prime"),
+            SYS_EESM: ("p", "l_d", "l_q", "l_m", "l_e", "r_s", "r_e", "k")}
 
 
 def default_masks(meta):
@@ -76,10 +86,11 @@ def default_masks(meta):
     (finite_cc_pmsm_env.py:106, cont_sc_scim_env.py:111)."""
     names = meta["state_names"]
     if meta["system"] == "DcMotorSystem":
-        if meta["motor"] == "DcShuntMotor":  # constraints=("i_a", "i_e"), cont_cc_shunt_dc_env.py:103
+        if meta["motor"] in ("DcShuntMotor", "DcExternallyExcitedMotor"):  # constraints=("i_a", "i_e"), cont_cc_shunt_dc_env.py:103
             return (1 << names.index("i_a")) | (1 << names.index("i_e")), 0
         return 1 << names.index("i"), 0
-    return 0, (1 << names.index("i_sd")) | (1 << names.index("i_sq"))
+    lim = 1 << names.index("i_e") if "i_e" in names else 0  # EESM: + LimitConstraint(("i_e",)), cont_cc_eesm_env.py:108
+    return lim, (1 << names.index("i_sd")) | (1 << names.index("i_sq"))
 
 
 def params_from_meta(meta, solver=None, episodic=None):
@@ -119,7 +130,7 @@ class OracleEnv:
         self.L.orc_init(C.byref(self.p), self._env)
         self.n_out = self.L.orc_n_out(C.byref(self.p))
         self.n_ode = self.L.orc_n_ode(C.byref(self.p))
-        self.n_act = 3 if self.p.converter == CONV_CB6 else 1
+        self.n_act = self.L.orc_n_act(C.byref(self.p))
 
     def reset(self):
         obs = np.zeros(self.n_out)
@@ -148,16 +159,18 @@ class OracleEnv:
         return bool(self.L.orc_done(C.byref(self.p), full.ctypes.data_as(C.c_void_p)))
 
     def kat_converter(self, action, t, currents):
-        """set_action + per-segment convert; currents [2,3] -> (nseg, volt [2,3])."""
+        """set_action + per-segment convert; currents [2,n] -> (nseg, volt [2,n])  (n = 3, or 2 / 4 for multi converters)."""
         a = np.ascontiguousarray(np.atleast_1d(action), dtype=np.float64)
-        cur = np.ascontiguousarray(currents, dtype=np.float64).reshape(2, 3)
-        volt = np.zeros((2, 3))
-        nseg = self.L.orc_kat_converter(C.byref(self.p), self._env, a.ctypes.data_as(C.c_void_p), C.c_double(t),
-                                        cur.ctypes.data_as(C.c_void_p), volt.ctypes.data_as(C.c_void_p))
+        cur = np.ascontiguousarray(currents, dtype=np.float64)
+        cur = cur.reshape(2, -1)
+        n = cur.shape[1]
+        volt = np.zeros((2, n))
+        nseg = self.L.orc_kat_converter_n(C.byref(self.p), self._env, a.ctypes.data_as(C.c_void_p), C.c_double(t),
+                                          cur.ctypes.data_as(C.c_void_p), volt.ctypes.data_as(C.c_void_p), C.c_int(n))
         return nseg, volt
 
     def kat_converter_reset(self):
-        u = np.zeros(3)
+        u = np.zeros(4)
         self.L.orc_kat_converter_reset(C.byref(self.p), self._env, u.ctypes.data_as(C.c_void_p))
         return u
 

@@ -72,7 +72,8 @@ def test_fixed_step_rk4_close_to_reference_default_solver(name):
 
 
 def test_model_constants_and_limits_match_reference():
-    for name in ("permexdc_free_held_euler", "pmsm_free_held_euler", "scim_free_held_euler"):
+    for name in ("permexdc_free_held_euler", "pmsm_free_held_euler", "scim_free_held_euler", "series_cont_free_held_euler",
+                 "shunt_cont_free_held_euler", "extex_cont_free_held_euler", "eesm_cont_free_held_euler"):
         d, meta = orc.load_golden(name)
         env = orc.OracleEnv(orc.params_from_meta(meta))
         ref = np.asarray(meta["model_constants"])
