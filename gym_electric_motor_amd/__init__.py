@@ -8,13 +8,17 @@ from .components import (  # noqa: F401
     ConstantSpeedLoad,
     ContB6BridgeConverter,
     ContFourQuadrantConverter,
+    ContMultiConverter,
+    DcExternallyExcitedMotor,
     DcPermanentlyExcitedMotor,
     DcSeriesMotor,
     DcShuntMotor,
     DormandPrince5Solver,
     EulerSolver,
+    ExternallyExcitedSynchronousMotor,
     FiniteB6BridgeConverter,
     FiniteFourQuadrantConverter,
+    FiniteMultiConverter,
     IdealVoltageSupply,
     PermanentMagnetSynchronousMotor,
     PolynomialStaticLoad,
@@ -25,6 +29,7 @@ from .components import (  # noqa: F401
 from .envs import BatchedElectricMotorEnv, make  # noqa: F401
 from .physical_systems import (  # noqa: F401
     BatchedDcMotorSystem,
+    BatchedExternallyExcitedSynchronousMotorSystem,
     BatchedSCMLSystem,
     BatchedSquirrelCageInductionMotorSystem,
     BatchedSynchronousMotorSystem,

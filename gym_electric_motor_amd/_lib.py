@@ -8,8 +8,9 @@ from . import build as _build
 MAX_ODE, MAX_OUT, MODEL_ROWS, MODEL_COLS = 8, 16, 5, 11
 ABI_VERSION = 1
 
-SYS_DC_PERMEX, SYS_SYNC, SYS_SCIM, SYS_DC_SERIES, SYS_DC_SHUNT = 0, 1, 2, 3, 4
+SYS_DC_PERMEX, SYS_SYNC, SYS_SCIM, SYS_DC_SERIES, SYS_DC_SHUNT, SYS_DC_EXTEX, SYS_EESM = 0, 1, 2, 3, 4, 5, 6
 CONV_CONT_4QC, CONV_FINITE_B6, CONV_CONT_B6, CONV_FINITE_4QC = 0, 1, 2, 3
+CONV_CONT_2X4QC, CONV_FINITE_2X4QC, CONV_CONT_B6_4QC, CONV_FINITE_B6_4QC = 4, 5, 6, 7
 LOAD_CONST_SPEED, LOAD_POLY_STATIC = 0, 1
 SOLVER_EULER, SOLVER_RK4, SOLVER_DP5 = 0, 1, 2
 F32, F64 = 0, 1

@@ -14,7 +14,7 @@ import math
 
 import numpy as np
 
-from .spaces import Box, Discrete
+from .spaces import Box, Discrete, MultiDiscrete
 
 
 def update_parameter_dict(source, update):
@@ -103,6 +103,59 @@ class FiniteFourQuadrantConverter(_Converter):
 
     def __init__(self, tau=1e-5, interlocking_time=0.0):
         super().__init__(tau, interlocking_time)
+
+
+class _MultiConverter(_Converter):
+    """Cont/FiniteMultiConverter, converters.py:498-740: a list of sub-converters whose actions, currents and voltages
+    are concatenated.  As in the reference, sub-converters given as classes are instantiated with the holder's kwargs;
+    the holder's own `interlocking_time` is never used -- the sub-converters' values are."""
+
+    def __init__(self, subconverters, tau, **kwargs):
+        super().__init__(tau, kwargs.get("interlocking_time", 0.0))
+        self._sub_converters = []
+        for sc in subconverters:
+            assert not isinstance(sc, str)
+            if isinstance(sc, type):
+                sc = sc(**kwargs)
+            self._sub_converters.append(sc)
+        self.subsignal_current_space_dims = np.array([int(np.squeeze(sc.currents.shape) or 1) for sc in self._sub_converters])
+        self.subsignal_voltage_space_dims = np.array([int(np.squeeze(sc.voltages.shape) or 1) for sc in self._sub_converters])
+        self.currents = Box(np.concatenate([sc.currents.low for sc in self._sub_converters]),
+                            np.concatenate([sc.currents.high for sc in self._sub_converters]), dtype=np.float64)
+        self.voltages = Box(np.concatenate([sc.voltages.low for sc in self._sub_converters]),
+                            np.concatenate([sc.voltages.high for sc in self._sub_converters]), dtype=np.float64)
+        self.tau = tau
+
+    @property
+    def sub_converters(self):
+        return self._sub_converters
+
+    @property
+    def tau(self):
+        return self._tau
+
+    @tau.setter
+    def tau(self, value):  # converters.py:504-508 / 608-612
+        self._tau = float(value)
+        for sc in getattr(self, "_sub_converters", ()):
+            sc.tau = value
+
+
+class ContMultiConverter(_MultiConverter):
+    """Key 'Cont-Multi', converters.py:598-740."""
+
+    def __init__(self, subconverters, tau=1e-4, **kwargs):
+        super().__init__(subconverters, tau, **kwargs)
+        self.action_space = Box(np.concatenate([sc.action_space.low for sc in self._sub_converters]),
+                                np.concatenate([sc.action_space.high for sc in self._sub_converters]), dtype=np.float64)
+
+
+class FiniteMultiConverter(_MultiConverter):
+    """Key 'Finite-Multi', converters.py:498-595 (action space MultiDiscrete of the sub-converters' action counts)."""
+
+    def __init__(self, subconverters, tau=1e-5, **kwargs):
+        super().__init__(subconverters, tau, **kwargs)
+        self.action_space = MultiDiscrete([sc.action_space.n for sc in self._sub_converters])
 
 
 # ------------------------------------------------------------------------------------------------- solvers
@@ -273,6 +326,48 @@ class DcShuntMotor(_ElectricMotor):
         return low, {"omega": 1, "torque": 1, "i_a": 1, "i_e": 1, "u": 1}
 
 
+class DcExternallyExcitedMotor(_ElectricMotor):
+    """electric_motors/dc_externally_excited_motor.py:6-120 over dc_motor.py: armature and exciting circuit fed by two
+    separate converters (u_a, u_e)."""
+
+    CURRENTS = ["i_a", "i_e"]
+    VOLTAGES = ["u_a", "u_e"]
+    _default_motor_parameter = {"r_a": 16e-3, "r_e": 16e-2, "l_a": 19e-6, "l_e_prime": 1.7e-3, "l_e": 5.4e-3, "j_rotor": 0.0025}
+    _default_nominal_values = dict(omega=300, torque=16.0, i=97, i_a=97, i_e=97, u=60, u_a=60, u_e=60)
+    _default_limits = dict(omega=400, torque=38.0, i=210, i_a=210, i_e=210, u=60, u_a=60, u_e=60)
+    _default_initializer = {"states": {"i_a": 0.0, "i_e": 0.0}, "interval": None, "random_init": None, "random_params": (None, None)}
+
+    def __init__(self, motor_parameter=None, nominal_values=None, limit_values=None, motor_initializer=None):
+        super().__init__(motor_parameter, nominal_values, limit_values, motor_initializer)
+        mp = self._motor_parameter
+        # DcMotor._update_model, dc_motor.py:96-104: features [i_a, i_e, omega * i_e, u_a, u_e]
+        self._model_constants = np.array([[-mp["r_a"], 0, -mp["l_e_prime"], 1, 0], [0, -mp["r_e"], 0, 0, 1]], dtype=float)
+        self._model_constants[0] = self._model_constants[0] / mp["l_a"]
+        self._model_constants[1] = self._model_constants[1] / mp["l_e"]
+        # _update_limits, dc_externally_excited_motor.py:107-120 + dc_motor.py:153-160
+        r_a = 1 if mp["r_a"] == 0 else mp["r_a"]
+        agenda = {"u_a": self._default_limits["u"], "u_e": self._default_limits["u"],
+                  "i_a": self._limits.get("i", None) or self._limits["u"] / r_a,
+                  "i_e": self._limits.get("i", None) or self._limits["u"] / mp["r_e"]}
+        agenda["torque"] = mp["l_e_prime"] * self._limits["i_a"] * self._limits["i_e"]
+        self._update_limits(agenda)
+
+    def torque_coefficients(self):
+        return [self._motor_parameter["l_e_prime"], 0.0]
+
+    def initial_motor_state(self):
+        vals = [float(v) for v in self._initial_states.values()]
+        return vals if len(vals) == 2 else [0.0, 0.0]
+
+    def get_state_space(self, input_currents, input_voltages):
+        """dc_motor.py:129-151."""
+        ca, ce = input_currents.low[0] == -1, input_currents.low[1] == -1
+        va, ve = input_voltages.low[0] == -1, input_voltages.low[1] == -1
+        low = {"omega": -1 if va or ve else 0, "torque": -1 if ca or ce else 0, "i_a": -1 if ca else 0, "i_e": -1 if ce else 0,
+               "u_a": -1 if va else 0, "u_e": -1 if ve else 0}
+        return low, {"omega": 1, "torque": 1, "i_a": 1, "i_e": 1, "u_a": 1, "u_e": 1}
+
+
 class _ThreePhaseMotor(_ElectricMotor):
     IO_VOLTAGES = []
     IO_CURRENTS = []
@@ -345,6 +440,76 @@ class PermanentMagnetSynchronousMotor(_ThreePhaseMotor):
         # synchronous_motor.py:125-131: np.asarray(list(self._initial_states.values())) -> dict ORDER, not names
         vals = [float(v) for v in self._initial_states.values()]
         return vals if len(vals) == 3 else [0.0, 0.0, 0.0]
+
+
+class ExternallyExcitedSynchronousMotor(_ThreePhaseMotor):
+    """electric_motors/externally_excited_synchronous_motor.py:7-180 (defaults lines 27-50, DOI 10.1109/ICELMACH.2014.6960287)."""
+
+    CURRENTS = ["i_sd", "i_sq", "i_e"]
+    VOLTAGES = ["u_sd", "u_sq", "u_e"]
+    IO_VOLTAGES = ["u_a", "u_b", "u_c", "u_sd", "u_sq", "u_e"]
+    IO_CURRENTS = ["i_a", "i_b", "i_c", "i_sd", "i_sq", "i_e"]
+    _default_motor_parameter = {"p": 3, "l_d": 1.66e-3, "l_q": 0.35e-3, "l_m": 1.589e-3, "l_e": 1.74e-3, "j_rotor": 0.3883,
+                                "r_s": 15.55e-3, "r_e": 7.2e-3, "k": 65.21}
+    _default_limits = dict(omega=12e3 * np.pi / 30, torque=0.0, i=150, i_e=150, epsilon=math.pi, u=320)
+    _default_nominal_values = dict(omega=4.3e3 * np.pi / 30, torque=0.0, i=120, i_e=150, epsilon=math.pi, u=320)
+    # dict order i_sq, i_sd, i_e, epsilon as in the reference (line 45): reset() fills the ODE slots
+    # [i_sd, i_sq, i_e, epsilon] with the VALUES in dict order (synchronous_motor.py:125-131)
+    _default_initializer = {"states": {"i_sq": 0.0, "i_sd": 0.0, "i_e": 0.0, "epsilon": 0.0}, "interval": None,
+                            "random_init": None, "random_params": (None, None)}
+
+    def __init__(self, motor_parameter=None, nominal_values=None, limit_values=None, motor_initializer=None):
+        super().__init__(motor_parameter, nominal_values, limit_values, motor_initializer)
+        mp = self._motor_parameter
+        # _update_model, lines 69-93: rotor quantities referred to the stator side (upper-case index)
+        mp["r_E"] = mp["k"] ** 2 * 3 / 2 * mp["r_e"]
+        mp["l_M"] = mp["k"] * 3 / 2 * mp["l_m"]
+        mp["l_E"] = mp["k"] ** 2 * 3 / 2 * mp["l_e"]
+        mp["i_k_rs"] = 2 / 3 / mp["k"]
+        mp["sigma"] = 1 - mp["l_M"] ** 2 / (mp["l_d"] * mp["l_E"])
+        sg, ik = mp["sigma"], mp["i_k_rs"]
+        # features [omega, i_d, i_q, i_e, u_d, u_q, u_e, omega*i_d, omega*i_q, omega*i_e]
+        m = np.array([
+            [0, -mp["r_s"] / sg, 0, mp["l_M"] * mp["r_E"] / (sg * mp["l_E"]) * ik, 1 / sg, 0, -mp["l_M"] * mp["k"] / (sg * mp["l_E"]), 0,
+             mp["l_q"] * mp["p"] / sg, 0],
+            [0, 0, -mp["r_s"], 0, 0, 1, 0, -mp["l_d"] * mp["p"], 0, -mp["p"] * mp["l_M"] * ik],
+            [0, mp["l_M"] * mp["r_s"] / (sg * mp["l_d"]), 0, -mp["r_E"] / sg * ik, -mp["l_M"] / (sg * mp["l_d"]), 0, mp["k"] / sg, 0,
+             -mp["p"] * mp["l_M"] * mp["l_q"] / (sg * mp["l_d"]), 0],
+            [mp["p"], 0, 0, 0, 0, 0, 0, 0, 0, 0],
+        ], dtype=float)
+        m[0] = m[0] / mp["l_d"]
+        m[1] = m[1] / mp["l_q"]
+        m[2] = m[2] / mp["l_E"] / ik
+        self._model_constants = m
+        self._three_phase_limits()
+
+    def torque(self, currents):
+        """lines 133-136; currents = [i_sd, i_sq, i_e, ...]."""
+        mp = self._motor_parameter
+        return 1.5 * mp["p"] * (mp["l_M"] * currents[2] * mp["i_k_rs"] + (mp["l_d"] - mp["l_q"]) * currents[0]) * currents[1]
+
+    def _torque_limit(self):
+        """lines 115-131."""
+        mp = self._motor_parameter
+        if mp["l_d"] == mp["l_q"]:
+            return self.torque([0, self._limits["i_sq"], self._limits["i_e"], 0])
+        i_n = self._nominal_values["i"]
+        _p = mp["l_M"] * i_n / (2 * (mp["l_d"] - mp["l_q"]))
+        _q = -(i_n**2) / 2
+        if mp["l_d"] < mp["l_q"]:
+            i_d_opt = -_p / 2 - np.sqrt((_p / 2) ** 2 - _q)
+        else:
+            i_d_opt = -_p / 2 + np.sqrt((_p / 2) ** 2 - _q)
+        i_q_opt = np.sqrt(i_n**2 - i_d_opt**2)
+        return self.torque([i_d_opt, i_q_opt, self._limits["i_e"], 0])
+
+    def torque_coefficients(self):
+        mp = self._motor_parameter
+        return [1.5 * mp["p"] * mp["l_M"] * mp["i_k_rs"], 1.5 * mp["p"] * (mp["l_d"] - mp["l_q"])]
+
+    def initial_motor_state(self):
+        vals = [float(v) for v in self._initial_states.values()]
+        return vals if len(vals) == 4 else [0.0] * 4
 
 
 class SynchronousReluctanceMotor(_ThreePhaseMotor):

@@ -64,6 +64,8 @@ int fail(int code, const char *fmt, ...) {
 static const int DC_IDX[][2] = {{0, 0}, {0, 1}, {0, 2}};
 static const int SERIES_IDX[][2] = {{0, 0}, {0, 1}, {0, 2}};
 static const int SHUNT_IDX[][2] = {{0, 0}, {0, 2}, {0, 3}, {1, 1}, {1, 4}};
+static const int EESM_IDX[][2] = {{0, 1}, {0, 3}, {0, 4}, {0, 6}, {0, 8}, {1, 2}, {1, 5}, {1, 7}, {1, 9},
+                                  {2, 1}, {2, 3}, {2, 4}, {2, 6}, {2, 8}};
 static const int SYNC_IDX[][2] = {{0, 1}, {0, 3}, {0, 6}, {1, 0}, {1, 2}, {1, 4}, {1, 5}};
 static const int SCIM_IDX[][2] = {{0, 1}, {0, 3}, {0, 6}, {0, 7}, {1, 2}, {1, 4}, {1, 5}, {1, 8},
                                   {2, 1}, {2, 3}, {2, 6}, {3, 2}, {3, 4}, {3, 5}};
@@ -74,7 +76,8 @@ static int pack_model(const gemx_config &c, double *m, double *pole) {
     switch (c.system_kind) {
         case GEMX_SYS_DC_PERMEX: idx = DC_IDX; n = 3; pole_row = -1; rows = 1; cols = 3; break;
         case GEMX_SYS_DC_SERIES: idx = SERIES_IDX; n = 3; pole_row = -1; rows = 1; cols = 3; break;
-        case GEMX_SYS_DC_SHUNT: idx = SHUNT_IDX; n = 5; pole_row = -1; rows = 2; cols = 5; break;
+        case GEMX_SYS_DC_SHUNT: case GEMX_SYS_DC_EXTEX: idx = SHUNT_IDX; n = 5; pole_row = -1; rows = 2; cols = 5; break;
+        case GEMX_SYS_EESM: idx = EESM_IDX; n = 14; pole_row = 3; rows = 4; cols = 10; break;
         case GEMX_SYS_SYNC: idx = SYNC_IDX; n = 7; pole_row = 2; rows = 3; cols = 7; break;
         case GEMX_SYS_SCIM: idx = SCIM_IDX; n = 14; pole_row = 4; rows = 5; cols = 9; break;  // u_r columns: zero rotor voltage
         default: return fail(GEMX_ERR_ARG, "unknown system_kind %d", c.system_kind);
@@ -125,8 +128,10 @@ template <class R> static void fill_params(const gemx_handle &h, const double *m
     P.auto_reset = c.auto_reset;
     P.obs_layout = c.obs_layout;
     // the env's default constraint gets the 3-instruction fast path (Stepper::default_done)
-    const bool is_dc = c.system_kind == GEMX_SYS_DC_PERMEX || c.system_kind == GEMX_SYS_DC_SERIES || c.system_kind == GEMX_SYS_DC_SHUNT;
-    const uint32_t def_limit = !is_dc ? 0u : (c.system_kind == GEMX_SYS_DC_SHUNT ? ((1u << 2) | (1u << 3)) : (1u << 2));
+    const bool is_dc = !h.has_angle;
+    const bool two_currents = c.system_kind == GEMX_SYS_DC_SHUNT || c.system_kind == GEMX_SYS_DC_EXTEX;
+    uint32_t def_limit = !is_dc ? 0u : (two_currents ? ((1u << 2) | (1u << 3)) : (1u << 2));
+    if (c.system_kind == GEMX_SYS_EESM) def_limit = 1u << 7;  // LimitConstraint(('i_e',)), cont_cc_eesm_env.py:108
     const uint32_t def_sq = is_dc ? 0u : ((1u << 5) | (1u << 6));
     if (c.limit_mask == 0 && c.squared_mask == 0) P.constr_kind = 0;
     else if (c.limit_mask == def_limit && c.squared_mask == def_sq) P.constr_kind = 1;
@@ -153,10 +158,26 @@ static void host_reset_obs(gemx_handle &h, const double *m) {
         const int nc = h.nd - 1;
         double torque = c.torque_coef[0] * y[1];
         if (c.system_kind == GEMX_SYS_DC_SERIES) torque = c.torque_coef[0] * y[1] * y[1];
-        if (c.system_kind == GEMX_SYS_DC_SHUNT) torque = c.torque_coef[0] * y[1] * y[2];
+        if (c.system_kind == GEMX_SYS_DC_SHUNT || c.system_kind == GEMX_SYS_DC_EXTEX) torque = c.torque_coef[0] * y[1] * y[2];
+        const int nu = c.system_kind == GEMX_SYS_DC_EXTEX ? 2 : 1;  // converter.reset() -> 0 V per 4QC
         o[0] = y[0]; o[1] = torque;
         for (int i = 0; i < nc; ++i) o[2 + i] = y[1 + i];
-        o[2 + nc] = 0.0 * us; o[3 + nc] = us;
+        for (int j = 0; j < nu; ++j) o[2 + nc + j] = 0.0 * us;
+        o[2 + nc + nu] = us;
+    } else if (c.system_kind == GEMX_SYS_EESM) {  // physical_systems.py:654-691
+        double uabc[3] = {-0.5 * us, -0.5 * us, -0.5 * us}, uab[2], iabc[3];
+        T23(uabc, uab);
+        double eps = y[4];
+        if (eps > kPi) eps -= kTwoPi;
+        const double cs = cos(eps), sn = sin(eps);
+        T32(cs * y[1] - sn * y[2], sn * y[1] + cs * y[2], iabc);
+        o[0] = y[0]; o[1] = (c.torque_coef[0] * y[3] + c.torque_coef[1] * y[1]) * y[2];
+        o[2] = iabc[0]; o[3] = iabc[1]; o[4] = iabc[2]; o[5] = y[1]; o[6] = y[2]; o[7] = y[3];
+        // the reference lays the reset voltages out as (u_a, u_b, u_c, u_e, u_sd, u_sq) (lines 679-690): u_e = 0 lands in
+        // the u_sd slot and (u_sd, u_sq) ~ 1e-17 in the u_sq / u_e slots; reproduced as is
+        o[8] = uabc[0]; o[9] = uabc[1]; o[10] = uabc[2]; o[11] = 0.0 * us;
+        o[12] = cs * uab[0] + sn * uab[1]; o[13] = -sn * uab[0] + cs * uab[1];
+        o[14] = eps; o[15] = us;
     } else {
         double uabc[3] = {-0.5 * us, -0.5 * us, -0.5 * us}, uab[2], iabc[3], idq[2], udq[2], eps, torque, cs, sn;
         T23(uabc, uab);
@@ -204,6 +225,10 @@ GEMX_DECL_UNIT(3, 0, 0) GEMX_DECL_UNIT(3, 0, 1)
 GEMX_DECL_UNIT(3, 3, 0) GEMX_DECL_UNIT(3, 3, 1)
 GEMX_DECL_UNIT(4, 0, 0) GEMX_DECL_UNIT(4, 0, 1)
 GEMX_DECL_UNIT(4, 3, 0) GEMX_DECL_UNIT(4, 3, 1)
+GEMX_DECL_UNIT(5, 4, 0) GEMX_DECL_UNIT(5, 4, 1)
+GEMX_DECL_UNIT(5, 5, 0) GEMX_DECL_UNIT(5, 5, 1)
+GEMX_DECL_UNIT(6, 6, 0) GEMX_DECL_UNIT(6, 6, 1)
+GEMX_DECL_UNIT(6, 7, 0) GEMX_DECL_UNIT(6, 7, 1)
 #undef GEMX_DECL_UNIT
 }  // namespace gemx
 
@@ -215,6 +240,7 @@ static int launch_advance(gemx_handle *h, const void *actions, int K, void *obs,
                  : gemx::launch_unit_##S##_##C##_0(h, actions, K, obs, done, obs_every, st);
     GEMX_UNIT(0, 0) GEMX_UNIT(1, 1) GEMX_UNIT(1, 2) GEMX_UNIT(2, 1) GEMX_UNIT(2, 2)
     GEMX_UNIT(0, 3) GEMX_UNIT(3, 0) GEMX_UNIT(3, 3) GEMX_UNIT(4, 0) GEMX_UNIT(4, 3)
+    GEMX_UNIT(5, 4) GEMX_UNIT(5, 5) GEMX_UNIT(6, 6) GEMX_UNIT(6, 7)
 #undef GEMX_UNIT
     return fail(GEMX_ERR_ARG, "unsupported system/converter combination %d/%d", s, c);
 }
@@ -253,18 +279,29 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
     const int s = cfg->system_kind, c = cfg->converter_kind;
     const bool dc_sys = s == GEMX_SYS_DC_PERMEX || s == GEMX_SYS_DC_SERIES || s == GEMX_SYS_DC_SHUNT;
     const bool combo = (dc_sys && (c == GEMX_CONV_CONT_4QC || c == GEMX_CONV_FINITE_4QC)) ||
-                       ((s == GEMX_SYS_SYNC || s == GEMX_SYS_SCIM) && (c == GEMX_CONV_FINITE_B6 || c == GEMX_CONV_CONT_B6));
+                       ((s == GEMX_SYS_SYNC || s == GEMX_SYS_SCIM) && (c == GEMX_CONV_FINITE_B6 || c == GEMX_CONV_CONT_B6)) ||
+                       (s == GEMX_SYS_DC_EXTEX && (c == GEMX_CONV_CONT_2X4QC || c == GEMX_CONV_FINITE_2X4QC)) ||
+                       (s == GEMX_SYS_EESM && (c == GEMX_CONV_CONT_B6_4QC || c == GEMX_CONV_FINITE_B6_4QC));
     if (!combo) return fail(GEMX_ERR_ARG, "unsupported system/converter combination %d/%d", s, c);
+    if (s == GEMX_SYS_EESM && cfg->interlocking_time > 0)
+        return fail(GEMX_ERR_ARG, "interlocking_time > 0 is not supported for the EESM system (the reference's dead-time branch, "
+                                  "physical_systems.py:628-638, cannot execute either)");
 
     gemx_handle *h = new (std::nothrow) gemx_handle();
     if (!h) return fail(GEMX_ERR_ALLOC, "out of host memory");
     h->cfg = *cfg;
     h->n = n_envs;
     h->device = device;
-    h->nd = (s == GEMX_SYS_DC_PERMEX || s == GEMX_SYS_DC_SERIES) ? 2 : ((s == GEMX_SYS_SYNC || s == GEMX_SYS_DC_SHUNT) ? 3 : 5);
-    h->nout = s == GEMX_SYS_DC_SHUNT ? 6 : (dc_sys ? 5 : 14);
-    h->has_angle = !dc_sys;
-    h->nact = c == GEMX_CONV_CONT_B6 ? 3 : 1;
+    switch (s) {  // ODE rows without the angle / observation length (SysTraits in gemx_common.hpp)
+        case GEMX_SYS_DC_PERMEX: case GEMX_SYS_DC_SERIES: h->nd = 2; h->nout = 5; break;
+        case GEMX_SYS_DC_SHUNT: h->nd = 3; h->nout = 6; break;
+        case GEMX_SYS_DC_EXTEX: h->nd = 3; h->nout = 7; break;
+        case GEMX_SYS_SYNC: h->nd = 3; h->nout = 14; break;
+        case GEMX_SYS_EESM: h->nd = 4; h->nout = 16; break;
+        default: h->nd = 5; h->nout = 14; break;
+    }
+    h->has_angle = !(dc_sys || s == GEMX_SYS_DC_EXTEX);
+    h->nact = c == GEMX_CONV_CONT_B6 ? 3 : (c == GEMX_CONV_CONT_2X4QC ? 2 : (c == GEMX_CONV_CONT_B6_4QC ? 4 : 1));
     for (int i = 0; i < h->nout; ++i)
         if (!(cfg->limits[i] > 0)) { delete h; return fail(GEMX_ERR_ARG, "limits[%d] must be positive", i); }
     if ((cfg->limit_mask | cfg->squared_mask) >> h->nout) { delete h; return fail(GEMX_ERR_ARG, "constraint mask has bits beyond S_out=%d", h->nout); }
@@ -360,7 +397,9 @@ int gemx_n_out(const gemx_handle *h) { return h ? h->nout : GEMX_ERR_ARG; }
 int gemx_n_action(const gemx_handle *h) { return h ? h->nact : GEMX_ERR_ARG; }
 int gemx_action_itemsize(const gemx_handle *h) {
     if (!h) return GEMX_ERR_ARG;
-    return (h->cfg.converter_kind == GEMX_CONV_FINITE_B6 || h->cfg.converter_kind == GEMX_CONV_FINITE_4QC) ? 1 : elem_size(h);
+    const int c = h->cfg.converter_kind;
+    const bool discrete = c == GEMX_CONV_FINITE_B6 || c == GEMX_CONV_FINITE_4QC || c == GEMX_CONV_FINITE_2X4QC || c == GEMX_CONV_FINITE_B6_4QC;
+    return discrete ? 1 : elem_size(h);
 }
 int gemx_reset_observation(const gemx_handle *h, double *obs_host) {
     if (!h || !obs_host) return fail(GEMX_ERR_ARG, "null argument");

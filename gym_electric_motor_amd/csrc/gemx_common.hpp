@@ -25,12 +25,26 @@ template <> struct SysTraits<GEMX_SYS_SYNC>      { static constexpr int ND = 3, 
 template <> struct SysTraits<GEMX_SYS_SCIM>      { static constexpr int ND = 5, NOUT = 14, HAS_ANGLE = 1; };  // omega, i_sa, i_sb, psi_ra, psi_rb (+eps)
 template <> struct SysTraits<GEMX_SYS_DC_SERIES> { static constexpr int ND = 2, NOUT = 5, HAS_ANGLE = 0; };   // omega, i
 template <> struct SysTraits<GEMX_SYS_DC_SHUNT>  { static constexpr int ND = 3, NOUT = 6, HAS_ANGLE = 0; };   // omega, i_a, i_e
+template <> struct SysTraits<GEMX_SYS_DC_EXTEX>  { static constexpr int ND = 3, NOUT = 7, HAS_ANGLE = 0; };   // omega, i_a, i_e
+template <> struct SysTraits<GEMX_SYS_EESM>      { static constexpr int ND = 4, NOUT = 16, HAS_ANGLE = 1; };  // omega, i_sd, i_sq, i_e (+eps)
+
+constexpr int MAX_ACT = 4;  // continuous action entries per env (Cont-B6C + Cont-4QC of the EESM envs)
+constexpr int MAX_U = 3;    // motor input voltages per segment (u_d, u_q, u_e)
 
 template <int CONV> struct ConvTraits;
 template <> struct ConvTraits<GEMX_CONV_CONT_4QC>   { static constexpr int NACT = 1, DISCRETE = 0, NACTIONS = 0; };
 template <> struct ConvTraits<GEMX_CONV_FINITE_B6>  { static constexpr int NACT = 1, DISCRETE = 1, NACTIONS = 8; };
 template <> struct ConvTraits<GEMX_CONV_CONT_B6>    { static constexpr int NACT = 3, DISCRETE = 0, NACTIONS = 0; };
 template <> struct ConvTraits<GEMX_CONV_FINITE_4QC> { static constexpr int NACT = 1, DISCRETE = 1, NACTIONS = 4; };
+// two-sub-converter MultiConverters; discrete: one byte = flat index of MultiDiscrete([n0, n1])
+template <> struct ConvTraits<GEMX_CONV_CONT_2X4QC>    { static constexpr int NACT = 2, DISCRETE = 0, NACTIONS = 0; };
+template <> struct ConvTraits<GEMX_CONV_FINITE_2X4QC>  { static constexpr int NACT = 1, DISCRETE = 1, NACTIONS = 16; };
+template <> struct ConvTraits<GEMX_CONV_CONT_B6_4QC>   { static constexpr int NACT = 4, DISCRETE = 0, NACTIONS = 0; };
+template <> struct ConvTraits<GEMX_CONV_FINITE_B6_4QC> { static constexpr int NACT = 1, DISCRETE = 1, NACTIONS = 32; };
+// converters that keep per-leg switching state between steps (dead time)
+template <int CONV> constexpr bool conv_has_legs() {
+    return CONV == GEMX_CONV_FINITE_B6 || CONV == GEMX_CONV_FINITE_4QC || CONV == GEMX_CONV_FINITE_2X4QC;
+}
 
 // ------------------------------------------------------------------------------------------------
 // uniform parameters (kernel argument, by value -> SGPRs)
@@ -135,7 +149,7 @@ template <class R> struct KArgs {
     DevParams<R> P;
     R *state;                       // [ND][N]
     typename Angle<R>::T *angle;    // [N] (systems with an angle)
-    uint8_t *sw;                    // [N] packed leg states (Finite-B6C with interlocking)
+    uint8_t *sw;                    // [N] packed leg states, 2 bits per half-bridge (finite converters with interlocking)
     const unsigned char *actions;   // [K][N][A] R  |  [K][N] uint8
     R *obs;                         // [K][N][NOUT] | [K][NOUT][N]  (or a single step's worth if !obs_every)
     uint8_t *done;                  // [K][N] | [N]

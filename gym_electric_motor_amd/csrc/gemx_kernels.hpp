@@ -49,31 +49,54 @@ template <int SYS, class R> struct Elec;
 template <class R> struct Elec<GEMX_SYS_DC_PERMEX, R> {
     static constexpr int NM = 1;
     struct Pre { R b; };
-    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[2]) { return Pre{P.m[0] * w + P.m[2] * u[0]}; }
+    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[MAX_U]) { return Pre{P.m[0] * w + P.m[2] * u[0]}; }
     static __device__ __forceinline__ void f(const DevParams<R> &P, const Pre &p, const R (&x)[1], R (&dx)[1]) { dx[0] = p.b + P.m[1] * x[0]; }
     static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[1]) { return P.tc0 * x[0]; }  // line 67-69
 };
 template <class R> struct Elec<GEMX_SYS_DC_SERIES, R> {  // dc_series_motor.py:68-83: di = (-(r_a+r_e) i - l_e' omega i + u) / (l_a+l_e)
     static constexpr int NM = 1;
     struct Pre { R a, b; };
-    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[2]) { return Pre{P.m[0] + P.m[1] * w, P.m[2] * u[0]}; }
+    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[MAX_U]) { return Pre{P.m[0] + P.m[1] * w, P.m[2] * u[0]}; }
     static __device__ __forceinline__ void f(const DevParams<R> &, const Pre &p, const R (&x)[1], R (&dx)[1]) { dx[0] = p.b + p.a * x[0]; }
     static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[1]) { return P.tc0 * x[0] * x[0]; }  // line 74-76
 };
 template <class R> struct Elec<GEMX_SYS_DC_SHUNT, R> {  // dc_motor.py:96-127 with u_a = u_e = u (dc_shunt_motor.py:72-74)
     static constexpr int NM = 2;
     struct Pre { R ba, be, w1; };
-    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[2]) { return Pre{P.m[2] * u[0], P.m[4] * u[0], P.m[1] * w}; }
+    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[MAX_U]) { return Pre{P.m[2] * u[0], P.m[4] * u[0], P.m[1] * w}; }
     static __device__ __forceinline__ void f(const DevParams<R> &P, const Pre &p, const R (&x)[2], R (&dx)[2]) {
         dx[0] = p.ba + P.m[0] * x[0] + p.w1 * x[1];
         dx[1] = p.be + P.m[3] * x[1];
     }
     static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[2]) { return P.tc0 * x[0] * x[1]; }  // dc_motor.py:106-108
 };
+template <class R> struct Elec<GEMX_SYS_DC_EXTEX, R> {  // dc_motor.py:96-127 with separately fed armature / excitation circuits
+    static constexpr int NM = 2;
+    struct Pre { R ba, be, w1; };
+    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[MAX_U]) { return Pre{P.m[2] * u[0], P.m[4] * u[1], P.m[1] * w}; }
+    static __device__ __forceinline__ void f(const DevParams<R> &P, const Pre &p, const R (&x)[2], R (&dx)[2]) {
+        dx[0] = p.ba + P.m[0] * x[0] + p.w1 * x[1];
+        dx[1] = p.be + P.m[3] * x[1];
+    }
+    static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[2]) { return P.tc0 * x[0] * x[1]; }  // dc_motor.py:106-108
+};
+template <class R> struct Elec<GEMX_SYS_EESM, R> {  // externally_excited_synchronous_motor.py:69-113, 133-136; x = i_sd, i_sq, i_e
+    static constexpr int NM = 3;
+    struct Pre { R bd, bq, be, w4, w7, w8, w13; };
+    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[MAX_U]) {
+        return Pre{P.m[2] * u[0] + P.m[3] * u[2], P.m[6] * u[1], P.m[11] * u[0] + P.m[12] * u[2], P.m[4] * w, P.m[7] * w, P.m[8] * w, P.m[13] * w};
+    }
+    static __device__ __forceinline__ void f(const DevParams<R> &P, const Pre &p, const R (&x)[3], R (&dx)[3]) {
+        dx[0] = p.bd + P.m[0] * x[0] + P.m[1] * x[2] + p.w4 * x[1];
+        dx[1] = p.bq + P.m[5] * x[1] + p.w7 * x[0] + p.w8 * x[2];
+        dx[2] = p.be + P.m[9] * x[0] + P.m[10] * x[2] + p.w13 * x[1];
+    }
+    static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[3]) { return (P.tc0 * x[2] + P.tc1 * x[0]) * x[1]; }
+};
 template <class R> struct Elec<GEMX_SYS_SYNC, R> {  // permanent_magnet_synchronous_motor.py:107-119, 134-139
     static constexpr int NM = 2;
     struct Pre { R bd, bq, wdq, wqd; };
-    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[2]) {
+    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[MAX_U]) {
         return Pre{P.m[1] * u[0], P.m[3] * w + P.m[5] * u[1], P.m[2] * w, P.m[6] * w};
     }
     static __device__ __forceinline__ void f(const DevParams<R> &P, const Pre &p, const R (&x)[2], R (&dx)[2]) {
@@ -85,7 +108,7 @@ template <class R> struct Elec<GEMX_SYS_SYNC, R> {  // permanent_magnet_synchron
 template <class R> struct Elec<GEMX_SYS_SCIM, R> {  // induction_motor.py:236-248, 287-312
     static constexpr int NM = 4;
     struct Pre { R ba, bb, w2, w6, w10, w13; };
-    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[2]) {
+    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[MAX_U]) {
         return Pre{P.m[3] * u[0], P.m[7] * u[1], P.m[2] * w, P.m[6] * w, P.m[10] * w, P.m[13] * w};
     }
     static __device__ __forceinline__ void f(const DevParams<R> &P, const Pre &p, const R (&x)[4], R (&dx)[4]) {
@@ -170,7 +193,7 @@ __device__ __forceinline__ R rk_step(R (&z)[NZ], R h, F &&rhs) {
 // y = [omega, motor states].  Returns the angle increment  pole * int(omega dt)  of the scheme.
 // ------------------------------------------------------------------------------------------------
 template <int SYS, int LOAD, int SOLVER, class R, bool NS1 = false>
-__device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<SYS>::ND], const R (&u)[2], R h) {
+__device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<SYS>::ND], const R (&u)[MAX_U], R h) {
     using E = Elec<SYS, R>;
     constexpr int NM = E::NM;
     const int ns = NS1 ? 1 : P.nsteps;     // NS1: the caller guarantees solver_nsteps == 1 (branch-free code)
@@ -251,7 +274,7 @@ template <int NLEG = 3> __device__ __forceinline__ uint32_t b6_interlock(uint32_
 
 // B6 bridges: phase voltages u_a, u_b, u_c [V].  `legs` only matters for Finite-B6C with IL.
 template <int CONV, bool IL, class R>
-__device__ __forceinline__ void b6_voltages(const DevParams<R> &P, const R (&act)[3], uint32_t dact, uint32_t legs, R ia, R ib, R ic,
+__device__ __forceinline__ void b6_voltages(const DevParams<R> &P, const R (&act)[MAX_ACT], uint32_t dact, uint32_t legs, R ia, R ib, R ic,
                                             R &ua, R &ub, R &uc) {
     if (CONV == GEMX_CONV_CONT_B6) {  // converters.py:888-903
         ua = (cont_leg<IL, R>(P, clip01(R(0.5) * (act[0] + R(1))), ia) - R(0.5)) * P.u_sup;
@@ -280,44 +303,63 @@ __device__ __forceinline__ void b6_voltages(const DevParams<R> &P, const R (&act
 // ------------------------------------------------------------------------------------------------
 template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper;
 
-// ---- DcMotorSystem (physical_systems.py:171-203, 290-318) for the DC motors with ONE converter voltage:
-// permanently excited, series, shunt; Cont-4QC (converters.py:438-495) or Finite-4QC (313-368) -----------------------
+// ---- DcMotorSystem (physical_systems.py:171-203, 290-318): permanently excited, series, shunt motors behind ONE
+// Cont-4QC (converters.py:438-495) / Finite-4QC (313-368); externally excited motor behind a MultiConverter of TWO
+// (converters.py:498-740: armature, excitation) ----------------------------------------------------------------------
 template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcStepper {
     using AngT = typename Angle<R>::T;
     static constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NC = ND - 1;
-    static constexpr int NH = 1;  // ho: u [V]
-    // i_in = motor.i_in(currents): the current (dc_permanently_excited_motor.py:77-79, dc_series_motor.py:85-87) or
-    // i_a + i_e for the shunt motor (dc_shunt_motor.py:68-70)
-    static __device__ __forceinline__ R i_in(const R (&y)[ND]) { return SYS == GEMX_SYS_DC_SHUNT ? y[1] + y[ND - 1] : y[1]; }
+    static constexpr int NU = SYS == GEMX_SYS_DC_EXTEX ? 2 : 1;  // converter output voltages
+    static constexpr int NH = NU;                                // ho: u [V]
+    static constexpr bool CONT = CONV == GEMX_CONV_CONT_4QC || CONV == GEMX_CONV_CONT_2X4QC;
+    static_assert((CONV == GEMX_CONV_CONT_2X4QC || CONV == GEMX_CONV_FINITE_2X4QC) == (NU == 2), "system / converter width mismatch");
+    // i_in = motor.i_in(currents): the current (dc_permanently_excited_motor.py:77-79, dc_series_motor.py:85-87),
+    // i_a + i_e for the shunt motor (dc_shunt_motor.py:68-70), [i_a, i_e] for the externally excited motor
+    // (dc_motor.py:110-112; MultiConverter.convert slices it per sub-converter, converters.py:550-558)
+    static __device__ __forceinline__ R i_in(const R (&y)[ND], int j) {
+        if (SYS == GEMX_SYS_DC_EXTEX) return y[1 + j];
+        return SYS == GEMX_SYS_DC_SHUNT ? y[1] + y[ND - 1] : y[1];
+    }
     template <bool NS1 = false>
-    static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[ND], AngT &, uint32_t &sw, const R (&act)[3], uint32_t dact,
+    static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[ND], AngT &, uint32_t &sw, const R (&act)[MAX_ACT], uint32_t dact,
                                                    R (&ho)[NH]) {
-        R u[2] = {R(0), R(0)};
-        if (CONV == GEMX_CONV_CONT_4QC) {
-            const R d0 = clip01(R(0.5) * (act[0] + R(1)));
-            const R d1 = clip01(R(-0.5) * (act[0] - R(1)));
-            const R i = i_in(y);
-            u[0] = (cont_leg<IL, R>(P, d0, i) - cont_leg<IL, R>(P, d1, i)) * P.u_sup;  // both sub-converters see the same i (line 483)
+        R u[MAX_U] = {R(0), R(0), R(0)};
+        if (CONT) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                const R d0 = clip01(R(0.5) * (act[j] + R(1)));
+                const R d1 = clip01(R(-0.5) * (act[j] - R(1)));
+                const R i = i_in(y, j);
+                u[j] = (cont_leg<IL, R>(P, d0, i) - cont_leg<IL, R>(P, d1, i)) * P.u_sup;  // both sub-converters see the same i (line 483)
+            }
             integrate<SYS, LOAD, SOLVER, R, NS1>(P, y, u, P.tau);
         } else {  // Finite-4QC: action -> (leg0, leg1) sub-actions [1,1,2,2] / [1,2,1,2] (converters.py:360-361)
-            uint32_t legs = ((dact & 2u) ? 2u : 1u) | (((dact & 1u) ? 2u : 1u) << 2);
+            uint32_t legs = 0;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                const uint32_t aj = (dact >> (2 * j)) & 3u;
+                legs |= (((aj & 2u) ? 2u : 1u) | (((aj & 1u) ? 2u : 1u) << 2)) << (4 * j);
+            }
             bool two = false;
             if (IL) {
-                if (P.t_il > R(0)) legs = b6_interlock<2>(sw, legs, two);
+                if (P.t_il > R(0)) legs = b6_interlock<2 * NU>(sw, legs, two);
                 sw = legs;
             }
             auto segment = [&](R h) {
-                R v0, v1;
-                if (!IL) {
-                    v0 = (legs & 3u) == 1u ? R(1) : R(0);
-                    v1 = ((legs >> 2) & 3u) == 1u ? R(1) : R(0);
-                } else {  // converters.py:350-352: leg 1 sees -i_out; dead leg -> freewheeling diode (277-285)
-                    const R i = i_in(y);
-                    const uint32_t s0 = legs & 3u, s1 = (legs >> 2) & 3u;
-                    v0 = ((s0 == 1u) | ((s0 == 0u) & (i < R(0)))) ? R(1) : R(0);
-                    v1 = ((s1 == 1u) | ((s1 == 0u) & (-i < R(0)))) ? R(1) : R(0);
+#pragma unroll
+                for (int j = 0; j < NU; ++j) {
+                    const uint32_t s0 = (legs >> (4 * j)) & 3u, s1 = (legs >> (4 * j + 2)) & 3u;
+                    R v0, v1;
+                    if (!IL) {
+                        v0 = s0 == 1u ? R(1) : R(0);
+                        v1 = s1 == 1u ? R(1) : R(0);
+                    } else {  // converters.py:350-352: leg 1 sees -i_out; dead leg -> freewheeling diode (277-285)
+                        const R i = i_in(y, j);
+                        v0 = ((s0 == 1u) | ((s0 == 0u) & (i < R(0)))) ? R(1) : R(0);
+                        v1 = ((s1 == 1u) | ((s1 == 0u) & (-i < R(0)))) ? R(1) : R(0);
+                    }
+                    u[j] = (v0 - v1) * P.u_sup;
                 }
-                u[0] = (v0 - v1) * P.u_sup;
                 integrate<SYS, LOAD, SOLVER, R, NS1>(P, y, u, h);
             };
             if (IL) {
@@ -327,7 +369,8 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
                 segment(P.tau);
             }
         }
-        ho[0] = u[0];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) ho[j] = u[j];
     }
     static __device__ __forceinline__ void observe(const DevParams<R> &P, const R (&y)[ND], AngT, const R (&ho)[NH], R (&obs)[NOUT]) {
         R x[NC];
@@ -337,11 +380,12 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
         obs[1] = Elec<SYS, R>::torque(P, x) * P.inv_lim[1];
 #pragma unroll
         for (int c = 0; c < NC; ++c) obs[2 + c] = y[1 + c] * P.inv_lim[2 + c];
-        obs[2 + NC] = ho[0] * P.inv_lim[2 + NC];
-        obs[3 + NC] = P.u_sup * P.inv_lim[3 + NC];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) obs[2 + NC + j] = ho[j] * P.inv_lim[2 + NC + j];
+        obs[2 + NC + NU] = P.u_sup * P.inv_lim[2 + NC + NU];
     }
     // default constraints of the DC envs: LimitConstraint on the current(s): ('i',) (cont_cc_permex_dc_env.py:104,
-    // cont_cc_series_dc_env.py:102) / ('i_a', 'i_e') (cont_cc_shunt_dc_env.py:103)
+    // cont_cc_series_dc_env.py:102) / ('i_a', 'i_e') (cont_cc_shunt_dc_env.py:103, cont_cc_extex_dc_env.py)
     static __device__ __forceinline__ bool default_done(const R (&obs)[NOUT]) {
         bool d = false;
 #pragma unroll
@@ -361,13 +405,15 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R>
 struct Stepper<GEMX_SYS_DC_SERIES, CONV, LOAD, SOLVER, IL, R> : DcStepper<GEMX_SYS_DC_SERIES, CONV, LOAD, SOLVER, IL, R> {};
 template <int CONV, int LOAD, int SOLVER, bool IL, class R>
 struct Stepper<GEMX_SYS_DC_SHUNT, CONV, LOAD, SOLVER, IL, R> : DcStepper<GEMX_SYS_DC_SHUNT, CONV, LOAD, SOLVER, IL, R> {};
+template <int CONV, int LOAD, int SOLVER, bool IL, class R>
+struct Stepper<GEMX_SYS_DC_EXTEX, CONV, LOAD, SOLVER, IL, R> : DcStepper<GEMX_SYS_DC_EXTEX, CONV, LOAD, SOLVER, IL, R> {};
 
 // ---- SynchronousMotorSystem (physical_systems.py:487-525), control_space 'abc' ---------------------------------
 template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_SYNC, CONV, LOAD, SOLVER, IL, R> {
     using AngT = typename Angle<R>::T;
     static constexpr int NH = 7;  // ho: sin, cos of the last segment-start angle, u_a, u_b, u_c, u_sd, u_sq
     template <bool NS1 = false>
-    static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[3], AngT &ang, uint32_t &sw, const R (&act)[3],
+    static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[3], AngT &ang, uint32_t &sw, const R (&act)[MAX_ACT],
                                                    uint32_t dact, R (&ho)[NH]) {
         R s, c;
         Angle<R>::sincos(ang, s, c);
@@ -378,7 +424,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             if (P.t_il > R(0)) legs = b6_interlock(sw, legs, two);  // converters.py:302: no dead time -> pattern [action]
             sw = legs;
         }
-        R ua, ub, uc, u[2];
+        R ua, ub, uc, u[MAX_U] = {R(0), R(0), R(0)};
         auto segment = [&](R h) {
             R ia = R(0), ib = R(0), ic = R(0);
             if (IL) {  // i_in = T32(Q(i_dq, eps)) (line 493/505); only its sign matters (dead legs / cont. interlocking)
@@ -434,6 +480,68 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     }
 };
 
+// ---- ExternallyExcitedSynchronousMotorSystem (physical_systems.py:619-652): SynchronousMotorSystem plus the
+// excitation circuit (i_e, u_e) fed by the 4QC of the MultiConverter.  Single segment only: gemx_create refuses a
+// dead time for this system (the reference's interlocking loop, lines 628-638, cannot execute). -------------------
+template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_EESM, CONV, LOAD, SOLVER, IL, R> {
+    using AngT = typename Angle<R>::T;
+    static constexpr int NH = 8;  // ho: sin, cos of the step-start angle, u_a, u_b, u_c, u_sd, u_sq, u_e
+    static constexpr int B6 = CONV == GEMX_CONV_CONT_B6_4QC ? GEMX_CONV_CONT_B6 : GEMX_CONV_FINITE_B6;
+    template <bool NS1 = false>
+    static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[4], AngT &ang, uint32_t &, const R (&act)[MAX_ACT],
+                                                   uint32_t dact, R (&ho)[NH]) {
+        R s, c;
+        Angle<R>::sincos(ang, s, c);
+        R ua, ub, uc, ue, u[MAX_U];
+        b6_voltages<B6, false, R>(P, act, dact & 7u, 0u, R(0), R(0), R(0), ua, ub, uc);
+        if (CONV == GEMX_CONV_CONT_B6_4QC) {  // converters.py:481-491 with t_il = 0
+            ue = (clip01(R(0.5) * (act[3] + R(1))) - clip01(R(-0.5) * (act[3] - R(1)))) * P.u_sup;
+        } else {  // Finite-4QC sub-actions [1,1,2,2] / [1,2,1,2] (converters.py:360-361), flat action = a_b6 + 8 * a_4qc
+            const uint32_t a1 = (dact >> 3) & 3u;
+            ue = (((a1 & 2u) ? R(0) : R(1)) - ((a1 & 1u) ? R(0) : R(1))) * P.u_sup;
+        }
+        R ual, ube;
+        t23(ua, ub, uc, ual, ube);
+        u[0] = c * ual + s * ube;  // Q^-1(., eps) at the step-start angle (line 643)
+        u[1] = -s * ual + c * ube;
+        u[2] = ue;
+        const R deps = integrate<GEMX_SYS_EESM, LOAD, SOLVER, R, NS1>(P, y, u, P.tau);
+        ang = Angle<R>::advance(ang, deps);
+        ho[0] = s; ho[1] = c; ho[2] = ua; ho[3] = ub; ho[4] = uc; ho[5] = u[0]; ho[6] = u[1]; ho[7] = ue;
+    }
+    static __device__ __forceinline__ void observe(const DevParams<R> &P, const R (&y)[4], AngT ang, const R (&ho)[NH], R (&obs)[16]) {
+        const R s = ho[0], c = ho[1];  // i_abc from the NEW i_dq with the step-start angle (line 646)
+        const R ial = c * y[1] - s * y[2], ibe = s * y[1] + c * y[2];
+        R ia, ib, ic;
+        t32(ial, ibe, ia, ib, ic);
+        const R x[3] = {y[1], y[2], y[3]};
+        obs[0] = y[0] * P.inv_lim[0];
+        obs[1] = Elec<GEMX_SYS_EESM, R>::torque(P, x) * P.inv_lim[1];
+        obs[2] = ia * P.inv_lim[2];
+        obs[3] = ib * P.inv_lim[3];
+        obs[4] = ic * P.inv_lim[4];
+        obs[5] = y[1] * P.inv_lim[5];
+        obs[6] = y[2] * P.inv_lim[6];
+        obs[7] = y[3] * P.inv_lim[7];
+        obs[8] = ho[2] * P.inv_lim[8];
+        obs[9] = ho[3] * P.inv_lim[9];
+        obs[10] = ho[4] * P.inv_lim[10];
+        obs[11] = ho[5] * P.inv_lim[11];
+        obs[12] = ho[6] * P.inv_lim[12];
+        obs[13] = ho[7] * P.inv_lim[13];
+        obs[14] = Angle<R>::wrapped(ang) * P.inv_lim[14];
+        obs[15] = P.u_sup * P.inv_lim[15];
+    }
+    // default constraints: SquaredConstraint(('i_sq','i_sd')) + LimitConstraint(('i_e',)) (cont_cc_eesm_env.py:108)
+    static __device__ __forceinline__ bool default_done(const R (&obs)[16]) {
+        return (obs[5] * obs[5] + obs[6] * obs[6] > R(1)) | (fabs(obs[7]) > R(1));
+    }
+    static __device__ __forceinline__ bool state_done(const DevParams<R> &P, const R (&y)[4], const R (&)[NH]) {
+        const R o5 = y[1] * P.inv_lim[5], o6 = y[2] * P.inv_lim[6], o7 = y[3] * P.inv_lim[7];
+        return (o5 * o5 + o6 * o6 > R(1)) | (fabs(o7) > R(1));
+    }
+};
+
 // ---- SquirrelCageInductionMotorSystem (physical_systems.py:771-814), control_space 'abc' -----------------------
 template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_SCIM, CONV, LOAD, SOLVER, IL, R> {
     using AngT = typename Angle<R>::T;
@@ -447,7 +555,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
         s = pb * rn;
     }
     template <bool NS1 = false>
-    static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[5], AngT &ang, uint32_t &sw, const R (&act)[3],
+    static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[5], AngT &ang, uint32_t &sw, const R (&act)[MAX_ACT],
                                                    uint32_t dact, R (&ho)[NH]) {
         R s, c;
         field_angle(y[3], y[4], s, c);
@@ -458,7 +566,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             if (P.t_il > R(0)) legs = b6_interlock(sw, legs, two);
             sw = legs;
         }
-        R ua, ub, uc, u[2];
+        R ua, ub, uc, u[MAX_U] = {R(0), R(0), R(0)};
         auto segment = [&](R h) {
             R ia = R(0), ib = R(0), ic = R(0);
             if (IL) t32(y[1], y[2], ia, ib, ic);  // i_in = T32(i_alphabeta) (line 780/792)
@@ -511,7 +619,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
 
 // step() for the single-wave kernel
 template <class ST, int ND, int NOUT, class R>
-__device__ __forceinline__ void full_step(const DevParams<R> &P, R (&y)[ND], typename Angle<R>::T &ang, uint32_t &sw, const R (&act)[3],
+__device__ __forceinline__ void full_step(const DevParams<R> &P, R (&y)[ND], typename Angle<R>::T &ang, uint32_t &sw, const R (&act)[MAX_ACT],
                                           uint32_t dact, R (&obs)[NOUT]) {
     R ho[ST::NH];
     ST::advance(P, y, ang, sw, act, dact, ho);
@@ -602,7 +710,7 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
     // Software pipeline (COOP): the action of step s+1 is read from LDS while step s computes, and the observation
     // row of step s is written to the ring at the top of iteration s+1, so the only LDS wait of an iteration (for the
     // action it is about to use) finds a read that was issued a whole step earlier.
-    auto read_action = [&](int s, R (&dst)[3], uint32_t &ddst) {
+    auto read_action = [&](int s, R (&dst)[MAX_ACT], uint32_t &ddst) {
         if (COOP) {
             if (DISCRETE) ddst = atile[s * ROWB + tid];
             else {
@@ -628,12 +736,12 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
         }
         donebuf[s * BLOCK + tid] = dn ? 1 : 0;
     };
-    R nact[3] = {R(0), R(0), R(0)};
+    R nact[MAX_ACT] = {R(0), R(0), R(0), R(0)};
     uint32_t ndact = 0;
     read_action(0, nact, ndact);
     bool pdone = false;
     for (int s = 0; s < sb; ++s) {
-        R act[3] = {nact[0], nact[1], nact[2]};
+        R act[MAX_ACT] = {nact[0], nact[1], nact[2], nact[3]};
         uint32_t dact = ndact;
         if (a.obs_every && s > 0) write_ring(s - 1, pdone);       // row of the previous step (obs still holds it)
         if (COOP && s + 1 < sb) read_action(s + 1, nact, ndact);   // prefetch (LDS only; global loads would add vmcnt waits)
@@ -704,7 +812,7 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
     AngT ang = AngT(0);
     if (SysTraits<SYS>::HAS_ANGLE) ang = a.angle[e];
     uint32_t sw = 0;
-    constexpr bool USE_SW = (CONV == GEMX_CONV_FINITE_B6 || CONV == GEMX_CONV_FINITE_4QC) && IL;
+    constexpr bool USE_SW = conv_has_legs<CONV>() && IL;
     if (USE_SW) sw = a.sw[e];
     const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
 
@@ -844,7 +952,7 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
         AngT ang = AngT(0);
         if (HAS_ANGLE) ang = a.angle[env];
         uint32_t sw = 0;
-        constexpr bool USE_SW = (CONV == GEMX_CONV_FINITE_B6 || CONV == GEMX_CONV_FINITE_4QC) && IL;
+        constexpr bool USE_SW = conv_has_legs<CONV>() && IL;
         if (USE_SW) sw = a.sw[env];
         const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
         const bool check_default = P.constr_kind == 1;
@@ -876,7 +984,7 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
             }
         };
         auto one_step = [&](const R (&act_in)[NACT], uint32_t dact, R *row) {
-            R act[3] = {R(0), R(0), R(0)};
+            R act[MAX_ACT] = {R(0), R(0), R(0), R(0)};
 #pragma unroll
             for (int i = 0; i < NACT; ++i) act[i] = act_in[i];
             if (DISCRETE) { bad_action |= dact >= (uint32_t)ConvTraits<CONV>::NACTIONS; dact &= (uint32_t)(ConvTraits<CONV>::NACTIONS - 1); }

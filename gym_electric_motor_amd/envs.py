@@ -7,7 +7,9 @@ reference env classes (supply voltage, converter, motor, load, tau, constraints)
     {Finite,Cont}-{CC,TC,SC}-{PermExDc,SeriesDc,ShuntDc}-v0   envs/gym_dcm/{permex,series,shunt}_dc_motor_env/*.py
     {Finite,Cont}-{CC,TC,SC}-{PMSM,SynRM}-v0                  envs/gym_pmsm/*.py, envs/gym_synrm/*.py
     {Finite,Cont}-{CC,TC,SC}-SCIM-v0                          envs/gym_im/squirrel_cage_induction_motor_envs/*.py
-(36 of the reference's 54 env ids; the rest need the multi-converter systems: ExtExDc, EESM, DFIM.)
+    {Finite,Cont}-{CC,TC,SC}-ExtExDc-v0                       envs/gym_dcm/extex_dc_motor_env/*.py   (MultiConverter 2 x 4QC)
+    {Finite,Cont}-{CC,TC,SC}-EESM-v0                          envs/gym_eesm/*.py                     (MultiConverter B6 + 4QC)
+(48 of the reference's 54 env ids; the remaining six are the doubly fed induction motor, DFIM.)
 
 Only the physical system + constraint monitor (done mask) are device-resident.  Reference generators, reward
 functions and visualisation are outside the accelerated path: `step()` returns
@@ -19,7 +21,7 @@ import re
 from . import components as comp
 from . import physical_systems as bps
 
-_ID = re.compile(r"^(Finite|Cont)-(CC|TC|SC)-(PermExDc|SeriesDc|ShuntDc|PMSM|SynRM|SCIM)-v0$")
+_ID = re.compile(r"^(Finite|Cont)-(CC|TC|SC)-(PermExDc|SeriesDc|ShuntDc|ExtExDc|PMSM|SynRM|SCIM|EESM)-v0$")
 
 
 def _initialize(arg, default_class, default_args):
@@ -44,9 +46,13 @@ _SC_LOAD = {
     ("Cont", "PermExDc"): dict(a=0.0, b=0.0, c=0.0, j_load=1e-4), ("Finite", "PermExDc"): dict(a=0.0, b=0.0, c=0.0, j_load=1e-3),
     ("Cont", "SeriesDc"): dict(a=0.01, b=0.05, c=0.0, j_load=1e-4), ("Finite", "SeriesDc"): dict(a=0.15, b=0.05, c=0.0, j_load=1e-4),
     ("Cont", "ShuntDc"): dict(a=0.05, b=0.01, c=0.0, j_load=1e-4), ("Finite", "ShuntDc"): dict(a=0.05, b=0.01, c=0.0, j_load=1e-4),
+    # cont_sc_extex_dc_env.py:161, finite_sc_extex_dc_env.py:162; cont_sc_eesm_env.py:165 (-> the fall-through default below),
+    # finite_sc_eesm_env.py:160 (PolynomialStaticLoad's own defaults)
+    ("Cont", "ExtExDc"): dict(a=0.0, b=0.0, c=0.0, j_load=1e-4), ("Finite", "ExtExDc"): dict(a=0.0, b=0.0, c=0.0, j_load=1e-4),
+    ("Finite", "EESM"): dict(),
 }
 # supply voltages that differ from the family default (60 V DC motors, 420 V three-phase)
-_U_NOMINAL = {"Cont-CC-PMSM-v0": 300.0, "Finite-CC-SeriesDc-v0": 420.0, "Finite-TC-SeriesDc-v0": 420.0}
+_U_NOMINAL = {"Cont-CC-PMSM-v0": 300.0, "Finite-CC-SeriesDc-v0": 420.0, "Finite-TC-SeriesDc-v0": 420.0, "Cont-CC-EESM-v0": 300.0}
 
 
 def default_components(env_id):
@@ -56,11 +62,23 @@ def default_components(env_id):
     m = _ID.match(env_id)
     if not m:
         raise KeyError(f"{env_id!r} is not on the accelerated path; supported: "
-                       "(Finite|Cont)-(CC|TC|SC)-(PermExDc|SeriesDc|ShuntDc|PMSM|SynRM|SCIM)-v0")
+                       "(Finite|Cont)-(CC|TC|SC)-(PermExDc|SeriesDc|ShuntDc|ExtExDc|PMSM|SynRM|SCIM|EESM)-v0")
     action, control, motor = m.groups()
     finite = action == "Finite"
     dc = motor.endswith("Dc")
-    if dc:
+    d_conv_args = dict()
+    if motor == "ExtExDc":  # cont_cc_extex_dc_env.py:146-160: MultiConverter of two 4QCs
+        sub = comp.FiniteFourQuadrantConverter if finite else comp.ContFourQuadrantConverter
+        d = dict(system=bps.BatchedDcMotorSystem, supply=dict(u_nominal=60.0), motor=comp.DcExternallyExcitedMotor,
+                 converter=comp.FiniteMultiConverter if finite else comp.ContMultiConverter, constraints=("i_a", "i_e"))
+        d_conv_args = dict(subconverters=(sub, sub))
+    elif motor == "EESM":  # cont_cc_eesm_env.py:153-170: B6 bridge + 4QC
+        subs = (comp.FiniteB6BridgeConverter, comp.FiniteFourQuadrantConverter) if finite else (comp.ContB6BridgeConverter, comp.ContFourQuadrantConverter)
+        d = dict(system=bps.BatchedExternallyExcitedSynchronousMotorSystem, supply=dict(u_nominal=420.0),
+                 motor=comp.ExternallyExcitedSynchronousMotor, converter=comp.FiniteMultiConverter if finite else comp.ContMultiConverter,
+                 constraints=(bps.SquaredConstraint(("i_sq", "i_sd")), bps.LimitConstraint(("i_e",))))
+        d_conv_args = dict(subconverters=subs)
+    elif dc:
         motor_cls = {"PermExDc": comp.DcPermanentlyExcitedMotor, "SeriesDc": comp.DcSeriesMotor, "ShuntDc": comp.DcShuntMotor}[motor]
         d = dict(system=bps.BatchedDcMotorSystem, supply=dict(u_nominal=60.0), motor=motor_cls,
                  converter=comp.FiniteFourQuadrantConverter if finite else comp.ContFourQuadrantConverter,
@@ -81,6 +99,7 @@ def default_components(env_id):
     else:
         d["load"] = (comp.ConstantSpeedLoad, dict(omega_fixed=100.0))
     d["tau"] = 1e-5 if finite else 1e-4
+    d["converter_args"] = d_conv_args
     return d
 
 
@@ -123,7 +142,7 @@ def make(env_id, n_envs=1, device=0, supply=None, converter=None, motor=None, lo
     conv_cls = d["converter"]
     system = d["system"](
         supply=_initialize(supply, comp.IdealVoltageSupply, d["supply"]),
-        converter=_initialize(converter, conv_cls, dict()),
+        converter=_initialize(converter, conv_cls, d["converter_args"]),
         motor=_initialize(motor, d["motor"], dict()),
         load=_initialize(load, d["load"][0], d["load"][1]),
         ode_solver=_initialize(ode_solver, comp.RK4Solver, dict()),

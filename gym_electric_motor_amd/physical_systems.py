@@ -209,6 +209,18 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
 
     def _converter_kind(self):
         c = self._converter
+        if _is_a(c, "ContMultiConverter", "FiniteMultiConverter"):
+            subs = list(getattr(c, "_sub_converters", ()))
+            names = tuple(next((n for n in ("ContFourQuadrantConverter", "FiniteFourQuadrantConverter", "ContB6BridgeConverter",
+                                            "FiniteB6BridgeConverter") if _is_a(sc, n)), type(sc).__name__) for sc in subs)
+            kinds = {("ContFourQuadrantConverter", "ContFourQuadrantConverter"): _lib.CONV_CONT_2X4QC,
+                     ("FiniteFourQuadrantConverter", "FiniteFourQuadrantConverter"): _lib.CONV_FINITE_2X4QC,
+                     ("ContB6BridgeConverter", "ContFourQuadrantConverter"): _lib.CONV_CONT_B6_4QC,
+                     ("FiniteB6BridgeConverter", "FiniteFourQuadrantConverter"): _lib.CONV_FINITE_B6_4QC}
+            if names not in kinds:
+                raise ValueError(f"multi converter of {names} is not on the accelerated path (supported: 2 x 4QC for the externally "
+                                 "excited DC motor, B6 + 4QC for the EESM)")
+            return kinds[names]
         if _is_a(c, "ContFourQuadrantConverter"):
             return _lib.CONV_CONT_4QC
         if _is_a(c, "FiniteB6BridgeConverter"):
@@ -219,6 +231,18 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             return _lib.CONV_CONT_B6
         raise ValueError(f"converter {type(c).__name__} is not on the accelerated path "
                          "(supported: ContFourQuadrantConverter, FiniteFourQuadrantConverter, FiniteB6BridgeConverter, ContB6BridgeConverter)")
+
+    def _interlocking_time(self):
+        """converter dead time.  A MultiConverter's own value is never used by the reference (converters.py:498-740): its
+        sub-converters' values are; the kernels take one value, so they must agree."""
+        c = self._converter
+        subs = getattr(c, "_sub_converters", None)
+        if subs is None:
+            return float(getattr(c, "_interlocking_time", 0.0))
+        tils = {float(getattr(sc, "_interlocking_time", 0.0)) for sc in subs}
+        if len(tils) != 1:
+            raise ValueError(f"the sub-converters of a multi converter must share one interlocking_time on the accelerated path, got {sorted(tils)}")
+        return tils.pop()
 
     def _solver_kind(self):
         s = self._ode_solver
@@ -248,8 +272,10 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         mp = m.motor_parameter
         if _is_a(m, "DcPermanentlyExcitedMotor"):
             return [mp["psi_e"], 0.0]
-        if _is_a(m, "DcSeriesMotor", "DcShuntMotor"):
+        if _is_a(m, "DcSeriesMotor", "DcShuntMotor", "DcExternallyExcitedMotor"):
             return [mp["l_e_prime"], 0.0]
+        if _is_a(m, "ExternallyExcitedSynchronousMotor"):
+            return [1.5 * mp["p"] * mp["l_M"] * mp["i_k_rs"], 1.5 * mp["p"] * (mp["l_d"] - mp["l_q"])]
         if _is_a(m, "PermanentMagnetSynchronousMotor"):
             return [1.5 * mp["p"] * mp["psi_p"], 1.5 * mp["p"] * (mp["l_d"] - mp["l_q"])]
         if _is_a(m, "SynchronousReluctanceMotor"):
@@ -280,7 +306,7 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         cfg.auto_reset = int(self._auto_reset)
         cfg.limit_mask, cfg.squared_mask = limit_mask, squared_mask
         cfg.tau = float(self.tau)
-        cfg.interlocking_time = float(getattr(self._converter, "_interlocking_time", 0.0))
+        cfg.interlocking_time = self._interlocking_time()
         cfg.u_nominal = float(self._supply.u_nominal)
         model = np.zeros((_lib.MODEL_ROWS, _lib.MODEL_COLS))
         mc = np.asarray(self._electrical_motor._model_constants, dtype=float)
@@ -349,6 +375,23 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
                 n *= d
             if actions.numel() == n * (1 if self._discrete else self._n_act):
                 return actions  # fast path: already what the kernel reads (no torch ops on the hot path)
+        nvec = getattr(self.action_space, "nvec", None)
+        if self._discrete and nvec is not None:
+            # MultiDiscrete([n0, n1]) of a FiniteMultiConverter: [..., 2] sub-actions -> the flat index a0 + n0 * a1 the kernel
+            # reads (include/gemx.h); an already flat tensor of shape `leading` passes through
+            n0, n1 = int(nvec[0]), int(nvec[1])
+            if not torch.is_tensor(actions):
+                arr = np.asarray(actions)
+                if arr.shape[-1:] == (2,) and arr.size == 2 * int(np.prod(leading)):
+                    if arr.size and (arr.min() < 0 or (arr[..., 0] >= n0).any() or (arr[..., 1] >= n1).any()):
+                        raise AssertionError(f"The selected action {arr.reshape(-1, 2)[0]} is not a valid element of the action space {self.action_space}.")
+                    arr = arr[..., 0] + n0 * arr[..., 1]
+                elif arr.size and (arr.min() < 0 or arr.max() >= n0 * n1):
+                    raise AssertionError(f"The selected flat action is not a valid element of the action space {self.action_space}.")
+                actions = torch.as_tensor(arr.astype(np.uint8))
+            elif actions.shape[-1:] == (2,) and actions.numel() == 2 * int(np.prod(leading)):
+                actions = actions[..., 0] + n0 * actions[..., 1]
+            return actions.to(device=self._tdev, dtype=torch.uint8).reshape(leading).contiguous()
         if self._discrete:
             if not torch.is_tensor(actions):
                 arr = np.asarray(actions)
@@ -380,7 +423,7 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         Otherwise `action` is [N, A] (float) or [N] (discrete) and the returned device tensor ([N, S_out]) is an
         internal buffer that the next call overwrites."""
         single = self._n_envs == 1 and not _torch().is_tensor(action)
-        if single and self._discrete:
+        if single and self._discrete and not hasattr(self.action_space, "nvec"):
             assert self.action_space.contains(action), (  # converters.py:204-206
                 f"The selected action {action} is not a valid element of the action space {self.action_space}.")
         a = self._actions_to_device(action, (self._n_envs,))
@@ -469,7 +512,8 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
 
 class BatchedDcMotorSystem(BatchedSCMLSystem):
     """DcMotorSystem (physical_systems.py:290-318) for N envs: permanently excited, series and shunt DC motors
-    (one converter voltage) with Cont-4QC or Finite-4QC."""
+    (one converter voltage) with Cont-4QC or Finite-4QC; externally excited DC motor with a Cont/FiniteMultiConverter
+    of two 4QCs (armature, excitation)."""
 
     def __init__(self, converter, motor, *args, **kwargs):
         if _is_a(motor, "DcSeriesMotor"):
@@ -478,9 +522,11 @@ class BatchedDcMotorSystem(BatchedSCMLSystem):
             self._SYSTEM_KIND = _lib.SYS_DC_SHUNT
         elif _is_a(motor, "DcPermanentlyExcitedMotor"):
             self._SYSTEM_KIND = _lib.SYS_DC_PERMEX
+        elif _is_a(motor, "DcExternallyExcitedMotor"):
+            self._SYSTEM_KIND = _lib.SYS_DC_EXTEX
         else:
             raise ValueError(f"motor {type(motor).__name__} is not on the accelerated path for DcMotorSystem "
-                             "(supported: DcPermanentlyExcitedMotor, DcSeriesMotor, DcShuntMotor)")
+                             "(supported: DcPermanentlyExcitedMotor, DcSeriesMotor, DcShuntMotor, DcExternallyExcitedMotor)")
         self._n_ode = 1 + len(motor.CURRENTS)
         super().__init__(converter, motor, *args, **kwargs)
 
@@ -574,6 +620,28 @@ class BatchedSynchronousMotorSystem(_BatchedThreePhaseMotorSystem):
     def _build_state_names(self):
         return self._mechanical_load.state_names + ["torque", "i_a", "i_b", "i_c", "i_sd", "i_sq", "u_a", "u_b", "u_c",
                                                     "u_sd", "u_sq", "epsilon", "u_sup"]
+
+
+class BatchedExternallyExcitedSynchronousMotorSystem(_BatchedThreePhaseMotorSystem):
+    """ExternallyExcitedSynchronousMotorSystem (physical_systems.py:564-691) for N envs: EESM behind a
+    Cont/FiniteMultiConverter of a B6 bridge (stator) and a 4QC (excitation).  No converter dead time (the reference's
+    interlocking branch for this system cannot execute)."""
+
+    _SYSTEM_KIND = _lib.SYS_EESM
+    _n_ode = 5
+
+    def _build_state_names(self):
+        return self._mechanical_load.state_names + ["torque", "i_a", "i_b", "i_c", "i_sd", "i_sq", "i_e", "u_a", "u_b", "u_c",
+                                                    "u_sd", "u_sq", "u_e", "epsilon", "u_sup"]
+
+    def _set_indices(self):
+        """physical_systems.py:595-617."""
+        self.OMEGA_IDX = 0
+        self.TORQUE_IDX = 1
+        self.CURRENTS_IDX = list(range(2, 8))
+        self.VOLTAGES_IDX = list(range(8, 14))
+        self.EPSILON_IDX = 14
+        self.U_SUP_IDX = [15]
 
 
 class BatchedSquirrelCageInductionMotorSystem(_BatchedThreePhaseMotorSystem):

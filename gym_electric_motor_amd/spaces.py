@@ -1,9 +1,9 @@
 """Action / state spaces.  gymnasium's spaces are used when gymnasium is installed (so the objects are the ones
-the reference's env shell expects); otherwise a minimal compatible Box / Discrete is provided."""
+the reference's env shell expects); otherwise a minimal compatible Box / Discrete / MultiDiscrete is provided."""
 import numpy as np
 
 try:  # pragma: no cover - depends on the environment
-    from gymnasium.spaces import Box, Discrete  # noqa: F401
+    from gymnasium.spaces import Box, Discrete, MultiDiscrete  # noqa: F401
 except Exception:  # gymnasium is optional
 
     class _Space:
@@ -60,3 +60,21 @@ except Exception:  # gymnasium is optional
 
         def __repr__(self):
             return f"Discrete({self.n})"
+
+    class MultiDiscrete(_Space):
+        def __init__(self, nvec):
+            self.nvec = np.asarray(nvec, dtype=np.int64)
+            super().__init__(self.nvec.shape, np.int64)
+
+        def sample(self):
+            return self._rng.integers(0, self.nvec).astype(np.int64)
+
+        def contains(self, x):
+            x = np.asarray(x)
+            return x.shape == self.shape and np.issubdtype(x.dtype, np.integer) and bool(np.all(x >= 0) and np.all(x < self.nvec))
+
+        def __eq__(self, other):
+            return isinstance(other, MultiDiscrete) and np.array_equal(self.nvec, other.nvec)
+
+        def __repr__(self):
+            return f"MultiDiscrete({self.nvec})"

@@ -47,11 +47,23 @@ typedef enum {
     GEMX_SYS_SYNC = 1,      /* SynchronousMotorSystem (PMSM, SynRM)                                         */
     GEMX_SYS_SCIM = 2,      /* SquirrelCageInductionMotorSystem                                             */
     GEMX_SYS_DC_SERIES = 3, /* DcMotorSystem + DcSeriesMotor (electric_motors/dc_series_motor.py)           */
-    GEMX_SYS_DC_SHUNT = 4   /* DcMotorSystem + DcShuntMotor  (electric_motors/dc_shunt_motor.py)            */
+    GEMX_SYS_DC_SHUNT = 4,  /* DcMotorSystem + DcShuntMotor  (electric_motors/dc_shunt_motor.py)            */
+    GEMX_SYS_DC_EXTEX = 5,  /* DcMotorSystem + DcExternallyExcitedMotor (dc_externally_excited_motor.py)     */
+    GEMX_SYS_EESM = 6       /* ExternallyExcitedSynchronousMotorSystem (physical_systems.py:564-691)         */
 } gemx_system_kind;
 /* ContFourQuadrantConverter (converters.py:438-495), FiniteB6BridgeConverter (743-839), ContB6BridgeConverter (842-911),
- * FiniteFourQuadrantConverter (313-368; DC systems, actions 0..3) */
-typedef enum { GEMX_CONV_CONT_4QC = 0, GEMX_CONV_FINITE_B6 = 1, GEMX_CONV_CONT_B6 = 2, GEMX_CONV_FINITE_4QC = 3 } gemx_converter_kind;
+ * FiniteFourQuadrantConverter (313-368; DC systems, actions 0..3).
+ * Kinds 4..7 are Cont/FiniteMultiConverter (converters.py:498-740) holding exactly the two sub-converters of the
+ * reference's ExtExDc envs (2 x 4QC: armature, excitation) and EESM envs (B6 stator + 4QC excitation).
+ *   continuous actions: the sub-converters' actions concatenated, A = 2 | 4;
+ *   discrete actions:   ONE uint8 = a_0 + n_0 * a_1, the flat index of the reference's MultiDiscrete([n_0, n_1])
+ *                       action [a_0, a_1] (n_0 = 4 | 8), i.e. 0..15 | 0..31.
+ * The two sub-converters share interlocking_time; EESM handles refuse interlocking_time > 0 (the reference's
+ * dead-time branch for this system cannot execute, physical_systems.py:634). */
+typedef enum {
+    GEMX_CONV_CONT_4QC = 0, GEMX_CONV_FINITE_B6 = 1, GEMX_CONV_CONT_B6 = 2, GEMX_CONV_FINITE_4QC = 3,
+    GEMX_CONV_CONT_2X4QC = 4, GEMX_CONV_FINITE_2X4QC = 5, GEMX_CONV_CONT_B6_4QC = 6, GEMX_CONV_FINITE_B6_4QC = 7
+} gemx_converter_kind;
 /* ConstantSpeedLoad (constant_speed_load.py), PolynomialStaticLoad (polynomial_static_load.py) */
 typedef enum { GEMX_LOAD_CONST_SPEED = 0, GEMX_LOAD_POLY_STATIC = 1 } gemx_load_kind;
 /* EulerSolver(nsteps) (solvers.py:79-136); classical RK4 (not in the reference); one fixed Dormand-Prince-5
@@ -79,11 +91,14 @@ typedef struct gemx_config {
      * DC    (1x3) [omega, i, u]                                  dc_permanently_excited_motor.py:71-84
      * SERIES(1x3) [i, omega*i, u]                                dc_series_motor.py:68-83
      * SHUNT (2x5) [i_a, i_e, omega*i_e, u_a, u_e] (u_a = u_e = u) dc_motor.py:96-127, dc_shunt_motor.py:72-74
+     * EXTEX (2x5) [i_a, i_e, omega*i_e, u_a, u_e]                 dc_motor.py:96-127
      * SYNC  (3x7) [omega, i_d, i_q, u_d, u_q, omega*i_d, omega*i_q]  synchronous_motor.py:143-168
+     * EESM  (4x10)[omega, i_d, i_q, i_e, u_d, u_q, u_e, omega*i_d, omega*i_q, omega*i_e]
+     *                                                            externally_excited_synchronous_motor.py:69-113
      * SCIM  (5x11)[omega, i_a, i_b, psi_a, psi_b, omega*psi_a, omega*psi_b, u_sa, u_sb, u_ra, u_rb] induction_motor.py:187-217 */
     double model[GEMX_MODEL_ROWS * GEMX_MODEL_COLS];
     /* torque: DC T = tc[0]*i ; SYNC T = (tc[0] + tc[1]*i_d)*i_q ; SCIM T = tc[0]*(psi_a*i_b - psi_b*i_a) ;
-     * SERIES T = tc[0]*i*i ; SHUNT T = tc[0]*i_a*i_e */
+     * SERIES T = tc[0]*i*i ; SHUNT / EXTEX T = tc[0]*i_a*i_e ; EESM T = (tc[0]*i_e + tc[1]*i_d)*i_q */
     double torque_coef[4];
     double j_total;                    /* load.j_total (j_load + j_rotor), mechanical_load.py:35-41 */
     double load_a, load_b, load_c;     /* PolynomialStaticLoad parameters */
@@ -105,9 +120,9 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
 int gemx_destroy(gemx_handle *h);
 
 int gemx_n_envs(const gemx_handle *h, int64_t *n);
-int gemx_n_ode(const gemx_handle *h);    /* S_ode: 2 | 3 | 4 | 6 */
-int gemx_n_out(const gemx_handle *h);    /* S_out: 5 | 6 | 14    */
-int gemx_n_action(const gemx_handle *h); /* A: 1 | 3         */
+int gemx_n_ode(const gemx_handle *h);    /* S_ode: 2 | 3 | 4 | 5 | 6  */
+int gemx_n_out(const gemx_handle *h);    /* S_out: 5 | 6 | 7 | 14 | 16 */
+int gemx_n_action(const gemx_handle *h); /* A: 1 | 2 | 3 | 4 (1 for every discrete converter) */
 int gemx_action_itemsize(const gemx_handle *h); /* 1 (uint8 discrete) | sizeof(R) */
 /* normalised state returned by reset() for the configured constant initialiser, host doubles [S_out] */
 int gemx_reset_observation(const gemx_handle *h, double *obs_host);

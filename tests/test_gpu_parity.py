@@ -34,7 +34,17 @@ def _make_from_meta(meta, n_envs, solver=None, dtype="float32", episodic=None, o
            "rk4x8": ga.RK4Solver(nsteps=8), "dp5x8": ga.DormandPrince5Solver(nsteps=8),
            "dopri5": ga.DormandPrince5Solver(), "dp5": ga.DormandPrince5Solver()}[solver]
     kw = dict(n_envs=n_envs, ode_solver=sol, tau=meta["tau"], dtype=dtype, obs_layout=obs_layout, auto_reset=auto_reset)
-    kw["converter"] = dict(interlocking_time=meta["interlocking_time"])
+    if "MultiConverter" in meta["converter"]:
+        # Cont/FiniteMultiConverter: the dead time lives in the sub-converters (a dict override would only reach the holder)
+        if meta["interlocking_time"] > 0:
+            til = meta["interlocking_time"]
+            subs = {"FiniteFourQuadrantConverter": ga.FiniteFourQuadrantConverter, "ContFourQuadrantConverter": ga.ContFourQuadrantConverter,
+                    "FiniteB6BridgeConverter": ga.FiniteB6BridgeConverter, "ContB6BridgeConverter": ga.ContB6BridgeConverter}
+            names = meta["converter"].split("[")[1].rstrip("]").split(",")
+            holder = ga.FiniteMultiConverter if meta["converter"].startswith("Finite") else ga.ContMultiConverter
+            kw["converter"] = holder(subconverters=[subs[n](interlocking_time=til) for n in names])
+    else:
+        kw["converter"] = dict(interlocking_time=meta["interlocking_time"])
     if meta["load"] == "ConstantSpeedLoad":
         kw["load"] = ga.ConstantSpeedLoad(omega_fixed=meta["omega_fixed"])
     else:
@@ -45,12 +55,15 @@ def _make_from_meta(meta, n_envs, solver=None, dtype="float32", episodic=None, o
     return ga.make(meta["env_id"], **kw)
 
 
-def _rel_err(got, ref, names):
+def _rel_err(got, ref, names, scale_ref=None):
+    """max over columns of (max |got - ref|) / (max |ref| of that column); `scale_ref`: take the column ranges from this
+    (longer) reference trajectory instead of `ref` itself."""
     diff = np.abs(got - ref)
     if "epsilon" in names:
         i = names.index("epsilon")
         diff[..., i] = np.minimum(diff[..., i], 2.0 - diff[..., i])
-    scale = np.maximum(np.abs(ref).reshape(-1, ref.shape[-1]).max(axis=0), 1e-9)
+    sr = ref if scale_ref is None else scale_ref
+    scale = np.maximum(np.abs(sr).reshape(-1, sr.shape[-1]).max(axis=0), 1e-9)
     return float((diff.reshape(-1, ref.shape[-1]).max(axis=0) / scale).max()), float(diff.max())
 
 
@@ -64,8 +77,8 @@ def _run_golden(name, dtype, solver=None, n_envs=70):
     acts = d["actions"]
     K = acts.shape[0]
     a = torch.as_tensor(np.repeat(acts.reshape(K, 1, -1), n_envs, axis=1))
-    if ps._discrete:
-        a = a.reshape(K, n_envs)
+    if ps._discrete and acts.ndim == 1:
+        a = a.reshape(K, n_envs)  # (MultiDiscrete actions stay [K, N, 2]: rollout() packs them into the flat index)
     obs, done = env.rollout(a.cuda())
     torch.cuda.synchronize()
     obs = obs.double().cpu().numpy()
@@ -84,7 +97,10 @@ def _check_done(meta, d, got_done, ref_states_full=None):
     assert meta["every"] == 1
     s = d["states"]
     names = meta["state_names"]
-    if meta["system"] == "DcMotorSystem" and meta["motor"] == "DcShuntMotor":
+    if meta["system"] == "ExternallyExcitedSynchronousMotorSystem":
+        margin = np.minimum(np.abs(s[:, names.index("i_sd")] ** 2 + s[:, names.index("i_sq")] ** 2 - 1.0),
+                            np.abs(np.abs(s[:, names.index("i_e")]) - 1.0))
+    elif meta["system"] == "DcMotorSystem" and meta["motor"] in ("DcShuntMotor", "DcExternallyExcitedMotor"):
         margin = np.minimum(np.abs(np.abs(s[:, names.index("i_a")]) - 1.0), np.abs(np.abs(s[:, names.index("i_e")]) - 1.0))
     elif meta["system"] == "DcMotorSystem":
         margin = np.abs(np.abs(s[:, names.index("i")]) - 1.0)
@@ -124,10 +140,11 @@ def test_fp32_fixed_step_matches_reference_default_dopri5(name, solver):
         solver += "x8"  # tiny inertia: one step per tau is 1e-3 off the adaptive reference solver, 8 sub-steps restore 1e-4
     d, meta, obs, done = _run_golden(name, "float32", solver=solver)
     if meta["episodic"]:
-        # after the first termination mismatch trajectories legitimately diverge; compare up to the first done
+        # after the first termination mismatch trajectories legitimately diverge; compare up to the first done (column
+        # ranges from the whole run: the first episode can be a few steps long, with omega / epsilon still ~1e-6)
         n = int(np.argmax(d["terminated"])) if d["terminated"].any() else len(d["terminated"])
         n = max(n, 1)
-        rel, _ = _rel_err(obs[:n], d["states"][:n], meta["state_names"])
+        rel, _ = _rel_err(obs[:n], d["states"][:n], meta["state_names"], scale_ref=d["states"])
     else:
         rel, _ = _rel_err(obs[d["state_index"]], d["states"], meta["state_names"])
     tol = 2e-4 if (meta["system"].startswith("SquirrelCage") and meta["load"] == "PolynomialStaticLoad") else 1e-4
@@ -191,9 +208,83 @@ def test_full_size_configs_against_oracle(env_id, n_envs, solver):
     assert worst < 1e-4, worst
 
 
+@pytest.mark.parametrize("env_id, golden, til", [
+    ("Cont-CC-ExtExDc-v0", "extex_cont_free_held_euler", 0.0), ("Cont-SC-ExtExDc-v0", "extex_cont_sc_free_held_euler", 2e-6),
+    ("Finite-CC-ExtExDc-v0", "extex_fin_free_held_euler", 0.0), ("Finite-CC-ExtExDc-v0", "extex_fin_free_held_til_euler", 1e-6),
+    ("Cont-CC-EESM-v0", "eesm_cont_free_held_euler", 0.0), ("Cont-SC-EESM-v0", "eesm_cont_sc_epi_held_euler", 0.0),
+    ("Finite-CC-EESM-v0", "eesm_fin_free_held_euler", 0.0),
+])
+def test_multi_converter_envs_per_env_actions_against_oracle(env_id, golden, til):
+    """ExtExDc (2 x 4QC) and EESM (B6 + 4QC): every env gets its own random action stream (flat MultiDiscrete index for
+    the finite converters); a sample of envs is checked against the fp64 oracle with the SAME integrator (RK4), and the
+    single-step path, the single-wave and the pipelined fused kernels must agree bit for bit."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+    from oracle import oracle as orc
+
+    K, n_envs = 160, 1024
+    _, meta = _load(golden)
+    fin = env_id.startswith("Finite")
+
+    def conv():
+        if not til:
+            return None
+        sub = ga.FiniteFourQuadrantConverter if fin else ga.ContFourQuadrantConverter
+        holder = ga.FiniteMultiConverter if fin else ga.ContMultiConverter
+        return holder(subconverters=[sub(interlocking_time=til), sub(interlocking_time=til)])
+
+    def mk():
+        return ga.make(env_id, n_envs=n_envs, ode_solver=ga.RK4Solver(), constraints=(), converter=conv())
+
+    env = mk()
+    ps = env.physical_system
+    g = torch.Generator(device="cuda").manual_seed(4321)
+    if ps._discrete:
+        nflat = int(np.prod(ps.action_space.nvec))
+        acts = torch.randint(0, nflat, (K, n_envs), device="cuda", generator=g, dtype=torch.uint8)
+    else:
+        acts = torch.rand((K, n_envs, ps._n_act), device="cuda", generator=g) * 2 - 1
+    obs, _ = env.rollout(acts)
+    torch.cuda.synchronize()
+    assert "advance_pipe_kernel" in ps.last_launch()
+    assert torch.isfinite(obs).all()
+    env2 = mk()
+    for k in range(4):
+        assert torch.equal(env2.physical_system.simulate(acts[k]), obs[k])
+    env2.close()
+    os.environ["GEMX_PIPE"] = "0"
+    try:
+        env3 = mk()
+        obs3, _ = env3.rollout(acts)
+        assert "advance_kernel" in env3.physical_system.last_launch()
+        assert torch.equal(obs3, obs)
+        env3.close()
+    finally:
+        del os.environ["GEMX_PIPE"]
+    meta = dict(meta, interlocking_time=til)
+    p = orc.params_from_meta(meta, solver="rk4", episodic=False)
+    a_host = acts.cpu().numpy().astype(np.float64)
+    if ps._discrete:  # flat index -> [a0, a1] as the reference's MultiDiscrete action
+        n0 = int(ps.action_space.nvec[0])
+        a_host = np.stack([a_host % n0, a_host // n0], axis=-1)
+    o_host = obs.double().cpu().numpy()
+    worst = 0.0
+    for j in (0, 63, 64, 517, n_envs - 1):
+        e = orc.OracleEnv(p)
+        e.reset()
+        ref, _ = e.rollout(a_host[:, j])
+        rel, _ = _rel_err(o_host[:, j], ref, meta["state_names"])
+        worst = max(worst, rel)
+    env.close()
+    assert worst < 1e-4, worst
+
+
 @pytest.mark.parametrize("name", ["pmsm_free_uniform_euler", "pmsm_epi_held_tau1e-4_euler", "pmsm_free_held_til_euler",
                                   "scim_epi_uniform_euler", "scim_free_held_til_euler", "permexdc_epi_held_euler",
-                                  "permexdc_free_held_til_euler", "pmsm_free_uniform_10k_euler"])
+                                  "permexdc_free_held_til_euler", "pmsm_free_uniform_10k_euler",
+                                  "extex_fin_free_held_til_euler", "extex_cont_epi_held_euler", "eesm_fin_epi_held_tau1e-4_euler",
+                                  "eesm_cont_free_uniform_euler"])
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 def test_two_wave_pipelined_kernel_matches_reference_and_single_wave_kernel(name, dtype, monkeypatch):
     """n_envs = 128 (full 64-env workgroups) takes the two-wave pipelined kernel; it must agree with the reference AND be

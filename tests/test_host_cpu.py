@@ -53,6 +53,12 @@ def test_library_exports_every_declared_symbol():
     ("Cont-CC-ShuntDc-v0", "shunt_cont_free_held_euler"),
     ("Cont-SC-ShuntDc-v0", "shunt_cont_sc_free_held_euler"),
     ("Finite-CC-ShuntDc-v0", "shunt_fin_free_held_til_euler"),
+    ("Cont-CC-ExtExDc-v0", "extex_cont_free_held_euler"),
+    ("Cont-SC-ExtExDc-v0", "extex_cont_sc_free_held_euler"),
+    ("Finite-CC-ExtExDc-v0", "extex_fin_free_held_euler"),
+    ("Cont-CC-EESM-v0", "eesm_cont_free_held_euler"),
+    ("Cont-SC-EESM-v0", "eesm_cont_sc_epi_held_euler"),
+    ("Finite-CC-EESM-v0", "eesm_fin_free_held_euler"),
 ])
 def test_host_metadata_matches_reference(env_id, golden):
     """limits / nominal_state / model constants / names / j_total as the live reference reported them."""
@@ -95,9 +101,9 @@ def test_pmsm_initialiser_dict_order_quirk():
 
 def test_unsupported_pieces_raise():
     with pytest.raises(KeyError):
-        ga.make("Cont-CC-ExtExDc-v0", n_envs=2, _defer_create=True)   # needs the multi-converter system
+        ga.make("Cont-CC-DFIM-v0", n_envs=2, _defer_create=True)   # doubly fed induction motor: not on the path yet
     with pytest.raises(KeyError):
-        ga.make("Finite-CC-EESM-v0", n_envs=2, _defer_create=True)
+        ga.make("Finite-TC-DFIM-v0", n_envs=2, _defer_create=True)
     with pytest.raises(ValueError):  # a DC system needs a one-voltage DC motor
         ga.BatchedDcMotorSystem(converter=ga.ContFourQuadrantConverter(), motor=ga.PermanentMagnetSynchronousMotor(),
                                 load=ga.ConstantSpeedLoad(100.0), supply=ga.IdealVoltageSupply(60.0), ode_solver=ga.EulerSolver(),
@@ -131,6 +137,37 @@ def test_c_abi_argument_validation_without_gpu():
     assert L.gemx_create(C.byref(bad), 4, 0, C.byref(h)) == -1 and b"sparsity" in L.gemx_last_error()
     assert L.gemx_create(C.byref(cfg), 0, 0, C.byref(h)) == -1
     assert L.gemx_destroy(None) == 0
+    # system / converter pairing, and no dead time for the EESM (the reference's branch for it cannot execute)
+    bad = _lib.GemxConfig.from_buffer_copy(cfg)
+    bad.converter_kind = _lib.CONV_CONT_2X4QC
+    assert L.gemx_create(C.byref(bad), 4, 0, C.byref(h)) == -1 and b"combination" in L.gemx_last_error()
+    eesm = ga.make("Finite-CC-EESM-v0", n_envs=2, _defer_create=True).physical_system._cfg
+    bad = _lib.GemxConfig.from_buffer_copy(eesm)
+    bad.interlocking_time = 1e-6
+    assert L.gemx_create(C.byref(bad), 4, 0, C.byref(h)) == -1 and b"EESM" in L.gemx_last_error()
+    bad = _lib.GemxConfig.from_buffer_copy(eesm)
+    bad.model[2 * _lib.MODEL_COLS + 2] = 1.0  # d(i_e)/dt has no i_q term
+    assert L.gemx_create(C.byref(bad), 4, 0, C.byref(h)) == -1 and b"sparsity" in L.gemx_last_error()
+
+
+def test_multi_converter_holders():
+    """Cont/FiniteMultiConverter mirrors (converters.py:498-740): spaces, tau propagation, per-sub-converter dead time."""
+    c = ga.ContMultiConverter(subconverters=[ga.ContB6BridgeConverter, ga.ContFourQuadrantConverter], tau=2e-4)
+    assert c.action_space.shape == (4,) and c.currents.shape == (4,) and c.voltages.shape == (4,)
+    assert [sc.tau for sc in c.sub_converters] == [2e-4, 2e-4]
+    c.tau = 1e-4
+    assert [sc.tau for sc in c.sub_converters] == [1e-4, 1e-4]
+    f = ga.FiniteMultiConverter(subconverters=[ga.FiniteFourQuadrantConverter(interlocking_time=1e-6),
+                                               ga.FiniteFourQuadrantConverter(interlocking_time=1e-6)])
+    assert list(f.action_space.nvec) == [4, 4]
+    ps = ga.make("Finite-CC-ExtExDc-v0", n_envs=2, converter=f, _defer_create=True).physical_system
+    assert ps._cfg.interlocking_time == 1e-6 and ps._cfg.converter_kind == _lib.CONV_FINITE_2X4QC
+    mixed = ga.FiniteMultiConverter(subconverters=[ga.FiniteFourQuadrantConverter(interlocking_time=1e-6), ga.FiniteFourQuadrantConverter()])
+    with pytest.raises(ValueError, match="share one interlocking_time"):
+        ga.make("Finite-CC-ExtExDc-v0", n_envs=2, converter=mixed, _defer_create=True)
+    with pytest.raises(ValueError, match="not on the accelerated path"):
+        ga.make("Finite-CC-ExtExDc-v0", n_envs=2, _defer_create=True,
+                converter=ga.FiniteMultiConverter(subconverters=[ga.FiniteB6BridgeConverter, ga.FiniteB6BridgeConverter]))
 
 
 def test_no_gpu_means_loud_failure_not_cpu_fallback():
