@@ -34,17 +34,18 @@
 #include <string.h>
 
 enum { ORC_SYS_DC_PERMEX = 0, ORC_SYS_PMSM = 1, ORC_SYS_SCIM = 2, ORC_SYS_DC_SERIES = 3, ORC_SYS_DC_SHUNT = 4,
-       ORC_SYS_DC_EXTEX = 5, ORC_SYS_EESM = 6 };
-/* 4..7: Cont/FiniteMultiConverter (converters.py:498-740) of exactly two sub-converters:
- * 2 x 4QC (the ExtExDc envs) and B6 + 4QC (the EESM envs) */
+       ORC_SYS_DC_EXTEX = 5, ORC_SYS_EESM = 6, ORC_SYS_DFIM = 7 };
+/* 4..9: Cont/FiniteMultiConverter (converters.py:498-740) of exactly two sub-converters:
+ * 2 x 4QC (the ExtExDc envs), B6 + 4QC (the EESM envs), 2 x B6 (the DFIM envs: stator, rotor) */
 enum { ORC_CONV_CONT_4QC = 0, ORC_CONV_FINITE_B6 = 1, ORC_CONV_CONT_B6 = 2, ORC_CONV_FINITE_4QC = 3,
-       ORC_CONV_CONT_2X4QC = 4, ORC_CONV_FINITE_2X4QC = 5, ORC_CONV_CONT_B6_4QC = 6, ORC_CONV_FINITE_B6_4QC = 7 };
+       ORC_CONV_CONT_2X4QC = 4, ORC_CONV_FINITE_2X4QC = 5, ORC_CONV_CONT_B6_4QC = 6, ORC_CONV_FINITE_B6_4QC = 7,
+       ORC_CONV_CONT_2XB6 = 8, ORC_CONV_FINITE_2XB6 = 9 };
 #define ORC_IS_DC(s) ((s) == ORC_SYS_DC_PERMEX || (s) == ORC_SYS_DC_SERIES || (s) == ORC_SYS_DC_SHUNT || (s) == ORC_SYS_DC_EXTEX)
 enum { ORC_LOAD_CONST_SPEED = 0, ORC_LOAD_POLY_STATIC = 1 };
 enum { ORC_SOLVER_EULER = 0, ORC_SOLVER_RK4 = 1, ORC_SOLVER_DOPRI5 = 2, ORC_SOLVER_DP5_FIXED = 3 };
 
 #define ORC_MAX_ODE 8
-#define ORC_MAX_OUT 16
+#define ORC_MAX_OUT 24
 
 typedef struct orc_params {
     int32_t system, converter, load, solver, nsteps;
@@ -65,12 +66,12 @@ typedef struct orc_env {
     int32_t k;          /* PhysicalSystem._k */
     /* converter state (converters.py:40-43, 193-197) */
     double action_start;
-    double duty[5][2];        /* Cont: per sub-converter clipped duty (ContDynamicallyAveragedConverter.set_action:144-146) */
-    int32_t sw_state[5];      /* FiniteTwoQuadrantConverter._switching_state, NOT cleared by reset() (45-54) */
-    int32_t sw_pattern[5][2]; /* _switching_pattern */
-    int32_t sw_plen[5];
+    double duty[6][2];        /* Cont: per sub-converter clipped duty (ContDynamicallyAveragedConverter.set_action:144-146) */
+    int32_t sw_state[6];      /* FiniteTwoQuadrantConverter._switching_state, NOT cleared by reset() (45-54) */
+    int32_t sw_pattern[6][2]; /* _switching_pattern */
+    int32_t sw_plen[6];
     /* solver f_params */
-    double u[3];
+    double u[4];
     double dp_h; /* dopri5: predicted step size carried between integrate() calls (0 -> HINIT) */
     /* constants */
     double C[5][11];
@@ -89,6 +90,7 @@ static int n_ode(const orc_params *p) {
 static int n_out(const orc_params *p) {
     if (p->system == ORC_SYS_DC_EXTEX) return 7;  /* [omega, torque, i_a, i_e, u_a, u_e, u_sup] */
     if (p->system == ORC_SYS_EESM) return 16;     /* physical_systems.py:575-593 */
+    if (p->system == ORC_SYS_DFIM) return 24;     /* physical_systems.py:882-909 */
     return p->system == ORC_SYS_DC_SHUNT ? 6 : (ORC_IS_DC(p->system) ? 5 : 14);
 }
 
@@ -187,7 +189,9 @@ static void electrical_ode(const orc_params *p, const orc_env *e, const double *
         nf = 7; nr = 3;
     } else {
         f[0] = omega; f[1] = ms[0]; f[2] = ms[1]; f[3] = ms[2]; f[4] = ms[3]; f[5] = omega * ms[2]; f[6] = omega * ms[3];
-        f[7] = u[0]; f[8] = u[1]; f[9] = 0.0; f[10] = 0.0; /* SCIM: zero rotor voltage */
+        f[7] = u[0]; f[8] = u[1];
+        if (p->system == ORC_SYS_DFIM) { f[9] = u[2]; f[10] = u[3]; } /* doubly_fed_induction_motor.py: u_sr_alphabeta */
+        else { f[9] = 0.0; f[10] = 0.0; }                              /* SCIM: zero rotor voltage */
         nf = 11; nr = 5;
     }
     for (int r = 0; r < nr; ++r) {
@@ -475,6 +479,8 @@ static int conv_subs(const orc_params *p, int *kinds) {
         case ORC_CONV_FINITE_2X4QC: kinds[0] = kinds[1] = ORC_CONV_FINITE_4QC; return 2;
         case ORC_CONV_CONT_B6_4QC: kinds[0] = ORC_CONV_CONT_B6; kinds[1] = ORC_CONV_CONT_4QC; return 2;
         case ORC_CONV_FINITE_B6_4QC: kinds[0] = ORC_CONV_FINITE_B6; kinds[1] = ORC_CONV_FINITE_4QC; return 2;
+        case ORC_CONV_CONT_2XB6: kinds[0] = kinds[1] = ORC_CONV_CONT_B6; return 2;
+        case ORC_CONV_FINITE_2XB6: kinds[0] = kinds[1] = ORC_CONV_FINITE_B6; return 2;
         default: kinds[0] = p->converter; return 1;
     }
 }
@@ -648,6 +654,54 @@ static void simulate_scim(const orc_params *p, orc_env *e, const double *action,
     normalise(p, obs);
 }
 
+/* DoublyFedInductionMotorSystem, physical_systems.py:850-1113 (simulate 948-1029).  Rotor current from the states
+ * (calculate_rotor_current, 931-946). */
+static void dfim_rotor_current(const orc_params *p, const double *y, double *ir) {
+    double l_m = p->mp[1], l_r = p->mp[1] + p->mp[3];
+    ir[0] = 1 / l_r * y[3] - l_m / l_r * y[1];
+    ir[1] = 1 / l_r * y[4] - l_m / l_r * y[2];
+}
+static void simulate_dfim(const orc_params *p, orc_env *e, const double *action, double *obs) {
+    double seg_end[2], i_in[6], u_n[6], u_in[6] = {0}, u_sdq[2] = {0}, u_rdq[2] = {0}, u_sab[2], u_rab[2], ir[2];
+    double u_sup = p->u_sup;
+    double eps_field = atan2(e->y[4], e->y[3]), eps_el = e->y[5];
+    t_32(e->y + 1, i_in);
+    dfim_rotor_current(p, e->y, ir);
+    t_32(ir, i_in + 3);
+    int nseg = conv_set_action(p, e, action, e->t, seg_end);
+    double t0 = e->t;
+    for (int s = 0; s < nseg; ++s) {
+        conv_convert(p, e, i_in, e->t, u_n);
+        for (int l = 0; l < 6; ++l) u_in[l] = u_n[l] * u_sup;
+        abc_to_dq(u_in, eps_field, u_sdq);                 /* line 990 (only the last segment's value is reported) */
+        abc_to_dq(u_in + 3, eps_field - eps_el, u_rdq);    /* line 972 / 991 */
+        t_23(u_in, u_sab);
+        q_rot(u_rdq, eps_field, u_rab);                    /* dq_to_alphabeta_space(u_rdq, eps_field), line 974 / 993 */
+        e->u[0] = u_sab[0]; e->u[1] = u_sab[1]; e->u[2] = u_rab[0]; e->u[3] = u_rab[1];
+        integrate(p, e, s == nseg - 1 ? t0 + p->tau : seg_end[s]);
+        if (s < nseg - 1) {
+            eps_field = atan2(e->y[4], e->y[3]); eps_el = e->y[5];
+            t_32(e->y + 1, i_in);
+            dfim_rotor_current(p, e->y, ir);
+            t_32(ir, i_in + 3);
+        }
+    }
+    e->k += 1;
+    double torque = motor_torque(p, e->y + 1);
+    double i_sdq[2], i_sabc[3], i_rdq[2], i_rdef[3];
+    q_rot(e->y + 1, -eps_field, i_sdq);                    /* stale field angle, line 1003 */
+    dq_to_abc(i_sdq, eps_field, i_sabc);
+    dfim_rotor_current(p, e->y, ir);
+    q_rot(ir, -eps_field, i_rdq);                          /* line 1005 */
+    dq_to_abc(i_rdq, eps_field - eps_el, i_rdef);          /* stale eps_el, line 1006 */
+    obs[0] = e->y[0]; obs[1] = torque;
+    for (int l = 0; l < 3; ++l) { obs[2 + l] = i_sabc[l]; obs[7 + l] = i_rdef[l]; obs[12 + l] = u_in[l]; obs[17 + l] = u_in[3 + l]; }
+    obs[5] = i_sdq[0]; obs[6] = i_sdq[1]; obs[10] = i_rdq[0]; obs[11] = i_rdq[1];
+    obs[15] = u_sdq[0]; obs[16] = u_sdq[1]; obs[20] = u_rdq[0]; obs[21] = u_rdq[1];
+    obs[22] = wrap_eps(e->y[5]); obs[23] = u_sup;
+    normalise(p, obs);
+}
+
 /* ---------------------------------------------------------------- public API ------------------- */
 void orc_init(const orc_params *p, orc_env *e) {
     memset(e, 0, sizeof(*e));
@@ -661,7 +715,7 @@ void orc_reset(const orc_params *p, orc_env *e, double *obs) {
     for (int i = 0; i < n; ++i) e->y[i] = p->init[i];
     e->t = 0.0; e->k = 0;
     e->dp_h = 0.0; /* ode.set_initial_value() re-creates the integrator work array */
-    double u_n[4], u_abc[4], u_dq[2], i_abc[3], i_dq[2];
+    double u_n[6], u_abc[6], u_dq[2], i_abc[3], i_dq[2];
     double u_sup = p->u_sup;
     conv_reset(p, e, u_n);
     double torque = motor_torque(p, e->y + 1);
@@ -683,6 +737,23 @@ void orc_reset(const orc_params *p, orc_env *e, double *obs) {
          * (lines 679-690); with the converter's reset voltages (u_e = 0, u_sd ~ u_sq ~ 0) this is invisible */
         obs[8] = u_abc[0]; obs[9] = u_abc[1]; obs[10] = u_abc[2]; obs[11] = u_abc[3]; obs[12] = u_dq[0]; obs[13] = u_dq[1];
         obs[14] = eps; obs[15] = u_sup;
+    } else if (p->system == ORC_SYS_DFIM) { /* physical_systems.py:1031-1113 */
+        double eps_el = e->y[5], eps_field = atan2(e->y[4], e->y[3]), ir[2], i_rdq[2], i_rdef[3], u_rdq[2];
+        if (eps_el > M_PI) eps_el -= 2.0 * M_PI;
+        if (eps_field > M_PI) eps_field -= 2.0 * M_PI;
+        for (int l = 0; l < 6; ++l) u_abc[l] = u_n[l] * u_sup;
+        abc_to_dq(u_abc, eps_field, u_dq);
+        abc_to_dq(u_abc + 3, eps_field - eps_el, u_rdq);
+        q_rot(e->y + 1, -eps_field, i_dq);
+        dq_to_abc(i_dq, eps_field, i_abc);
+        dfim_rotor_current(p, e->y, ir);
+        q_rot(ir, -(eps_field - eps_el), i_rdq);           /* reset uses eps_field - eps_el here (line 1084), simulate eps_field */
+        dq_to_abc(i_rdq, eps_field - eps_el, i_rdef);
+        obs[0] = e->y[0]; obs[1] = torque;
+        for (int l = 0; l < 3; ++l) { obs[2 + l] = i_abc[l]; obs[7 + l] = i_rdef[l]; obs[12 + l] = u_abc[l]; obs[17 + l] = u_abc[3 + l]; }
+        obs[5] = i_dq[0]; obs[6] = i_dq[1]; obs[10] = i_rdq[0]; obs[11] = i_rdq[1];
+        obs[15] = u_dq[0]; obs[16] = u_dq[1]; obs[20] = u_rdq[0]; obs[21] = u_rdq[1];
+        obs[22] = eps_el; obs[23] = u_sup;
     } else if (p->system == ORC_SYS_PMSM) {
         double eps = e->y[3];
         if (eps > M_PI) eps -= 2.0 * M_PI;
@@ -711,6 +782,7 @@ void orc_step(const orc_params *p, orc_env *e, const double *action, double *obs
     if (ORC_IS_DC(p->system)) simulate_dc(p, e, action, obs);
     else if (p->system == ORC_SYS_PMSM) simulate_pmsm(p, e, action, obs);
     else if (p->system == ORC_SYS_EESM) simulate_eesm(p, e, action, obs);
+    else if (p->system == ORC_SYS_DFIM) simulate_dfim(p, e, action, obs);
     else simulate_scim(p, e, action, obs);
 }
 

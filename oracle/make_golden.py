@@ -61,9 +61,11 @@ def gen_actions(space_kind, K, seed, mode):
         shape, disc = (K, 2), False
     elif space_kind == "box4":
         shape, disc = (K, 4), False
+    elif space_kind == "box6":
+        shape, disc = (K, 6), False
     elif space_kind in ("disc8", "disc4"):
         shape, disc = (K,), True
-    elif space_kind in ("mdisc44", "mdisc84"):  # MultiDiscrete of a FiniteMultiConverter (converters.py:546)
+    elif space_kind in ("mdisc44", "mdisc84", "mdisc88"):  # MultiDiscrete of a FiniteMultiConverter (converters.py:546)
         shape, disc = (K, 2), True
     else:
         raise KeyError(space_kind)
@@ -296,11 +298,14 @@ def converter_kats():
 
 
 def main(only=None):
-    """`only`: optional set of groups to (re)generate -- {"multi"}; default: everything."""
+    """`only`: optional set of groups to (re)generate -- {"multi", "dfim"}; default: everything."""
     os.makedirs(OUT, exist_ok=True)
     if not only:
         main_base()
-    main_multi(only)
+    if not only or "multi" in only:
+        main_multi()
+    if not only or "dfim" in only:
+        main_dfim()
 
 
 def main_base():
@@ -374,7 +379,7 @@ def main_base():
     run_case("shunt_cont_epi_held_euler", "Cont-CC-ShuntDc-v0", "euler", K, 1253, "held", True, "box1")
 
 
-def main_multi(only=None):
+def main_multi():
     """Multi-converter systems: ExtExDc = 2 x 4QC, EESM = B6 + 4QC."""
     K = 2000
     xc, xf = "Cont-CC-ExtExDc-v0", "Finite-CC-ExtExDc-v0"
@@ -405,6 +410,26 @@ def main_multi(only=None):
     run_case("eesm_cont_epi_held_euler", "Cont-CC-EESM-v0", "euler", 4000, 1274, "held", True, "box4")
     run_case("eesm_fin_epi_held_tau1e-4_euler", "Finite-CC-EESM-v0", "euler", 4000, 1275, "held", True, "mdisc84", tau=1e-4)
     run_case("eesm_fin_free_uniform_euler", "Finite-CC-EESM-v0", "euler", K, 1276, "uniform", False, "mdisc84")
+
+
+def main_dfim():
+    """Doubly fed induction motor: MultiConverter of two B6 bridges (stator, rotor), 24 system states."""
+    K = 2000
+    for solver in ("euler", "dopri5"):
+        run_case(f"dfim_cont_free_held_{solver}", "Cont-CC-DFIM-v0", solver, K, 1280, "held", False, "box6")
+        run_case(f"dfim_cont_sc_free_held_{solver}", "Cont-SC-DFIM-v0", solver, K, 1281, "held", False, "box6")
+        run_case(f"dfim_fin_free_held_{solver}", "Finite-CC-DFIM-v0", solver, K, 1282, "held", False, "mdisc88")
+    run_case("dfim_cont_free_uniform_euler", "Cont-CC-DFIM-v0", "euler", K, 1283, "uniform", False, "box6")
+    run_case("dfim_cont_sc_epi_held_euler", "Cont-SC-DFIM-v0", "euler", K, 1284, "held", True, "box6")
+    run_case("dfim_fin_epi_held_tau1e-4_euler", "Finite-CC-DFIM-v0", "euler", 4000, 1285, "held", True, "mdisc88", tau=1e-4)
+    run_case("dfim_fin_sc_free_uniform_euler", "Finite-SC-DFIM-v0", "euler", K, 1286, "uniform", False, "mdisc88")
+    b6til = lambda cls, til: [cls(interlocking_time=til), cls(interlocking_time=til)]  # noqa: E731
+    run_case("dfim_fin_free_uniform_til_euler", "Finite-CC-DFIM-v0", "euler", K, 1287, "uniform", False, "mdisc88",
+             converter=ps.FiniteMultiConverter(subconverters=b6til(ps.FiniteB6BridgeConverter, 1e-6)))
+    run_case("dfim_fin_free_held_til_dopri5", "Finite-CC-DFIM-v0", "dopri5", K, 1288, "held", False, "mdisc88",
+             converter=ps.FiniteMultiConverter(subconverters=b6til(ps.FiniteB6BridgeConverter, 1e-6)))
+    run_case("dfim_cont_free_held_til_euler", "Cont-CC-DFIM-v0", "euler", K, 1289, "held", False, "box6",
+             converter=ps.ContMultiConverter(subconverters=b6til(ps.ContB6BridgeConverter, 2e-6)))
 
 
 if __name__ == "__main__":

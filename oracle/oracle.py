@@ -13,13 +13,13 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgemx_oracle.so")
 
-SYS_DC, SYS_PMSM, SYS_SCIM, SYS_DC_SERIES, SYS_DC_SHUNT, SYS_DC_EXTEX, SYS_EESM = 0, 1, 2, 3, 4, 5, 6
+SYS_DC, SYS_PMSM, SYS_SCIM, SYS_DC_SERIES, SYS_DC_SHUNT, SYS_DC_EXTEX, SYS_EESM, SYS_DFIM = 0, 1, 2, 3, 4, 5, 6, 7
 CONV_C4QC, CONV_FB6, CONV_CB6, CONV_F4QC = 0, 1, 2, 3
-CONV_C2X4QC, CONV_F2X4QC, CONV_CB6_4QC, CONV_FB6_4QC = 4, 5, 6, 7  # Cont/FiniteMultiConverter of two sub-converters
+CONV_C2X4QC, CONV_F2X4QC, CONV_CB6_4QC, CONV_FB6_4QC, CONV_C2XB6, CONV_F2XB6 = 4, 5, 6, 7, 8, 9  # Cont/FiniteMultiConverter of two sub-converters
 LOAD_CONST, LOAD_POLY = 0, 1
 SOLVER_EULER, SOLVER_RK4, SOLVER_DOPRI5, SOLVER_DP5_FIXED = 0, 1, 2, 3
 
-MAX_ODE, MAX_OUT = 8, 16
+MAX_ODE, MAX_OUT = 8, 24
 
 
 class OrcParams(C.Structure):
@@ -60,14 +60,16 @@ def lib():
 
 
 _SYS = {"DcMotorSystem": SYS_DC, "SynchronousMotorSystem": SYS_PMSM, "SquirrelCageInductionMotorSystem": SYS_SCIM,
-        "ExternallyExcitedSynchronousMotorSystem": SYS_EESM}
+        "ExternallyExcitedSynchronousMotorSystem": SYS_EESM, "DoublyFedInductionMotorSystem": SYS_DFIM}
 _CONV = {"ContFourQuadrantConverter": CONV_C4QC, "FiniteB6BridgeConverter": CONV_FB6, "ContB6BridgeConverter": CONV_CB6,
          "FiniteFourQuadrantConverter": CONV_F4QC,
          # multi converters: make_golden.describe() appends the sub-converter class names
          "ContMultiConverter[ContFourQuadrantConverter,ContFourQuadrantConverter]": CONV_C2X4QC,
          "FiniteMultiConverter[FiniteFourQuadrantConverter,FiniteFourQuadrantConverter]": CONV_F2X4QC,
          "ContMultiConverter[ContB6BridgeConverter,ContFourQuadrantConverter]": CONV_CB6_4QC,
-         "FiniteMultiConverter[FiniteB6BridgeConverter,FiniteFourQuadrantConverter]": CONV_FB6_4QC}
+         "FiniteMultiConverter[FiniteB6BridgeConverter,FiniteFourQuadrantConverter]": CONV_FB6_4QC,
+         "ContMultiConverter[ContB6BridgeConverter,ContB6BridgeConverter]": CONV_C2XB6,
+         "FiniteMultiConverter[FiniteB6BridgeConverter,FiniteB6BridgeConverter]": CONV_F2XB6}
 _DC_MOTOR_SYS = {"DcPermanentlyExcitedMotor": SYS_DC, "DcSeriesMotor": SYS_DC_SERIES, "DcShuntMotor": SYS_DC_SHUNT,
                  "DcExternallyExcitedMotor": SYS_DC_EXTEX}
 _LOAD = {"ConstantSpeedLoad": LOAD_CONST, "PolynomialStaticLoad": LOAD_POLY}
@@ -77,7 +79,8 @@ _MP_KEYS = {SYS_DC: ("r_a", "l_a", "psi_e"), SYS_PMSM: ("p", "l_d", "l_q", "r_s"
             SYS_SCIM: ("p", "l_m", "l_sigs", "l_sigr", "r_s", "r_r"),
             SYS_DC_SERIES: ("r_a", "r_e", "l_a", "l_e", "l_e_prime"), SYS_DC_SHUNT: ("r_a", "r_e", "l_a", "l_e", "l_e_prime"),
             SYS_DC_EXTEX: ("r_a", "r_e", "l_a", "l_e", "l_e_prime"),
-            SYS_EESM: ("p", "l_d", "l_q", "l_m", "l_e", "r_s", "r_e", "k")}
+            SYS_EESM: ("p", "l_d", "l_q", "l_m", "l_e", "r_s", "r_e", "k"),
+            SYS_DFIM: ("p", "l_m", "l_sigs", "l_sigr", "r_s", "r_r")}
 
 
 def default_masks(meta):
@@ -132,6 +135,11 @@ class OracleEnv:
         self.n_ode = self.L.orc_n_ode(C.byref(self.p))
         self.n_act = self.L.orc_n_act(C.byref(self.p))
 
+    @property
+    def y(self):
+        """ODE state [omega, motor states...] (a view into the C struct: orc_env starts with `double y[8]`)."""
+        return np.frombuffer(self._env, dtype=np.float64, count=MAX_ODE)
+
     def reset(self):
         obs = np.zeros(self.n_out)
         self.L.orc_reset(C.byref(self.p), self._env, obs.ctypes.data_as(C.c_void_p))
@@ -170,7 +178,7 @@ class OracleEnv:
         return nseg, volt
 
     def kat_converter_reset(self):
-        u = np.zeros(4)
+        u = np.zeros(6)
         self.L.orc_kat_converter_reset(C.byref(self.p), self._env, u.ctypes.data_as(C.c_void_p))
         return u
 
@@ -178,6 +186,29 @@ class OracleEnv:
         Cm = np.zeros((5, 11))
         self.L.orc_model_constants(C.byref(self.p), Cm.ctypes.data_as(C.c_void_p))
         return Cm
+
+
+def undefined_field_angle_steps(params, actions, auto_reset=True, flux_floor=1e-9):
+    """Induction-motor systems report dq quantities in the rotor-flux frame, eps_field = arctan2(psi_rbeta, psi_ralpha)
+    (physical_systems.py:765-769 / 918-929).  While the rotor flux is still (numerically) zero -- the first steps after a
+    reset -- the reference's angle is the arctan2 of matmul rounding noise (~1e-17 Wb), which no restatement can reproduce.
+    Returns a bool mask [K]: True where the flux magnitude at the START of step k is below `flux_floor` [Wb], i.e. where the
+    dq columns of step k are not comparable (everything else, including |i_dq| and the done mask, is)."""
+    a = np.asarray(actions, dtype=np.float64).reshape(len(actions), -1)
+    env = OracleEnv(params)
+    env.reset()
+    mask = np.zeros(len(a), dtype=bool)
+    if params.system not in (SYS_SCIM, SYS_DFIM):
+        return mask
+    for k in range(len(a)):
+        mask[k] = np.hypot(env.y[3], env.y[4]) < flux_floor
+        obs = env.step(a[k])
+        if auto_reset and env.done(obs):
+            env.reset()
+    return mask
+
+
+DQ_COLUMNS = ("i_sd", "i_sq", "i_rd", "i_rq", "u_sd", "u_sq", "u_rd", "u_rq")
 
 
 def rollout_many(params, actions, auto_reset=True):

@@ -32,8 +32,14 @@ def test_oracle_reproduces_reference_trajectory(name):
     assert np.abs(r - d["reset_state"]).max() < 1e-14
     obs, done = env.rollout(d["actions"], auto_reset=True)
     ref = d["states"]
-    err = (np.abs(obs[d["state_index"]] - ref) / np.maximum(1.0, np.abs(ref))).max()  # states reach 20x the limits in free runs
-    assert err < 1e-9, err  # observed <= 1e-12 except Cont-SC-SynRM (tiny inertia: rounding amplified to 4e-10)
+    diff = np.abs(obs[d["state_index"]] - ref) / np.maximum(1.0, np.abs(ref))  # states reach 20x the limits in free runs
+    if meta["system"] == "DoublyFedInductionMotorSystem":
+        # dq columns of steps that start with zero rotor flux: the reference's field angle is arctan2(rounding noise)
+        bad = orc.undefined_field_angle_steps(orc.params_from_meta(meta), d["actions"])[d["state_index"]]
+        assert bad.sum() <= 2 * (1 + d["terminated"].sum())  # only the first two steps of an episode can be affected
+        cols = [meta["state_names"].index(c) for c in orc.DQ_COLUMNS if c in meta["state_names"]]
+        diff[np.ix_(bad, cols)] = 0.0
+    assert diff.max() < 1e-9, diff.max()  # observed <= 1e-12 except Cont-SC-SynRM (tiny inertia: rounding amplified to 4e-10)
     assert np.array_equal(done, d["terminated"])
 
 
@@ -73,7 +79,7 @@ def test_fixed_step_rk4_close_to_reference_default_solver(name):
 
 def test_model_constants_and_limits_match_reference():
     for name in ("permexdc_free_held_euler", "pmsm_free_held_euler", "scim_free_held_euler", "series_cont_free_held_euler",
-                 "shunt_cont_free_held_euler", "extex_cont_free_held_euler", "eesm_cont_free_held_euler"):
+                 "shunt_cont_free_held_euler", "extex_cont_free_held_euler", "eesm_cont_free_held_euler", "dfim_cont_free_held_euler"):
         d, meta = orc.load_golden(name)
         env = orc.OracleEnv(orc.params_from_meta(meta))
         ref = np.asarray(meta["model_constants"])
