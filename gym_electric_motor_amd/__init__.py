@@ -13,6 +13,7 @@ from .components import (  # noqa: F401
     DcPermanentlyExcitedMotor,
     DcSeriesMotor,
     DcShuntMotor,
+    DoublyFedInductionMotor,
     DormandPrince5Solver,
     EulerSolver,
     ExternallyExcitedSynchronousMotor,
@@ -29,6 +30,7 @@ from .components import (  # noqa: F401
 from .envs import BatchedElectricMotorEnv, make  # noqa: F401
 from .physical_systems import (  # noqa: F401
     BatchedDcMotorSystem,
+    BatchedDoublyFedInductionMotorSystem,
     BatchedExternallyExcitedSynchronousMotorSystem,
     BatchedSCMLSystem,
     BatchedSquirrelCageInductionMotorSystem,

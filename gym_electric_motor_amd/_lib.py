@@ -5,12 +5,12 @@ import os
 
 from . import build as _build
 
-MAX_ODE, MAX_OUT, MODEL_ROWS, MODEL_COLS = 8, 16, 5, 11
-ABI_VERSION = 1
+MAX_ODE, MAX_OUT, MODEL_ROWS, MODEL_COLS = 8, 24, 5, 11
+ABI_VERSION = 2
 
-SYS_DC_PERMEX, SYS_SYNC, SYS_SCIM, SYS_DC_SERIES, SYS_DC_SHUNT, SYS_DC_EXTEX, SYS_EESM = 0, 1, 2, 3, 4, 5, 6
+SYS_DC_PERMEX, SYS_SYNC, SYS_SCIM, SYS_DC_SERIES, SYS_DC_SHUNT, SYS_DC_EXTEX, SYS_EESM, SYS_DFIM = 0, 1, 2, 3, 4, 5, 6, 7
 CONV_CONT_4QC, CONV_FINITE_B6, CONV_CONT_B6, CONV_FINITE_4QC = 0, 1, 2, 3
-CONV_CONT_2X4QC, CONV_FINITE_2X4QC, CONV_CONT_B6_4QC, CONV_FINITE_B6_4QC = 4, 5, 6, 7
+CONV_CONT_2X4QC, CONV_FINITE_2X4QC, CONV_CONT_B6_4QC, CONV_FINITE_B6_4QC, CONV_CONT_2XB6, CONV_FINITE_2XB6 = 4, 5, 6, 7, 8, 9
 LOAD_CONST_SPEED, LOAD_POLY_STATIC = 0, 1
 SOLVER_EULER, SOLVER_RK4, SOLVER_DP5 = 0, 1, 2
 F32, F64 = 0, 1
@@ -44,7 +44,7 @@ _lib = None
 
 EXPORTS = (
     "gemx_abi_version", "gemx_sizeof_config", "gemx_last_error", "gemx_device_count", "gemx_create", "gemx_destroy",
-    "gemx_n_envs", "gemx_n_ode", "gemx_n_out", "gemx_n_action", "gemx_action_itemsize", "gemx_reset_observation",
+    "gemx_n_envs", "gemx_n_ode", "gemx_n_out", "gemx_n_action", "gemx_action_itemsize", "gemx_n_switch_bytes", "gemx_reset_observation",
     "gemx_reset", "gemx_step", "gemx_rollout", "gemx_get_state", "gemx_set_state", "gemx_get_switch_state",
     "gemx_set_switch_state", "gemx_set_steps_per_block", "gemx_last_launch", "gemx_error_flags",
 )

@@ -604,6 +604,43 @@ class SquirrelCageInductionMotor(_ThreePhaseMotor):
         return vals if len(vals) == 5 else [0.0] * 5
 
 
+class DoublyFedInductionMotor(SquirrelCageInductionMotor):
+    """electric_motors/doubly_fed_induction_motor.py:8-240 over induction_motor.py: same model matrix as the SCIM
+    (InductionMotor._update_model, induction_motor.py:287-312) with a live rotor voltage; defaults lines 85-110
+    (DOI 10.1016/j.jestch.2016.01.015)."""
+
+    ROTOR_VOLTAGES = ["u_ralpha", "u_rbeta"]
+    ROTOR_CURRENTS = ["i_ralpha", "i_rbeta"]
+    IO_ROTOR_VOLTAGES = ["u_ra", "u_rb", "u_rc", "u_rd", "u_rq"]
+    IO_ROTOR_CURRENTS = ["i_ra", "i_rb", "i_rc", "i_rd", "i_rq"]
+    IO_VOLTAGES = SquirrelCageInductionMotor.IO_VOLTAGES + IO_ROTOR_VOLTAGES
+    IO_CURRENTS = SquirrelCageInductionMotor.IO_CURRENTS + IO_ROTOR_CURRENTS
+    _default_motor_parameter = {"p": 2, "l_m": 297.5e-3, "l_sigs": 25.71e-3, "l_sigr": 25.71e-3, "j_rotor": 13.695e-3,
+                                "r_s": 4.42, "r_r": 3.51}
+    _default_limits = dict(omega=1800 * np.pi / 30, torque=0.0, i=9, epsilon=math.pi, u=720)
+    _default_nominal_values = dict(omega=1650 * np.pi / 30, torque=0.0, i=7.5, epsilon=math.pi, u=720)
+
+    def _three_phase_limits(self):
+        """doubly_fed_induction_motor.py:119-141: like the SCIM, over stator AND rotor quantities, with r_r as the fallback."""
+        voltage_limit = 0.5 * self._limits["u"]
+        voltage_nominal = 0.5 * self._nominal_values["u"]
+        limits_agenda, nominal_agenda = {}, {}
+        r_r = self._motor_parameter["r_r"]
+        for u, i in zip(self.IO_VOLTAGES + self.ROTOR_VOLTAGES, self.IO_CURRENTS + self.ROTOR_CURRENTS):
+            limits_agenda[u] = voltage_limit
+            nominal_agenda[u] = voltage_nominal
+            limits_agenda[i] = self._limits.get("i", None) or self._limits[u] / r_r
+            nominal_agenda[i] = self._nominal_values.get("i", None) or self._nominal_values[u] / r_r
+        self._update_limits(limits_agenda, nominal_agenda)
+        self._update_limits(dict(torque=self._torque_limit()))
+
+    def rotor_current_coefficients(self):
+        """calculate_rotor_current (physical_systems.py:931-946): i_r = psi_r / l_r - l_m / l_r * i_s."""
+        mp = self._motor_parameter
+        l_r = mp["l_m"] + mp["l_sigr"]
+        return [1 / l_r, mp["l_m"] / l_r]
+
+
 # ------------------------------------------------------------------------------------------------- loads
 class _MechanicalLoad:
     """mechanical_loads/mechanical_load.py:9-236 (bookkeeping only)."""

@@ -70,6 +70,9 @@ static const int SYNC_IDX[][2] = {{0, 1}, {0, 3}, {0, 6}, {1, 0}, {1, 2}, {1, 4}
 static const int SCIM_IDX[][2] = {{0, 1}, {0, 3}, {0, 6}, {0, 7}, {1, 2}, {1, 4}, {1, 5}, {1, 8},
                                   {2, 1}, {2, 3}, {2, 6}, {3, 2}, {3, 4}, {3, 5}};
 
+static const int DFIM_IDX[][2] = {{0, 1}, {0, 3}, {0, 6}, {0, 7}, {1, 2}, {1, 4}, {1, 5}, {1, 8}, {2, 1}, {2, 3},
+                                  {2, 6}, {3, 2}, {3, 4}, {3, 5}, {0, 9}, {1, 10}, {2, 9}, {3, 10}};
+
 static int pack_model(const gemx_config &c, double *m, double *pole) {
     const int(*idx)[2];
     int n, pole_row, rows, cols;
@@ -80,6 +83,7 @@ static int pack_model(const gemx_config &c, double *m, double *pole) {
         case GEMX_SYS_EESM: idx = EESM_IDX; n = 14; pole_row = 3; rows = 4; cols = 10; break;
         case GEMX_SYS_SYNC: idx = SYNC_IDX; n = 7; pole_row = 2; rows = 3; cols = 7; break;
         case GEMX_SYS_SCIM: idx = SCIM_IDX; n = 14; pole_row = 4; rows = 5; cols = 9; break;  // u_r columns: zero rotor voltage
+        case GEMX_SYS_DFIM: idx = DFIM_IDX; n = 18; pole_row = 4; rows = 5; cols = 11; break;
         default: return fail(GEMX_ERR_ARG, "unknown system_kind %d", c.system_kind);
     }
     bool used[GEMX_MODEL_ROWS][GEMX_MODEL_COLS] = {};
@@ -104,9 +108,11 @@ static int pack_model(const gemx_config &c, double *m, double *pole) {
 template <class R> static void fill_params(const gemx_handle &h, const double *m, double pole, DevParams<R> &P) {
     const gemx_config &c = h.cfg;
     memset(&P, 0, sizeof(P));
-    for (int i = 0; i < 16; ++i) P.m[i] = (R)m[i];
+    for (int i = 0; i < 20; ++i) P.m[i] = (R)m[i];
     P.tc0 = (R)c.torque_coef[0];
     P.tc1 = (R)c.torque_coef[1];
+    P.tc2 = (R)c.torque_coef[2];
+    P.tc3 = (R)c.torque_coef[3];
     P.pole = (R)pole;
     P.inv_j = (R)(c.j_total > 0 ? 1.0 / c.j_total : 0.0);
     P.la = (R)c.load_a; P.lb = (R)c.load_b; P.lc = (R)c.load_c;
@@ -178,6 +184,24 @@ static void host_reset_obs(gemx_handle &h, const double *m) {
         o[8] = uabc[0]; o[9] = uabc[1]; o[10] = uabc[2]; o[11] = 0.0 * us;
         o[12] = cs * uab[0] + sn * uab[1]; o[13] = -sn * uab[0] + cs * uab[1];
         o[14] = eps; o[15] = us;
+    } else if (c.system_kind == GEMX_SYS_DFIM) {  // physical_systems.py:1031-1113
+        double uabc[3] = {-0.5 * us, -0.5 * us, -0.5 * us}, uab[2], isabc[3], irdef[3];
+        T23(uabc, uab);
+        double eps_el = y[5], eps_f = atan2(y[4], y[3]);
+        if (eps_el > kPi) eps_el -= kTwoPi;
+        if (eps_f > kPi) eps_f -= kTwoPi;
+        const double cf = cos(eps_f), sf = sin(eps_f), cd = cos(eps_f - eps_el), sd = sin(eps_f - eps_el);
+        const double ira = c.torque_coef[2] * y[3] - c.torque_coef[3] * y[1], irb = c.torque_coef[2] * y[4] - c.torque_coef[3] * y[2];
+        const double isd = cf * y[1] + sf * y[2], isq = -sf * y[1] + cf * y[2];
+        const double ird = cd * ira + sd * irb, irq = -sd * ira + cd * irb;  // reset() rotates by eps_field - eps_el (line 1084)
+        T32(y[1], y[2], isabc);
+        T32(cd * ird - sd * irq, sd * ird + cd * irq, irdef);
+        o[0] = y[0]; o[1] = c.torque_coef[0] * (y[3] * y[2] - y[4] * y[1]);
+        for (int l = 0; l < 3; ++l) { o[2 + l] = isabc[l]; o[7 + l] = irdef[l]; o[12 + l] = uabc[l]; o[17 + l] = uabc[l]; }
+        o[5] = isd; o[6] = isq; o[10] = ird; o[11] = irq;
+        o[15] = cf * uab[0] + sf * uab[1]; o[16] = -sf * uab[0] + cf * uab[1];
+        o[20] = cd * uab[0] + sd * uab[1]; o[21] = -sd * uab[0] + cd * uab[1];
+        o[22] = eps_el; o[23] = us;
     } else {
         double uabc[3] = {-0.5 * us, -0.5 * us, -0.5 * us}, uab[2], iabc[3], idq[2], udq[2], eps, torque, cs, sn;
         T23(uabc, uab);
@@ -229,6 +253,8 @@ GEMX_DECL_UNIT(5, 4, 0) GEMX_DECL_UNIT(5, 4, 1)
 GEMX_DECL_UNIT(5, 5, 0) GEMX_DECL_UNIT(5, 5, 1)
 GEMX_DECL_UNIT(6, 6, 0) GEMX_DECL_UNIT(6, 6, 1)
 GEMX_DECL_UNIT(6, 7, 0) GEMX_DECL_UNIT(6, 7, 1)
+GEMX_DECL_UNIT(7, 8, 0) GEMX_DECL_UNIT(7, 8, 1)
+GEMX_DECL_UNIT(7, 9, 0) GEMX_DECL_UNIT(7, 9, 1)
 #undef GEMX_DECL_UNIT
 }  // namespace gemx
 
@@ -240,7 +266,7 @@ static int launch_advance(gemx_handle *h, const void *actions, int K, void *obs,
                  : gemx::launch_unit_##S##_##C##_0(h, actions, K, obs, done, obs_every, st);
     GEMX_UNIT(0, 0) GEMX_UNIT(1, 1) GEMX_UNIT(1, 2) GEMX_UNIT(2, 1) GEMX_UNIT(2, 2)
     GEMX_UNIT(0, 3) GEMX_UNIT(3, 0) GEMX_UNIT(3, 3) GEMX_UNIT(4, 0) GEMX_UNIT(4, 3)
-    GEMX_UNIT(5, 4) GEMX_UNIT(5, 5) GEMX_UNIT(6, 6) GEMX_UNIT(6, 7)
+    GEMX_UNIT(5, 4) GEMX_UNIT(5, 5) GEMX_UNIT(6, 6) GEMX_UNIT(6, 7) GEMX_UNIT(7, 8) GEMX_UNIT(7, 9)
 #undef GEMX_UNIT
     return fail(GEMX_ERR_ARG, "unsupported system/converter combination %d/%d", s, c);
 }
@@ -281,7 +307,8 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
     const bool combo = (dc_sys && (c == GEMX_CONV_CONT_4QC || c == GEMX_CONV_FINITE_4QC)) ||
                        ((s == GEMX_SYS_SYNC || s == GEMX_SYS_SCIM) && (c == GEMX_CONV_FINITE_B6 || c == GEMX_CONV_CONT_B6)) ||
                        (s == GEMX_SYS_DC_EXTEX && (c == GEMX_CONV_CONT_2X4QC || c == GEMX_CONV_FINITE_2X4QC)) ||
-                       (s == GEMX_SYS_EESM && (c == GEMX_CONV_CONT_B6_4QC || c == GEMX_CONV_FINITE_B6_4QC));
+                       (s == GEMX_SYS_EESM && (c == GEMX_CONV_CONT_B6_4QC || c == GEMX_CONV_FINITE_B6_4QC)) ||
+                       (s == GEMX_SYS_DFIM && (c == GEMX_CONV_CONT_2XB6 || c == GEMX_CONV_FINITE_2XB6));
     if (!combo) return fail(GEMX_ERR_ARG, "unsupported system/converter combination %d/%d", s, c);
     if (s == GEMX_SYS_EESM && cfg->interlocking_time > 0)
         return fail(GEMX_ERR_ARG, "interlocking_time > 0 is not supported for the EESM system (the reference's dead-time branch, "
@@ -298,15 +325,17 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         case GEMX_SYS_DC_EXTEX: h->nd = 3; h->nout = 7; break;
         case GEMX_SYS_SYNC: h->nd = 3; h->nout = 14; break;
         case GEMX_SYS_EESM: h->nd = 4; h->nout = 16; break;
+        case GEMX_SYS_DFIM: h->nd = 5; h->nout = 24; break;
         default: h->nd = 5; h->nout = 14; break;
     }
     h->has_angle = !(dc_sys || s == GEMX_SYS_DC_EXTEX);
-    h->nact = c == GEMX_CONV_CONT_B6 ? 3 : (c == GEMX_CONV_CONT_2X4QC ? 2 : (c == GEMX_CONV_CONT_B6_4QC ? 4 : 1));
+    h->nact = c == GEMX_CONV_CONT_B6 ? 3 : (c == GEMX_CONV_CONT_2X4QC ? 2 : (c == GEMX_CONV_CONT_B6_4QC ? 4 : (c == GEMX_CONV_CONT_2XB6 ? 6 : 1)));
+    h->sw_rows = c == GEMX_CONV_FINITE_2XB6 ? 2 : 1;
     for (int i = 0; i < h->nout; ++i)
         if (!(cfg->limits[i] > 0)) { delete h; return fail(GEMX_ERR_ARG, "limits[%d] must be positive", i); }
     if ((cfg->limit_mask | cfg->squared_mask) >> h->nout) { delete h; return fail(GEMX_ERR_ARG, "constraint mask has bits beyond S_out=%d", h->nout); }
 
-    double m[16] = {0}, pole = 0;
+    double m[20] = {0}, pole = 0;
     int rc = pack_model(*cfg, m, &pole);
     if (rc != GEMX_OK) { delete h; return rc; }
 
@@ -337,7 +366,7 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
     if (hipMalloc(&h->state, es * h->nd * (size_t)h->n) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(state) failed"));
     if (h->has_angle && hipMalloc(&h->angle, (cfg->dtype == GEMX_F64 ? 8 : 4) * (size_t)h->n) != hipSuccess)
         return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(angle) failed"));
-    if (hipMalloc((void **)&h->sw, (size_t)h->n) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(sw) failed"));
+    if (hipMalloc((void **)&h->sw, (size_t)h->n * h->sw_rows) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(sw) failed"));
     if (hipMalloc((void **)&h->err, sizeof(uint32_t)) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(err) failed"));
     if (hipMalloc(&h->reset_obs_dev, es * GEMX_MAX_OUT) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(reset_obs) failed"));
     if (hipMalloc(&h->cw_dev, es * 2 * GEMX_MAX_OUT) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(cw) failed"));
@@ -356,7 +385,7 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
     }
     fill_params<float>(*h, m, pole, h->pf);
     fill_params<double>(*h, m, pole, h->pd);
-    if (hipMemset(h->sw, 0, (size_t)h->n) != hipSuccess || hipMemset(h->err, 0, sizeof(uint32_t)) != hipSuccess)
+    if (hipMemset(h->sw, 0, (size_t)h->n * h->sw_rows) != hipSuccess || hipMemset(h->err, 0, sizeof(uint32_t)) != hipSuccess)
         return cleanup(fail(GEMX_ERR_DEVICE, "hipMemset failed"));
     if (cfg->dtype == GEMX_F64) {
         if (hipMemcpy(h->reset_obs_dev, h->reset_obs, sizeof(double) * GEMX_MAX_OUT, hipMemcpyHostToDevice) != hipSuccess)
@@ -398,9 +427,11 @@ int gemx_n_action(const gemx_handle *h) { return h ? h->nact : GEMX_ERR_ARG; }
 int gemx_action_itemsize(const gemx_handle *h) {
     if (!h) return GEMX_ERR_ARG;
     const int c = h->cfg.converter_kind;
-    const bool discrete = c == GEMX_CONV_FINITE_B6 || c == GEMX_CONV_FINITE_4QC || c == GEMX_CONV_FINITE_2X4QC || c == GEMX_CONV_FINITE_B6_4QC;
+    const bool discrete = c == GEMX_CONV_FINITE_B6 || c == GEMX_CONV_FINITE_4QC || c == GEMX_CONV_FINITE_2X4QC || c == GEMX_CONV_FINITE_B6_4QC ||
+                          c == GEMX_CONV_FINITE_2XB6;
     return discrete ? 1 : elem_size(h);
 }
+int gemx_n_switch_bytes(const gemx_handle *h) { return h ? h->sw_rows : GEMX_ERR_ARG; }
 int gemx_reset_observation(const gemx_handle *h, double *obs_host) {
     if (!h || !obs_host) return fail(GEMX_ERR_ARG, "null argument");
     memcpy(obs_host, h->reset_obs, sizeof(double) * h->nout);
@@ -455,12 +486,12 @@ int gemx_set_state(gemx_handle *h, const void *soa_in_dev, void *stream) {
 }
 int gemx_get_switch_state(gemx_handle *h, uint8_t *out_dev, void *stream) {
     if (!h || !out_dev) return fail(GEMX_ERR_ARG, "null argument");
-    HIP_TRY(hipMemcpyAsync(out_dev, h->sw, (size_t)h->n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(out_dev, h->sw, (size_t)h->n * h->sw_rows, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return GEMX_OK;
 }
 int gemx_set_switch_state(gemx_handle *h, const uint8_t *in_dev, void *stream) {
     if (!h || !in_dev) return fail(GEMX_ERR_ARG, "null argument");
-    HIP_TRY(hipMemcpyAsync(h->sw, in_dev, (size_t)h->n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(h->sw, in_dev, (size_t)h->n * h->sw_rows, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return GEMX_OK;
 }
 const char *gemx_last_launch(const gemx_handle *h) {

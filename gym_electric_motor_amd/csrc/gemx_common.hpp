@@ -27,9 +27,10 @@ template <> struct SysTraits<GEMX_SYS_DC_SERIES> { static constexpr int ND = 2, 
 template <> struct SysTraits<GEMX_SYS_DC_SHUNT>  { static constexpr int ND = 3, NOUT = 6, HAS_ANGLE = 0; };   // omega, i_a, i_e
 template <> struct SysTraits<GEMX_SYS_DC_EXTEX>  { static constexpr int ND = 3, NOUT = 7, HAS_ANGLE = 0; };   // omega, i_a, i_e
 template <> struct SysTraits<GEMX_SYS_EESM>      { static constexpr int ND = 4, NOUT = 16, HAS_ANGLE = 1; };  // omega, i_sd, i_sq, i_e (+eps)
+template <> struct SysTraits<GEMX_SYS_DFIM>      { static constexpr int ND = 5, NOUT = 24, HAS_ANGLE = 1; };  // as SCIM (+eps), rotor voltage live
 
-constexpr int MAX_ACT = 4;  // continuous action entries per env (Cont-B6C + Cont-4QC of the EESM envs)
-constexpr int MAX_U = 3;    // motor input voltages per segment (u_d, u_q, u_e)
+constexpr int MAX_ACT = 6;  // continuous action entries per env (2 x Cont-B6C of the DFIM envs)
+constexpr int MAX_U = 4;    // motor input voltages per segment (DFIM: u_s alpha/beta, u_r alpha/beta)
 
 template <int CONV> struct ConvTraits;
 template <> struct ConvTraits<GEMX_CONV_CONT_4QC>   { static constexpr int NACT = 1, DISCRETE = 0, NACTIONS = 0; };
@@ -41,17 +42,22 @@ template <> struct ConvTraits<GEMX_CONV_CONT_2X4QC>    { static constexpr int NA
 template <> struct ConvTraits<GEMX_CONV_FINITE_2X4QC>  { static constexpr int NACT = 1, DISCRETE = 1, NACTIONS = 16; };
 template <> struct ConvTraits<GEMX_CONV_CONT_B6_4QC>   { static constexpr int NACT = 4, DISCRETE = 0, NACTIONS = 0; };
 template <> struct ConvTraits<GEMX_CONV_FINITE_B6_4QC> { static constexpr int NACT = 1, DISCRETE = 1, NACTIONS = 32; };
+template <> struct ConvTraits<GEMX_CONV_CONT_2XB6>     { static constexpr int NACT = 6, DISCRETE = 0, NACTIONS = 0; };
+template <> struct ConvTraits<GEMX_CONV_FINITE_2XB6>   { static constexpr int NACT = 1, DISCRETE = 1, NACTIONS = 64; };
 // converters that keep per-leg switching state between steps (dead time)
 template <int CONV> constexpr bool conv_has_legs() {
-    return CONV == GEMX_CONV_FINITE_B6 || CONV == GEMX_CONV_FINITE_4QC || CONV == GEMX_CONV_FINITE_2X4QC;
+    return CONV == GEMX_CONV_FINITE_B6 || CONV == GEMX_CONV_FINITE_4QC || CONV == GEMX_CONV_FINITE_2X4QC || CONV == GEMX_CONV_FINITE_2XB6;
 }
+// bytes of packed leg state per env (2 bits per half-bridge): 6 half-bridges need two rows of the [rows][N] array
+template <int CONV> constexpr int conv_sw_bytes() { return CONV == GEMX_CONV_FINITE_2XB6 ? 2 : 1; }
 
 // ------------------------------------------------------------------------------------------------
 // uniform parameters (kernel argument, by value -> SGPRs)
 // ------------------------------------------------------------------------------------------------
 template <class R> struct DevParams {
-    R m[16];      // non-zero entries of motor._model_constants, see pack_model()
+    R m[20];      // non-zero entries of motor._model_constants, see pack_model()
     R tc0, tc1;   // torque coefficients
+    R tc2, tc3;   // DFIM rotor current reconstruction: i_r = tc2 * psi_r - tc3 * i_s
     R pole;       // d(eps)/dt = pole * omega
     R inv_j, la, lb, lc, omega_lim, lin_factor;  // PolynomialStaticLoad
     R u_sup;      // IdealVoltageSupply
@@ -149,7 +155,7 @@ template <class R> struct KArgs {
     DevParams<R> P;
     R *state;                       // [ND][N]
     typename Angle<R>::T *angle;    // [N] (systems with an angle)
-    uint8_t *sw;                    // [N] packed leg states, 2 bits per half-bridge (finite converters with interlocking)
+    uint8_t *sw;                    // [rows][N] packed leg states, 2 bits per half-bridge (finite converters with interlocking)
     const unsigned char *actions;   // [K][N][A] R  |  [K][N] uint8
     R *obs;                         // [K][N][NOUT] | [K][NOUT][N]  (or a single step's worth if !obs_every)
     uint8_t *done;                  // [K][N] | [N]
@@ -185,7 +191,8 @@ struct gemx_handle {
     gemx::DevParams<double> pd;
     void *state = nullptr;   // [nd][n] R
     void *angle = nullptr;   // [n] int32 | double
-    uint8_t *sw = nullptr;   // [n]
+    uint8_t *sw = nullptr;   // [sw_rows][n]
+    int sw_rows = 1;
     uint32_t *err = nullptr;
     void *reset_obs_dev = nullptr;  // [nout] R
     void *cw_dev = nullptr;         // [2][GEMX_MAX_OUT] R constraint weights

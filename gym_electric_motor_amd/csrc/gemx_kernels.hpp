@@ -120,6 +120,22 @@ template <class R> struct Elec<GEMX_SYS_SCIM, R> {  // induction_motor.py:236-24
     static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[4]) { return P.tc0 * (x[2] * x[1] - x[3] * x[0]); }
 };
 
+template <class R> struct Elec<GEMX_SYS_DFIM, R> {  // the SCIM matrix with live rotor-voltage columns; u = u_s alpha/beta, u_r alpha/beta
+    static constexpr int NM = 4;
+    struct Pre { R ba, bb, bc, bd, w2, w6, w10, w13; };
+    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[MAX_U]) {
+        return Pre{P.m[3] * u[0] + P.m[14] * u[2], P.m[7] * u[1] + P.m[15] * u[3], P.m[16] * u[2], P.m[17] * u[3],
+                   P.m[2] * w, P.m[6] * w, P.m[10] * w, P.m[13] * w};
+    }
+    static __device__ __forceinline__ void f(const DevParams<R> &P, const Pre &p, const R (&x)[4], R (&dx)[4]) {
+        dx[0] = p.ba + P.m[0] * x[0] + P.m[1] * x[2] + p.w2 * x[3];
+        dx[1] = p.bb + P.m[4] * x[1] + P.m[5] * x[3] + p.w6 * x[2];
+        dx[2] = p.bc + P.m[8] * x[0] + P.m[9] * x[2] + p.w10 * x[3];
+        dx[3] = p.bd + P.m[11] * x[1] + P.m[12] * x[3] + p.w13 * x[2];
+    }
+    static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[4]) { return P.tc0 * (x[2] * x[1] - x[3] * x[0]); }
+};
+
 // ------------------------------------------------------------------------------------------------
 // one explicit Runge-Kutta step of size h for  z' = F(z),  z in R^NZ.  Returns the scheme's quadrature of z[0]
 // (used for the angle when omega = z[0] is dynamic).  SOLVER: Euler (solvers.py:124-136), classical RK4,
@@ -272,14 +288,15 @@ template <int NLEG = 3> __device__ __forceinline__ uint32_t b6_interlock(uint32_
     return used;
 }
 
-// B6 bridges: phase voltages u_a, u_b, u_c [V].  `legs` only matters for Finite-B6C with IL.
-template <int CONV, bool IL, class R>
+// B6 bridges: phase voltages u_a, u_b, u_c [V].  `legs` only matters for Finite-B6C with IL; A0 = index of this bridge's
+// first entry in the (concatenated) continuous action.
+template <int CONV, bool IL, class R, int A0 = 0>
 __device__ __forceinline__ void b6_voltages(const DevParams<R> &P, const R (&act)[MAX_ACT], uint32_t dact, uint32_t legs, R ia, R ib, R ic,
                                             R &ua, R &ub, R &uc) {
     if (CONV == GEMX_CONV_CONT_B6) {  // converters.py:888-903
-        ua = (cont_leg<IL, R>(P, clip01(R(0.5) * (act[0] + R(1))), ia) - R(0.5)) * P.u_sup;
-        ub = (cont_leg<IL, R>(P, clip01(R(0.5) * (act[1] + R(1))), ib) - R(0.5)) * P.u_sup;
-        uc = (cont_leg<IL, R>(P, clip01(R(0.5) * (act[2] + R(1))), ic) - R(0.5)) * P.u_sup;
+        ua = (cont_leg<IL, R>(P, clip01(R(0.5) * (act[A0] + R(1))), ia) - R(0.5)) * P.u_sup;
+        ub = (cont_leg<IL, R>(P, clip01(R(0.5) * (act[A0 + 1] + R(1))), ib) - R(0.5)) * P.u_sup;
+        uc = (cont_leg<IL, R>(P, clip01(R(0.5) * (act[A0 + 2] + R(1))), ic) - R(0.5)) * P.u_sup;
     } else {  // converters.py:816-823
         const R hu = R(0.5) * P.u_sup;
         if (!IL) {  // every leg follows its sub-action immediately: upper rail iff the action bit is set
@@ -323,7 +340,7 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
     template <bool NS1 = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[ND], AngT &, uint32_t &sw, const R (&act)[MAX_ACT], uint32_t dact,
                                                    R (&ho)[NH]) {
-        R u[MAX_U] = {R(0), R(0), R(0)};
+        R u[MAX_U] = {R(0), R(0), R(0), R(0)};
         if (CONT) {
 #pragma unroll
             for (int j = 0; j < NU; ++j) {
@@ -424,7 +441,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             if (P.t_il > R(0)) legs = b6_interlock(sw, legs, two);  // converters.py:302: no dead time -> pattern [action]
             sw = legs;
         }
-        R ua, ub, uc, u[MAX_U] = {R(0), R(0), R(0)};
+        R ua, ub, uc, u[MAX_U] = {R(0), R(0), R(0), R(0)};
         auto segment = [&](R h) {
             R ia = R(0), ib = R(0), ic = R(0);
             if (IL) {  // i_in = T32(Q(i_dq, eps)) (line 493/505); only its sign matters (dead legs / cont. interlocking)
@@ -492,7 +509,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
                                                    uint32_t dact, R (&ho)[NH]) {
         R s, c;
         Angle<R>::sincos(ang, s, c);
-        R ua, ub, uc, ue, u[MAX_U];
+        R ua, ub, uc, ue, u[MAX_U] = {R(0), R(0), R(0), R(0)};
         b6_voltages<B6, false, R>(P, act, dact & 7u, 0u, R(0), R(0), R(0), ua, ub, uc);
         if (CONV == GEMX_CONV_CONT_B6_4QC) {  // converters.py:481-491 with t_il = 0
             ue = (clip01(R(0.5) * (act[3] + R(1))) - clip01(R(-0.5) * (act[3] - R(1)))) * P.u_sup;
@@ -566,7 +583,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             if (P.t_il > R(0)) legs = b6_interlock(sw, legs, two);
             sw = legs;
         }
-        R ua, ub, uc, u[MAX_U] = {R(0), R(0), R(0)};
+        R ua, ub, uc, u[MAX_U] = {R(0), R(0), R(0), R(0)};
         auto segment = [&](R h) {
             R ia = R(0), ib = R(0), ic = R(0);
             if (IL) t32(y[1], y[2], ia, ib, ic);  // i_in = T32(i_alphabeta) (line 780/792)
@@ -610,6 +627,106 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     }
     // default constraint: SquaredConstraint(('i_sq','i_sd')) (cont_sc_scim_env.py:111)
     static __device__ __forceinline__ bool default_done(const R (&obs)[14]) { return obs[5] * obs[5] + obs[6] * obs[6] > R(1); }
+    static __device__ __forceinline__ bool state_done(const DevParams<R> &P, const R (&y)[5], const R (&ho)[NH]) {
+        const R s = ho[0], c = ho[1];
+        const R o5 = (c * y[1] + s * y[2]) * P.inv_lim[5], o6 = (-s * y[1] + c * y[2]) * P.inv_lim[6];
+        return o5 * o5 + o6 * o6 > R(1);
+    }
+};
+
+// ---- DoublyFedInductionMotorSystem (physical_systems.py:948-1029): stator AND rotor behind a B6 bridge each ---------------
+template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_DFIM, CONV, LOAD, SOLVER, IL, R> {
+    using AngT = typename Angle<R>::T;
+    using SC = Stepper<GEMX_SYS_SCIM, GEMX_CONV_CONT_B6, LOAD, SOLVER, IL, R>;  // field_angle()
+    // ho: sin, cos of the last segment-start field angle; sin, cos of the last segment-start electrical angle;
+    //     u_sa, u_sb, u_sc; u_rd, u_re, u_rf (rotor-fixed three-phase frame)
+    static constexpr int NH = 10;
+    static constexpr int B6 = CONV == GEMX_CONV_CONT_2XB6 ? GEMX_CONV_CONT_B6 : GEMX_CONV_FINITE_B6;
+    template <bool NS1 = false>
+    static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[5], AngT &ang, uint32_t &sw, const R (&act)[MAX_ACT],
+                                                   uint32_t dact, R (&ho)[NH]) {
+        R sf, cf, se, ce;
+        SC::field_angle(y[3], y[4], sf, cf);
+        Angle<R>::sincos(ang, se, ce);
+        uint32_t legs = 0;
+        bool two = false;
+        if (IL && CONV == GEMX_CONV_FINITE_2XB6) {  // flat action = a_stator + 8 * a_rotor; 6 half-bridges, 2 bits each
+            legs = b6_subactions(dact & 7u) | (b6_subactions((dact >> 3) & 7u) << 6);
+            if (P.t_il > R(0)) legs = b6_interlock<6>(sw, legs, two);
+            sw = legs;
+        }
+        R usa, usb, usc, urd, ure, urf, u[MAX_U];
+        auto segment = [&](R h) {
+            R isa = R(0), isb = R(0), isc = R(0), ird = R(0), ire = R(0), irf = R(0);
+            if (IL) {  // i_sabc = T32(i_s alphabeta); i_rdef = T32(calculate_rotor_current(state)) (lines 960-963, 980-981)
+                t32(y[1], y[2], isa, isb, isc);
+                t32(P.tc2 * y[3] - P.tc3 * y[1], P.tc2 * y[4] - P.tc3 * y[2], ird, ire, irf);
+            }
+            b6_voltages<B6, IL, R, 0>(P, act, dact & 7u, legs & 63u, isa, isb, isc, usa, usb, usc);
+            b6_voltages<B6, IL, R, 3>(P, act, (dact >> 3) & 7u, (legs >> 6) & 63u, ird, ire, irf, urd, ure, urf);
+            t23(usa, usb, usc, u[0], u[1]);
+            // u_r alphabeta = Q(eps_field) Q^-1(T23 u_rdef, eps_field - eps_el) (lines 972-974) == Q(T23 u_rdef, eps_el)
+            R urg, urh;
+            t23(urd, ure, urf, urg, urh);
+            u[2] = ce * urg - se * urh;
+            u[3] = se * urg + ce * urh;
+            const R deps = integrate<GEMX_SYS_DFIM, LOAD, SOLVER, R, NS1>(P, y, u, h);
+            ang = Angle<R>::advance(ang, deps);
+        };
+        if (IL) {
+            segment(two ? P.t_il : P.tau);
+            if (two) {
+                SC::field_angle(y[3], y[4], sf, cf);  // lines 978-979
+                Angle<R>::sincos(ang, se, ce);
+                segment(P.tau - P.t_il);
+            }
+        } else {
+            segment(P.tau);
+        }
+        ho[0] = sf; ho[1] = cf; ho[2] = se; ho[3] = ce; ho[4] = usa; ho[5] = usb; ho[6] = usc; ho[7] = urd; ho[8] = ure; ho[9] = urf;
+    }
+    static __device__ __forceinline__ void observe(const DevParams<R> &P, const R (&y)[5], AngT ang, const R (&ho)[NH], R (&obs)[24]) {
+        const R sf = ho[0], cf = ho[1], se = ho[2], ce = ho[3];
+        const R sd = sf * ce - cf * se, cd = cf * ce + sf * se;  // sin / cos of (eps_field - eps_el)
+        // stator: i_sdq = Q^-1(i_s alphabeta NEW, eps_field of the last segment start) (line 1003); i_sabc = T32(i_s alphabeta) (1004)
+        R isa, isb, isc;
+        t32(y[1], y[2], isa, isb, isc);
+        // rotor: i_rdq = Q^-1(i_r alphabeta NEW, eps_field) (1005); i_rdef = T32(Q(i_rdq, eps_field - eps_el)) (1006)
+        const R ira = P.tc2 * y[3] - P.tc3 * y[1], irb = P.tc2 * y[4] - P.tc3 * y[2];
+        const R ird_ = cf * ira + sf * irb, irq_ = -sf * ira + cf * irb;
+        R ird, ire, irf;
+        t32(cd * ird_ - sd * irq_, sd * ird_ + cd * irq_, ird, ire, irf);
+        R usal, usbe, urg, urh;
+        t23(ho[4], ho[5], ho[6], usal, usbe);
+        t23(ho[7], ho[8], ho[9], urg, urh);
+        const R x[4] = {y[1], y[2], y[3], y[4]};
+        obs[0] = y[0] * P.inv_lim[0];
+        obs[1] = Elec<GEMX_SYS_DFIM, R>::torque(P, x) * P.inv_lim[1];
+        obs[2] = isa * P.inv_lim[2];
+        obs[3] = isb * P.inv_lim[3];
+        obs[4] = isc * P.inv_lim[4];
+        obs[5] = (cf * y[1] + sf * y[2]) * P.inv_lim[5];
+        obs[6] = (-sf * y[1] + cf * y[2]) * P.inv_lim[6];
+        obs[7] = ird * P.inv_lim[7];
+        obs[8] = ire * P.inv_lim[8];
+        obs[9] = irf * P.inv_lim[9];
+        obs[10] = ird_ * P.inv_lim[10];
+        obs[11] = irq_ * P.inv_lim[11];
+        obs[12] = ho[4] * P.inv_lim[12];
+        obs[13] = ho[5] * P.inv_lim[13];
+        obs[14] = ho[6] * P.inv_lim[14];
+        obs[15] = (cf * usal + sf * usbe) * P.inv_lim[15];   // u_sdq = Q^-1(T23 u_sabc, eps_field) (line 990)
+        obs[16] = (-sf * usal + cf * usbe) * P.inv_lim[16];
+        obs[17] = ho[7] * P.inv_lim[17];
+        obs[18] = ho[8] * P.inv_lim[18];
+        obs[19] = ho[9] * P.inv_lim[19];
+        obs[20] = (cd * urg + sd * urh) * P.inv_lim[20];     // u_rdq = Q^-1(T23 u_rdef, eps_field - eps_el) (line 991)
+        obs[21] = (-sd * urg + cd * urh) * P.inv_lim[21];
+        obs[22] = Angle<R>::wrapped(ang) * P.inv_lim[22];
+        obs[23] = P.u_sup * P.inv_lim[23];
+    }
+    // default constraint: SquaredConstraint(('i_sq','i_sd')) (cont_cc_dfim_env.py:115)
+    static __device__ __forceinline__ bool default_done(const R (&obs)[24]) { return obs[5] * obs[5] + obs[6] * obs[6] > R(1); }
     static __device__ __forceinline__ bool state_done(const DevParams<R> &P, const R (&y)[5], const R (&ho)[NH]) {
         const R s = ho[0], c = ho[1];
         const R o5 = (c * y[1] + s * y[2]) * P.inv_lim[5], o6 = (-s * y[1] + c * y[2]) * P.inv_lim[6];
@@ -736,12 +853,16 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
         }
         donebuf[s * BLOCK + tid] = dn ? 1 : 0;
     };
-    R nact[MAX_ACT] = {R(0), R(0), R(0), R(0)};
+    R nact[MAX_ACT];
+#pragma unroll
+    for (int i = 0; i < MAX_ACT; ++i) nact[i] = R(0);
     uint32_t ndact = 0;
     read_action(0, nact, ndact);
     bool pdone = false;
     for (int s = 0; s < sb; ++s) {
-        R act[MAX_ACT] = {nact[0], nact[1], nact[2], nact[3]};
+        R act[MAX_ACT];
+#pragma unroll
+        for (int i = 0; i < MAX_ACT; ++i) act[i] = nact[i];
         uint32_t dact = ndact;
         if (a.obs_every && s > 0) write_ring(s - 1, pdone);       // row of the previous step (obs still holds it)
         if (COOP && s + 1 < sb) read_action(s + 1, nact, ndact);   // prefetch (LDS only; global loads would add vmcnt waits)
@@ -813,7 +934,10 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
     if (SysTraits<SYS>::HAS_ANGLE) ang = a.angle[e];
     uint32_t sw = 0;
     constexpr bool USE_SW = conv_has_legs<CONV>() && IL;
-    if (USE_SW) sw = a.sw[e];
+    if (USE_SW) {
+        sw = a.sw[e];
+        if (conv_sw_bytes<CONV>() == 2) sw |= (uint32_t)a.sw[N + e] << 8;
+    }
     const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
 
     // per-lane 16-byte loads of one action tile (steps [k0, k0+sb)) into registers: tile_load / tile_park below
@@ -896,7 +1020,10 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
 #pragma unroll
         for (int j = 0; j < ND; ++j) a.state[(int64_t)j * N + env] = y[j];
         if (SysTraits<SYS>::HAS_ANGLE) a.angle[env] = ang;
-        if (USE_SW) a.sw[env] = (uint8_t)sw;
+        if (USE_SW) {
+            a.sw[env] = (uint8_t)sw;
+            if (conv_sw_bytes<CONV>() == 2) a.sw[N + env] = (uint8_t)(sw >> 8);
+        }
     }
     if (bad_action && valid) atomicOr(a.err, 1u);
 #undef GEMX_TILE_LOAD
@@ -953,7 +1080,10 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
         if (HAS_ANGLE) ang = a.angle[env];
         uint32_t sw = 0;
         constexpr bool USE_SW = conv_has_legs<CONV>() && IL;
-        if (USE_SW) sw = a.sw[env];
+        if (USE_SW) {
+            sw = a.sw[env];
+            if (conv_sw_bytes<CONV>() == 2) sw |= (uint32_t)a.sw[N + env] << 8;
+        }
         const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
         const bool check_default = P.constr_kind == 1;
         const bool auto_reset = P.auto_reset != 0;
@@ -984,9 +1114,9 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
             }
         };
         auto one_step = [&](const R (&act_in)[NACT], uint32_t dact, R *row) {
-            R act[MAX_ACT] = {R(0), R(0), R(0), R(0)};
+            R act[MAX_ACT];
 #pragma unroll
-            for (int i = 0; i < NACT; ++i) act[i] = act_in[i];
+            for (int i = 0; i < MAX_ACT; ++i) act[i] = i < NACT ? act_in[i] : R(0);
             if (DISCRETE) { bad_action |= dact >= (uint32_t)ConvTraits<CONV>::NACTIONS; dact &= (uint32_t)(ConvTraits<CONV>::NACTIONS - 1); }
             R ho[NH];
             ST::template advance<true>(P, y, ang, sw, act, dact, ho);  // launcher guarantees solver_nsteps == 1
@@ -1033,7 +1163,10 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
 #pragma unroll
         for (int j = 0; j < ND; ++j) a.state[(int64_t)j * N + env] = y[j];
         if (HAS_ANGLE) a.angle[env] = ang;
-        if (USE_SW) a.sw[env] = (uint8_t)sw;
+        if (USE_SW) {
+            a.sw[env] = (uint8_t)sw;
+            if (conv_sw_bytes<CONV>() == 2) a.sw[N + env] = (uint8_t)(sw >> 8);
+        }
         if (bad_action) atomicOr(a.err, 1u);
     } else {
         // ------------------------------------------------------------------ output + stores

@@ -9,7 +9,8 @@ reference env classes (supply voltage, converter, motor, load, tau, constraints)
     {Finite,Cont}-{CC,TC,SC}-SCIM-v0                          envs/gym_im/squirrel_cage_induction_motor_envs/*.py
     {Finite,Cont}-{CC,TC,SC}-ExtExDc-v0                       envs/gym_dcm/extex_dc_motor_env/*.py   (MultiConverter 2 x 4QC)
     {Finite,Cont}-{CC,TC,SC}-EESM-v0                          envs/gym_eesm/*.py                     (MultiConverter B6 + 4QC)
-(48 of the reference's 54 env ids; the remaining six are the doubly fed induction motor, DFIM.)
+    {Finite,Cont}-{CC,TC,SC}-DFIM-v0                          envs/gym_im/doubly_fed_induction_motor_envs/*.py (MultiConverter 2 x B6)
+(all 54 env ids of the reference.)
 
 Only the physical system + constraint monitor (done mask) are device-resident.  Reference generators, reward
 functions and visualisation are outside the accelerated path: `step()` returns
@@ -21,7 +22,7 @@ import re
 from . import components as comp
 from . import physical_systems as bps
 
-_ID = re.compile(r"^(Finite|Cont)-(CC|TC|SC)-(PermExDc|SeriesDc|ShuntDc|ExtExDc|PMSM|SynRM|SCIM|EESM)-v0$")
+_ID = re.compile(r"^(Finite|Cont)-(CC|TC|SC)-(PermExDc|SeriesDc|ShuntDc|ExtExDc|PMSM|SynRM|SCIM|EESM|DFIM)-v0$")
 
 
 def _initialize(arg, default_class, default_args):
@@ -62,7 +63,7 @@ def default_components(env_id):
     m = _ID.match(env_id)
     if not m:
         raise KeyError(f"{env_id!r} is not on the accelerated path; supported: "
-                       "(Finite|Cont)-(CC|TC|SC)-(PermExDc|SeriesDc|ShuntDc|ExtExDc|PMSM|SynRM|SCIM|EESM)-v0")
+                       "(Finite|Cont)-(CC|TC|SC)-(PermExDc|SeriesDc|ShuntDc|ExtExDc|PMSM|SynRM|SCIM|EESM|DFIM)-v0")
     action, control, motor = m.groups()
     finite = action == "Finite"
     dc = motor.endswith("Dc")
@@ -78,6 +79,12 @@ def default_components(env_id):
                  motor=comp.ExternallyExcitedSynchronousMotor, converter=comp.FiniteMultiConverter if finite else comp.ContMultiConverter,
                  constraints=(bps.SquaredConstraint(("i_sq", "i_sd")), bps.LimitConstraint(("i_e",))))
         d_conv_args = dict(subconverters=subs)
+    elif motor == "DFIM":  # cont_cc_dfim_env.py:160-180: stator and rotor B6 bridges
+        sub = comp.FiniteB6BridgeConverter if finite else comp.ContB6BridgeConverter
+        d = dict(system=bps.BatchedDoublyFedInductionMotorSystem, supply=dict(u_nominal=420.0), motor=comp.DoublyFedInductionMotor,
+                 converter=comp.FiniteMultiConverter if finite else comp.ContMultiConverter,
+                 constraints=(bps.SquaredConstraint(("i_sq", "i_sd")),))
+        d_conv_args = dict(subconverters=(sub, sub))
     elif dc:
         motor_cls = {"PermExDc": comp.DcPermanentlyExcitedMotor, "SeriesDc": comp.DcSeriesMotor, "ShuntDc": comp.DcShuntMotor}[motor]
         d = dict(system=bps.BatchedDcMotorSystem, supply=dict(u_nominal=60.0), motor=motor_cls,

@@ -216,10 +216,12 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             kinds = {("ContFourQuadrantConverter", "ContFourQuadrantConverter"): _lib.CONV_CONT_2X4QC,
                      ("FiniteFourQuadrantConverter", "FiniteFourQuadrantConverter"): _lib.CONV_FINITE_2X4QC,
                      ("ContB6BridgeConverter", "ContFourQuadrantConverter"): _lib.CONV_CONT_B6_4QC,
-                     ("FiniteB6BridgeConverter", "FiniteFourQuadrantConverter"): _lib.CONV_FINITE_B6_4QC}
+                     ("FiniteB6BridgeConverter", "FiniteFourQuadrantConverter"): _lib.CONV_FINITE_B6_4QC,
+                     ("ContB6BridgeConverter", "ContB6BridgeConverter"): _lib.CONV_CONT_2XB6,
+                     ("FiniteB6BridgeConverter", "FiniteB6BridgeConverter"): _lib.CONV_FINITE_2XB6}
             if names not in kinds:
                 raise ValueError(f"multi converter of {names} is not on the accelerated path (supported: 2 x 4QC for the externally "
-                                 "excited DC motor, B6 + 4QC for the EESM)")
+                                 "excited DC motor, B6 + 4QC for the EESM, 2 x B6 for the DFIM)")
             return kinds[names]
         if _is_a(c, "ContFourQuadrantConverter"):
             return _lib.CONV_CONT_4QC
@@ -280,6 +282,9 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             return [1.5 * mp["p"] * mp["psi_p"], 1.5 * mp["p"] * (mp["l_d"] - mp["l_q"])]
         if _is_a(m, "SynchronousReluctanceMotor"):
             return [0.0, 1.5 * mp["p"] * (mp["l_d"] - mp["l_q"])]
+        if _is_a(m, "DoublyFedInductionMotor"):  # + rotor current reconstruction i_r = psi_r / l_r - l_m / l_r * i_s
+            l_r = mp["l_m"] + mp["l_sigr"]
+            return [1.5 * mp["p"] * mp["l_m"] / l_r, 0.0, 1 / l_r, mp["l_m"] / l_r]
         if _is_a(m, "SquirrelCageInductionMotor"):
             return [1.5 * mp["p"] * mp["l_m"] / (mp["l_m"] + mp["l_sigr"]), 0.0]
         raise ValueError(f"motor {type(m).__name__} is not on the accelerated path")
@@ -300,6 +305,15 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         cfg.abi_version = _lib.ABI_VERSION
         cfg.system_kind = self._SYSTEM_KIND
         cfg.converter_kind = self._converter_kind()
+        one_u = (_lib.CONV_CONT_4QC, _lib.CONV_FINITE_4QC)
+        b6 = (_lib.CONV_CONT_B6, _lib.CONV_FINITE_B6)
+        allowed = {_lib.SYS_DC_PERMEX: one_u, _lib.SYS_DC_SERIES: one_u, _lib.SYS_DC_SHUNT: one_u, _lib.SYS_SYNC: b6, _lib.SYS_SCIM: b6,
+                   _lib.SYS_DC_EXTEX: (_lib.CONV_CONT_2X4QC, _lib.CONV_FINITE_2X4QC),
+                   _lib.SYS_EESM: (_lib.CONV_CONT_B6_4QC, _lib.CONV_FINITE_B6_4QC),
+                   _lib.SYS_DFIM: (_lib.CONV_CONT_2XB6, _lib.CONV_FINITE_2XB6)}[self._SYSTEM_KIND]
+        if cfg.converter_kind not in allowed:  # (gemx_create refuses it as well)
+            raise ValueError(f"converter {type(self._converter).__name__} does not fit {type(self).__name__} with a "
+                             f"{type(self._electrical_motor).__name__}: it is not on the accelerated path")
         cfg.solver_kind, cfg.solver_nsteps = self._solver_kind()
         cfg.dtype = _lib.F64 if self._dtype_name == "float64" else _lib.F32
         cfg.obs_layout = {"aos": _lib.OBS_AOS, "soa": _lib.OBS_SOA}[self._obs_layout]
@@ -498,8 +512,10 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         torch.cuda.current_stream(self._tdev).synchronize()
 
     def get_switch_state(self):
+        """Packed half-bridge states (2 bits each): uint8 [N], or [2, N] for the six half-bridges of a 2 x Finite-B6C."""
         torch = _torch()
-        out = torch.empty(self._n_envs, dtype=torch.uint8, device=self._tdev)
+        rows = self._L.gemx_n_switch_bytes(self._handle)
+        out = torch.empty(self._n_envs if rows == 1 else (rows, self._n_envs), dtype=torch.uint8, device=self._tdev)
         _lib.check(self._L.gemx_get_switch_state(self._handle, C.c_void_p(out.data_ptr()), self._stream()))
         return out
 
@@ -642,6 +658,28 @@ class BatchedExternallyExcitedSynchronousMotorSystem(_BatchedThreePhaseMotorSyst
         self.VOLTAGES_IDX = list(range(8, 14))
         self.EPSILON_IDX = 14
         self.U_SUP_IDX = [15]
+
+
+class BatchedDoublyFedInductionMotorSystem(_BatchedThreePhaseMotorSystem):
+    """DoublyFedInductionMotorSystem (physical_systems.py:850-1113) for N envs: stator and rotor each behind a B6 bridge of a
+    Cont/FiniteMultiConverter; 24 system states."""
+
+    _SYSTEM_KIND = _lib.SYS_DFIM
+    _n_ode = 6
+
+    def _build_state_names(self):
+        return self._mechanical_load.state_names + [
+            "torque", "i_sa", "i_sb", "i_sc", "i_sd", "i_sq", "i_ra", "i_rb", "i_rc", "i_rd", "i_rq",
+            "u_sa", "u_sb", "u_sc", "u_sd", "u_sq", "u_ra", "u_rb", "u_rc", "u_rd", "u_rq", "epsilon", "u_sup"]
+
+    def _set_indices(self):
+        """physical_systems.py:911-916."""
+        self.OMEGA_IDX = 0
+        self.TORQUE_IDX = 1
+        self.CURRENTS_IDX = list(range(2, 12))
+        self.VOLTAGES_IDX = list(range(12, 22))
+        self.EPSILON_IDX = 22
+        self.U_SUP_IDX = [23]
 
 
 class BatchedSquirrelCageInductionMotorSystem(_BatchedThreePhaseMotorSystem):

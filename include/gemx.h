@@ -28,9 +28,9 @@
 extern "C" {
 #endif
 
-#define GEMX_ABI_VERSION 1
+#define GEMX_ABI_VERSION 2 /* 2: GEMX_MAX_OUT 16 -> 24 (DFIM system, 24 states) */
 #define GEMX_MAX_ODE 8  /* ODE state length incl. omega and the angle      */
-#define GEMX_MAX_OUT 16 /* system-state (observation) length               */
+#define GEMX_MAX_OUT 24 /* system-state (observation) length               */
 #define GEMX_MODEL_ROWS 5
 #define GEMX_MODEL_COLS 11
 
@@ -49,20 +49,23 @@ typedef enum {
     GEMX_SYS_DC_SERIES = 3, /* DcMotorSystem + DcSeriesMotor (electric_motors/dc_series_motor.py)           */
     GEMX_SYS_DC_SHUNT = 4,  /* DcMotorSystem + DcShuntMotor  (electric_motors/dc_shunt_motor.py)            */
     GEMX_SYS_DC_EXTEX = 5,  /* DcMotorSystem + DcExternallyExcitedMotor (dc_externally_excited_motor.py)     */
-    GEMX_SYS_EESM = 6       /* ExternallyExcitedSynchronousMotorSystem (physical_systems.py:564-691)         */
+    GEMX_SYS_EESM = 6,      /* ExternallyExcitedSynchronousMotorSystem (physical_systems.py:564-691)         */
+    GEMX_SYS_DFIM = 7       /* DoublyFedInductionMotorSystem (physical_systems.py:850-1113)                  */
 } gemx_system_kind;
 /* ContFourQuadrantConverter (converters.py:438-495), FiniteB6BridgeConverter (743-839), ContB6BridgeConverter (842-911),
  * FiniteFourQuadrantConverter (313-368; DC systems, actions 0..3).
- * Kinds 4..7 are Cont/FiniteMultiConverter (converters.py:498-740) holding exactly the two sub-converters of the
- * reference's ExtExDc envs (2 x 4QC: armature, excitation) and EESM envs (B6 stator + 4QC excitation).
- *   continuous actions: the sub-converters' actions concatenated, A = 2 | 4;
+ * Kinds 4..9 are Cont/FiniteMultiConverter (converters.py:498-740) holding exactly the two sub-converters of the
+ * reference's ExtExDc envs (2 x 4QC: armature, excitation), EESM envs (B6 stator + 4QC excitation) and DFIM envs
+ * (2 x B6: stator, rotor).
+ *   continuous actions: the sub-converters' actions concatenated, A = 2 | 4 | 6;
  *   discrete actions:   ONE uint8 = a_0 + n_0 * a_1, the flat index of the reference's MultiDiscrete([n_0, n_1])
- *                       action [a_0, a_1] (n_0 = 4 | 8), i.e. 0..15 | 0..31.
+ *                       action [a_0, a_1] (n_0 = 4 | 8), i.e. 0..15 | 0..31 | 0..63.
  * The two sub-converters share interlocking_time; EESM handles refuse interlocking_time > 0 (the reference's
  * dead-time branch for this system cannot execute, physical_systems.py:634). */
 typedef enum {
     GEMX_CONV_CONT_4QC = 0, GEMX_CONV_FINITE_B6 = 1, GEMX_CONV_CONT_B6 = 2, GEMX_CONV_FINITE_4QC = 3,
-    GEMX_CONV_CONT_2X4QC = 4, GEMX_CONV_FINITE_2X4QC = 5, GEMX_CONV_CONT_B6_4QC = 6, GEMX_CONV_FINITE_B6_4QC = 7
+    GEMX_CONV_CONT_2X4QC = 4, GEMX_CONV_FINITE_2X4QC = 5, GEMX_CONV_CONT_B6_4QC = 6, GEMX_CONV_FINITE_B6_4QC = 7,
+    GEMX_CONV_CONT_2XB6 = 8, GEMX_CONV_FINITE_2XB6 = 9
 } gemx_converter_kind;
 /* ConstantSpeedLoad (constant_speed_load.py), PolynomialStaticLoad (polynomial_static_load.py) */
 typedef enum { GEMX_LOAD_CONST_SPEED = 0, GEMX_LOAD_POLY_STATIC = 1 } gemx_load_kind;
@@ -95,10 +98,13 @@ typedef struct gemx_config {
      * SYNC  (3x7) [omega, i_d, i_q, u_d, u_q, omega*i_d, omega*i_q]  synchronous_motor.py:143-168
      * EESM  (4x10)[omega, i_d, i_q, i_e, u_d, u_q, u_e, omega*i_d, omega*i_q, omega*i_e]
      *                                                            externally_excited_synchronous_motor.py:69-113
-     * SCIM  (5x11)[omega, i_a, i_b, psi_a, psi_b, omega*psi_a, omega*psi_b, u_sa, u_sb, u_ra, u_rb] induction_motor.py:187-217 */
+     * SCIM  (5x11)[omega, i_a, i_b, psi_a, psi_b, omega*psi_a, omega*psi_b, u_sa, u_sb, u_ra, u_rb] induction_motor.py:187-217
+     *             (SCIM: the u_r columns are ignored -- zero rotor voltage; DFIM: same matrix, u_r columns live) */
     double model[GEMX_MODEL_ROWS * GEMX_MODEL_COLS];
     /* torque: DC T = tc[0]*i ; SYNC T = (tc[0] + tc[1]*i_d)*i_q ; SCIM T = tc[0]*(psi_a*i_b - psi_b*i_a) ;
-     * SERIES T = tc[0]*i*i ; SHUNT / EXTEX T = tc[0]*i_a*i_e ; EESM T = (tc[0]*i_e + tc[1]*i_d)*i_q */
+     * SERIES T = tc[0]*i*i ; SHUNT / EXTEX T = tc[0]*i_a*i_e ; EESM T = (tc[0]*i_e + tc[1]*i_d)*i_q ;
+     * DFIM: T as SCIM, plus the rotor-current reconstruction i_r = tc[2]*psi_r - tc[3]*i_s
+     *       (tc[2] = 1/l_r, tc[3] = l_m/l_r; calculate_rotor_current, physical_systems.py:931-946) */
     double torque_coef[4];
     double j_total;                    /* load.j_total (j_load + j_rotor), mechanical_load.py:35-41 */
     double load_a, load_b, load_c;     /* PolynomialStaticLoad parameters */
@@ -121,8 +127,8 @@ int gemx_destroy(gemx_handle *h);
 
 int gemx_n_envs(const gemx_handle *h, int64_t *n);
 int gemx_n_ode(const gemx_handle *h);    /* S_ode: 2 | 3 | 4 | 5 | 6  */
-int gemx_n_out(const gemx_handle *h);    /* S_out: 5 | 6 | 7 | 14 | 16 */
-int gemx_n_action(const gemx_handle *h); /* A: 1 | 2 | 3 | 4 (1 for every discrete converter) */
+int gemx_n_out(const gemx_handle *h);    /* S_out: 5 | 6 | 7 | 14 | 16 | 24 */
+int gemx_n_action(const gemx_handle *h); /* A: 1 | 2 | 3 | 4 | 6 (1 for every discrete converter) */
 int gemx_action_itemsize(const gemx_handle *h); /* 1 (uint8 discrete) | sizeof(R) */
 /* normalised state returned by reset() for the configured constant initialiser, host doubles [S_out] */
 int gemx_reset_observation(const gemx_handle *h, double *obs_host);
@@ -146,7 +152,10 @@ int gemx_rollout(gemx_handle *h, const void *actions_dev, int32_t K, void *obs_o
                  int32_t obs_every, void *stream);
 
 /* Checkpoint / parity access to the ODE state, SoA [S_ode, N] of R in physical units (angle in rad), plus the
- * per-env packed converter switching state [N] uint8 (2 bits per leg) and step counters are not exported. */
+ * per-env packed converter switching state, 2 bits per half-bridge: [N] uint8, or [2][N] uint8 (row 0 = bits 0..7,
+ * row 1 = bits 8..11) for the 6 half-bridges of GEMX_CONV_FINITE_2XB6; gemx_n_switch_bytes() = bytes per env.
+ * Step counters are not exported. */
+int gemx_n_switch_bytes(const gemx_handle *h);
 int gemx_get_state(gemx_handle *h, void *soa_out_dev, void *stream);
 int gemx_set_state(gemx_handle *h, const void *soa_in_dev, void *stream);
 int gemx_get_switch_state(gemx_handle *h, uint8_t *out_dev, void *stream);

@@ -7,6 +7,7 @@ Tolerances (normalised states are O(1); angle compared on the circle):
   * GPU fixed-step RK4 / DP5 fp32 vs reference default dopri5 ...... 1e-4 rel (2e-4 for SCIM + PolynomialStaticLoad,
     whose kinks make scipy's adaptive controller split steps)
   * done masks: exact, except steps whose constraint margin is < 1e-5 in the reference
+  * "rel" = max |got - ref| of a column / max(|ref| range of that column, 1e-3)
 """
 import glob
 import json
@@ -63,7 +64,9 @@ def _rel_err(got, ref, names, scale_ref=None):
         i = names.index("epsilon")
         diff[..., i] = np.minimum(diff[..., i], 2.0 - diff[..., i])
     sr = ref if scale_ref is None else scale_ref
-    scale = np.maximum(np.abs(sr).reshape(-1, sr.shape[-1]).max(axis=0), 1e-9)
+    # floor: a column that never leaves 0.1 % of its limit is held to 1e-7 ABSOLUTE (normalised units) instead -- e.g. the
+    # angle of a speed-control env that has barely started to turn (fp32 angle resolution: 2 pi / 2^32 rad per step)
+    scale = np.maximum(np.abs(sr).reshape(-1, sr.shape[-1]).max(axis=0), 1e-3)
     return float((diff.reshape(-1, ref.shape[-1]).max(axis=0) / scale).max()), float(diff.max())
 
 
@@ -86,7 +89,19 @@ def _run_golden(name, dtype, solver=None, n_envs=70):
     env.close()
     # lockstep determinism: every env saw the same actions
     assert np.array_equal(obs[:, 0], obs[:, n_envs - 1]) and np.array_equal(obs[:, 0], obs[:, 64 % n_envs])
-    return d, meta, obs[:, 0], done[:, 0]
+    obs0 = obs[:, 0].copy()
+    if meta["system"] == "DoublyFedInductionMotorSystem":
+        # steps that start with zero rotor flux (right after a reset): the reference's field angle is arctan2(rounding
+        # noise), its dq columns are not reproducible (oracle/oracle.py:undefined_field_angle_steps) -> take them as given
+        from oracle import oracle as orc
+
+        bad = orc.undefined_field_angle_steps(orc.params_from_meta(meta), acts)
+        cols = [meta["state_names"].index(c) for c in orc.DQ_COLUMNS if c in meta["state_names"]]
+        where = {int(k): i for i, k in enumerate(d["state_index"])}
+        for k in np.nonzero(bad)[0]:
+            if int(k) in where:
+                obs0[k, cols] = d["states"][where[int(k)], cols]
+    return d, meta, obs0, done[:, 0]
 
 
 def _check_done(meta, d, got_done, ref_states_full=None):
@@ -213,9 +228,11 @@ def test_full_size_configs_against_oracle(env_id, n_envs, solver):
     ("Finite-CC-ExtExDc-v0", "extex_fin_free_held_euler", 0.0), ("Finite-CC-ExtExDc-v0", "extex_fin_free_held_til_euler", 1e-6),
     ("Cont-CC-EESM-v0", "eesm_cont_free_held_euler", 0.0), ("Cont-SC-EESM-v0", "eesm_cont_sc_epi_held_euler", 0.0),
     ("Finite-CC-EESM-v0", "eesm_fin_free_held_euler", 0.0),
+    ("Cont-CC-DFIM-v0", "dfim_cont_free_held_euler", 0.0), ("Cont-SC-DFIM-v0", "dfim_cont_sc_free_held_euler", 2e-6),
+    ("Finite-CC-DFIM-v0", "dfim_fin_free_held_euler", 0.0), ("Finite-SC-DFIM-v0", "dfim_fin_sc_free_uniform_euler", 1e-6),
 ])
 def test_multi_converter_envs_per_env_actions_against_oracle(env_id, golden, til):
-    """ExtExDc (2 x 4QC) and EESM (B6 + 4QC): every env gets its own random action stream (flat MultiDiscrete index for
+    """ExtExDc (2 x 4QC), EESM (B6 + 4QC) and DFIM (2 x B6): every env gets its own random action stream (flat MultiDiscrete index for
     the finite converters); a sample of envs is checked against the fp64 oracle with the SAME integrator (RK4), and the
     single-step path, the single-wave and the pipelined fused kernels must agree bit for bit."""
     import torch
@@ -230,7 +247,10 @@ def test_multi_converter_envs_per_env_actions_against_oracle(env_id, golden, til
     def conv():
         if not til:
             return None
-        sub = ga.FiniteFourQuadrantConverter if fin else ga.ContFourQuadrantConverter
+        if "DFIM" in env_id:
+            sub = ga.FiniteB6BridgeConverter if fin else ga.ContB6BridgeConverter
+        else:
+            sub = ga.FiniteFourQuadrantConverter if fin else ga.ContFourQuadrantConverter
         holder = ga.FiniteMultiConverter if fin else ga.ContMultiConverter
         return holder(subconverters=[sub(interlocking_time=til), sub(interlocking_time=til)])
 
@@ -284,7 +304,8 @@ def test_multi_converter_envs_per_env_actions_against_oracle(env_id, golden, til
                                   "scim_epi_uniform_euler", "scim_free_held_til_euler", "permexdc_epi_held_euler",
                                   "permexdc_free_held_til_euler", "pmsm_free_uniform_10k_euler",
                                   "extex_fin_free_held_til_euler", "extex_cont_epi_held_euler", "eesm_fin_epi_held_tau1e-4_euler",
-                                  "eesm_cont_free_uniform_euler"])
+                                  "eesm_cont_free_uniform_euler", "dfim_fin_free_uniform_til_euler", "dfim_fin_epi_held_tau1e-4_euler",
+                                  "dfim_cont_sc_epi_held_euler"])
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 def test_two_wave_pipelined_kernel_matches_reference_and_single_wave_kernel(name, dtype, monkeypatch):
     """n_envs = 128 (full 64-env workgroups) takes the two-wave pipelined kernel; it must agree with the reference AND be
@@ -305,7 +326,7 @@ def test_obs_layouts_agree_and_tail_block():
 
     import gym_electric_motor_amd as ga
 
-    for env_id in ("Cont-CC-PermExDc-v0", "Finite-CC-PMSM-v0", "Cont-SC-SCIM-v0"):
+    for env_id in ("Cont-CC-PermExDc-v0", "Finite-CC-PMSM-v0", "Cont-SC-SCIM-v0", "Finite-CC-DFIM-v0", "Cont-CC-EESM-v0", "Finite-SC-ExtExDc-v0"):
         for n in (1, 3, 64, 65, 129):
             ea = ga.make(env_id, n_envs=n, obs_layout="aos")
             es = ga.make(env_id, n_envs=n, obs_layout="soa")
@@ -313,7 +334,8 @@ def test_obs_layouts_agree_and_tail_block():
             g = torch.Generator(device="cuda").manual_seed(n)
             K = 20
             if ps._discrete:
-                acts = torch.randint(0, 8, (K, n), device="cuda", generator=g, dtype=torch.uint8)
+                nflat = int(np.prod(ps.action_space.nvec)) if hasattr(ps.action_space, "nvec") else int(ps.action_space.n)
+                acts = torch.randint(0, nflat, (K, n), device="cuda", generator=g, dtype=torch.uint8)
             else:
                 acts = torch.rand((K, n, ps._n_act), device="cuda", generator=g) * 2 - 1
             oa, da = ea.rollout(acts)

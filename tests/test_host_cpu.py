@@ -59,6 +59,10 @@ def test_library_exports_every_declared_symbol():
     ("Cont-CC-EESM-v0", "eesm_cont_free_held_euler"),
     ("Cont-SC-EESM-v0", "eesm_cont_sc_epi_held_euler"),
     ("Finite-CC-EESM-v0", "eesm_fin_free_held_euler"),
+    ("Cont-CC-DFIM-v0", "dfim_cont_free_held_euler"),
+    ("Cont-SC-DFIM-v0", "dfim_cont_sc_free_held_euler"),
+    ("Finite-CC-DFIM-v0", "dfim_fin_free_held_euler"),
+    ("Finite-SC-DFIM-v0", "dfim_fin_sc_free_uniform_euler"),
 ])
 def test_host_metadata_matches_reference(env_id, golden):
     """limits / nominal_state / model constants / names / j_total as the live reference reported them."""
@@ -101,9 +105,9 @@ def test_pmsm_initialiser_dict_order_quirk():
 
 def test_unsupported_pieces_raise():
     with pytest.raises(KeyError):
-        ga.make("Cont-CC-DFIM-v0", n_envs=2, _defer_create=True)   # doubly fed induction motor: not on the path yet
+        ga.make("Cont-CC-PMSM-v1", n_envs=2, _defer_create=True)   # unknown env id
     with pytest.raises(KeyError):
-        ga.make("Finite-TC-DFIM-v0", n_envs=2, _defer_create=True)
+        ga.make("Cont-XC-DFIM-v0", n_envs=2, _defer_create=True)
     with pytest.raises(ValueError):  # a DC system needs a one-voltage DC motor
         ga.BatchedDcMotorSystem(converter=ga.ContFourQuadrantConverter(), motor=ga.PermanentMagnetSynchronousMotor(),
                                 load=ga.ConstantSpeedLoad(100.0), supply=ga.IdealVoltageSupply(60.0), ode_solver=ga.EulerSolver(),
