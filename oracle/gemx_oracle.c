@@ -51,7 +51,13 @@ typedef struct orc_params {
     int32_t system, converter, load, solver, nsteps;
     int32_t limit_mask;   /* bit i set: LimitConstraint observes system-state entry i   (constraints.py:55-58) */
     int32_t squared_mask; /* bit i set: SquaredConstraint sums entry i                   (constraints.py:96-98) */
-    int32_t reserved;
+    /* action path in front of simulate():
+     * dq_mode 1: SynchronousMotorSystem / SquirrelCage...System(control_space='dq') (physical_systems.py:491-492, 777-778)
+     * dq_mode 2: DqToAbcActionProcessor around the system (physical_system_wrappers/dq_to_abc_action_processor.py:100-114,
+     *            EESM variant 158-175): abc = T32(Q(a_dq, eps + (0.5 + act_delay) * tau * omega * p))
+     * act_delay: DeadTimeProcessor(steps) INSIDE the dq processor (dead_time_processor.py:63-85), reset action = zeros */
+    int32_t dq_mode;
+    int32_t act_delay, pad0;
     double tau, t_il, u_sup;
     double mp[8]; /* DC permex: r_a,l_a,psi_e | PMSM/SynRM: p,l_d,l_q,r_s,psi_p(0 for SynRM) | SCIM: p,l_m,l_sigs,l_sigr,r_s,r_r
                    * DC series / shunt / extex: r_a,r_e,l_a,l_e,l_e_prime | EESM: p,l_d,l_q,l_m,l_e,r_s,r_e,k */
@@ -75,6 +81,9 @@ typedef struct orc_env {
     double dp_h; /* dopri5: predicted step size carried between integrate() calls (0 -> HINIT) */
     /* constants */
     double C[5][11];
+    /* wrappers */
+    double last_state[ORC_MAX_OUT]; /* DqToAbcActionProcessor._state = normalised state * limits (lines 96, 112) */
+    double fifo[8][6];              /* DeadTimeProcessor._action_deque (oldest first) */
 } orc_env;
 
 static int n_ode(const orc_params *p) {
@@ -494,7 +503,7 @@ static int conv_nact(const orc_params *p) {
     for (int i = 0; i < n; ++i) tot += sub_nact(kinds[i]);
     return tot;
 }
-int orc_n_act(const orc_params *p) { return conv_nact(p); }
+int orc_n_act(const orc_params *p) { return p->dq_mode ? conv_nact(p) - 1 : conv_nact(p); } /* (u_d, u_q) replace (u_a, u_b, u_c) */
 
 /* converter.set_action: returns the number of integration segments; seg_end[] = absolute switching times.
  * MultiConverter.set_action (converters.py:566-570 / 678-685): the action is split per sub-converter and the
@@ -604,7 +613,8 @@ static void simulate_eesm(const orc_params *p, orc_env *e, const double *action,
 static void simulate_pmsm(const orc_params *p, orc_env *e, const double *action, double *obs) {
     double seg_end[2], i_in[3], u_n[3], u_in[3] = {0}, u_dq[2] = {0}, i_abc[3];
     double u_sup = p->u_sup;
-    double eps = e->y[3];
+    double eps = e->y[3], a_abc[3];
+    if (p->dq_mode == 1) { dq_to_abc(action, eps, a_abc); action = a_abc; } /* control_space == 'dq', line 491-492 */
     dq_to_abc(e->y + 1, eps, i_in);
     int nseg = conv_set_action(p, e, action, e->t, seg_end);
     double t0 = e->t;
@@ -630,7 +640,8 @@ static void simulate_pmsm(const orc_params *p, orc_env *e, const double *action,
 static void simulate_scim(const orc_params *p, orc_env *e, const double *action, double *obs) {
     double seg_end[2], i_in[3], u_n[3], u_in[3] = {0}, u_dq[2] = {0}, u_ab[2], i_dq[2], i_abc[3];
     double u_sup = p->u_sup;
-    double eps_fs = atan2(e->y[4], e->y[3]); /* calculate_field_angle, 765-769 */
+    double eps_fs = atan2(e->y[4], e->y[3]), a_abc[3]; /* calculate_field_angle, 765-769 */
+    if (p->dq_mode == 1) { dq_to_abc(action, eps_fs, a_abc); action = a_abc; } /* control_space == 'dq', line 777-778 */
     t_32(e->y + 1, i_in);
     int nseg = conv_set_action(p, e, action, e->t, seg_end);
     double t0 = e->t;
@@ -775,10 +786,37 @@ void orc_reset(const orc_params *p, orc_env *e, double *obs) {
         obs[5] = i_dq[0]; obs[6] = i_dq[1]; obs[7] = u_abc[0]; obs[8] = u_abc[1]; obs[9] = u_abc[2];
         obs[10] = u_dq[0]; obs[11] = u_dq[1]; obs[12] = eps; obs[13] = u_sup;
     }
+    memset(e->fifo, 0, sizeof(e->fifo)); /* DeadTimeProcessor.reset: deque refilled with the reset action (zeros) */
     normalise(p, obs);
+    for (int i = 0; i < n_out(p); ++i) e->last_state[i] = obs[i] * p->limits[i]; /* dq processor reset(), line 96 */
 }
 
+static void system_simulate(const orc_params *p, orc_env *e, const double *action, double *obs);
+
+/* wrapper chain [DqToAbcActionProcessor [DeadTimeProcessor [system]]] */
 void orc_step(const orc_params *p, orc_env *e, const double *action, double *obs) {
+    double a_abc[6], active[6];
+    int nc = conv_nact(p);
+    if (p->dq_mode == 2) {
+        int eps_idx = p->system == ORC_SYS_EESM ? 14 : 12;
+        double adv = 0.5 + p->act_delay; /* set_physical_system, lines 83-86 */
+        double angle = e->last_state[eps_idx] + adv * p->tau * e->last_state[0] * p->mp[0]; /* _advance_angle, 98-100 */
+        dq_to_abc(action, angle, a_abc);                         /* _transformation, line 15-16 */
+        if (p->system == ORC_SYS_EESM) a_abc[3] = action[2];     /* line 170 */
+        action = a_abc;
+    }
+    if (p->act_delay > 0) { /* active = deque.pop(); deque.appendleft(action) */
+        int D = p->act_delay;
+        for (int i = 0; i < nc; ++i) active[i] = e->fifo[0][i];
+        for (int s = 0; s + 1 < D; ++s) memcpy(e->fifo[s], e->fifo[s + 1], sizeof(e->fifo[0]));
+        for (int i = 0; i < nc; ++i) e->fifo[D - 1][i] = action[i];
+        action = active;
+    }
+    system_simulate(p, e, action, obs);
+    for (int i = 0; i < n_out(p); ++i) e->last_state[i] = obs[i] * p->limits[i];
+}
+
+static void system_simulate(const orc_params *p, orc_env *e, const double *action, double *obs) {
     if (ORC_IS_DC(p->system)) simulate_dc(p, e, action, obs);
     else if (p->system == ORC_SYS_PMSM) simulate_pmsm(p, e, action, obs);
     else if (p->system == ORC_SYS_EESM) simulate_eesm(p, e, action, obs);

@@ -108,7 +108,7 @@ def describe(env):
         model_constants=np.asarray(motor._model_constants, dtype=float).tolist(),
         j_total=float(load.j_total),
     )
-    subs = getattr(conv, "_sub_converters", None)
+    subs = getattr(conv, "_sub_converters", None) if type(conv).__name__.endswith("MultiConverter") else None
     if subs is not None:
         # Cont/FiniteMultiConverter: the holder's own interlocking time is never used; the sub-converters' are
         meta["converter"] += "[" + ",".join(type(sc).__name__ for sc in subs) + "]"
@@ -123,12 +123,28 @@ def describe(env):
     return meta
 
 
-def run_case(name, env_id, solver, K, seed, mode, episodic, space_kind, every=1, **make_kwargs):
+def run_case(name, env_id, solver, K, seed, mode, episodic, space_kind, every=1, action_frame="abc", dead_time_steps=0,
+             **make_kwargs):
+    """action_frame: 'abc' | 'dq' (system.control_space = 'dq') | 'dq_processor' (DqToAbcActionProcessor wrapper);
+    dead_time_steps > 0: DeadTimeProcessor(steps) wrapped INSIDE the dq processor, as the reference's processors expect."""
+    from gym_electric_motor.physical_system_wrappers import DeadTimeProcessor, DqToAbcActionProcessor
+
     kw = dict(make_kwargs)
+    wrappers = []
+    if dead_time_steps:
+        wrappers.append(DeadTimeProcessor(steps=dead_time_steps))
+    if action_frame == "dq_processor":
+        wrappers.append(DqToAbcActionProcessor.make("EESM" if "EESM" in env_id else "PMSM"))
+    if wrappers:
+        kw["physical_system_wrappers"] = tuple(wrappers)
     kw["ode_solver"] = make_solver(solver)
     if not episodic:
         kw["constraints"] = ()
     env = gem.make(env_id, **kw)
+    if action_frame == "dq":  # no env class forwards control_space; the attribute is read at simulate() time (lines 491, 777)
+        env.physical_system.unwrapped.control_space = "dq"
+    if action_frame != "abc":
+        env._callbacks = []  # the default dashboard's action plots index three abc actions; plotting is not on the path
     (s0, _), _ = env.reset(seed=0)
     # physical-system wrappers that only post-process the observation (e.g. the shunt envs' CurrentSumProcessor, which
     # appends 'i_sum') are outside the path: keep the columns of the unwrapped physical system
@@ -150,7 +166,8 @@ def run_case(name, env_id, solver, K, seed, mode, episodic, space_kind, every=1,
             env.reset()
     meta = describe(env)
     meta.update(name=name, env_id=env_id, solver=solver, K=K, seed=seed, mode=mode, episodic=bool(episodic),
-                every=every, constraints=("default" if episodic else "none"))
+                every=every, constraints=("default" if episodic else "none"), action_frame=action_frame,
+                dead_time_steps=int(dead_time_steps))
     idx = np.arange(K)
     keep = idx[(idx % every == every - 1)] if every > 1 else idx
     np.savez_compressed(
@@ -306,6 +323,8 @@ def main(only=None):
         main_multi()
     if not only or "dfim" in only:
         main_dfim()
+    if not only or "wrappers" in only:
+        main_wrappers()
 
 
 def main_base():
@@ -410,6 +429,32 @@ def main_multi():
     run_case("eesm_cont_epi_held_euler", "Cont-CC-EESM-v0", "euler", 4000, 1274, "held", True, "box4")
     run_case("eesm_fin_epi_held_tau1e-4_euler", "Finite-CC-EESM-v0", "euler", 4000, 1275, "held", True, "mdisc84", tau=1e-4)
     run_case("eesm_fin_free_uniform_euler", "Finite-CC-EESM-v0", "euler", K, 1276, "uniform", False, "mdisc84")
+
+
+def main_wrappers():
+    """SURVEY 8f rank 1 (control_space='dq') and rank 2 (DqToAbcActionProcessor, DeadTimeProcessor in front of simulate())."""
+    K = 2000
+    pm, sc, ee = "Cont-CC-PMSM-v0", "Cont-SC-SCIM-v0", "Cont-CC-EESM-v0"
+    for solver in ("euler", "dopri5"):
+        run_case(f"pmsm_cont_dqspace_free_held_{solver}", pm, solver, K, 1300, "held", False, "box2", action_frame="dq")
+        run_case(f"scim_cont_dqspace_free_held_{solver}", sc, solver, K, 1301, "held", False, "box2", action_frame="dq")
+        run_case(f"pmsm_cont_dqproc_free_held_{solver}", pm, solver, K, 1302, "held", False, "box2", action_frame="dq_processor")
+        run_case(f"pmsm_cont_dqproc_dead2_free_held_{solver}", pm, solver, K, 1303, "held", False, "box2",
+                 action_frame="dq_processor", dead_time_steps=2)
+    run_case("pmsm_cont_sc_dqproc_dead1_epi_uniform_euler", "Cont-SC-PMSM-v0", "euler", K, 1304, "uniform", True, "box2",
+             action_frame="dq_processor", dead_time_steps=1)
+    run_case("synrm_cont_dqspace_free_held_euler", "Cont-CC-SynRM-v0", "euler", K, 1305, "held", False, "box2", action_frame="dq")
+    run_case("eesm_cont_dqproc_free_held_euler", ee, "euler", K, 1306, "held", False, "box3", action_frame="dq_processor")
+    run_case("eesm_cont_dqproc_dead1_epi_held_euler", ee, "euler", 4000, 1307, "held", True, "box3",
+             action_frame="dq_processor", dead_time_steps=1)
+    # DeadTimeProcessor alone: continuous and discrete actions (reset action zeros / 0), episodic -> deque refilled on reset
+    run_case("pmsm_fin_dead1_free_uniform_euler", "Finite-CC-PMSM-v0", "euler", K, 1308, "uniform", False, "disc8", dead_time_steps=1)
+    run_case("pmsm_fin_dead3_epi_held_tau1e-4_euler", "Finite-CC-PMSM-v0", "euler", 4000, 1309, "held", True, "disc8", tau=1e-4,
+             dead_time_steps=3)
+    run_case("permexdc_cont_dead2_epi_held_euler", "Cont-CC-PermExDc-v0", "euler", K, 1310, "held", True, "box1", dead_time_steps=2)
+    run_case("scim_cont_dead1_free_held_dopri5", sc, "dopri5", K, 1311, "held", False, "box3", dead_time_steps=1)
+    run_case("pmsm_fin_dead1_til_free_uniform_euler", "Finite-CC-PMSM-v0", "euler", K, 1312, "uniform", False, "disc8",
+             dead_time_steps=1, converter=dict(interlocking_time=1e-6))
 
 
 def main_dfim():

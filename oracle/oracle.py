@@ -25,7 +25,8 @@ MAX_ODE, MAX_OUT = 8, 24
 class OrcParams(C.Structure):
     _fields_ = [
         ("system", C.c_int32), ("converter", C.c_int32), ("load", C.c_int32), ("solver", C.c_int32),
-        ("nsteps", C.c_int32), ("limit_mask", C.c_int32), ("squared_mask", C.c_int32), ("reserved", C.c_int32),
+        ("nsteps", C.c_int32), ("limit_mask", C.c_int32), ("squared_mask", C.c_int32), ("dq_mode", C.c_int32),
+        ("act_delay", C.c_int32), ("pad0", C.c_int32),
         ("tau", C.c_double), ("t_il", C.c_double), ("u_sup", C.c_double),
         ("mp", C.c_double * 8),
         ("j_total", C.c_double), ("load_a", C.c_double), ("load_b", C.c_double), ("load_c", C.c_double),
@@ -120,6 +121,9 @@ def params_from_meta(meta, solver=None, episodic=None):
     for i, v in enumerate(meta["limits"]):
         p.limits[i] = v
     p.init[0] = meta.get("omega_fixed", 0.0)  # default initialisers: omega_fixed | 0, motor states 0
+    # action-side wrappers / control space recorded by make_golden.run_case
+    p.dq_mode = {"abc": 0, "dq": 1, "dq_processor": 2}[meta.get("action_frame", "abc")]
+    p.act_delay = int(meta.get("dead_time_steps", 0))
     return p
 
 
