@@ -12,11 +12,14 @@ namespace gemx {
 // reset: masked envs back to the initial ODE state; optional broadcast of the reset observation
 template <class R>
 __global__ void reset_kernel(R *state, typename Angle<R>::T *angle, const uint8_t *mask, R *obs, int64_t N, int nd, int nout,
-                             int has_angle, int obs_layout, DevParams<R> P, const R *reset_obs) {
+                             int has_angle, int obs_layout, DevParams<R> P, const R *reset_obs, unsigned char *ring, int ring_row_bytes) {
     int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= N) return;
     if (mask != nullptr && mask[env] == 0) return;
     for (int j = 0; j < nd; ++j) state[(int64_t)j * N + env] = P.init[j];
+    // DeadTimeProcessor.reset (dead_time_processor.py:63-72): the deque is refilled with the (zero) reset action
+    for (int d = 0; d < P.delay; ++d)
+        for (int b = 0; b < ring_row_bytes; ++b) ring[((int64_t)d * N + env) * ring_row_bytes + b] = 0;
     if (has_angle) angle[env] = Angle<R>::from_bits(P.init_angle_rep);
     if (obs != nullptr) {
         for (int j = 0; j < nout; ++j) {
@@ -131,6 +134,9 @@ template <class R> static void fill_params(const gemx_handle &h, const double *m
     for (int i = 0; i < h.nd; ++i) P.init[i] = (R)c.init_state[i];
     P.init_angle_rep = Angle<R>::to_bits(Angle<R>::from_rad(h.has_angle ? c.init_state[h.nd] : 0.0));
     P.nsteps = c.solver_nsteps;
+    P.dq_processor = c.action_frame == GEMX_ACT_DQ_PROCESSOR;
+    P.delay = c.action_delay;
+    P.dq_adv = (R)((0.5 + c.action_delay) * c.tau * pole);  // dq_to_abc_action_processor.py:83-86, 98-100
     P.auto_reset = c.auto_reset;
     P.obs_layout = c.obs_layout;
     // the env's default constraint gets the 3-instruction fast path (Stepper::default_done)
@@ -232,7 +238,8 @@ template <class R> static int launch_reset(gemx_handle *h, const uint8_t *mask, 
     const DevParams<R> &P = params_of<R>(h);
     int64_t blocks = (h->n + 255) / 256;
     hipLaunchKernelGGL(reset_kernel<R>, dim3((unsigned)blocks), dim3(256), 0, st, (R *)h->state, (AngT *)h->angle, mask, (R *)obs, h->n,
-                       h->nd, h->nout, h->has_angle, h->cfg.obs_layout, P, (const R *)h->reset_obs_dev);
+                       h->nd, h->nout, h->has_angle, h->cfg.obs_layout, P, (const R *)h->reset_obs_dev, (unsigned char *)h->ring,
+                       h->cfg.action_delay > 0 ? (int)(h->ring_bytes / ((size_t)h->cfg.action_delay * (size_t)h->n)) : 0);
     HIP_TRY(hipGetLastError());
     return GEMX_OK;
 }
@@ -255,11 +262,14 @@ GEMX_DECL_UNIT(6, 6, 0) GEMX_DECL_UNIT(6, 6, 1)
 GEMX_DECL_UNIT(6, 7, 0) GEMX_DECL_UNIT(6, 7, 1)
 GEMX_DECL_UNIT(7, 8, 0) GEMX_DECL_UNIT(7, 8, 1)
 GEMX_DECL_UNIT(7, 9, 0) GEMX_DECL_UNIT(7, 9, 1)
+GEMX_DECL_UNIT(1, 10, 0) GEMX_DECL_UNIT(1, 10, 1)
+GEMX_DECL_UNIT(2, 10, 0) GEMX_DECL_UNIT(2, 10, 1)
+GEMX_DECL_UNIT(6, 11, 0) GEMX_DECL_UNIT(6, 11, 1)
 #undef GEMX_DECL_UNIT
 }  // namespace gemx
 
 static int launch_advance(gemx_handle *h, const void *actions, int K, void *obs, uint8_t *done, int obs_every, hipStream_t st) {
-    const int s = h->cfg.system_kind, c = h->cfg.converter_kind, f = h->cfg.dtype == GEMX_F64;
+    const int s = h->cfg.system_kind, c = h->conv_unit, f = h->cfg.dtype == GEMX_F64;
 #define GEMX_UNIT(S, C)                                                                                     \
     if (s == S && c == C)                                                                                   \
         return f ? gemx::launch_unit_##S##_##C##_1(h, actions, K, obs, done, obs_every, st)                 \
@@ -267,6 +277,7 @@ static int launch_advance(gemx_handle *h, const void *actions, int K, void *obs,
     GEMX_UNIT(0, 0) GEMX_UNIT(1, 1) GEMX_UNIT(1, 2) GEMX_UNIT(2, 1) GEMX_UNIT(2, 2)
     GEMX_UNIT(0, 3) GEMX_UNIT(3, 0) GEMX_UNIT(3, 3) GEMX_UNIT(4, 0) GEMX_UNIT(4, 3)
     GEMX_UNIT(5, 4) GEMX_UNIT(5, 5) GEMX_UNIT(6, 6) GEMX_UNIT(6, 7) GEMX_UNIT(7, 8) GEMX_UNIT(7, 9)
+    GEMX_UNIT(1, 10) GEMX_UNIT(2, 10) GEMX_UNIT(6, 11)
 #undef GEMX_UNIT
     return fail(GEMX_ERR_ARG, "unsupported system/converter combination %d/%d", s, c);
 }
@@ -310,6 +321,17 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
                        (s == GEMX_SYS_EESM && (c == GEMX_CONV_CONT_B6_4QC || c == GEMX_CONV_FINITE_B6_4QC)) ||
                        (s == GEMX_SYS_DFIM && (c == GEMX_CONV_CONT_2XB6 || c == GEMX_CONV_FINITE_2XB6));
     if (!combo) return fail(GEMX_ERR_ARG, "unsupported system/converter combination %d/%d", s, c);
+    if (cfg->action_delay < 0 || cfg->action_delay > GEMX_MAX_DELAY)
+        return fail(GEMX_ERR_ARG, "action_delay must be in [0, %d]", GEMX_MAX_DELAY);
+    if (cfg->action_frame != GEMX_ACT_ABC) {
+        const bool space_ok = cfg->action_frame == GEMX_ACT_DQ_SPACE && (s == GEMX_SYS_SYNC || s == GEMX_SYS_SCIM) && c == GEMX_CONV_CONT_B6;
+        const bool proc_ok = cfg->action_frame == GEMX_ACT_DQ_PROCESSOR &&
+                             ((s == GEMX_SYS_SYNC && c == GEMX_CONV_CONT_B6) || (s == GEMX_SYS_EESM && c == GEMX_CONV_CONT_B6_4QC));
+        if (!space_ok && !proc_ok)
+            return fail(GEMX_ERR_ARG, "action_frame %d needs a continuous B6 converter on a synchronous / EESM system (control_space='dq' "
+                                      "also SCIM); the SCIM / DFIM dq processors need a flux observer, which is not on the accelerated path",
+                        cfg->action_frame);
+    }
     if (s == GEMX_SYS_EESM && cfg->interlocking_time > 0)
         return fail(GEMX_ERR_ARG, "interlocking_time > 0 is not supported for the EESM system (the reference's dead-time branch, "
                                   "physical_systems.py:628-638, cannot execute either)");
@@ -331,6 +353,12 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
     h->has_angle = !(dc_sys || s == GEMX_SYS_DC_EXTEX);
     h->nact = c == GEMX_CONV_CONT_B6 ? 3 : (c == GEMX_CONV_CONT_2X4QC ? 2 : (c == GEMX_CONV_CONT_B6_4QC ? 4 : (c == GEMX_CONV_CONT_2XB6 ? 6 : 1)));
     h->sw_rows = c == GEMX_CONV_FINITE_2XB6 ? 2 : 1;
+    h->nact_conv = h->nact;
+    h->conv_unit = c;
+    if (cfg->action_frame != GEMX_ACT_ABC) {  // the caller passes (u_d, u_q[, u_e]); the kernel unit is the internal dq kind
+        h->nact = h->nact_conv - 1;
+        h->conv_unit = c == GEMX_CONV_CONT_B6 ? CONV_CONT_B6_DQ : CONV_CONT_B6_4QC_DQ;
+    }
     for (int i = 0; i < h->nout; ++i)
         if (!(cfg->limits[i] > 0)) { delete h; return fail(GEMX_ERR_ARG, "limits[%d] must be positive", i); }
     if ((cfg->limit_mask | cfg->squared_mask) >> h->nout) { delete h; return fail(GEMX_ERR_ARG, "constraint mask has bits beyond S_out=%d", h->nout); }
@@ -367,6 +395,12 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
     if (h->has_angle && hipMalloc(&h->angle, (cfg->dtype == GEMX_F64 ? 8 : 4) * (size_t)h->n) != hipSuccess)
         return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(angle) failed"));
     if (hipMalloc((void **)&h->sw, (size_t)h->n * h->sw_rows) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(sw) failed"));
+    if (cfg->action_delay > 0) {
+        const bool disc = c == GEMX_CONV_FINITE_B6 || c == GEMX_CONV_FINITE_4QC || c == GEMX_CONV_FINITE_2X4QC || c == GEMX_CONV_FINITE_B6_4QC ||
+                          c == GEMX_CONV_FINITE_2XB6;
+        h->ring_bytes = (size_t)cfg->action_delay * (size_t)h->n * (disc ? 1 : (size_t)h->nact_conv * es);
+        if (hipMalloc(&h->ring, h->ring_bytes) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(delay ring) failed"));
+    }
     if (hipMalloc((void **)&h->err, sizeof(uint32_t)) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(err) failed"));
     if (hipMalloc(&h->reset_obs_dev, es * GEMX_MAX_OUT) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(reset_obs) failed"));
     if (hipMalloc(&h->cw_dev, es * 2 * GEMX_MAX_OUT) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(cw) failed"));
@@ -409,6 +443,7 @@ int gemx_destroy(gemx_handle *h) {
     if (h->state) (void)hipFree(h->state);
     if (h->angle) (void)hipFree(h->angle);
     if (h->sw) (void)hipFree(h->sw);
+    if (h->ring) (void)hipFree(h->ring);
     if (h->err) (void)hipFree(h->err);
     if (h->reset_obs_dev) (void)hipFree(h->reset_obs_dev);
     if (h->cw_dev) (void)hipFree(h->cw_dev);

@@ -44,6 +44,17 @@ template <> struct ConvTraits<GEMX_CONV_CONT_B6_4QC>   { static constexpr int NA
 template <> struct ConvTraits<GEMX_CONV_FINITE_B6_4QC> { static constexpr int NACT = 1, DISCRETE = 1, NACTIONS = 32; };
 template <> struct ConvTraits<GEMX_CONV_CONT_2XB6>     { static constexpr int NACT = 6, DISCRETE = 0, NACTIONS = 0; };
 template <> struct ConvTraits<GEMX_CONV_FINITE_2XB6>   { static constexpr int NACT = 1, DISCRETE = 1, NACTIONS = 64; };
+// internal kinds: a continuous B6 bridge whose caller-side action is (u_d, u_q[, u_e]) -- gemx_config.action_frame != ABC
+constexpr int CONV_CONT_B6_DQ = 10;      // SYNC / SCIM + Cont-B6C
+constexpr int CONV_CONT_B6_4QC_DQ = 11;  // EESM + MultiConverter(Cont-B6C, Cont-4QC)
+template <> struct ConvTraits<CONV_CONT_B6_DQ>     { static constexpr int NACT = 2, DISCRETE = 0, NACTIONS = 0; };
+template <> struct ConvTraits<CONV_CONT_B6_4QC_DQ> { static constexpr int NACT = 3, DISCRETE = 0, NACTIONS = 0; };
+template <int CONV> constexpr bool conv_dq() { return CONV == CONV_CONT_B6_DQ || CONV == CONV_CONT_B6_4QC_DQ; }
+// the converter behind the action stage, and the width of ITS action
+template <int CONV> constexpr int conv_base() {
+    return CONV == CONV_CONT_B6_DQ ? (int)GEMX_CONV_CONT_B6 : (CONV == CONV_CONT_B6_4QC_DQ ? (int)GEMX_CONV_CONT_B6_4QC : CONV);
+}
+template <int CONV> constexpr int conv_nact_c() { return ConvTraits<conv_base<CONV>()>::NACT; }
 // converters that keep per-leg switching state between steps (dead time)
 template <int CONV> constexpr bool conv_has_legs() {
     return CONV == GEMX_CONV_FINITE_B6 || CONV == GEMX_CONV_FINITE_4QC || CONV == GEMX_CONV_FINITE_2X4QC || CONV == GEMX_CONV_FINITE_2XB6;
@@ -70,6 +81,9 @@ template <class R> struct DevParams {
     int64_t init_angle_rep; // initial angle in Angle<R>::T representation (bit pattern)
     int32_t nsteps, auto_reset, obs_layout;
     int32_t constr_kind;    // 0 none, 1 the system's default constraint (fast path), 2 generic weights
+    int32_t dq_processor;   // dq action frames: 0 control_space='dq' (step-start angle), 1 DqToAbcActionProcessor (advanced angle)
+    int32_t delay;          // DeadTimeProcessor steps
+    R dq_adv;               // (0.5 + delay) * tau * pole: angle advance per rad/s of omega
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -159,6 +173,8 @@ template <class R> struct KArgs {
     const unsigned char *actions;   // [K][N][A] R  |  [K][N] uint8
     R *obs;                         // [K][N][NOUT] | [K][NOUT][N]  (or a single step's worth if !obs_every)
     uint8_t *done;                  // [K][N] | [N]
+    unsigned char *ring;            // [delay][N][A_conv] R | [delay][N] uint8: DeadTimeProcessor FIFO between launches
+    int32_t ring_phase;             // FIFO slot of this launch's first step (global step count mod delay)
     uint32_t *err;                  // device error word (bit 0: discrete action out of range)
     int64_t N;
     int32_t K, obs_every;
@@ -193,6 +209,11 @@ struct gemx_handle {
     void *angle = nullptr;   // [n] int32 | double
     uint8_t *sw = nullptr;   // [sw_rows][n]
     int sw_rows = 1;
+    void *ring = nullptr;    // DeadTimeProcessor FIFO [delay][n][nact_conv] R | [delay][n] uint8
+    size_t ring_bytes = 0;
+    int nact_conv = 1;       // converter-side action width (== nact unless a dq action frame is configured)
+    int conv_unit = 0;       // converter kind of the kernel unit (internal dq kinds included)
+    unsigned long long steps_total = 0;  // control steps launched since creation (FIFO phase)
     uint32_t *err = nullptr;
     void *reset_obs_dev = nullptr;  // [nout] R
     void *cw_dev = nullptr;         // [2][GEMX_MAX_OUT] R constraint weights

@@ -311,6 +311,35 @@ __device__ __forceinline__ void b6_voltages(const DevParams<R> &P, const R (&act
     }
 }
 
+// cos/sin of the rotor-flux angle eps_fs = atan2(psi_b, psi_a) (calculate_field_angle, physical_systems.py:765-769) without atan2
+template <class R> __device__ __forceinline__ void flux_angle(R pa, R pb, R &s, R &c) {
+    R n2 = pa * pa + pb * pb;
+    if (n2 < R(1e-30)) { pa *= R(1e18); pb *= R(1e18); n2 = pa * pa + pb * pb; }
+    const R rn = n2 > R(0) ? R(1) / sqrt(n2) : R(0);
+    c = n2 > R(0) ? pa * rn : R(1);  // atan2(0, 0) = 0
+    s = pb * rn;
+}
+
+// ------------------------------------------------------------------------------------------------
+// action stage in front of the converter (gemx_config.action_frame): (u_d, u_q[, u_e]) -> (u_a, u_b, u_c[, u_e]).
+//   control_space='dq' (physical_systems.py:491-492 / 777-778): Park angle = the step-start electrical angle (synchronous
+//     motors) or rotor-flux angle (SCIM);
+//   DqToAbcActionProcessor (dq_to_abc_action_processor.py:98-114, EESM 158-175): angle of the last returned state advanced
+//     by (0.5 + dead-time steps) * tau * omega * p.
+// ------------------------------------------------------------------------------------------------
+template <int SYS, int CONV, class R>
+__device__ __forceinline__ void dq_action_stage(const DevParams<R> &P, const R (&y)[SysTraits<SYS>::ND], typename Angle<R>::T ang,
+                                                R (&act)[MAX_ACT]) {
+    if (!conv_dq<CONV>()) return;
+    R s, c;
+    if (P.dq_processor) Angle<R>::sincos(Angle<R>::advance(ang, P.dq_adv * y[0]), s, c);
+    else if (SYS == GEMX_SYS_SCIM) flux_angle<R>(y[SysTraits<SYS>::ND - 2], y[SysTraits<SYS>::ND - 1], s, c);
+    else Angle<R>::sincos(ang, s, c);
+    const R ud = act[0], uq = act[1], ue = act[2];
+    t32(c * ud - s * uq, s * ud + c * uq, act[0], act[1], act[2]);
+    if (CONV == CONV_CONT_B6_4QC_DQ) act[3] = ue;
+}
+
 // ------------------------------------------------------------------------------------------------
 // one control step of one env, in two halves so that they can run in different waves (advance_pipe_kernel):
 //   advance(): converter -> voltages -> ODE integration -> new (y, ang, sw); leaves in ho[] what observe() needs
@@ -563,14 +592,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
 template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_SCIM, CONV, LOAD, SOLVER, IL, R> {
     using AngT = typename Angle<R>::T;
     static constexpr int NH = 7;  // ho: sin, cos of the last segment-start field angle, u_a, u_b, u_c, u_alpha, u_beta
-    // cos/sin of the rotor-flux angle eps_fs = atan2(psi_b, psi_a) (calculate_field_angle, 765-769) without atan2
-    static __device__ __forceinline__ void field_angle(R pa, R pb, R &s, R &c) {
-        R n2 = pa * pa + pb * pb;
-        if (n2 < R(1e-30)) { pa *= R(1e18); pb *= R(1e18); n2 = pa * pa + pb * pb; }
-        const R rn = n2 > R(0) ? R(1) / sqrt(n2) : R(0);
-        c = n2 > R(0) ? pa * rn : R(1);  // atan2(0, 0) = 0
-        s = pb * rn;
-    }
+    static __device__ __forceinline__ void field_angle(R pa, R pb, R &s, R &c) { flux_angle<R>(pa, pb, s, c); }
     template <bool NS1 = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[5], AngT &ang, uint32_t &sw, const R (&act)[MAX_ACT],
                                                    uint32_t dact, R (&ho)[NH]) {
@@ -817,12 +839,13 @@ template <bool COOP, int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R>
 __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTraits<SYS>::ND], typename Angle<R>::T &ang, uint32_t &sw,
                                               R (&obs)[SysTraits<SYS>::NOUT], uint32_t &done_or, uint32_t &bad_action, R *ring,
                                               const unsigned char *atile, unsigned char *donebuf, int k0, int sb, int tid,
-                                              int64_t e, typename Angle<R>::T init_ang) {
+                                              int64_t e, typename Angle<R>::T init_ang, R *fifo, int &slot) {
     constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
     constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
     constexpr int ABYTES = DISCRETE ? 1 : NACT * (int)sizeof(R);
     constexpr int ROWB = BLOCK * ABYTES;
-    using ST = Stepper<SYS, CONV, LOAD, SOLVER, IL, R>;
+    using ST = Stepper<SYS, conv_base<CONV>(), LOAD, SOLVER, IL, R>;
+    constexpr int NACTC = conv_nact_c<CONV>();  // converter-side action width (FIFO entries)
     const DevParams<R> &P = a.P;
     // Software pipeline (COOP): the action of step s+1 is read from LDS while step s computes, and the observation
     // row of step s is written to the ring at the top of iteration s+1, so the only LDS wait of an iteration (for the
@@ -867,6 +890,22 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
         if (a.obs_every && s > 0) write_ring(s - 1, pdone);       // row of the previous step (obs still holds it)
         if (COOP && s + 1 < sb) read_action(s + 1, nact, ndact);   // prefetch (LDS only; global loads would add vmcnt waits)
         if (DISCRETE) { bad_action |= dact >= (uint32_t)ConvTraits<CONV>::NACTIONS; dact &= (uint32_t)(ConvTraits<CONV>::NACTIONS - 1); }
+        // wrapper order of the reference: [DqToAbcActionProcessor [DeadTimeProcessor [system(control_space)]]] -- the processor
+        // transforms BEFORE the delay queue, a system built with control_space='dq' transforms the delayed (u_d, u_q) AFTER it
+        if (conv_dq<CONV>() && P.dq_processor) dq_action_stage<SYS, CONV, R>(P, y, ang, act);
+        if (P.delay > 0) {  // DeadTimeProcessor.simulate (dead_time_processor.py:74-85): swap with the FIFO slot of this step
+            R *f = fifo + ((size_t)slot * BLOCK + tid) * NACTC;
+            if (DISCRETE) {
+                const uint32_t old = (uint32_t)f[0];  // small integers are exact in R
+                f[0] = (R)dact;
+                dact = old;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NACTC; ++i) { const R old = f[i]; f[i] = act[i]; act[i] = old; }
+            }
+            slot = slot + 1 == P.delay ? 0 : slot + 1;
+        }
+        if (conv_dq<CONV>() && !P.dq_processor) dq_action_stage<SYS, CONV, R>(P, y, ang, act);
         full_step<ST, ND, NOUT, R>(P, y, ang, sw, act, dact, obs);
         const bool done = constraint_done<ST, NOUT, R>(P, obs);
         done_or |= done ? 1u : 0u;
@@ -875,6 +914,10 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
 #pragma unroll
             for (int j = 0; j < ND; ++j) y[j] = P.init[j];
             ang = init_ang;
+            for (int d = 0; d < P.delay; ++d) {  // DeadTimeProcessor.reset: the deque is refilled with the reset action
+#pragma unroll
+                for (int i = 0; i < NACTC; ++i) fifo[((size_t)d * BLOCK + tid) * NACTC + i] = R(0);
+            }
         }
         if (!COOP && s + 1 < sb) read_action(s + 1, nact, ndact);
     }
@@ -925,6 +968,10 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
     R *ring = reinterpret_cast<R *>(gemx_smem);
     unsigned char *actbuf = gemx_smem + (size_t)S * BLOCK * NOUT * sizeof(R);
     unsigned char *donebuf = actbuf + 2 * (size_t)S * ROWB;
+    constexpr int NACTC = conv_nact_c<CONV>();
+    // DeadTimeProcessor FIFO [delay][64][NACTC] R behind the (16-byte padded) done ring
+    R *fifo = reinterpret_cast<R *>(donebuf + (((size_t)S * BLOCK + 15) & ~(size_t)15));
+    int slot = a.ring_phase;
     const bool coop = a.coop && full && K > 1;   // cooperative action staging for this workgroup (uniform)
 
     R y[ND];
@@ -939,6 +986,13 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
         if (conv_sw_bytes<CONV>() == 2) sw |= (uint32_t)a.sw[N + e] << 8;
     }
     const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
+    for (int d = 0; d < P.delay; ++d) {  // this lane's FIFO entries (only this lane ever touches them)
+#pragma unroll
+        for (int i = 0; i < NACTC; ++i) {
+            const int64_t gi = ((int64_t)d * N + e) * NACTC + i;
+            fifo[((size_t)d * BLOCK + tid) * NACTC + i] = DISCRETE ? (R)a.ring[gi] : reinterpret_cast<const R *>(a.ring)[gi];
+        }
+    }
 
     // per-lane 16-byte loads of one action tile (steps [k0, k0+sb)) into registers: tile_load / tile_park below
     V tile[NCH];
@@ -990,8 +1044,8 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
 
         // 2. compute: no global memory traffic in here when coop
         const unsigned char *atile = actbuf + (size_t)half * S * ROWB;
-        if (coop) compute_block<true, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang);
-        else compute_block<false, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang);
+        if (coop) compute_block<true, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot);
+        else compute_block<false, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot);
         __syncthreads();
 
         // 3. park the prefetched tile
@@ -1024,6 +1078,15 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
             a.sw[env] = (uint8_t)sw;
             if (conv_sw_bytes<CONV>() == 2) a.sw[N + env] = (uint8_t)(sw >> 8);
         }
+        for (int d = 0; d < P.delay; ++d) {
+#pragma unroll
+            for (int i = 0; i < NACTC; ++i) {
+                const int64_t gi = ((int64_t)d * N + env) * NACTC + i;
+                const R v = fifo[((size_t)d * BLOCK + tid) * NACTC + i];
+                if (DISCRETE) a.ring[gi] = (unsigned char)(uint32_t)v;
+                else reinterpret_cast<R *>(a.ring)[gi] = v;
+            }
+        }
     }
     if (bad_action && valid) atomicOr(a.err, 1u);
 #undef GEMX_TILE_LOAD
@@ -1051,7 +1114,7 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
     constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
     constexpr bool HAS_ANGLE = SysTraits<SYS>::HAS_ANGLE;
     using AngT = typename Angle<R>::T;
-    using ST = Stepper<SYS, CONV, LOAD, SOLVER, IL, R>;
+    using ST = Stepper<SYS, conv_base<CONV>(), LOAD, SOLVER, IL, R>;
     constexpr int NH = ST::NH;
     constexpr int NHT = ND + (HAS_ANGLE ? 1 : 0) + NH + 1;  // hand-off row: y, angle bits, ho, done
 
@@ -1118,6 +1181,7 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
 #pragma unroll
             for (int i = 0; i < MAX_ACT; ++i) act[i] = i < NACT ? act_in[i] : R(0);
             if (DISCRETE) { bad_action |= dact >= (uint32_t)ConvTraits<CONV>::NACTIONS; dact &= (uint32_t)(ConvTraits<CONV>::NACTIONS - 1); }
+            dq_action_stage<SYS, CONV, R>(P, y, ang, act);
             R ho[NH];
             ST::template advance<true>(P, y, ang, sw, act, dact, ho);  // launcher guarantees solver_nsteps == 1
             const bool done = ST::state_done(P, y, ho) & check_default;
@@ -1243,6 +1307,7 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
 // number of workgroups that should be co-resident per CU, capped by the per-lane action-prefetch registers.
 inline int choose_steps_per_block(const gemx_handle *h, int K, int es, int abytes) {
     if (K <= 1) return 1;
+    const size_t lds_max = h->lds_max - (size_t)h->cfg.action_delay * BLOCK * h->nact_conv * es - 64;  // minus the DeadTimeProcessor FIFO
     const size_t per_step = (size_t)BLOCK * h->nout * es + 2 * (size_t)BLOCK * abytes + BLOCK;
     int S = h->steps_per_block;
     if (S <= 0) {
@@ -1250,13 +1315,13 @@ inline int choose_steps_per_block(const gemx_handle *h, int K, int es, int abyte
         int64_t per_cu = (nblocks + h->n_cu - 1) / h->n_cu;
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 16) per_cu = 16;
-        S = (int)((h->lds_max - 1024) / per_cu / per_step);
+        S = (int)((lds_max - 1024) / per_cu / per_step);
         if (S > MAX_STEPS_PER_BLOCK) S = MAX_STEPS_PER_BLOCK;
     }
     const int cpr = BLOCK * abytes / 16;
     const int s_regs = act_chunks(cpr) * BLOCK / cpr;  // steps whose action rows fit the per-lane prefetch registers
     if (S > s_regs) S = s_regs;
-    const int s_lds = (int)((h->lds_max - 256) / per_step);
+    const int s_lds = (int)((lds_max - 256) / per_step);
     if (S > s_lds) S = s_lds;
     if (S > K) S = K;
     if (S < 1) S = 1;
@@ -1274,6 +1339,10 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     a.actions = (const unsigned char *)actions;
     a.obs = (R *)obs;
     a.done = done;
+    a.ring = (unsigned char *)h->ring;
+    const int delay = h->cfg.action_delay;
+    a.ring_phase = delay > 0 ? (int)(h->steps_total % (unsigned long long)delay) : 0;
+    h->steps_total += (unsigned long long)K;
     a.err = h->err;
     a.N = h->n;
     a.K = K;
@@ -1286,12 +1355,13 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     a.obs_vec = (((size_t)h->n * h->nout * sizeof(R)) % 16 == 0) ? 1 : 0;
     size_t smem = (size_t)a.S * BLOCK * h->nout * sizeof(R) + 2 * (size_t)a.S * BLOCK * ABYTES + (size_t)a.S * BLOCK;
     smem = (smem + 15) & ~(size_t)15;
+    smem += (size_t)delay * BLOCK * conv_nact_c<CONV>() * sizeof(R);  // DeadTimeProcessor FIFO
     const int64_t blocks = (h->n + BLOCK - 1) / BLOCK;
     // two-wave pipelined kernel for small N (the chip is not full: a single wave per SIMD is issue-bound)
     const bool pipe_ok = h->use_pipe != 0 && K >= 2 && obs_every && a.coop && a.obs_vec && (h->n % BLOCK) == 0 &&
-                         params_of<R>(h).constr_kind <= 1 && h->cfg.solver_nsteps == 1;
+                         params_of<R>(h).constr_kind <= 1 && h->cfg.solver_nsteps == 1 && delay == 0;
     if (pipe_ok) {
-        using ST = Stepper<SYS, CONV, LOAD, SOLVER, IL, R>;
+        using ST = Stepper<SYS, conv_base<CONV>(), LOAD, SOLVER, IL, R>;
         constexpr int NHT = SysTraits<SYS>::ND + (SysTraits<SYS>::HAS_ANGLE ? 1 : 0) + ST::NH + 1;
         // hand-off depth: 8 steps per barrier when one resident round of workgroups covers N, else 4 (half the LDS ->
         // twice the resident workgroups).  Small-N regime only: at most two rounds of resident workgroups.

@@ -142,8 +142,14 @@ class BatchedElectricMotorEnv:
 
 
 def make(env_id, n_envs=1, device=0, supply=None, converter=None, motor=None, load=None, ode_solver=None, tau=None,
-         constraints=None, dtype="float32", auto_reset=None, obs_layout="aos", **kwargs):
-    """Build a batched env.  Component arguments follow the reference's env-arg convention (instance | dict | None)."""
+         constraints=None, dtype="float32", auto_reset=None, obs_layout="aos", physical_system_wrappers=(), **kwargs):
+    """Build a batched env.  Component arguments follow the reference's env-arg convention (instance | dict | None).
+    physical_system_wrappers: reference-style tuple (innermost first) of DeadTimeProcessor / DqToAbcActionProcessor holders
+    (or the reference's own instances); they are folded into the kernel's action stage."""
+    from .physical_system_wrappers import fold_wrappers
+
+    if physical_system_wrappers:
+        kwargs = dict(kwargs, **fold_wrappers(physical_system_wrappers))
     d = default_components(env_id)
     tau = d["tau"] if tau is None else tau
     conv_cls = d["converter"]

@@ -86,7 +86,8 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
     _SYSTEM_KIND = None
 
     def __init__(self, converter, motor, load, supply, ode_solver, tau=1e-4, calc_jacobian=None, n_envs=1, device=0,
-                 dtype="float32", constraints=(), auto_reset=None, obs_layout="aos", control_space="abc", _defer_create=False):
+                 dtype="float32", constraints=(), auto_reset=None, obs_layout="aos", control_space="abc", action_frame=None,
+                 action_delay=0, _defer_create=False):
         """
         Args (first six as in SCMLSystem.__init__, physical_systems.py:54-65):
             converter, motor, load, supply: component instances (this package's or the reference's).
@@ -102,9 +103,23 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             auto_reset(bool): restart an env from its initial state on the step after `done`.
                 Default: True when n_envs > 1 and constraints are given, else False.
             obs_layout: 'aos' -> observations [N, S_out] (reference contract); 'soa' -> [S_out, N].
+            control_space: 'abc' | 'dq' as in SynchronousMotorSystem / SquirrelCageInductionMotorSystem
+                (physical_systems.py:423-435, 701-710): actions are (u_d, u_q) in the step-start (field) angle's frame.
+            action_frame: None (from control_space) | 'abc' | 'dq' | 'dq_processor' -- the latter is the reference's
+                DqToAbcActionProcessor wrapper folded into the kernel (angle advanced by 0.5 + action_delay steps).
+            action_delay(int): DeadTimeProcessor(steps) folded into the kernel: the converter sees the action submitted
+                `action_delay` steps earlier (zero action right after a reset).
         """
-        if control_space != "abc":
-            raise NotImplementedError("control_space='dq' is not on the accelerated path yet (SURVEY.md 8f rank 1)")
+        if control_space not in ("abc", "dq"):
+            raise ValueError(f"control_space must be 'abc' or 'dq', got {control_space!r}")
+        if action_frame is None:
+            action_frame = "dq" if control_space == "dq" else "abc"
+        if action_frame not in ("abc", "dq", "dq_processor"):
+            raise ValueError(f"action_frame must be 'abc', 'dq' or 'dq_processor', got {action_frame!r}")
+        self._action_frame = action_frame
+        self._action_delay = int(action_delay)
+        if not 0 <= self._action_delay <= _lib.MAX_DELAY:
+            raise ValueError(f"action_delay must be in [0, {_lib.MAX_DELAY}]")
         self._converter = converter
         self._electrical_motor = motor
         self._mechanical_load = load
@@ -124,7 +139,13 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         state_names = self._build_state_names()
         self._set_indices()
         # PhysicalSystem.__init__ (core.py:662-676)
-        _PhysicalSystemBase.__init__(self, self._converter.action_space, None, state_names, tau)
+        action_space = self._converter.action_space
+        if action_frame != "abc":
+            # physical_systems.py:431-435: dq-control space is only available for continuous converters
+            assert isinstance(action_space, Box), "dq-control space is only available for Continuous Controlled Converters"
+            n_dq = int(action_space.shape[0]) - 1  # (u_a, u_b, u_c[, u_e]) -> (u_d, u_q[, u_e])
+            action_space = Box(-1, 1, shape=(n_dq,), dtype=np.float64)
+        _PhysicalSystemBase.__init__(self, action_space, None, state_names, tau)
         self._state_space = self._build_state_space(state_names)
         self._limits = np.zeros(len(state_names), dtype=float)
         self._nominal_state = np.zeros(len(state_names), dtype=float)
@@ -150,6 +171,7 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
     mechanical_load = property(lambda self: self._mechanical_load)
     n_envs = property(lambda self: self._n_envs)
     device = property(lambda self: self._device)
+    dead_time = property(lambda self: self._action_delay)  # DeadTimeProcessor.dead_time (dead_time_processor.py:43-46)
 
     def _set_limits(self):
         """physical_systems.py:105-113."""
@@ -319,6 +341,17 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         cfg.obs_layout = {"aos": _lib.OBS_AOS, "soa": _lib.OBS_SOA}[self._obs_layout]
         cfg.auto_reset = int(self._auto_reset)
         cfg.limit_mask, cfg.squared_mask = limit_mask, squared_mask
+        cfg.action_frame = {"abc": _lib.ACT_ABC, "dq": _lib.ACT_DQ_SPACE, "dq_processor": _lib.ACT_DQ_PROCESSOR}[self._action_frame]
+        cfg.action_delay = self._action_delay
+        if self._action_frame != "abc":
+            sysk, convk = self._SYSTEM_KIND, self._converter_kind()
+            ok = (self._action_frame == "dq" and sysk in (_lib.SYS_SYNC, _lib.SYS_SCIM) and convk == _lib.CONV_CONT_B6) or \
+                 (self._action_frame == "dq_processor" and ((sysk == _lib.SYS_SYNC and convk == _lib.CONV_CONT_B6) or
+                                                           (sysk == _lib.SYS_EESM and convk == _lib.CONV_CONT_B6_4QC)))
+            if not ok:  # (gemx_create refuses it as well)
+                raise ValueError(f"action_frame={self._action_frame!r} is not available for {type(self).__name__} with a "
+                                 f"{type(self._converter).__name__}: control_space='dq' needs a synchronous or squirrel-cage system, "
+                                 "the dq processor a synchronous or EESM system, both a continuous B6 converter")
         cfg.tau = float(self.tau)
         cfg.interlocking_time = self._interlocking_time()
         cfg.u_nominal = float(self._supply.u_nominal)

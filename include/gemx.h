@@ -75,6 +75,8 @@ typedef enum { GEMX_SOLVER_EULER = 0, GEMX_SOLVER_RK4 = 1, GEMX_SOLVER_DP5 = 2 }
 typedef enum { GEMX_F32 = 0, GEMX_F64 = 1 } gemx_dtype;
 /* observation layout: [N, S_out] rows per env (the reference contract) or [S_out, N] */
 typedef enum { GEMX_OBS_AOS = 0, GEMX_OBS_SOA = 1 } gemx_obs_layout;
+typedef enum { GEMX_ACT_ABC = 0, GEMX_ACT_DQ_SPACE = 1, GEMX_ACT_DQ_PROCESSOR = 2 } gemx_action_frame;
+#define GEMX_MAX_DELAY 8
 
 /* Flat description of ONE SCML system shared by all N envs of a handle (parameters are uniform across envs:
  * they travel as kernel arguments -> SGPRs, 0 bytes of HBM traffic per env). */
@@ -87,6 +89,18 @@ typedef struct gemx_config {
     int32_t auto_reset;    /* 1: an env whose step ended `done` restarts from init_state on its next step */
     uint32_t limit_mask;   /* LimitConstraint:   done if any |obs[i]| > 1      over set bits (constraints.py:55-58) */
     uint32_t squared_mask; /* SquaredConstraint: done if sum obs[i]^2 > 1      over set bits (constraints.py:96-98) */
+    /* Action path in front of simulate() (continuous B6 converters of SYNC / SCIM / EESM systems only for the dq frames):
+     *   GEMX_ACT_ABC          actions are the converter's own (default);
+     *   GEMX_ACT_DQ_SPACE     system built with control_space='dq' (physical_systems.py:423-435, 491-492, 777-778):
+     *                         A = 2, abc = T32(Q(a_dq, eps)) with the step-start (field) angle; SYNC and SCIM;
+     *   GEMX_ACT_DQ_PROCESSOR DqToAbcActionProcessor around the system (physical_system_wrappers/
+     *                         dq_to_abc_action_processor.py:100-114; EESM 158-175): A = 2 (SYNC) | 3 (EESM: u_d, u_q, u_e),
+     *                         abc = T32(Q(a_dq, eps + (0.5 + action_delay) * tau * omega * p)).
+     * action_delay = DeadTimeProcessor(steps) INSIDE the dq processor (dead_time_processor.py:63-85): the converter
+     * receives the action submitted action_delay steps earlier; the per-env FIFO is refilled with the zero action
+     * by every reset (default reset_actions).  Any system / converter; 0 = none, max GEMX_MAX_DELAY. */
+    int32_t action_frame;
+    int32_t action_delay;
     double tau;               /* control step, PhysicalSystem.tau */
     double interlocking_time; /* converter dead time, converters.py:35-41; must be < tau */
     double u_nominal;         /* IdealVoltageSupply.u_nominal, voltage_supplies.py:60-72 */
@@ -128,7 +142,7 @@ int gemx_destroy(gemx_handle *h);
 int gemx_n_envs(const gemx_handle *h, int64_t *n);
 int gemx_n_ode(const gemx_handle *h);    /* S_ode: 2 | 3 | 4 | 5 | 6  */
 int gemx_n_out(const gemx_handle *h);    /* S_out: 5 | 6 | 7 | 14 | 16 | 24 */
-int gemx_n_action(const gemx_handle *h); /* A: 1 | 2 | 3 | 4 | 6 (1 for every discrete converter) */
+int gemx_n_action(const gemx_handle *h); /* A: 1 | 2 | 3 | 4 | 6 (1 for every discrete converter; dq frames: 2 | 3) */
 int gemx_action_itemsize(const gemx_handle *h); /* 1 (uint8 discrete) | sizeof(R) */
 /* normalised state returned by reset() for the configured constant initialiser, host doubles [S_out] */
 int gemx_reset_observation(const gemx_handle *h, double *obs_host);

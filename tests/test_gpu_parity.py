@@ -53,6 +53,17 @@ def _make_from_meta(meta, n_envs, solver=None, dtype="float32", episodic=None, o
     epi = meta["episodic"] if episodic is None else episodic
     if not epi:
         kw["constraints"] = ()
+    # action-side wrappers / control space recorded by oracle/make_golden.py:run_case
+    frame = meta.get("action_frame", "abc")
+    wrappers = []
+    if meta.get("dead_time_steps", 0):
+        wrappers.append(ga.DeadTimeProcessor(steps=meta["dead_time_steps"]))
+    if frame == "dq_processor":
+        wrappers.append(ga.DqToAbcActionProcessor.make("EESM" if "EESM" in meta["env_id"] else "PMSM"))
+    if wrappers:
+        kw["physical_system_wrappers"] = tuple(wrappers)
+    if frame == "dq":
+        kw["control_space"] = "dq"
     return ga.make(meta["env_id"], **kw)
 
 
@@ -319,6 +330,75 @@ def test_two_wave_pipelined_kernel_matches_reference_and_single_wave_kernel(name
     assert (rel < 1e-4) if dtype == "float32" else (ab < 1e-9)
     if meta["episodic"]:
         _check_done(meta, d, done_p)
+
+
+@pytest.mark.parametrize("env_id, wrappers, control_space", [
+    ("Cont-CC-PMSM-v0", ("dead2", "dq"), "abc"), ("Finite-CC-PMSM-v0", ("dead3",), "abc"), ("Cont-SC-SCIM-v0", ("dead1",), "dq"),
+    ("Cont-CC-EESM-v0", ("dead1", "dq"), "abc"), ("Finite-CC-DFIM-v0", ("dead2",), "abc"), ("Cont-CC-PermExDc-v0", ("dead1",), "abc"),
+    ("Cont-CC-SynRM-v0", ("dq",), "abc"),
+])
+def test_action_stage_chunking_and_single_step_are_bit_identical(env_id, wrappers, control_space):
+    """DeadTimeProcessor FIFO / dq action stage across launches: one K-step rollout == the same steps in uneven chunks ==
+    step-by-step simulate() (the FIFO lives in HBM between launches), bit for bit, with per-env random actions, episodic
+    (auto-reset refills the FIFO), odd env count (tail workgroup); and the oracle agrees on a sample of envs."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+    from oracle import oracle as orc
+
+    K, n = 96, 200
+
+    def mk():
+        ws = []
+        for w in wrappers:
+            if w.startswith("dead"):
+                ws.append(ga.DeadTimeProcessor(steps=int(w[4:])))
+            else:
+                ws.append(ga.DqToAbcActionProcessor.make("EESM" if "EESM" in env_id else "PMSM"))
+        return ga.make(env_id, n_envs=n, ode_solver=ga.RK4Solver(), physical_system_wrappers=tuple(ws), control_space=control_space)
+
+    env = mk()
+    ps = env.physical_system
+    g = torch.Generator(device="cuda").manual_seed(99)
+    if ps._discrete:
+        nflat = int(np.prod(ps.action_space.nvec)) if hasattr(ps.action_space, "nvec") else int(ps.action_space.n)
+        acts = torch.randint(0, nflat, (K, n), device="cuda", generator=g, dtype=torch.uint8)
+    else:
+        acts = torch.rand((K, n, ps._n_act), device="cuda", generator=g) * 2 - 1
+    obs, done = env.rollout(acts)
+    e2 = mk()
+    parts, k0 = [], 0
+    for kk in (1, 7, 2, 30, 56):
+        parts.append(e2.rollout(acts[k0:k0 + kk]))
+        k0 += kk
+    assert torch.equal(torch.cat([p[0] for p in parts]), obs) and torch.equal(torch.cat([p[1] for p in parts]), done)
+    e3 = mk()
+    for k in range(12):
+        assert torch.equal(e3.physical_system.simulate(acts[k]), obs[k])
+        assert torch.equal(e3.physical_system.done, done[k])
+    # oracle (same integrator, same wrappers) on a few envs
+    golden = {"PMSM": "pmsm_cont_dqproc_free_held_euler", "SCIM": "scim_cont_dqspace_free_held_euler", "EESM": "eesm_cont_dqproc_free_held_euler",
+              "DFIM": "dfim_fin_free_held_euler", "PermExDc": "permexdc_free_held_euler", "SynRM": "synrm_cont_dqspace_free_held_euler"}
+    key = env_id.split("-")[2]
+    _, meta = _load(golden[key] if not env_id.startswith("Finite-CC-PMSM") else "pmsm_free_held_euler")
+    meta = dict(meta, episodic=True, dead_time_steps=sum(int(w[4:]) for w in wrappers if w.startswith("dead")),
+                action_frame="dq_processor" if "dq" in wrappers else ("dq" if control_space == "dq" else "abc"))
+    p = orc.params_from_meta(meta, solver="rk4", episodic=True)
+    a_host = acts.cpu().numpy().astype(np.float64)
+    if ps._discrete and hasattr(ps.action_space, "nvec"):
+        n0 = int(ps.action_space.nvec[0])
+        a_host = np.stack([a_host % n0, a_host // n0], axis=-1)
+    o_host, d_host = obs.double().cpu().numpy(), done.cpu().numpy().astype(bool)
+    for j in (0, 64, n - 1):
+        e = orc.OracleEnv(p)
+        e.reset()
+        ref, rdone = e.rollout(a_host[:, j], auto_reset=True)
+        first = int(np.argmax(rdone != d_host[:, j])) if (rdone != d_host[:, j]).any() else K
+        rel, _ = _rel_err(o_host[:first + 1, j], ref[:first + 1], meta["state_names"], scale_ref=ref)
+        assert rel < 1e-4, (j, rel)
+        assert first >= K or first > 0  # a done flip (fp32 vs fp64 at the limit) may end the comparison, never at step 0
+    for e_ in (env, e2, e3):
+        e_.close()
 
 
 def test_obs_layouts_agree_and_tail_block():

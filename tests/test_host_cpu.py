@@ -120,8 +120,15 @@ def test_unsupported_pieces_raise():
         ga.make("Cont-CC-PermExDc-v0", n_envs=2, ode_solver=ScipyOdeSolver(), _defer_create=True)
     with pytest.raises(KeyError):  # update_parameter_dict semantics, utils.py:73-94
         ga.DcPermanentlyExcitedMotor(motor_parameter=dict(r_x=1.0))
-    with pytest.raises(NotImplementedError):
-        ga.make("Cont-CC-PMSM-v0", n_envs=2, control_space="dq", _defer_create=True)
+    with pytest.raises(AssertionError, match="only available for Continuous"):  # physical_systems.py:431-434
+        ga.make("Finite-CC-PMSM-v0", n_envs=2, control_space="dq", _defer_create=True)
+    with pytest.raises(ValueError, match="action_frame"):  # a DC system has no dq frame
+        ga.make("Cont-CC-ExtExDc-v0", n_envs=2, control_space="dq", _defer_create=True)
+    with pytest.raises(NotImplementedError, match="flux observer"):
+        ga.DqToAbcActionProcessor.make("SCIM")
+    with pytest.raises(ValueError, match="INSIDE"):
+        ga.make("Cont-CC-PMSM-v0", n_envs=2, _defer_create=True,
+                physical_system_wrappers=(ga.DqToAbcActionProcessor.make("PMSM"), ga.DeadTimeProcessor(1)))
 
 
 def test_c_abi_argument_validation_without_gpu():
@@ -152,6 +159,28 @@ def test_c_abi_argument_validation_without_gpu():
     bad = _lib.GemxConfig.from_buffer_copy(eesm)
     bad.model[2 * _lib.MODEL_COLS + 2] = 1.0  # d(i_e)/dt has no i_q term
     assert L.gemx_create(C.byref(bad), 4, 0, C.byref(h)) == -1 and b"sparsity" in L.gemx_last_error()
+
+
+def test_action_stage_config():
+    """control_space='dq', DqToAbcActionProcessor and DeadTimeProcessor fold into gemx_config.action_frame / action_delay."""
+    ps = ga.make("Cont-CC-PMSM-v0", n_envs=2, control_space="dq", _defer_create=True).physical_system
+    assert ps._cfg.action_frame == _lib.ACT_DQ_SPACE and ps._cfg.action_delay == 0 and ps.action_space.shape == (2,)
+    ps = ga.make("Cont-SC-SCIM-v0", n_envs=2, control_space="dq", _defer_create=True).physical_system
+    assert ps._cfg.action_frame == _lib.ACT_DQ_SPACE and ps.action_space.shape == (2,)
+    ps = ga.make("Cont-CC-EESM-v0", n_envs=2, _defer_create=True,
+                 physical_system_wrappers=(ga.DeadTimeProcessor(steps=2), ga.DqToAbcActionProcessor.make("EESM"))).physical_system
+    assert ps._cfg.action_frame == _lib.ACT_DQ_PROCESSOR and ps._cfg.action_delay == 2 and ps.action_space.shape == (3,)
+    assert ps.dead_time == 2
+    ps = ga.make("Finite-CC-DFIM-v0", n_envs=2, _defer_create=True, physical_system_wrappers=(ga.DeadTimeProcessor(3),)).physical_system
+    assert ps._cfg.action_frame == _lib.ACT_ABC and ps._cfg.action_delay == 3 and list(ps.action_space.nvec) == [8, 8]
+    L = _lib.load()
+    h = C.c_void_p()
+    bad = _lib.GemxConfig.from_buffer_copy(ps._cfg)
+    bad.action_delay = 99
+    assert L.gemx_create(C.byref(bad), 4, 0, C.byref(h)) == -1 and b"action_delay" in L.gemx_last_error()
+    bad = _lib.GemxConfig.from_buffer_copy(ps._cfg)
+    bad.action_frame = _lib.ACT_DQ_PROCESSOR
+    assert L.gemx_create(C.byref(bad), 4, 0, C.byref(h)) == -1 and b"action_frame" in L.gemx_last_error()
 
 
 def test_multi_converter_holders():
