@@ -872,6 +872,18 @@ void orc_rollout_many(const orc_params *p, int n_env, const double *actions, int
     if (n_done) *n_done = nd;
 }
 
+/* WeightedSumOfErrors.reward, reward_functions/weighted_sum_of_errors.py:125-129:
+ *   (1 - v) * (-sum_i w_i * (|s_i - ref_i| / len_i) ** n_i + bias) + v * violation_reward,  v = violation degree (0 | 1).
+ * `reference` is the generator's full-length array (zero at un-referenced states, core.py:346). */
+double orc_reward(int n, const double *weights, const double *powers, const double *state_length, double bias,
+                  double violation_reward, const double *state, const double *reference, int violated) {
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) acc += weights[i] * pow(fabs(state[i] - reference[i]) / state_length[i], powers[i]);
+    double wse = -acc + bias;
+    double v = violated ? 1.0 : 0.0;
+    return (1.0 - v) * wse + v * violation_reward;
+}
+
 /* Bare pieces exported for known-answer tests */
 double orc_kat_poly_load(const orc_params *p, double omega, double torque) { return mechanical_ode(p, omega, torque); }
 size_t orc_sizeof_params(void) { return sizeof(orc_params); }

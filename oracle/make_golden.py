@@ -123,8 +123,34 @@ def describe(env):
     return meta
 
 
+class _StepRecorder:
+    """gym_electric_motor.core.Callback-shaped recorder of the reference the reward was computed against (core.py:346-362)."""
+
+    def __init__(self):
+        self.references, self.rewards = [], []
+
+    def set_env(self, env):
+        pass
+
+    def on_reset_begin(self):
+        pass
+
+    def on_reset_end(self, *_):
+        pass
+
+    def on_step_begin(self, *_):
+        pass
+
+    def on_step_end(self, k, state, reference, reward, terminated):
+        self.references.append(np.array(reference, dtype=float))
+        self.rewards.append(float(reward))
+
+    def on_close(self):
+        pass
+
+
 def run_case(name, env_id, solver, K, seed, mode, episodic, space_kind, every=1, action_frame="abc", dead_time_steps=0,
-             **make_kwargs):
+             record_reward=False, **make_kwargs):
     """action_frame: 'abc' | 'dq' (system.control_space = 'dq') | 'dq_processor' (DqToAbcActionProcessor wrapper);
     dead_time_steps > 0: DeadTimeProcessor(steps) wrapped INSIDE the dq processor, as the reference's processors expect."""
     from gym_electric_motor.physical_system_wrappers import DeadTimeProcessor, DqToAbcActionProcessor
@@ -140,11 +166,14 @@ def run_case(name, env_id, solver, K, seed, mode, episodic, space_kind, every=1,
     kw["ode_solver"] = make_solver(solver)
     if not episodic:
         kw["constraints"] = ()
+    recorder = _StepRecorder()
+    if record_reward:
+        kw["callbacks"] = (recorder,)
     env = gem.make(env_id, **kw)
     if action_frame == "dq":  # no env class forwards control_space; the attribute is read at simulate() time (lines 491, 777)
         env.physical_system.unwrapped.control_space = "dq"
     if action_frame != "abc":
-        env._callbacks = []  # the default dashboard's action plots index three abc actions; plotting is not on the path
+        env._callbacks = [recorder] if record_reward else []  # the default dashboard's action plots index three abc actions
     (s0, _), _ = env.reset(seed=0)
     # physical-system wrappers that only post-process the observation (e.g. the shunt envs' CurrentSumProcessor, which
     # appends 'i_sum') are outside the path: keep the columns of the unwrapped physical system
@@ -170,8 +199,18 @@ def run_case(name, env_id, solver, K, seed, mode, episodic, space_kind, every=1,
                 dead_time_steps=int(dead_time_steps))
     idx = np.arange(K)
     keep = idx[(idx % every == every - 1)] if every > 1 else idx
+    extra = {}
+    if record_reward:
+        rf = env._reward_function  # WeightedSumOfErrors (reward_functions/weighted_sum_of_errors.py:88-129)
+        meta["reward"] = dict(weights=[float(x) for x in rf._reward_weights], powers=[float(x) for x in np.asarray(rf._n, dtype=float)],
+                              state_length=[float(x) for x in rf._state_length], bias=float(rf._bias),
+                              violation_reward=float(rf._violation_reward),
+                              referenced_states=[bool(x) for x in env.reference_generator.referenced_states])
+        extra = dict(references=np.asarray(recorder.references)[:, :n_keep], rewards=np.asarray(recorder.rewards))
+        assert len(recorder.rewards) == K
     np.savez_compressed(
         os.path.join(OUT, name + ".npz"),
+        **extra,
         actions=actions.astype(np.uint8) if "disc" in space_kind else actions,
         states=states[keep],
         state_index=keep.astype(np.int64),
@@ -325,6 +364,8 @@ def main(only=None):
         main_dfim()
     if not only or "wrappers" in only:
         main_wrappers()
+    if not only or "reward" in only:
+        main_reward()
 
 
 def main_base():
@@ -455,6 +496,25 @@ def main_wrappers():
     run_case("scim_cont_dead1_free_held_dopri5", sc, "dopri5", K, 1311, "held", False, "box3", dead_time_steps=1)
     run_case("pmsm_fin_dead1_til_free_uniform_euler", "Finite-CC-PMSM-v0", "euler", K, 1312, "uniform", False, "disc8",
              dead_time_steps=1, converter=dict(interlocking_time=1e-6))
+
+
+def main_reward():
+    """SURVEY 8f rank 3: WeightedSumOfErrors reward against the reference the env's generator produced (recorded as data;
+    the generators' numpy PCG64 streams themselves are not reproducible on the device)."""
+    K = 2000
+    run_case("rw_pmsm_cont_cc_epi_held_euler", "Cont-CC-PMSM-v0", "euler", K, 1400, "held", True, "box3", record_reward=True)
+    run_case("rw_pmsm_fin_cc_epi_uniform_tau1e-4_euler", "Finite-CC-PMSM-v0", "euler", K, 1401, "uniform", True, "disc8", tau=1e-4,
+             record_reward=True)
+    run_case("rw_scim_cont_sc_epi_held_euler", "Cont-SC-SCIM-v0", "euler", K, 1402, "held", True, "box3", record_reward=True)
+    run_case("rw_permexdc_cont_tc_epi_held_euler", "Cont-TC-PermExDc-v0", "euler", K, 1403, "held", True, "box1", record_reward=True)
+    run_case("rw_dfim_cont_cc_epi_held_euler", "Cont-CC-DFIM-v0", "euler", K, 1404, "held", True, "box6", record_reward=True)
+    from gym_electric_motor.reward_functions import WeightedSumOfErrors
+    run_case("rw_pmsm_cont_cc_pow2_epi_held_euler", "Cont-CC-PMSM-v0", "euler", K, 1405, "held", True, "box3", record_reward=True,
+             reward_function=WeightedSumOfErrors(reward_weights=dict(i_sd=0.3, i_sq=0.6, omega=0.1), reward_power=2, bias="positive",
+                                                 violation_reward=-7.5, normed_reward_weights=True))
+    run_case("rw_eesm_cont_cc_pow_mixed_epi_held_euler", "Cont-CC-EESM-v0", "euler", K, 1406, "held", True, "box4", record_reward=True,
+             reward_function=WeightedSumOfErrors(reward_weights=dict(i_sd=0.4, i_sq=0.4, i_e=0.2), reward_power=dict(i_sd=1, i_sq=2, i_e=0.5),
+                                                 gamma=0.95))
 
 
 def main_dfim():

@@ -215,6 +215,21 @@ def undefined_field_angle_steps(params, actions, auto_reset=True, flux_floor=1e-
 DQ_COLUMNS = ("i_sd", "i_sq", "i_rd", "i_rq", "u_sd", "u_sq", "u_rd", "u_rq")
 
 
+def rewards(meta, states, references, violated):
+    """WeightedSumOfErrors over a trajectory: states / references [K, S_out] (normalised), violated [K] -> rewards [K]."""
+    rw = meta["reward"]
+    L = lib()
+    L.orc_reward.restype = C.c_double
+    n = len(rw["weights"])
+    arr = lambda x: (C.c_double * n)(*[float(v) for v in x])  # noqa: E731
+    w, pw, sl = arr(rw["weights"]), arr(rw["powers"]), arr(rw["state_length"])
+    out = np.zeros(len(states))
+    for k in range(len(states)):
+        out[k] = L.orc_reward(C.c_int(n), w, pw, sl, C.c_double(rw["bias"]), C.c_double(rw["violation_reward"]), arr(states[k]),
+                              arr(references[k]), C.c_int(int(violated[k])))
+    return out
+
+
 def rollout_many(params, actions, auto_reset=True):
     """actions [K, n_env, A] -> (last_obs [n_env, S_out], n_done).  Single-threaded; used as cpu_baseline 'port'."""
     a = np.ascontiguousarray(actions, dtype=np.float64)

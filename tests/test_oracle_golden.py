@@ -43,6 +43,19 @@ def test_oracle_reproduces_reference_trajectory(name):
     assert np.array_equal(done, d["terminated"])
 
 
+@pytest.mark.parametrize("name", [c for c in CASES if c.startswith("rw_")])
+def test_oracle_reward_matches_reference(name):
+    """WeightedSumOfErrors (weighted_sum_of_errors.py:125-129) on the ORACLE's own trajectory against the references the env's
+    generator produced: rewards within 1e-12 of what env.step() returned, incl. the violation reward on terminating steps."""
+    d, meta = orc.load_golden(name)
+    env = orc.OracleEnv(orc.params_from_meta(meta))
+    env.reset()
+    obs, done = env.rollout(d["actions"], auto_reset=True)
+    got = orc.rewards(meta, obs, d["references"], done)
+    assert np.abs(got - d["rewards"]).max() < 1e-12
+    assert (got[done] == meta["reward"]["violation_reward"]).all() and done.sum() == d["terminated"].sum() > 0
+
+
 def test_reference_ref_data_npz():
     """reference tests/integration_tests/test_integration.py:88-97 compares with np.allclose; we hold 1e-12."""
     d, meta = orc.load_golden("refdata_cont_sc_permexdc_dopri5")
