@@ -45,9 +45,22 @@ class GemxError(RuntimeError):
 
 _lib = None
 
+MAX_REF = 4
+
+
+class GemxRewardConfig(C.Structure):
+    """Mirror of `gemx_reward_config` (include/gemx.h)."""
+
+    _fields_ = [
+        ("struct_size", C.c_int32), ("n_ref", C.c_int32), ("ref_index", C.c_int32 * MAX_REF),
+        ("weight", C.c_double * MAX_OUT), ("power", C.c_double * MAX_OUT), ("state_length", C.c_double * MAX_OUT),
+        ("bias", C.c_double), ("violation_reward", C.c_double),
+    ]
+
+
 EXPORTS = (
     "gemx_abi_version", "gemx_sizeof_config", "gemx_last_error", "gemx_device_count", "gemx_create", "gemx_destroy",
-    "gemx_n_envs", "gemx_n_ode", "gemx_n_out", "gemx_n_action", "gemx_action_itemsize", "gemx_n_switch_bytes", "gemx_reset_observation",
+    "gemx_n_envs", "gemx_n_ode", "gemx_n_out", "gemx_n_action", "gemx_action_itemsize", "gemx_n_switch_bytes", "gemx_reset_observation", "gemx_set_reward", "gemx_rollout_reward",
     "gemx_reset", "gemx_step", "gemx_rollout", "gemx_get_state", "gemx_set_state", "gemx_get_switch_state",
     "gemx_set_switch_state", "gemx_set_steps_per_block", "gemx_last_launch", "gemx_error_flags",
 )
@@ -84,6 +97,8 @@ def load():
     L.gemx_reset.argtypes = [vp, vp, vp, vp]
     L.gemx_step.argtypes = [vp, vp, vp, vp, vp]
     L.gemx_rollout.argtypes = [vp, vp, i32, vp, vp, i32, vp]
+    L.gemx_set_reward.argtypes = [vp, C.POINTER(GemxRewardConfig)]
+    L.gemx_rollout_reward.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
     L.gemx_get_state.argtypes = [vp, vp, vp]
     L.gemx_set_state.argtypes = [vp, vp, vp]
     L.gemx_get_switch_state.argtypes = [vp, vp, vp]

@@ -19,7 +19,7 @@ SOURCES = [os.path.join(CSRC, f) for f in ("gemx_common.hpp", "gemx_kernels.hpp"
 HEADER = os.path.join(REPO, "include", "gemx.h")
 LIB = os.path.join(PKG_DIR, "libgemx.so")
 OBJ_DIR = os.path.join(PKG_DIR, "build")
-STAMP = os.path.join(OBJ_DIR, "sources.sha256")
+STAMP = LIB + ".sha256"  # next to the library (the object directory does not travel to the GPU box: .gpurunignore)
 
 # (system_kind, converter_kind) pairs on the accelerated path; each for fp32 (0) and fp64 (1)
 UNITS = [(0, 0), (1, 1), (1, 2), (2, 1), (2, 2), (0, 3), (3, 0), (3, 3), (4, 0), (4, 3), (5, 4), (5, 5), (6, 6), (6, 7), (7, 8), (7, 9), (1, 10), (2, 10), (6, 11)]

@@ -284,6 +284,28 @@ static int launch_advance(gemx_handle *h, const void *actions, int K, void *obs,
 
 static int elem_size(const gemx_handle *h) { return h->cfg.dtype == GEMX_F64 ? 8 : 4; }
 
+template <class R> static void build_reward(const gemx_handle *h, const gemx_reward_config *rc, RewardDev<R> &W) {
+    memset(&W, 0, sizeof(W));
+    int t = 0;
+    bool referenced[GEMX_MAX_OUT] = {};
+    auto add = [&](int col) {
+        W.col[t] = col;
+        const double pw = rc->power[col];
+        W.kind[t] = pw == 1.0 ? 1 : (pw == 2.0 ? 2 : 3);
+        W.coef[t] = (R)rc->weight[col];
+        W.inv_len[t] = (R)(1.0 / rc->state_length[col]);
+        W.power[t] = (R)pw;
+        ++t;
+    };
+    for (int j = 0; j < rc->n_ref; ++j) { add(rc->ref_index[j]); referenced[rc->ref_index[j]] = true; }
+    W.n_ref = rc->n_ref;
+    for (int i = 0; i < h->nout; ++i)
+        if (!referenced[i] && rc->weight[i] != 0.0) add(i);  // weighted but un-referenced states are compared with 0 (core.py:346)
+    W.n_term = t;
+    W.bias = (R)rc->bias;
+    W.violation_reward = (R)rc->violation_reward;
+}
+
 extern "C" {
 
 int gemx_abi_version(void) { return GEMX_ABI_VERSION; }
@@ -444,6 +466,7 @@ int gemx_destroy(gemx_handle *h) {
     if (h->angle) (void)hipFree(h->angle);
     if (h->sw) (void)hipFree(h->sw);
     if (h->ring) (void)hipFree(h->ring);
+    if (h->rw_dev) (void)hipFree(h->rw_dev);
     if (h->err) (void)hipFree(h->err);
     if (h->reset_obs_dev) (void)hipFree(h->reset_obs_dev);
     if (h->cw_dev) (void)hipFree(h->cw_dev);
@@ -487,6 +510,46 @@ int gemx_rollout(gemx_handle *h, const void *actions_dev, int32_t K, void *obs_o
     if (((uintptr_t)obs_out_dev & 15u) != 0) return fail(GEMX_ERR_ARG, "obs_out_dev must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     return launch_advance(h, actions_dev, K, obs_out_dev, done_out_dev, obs_every ? 1 : 0, st);
+}
+
+int gemx_set_reward(gemx_handle *h, const gemx_reward_config *rc) {
+    if (!h) return fail(GEMX_ERR_ARG, "null handle");
+    if (!rc) { h->rw_n_ref = -1; return GEMX_OK; }
+    if (rc->struct_size != (int32_t)sizeof(gemx_reward_config)) return fail(GEMX_ERR_ARG, "gemx_reward_config size mismatch");
+    if (rc->n_ref < 0 || rc->n_ref > GEMX_MAX_REF) return fail(GEMX_ERR_ARG, "n_ref must be in [0, %d]", GEMX_MAX_REF);
+    for (int j = 0; j < rc->n_ref; ++j) {
+        if (rc->ref_index[j] < 0 || rc->ref_index[j] >= h->nout) return fail(GEMX_ERR_ARG, "ref_index[%d] out of range", j);
+        for (int k = 0; k < j; ++k)
+            if (rc->ref_index[k] == rc->ref_index[j]) return fail(GEMX_ERR_ARG, "ref_index has duplicates");
+    }
+    for (int i = 0; i < h->nout; ++i)
+        if (rc->weight[i] != 0.0 && !(rc->state_length[i] > 0)) return fail(GEMX_ERR_ARG, "state_length[%d] must be positive", i);
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->rw_dev && hipMalloc(&h->rw_dev, sizeof(RewardDev<double>)) != hipSuccess) return fail(GEMX_ERR_ALLOC, "hipMalloc(reward) failed");
+    if (h->cfg.dtype == GEMX_F64) {
+        RewardDev<double> W;
+        build_reward(h, rc, W);
+        HIP_TRY(hipMemcpy(h->rw_dev, &W, sizeof(W), hipMemcpyHostToDevice));
+    } else {
+        RewardDev<float> W;
+        build_reward(h, rc, W);
+        HIP_TRY(hipMemcpy(h->rw_dev, &W, sizeof(W), hipMemcpyHostToDevice));
+    }
+    h->rw_n_ref = rc->n_ref;
+    return GEMX_OK;
+}
+
+int gemx_rollout_reward(gemx_handle *h, const void *actions_dev, int32_t K, const void *refs_dev, void *obs_out_dev, uint8_t *done_out_dev,
+                        void *reward_out_dev, void *stream) {
+    if (!h) return fail(GEMX_ERR_ARG, "null handle");
+    if (h->rw_n_ref < 0) return fail(GEMX_ERR_ARG, "no reward function installed (gemx_set_reward)");
+    if (!reward_out_dev || (h->rw_n_ref > 0 && !refs_dev)) return fail(GEMX_ERR_ARG, "refs_dev and reward_out_dev must not be null");
+    h->cur_refs = refs_dev;
+    h->cur_reward = reward_out_dev;
+    const int rc = gemx_rollout(h, actions_dev, K, obs_out_dev, done_out_dev, 1, stream);
+    h->cur_refs = nullptr;
+    h->cur_reward = nullptr;
+    return rc;
 }
 
 int gemx_step(gemx_handle *h, const void *actions_dev, void *obs_out_dev, uint8_t *done_out_dev, void *stream) {

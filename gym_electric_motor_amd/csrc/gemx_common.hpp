@@ -163,6 +163,20 @@ template <class R> __device__ __forceinline__ void t32(R al, R be, R &a, R &b, R
 
 
 // ------------------------------------------------------------------------------------------------
+// fused reward (WeightedSumOfErrors): device-resident description, read through scalar loads when a reward is requested
+// ------------------------------------------------------------------------------------------------
+template <class R> struct RewardDev {
+    // terms 0 .. n_ref-1 compare state column col[t] with reference column t; terms n_ref .. n_term-1 compare with 0
+    int32_t n_ref, n_term;
+    int32_t col[GEMX_MAX_OUT];
+    int32_t kind[GEMX_MAX_OUT];   // 1: power 1, 2: power 2, 3: general power (pow)
+    R coef[GEMX_MAX_OUT];         // weight (applied after the power)
+    R inv_len[GEMX_MAX_OUT];      // 1 / state_length
+    R power[GEMX_MAX_OUT];
+    R bias, violation_reward;
+};
+
+// ------------------------------------------------------------------------------------------------
 // kernel arguments
 // ------------------------------------------------------------------------------------------------
 template <class R> struct KArgs {
@@ -176,6 +190,9 @@ template <class R> struct KArgs {
     unsigned char *ring;            // [delay][N][A_conv] R | [delay][N] uint8: DeadTimeProcessor FIFO between launches
     int32_t ring_phase;             // FIFO slot of this launch's first step (global step count mod delay)
     uint32_t *err;                  // device error word (bit 0: discrete action out of range)
+    const RewardDev<R> *rw;         // fused reward: description (nullptr: no reward), references [K][N][n_ref], output [K][N]
+    const R *refs;
+    R *reward;
     int64_t N;
     int32_t K, obs_every;
     int32_t S;                      // control steps per I/O block (LDS ring depth)
@@ -209,6 +226,10 @@ struct gemx_handle {
     void *angle = nullptr;   // [n] int32 | double
     uint8_t *sw = nullptr;   // [sw_rows][n]
     int sw_rows = 1;
+    void *rw_dev = nullptr;  // RewardDev<R> (gemx_set_reward)
+    int rw_n_ref = -1;       // -1: no reward installed
+    const void *cur_refs = nullptr;  // set by gemx_rollout_reward around the launch
+    void *cur_reward = nullptr;
     void *ring = nullptr;    // DeadTimeProcessor FIFO [delay][n][nact_conv] R | [delay][n] uint8
     size_t ring_bytes = 0;
     int nact_conv = 1;       // converter-side action width (== nact unless a dq action frame is configured)

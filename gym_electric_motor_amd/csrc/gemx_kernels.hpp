@@ -831,6 +831,52 @@ __device__ __forceinline__ void flush_rings(const KArgs<R> &a, const R *ring, co
     }
 }
 
+// Fused reward for `nr` staged rows (control steps k0 .. k0+nr-1) of one 64-env workgroup, from the observation rows in the LDS
+// ring and the caller's reference tensor (WeightedSumOfErrors.reward, weighted_sum_of_errors.py:125-129).  One lane = one env.
+// References are fetched for up to RB rows at a time before any arithmetic so that their latency is paid once per group.
+template <int NOUT, class R>
+__device__ __forceinline__ void reward_rows(const KArgs<R> &a, const R *ring, const unsigned char *donebuf, int k0, int nr, int tid,
+                                            int64_t env, bool valid) {
+    constexpr int RB = 8;
+    const RewardDev<R> &W = *a.rw;  // wave-uniform: scalar loads
+    const int64_t N = a.N;
+    const int n_ref = W.n_ref, n_term = W.n_term;
+    const bool aos = a.P.obs_layout == GEMX_OBS_AOS;
+    const int64_t e = valid ? env : N - 1;
+    for (int s0 = 0; s0 < nr; s0 += RB) {
+        R rv[RB][GEMX_MAX_REF];
+#pragma unroll
+        for (int s = 0; s < RB; ++s) {
+#pragma unroll
+            for (int j = 0; j < GEMX_MAX_REF; ++j) {
+                rv[s][j] = R(0);
+                if (s0 + s < nr && j < n_ref) rv[s][j] = a.refs[((int64_t)(k0 + s0 + s) * N + e) * n_ref + j];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < RB; ++s) {
+            if (s0 + s < nr) {
+                const int row = s0 + s;
+                R acc = R(0);
+                for (int t = 0; t < n_term; ++t) {
+                    const int c = W.col[t];
+                    const R o = aos ? ring[((size_t)row * BLOCK + tid) * NOUT + c] : ring[((size_t)row * NOUT + c) * BLOCK + tid];
+                    R ref = R(0);
+#pragma unroll
+                    for (int j = 0; j < GEMX_MAX_REF; ++j) ref = (t == j) ? rv[s][j] : ref;  // terms < n_ref are the referenced states
+                    const R dlt = fabs(o - ref) * W.inv_len[t];
+                    const int kind = W.kind[t];
+                    const R p = kind == 1 ? dlt : (kind == 2 ? dlt * dlt : pow(dlt, W.power[t]));
+                    acc += W.coef[t] * p;
+                }
+                const R wse = W.bias - acc;
+                const R r = donebuf[row * BLOCK + tid] ? W.violation_reward : wse;  // (1 - v) * wse + v * violation_reward, v in {0, 1}
+                if (valid) a.reward[(int64_t)(k0 + row) * N + env] = r;
+            }
+        }
+    }
+}
+
 // S control steps of one I/O block.  COOP: actions come from the LDS tile (no global memory access at all in
 // this loop); otherwise straight from global memory (K == 1, tail workgroup, unaligned tensors).  The two variants
 // are separate instantiations on purpose: a pointer that may be LDS or global would compile to FLAT loads, whose
@@ -1051,7 +1097,8 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
         // 3. park the prefetched tile
         if (coop && sb_next > 0) GEMX_TILE_PARK(half ^ 1, sb_next);
 
-        // 4. flush the rings
+        // 4. flush the rings (+ the fused reward of the staged rows)
+        if (a.obs_every && a.rw != nullptr) reward_rows<NOUT, R>(a, ring, donebuf, k0, sb, tid, env, valid);
         if (a.obs_every) flush_rings<NOUT, R>(a, ring, donebuf, k0, sb, tid, blk0, rows, full, valid, env);
         __syncthreads();
         half ^= 1;
@@ -1289,6 +1336,8 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
                     }
                 }
             }
+            if (a.rw != nullptr)
+                reward_rows<NOUT, R>(a, ring + (size_t)r0 * BLOCK * NOUT, donebuf + (size_t)r0 * BLOCK, pb * D + r0, nr, tid, env, true);
             flush_rings<NOUT, R>(a, ring + (size_t)r0 * BLOCK * NOUT, donebuf + (size_t)r0 * BLOCK, pb * D + r0, nr, tid, blk0, BLOCK, true,
                                  true, env);
         };
@@ -1344,6 +1393,9 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     a.ring_phase = delay > 0 ? (int)(h->steps_total % (unsigned long long)delay) : 0;
     h->steps_total += (unsigned long long)K;
     a.err = h->err;
+    a.rw = h->cur_reward != nullptr ? (const RewardDev<R> *)h->rw_dev : nullptr;
+    a.refs = (const R *)h->cur_refs;
+    a.reward = (R *)h->cur_reward;
     a.N = h->n;
     a.K = K;
     a.obs_every = obs_every;

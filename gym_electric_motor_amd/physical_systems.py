@@ -483,11 +483,14 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             return self._obs.reshape(-1).double().cpu().numpy()
         return self._obs
 
-    def rollout(self, actions, obs_out=None, done_out=None, last_only=False):
+    def rollout(self, actions, obs_out=None, done_out=None, last_only=False, references=None, reward_out=None):
         """K fused control steps in one launch.  actions: [K, N, A] / [K, N]; returns (obs [K, N, S_out], done [K, N])
-        device tensors (or the last step's [N, S_out], [N] with last_only=True)."""
+        device tensors (or the last step's [N, S_out], [N] with last_only=True).
+        references [K, N, n_ref] (after `set_reward`): additionally returns reward [K, N] computed in the same launch."""
         torch = _torch()
         K = int(actions.shape[0])
+        if references is not None or reward_out is not None:
+            return self._rollout_reward(actions, K, obs_out, done_out, references, reward_out)
         a = self._actions_to_device(actions, (K, self._n_envs))
         if last_only:
             oshape, dshape = tuple(self._obs.shape), (self._n_envs,)
@@ -504,6 +507,100 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
                                         C.c_void_p(done_out.data_ptr()), 0 if last_only else 1, self._stream()))
         self._k += K
         return obs_out, done_out
+
+    # ------------------------------------------------------------------ fused reward
+    def set_reward(self, reward_weights=None, referenced_states=(), normed_reward_weights=False, violation_reward=None, gamma=0.9,
+                   reward_power=1, bias=0.0):
+        """Install a WeightedSumOfErrors reward (reward_functions/weighted_sum_of_errors.py:9-129; same arguments, same defaults)
+        that `rollout(..., references=...)` / `simulate(..., references=...)` evaluate in-kernel.
+
+        referenced_states: names of the states the caller's reference tensor carries, i.e. the reference generator's
+            `referenced_states`; the tensor's last axis follows the order of `state_names`.  All other states are compared
+            with 0, as the reference's generators return 0 there (core.py:346).
+        Pass reward_weights=False to remove the reward function."""
+        if reward_weights is False:
+            _lib.check(self._L.gemx_set_reward(self._handle, None))
+            self._reward_cfg = None
+            return None
+        rc = self._build_reward_config(reward_weights, referenced_states, normed_reward_weights, violation_reward, gamma, reward_power, bias)
+        if self._handle is not None:
+            _lib.check(self._L.gemx_set_reward(self._handle, C.byref(rc)))
+        self._reward_cfg = rc
+        return rc
+
+    def _build_reward_config(self, reward_weights, referenced_states, normed, violation_reward, gamma, reward_power, bias):
+        names = list(self._state_names)
+        n = len(names)
+
+        def state_array(v):  # utils.set_state_array (utils.py:40-70)
+            if isinstance(v, dict):
+                arr = np.zeros(n)
+                for k_, x in v.items():
+                    arr[names.index(k_)] = x
+                return arr
+            if np.ndim(v) == 0:
+                return np.full(n, float(v))
+            arr = np.asarray(v, dtype=float)
+            assert len(arr) == n
+            return arr
+
+        ref_idx = sorted(names.index(r) for r in referenced_states)
+        if len(ref_idx) > _lib.MAX_REF:
+            raise ValueError(f"at most {_lib.MAX_REF} referenced states")
+        if reward_weights is None:  # set_modules, lines 97-112: equal weights over the referenced states (or over all states)
+            sel = ref_idx if ref_idx else list(range(n))
+            w = np.zeros(n)
+            w[sel] = 1 / len(sel)
+        else:
+            w = state_array(reward_weights)
+        powers = state_array(reward_power)
+        length = self._state_space.high - self._state_space.low
+        rw_sum = float(sum(w))
+        if normed:  # lines 117-127
+            if bias == "positive":
+                bias = 1
+            w = w / rw_sum
+            rng = (-1 + bias, bias)
+        else:
+            if bias == "positive":
+                bias = rw_sum
+            rng = (-rw_sum + bias, bias)
+        if violation_reward is None:
+            violation_reward = min(rng[0] / (1.0 - gamma), 0)
+        rc = _lib.GemxRewardConfig()
+        rc.struct_size = C.sizeof(_lib.GemxRewardConfig)
+        rc.n_ref = len(ref_idx)
+        for j, i in enumerate(ref_idx):
+            rc.ref_index[j] = i
+        for i in range(n):
+            rc.weight[i], rc.power[i], rc.state_length[i] = float(w[i]), float(powers[i]), float(length[i])
+        rc.bias, rc.violation_reward = float(bias), float(violation_reward)
+        self.reward_range = rng
+        return rc
+
+    def _rollout_reward(self, actions, K, obs_out, done_out, references, reward_out):
+        torch = _torch()
+        if getattr(self, "_reward_cfg", None) is None:
+            raise ValueError("no reward function installed: call set_reward(...) first")
+        n_ref = int(self._reward_cfg.n_ref)
+        a = self._actions_to_device(actions, (K, self._n_envs))
+        r = None
+        if n_ref:
+            r = torch.as_tensor(references).to(device=self._tdev, dtype=self._tdtype).reshape(K, self._n_envs, n_ref).contiguous()
+        oshape = (K,) + tuple(self._obs.shape)
+        if obs_out is None:
+            obs_out = torch.empty(oshape, dtype=self._tdtype, device=self._tdev)
+        if done_out is None:
+            done_out = torch.empty((K, self._n_envs), dtype=torch.uint8, device=self._tdev)
+        if reward_out is None:
+            reward_out = torch.empty((K, self._n_envs), dtype=self._tdtype, device=self._tdev)
+        assert tuple(obs_out.shape) == oshape and obs_out.is_contiguous() and obs_out.dtype == self._tdtype
+        assert tuple(reward_out.shape) == (K, self._n_envs) and reward_out.is_contiguous() and reward_out.dtype == self._tdtype
+        _lib.check(self._L.gemx_rollout_reward(self._handle, C.c_void_p(a.data_ptr()), K, C.c_void_p(r.data_ptr()) if r is not None else None,
+                                               C.c_void_p(obs_out.data_ptr()), C.c_void_p(done_out.data_ptr()),
+                                               C.c_void_p(reward_out.data_ptr()), self._stream()))
+        self._k += K
+        return obs_out, done_out, reward_out
 
     def reset(self, mask=None, *_):
         """PhysicalSystem.reset (core.py:678-685).  mask: optional [N] bool/uint8 selecting the envs to reset."""

@@ -165,6 +165,27 @@ int gemx_step(gemx_handle *h, const void *actions_dev, void *obs_out_dev, uint8_
 int gemx_rollout(gemx_handle *h, const void *actions_dev, int32_t K, void *obs_out_dev, uint8_t *done_out_dev,
                  int32_t obs_every, void *stream);
 
+/* Reward fused into the rollout: WeightedSumOfErrors.reward (reward_functions/
+ * weighted_sum_of_errors.py:125-129) with the caller's reference tensor,
+ *   r = (1 - v) * (bias - sum_i weight[i] * (|s_i - ref_i| / state_length[i]) ** power[i]) + v * violation_reward,
+ * v = this step's done flag (ConstraintMonitor violation degree 0 | 1, core.py:348-350); ref_i = refs[.., j] for the n_ref
+ * referenced states ref_index[j] (the generator's referenced_states, in ascending state order), 0 for all others.
+ * weight / power / state_length are full-length state arrays exactly as the reference's reward function holds them
+ * (_reward_weights, _n, _state_length = state_space.high - low). */
+#define GEMX_MAX_REF 4
+typedef struct gemx_reward_config {
+    int32_t struct_size; /* = sizeof(gemx_reward_config) */
+    int32_t n_ref;       /* 0..GEMX_MAX_REF columns of the reference tensor */
+    int32_t ref_index[GEMX_MAX_REF];
+    double weight[GEMX_MAX_OUT], power[GEMX_MAX_OUT], state_length[GEMX_MAX_OUT];
+    double bias, violation_reward;
+} gemx_reward_config;
+/* Install (rc != NULL) or remove (NULL) the reward function of a handle. */
+int gemx_set_reward(gemx_handle *h, const gemx_reward_config *rc);
+/* gemx_rollout (obs_every = 1) that additionally reads refs_dev [K, N, n_ref] (R) and writes reward_out_dev [K, N] (R). */
+int gemx_rollout_reward(gemx_handle *h, const void *actions_dev, int32_t K, const void *refs_dev, void *obs_out_dev,
+                        uint8_t *done_out_dev, void *reward_out_dev, void *stream);
+
 /* Checkpoint / parity access to the ODE state, SoA [S_ode, N] of R in physical units (angle in rad), plus the
  * per-env packed converter switching state, 2 bits per half-bridge: [N] uint8, or [2][N] uint8 (row 0 = bits 0..7,
  * row 1 = bits 8..11) for the 6 half-bridges of GEMX_CONV_FINITE_2XB6; gemx_n_switch_bytes() = bytes per env.

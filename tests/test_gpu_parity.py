@@ -401,6 +401,81 @@ def test_action_stage_chunking_and_single_step_are_bit_identical(env_id, wrapper
         e_.close()
 
 
+REWARD_CASES = [c for c in CASES if c.startswith("rw_")]
+
+
+def _install_reward(ps, meta):
+    rw = meta["reward"]
+    names = meta["state_names"]
+    return ps.set_reward(reward_weights=np.array(rw["weights"]), reward_power=np.array(rw["powers"]), bias=rw["bias"],
+                         violation_reward=rw["violation_reward"],
+                         referenced_states=[n for n, r in zip(names, rw["referenced_states"]) if r])
+
+
+@pytest.mark.parametrize("name", REWARD_CASES)
+@pytest.mark.parametrize("n_envs", [70, 128])
+def test_fused_reward_matches_reference_env_rewards(name, n_envs, monkeypatch):
+    """WeightedSumOfErrors fused into the rollout (gemx_rollout_reward): rewards env.step() returned in the reference run, with
+    the references its generator produced fed in as data.  fp32: |dr| <= 1e-4 * reward scale; the violation reward exact.
+    n_envs = 128 takes the pipelined kernel (reward computed by the output waves), 70 the single-wave kernel with a tail."""
+    import torch
+
+    d, meta = _load(name)
+    env = _make_from_meta(meta, n_envs, dtype="float32", auto_reset=True)
+    ps = env.physical_system
+    _install_reward(ps, meta)
+    K = d["actions"].shape[0]
+    a = torch.as_tensor(np.repeat(d["actions"].reshape(K, 1, -1), n_envs, axis=1))
+    if ps._discrete and d["actions"].ndim == 1:
+        a = a.reshape(K, n_envs)
+    cols = [i for i, r in enumerate(meta["reward"]["referenced_states"]) if r]
+    refs = torch.as_tensor(np.repeat(d["references"][:, None, cols], n_envs, axis=1))
+    obs, done, rew = ps.rollout(a.cuda(), references=refs.cuda())
+    torch.cuda.synchronize()
+    assert ("advance_pipe_kernel" in ps.last_launch()) == (n_envs == 128)
+    rew, done = rew.double().cpu().numpy(), done.cpu().numpy().astype(bool)
+    assert np.array_equal(rew[:, 0], rew[:, n_envs - 1])
+    ref_done = d["terminated"]
+    first = int(np.argmax(done[:, 0] != ref_done)) if (done[:, 0] != ref_done).any() else K
+    assert first > 100  # (a done flip at a < 1e-5 constraint margin ends the like-for-like comparison)
+    scale = max(1.0, float(np.abs(d["rewards"][~ref_done]).max()))
+    assert np.abs(rew[:first, 0] - d["rewards"][:first]).max() < 1e-4 * scale
+    viol = np.float32(meta["reward"]["violation_reward"])
+    assert (rew[:first, 0][ref_done[:first]] == viol).all() and ref_done[:first].sum() > 0
+    # chunked launches and the no-reward rollout give the same bits
+    env2 = _make_from_meta(meta, n_envs, dtype="float32", auto_reset=True)
+    _install_reward(env2.physical_system, meta)
+    o1, d1, r1 = env2.physical_system.rollout(a[:333].cuda(), references=refs[:333].cuda())
+    o2, d2, r2 = env2.physical_system.rollout(a[333:].cuda(), references=refs[333:].cuda())
+    assert np.array_equal(torch.cat([r1, r2]).double().cpu().numpy(), rew) and torch.equal(torch.cat([o1, o2]), obs)
+    env3 = _make_from_meta(meta, n_envs, dtype="float32", auto_reset=True)
+    o3, d3 = env3.physical_system.rollout(a.cuda())
+    assert torch.equal(o3, obs)
+    for e in (env, env2, env3):
+        e.close()
+
+
+def test_fused_reward_fp64_and_soa_layout():
+    import torch
+
+    name = "rw_eesm_cont_cc_pow_mixed_epi_held_euler"  # powers 1, 2 and 0.5
+    d, meta = _load(name)
+    K = d["actions"].shape[0]
+    cols = [i for i, r in enumerate(meta["reward"]["referenced_states"]) if r]
+    out = {}
+    for layout in ("aos", "soa"):
+        env = _make_from_meta(meta, 65, dtype="float64", auto_reset=True, obs_layout=layout)
+        _install_reward(env.physical_system, meta)
+        a = torch.as_tensor(np.repeat(d["actions"].reshape(K, 1, -1), 65, axis=1)).cuda()
+        refs = torch.as_tensor(np.repeat(d["references"][:, None, cols], 65, axis=1)).cuda()
+        obs, done, rew = env.physical_system.rollout(a, references=refs)
+        out[layout] = rew.cpu().numpy()
+        assert np.array_equal(done[:, 0].cpu().numpy().astype(bool), d["terminated"])
+        assert np.abs(out[layout][:, 0] - d["rewards"]).max() < 1e-9
+        env.close()
+    assert np.array_equal(out["aos"], out["soa"])
+
+
 def test_obs_layouts_agree_and_tail_block():
     import torch
 

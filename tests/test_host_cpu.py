@@ -183,6 +183,32 @@ def test_action_stage_config():
     assert L.gemx_create(C.byref(bad), 4, 0, C.byref(h)) == -1 and b"action_frame" in L.gemx_last_error()
 
 
+@pytest.mark.parametrize("name, kwargs", [
+    ("rw_pmsm_cont_cc_epi_held_euler", dict(reward_weights=dict(i_sd=0.5, i_sq=0.5))),
+    ("rw_scim_cont_sc_epi_held_euler", dict(reward_weights=dict(omega=1.0))),
+    ("rw_permexdc_cont_tc_epi_held_euler", dict(reward_weights=dict(torque=1.0))),
+    ("rw_pmsm_cont_cc_pow2_epi_held_euler", dict(reward_weights=dict(i_sd=0.3, i_sq=0.6, omega=0.1), reward_power=2, bias="positive",
+                                                violation_reward=-7.5, normed_reward_weights=True)),
+    ("rw_eesm_cont_cc_pow_mixed_epi_held_euler", dict(reward_weights=dict(i_sd=0.4, i_sq=0.4, i_e=0.2),
+                                                     reward_power=dict(i_sd=1, i_sq=2, i_e=0.5), gamma=0.95)),
+])
+def test_reward_config_derivation_matches_reference(name, kwargs):
+    """set_reward() with WeightedSumOfErrors' own arguments derives the arrays the live reference's reward function held
+    (weights after normalisation, powers, state lengths, bias, default violation reward = min(range[0] / (1 - gamma), 0))."""
+    meta = _meta(name)
+    rw = meta["reward"]
+    ps = ga.make(meta["env_id"], n_envs=2, _defer_create=True).physical_system
+    refd = [n for n, r in zip(meta["state_names"], rw["referenced_states"]) if r]
+    rc = ps.set_reward(referenced_states=refd, **kwargs)
+    n = len(meta["state_names"])
+    assert np.allclose(list(rc.weight)[:n], rw["weights"], rtol=1e-15, atol=0)
+    assert np.allclose(list(rc.state_length)[:n], rw["state_length"], rtol=0, atol=0)
+    w = np.array(rw["weights"])
+    assert np.allclose(np.array(list(rc.power)[:n])[w != 0], np.array(rw["powers"])[w != 0])
+    assert rc.bias == pytest.approx(rw["bias"], abs=1e-15) and rc.violation_reward == pytest.approx(rw["violation_reward"], rel=1e-14)
+    assert [rc.ref_index[j] for j in range(rc.n_ref)] == [i for i, r in enumerate(rw["referenced_states"]) if r]
+
+
 def test_multi_converter_holders():
     """Cont/FiniteMultiConverter mirrors (converters.py:498-740): spaces, tau propagation, per-sub-converter dead time."""
     c = ga.ContMultiConverter(subconverters=[ga.ContB6BridgeConverter, ga.ContFourQuadrantConverter], tau=2e-4)
