@@ -831,49 +831,88 @@ __device__ __forceinline__ void flush_rings(const KArgs<R> &a, const R *ring, co
     }
 }
 
-// Fused reward for `nr` staged rows (control steps k0 .. k0+nr-1) of one 64-env workgroup, from the observation rows in the LDS
-// ring and the caller's reference tensor (WeightedSumOfErrors.reward, weighted_sum_of_errors.py:125-129).  One lane = one env.
-// References are fetched for up to RB rows at a time before any arithmetic so that their latency is paid once per group.
+// Fused reward (WeightedSumOfErrors.reward, weighted_sum_of_errors.py:125-129) of staged observation rows of one 64-env
+// workgroup, from the LDS ring and the caller's reference tensor.  One lane = one env.  Two halves, so that the reference
+// loads can be issued long before they are needed (their latency is never on the critical path):
+//   reward_fetch: this lane's references of rows k0 .. k0+nr-1 (nr <= RB) -> registers;
+//   reward_apply: reward of those rows -> reward tensor.
+template <int RB, class R>
+__device__ __forceinline__ void reward_fetch(const KArgs<R> &a, int k0, int nr, int64_t e, R (&rv)[RB][GEMX_MAX_REF]) {
+    const int n_ref = a.rw->n_ref;
+    const int64_t N = a.N;
+#pragma unroll
+    for (int s = 0; s < RB; ++s) {
+#pragma unroll
+        for (int j = 0; j < GEMX_MAX_REF; ++j) {
+            rv[s][j] = R(0);
+            if (s < nr && j < n_ref) rv[s][j] = a.refs[((int64_t)(k0 + s) * N + e) * n_ref + j];
+        }
+    }
+}
+// The reward description as wave-uniform VALUES (SGPRs): read once per kernel, so that no scalar load sits in the row loops
+// (stores to the reward tensor could alias the description as far as the compiler knows).  The first HOT terms cover every
+// reference env (<= 3 referenced states); further weighted states take the slow path through memory.
+template <class R> struct RewardRegs {
+    static constexpr int HOT = 4;
+    int32_t n_term, col[HOT], kind[HOT];
+    R coef[HOT], inv_len[HOT], power[HOT], bias, violation_reward;
+    __device__ __forceinline__ void load(const RewardDev<R> *w) {
+        n_term = w->n_term;
+#pragma unroll
+        for (int t = 0; t < HOT; ++t) {
+            col[t] = w->col[t]; kind[t] = w->kind[t]; coef[t] = w->coef[t]; inv_len[t] = w->inv_len[t]; power[t] = w->power[t];
+        }
+        bias = w->bias;
+        violation_reward = w->violation_reward;
+    }
+};
+template <class R> __device__ __forceinline__ R reward_term(R o, R ref, R inv_len, int kind, R power, R coef) {
+    const R dlt = fabs(o - ref) * inv_len;
+    const R p = kind == 1 ? dlt : (kind == 2 ? dlt * dlt : pow(dlt, power));
+    return coef * p;
+}
+template <int NOUT, int RB, class R>
+__device__ __forceinline__ void reward_apply(const KArgs<R> &a, const RewardRegs<R> &W, const R *ring, const unsigned char *donebuf, int k0,
+                                             int row0, int nr, int tid, int64_t env, bool valid, const R (&rv)[RB][GEMX_MAX_REF]) {
+    constexpr int HOT = RewardRegs<R>::HOT;
+    static_assert(HOT >= GEMX_MAX_REF, "referenced states must be hot terms");
+    const int64_t N = a.N;
+    const bool aos = a.P.obs_layout == GEMX_OBS_AOS;
+    auto obs_at = [&](int row, int c) { return aos ? ring[((size_t)row * BLOCK + tid) * NOUT + c] : ring[((size_t)row * NOUT + c) * BLOCK + tid]; };
+#pragma unroll
+    for (int s = 0; s < RB; ++s) {
+        if (s < nr) {
+            const int row = row0 + s;  // row of the ring / done ring
+            R acc = R(0);
+#pragma unroll
+            for (int t = 0; t < HOT; ++t) {  // terms < n_ref are the referenced states (reference column t), the others compare with 0
+                if (t < W.n_term) acc += reward_term<R>(obs_at(row, W.col[t]), t < GEMX_MAX_REF ? rv[s][t] : R(0), W.inv_len[t], W.kind[t], W.power[t], W.coef[t]);
+            }
+            for (int t = HOT; t < W.n_term; ++t)
+                acc += reward_term<R>(obs_at(row, a.rw->col[t]), R(0), a.rw->inv_len[t], a.rw->kind[t], a.rw->power[t], a.rw->coef[t]);
+            const R wse = W.bias - acc;
+            const R r = donebuf[row * BLOCK + tid] ? W.violation_reward : wse;  // (1 - v) * wse + v * violation_reward, v in {0, 1}
+            if (valid) a.reward[(int64_t)(k0 + s) * N + env] = r;
+        }
+    }
+}
+// all `nr` rows of an I/O block (single-wave kernel): groups of RB rows, group g+1 fetched while group g is evaluated; the
+// first group (`ra`) was fetched by the caller BEFORE the block's compute phase
+constexpr int REWARD_RB = 4;
 template <int NOUT, class R>
 __device__ __forceinline__ void reward_rows(const KArgs<R> &a, const R *ring, const unsigned char *donebuf, int k0, int nr, int tid,
-                                            int64_t env, bool valid) {
-    constexpr int RB = 8;
-    const RewardDev<R> &W = *a.rw;  // wave-uniform: scalar loads
-    const int64_t N = a.N;
-    const int n_ref = W.n_ref, n_term = W.n_term;
-    const bool aos = a.P.obs_layout == GEMX_OBS_AOS;
-    const int64_t e = valid ? env : N - 1;
-    for (int s0 = 0; s0 < nr; s0 += RB) {
-        R rv[RB][GEMX_MAX_REF];
-#pragma unroll
-        for (int s = 0; s < RB; ++s) {
-#pragma unroll
-            for (int j = 0; j < GEMX_MAX_REF; ++j) {
-                rv[s][j] = R(0);
-                if (s0 + s < nr && j < n_ref) rv[s][j] = a.refs[((int64_t)(k0 + s0 + s) * N + e) * n_ref + j];
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < RB; ++s) {
-            if (s0 + s < nr) {
-                const int row = s0 + s;
-                R acc = R(0);
-                for (int t = 0; t < n_term; ++t) {
-                    const int c = W.col[t];
-                    const R o = aos ? ring[((size_t)row * BLOCK + tid) * NOUT + c] : ring[((size_t)row * NOUT + c) * BLOCK + tid];
-                    R ref = R(0);
-#pragma unroll
-                    for (int j = 0; j < GEMX_MAX_REF; ++j) ref = (t == j) ? rv[s][j] : ref;  // terms < n_ref are the referenced states
-                    const R dlt = fabs(o - ref) * W.inv_len[t];
-                    const int kind = W.kind[t];
-                    const R p = kind == 1 ? dlt : (kind == 2 ? dlt * dlt : pow(dlt, W.power[t]));
-                    acc += W.coef[t] * p;
-                }
-                const R wse = W.bias - acc;
-                const R r = donebuf[row * BLOCK + tid] ? W.violation_reward : wse;  // (1 - v) * wse + v * violation_reward, v in {0, 1}
-                if (valid) a.reward[(int64_t)(k0 + row) * N + env] = r;
-            }
-        }
+                                            int64_t env, bool valid, R (&ra)[REWARD_RB][GEMX_MAX_REF]) {
+    constexpr int RB = REWARD_RB;
+    const int64_t e = valid ? env : a.N - 1;
+    RewardRegs<R> W;
+    W.load(a.rw);
+    R rb[RB][GEMX_MAX_REF];
+    auto cnt = [&](int s0) { return nr - s0 < RB ? (nr - s0 < 0 ? 0 : nr - s0) : RB; };
+    for (int s0 = 0; s0 < nr; s0 += 2 * RB) {
+        reward_fetch<RB, R>(a, k0 + s0 + RB, cnt(s0 + RB), e, rb);
+        reward_apply<NOUT, RB, R>(a, W, ring, donebuf, k0 + s0, s0, cnt(s0), tid, env, valid, ra);
+        reward_fetch<RB, R>(a, k0 + s0 + 2 * RB, cnt(s0 + 2 * RB), e, ra);
+        reward_apply<NOUT, RB, R>(a, W, ring, donebuf, k0 + s0 + RB, s0 + RB, cnt(s0 + RB), tid, env, valid, rb);
     }
 }
 
@@ -1087,6 +1126,8 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
         const int k1 = k0 + sb;
         const int sb_next = (K - k1) < S ? (K - k1) : S;
         if (coop && sb_next > 0) GEMX_TILE_LOAD(k1, sb_next);  // 1. prefetch (no wait)
+        R rfirst[REWARD_RB][GEMX_MAX_REF];  // fused reward: references of this block's first rows, in flight during the compute phase
+        if (a.obs_every && a.rw != nullptr) reward_fetch<REWARD_RB, R>(a, k0, sb < REWARD_RB ? sb : REWARD_RB, e, rfirst);
 
         // 2. compute: no global memory traffic in here when coop
         const unsigned char *atile = actbuf + (size_t)half * S * ROWB;
@@ -1098,7 +1139,7 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
         if (coop && sb_next > 0) GEMX_TILE_PARK(half ^ 1, sb_next);
 
         // 4. flush the rings (+ the fused reward of the staged rows)
-        if (a.obs_every && a.rw != nullptr) reward_rows<NOUT, R>(a, ring, donebuf, k0, sb, tid, env, valid);
+        if (a.obs_every && a.rw != nullptr) reward_rows<NOUT, R>(a, ring, donebuf, k0, sb, tid, env, valid, rfirst);
         if (a.obs_every) flush_rings<NOUT, R>(a, ring, donebuf, k0, sb, tid, blk0, rows, full, valid, env);
         __syncthreads();
         half ^= 1;
@@ -1179,6 +1220,8 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
     R *ring = reinterpret_cast<R *>(gemx_smem);
     unsigned char *donebuf = gemx_smem + (size_t)S * BLOCK * NOUT * sizeof(R);
     R *hand = reinterpret_cast<R *>(donebuf + (size_t)S * BLOCK);
+    constexpr int NACTC = conv_nact_c<CONV>();
+    R *fifo = hand + 2 * (size_t)D * BLOCK * NHT;  // DeadTimeProcessor FIFO [delay][64][NACTC], touched by the integrator wave only
     auto steps_of = [&](int b) { return (K - b * D) < D ? (K - b * D) : D; };
 
     if (wave == 0) {
@@ -1195,6 +1238,14 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
             if (conv_sw_bytes<CONV>() == 2) sw |= (uint32_t)a.sw[N + env] << 8;
         }
         const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
+        int slot = a.ring_phase;
+        for (int d = 0; d < P.delay; ++d) {
+#pragma unroll
+            for (int i = 0; i < NACTC; ++i) {
+                const int64_t gi = ((int64_t)d * N + env) * NACTC + i;
+                fifo[((size_t)d * BLOCK + tid) * NACTC + i] = DISCRETE ? (R)a.ring[gi] : reinterpret_cast<const R *>(a.ring)[gi];
+            }
+        }
         const bool check_default = P.constr_kind == 1;
         const bool auto_reset = P.auto_reset != 0;
         uint32_t bad_action = 0;
@@ -1223,12 +1274,29 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
                 }
             }
         };
-        auto one_step = [&](const R (&act_in)[NACT], uint32_t dact, R *row) {
+        // `fifo_possible` (a std::bool_constant): false_type compiles the DeadTimeProcessor queue out, so that the fully
+        // unrolled blocks of the common case stay ONE branch-free basic block; true_type keeps the wave-uniform run-time test
+        auto one_step = [&](auto fifo_possible, const R (&act_in)[NACT], uint32_t dact, R *row) {
+            constexpr bool FIFO = decltype(fifo_possible)::value;
             R act[MAX_ACT];
 #pragma unroll
             for (int i = 0; i < MAX_ACT; ++i) act[i] = i < NACT ? act_in[i] : R(0);
             if (DISCRETE) { bad_action |= dact >= (uint32_t)ConvTraits<CONV>::NACTIONS; dact &= (uint32_t)(ConvTraits<CONV>::NACTIONS - 1); }
-            dq_action_stage<SYS, CONV, R>(P, y, ang, act);
+            // action stage, exactly as in compute_block(): [DqToAbcActionProcessor [DeadTimeProcessor [system(control_space)]]]
+            if (conv_dq<CONV>() && P.dq_processor) dq_action_stage<SYS, CONV, R>(P, y, ang, act);
+            if (FIFO && P.delay > 0) {
+                R *f = fifo + ((size_t)slot * BLOCK + tid) * NACTC;
+                if (DISCRETE) {
+                    const uint32_t old = (uint32_t)f[0];
+                    f[0] = (R)dact;
+                    dact = old;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NACTC; ++i) { const R old = f[i]; f[i] = act[i]; act[i] = old; }
+                }
+                slot = slot + 1 == P.delay ? 0 : slot + 1;
+            }
+            if (conv_dq<CONV>() && !P.dq_processor) dq_action_stage<SYS, CONV, R>(P, y, ang, act);
             R ho[NH];
             ST::template advance<true>(P, y, ang, sw, act, dact, ho);  // launcher guarantees solver_nsteps == 1
             const bool done = ST::state_done(P, y, ho) & check_default;
@@ -1246,6 +1314,12 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
 #pragma unroll
             for (int j = 0; j < ND; ++j) y[j] = rs ? P.init[j] : y[j];
             ang = rs ? init_ang : ang;
+            if (FIFO && P.delay > 0 && rs) {  // DeadTimeProcessor.reset: the deque is refilled with the (zero) reset action
+                for (int d = 0; d < P.delay; ++d) {
+#pragma unroll
+                    for (int i = 0; i < NACTC; ++i) fifo[((size_t)d * BLOCK + tid) * NACTC + i] = R(0);
+                }
+            }
         };
         load_actions(0);
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): state + first block of actions have landed
@@ -1261,13 +1335,16 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
                 for (int i = 0; i < NACT; ++i) cur[s][i] = pre[s][i];
             }
             if (b + 1 < nb) load_actions(b + 1);  // prefetch: lands while this block integrates
-            if (sb == D) {
+            if (sb == D && P.delay == 0) {
 #pragma unroll
-                for (int s = 0; s < D; ++s) one_step(cur[s], dcur[s], hb + (size_t)s * BLOCK * NHT);
+                for (int s = 0; s < D; ++s) one_step(std::false_type{}, cur[s], dcur[s], hb + (size_t)s * BLOCK * NHT);
+            } else if (sb == D) {
+#pragma unroll
+                for (int s = 0; s < D; ++s) one_step(std::true_type{}, cur[s], dcur[s], hb + (size_t)s * BLOCK * NHT);
             } else {
 #pragma unroll
                 for (int s = 0; s < D; ++s)
-                    if (s < sb) one_step(cur[s], dcur[s], hb + (size_t)s * BLOCK * NHT);
+                    if (s < sb) one_step(std::true_type{}, cur[s], dcur[s], hb + (size_t)s * BLOCK * NHT);
             }
             __syncthreads();  // publishes hand-off block b; wave 1 is done reading block b-1 (other half)
         }
@@ -1277,6 +1354,15 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
         if (USE_SW) {
             a.sw[env] = (uint8_t)sw;
             if (conv_sw_bytes<CONV>() == 2) a.sw[N + env] = (uint8_t)(sw >> 8);
+        }
+        for (int d = 0; d < P.delay; ++d) {
+#pragma unroll
+            for (int i = 0; i < NACTC; ++i) {
+                const int64_t gi = ((int64_t)d * N + env) * NACTC + i;
+                const R v = fifo[((size_t)d * BLOCK + tid) * NACTC + i];
+                if (DISCRETE) a.ring[gi] = (unsigned char)(uint32_t)v;
+                else reinterpret_cast<R *>(a.ring)[gi] = v;
+            }
         }
         if (bad_action) atomicOr(a.err, 1u);
     } else {
@@ -1314,9 +1400,15 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
         constexpr int RPW = D / PIPE_OUT_WAVES;
         const int ow = wave - 1;
         const int r0 = ow * RPW;
-        auto process = [&](int pb) {
+        auto rows_of = [&](int pb) {  // rows of this wave in block pb (may be <= 0 in the tail block)
             const int sb = steps_of(pb);
-            const int nr = sb - r0 < RPW ? sb - r0 : RPW;  // rows of this wave in this block (may be <= 0 in the tail block)
+            return sb - r0 < RPW ? (sb - r0 < 0 ? 0 : sb - r0) : RPW;
+        };
+        R rv[RPW][GEMX_MAX_REF];  // fused reward: this wave's references of the next block to process
+        RewardRegs<R> WR;
+        if (a.rw != nullptr) WR.load(a.rw);
+        auto process = [&](int pb) {
+            const int nr = rows_of(pb);
             if (nr <= 0) return;
             const R *hb = hand + (size_t)(pb & 1) * D * BLOCK * NHT + (size_t)r0 * BLOCK * NHT + (size_t)tid * NHT;
             R rows[2][NHT];
@@ -1336,11 +1428,15 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
                     }
                 }
             }
-            if (a.rw != nullptr)
-                reward_rows<NOUT, R>(a, ring + (size_t)r0 * BLOCK * NOUT, donebuf + (size_t)r0 * BLOCK, pb * D + r0, nr, tid, env, true);
+            if (a.rw != nullptr) {
+                // references of this block were fetched a whole block ago; the next block's are issued before this block's stores
+                reward_apply<NOUT, RPW, R>(a, WR, ring, donebuf, pb * D + r0, r0, nr, tid, env, true, rv);
+                if (pb + 1 < nb) reward_fetch<RPW, R>(a, (pb + 1) * D + r0, rows_of(pb + 1), env, rv);
+            }
             flush_rings<NOUT, R>(a, ring + (size_t)r0 * BLOCK * NOUT, donebuf + (size_t)r0 * BLOCK, pb * D + r0, nr, tid, blk0, BLOCK, true,
                                  true, env);
         };
+        if (a.rw != nullptr) reward_fetch<RPW, R>(a, r0, rows_of(0), env, rv);
         for (int b = 0; b < nb; ++b) {
             if (b >= 1) process(b - 1);
             __syncthreads();
@@ -1354,7 +1450,7 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
 // ------------------------------------------------------------------------------------------------
 // I/O block depth S (control steps staged in LDS between global-memory bursts): as deep as the LDS allows for the
 // number of workgroups that should be co-resident per CU, capped by the per-lane action-prefetch registers.
-inline int choose_steps_per_block(const gemx_handle *h, int K, int es, int abytes) {
+inline int choose_steps_per_block(const gemx_handle *h, int K, int es, int abytes, int max_wg_per_cu = 16) {
     if (K <= 1) return 1;
     const size_t lds_max = h->lds_max - (size_t)h->cfg.action_delay * BLOCK * h->nact_conv * es - 64;  // minus the DeadTimeProcessor FIFO
     const size_t per_step = (size_t)BLOCK * h->nout * es + 2 * (size_t)BLOCK * abytes + BLOCK;
@@ -1364,6 +1460,7 @@ inline int choose_steps_per_block(const gemx_handle *h, int K, int es, int abyte
         int64_t per_cu = (nblocks + h->n_cu - 1) / h->n_cu;
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 16) per_cu = 16;
+        if (per_cu > max_wg_per_cu) per_cu = max_wg_per_cu;  // register-limited residency: deeper I/O blocks instead of idle LDS
         S = (int)((lds_max - 1024) / per_cu / per_step);
         if (S > MAX_STEPS_PER_BLOCK) S = MAX_STEPS_PER_BLOCK;
     }
@@ -1399,7 +1496,19 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     a.N = h->n;
     a.K = K;
     a.obs_every = obs_every;
-    a.S = choose_steps_per_block(h, K, (int)sizeof(R), ABYTES);
+    auto kern = advance_kernel<SYS, CONV, LOAD, SOLVER, IL, R>;
+    static int wg_per_cu = 0;  // per instantiation: single-wave workgroups a CU can hold, from the kernel's VGPR count
+    if (wg_per_cu == 0) {
+        hipFuncAttributes fa;
+        wg_per_cu = 16;
+        if (hipFuncGetAttributes(&fa, (const void *)kern) == hipSuccess && fa.numRegs > 0) {
+            int waves = 512 / ((fa.numRegs + 7) & ~7);  // gfx950: 512 VGPRs per SIMD lane, allocation granule 8
+            if (waves < 1) waves = 1;
+            if (waves > 8) waves = 8;
+            wg_per_cu = 4 * waves;
+        }
+    }
+    a.S = choose_steps_per_block(h, K, (int)sizeof(R), ABYTES, wg_per_cu);
     a.D = 1;
     // 16-byte alignment of every full block's rows: row starts are (k*N + blk0) * bytes_per_env with blk0 % 64 == 0
     a.coop = (((uintptr_t)actions & 15u) == 0 && ((size_t)h->n * ABYTES) % 16 == 0 &&
@@ -1411,7 +1520,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     const int64_t blocks = (h->n + BLOCK - 1) / BLOCK;
     // two-wave pipelined kernel for small N (the chip is not full: a single wave per SIMD is issue-bound)
     const bool pipe_ok = h->use_pipe != 0 && K >= 2 && obs_every && a.coop && a.obs_vec && (h->n % BLOCK) == 0 &&
-                         params_of<R>(h).constr_kind <= 1 && h->cfg.solver_nsteps == 1 && delay == 0;
+                         params_of<R>(h).constr_kind <= 1 && h->cfg.solver_nsteps == 1;
     if (pipe_ok) {
         using ST = Stepper<SYS, conv_base<CONV>(), LOAD, SOLVER, IL, R>;
         constexpr int NHT = SysTraits<SYS>::ND + (SysTraits<SYS>::HAS_ANGLE ? 1 : 0) + ST::NH + 1;
@@ -1419,6 +1528,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         // twice the resident workgroups).  Small-N regime only: at most two rounds of resident workgroups.
         auto smem_of = [&](int D) {
             size_t b = (size_t)D * BLOCK * h->nout * sizeof(R) + (size_t)D * BLOCK + 2 * (size_t)D * BLOCK * NHT * sizeof(R);
+            b += (size_t)delay * BLOCK * conv_nact_c<CONV>() * sizeof(R);  // DeadTimeProcessor FIFO
             return (b + 15) & ~(size_t)15;
         };
         auto resident = [&](int D) {
@@ -1444,7 +1554,6 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             return GEMX_OK;
         }
     }
-    auto kern = advance_kernel<SYS, CONV, LOAD, SOLVER, IL, R>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         GEMX_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max));

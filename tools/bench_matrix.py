@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Throughput matrix over the widened scope: every motor family, the action stage and the fused reward.
+
+    python tools/bench_matrix.py [--envs 16384 131072] [--steps 500] > profiles/<round>_matrix.md
+
+For each case: fused rollouts of `--steps` control steps (observation rows + done bytes written every step, default
+constraints + auto-reset, RK4, fp32, uniformly random actions resident in HBM), mean launch time over 5 launches after
+2 warm-up launches (HIP events on the launch stream).  Algorithmic bytes per env-step = action + 4 * S_out + 1
+(+ 4 * n_ref + 4 with the fused reward)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+CASES = [
+    # label, env_id, make kwargs, reward?
+    ("PermExDc cont", "Cont-CC-PermExDc-v0", {}, False),
+    ("SeriesDc cont SC", "Cont-SC-SeriesDc-v0", {}, False),
+    ("ShuntDc finite", "Finite-CC-ShuntDc-v0", {}, False),
+    ("ExtExDc cont (2x4QC)", "Cont-CC-ExtExDc-v0", {}, False),
+    ("ExtExDc finite (2x4QC)", "Finite-CC-ExtExDc-v0", {}, False),
+    ("PMSM finite (headline)", "Finite-CC-PMSM-v0", {}, False),
+    ("PMSM cont", "Cont-CC-PMSM-v0", {}, False),
+    ("PMSM cont SC (poly load)", "Cont-SC-PMSM-v0", {}, False),
+    ("SynRM finite", "Finite-CC-SynRM-v0", {}, False),
+    ("EESM cont (B6+4QC)", "Cont-CC-EESM-v0", {}, False),
+    ("EESM finite (B6+4QC)", "Finite-CC-EESM-v0", {}, False),
+    ("SCIM cont SC", "Cont-SC-SCIM-v0", {}, False),
+    ("SCIM finite", "Finite-CC-SCIM-v0", {}, False),
+    ("DFIM cont (2xB6)", "Cont-CC-DFIM-v0", {}, False),
+    ("DFIM finite (2xB6)", "Finite-CC-DFIM-v0", {}, False),
+    ("PMSM finite + dead time 1us", "Finite-CC-PMSM-v0", {"converter": dict(interlocking_time=1e-6)}, False),
+    ("PMSM cont control_space=dq", "Cont-CC-PMSM-v0", {"control_space": "dq"}, False),
+    ("PMSM cont DqToAbc + DeadTime(1)", "Cont-CC-PMSM-v0", {"wrappers": ("dead1", "dq")}, False),
+    ("PMSM finite DeadTime(2)", "Finite-CC-PMSM-v0", {"wrappers": ("dead2",)}, False),
+    ("PMSM finite + fused reward", "Finite-CC-PMSM-v0", {}, True),
+    ("SCIM cont SC + fused reward", "Cont-SC-SCIM-v0", {}, True),
+]
+REWARD = {"Finite-CC-PMSM-v0": dict(reward_weights=dict(i_sd=0.5, i_sq=0.5), referenced_states=("i_sd", "i_sq")),
+          "Cont-SC-SCIM-v0": dict(reward_weights=dict(omega=1.0), referenced_states=("omega",))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, nargs="+", default=[16384, 131072])
+    ap.add_argument("--steps", type=int, default=500)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    K = args.steps
+    print(f"| case | envs | G env-steps/s | B/env-step | GB/s (algorithmic) | frac of 8 TB/s | kernel |")
+    print("|---|---|---|---|---|---|---|")
+    for label, env_id, kw, with_reward in CASES:
+        for n in args.envs:
+            kw2 = dict(kw)
+            ws = []
+            for wname in kw2.pop("wrappers", ()):
+                ws.append(ga.DeadTimeProcessor(int(wname[4:])) if wname.startswith("dead") else ga.DqToAbcActionProcessor.make("PMSM"))
+            env = ga.make(env_id, n_envs=n, ode_solver=ga.RK4Solver(), physical_system_wrappers=tuple(ws), **kw2)
+            ps = env.physical_system
+            g = torch.Generator(device="cuda").manual_seed(1)
+            if ps._discrete:
+                nflat = int(np.prod(ps.action_space.nvec)) if hasattr(ps.action_space, "nvec") else int(ps.action_space.n)
+                acts = torch.randint(0, nflat, (K, n), device="cuda", generator=g, dtype=torch.uint8)
+                a_bytes = 1
+            else:
+                acts = torch.rand((K, n, ps._n_act), device="cuda", generator=g) * 2 - 1
+                a_bytes = 4 * ps._n_act
+            obs = torch.empty((K, n, ps._n_out), device="cuda")
+            done = torch.empty((K, n), dtype=torch.uint8, device="cuda")
+            refs = rew = None
+            b = a_bytes + 4 * ps._n_out + 1
+            if with_reward:
+                rc = ps.set_reward(**REWARD[env_id])
+                refs = torch.rand((K, n, int(rc.n_ref)), device="cuda", generator=g) - 0.5
+                rew = torch.empty((K, n), device="cuda")
+                b += 4 * int(rc.n_ref) + 4
+
+            def launch():
+                if with_reward:
+                    ps.rollout(acts, obs_out=obs, done_out=done, references=refs, reward_out=rew)
+                else:
+                    ps.rollout(acts, obs_out=obs, done_out=done)
+
+            for _ in range(2):
+                launch()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                launch()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            rate = n * K / (ms * 1e-3)
+            gbs = rate * b / 1e9
+            kern = ps.last_launch().split(" grid")[0].replace("gemx::", "")
+            print(f"| {label} | {n} | {rate / 1e9:.1f} | {b} | {gbs:.0f} | {gbs / 8000:.3f} | `{kern}` |", flush=True)
+            assert torch.isfinite(obs).all()
+            env.close()
+
+
+if __name__ == "__main__":
+    main()
