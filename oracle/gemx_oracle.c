@@ -57,13 +57,15 @@ typedef struct orc_params {
      *            EESM variant 158-175): abc = T32(Q(a_dq, eps + (0.5 + act_delay) * tau * omega * p))
      * act_delay: DeadTimeProcessor(steps) INSIDE the dq processor (dead_time_processor.py:63-85), reset action = zeros */
     int32_t dq_mode;
-    int32_t act_delay, pad0;
+    int32_t act_delay;
+    int32_t rc_supply; /* 1: RCVoltageSupply (voltage_supplies.py:75-123) with sup_r, sup_c below; u_sup = u_0 */
     double tau, t_il, u_sup;
     double mp[8]; /* DC permex: r_a,l_a,psi_e | PMSM/SynRM: p,l_d,l_q,r_s,psi_p(0 for SynRM) | SCIM: p,l_m,l_sigs,l_sigr,r_s,r_r
                    * DC series / shunt / extex: r_a,r_e,l_a,l_e,l_e_prime | EESM: p,l_d,l_q,l_m,l_e,r_s,r_e,k */
     double j_total, load_a, load_b, load_c, tau_decay;
     double limits[ORC_MAX_OUT];
     double init[ORC_MAX_ODE]; /* initial ODE state [omega, motor states...] */
+    double sup_r, sup_c;      /* RCVoltageSupply supply_parameter R, C */
 } orc_params;
 
 typedef struct orc_env {
@@ -82,6 +84,8 @@ typedef struct orc_env {
     /* constants */
     double C[5][11];
     /* wrappers */
+    /* RCVoltageSupply: its own EulerSolver state and time (voltage_supplies.py:96-123) */
+    double sup_u, sup_t;
     double last_state[ORC_MAX_OUT]; /* DqToAbcActionProcessor._state = normalised state * limits (lines 96, 112) */
     double fifo[8][6];              /* DeadTimeProcessor._action_deque (oldest first) */
 } orc_env;
@@ -542,6 +546,41 @@ static void conv_reset(const orc_params *p, orc_env *e, double *u) {
     }
 }
 
+/* converter.i_sup(i_out): current drawn from the supply for the converter's CURRENT internal state, i.e. (as *.simulate()
+ * calls it before convert()) the new duty cycles of a continuous converter but the PREVIOUS convert()'s switching state of a
+ * finite one.  Cont-2QC converters.py:429-435, Finite-2QC 289-298, 4QC 366-368 / 493-495, B6 837-839 / 909-911, Multi 572-580. */
+static double cont2qc_i_sup(const orc_params *p, double duty, double i) {
+    double interlocking_current = i < 0 ? 1.0 : 0.0;
+    return (duty + p->t_il / p->tau * (interlocking_current - duty)) * i;
+}
+static double fin2qc_i_sup(const orc_env *e, int leg, double i) {
+    if (e->sw_state[leg] == 0) return i < 0 ? i : 0.0;
+    if (e->sw_state[leg] == 1) return i;
+    return 0.0;
+}
+static double conv_i_sup(const orc_params *p, const orc_env *e, const double *i_in) {
+    int kinds[2], n = conv_subs(p, kinds), leg0 = 0;
+    double tot = 0.0;
+    for (int k = 0; k < n; ++k) {
+        if (kinds[k] == ORC_CONV_CONT_4QC) tot += cont2qc_i_sup(p, e->duty[leg0][0], i_in[0]) + cont2qc_i_sup(p, e->duty[leg0][1], -i_in[0]);
+        else if (kinds[k] == ORC_CONV_CONT_B6) for (int l = 0; l < 3; ++l) tot += cont2qc_i_sup(p, e->duty[leg0 + l][0], i_in[l]);
+        else if (kinds[k] == ORC_CONV_FINITE_4QC) tot += fin2qc_i_sup(e, leg0, i_in[0]) + fin2qc_i_sup(e, leg0 + 1, -i_in[0]);
+        else for (int l = 0; l < 3; ++l) tot += fin2qc_i_sup(e, leg0 + l, i_in[l]);
+        i_in += sub_nsig(kinds[k]);
+        leg0 += sub_nleg(kinds[k]);
+    }
+    return tot;
+}
+/* supply.get_voltage(t, i_sup): Ideal voltage_supplies.py:70-72; RC 116-123 = one explicit Euler step of
+ * du/dt = (u_0 - u - R i_sup) / (R C) from the supply solver's own time to t (EulerSolver._integrate_one_step, solvers.py:131-136) */
+static double supply_voltage(const orc_params *p, orc_env *e, double t, const double *i_in) {
+    if (!p->rc_supply) return p->u_sup;
+    double i_sup = conv_i_sup(p, e, i_in);
+    e->sup_u = e->sup_u + (p->u_sup - e->sup_u - p->sup_r * i_sup) / (p->sup_r * p->sup_c) * (t - e->sup_t);
+    e->sup_t = t;
+    return e->sup_u;
+}
+
 /* ---------------------------------------------------------------- simulate --------------------- */
 static double wrap_eps(double eps) { /* physical_systems.py:520-522 / 809-811 */
     eps = fmod(eps, 2.0 * M_PI);
@@ -565,12 +604,13 @@ static void dc_i_in(const orc_params *p, const orc_env *e, double *i_in) {
 }
 static void simulate_dc(const orc_params *p, orc_env *e, const double *action, double *obs) {
     double seg_end[2], i_in[2], u_n[2], u_in[2] = {0};
-    double u_sup = p->u_sup; /* IdealVoltageSupply.get_voltage, voltage_supplies.py:70-72 */
+    double u_sup = p->u_sup;
     int nu = conv_nsig(p);
     dc_i_in(p, e, i_in);
     int nseg = conv_set_action(p, e, action, e->t, seg_end);
     double t0 = e->t;
     for (int s = 0; s < nseg; ++s) {
+        u_sup = supply_voltage(p, e, t0, i_in); /* get_voltage(self._t, i_sup): self._t is the STEP start in every segment */
         conv_convert(p, e, i_in, e->t, u_n);
         for (int j = 0; j < nu; ++j) { u_in[j] = u_n[j] * u_sup; e->u[j] = u_in[j]; }
         integrate(p, e, s == nseg - 1 ? t0 + p->tau : seg_end[s]);
@@ -594,6 +634,7 @@ static void simulate_eesm(const orc_params *p, orc_env *e, const double *action,
     dq_to_abc(e->y + 1, eps, i_in);
     i_in[3] = e->y[3];
     conv_set_action(p, e, action, e->t, seg_end);
+    u_sup = supply_voltage(p, e, e->t, i_in);
     conv_convert(p, e, i_in, e->t, u_n);
     for (int l = 0; l < 4; ++l) u_in[l] = u_n[l] * u_sup;
     abc_to_dq(u_in, eps, u_dq);
@@ -619,6 +660,7 @@ static void simulate_pmsm(const orc_params *p, orc_env *e, const double *action,
     int nseg = conv_set_action(p, e, action, e->t, seg_end);
     double t0 = e->t;
     for (int s = 0; s < nseg; ++s) {
+        u_sup = supply_voltage(p, e, t0, i_in);
         conv_convert(p, e, i_in, e->t, u_n);
         for (int l = 0; l < 3; ++l) u_in[l] = u_n[l] * u_sup;
         abc_to_dq(u_in, eps, u_dq);
@@ -646,6 +688,7 @@ static void simulate_scim(const orc_params *p, orc_env *e, const double *action,
     int nseg = conv_set_action(p, e, action, e->t, seg_end);
     double t0 = e->t;
     for (int s = 0; s < nseg; ++s) {
+        u_sup = supply_voltage(p, e, t0, i_in);
         conv_convert(p, e, i_in, e->t, u_n);
         for (int l = 0; l < 3; ++l) u_in[l] = u_n[l] * u_sup;
         abc_to_dq(u_in, eps_fs, u_dq);
@@ -682,6 +725,7 @@ static void simulate_dfim(const orc_params *p, orc_env *e, const double *action,
     int nseg = conv_set_action(p, e, action, e->t, seg_end);
     double t0 = e->t;
     for (int s = 0; s < nseg; ++s) {
+        u_sup = supply_voltage(p, e, t0, i_in);
         conv_convert(p, e, i_in, e->t, u_n);
         for (int l = 0; l < 6; ++l) u_in[l] = u_n[l] * u_sup;
         abc_to_dq(u_in, eps_field, u_sdq);                 /* line 990 (only the last segment's value is reported) */
@@ -726,6 +770,7 @@ void orc_reset(const orc_params *p, orc_env *e, double *obs) {
     for (int i = 0; i < n; ++i) e->y[i] = p->init[i];
     e->t = 0.0; e->k = 0;
     e->dp_h = 0.0; /* ode.set_initial_value() re-creates the integrator work array */
+    e->sup_u = p->u_sup; e->sup_t = 0.0; /* RCVoltageSupply.reset: the capacitor is loaded again (voltage_supplies.py:108-114) */
     double u_n[6], u_abc[6], u_dq[2], i_abc[3], i_dq[2];
     double u_sup = p->u_sup;
     conv_reset(p, e, u_n);

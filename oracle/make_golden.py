@@ -108,6 +108,8 @@ def describe(env):
         model_constants=np.asarray(motor._model_constants, dtype=float).tolist(),
         j_total=float(load.j_total),
     )
+    if isinstance(sup, ps.RCVoltageSupply):
+        meta["supply_parameter"] = dict(R=float(sup._r), C=float(sup._c))
     subs = getattr(conv, "_sub_converters", None) if type(conv).__name__.endswith("MultiConverter") else None
     if subs is not None:
         # Cont/FiniteMultiConverter: the holder's own interlocking time is never used; the sub-converters' are
@@ -366,6 +368,8 @@ def main(only=None):
         main_wrappers()
     if not only or "reward" in only:
         main_reward()
+    if not only or "supply" in only:
+        main_supply()
 
 
 def main_base():
@@ -515,6 +519,26 @@ def main_reward():
     run_case("rw_eesm_cont_cc_pow_mixed_epi_held_euler", "Cont-CC-EESM-v0", "euler", K, 1406, "held", True, "box4", record_reward=True,
              reward_function=WeightedSumOfErrors(reward_weights=dict(i_sd=0.4, i_sq=0.4, i_e=0.2), reward_power=dict(i_sd=1, i_sq=2, i_e=0.5),
                                                  gamma=0.95))
+
+
+def main_supply():
+    """RCVoltageSupply (one Euler state fed by converter.i_sup, which makes i_sup live)."""
+    K = 2000
+    rc = lambda u, r=1.0, c=4e-3: ps.RCVoltageSupply(u_nominal=u, supply_parameter=dict(R=r, C=c))  # noqa: E731
+    for solver in ("euler", "dopri5"):
+        run_case(f"rc_permexdc_cont_free_held_{solver}", "Cont-CC-PermExDc-v0", solver, K, 1500, "held", False, "box1", supply=rc(60.0, 0.05))
+        run_case(f"rc_pmsm_fin_free_held_{solver}", "Finite-CC-PMSM-v0", solver, K, 1501, "held", False, "disc8", supply=rc(420.0))
+        run_case(f"rc_scim_cont_sc_free_held_{solver}", "Cont-SC-SCIM-v0", solver, K, 1502, "held", False, "box3", supply=rc(420.0, 2.0, 1e-3))
+    run_case("rc_permexdc_fin_epi_held_euler", "Finite-CC-PermExDc-v0", "euler", K, 1503, "held", True, "disc4", supply=rc(60.0, 0.05))
+    run_case("rc_permexdc_cont_til_free_uniform_euler", "Cont-CC-PermExDc-v0", "euler", K, 1504, "uniform", False, "box1",
+             supply=rc(60.0, 0.05), converter=dict(interlocking_time=2e-6))
+    run_case("rc_pmsm_fin_til_epi_uniform_tau1e-4_euler", "Finite-CC-PMSM-v0", "euler", 4000, 1505, "uniform", True, "disc8", tau=1e-4,
+             supply=rc(420.0, 0.5), converter=dict(interlocking_time=1e-6))
+    run_case("rc_pmsm_cont_free_uniform_euler", "Cont-CC-PMSM-v0", "euler", K, 1506, "uniform", False, "box3", supply=rc(300.0))
+    run_case("rc_extex_fin_free_held_euler", "Finite-CC-ExtExDc-v0", "euler", K, 1507, "held", False, "mdisc44", supply=rc(60.0, 0.05))
+    run_case("rc_eesm_cont_epi_held_euler", "Cont-CC-EESM-v0", "euler", K, 1508, "held", True, "box4", supply=rc(300.0))
+    run_case("rc_dfim_fin_free_uniform_euler", "Finite-CC-DFIM-v0", "euler", K, 1509, "uniform", False, "mdisc88", supply=rc(420.0, 2.0))
+    run_case("rc_series_cont_sc_free_held_euler", "Cont-SC-SeriesDc-v0", "euler", K, 1510, "held", False, "box1", supply=rc(60.0, 0.05))
 
 
 def main_dfim():

@@ -26,13 +26,14 @@ class OrcParams(C.Structure):
     _fields_ = [
         ("system", C.c_int32), ("converter", C.c_int32), ("load", C.c_int32), ("solver", C.c_int32),
         ("nsteps", C.c_int32), ("limit_mask", C.c_int32), ("squared_mask", C.c_int32), ("dq_mode", C.c_int32),
-        ("act_delay", C.c_int32), ("pad0", C.c_int32),
+        ("act_delay", C.c_int32), ("rc_supply", C.c_int32),
         ("tau", C.c_double), ("t_il", C.c_double), ("u_sup", C.c_double),
         ("mp", C.c_double * 8),
         ("j_total", C.c_double), ("load_a", C.c_double), ("load_b", C.c_double), ("load_c", C.c_double),
         ("tau_decay", C.c_double),
         ("limits", C.c_double * MAX_OUT),
         ("init", C.c_double * MAX_ODE),
+        ("sup_r", C.c_double), ("sup_c", C.c_double),
     ]
 
 
@@ -124,6 +125,8 @@ def params_from_meta(meta, solver=None, episodic=None):
     # action-side wrappers / control space recorded by make_golden.run_case
     p.dq_mode = {"abc": 0, "dq": 1, "dq_processor": 2}[meta.get("action_frame", "abc")]
     p.act_delay = int(meta.get("dead_time_steps", 0))
+    if meta["supply"] == "RCVoltageSupply":
+        p.rc_supply, p.sup_r, p.sup_c = 1, meta["supply_parameter"]["R"], meta["supply_parameter"]["C"]
     return p
 
 
