@@ -23,6 +23,7 @@ from .components import (  # noqa: F401
     IdealVoltageSupply,
     PermanentMagnetSynchronousMotor,
     PolynomialStaticLoad,
+    RCVoltageSupply,
     RK4Solver,
     SquirrelCageInductionMotor,
     SynchronousReluctanceMotor,

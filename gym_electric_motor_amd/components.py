@@ -42,6 +42,20 @@ class IdealVoltageSupply:
         return self._u_nominal
 
 
+class RCVoltageSupply(IdealVoltageSupply):
+    """voltage_supplies.py:75-123: a capacitor C fed through R from an ideal source u_nominal; the kernels advance its voltage by
+    one explicit Euler step per control step with the current the converter draws (converter.i_sup)."""
+
+    def __init__(self, u_nominal=600.0, supply_parameter=None):
+        super().__init__(u_nominal)
+        supply_parameter = supply_parameter or {"R": 1, "C": 4e-3}
+        assert "R" in supply_parameter.keys(), "Pass key 'R' for Resistance in your dict"
+        assert "C" in supply_parameter.keys(), "Pass key 'C' for Capacitance in your dict"
+        self.supply_range = (0, u_nominal)
+        self._r = supply_parameter["R"]
+        self._c = supply_parameter["C"]
+
+
 # ------------------------------------------------------------------------------------------------- converters
 class _Converter:
     """converters.py:5-111 (tau, interlocking_time)."""

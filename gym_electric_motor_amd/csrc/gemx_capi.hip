@@ -17,6 +17,10 @@ __global__ void reset_kernel(R *state, typename Angle<R>::T *angle, const uint8_
     if (env >= N) return;
     if (mask != nullptr && mask[env] == 0) return;
     for (int j = 0; j < nd; ++j) state[(int64_t)j * N + env] = P.init[j];
+    if (P.rc_supply) {  // RCVoltageSupply.reset (voltage_supplies.py:108-114): capacitor loaded, the supply's clock at 0
+        state[(int64_t)nd * N + env] = P.u_sup;
+        state[(int64_t)(nd + 1) * N + env] = R(0);
+    }
     // DeadTimeProcessor.reset (dead_time_processor.py:63-72): the deque is refilled with the (zero) reset action
     for (int d = 0; d < P.delay; ++d)
         for (int b = 0; b < ring_row_bytes; ++b) ring[((int64_t)d * N + env) * ring_row_bytes + b] = 0;
@@ -134,6 +138,9 @@ template <class R> static void fill_params(const gemx_handle &h, const double *m
     for (int i = 0; i < h.nd; ++i) P.init[i] = (R)c.init_state[i];
     P.init_angle_rep = Angle<R>::to_bits(Angle<R>::from_rad(h.has_angle ? c.init_state[h.nd] : 0.0));
     P.nsteps = c.solver_nsteps;
+    P.rc_supply = c.supply_kind == GEMX_SUPPLY_RC;
+    P.sup_r = (R)c.supply_r;
+    P.sup_inv_rc = (R)(P.rc_supply ? 1.0 / (c.supply_r * c.supply_c) : 0.0);
     P.dq_processor = c.action_frame == GEMX_ACT_DQ_PROCESSOR;
     P.delay = c.action_delay;
     P.dq_adv = (R)((0.5 + c.action_delay) * c.tau * pole);  // dq_to_abc_action_processor.py:83-86, 98-100
@@ -354,6 +361,12 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
                                       "also SCIM); the SCIM / DFIM dq processors need a flux observer, which is not on the accelerated path",
                         cfg->action_frame);
     }
+    if (cfg->supply_kind != GEMX_SUPPLY_IDEAL && cfg->supply_kind != GEMX_SUPPLY_RC) return fail(GEMX_ERR_ARG, "unknown supply_kind");
+    if (cfg->supply_kind == GEMX_SUPPLY_RC) {
+        if (!(cfg->supply_r > 0 && cfg->supply_c > 0)) return fail(GEMX_ERR_ARG, "RC supply needs supply_r > 0 and supply_c > 0");
+        if (c == GEMX_CONV_FINITE_B6_4QC)
+            return fail(GEMX_ERR_ARG, "the RC supply is not available for the finite EESM converter (its leg states are not tracked)");
+    }
     if (s == GEMX_SYS_EESM && cfg->interlocking_time > 0)
         return fail(GEMX_ERR_ARG, "interlocking_time > 0 is not supported for the EESM system (the reference's dead-time branch, "
                                   "physical_systems.py:628-638, cannot execute either)");
@@ -413,7 +426,7 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
 
     const size_t es = (size_t)elem_size(h);
     auto cleanup = [&](int code) { gemx_destroy(h); return code; };
-    if (hipMalloc(&h->state, es * h->nd * (size_t)h->n) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(state) failed"));
+    if (hipMalloc(&h->state, es * (h->nd + (cfg->supply_kind == GEMX_SUPPLY_RC ? 2 : 0)) * (size_t)h->n) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(state) failed"));
     if (h->has_angle && hipMalloc(&h->angle, (cfg->dtype == GEMX_F64 ? 8 : 4) * (size_t)h->n) != hipSuccess)
         return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(angle) failed"));
     if (hipMalloc((void **)&h->sw, (size_t)h->n * h->sw_rows) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(sw) failed"));

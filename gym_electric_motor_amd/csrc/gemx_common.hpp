@@ -81,6 +81,8 @@ template <class R> struct DevParams {
     int64_t init_angle_rep; // initial angle in Angle<R>::T representation (bit pattern)
     int32_t nsteps, auto_reset, obs_layout;
     int32_t constr_kind;    // 0 none, 1 the system's default constraint (fast path), 2 generic weights
+    int32_t rc_supply;      // RCVoltageSupply: u_sup is a per-env state (rows ND, ND+1 of the state array: u, time since last update)
+    R sup_r, sup_inv_rc;    // R, 1 / (R C)
     int32_t dq_processor;   // dq action frames: 0 control_space='dq' (step-start angle), 1 DqToAbcActionProcessor (advanced angle)
     int32_t delay;          // DeadTimeProcessor steps
     R dq_adv;               // (0.5 + delay) * tau * pole: angle advance per rad/s of omega

@@ -756,6 +756,54 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// RCVoltageSupply: i_sup = converter.i_sup(i_in) as *.simulate() evaluates it at the start of a step -- after set_action(), before
+// convert() -- i.e. with the NEW duty cycles of a continuous converter (Cont-2QC: converters.py:429-435) but the switching state the
+// PREVIOUS convert() left behind in a finite one (Finite-2QC: 289-298); 4QC = leg(i) + leg(-i) (366-368, 493-495), B6 = sum over the
+// legs (837-839, 909-911), MultiConverter = sum over the sub-converters (572-580).  `act` is the converter-side action, `sw` the stored
+// leg states (2 bits per half-bridge).
+// ------------------------------------------------------------------------------------------------
+template <class R> __device__ __forceinline__ R cont_leg_i_sup(const DevParams<R> &P, R duty, R i) {
+    const R ic = i < R(0) ? R(1) : R(0);
+    return (duty + P.il_ratio * (ic - duty)) * i;
+}
+template <class R> __device__ __forceinline__ R fin_leg_i_sup(uint32_t st, R i) {
+    return st == 1u ? i : ((st == 0u && i < R(0)) ? i : R(0));
+}
+template <bool FIN, class R> __device__ __forceinline__ R qc4_i_sup(const DevParams<R> &P, R a, uint32_t legs, R i) {
+    if (FIN) return fin_leg_i_sup<R>(legs & 3u, i) + fin_leg_i_sup<R>((legs >> 2) & 3u, -i);
+    return cont_leg_i_sup<R>(P, clip01(R(0.5) * (a + R(1))), i) + cont_leg_i_sup<R>(P, clip01(R(-0.5) * (a - R(1))), -i);
+}
+template <bool FIN, class R> __device__ __forceinline__ R b6_i_sup(const DevParams<R> &P, R a0, R a1, R a2, uint32_t legs, R ia, R ib, R ic) {
+    if (FIN) return fin_leg_i_sup<R>(legs & 3u, ia) + fin_leg_i_sup<R>((legs >> 2) & 3u, ib) + fin_leg_i_sup<R>((legs >> 4) & 3u, ic);
+    return cont_leg_i_sup<R>(P, clip01(R(0.5) * (a0 + R(1))), ia) + cont_leg_i_sup<R>(P, clip01(R(0.5) * (a1 + R(1))), ib) +
+           cont_leg_i_sup<R>(P, clip01(R(0.5) * (a2 + R(1))), ic);
+}
+template <int SYS, int CONV, class R>
+__device__ __forceinline__ R supply_current(const DevParams<R> &P, const R (&y)[SysTraits<SYS>::ND], typename Angle<R>::T ang, uint32_t sw,
+                                            const R (&act)[MAX_ACT]) {
+    constexpr bool FIN = ConvTraits<CONV>::DISCRETE != 0;
+    if (SYS == GEMX_SYS_DC_PERMEX || SYS == GEMX_SYS_DC_SERIES) return qc4_i_sup<FIN, R>(P, act[0], sw, y[1]);
+    if (SYS == GEMX_SYS_DC_SHUNT) return qc4_i_sup<FIN, R>(P, act[0], sw, y[1] + y[SysTraits<SYS>::ND - 1]);
+    if (SYS == GEMX_SYS_DC_EXTEX) return qc4_i_sup<FIN, R>(P, act[0], sw, y[1]) + qc4_i_sup<FIN, R>(P, act[1], sw >> 4, y[SysTraits<SYS>::ND - 1]);
+    R ia, ib, ic;
+    if (SYS == GEMX_SYS_SYNC || SYS == GEMX_SYS_EESM) {
+        R s, c;
+        Angle<R>::sincos(ang, s, c);
+        t32(c * y[1] - s * y[2], s * y[1] + c * y[2], ia, ib, ic);
+    } else {
+        t32(y[1], y[2], ia, ib, ic);
+    }
+    R tot = b6_i_sup<FIN, R>(P, act[0], act[1], act[2], sw, ia, ib, ic);
+    if (SYS == GEMX_SYS_EESM) tot += qc4_i_sup<false, R>(P, act[3], 0u, y[SysTraits<SYS>::ND - 1]);  // continuous converter only (gemx_create)
+    if (SYS == GEMX_SYS_DFIM) {  // rotor bridge: i_rdef = T32(calculate_rotor_current(state))
+        R ra, rb, rc;
+        t32(P.tc2 * y[3] - P.tc3 * y[1], P.tc2 * y[SysTraits<SYS>::ND - 1] - P.tc3 * y[2], ra, rb, rc);
+        tot += b6_i_sup<FIN, R>(P, act[3], act[4], act[5], sw >> 6, ra, rb, rc);
+    }
+    return tot;
+}
+
 // step() for the single-wave kernel
 template <class ST, int ND, int NOUT, class R>
 __device__ __forceinline__ void full_step(const DevParams<R> &P, R (&y)[ND], typename Angle<R>::T &ang, uint32_t &sw, const R (&act)[MAX_ACT],
@@ -924,7 +972,7 @@ template <bool COOP, int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R>
 __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTraits<SYS>::ND], typename Angle<R>::T &ang, uint32_t &sw,
                                               R (&obs)[SysTraits<SYS>::NOUT], uint32_t &done_or, uint32_t &bad_action, R *ring,
                                               const unsigned char *atile, unsigned char *donebuf, int k0, int sb, int tid,
-                                              int64_t e, typename Angle<R>::T init_ang, R *fifo, int &slot) {
+                                              int64_t e, typename Angle<R>::T init_ang, R *fifo, int &slot, R (&sup)[2]) {
     constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
     constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
     constexpr int ABYTES = DISCRETE ? 1 : NACT * (int)sizeof(R);
@@ -991,7 +1039,16 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
             slot = slot + 1 == P.delay ? 0 : slot + 1;
         }
         if (conv_dq<CONV>() && !P.dq_processor) dq_action_stage<SYS, CONV, R>(P, y, ang, act);
-        full_step<ST, ND, NOUT, R>(P, y, ang, sw, act, dact, obs);
+        // RCVoltageSupply.get_voltage(self._t, i_sup) (voltage_supplies.py:116-123): one explicit Euler step of the supply's own
+        // state over the time since the previous control step (0 right after a reset), before the converter is evaluated
+        DevParams<R> PL = P;  // per-lane view of the parameters: only u_sup differs between lanes
+        if (P.rc_supply) {
+            const R isup = supply_current<SYS, conv_base<CONV>(), R>(P, y, ang, sw, act);
+            sup[0] = sup[0] + (P.u_sup - sup[0] - P.sup_r * isup) * P.sup_inv_rc * sup[1];
+            sup[1] = P.tau;
+            PL.u_sup = sup[0];
+        }
+        full_step<ST, ND, NOUT, R>(PL, y, ang, sw, act, dact, obs);
         const bool done = constraint_done<ST, NOUT, R>(P, obs);
         done_or |= done ? 1u : 0u;
         pdone = done;
@@ -999,6 +1056,8 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
 #pragma unroll
             for (int j = 0; j < ND; ++j) y[j] = P.init[j];
             ang = init_ang;
+            sup[0] = P.u_sup;  // RCVoltageSupply.reset: the capacitor is loaded again, the supply's clock restarts
+            sup[1] = R(0);
             for (int d = 0; d < P.delay; ++d) {  // DeadTimeProcessor.reset: the deque is refilled with the reset action
 #pragma unroll
                 for (int i = 0; i < NACTC; ++i) fifo[((size_t)d * BLOCK + tid) * NACTC + i] = R(0);
@@ -1071,6 +1130,11 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
         if (conv_sw_bytes<CONV>() == 2) sw |= (uint32_t)a.sw[N + e] << 8;
     }
     const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
+    R sup[2] = {P.u_sup, R(0)};  // RCVoltageSupply: capacitor voltage, time since the supply's last update
+    if (P.rc_supply) {
+        sup[0] = a.state[(int64_t)ND * N + e];
+        sup[1] = a.state[(int64_t)(ND + 1) * N + e];
+    }
     for (int d = 0; d < P.delay; ++d) {  // this lane's FIFO entries (only this lane ever touches them)
 #pragma unroll
         for (int i = 0; i < NACTC; ++i) {
@@ -1131,8 +1195,8 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
 
         // 2. compute: no global memory traffic in here when coop
         const unsigned char *atile = actbuf + (size_t)half * S * ROWB;
-        if (coop) compute_block<true, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot);
-        else compute_block<false, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot);
+        if (coop) compute_block<true, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot, sup);
+        else compute_block<false, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot, sup);
         __syncthreads();
 
         // 3. park the prefetched tile
@@ -1165,6 +1229,10 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
         if (USE_SW) {
             a.sw[env] = (uint8_t)sw;
             if (conv_sw_bytes<CONV>() == 2) a.sw[N + env] = (uint8_t)(sw >> 8);
+        }
+        if (P.rc_supply) {
+            a.state[(int64_t)ND * N + env] = sup[0];
+            a.state[(int64_t)(ND + 1) * N + env] = sup[1];
         }
         for (int d = 0; d < P.delay; ++d) {
 #pragma unroll
@@ -1520,7 +1588,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     const int64_t blocks = (h->n + BLOCK - 1) / BLOCK;
     // two-wave pipelined kernel for small N (the chip is not full: a single wave per SIMD is issue-bound)
     const bool pipe_ok = h->use_pipe != 0 && K >= 2 && obs_every && a.coop && a.obs_vec && (h->n % BLOCK) == 0 &&
-                         params_of<R>(h).constr_kind <= 1 && h->cfg.solver_nsteps == 1;
+                         params_of<R>(h).constr_kind <= 1 && h->cfg.solver_nsteps == 1 && h->cfg.supply_kind == GEMX_SUPPLY_IDEAL;
     if (pipe_ok) {
         using ST = Stepper<SYS, conv_base<CONV>(), LOAD, SOLVER, IL, R>;
         constexpr int NHT = SysTraits<SYS>::ND + (SysTraits<SYS>::HAS_ANGLE ? 1 : 0) + ST::NH + 1;
@@ -1569,7 +1637,8 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
 // IL = false only exists for fp32 (the product path); the fp64 diagnostic build always takes the general code.
 template <int SYS, int CONV, class R>
 int launch_advance_unit(gemx_handle *h, const void *actions, int K, void *obs, uint8_t *done, int obs_every, hipStream_t st) {
-    const bool il = sizeof(R) == 8 || h->cfg.interlocking_time > 0.0;
+    // finite converters behind an RC supply need the leg states of the previous step (i_sup): the IL code keeps them
+    const bool il = sizeof(R) == 8 || h->cfg.interlocking_time > 0.0 || (h->cfg.supply_kind == GEMX_SUPPLY_RC && ConvTraits<CONV>::DISCRETE);
     const int ld = h->cfg.load_kind, sv = h->cfg.solver_kind;
 #define GEMX_CASE(LD, SV)                                                                                                  \
     if (ld == LD && sv == SV) {                                                                                            \

@@ -355,6 +355,10 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         cfg.tau = float(self.tau)
         cfg.interlocking_time = self._interlocking_time()
         cfg.u_nominal = float(self._supply.u_nominal)
+        if _is_a(self._supply, "RCVoltageSupply"):
+            cfg.supply_kind, cfg.supply_r, cfg.supply_c = _lib.SUPPLY_RC, float(self._supply._r), float(self._supply._c)
+        elif not _is_a(self._supply, "IdealVoltageSupply"):
+            raise ValueError(f"supply {type(self._supply).__name__} is not on the accelerated path (supported: IdealVoltageSupply, RCVoltageSupply)")
         model = np.zeros((_lib.MODEL_ROWS, _lib.MODEL_COLS))
         mc = np.asarray(self._electrical_motor._model_constants, dtype=float)
         model[: mc.shape[0], : mc.shape[1]] = mc

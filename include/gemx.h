@@ -75,6 +75,7 @@ typedef enum { GEMX_SOLVER_EULER = 0, GEMX_SOLVER_RK4 = 1, GEMX_SOLVER_DP5 = 2 }
 typedef enum { GEMX_F32 = 0, GEMX_F64 = 1 } gemx_dtype;
 /* observation layout: [N, S_out] rows per env (the reference contract) or [S_out, N] */
 typedef enum { GEMX_OBS_AOS = 0, GEMX_OBS_SOA = 1 } gemx_obs_layout;
+typedef enum { GEMX_SUPPLY_IDEAL = 0, GEMX_SUPPLY_RC = 1 } gemx_supply_kind;
 typedef enum { GEMX_ACT_ABC = 0, GEMX_ACT_DQ_SPACE = 1, GEMX_ACT_DQ_PROCESSOR = 2 } gemx_action_frame;
 #define GEMX_MAX_DELAY 8
 
@@ -101,6 +102,15 @@ typedef struct gemx_config {
      * by every reset (default reset_actions).  Any system / converter; 0 = none, max GEMX_MAX_DELAY. */
     int32_t action_frame;
     int32_t action_delay;
+    /* Supply: GEMX_SUPPLY_IDEAL (IdealVoltageSupply, voltage_supplies.py:60-72: u_sup = u_nominal) or GEMX_SUPPLY_RC
+     * (RCVoltageSupply, 75-123): one extra state per env, advanced at the start of every control step by one explicit Euler
+     * step of du/dt = (u_nominal - u - supply_r * i_sup) / (supply_r * supply_c) over the time since the previous step, with
+     * i_sup = converter.i_sup(i_in) (converters.py:289-298, 429-435, 366-368, 493-495, 837-839, 909-911) evaluated, as the
+     * reference does, on the NEW duty cycles of a continuous converter / the PREVIOUS step's final switching state of a
+     * finite one.  reset() reloads the capacitor (u = u_nominal).  Not available for the finite EESM converter. */
+    int32_t supply_kind;
+    int32_t reserved0;
+    double supply_r, supply_c;
     double tau;               /* control step, PhysicalSystem.tau */
     double interlocking_time; /* converter dead time, converters.py:35-41; must be < tau */
     double u_nominal;         /* IdealVoltageSupply.u_nominal, voltage_supplies.py:60-72 */

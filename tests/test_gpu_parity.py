@@ -64,6 +64,8 @@ def _make_from_meta(meta, n_envs, solver=None, dtype="float32", episodic=None, o
         kw["physical_system_wrappers"] = tuple(wrappers)
     if frame == "dq":
         kw["control_space"] = "dq"
+    if meta["supply"] == "RCVoltageSupply":
+        kw["supply"] = ga.RCVoltageSupply(u_nominal=meta["u_nominal"], supply_parameter=meta["supply_parameter"])
     return ga.make(meta["env_id"], **kw)
 
 
@@ -335,7 +337,8 @@ def test_two_wave_pipelined_kernel_matches_reference_and_single_wave_kernel(name
 @pytest.mark.parametrize("env_id, wrappers, control_space", [
     ("Cont-CC-PMSM-v0", ("dead2", "dq"), "abc"), ("Finite-CC-PMSM-v0", ("dead3",), "abc"), ("Cont-SC-SCIM-v0", ("dead1",), "dq"),
     ("Cont-CC-EESM-v0", ("dead1", "dq"), "abc"), ("Finite-CC-DFIM-v0", ("dead2",), "abc"), ("Cont-CC-PermExDc-v0", ("dead1",), "abc"),
-    ("Cont-CC-SynRM-v0", ("dq",), "abc"),
+    ("Cont-CC-SynRM-v0", ("dq",), "abc"), ("Finite-CC-PMSM-v0", ("rc",), "abc"), ("Cont-CC-DFIM-v0", ("rc", "dead1"), "abc"),
+    ("Finite-SC-ExtExDc-v0", ("rc",), "abc"),
 ])
 def test_action_stage_chunking_and_single_step_are_bit_identical(env_id, wrappers, control_space):
     """DeadTimeProcessor FIFO / dq action stage across launches: one K-step rollout == the same steps in uneven chunks ==
@@ -349,13 +352,15 @@ def test_action_stage_chunking_and_single_step_are_bit_identical(env_id, wrapper
     K, n = 96, 200
 
     def mk():
-        ws = []
+        ws, kw = [], {}
         for w in wrappers:
             if w.startswith("dead"):
                 ws.append(ga.DeadTimeProcessor(steps=int(w[4:])))
+            elif w == "rc":  # RCVoltageSupply: the supply state lives in HBM between launches, like the FIFO
+                kw["supply"] = ga.RCVoltageSupply(u_nominal=60.0 if "Dc" in env_id else 420.0, supply_parameter=dict(R=0.5, C=2e-3))
             else:
                 ws.append(ga.DqToAbcActionProcessor.make("EESM" if "EESM" in env_id else "PMSM"))
-        return ga.make(env_id, n_envs=n, ode_solver=ga.RK4Solver(), physical_system_wrappers=tuple(ws), control_space=control_space)
+        return ga.make(env_id, n_envs=n, ode_solver=ga.RK4Solver(), physical_system_wrappers=tuple(ws), control_space=control_space, **kw)
 
     env = mk()
     ps = env.physical_system
@@ -378,9 +383,19 @@ def test_action_stage_chunking_and_single_step_are_bit_identical(env_id, wrapper
         assert torch.equal(e3.physical_system.done, done[k])
     # oracle (same integrator, same wrappers) on a few envs
     golden = {"PMSM": "pmsm_cont_dqproc_free_held_euler", "SCIM": "scim_cont_dqspace_free_held_euler", "EESM": "eesm_cont_dqproc_free_held_euler",
-              "DFIM": "dfim_fin_free_held_euler", "PermExDc": "permexdc_free_held_euler", "SynRM": "synrm_cont_dqspace_free_held_euler"}
+              "DFIM": "dfim_fin_free_held_euler", "PermExDc": "permexdc_free_held_euler", "SynRM": "synrm_cont_dqspace_free_held_euler",
+              "ExtExDc": "extex_fin_free_held_euler"}
     key = env_id.split("-")[2]
-    _, meta = _load(golden[key] if not env_id.startswith("Finite-CC-PMSM") else "pmsm_free_held_euler")
+    gname = golden[key] if not env_id.startswith("Finite-CC-PMSM") else "pmsm_free_held_euler"
+    gname = {"Cont-CC-DFIM-v0": "dfim_cont_free_held_euler", "Finite-SC-ExtExDc-v0": "rc_extex_fin_free_held_euler"}.get(env_id, gname)
+    _, meta = _load(gname)
+    if "rc" in wrappers:
+        lp = env.physical_system.mechanical_load
+        meta = dict(meta, supply="RCVoltageSupply", supply_parameter=dict(R=0.5, C=2e-3), u_nominal=env.physical_system.supply.u_nominal,
+                    limits=[float(x) for x in env.physical_system.limits], j_total=float(lp.j_total))
+        if env_id == "Finite-SC-ExtExDc-v0":
+            meta.update(load="PolynomialStaticLoad", load_parameter=dict(lp.load_parameter), tau_decay=lp.tau_decay)
+            meta.pop("omega_fixed", None)
     meta = dict(meta, episodic=True, dead_time_steps=sum(int(w[4:]) for w in wrappers if w.startswith("dead")),
                 action_frame="dq_processor" if "dq" in wrappers else ("dq" if control_space == "dq" else "abc"))
     p = orc.params_from_meta(meta, solver="rk4", episodic=True)

@@ -209,6 +209,30 @@ def test_reward_config_derivation_matches_reference(name, kwargs):
     assert [rc.ref_index[j] for j in range(rc.n_ref)] == [i for i, r in enumerate(rw["referenced_states"]) if r]
 
 
+def test_rc_supply_config():
+    """RCVoltageSupply (voltage_supplies.py:75-123) -> gemx_config.supply_kind / supply_r / supply_c; state space low 0 for u_sup."""
+    sup = ga.RCVoltageSupply(u_nominal=420.0, supply_parameter=dict(R=0.5, C=2e-3))
+    ps = ga.make("Finite-CC-PMSM-v0", n_envs=2, supply=sup, _defer_create=True).physical_system
+    assert ps._cfg.supply_kind == _lib.SUPPLY_RC and ps._cfg.supply_r == 0.5 and ps._cfg.supply_c == 2e-3 and ps._cfg.u_nominal == 420.0
+    assert ps.state_space.low[ps.state_positions["u_sup"]] == 0.0 and sup.supply_range == (0, 420.0)
+    with pytest.raises(AssertionError):
+        ga.RCVoltageSupply(supply_parameter=dict(R=1.0))
+    L = _lib.load()
+    h = C.c_void_p()
+    bad = _lib.GemxConfig.from_buffer_copy(ps._cfg)
+    bad.supply_c = 0.0
+    assert L.gemx_create(C.byref(bad), 4, 0, C.byref(h)) == -1 and b"supply_r" in L.gemx_last_error()
+    eesm = ga.make("Finite-CC-EESM-v0", n_envs=2, supply=ga.RCVoltageSupply(420.0), _defer_create=True).physical_system._cfg
+    assert L.gemx_create(C.byref(eesm), 4, 0, C.byref(h)) == -1 and b"finite EESM" in L.gemx_last_error()
+
+    class AC1PhaseSupply:  # stands for the reference's AC supplies
+        u_nominal = 230.0
+        supply_range = (-325.0, 325.0)
+
+    with pytest.raises(ValueError, match="not on the accelerated path"):
+        ga.make("Cont-CC-PermExDc-v0", n_envs=2, supply=AC1PhaseSupply(), _defer_create=True)
+
+
 def test_multi_converter_holders():
     """Cont/FiniteMultiConverter mirrors (converters.py:498-740): spaces, tau propagation, per-sub-converter dead time."""
     c = ga.ContMultiConverter(subconverters=[ga.ContB6BridgeConverter, ga.ContFourQuadrantConverter], tau=2e-4)
