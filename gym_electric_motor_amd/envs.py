@@ -127,10 +127,14 @@ class BatchedElectricMotorEnv:
         """All envs to the initial state; returns (observations, {})."""
         return self.physical_system.reset(), {}
 
-    def step(self, actions):
-        """-> (obs [N, S_out], reward=None, terminated [N] uint8, truncated=False, {}).  With auto_reset (default for
+    def step(self, actions, references=None):
+        """-> (obs [N, S_out], reward, terminated [N] uint8, truncated=False, {}).  reward: [N] device tensor when a reward function is
+        installed (`physical_system.set_reward`) and `references [N, n_ref]` are passed, else None.  With auto_reset (default for
         n_envs > 1) an env that terminated restarts from the reset state on its next step; the state it shows
         right after that restart is `physical_system.reset_observation`."""
+        if references is not None:
+            obs = self.physical_system.simulate(actions, references=references)
+            return obs, self.physical_system.reward, self.physical_system.done, False, {}
         obs = self.physical_system.simulate(actions)
         return obs, None, self.physical_system.done, False, {}
 

@@ -465,14 +465,28 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         return self._done
 
     @property
+    def reward(self):
+        """[N] device tensor: reward of the last `simulate(action, references=...)` (fused WeightedSumOfErrors)."""
+        return None if getattr(self, "_reward_buf", None) is None else self._reward_buf[0]
+
+    @property
     def reset_observation(self):
         """Normalised state every env shows right after a reset (constant initialiser), numpy [S_out]."""
         return self._reset_obs.copy()
 
-    def simulate(self, action, *_, **__):
+    def simulate(self, action, *_, references=None, **__):
         """One control step.  n_envs == 1: 1-D numpy in / out (reference contract, physical_systems.py:171-203).
         Otherwise `action` is [N, A] (float) or [N] (discrete) and the returned device tensor ([N, S_out]) is an
-        internal buffer that the next call overwrites."""
+        internal buffer that the next call overwrites.
+        references [N, n_ref] (after `set_reward`): the step's reward is evaluated in the same launch -> `self.reward` [N]."""
+        if references is not None:
+            torch = _torch()
+            a = self._actions_to_device(action, (self._n_envs,))
+            if getattr(self, "_reward_buf", None) is None:
+                self._reward_buf = torch.empty((1, self._n_envs), dtype=self._tdtype, device=self._tdev)
+            self._rollout_reward(a.reshape((1,) + tuple(a.shape)), 1, self._obs.reshape((1,) + tuple(self._obs.shape)),
+                                 self._done.reshape(1, -1), torch.as_tensor(references).reshape(1, self._n_envs, -1), self._reward_buf)
+            return self._obs
         single = self._n_envs == 1 and not _torch().is_tensor(action)
         if single and self._discrete and not hasattr(self.action_space, "nvec"):
             assert self.action_space.contains(action), (  # converters.py:204-206

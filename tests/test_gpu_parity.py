@@ -466,6 +466,14 @@ def test_fused_reward_matches_reference_env_rewards(name, n_envs, monkeypatch):
     env3 = _make_from_meta(meta, n_envs, dtype="float32", auto_reset=True)
     o3, d3 = env3.physical_system.rollout(a.cuda())
     assert torch.equal(o3, obs)
+    # closed-loop form: env.step(actions, references) -> (obs, reward, terminated, ...) with the same bits
+    env4 = _make_from_meta(meta, n_envs, dtype="float32", auto_reset=True)
+    _install_reward(env4.physical_system, meta)
+    ac, rc_ = a.cuda(), refs.cuda().float()
+    for k in range(6):
+        o4, r4, t4, _, _ = env4.step(ac[k], references=rc_[k])
+        assert torch.equal(o4, obs[k]) and np.array_equal(r4.double().cpu().numpy(), rew[k])
+    env4.close()
     for e in (env, env2, env3):
         e.close()
 

@@ -34,6 +34,7 @@ CASES = [
     ("PMSM cont control_space=dq", "Cont-CC-PMSM-v0", {"control_space": "dq"}, False),
     ("PMSM cont DqToAbc + DeadTime(1)", "Cont-CC-PMSM-v0", {"wrappers": ("dead1", "dq")}, False),
     ("PMSM finite DeadTime(2)", "Finite-CC-PMSM-v0", {"wrappers": ("dead2",)}, False),
+    ("PMSM finite + RC supply", "Finite-CC-PMSM-v0", {"rc": True}, False),
     ("PMSM finite + fused reward", "Finite-CC-PMSM-v0", {}, True),
     ("SCIM cont SC + fused reward", "Cont-SC-SCIM-v0", {}, True),
 ]
@@ -57,6 +58,8 @@ def main():
     for label, env_id, kw, with_reward in CASES:
         for n in args.envs:
             kw2 = dict(kw)
+            if kw2.pop("rc", False):
+                kw2["supply"] = ga.RCVoltageSupply(u_nominal=420.0, supply_parameter=dict(R=0.5, C=2e-3))
             ws = []
             for wname in kw2.pop("wrappers", ()):
                 ws.append(ga.DeadTimeProcessor(int(wname[4:])) if wname.startswith("dead") else ga.DqToAbcActionProcessor.make("PMSM"))
