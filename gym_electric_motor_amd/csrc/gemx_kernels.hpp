@@ -1290,6 +1290,8 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
     R *hand = reinterpret_cast<R *>(donebuf + (size_t)S * BLOCK);
     constexpr int NACTC = conv_nact_c<CONV>();
     R *fifo = hand + 2 * (size_t)D * BLOCK * NHT;  // DeadTimeProcessor FIFO [delay][64][NACTC], touched by the integrator wave only
+    // action staging buffer [2][D][64 * action bytes], filled by global -> LDS direct loads of the integrator wave
+    unsigned char *actb = reinterpret_cast<unsigned char *>(fifo + (size_t)P.delay * BLOCK * NACTC);
     auto steps_of = [&](int b) { return (K - b * D) < D ? (K - b * D) : D; };
 
     if (wave == 0) {
@@ -1318,28 +1320,43 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
         const bool auto_reset = P.auto_reset != 0;
         uint32_t bad_action = 0;
 
-        // this lane's actions of one block, in registers
-        R pre[D][NACT];
-        uint32_t dpre[D];
-#pragma unroll
-        for (int s = 0; s < D; ++s) {
-            dpre[s] = 0;
-#pragma unroll
-            for (int i = 0; i < NACT; ++i) pre[s][i] = R(0);
-        }
-        const R *act_r = reinterpret_cast<const R *>(a.actions);
-        auto load_actions = [&](int b) {  // coalesced: 64 lanes read 64 consecutive envs of row k
+        // Action staging: global memory -> LDS DIRECTLY (`global_load_lds_dword`: each lane's dword lands at M0 + 4 * lane, no VGPR
+        // destination), one block ahead, double-buffered.  Staging through registers instead put up to D*NACT pending-load VGPRs
+        // into the unrolled steps, and whenever the register allocator placed one of them next to an operand of a packed
+        // instruction (v_pk_* read register PAIRS) the compiler had to insert `s_waitcnt vmcnt(0)` in the middle of the block
+        // (measured 150 -> 164 us per 500-step launch).  The integrator reads its action of a step from LDS one step ahead.
+        constexpr int ABYTES = DISCRETE ? 1 : NACT * (int)sizeof(R);
+        constexpr int ROWB = BLOCK * ABYTES;  // bytes of one 64-env action row (contiguous in the [K][N][A] tensor)
+        auto stage_actions = [&](int b) {
             const int sb = steps_of(b);
+            unsigned char *dst = actb + (size_t)(b & 1) * D * ROWB;
+            const unsigned char *src = a.actions + ((int64_t)b * D * N + blk0) * ABYTES;
+            if (ROWB == 64) {  // uint8 actions: 16 lanes cover a row, so one instruction stages four rows
 #pragma unroll
-            for (int s = 0; s < D; ++s) {
-                if (s < sb) {
-                    const int64_t k = (int64_t)b * D + s;
-                    if (DISCRETE) dpre[s] = a.actions[k * N + env];
-                    else {
-#pragma unroll
-                        for (int i = 0; i < NACT; ++i) pre[s][i] = act_r[(k * N + env) * NACT + i];
-                    }
+                for (int j = 0; j < (D + 3) / 4; ++j) {
+                    int row = 4 * j + (tid >> 4);
+                    row = row < sb ? row : sb - 1;  // tail block: re-read the last valid row
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + (int64_t)row * N + (tid & 15) * 4),
+                                                     (void __attribute__((address_space(3))) *)(dst + (size_t)j * 256), 4, 0, 0);
                 }
+            } else {  // ROWB is a multiple of 256 bytes: each instruction moves 64 consecutive dwords of a row
+#pragma unroll
+                for (int s = 0; s < D; ++s) {
+                    const int row = s < sb ? s : sb - 1;
+#pragma unroll
+                    for (int i = 0; i < ROWB / 256; ++i)
+                        __builtin_amdgcn_global_load_lds(
+                            (const void __attribute__((address_space(1))) *)(src + (int64_t)row * N * ABYTES + i * 256 + tid * 4),
+                            (void __attribute__((address_space(3))) *)(dst + (size_t)s * ROWB + i * 256), 4, 0, 0);
+                }
+            }
+        };
+        auto read_action = [&](int b, int s, R (&dst)[NACT], uint32_t &ddst) {
+            const unsigned char *row = actb + ((size_t)(b & 1) * D + s) * ROWB;
+            if (DISCRETE) ddst = row[tid];
+            else {
+#pragma unroll
+                for (int i = 0; i < NACT; ++i) dst[i] = reinterpret_cast<const R *>(row)[tid * NACT + i];
             }
         };
         // `fifo_possible` (a std::bool_constant): false_type compiles the DeadTimeProcessor queue out, so that the fully
@@ -1389,30 +1406,36 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
                 }
             }
         };
-        load_actions(0);
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): state + first block of actions have landed
+        stage_actions(0);
         for (int b = 0; b < nb; ++b) {
             const int sb = steps_of(b);
             R *hb = hand + (size_t)(b & 1) * D * BLOCK * NHT + (size_t)tid * NHT;
-            R cur[D][NACT];
-            uint32_t dcur[D];
+            // block b's actions (and, the first time, the state) have landed: staged a whole block ago.  Only THEN issue the next
+            // block's staging loads -- they go to the other half of the buffer, which nobody reads during this block.
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            if (b + 1 < nb) stage_actions(b + 1);
+            R an[NACT], ac[NACT];
+            uint32_t dn = 0, dc = 0;
 #pragma unroll
-            for (int s = 0; s < D; ++s) {
-                dcur[s] = dpre[s];
-#pragma unroll
-                for (int i = 0; i < NACT; ++i) cur[s][i] = pre[s][i];
-            }
-            if (b + 1 < nb) load_actions(b + 1);  // prefetch: lands while this block integrates
+            for (int i = 0; i < NACT; ++i) an[i] = R(0);
+            read_action(b, 0, an, dn);
             if (sb == D && P.delay == 0) {
 #pragma unroll
-                for (int s = 0; s < D; ++s) one_step(std::false_type{}, cur[s], dcur[s], hb + (size_t)s * BLOCK * NHT);
-            } else if (sb == D) {
+                for (int s = 0; s < D; ++s) {
+                    dc = dn;
 #pragma unroll
-                for (int s = 0; s < D; ++s) one_step(std::true_type{}, cur[s], dcur[s], hb + (size_t)s * BLOCK * NHT);
-            } else {
+                    for (int i = 0; i < NACT; ++i) ac[i] = an[i];
+                    if (s + 1 < D) read_action(b, s + 1, an, dn);  // one step ahead: its LDS latency hides behind this step
+                    one_step(std::false_type{}, ac, dc, hb + (size_t)s * BLOCK * NHT);
+                }
+            } else {  // tail block, or a DeadTimeProcessor queue is configured
 #pragma unroll
-                for (int s = 0; s < D; ++s)
-                    if (s < sb) one_step(std::true_type{}, cur[s], dcur[s], hb + (size_t)s * BLOCK * NHT);
+                for (int s = 0; s < D; ++s) {
+                    if (s < sb) {
+                        read_action(b, s, ac, dc);
+                        one_step(std::true_type{}, ac, dc, hb + (size_t)s * BLOCK * NHT);
+                    }
+                }
             }
             __syncthreads();  // publishes hand-off block b; wave 1 is done reading block b-1 (other half)
         }
@@ -1473,8 +1496,6 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
             return sb - r0 < RPW ? (sb - r0 < 0 ? 0 : sb - r0) : RPW;
         };
         R rv[RPW][GEMX_MAX_REF];  // fused reward: this wave's references of the next block to process
-        RewardRegs<R> WR;
-        if (a.rw != nullptr) WR.load(a.rw);
         auto process = [&](int pb) {
             const int nr = rows_of(pb);
             if (nr <= 0) return;
@@ -1497,7 +1518,10 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
                 }
             }
             if (a.rw != nullptr) {
-                // references of this block were fetched a whole block ago; the next block's are issued before this block's stores
+                // references of this block were fetched a whole block ago; the next block's are issued before this block's stores.
+                // The description is (re)read from the scalar cache once per block, so that its ~25 SGPRs are live only here
+                RewardRegs<R> WR;
+                WR.load(a.rw);
                 reward_apply<NOUT, RPW, R>(a, WR, ring, donebuf, pb * D + r0, r0, nr, tid, env, true, rv);
                 if (pb + 1 < nb) reward_fetch<RPW, R>(a, (pb + 1) * D + r0, rows_of(pb + 1), env, rv);
             }
@@ -1597,6 +1621,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         auto smem_of = [&](int D) {
             size_t b = (size_t)D * BLOCK * h->nout * sizeof(R) + (size_t)D * BLOCK + 2 * (size_t)D * BLOCK * NHT * sizeof(R);
             b += (size_t)delay * BLOCK * conv_nact_c<CONV>() * sizeof(R);  // DeadTimeProcessor FIFO
+            b += 2 * (size_t)D * BLOCK * ABYTES;                           // action staging (global -> LDS direct)
             return (b + 15) & ~(size_t)15;
         };
         auto resident = [&](int D) {
