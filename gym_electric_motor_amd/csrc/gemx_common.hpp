@@ -205,8 +205,11 @@ template <class R> struct KArgs {
 
 constexpr int MAX_ACT_CHUNKS = 12;  // upper bound of 16-byte chunks of staged actions per lane and I/O block
 constexpr int MAX_STEPS_PER_BLOCK = 32;
-constexpr int PIPE_D = 8;           // pipelined kernel: control steps per hand-off block (one barrier per block)
-constexpr int PIPE_OUT_WAVES = 2;   // pipelined kernel: output/store waves per workgroup (each owns PIPE_D / PIPE_OUT_WAVES rows)      // pipelined kernel: max observation-ring depth
+// pipelined kernel: <control steps per hand-off block (one barrier per block), output/store waves per workgroup>.
+//   <12, 3>: N small enough for one resident workgroup per CU: integrator + 3 output waves = one wave on each of the CU's 4 SIMDs;
+//   < 4, 2>: up to ~2 rounds of 4 resident workgroups per CU (a third of the LDS per workgroup).
+constexpr int PIPE_D = 12, PIPE_OUT_WAVES = 3;
+constexpr int PIPE_D2 = 4, PIPE_OUT_WAVES2 = 2;
 // chunks per lane needed to stage MAX_STEPS_PER_BLOCK steps of a row made of `cpr` 16-byte chunks
 __host__ __device__ constexpr int act_chunks(int cpr) {
     return (MAX_STEPS_PER_BLOCK * cpr + BLOCK - 1) / BLOCK < MAX_ACT_CHUNKS ? (MAX_STEPS_PER_BLOCK * cpr + BLOCK - 1) / BLOCK : MAX_ACT_CHUNKS;

@@ -1264,8 +1264,8 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
 // Preconditions (checked by the launcher): full 64-env workgroups, 16-byte aligned tensors (coop), obs_every, K >= 2,
 // constraint kind none/default, S a multiple of PIPE_D.
 // ------------------------------------------------------------------------------------------------
-template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R, int D>
-__global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_kernel(const KArgs<R> a) {
+template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R, int D, int OW>
+__global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KArgs<R> a) {
     constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
     constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
     constexpr bool HAS_ANGLE = SysTraits<SYS>::HAS_ANGLE;
@@ -1327,9 +1327,10 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
         // (measured 150 -> 164 us per 500-step launch).  The integrator reads its action of a step from LDS one step ahead.
         constexpr int ABYTES = DISCRETE ? 1 : NACT * (int)sizeof(R);
         constexpr int ROWB = BLOCK * ABYTES;  // bytes of one 64-env action row (contiguous in the [K][N][A] tensor)
+        constexpr int DP = ROWB == 64 ? (D + 3) / 4 * 4 : D;  // rows per buffer half (uint8 rows are staged four at a time)
         auto stage_actions = [&](int b) {
             const int sb = steps_of(b);
-            unsigned char *dst = actb + (size_t)(b & 1) * D * ROWB;
+            unsigned char *dst = actb + (size_t)(b & 1) * DP * ROWB;
             const unsigned char *src = a.actions + ((int64_t)b * D * N + blk0) * ABYTES;
             if (ROWB == 64) {  // uint8 actions: 16 lanes cover a row, so one instruction stages four rows
 #pragma unroll
@@ -1352,7 +1353,7 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
             }
         };
         auto read_action = [&](int b, int s, R (&dst)[NACT], uint32_t &ddst) {
-            const unsigned char *row = actb + ((size_t)(b & 1) * D + s) * ROWB;
+            const unsigned char *row = actb + ((size_t)(b & 1) * DP + s) * ROWB;
             if (DISCRETE) ddst = row[tid];
             else {
 #pragma unroll
@@ -1485,10 +1486,11 @@ __global__ __launch_bounds__((1 + PIPE_OUT_WAVES) * BLOCK) void advance_pipe_ker
 #pragma unroll
             for (int j = 0; j < NHT; ++j) row[j] = src[j];
         };
-        // output wave `ow` of PIPE_OUT_WAVES owns rows [ow*RPW, (ow+1)*RPW) of every hand-off block: it turns them into
+        // output wave `ow` of OW owns rows [ow*RPW, (ow+1)*RPW) of every hand-off block: it turns them into
         // observation rows in ITS part of the ring and flushes them itself -- the output waves never synchronise with
         // each other, only with the integrator at the block barrier.
-        constexpr int RPW = D / PIPE_OUT_WAVES;
+        static_assert(D % OW == 0, "rows per output wave");
+        constexpr int RPW = D / OW;
         const int ow = wave - 1;
         const int r0 = ow * RPW;
         auto rows_of = [&](int pb) {  // rows of this wave in block pb (may be <= 0 in the tail block)
@@ -1621,29 +1623,32 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         auto smem_of = [&](int D) {
             size_t b = (size_t)D * BLOCK * h->nout * sizeof(R) + (size_t)D * BLOCK + 2 * (size_t)D * BLOCK * NHT * sizeof(R);
             b += (size_t)delay * BLOCK * conv_nact_c<CONV>() * sizeof(R);  // DeadTimeProcessor FIFO
-            b += 2 * (size_t)D * BLOCK * ABYTES;                           // action staging (global -> LDS direct)
+            b += 2 * (size_t)((D + 3) / 4 * 4) * BLOCK * ABYTES;           // action staging (global -> LDS direct)
             return (b + 15) & ~(size_t)15;
         };
-        auto resident = [&](int D) {
+        auto resident = [&](int D, int OW) {
             int64_t w = (int64_t)(h->lds_max / smem_of(D));
-            const int64_t wmax = 32 / (1 + PIPE_OUT_WAVES);
+            const int64_t wmax = 32 / (1 + OW);
             return (w > wmax ? wmax : w) * (int64_t)h->n_cu;
         };
-        const int D = (blocks <= resident(PIPE_D) || resident(PIPE_D / 2) == resident(PIPE_D)) ? PIPE_D : PIPE_D / 2;
-        if (smem_of(D) <= h->lds_max && (h->use_pipe > 0 || blocks <= 2 * resident(D))) {
+        // one resident round of the 4-wave variant if N is that small, else the 3-wave variant for up to two rounds
+        int D = 0, OW = 0;
+        if (smem_of(PIPE_D) <= h->lds_max && blocks <= resident(PIPE_D, PIPE_OUT_WAVES)) { D = PIPE_D; OW = PIPE_OUT_WAVES; }
+        else if (smem_of(PIPE_D2) <= h->lds_max && (h->use_pipe > 0 || blocks <= 2 * resident(PIPE_D2, PIPE_OUT_WAVES2))) { D = PIPE_D2; OW = PIPE_OUT_WAVES2; }
+        if (D != 0) {
             a.S = D;
             a.D = D;
             const size_t psmem = smem_of(D);
-            auto pkern = D == PIPE_D ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D>
-                                     : advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D / 2>;
+            auto pkern = D == PIPE_D ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES>
+                                     : advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2>;
             static bool pattr_set[2] = {false, false};
             if (!pattr_set[D == PIPE_D]) {
                 GEMX_HIP_TRY(hipFuncSetAttribute((const void *)pkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max));
                 pattr_set[D == PIPE_D] = true;
             }
-            hipLaunchKernelGGL(pkern, dim3((unsigned)blocks), dim3((1 + PIPE_OUT_WAVES) * BLOCK), psmem, st, a);
+            hipLaunchKernelGGL(pkern, dim3((unsigned)blocks), dim3((1 + OW) * BLOCK), psmem, st, a);
             GEMX_HIP_TRY(hipGetLastError());
-            h->ll = {1, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), D, (1 + PIPE_OUT_WAVES) * BLOCK, K, D, (long long)blocks, psmem};
+            h->ll = {1, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), D, (1 + OW) * BLOCK, K, D, (long long)blocks, psmem};
             return GEMX_OK;
         }
     }
