@@ -250,7 +250,7 @@ struct gemx_handle {
     struct LastLaunch { int pipe, sys, conv, load, solver, il, real_size, d, threads, k, s; long long blocks; size_t lds; };
     LastLaunch ll = {};            // most recent advance launch (formatted lazily by gemx_last_launch)
     mutable char last_launch[256] = "";
-    int use_pipe = -1;        // two-wave pipelined kernel: -1 auto (small N only), 0 never, 1 whenever eligible
+    int use_pipe = -1;        // pipelined kernel: -1 / 1 whenever eligible (default), 0 never (GEMX_PIPE=0: A/B and bit-identity tests)
 };
 
 namespace gemx {

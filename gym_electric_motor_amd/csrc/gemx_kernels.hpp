@@ -1631,10 +1631,12 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             const int64_t wmax = 32 / (1 + OW);
             return (w > wmax ? wmax : w) * (int64_t)h->n_cu;
         };
-        // one resident round of the 4-wave variant if N is that small, else the 3-wave variant for up to two rounds
+        // one resident round of the 4-wave shape if N is that small, else the 3-wave shape at ANY N: measured at 131072 and 1048576
+        // envs over all motor families (profiles/r01d_matrix.md) it is on par with or ahead of the single-wave kernel (PMSM
+        // 1M envs: 100 vs 86 G env-steps/s) -- the split keeps stores fire-and-forget and the integrator free of vmcnt waits
         int D = 0, OW = 0;
         if (smem_of(PIPE_D) <= h->lds_max && blocks <= resident(PIPE_D, PIPE_OUT_WAVES)) { D = PIPE_D; OW = PIPE_OUT_WAVES; }
-        else if (smem_of(PIPE_D2) <= h->lds_max && (h->use_pipe > 0 || blocks <= 2 * resident(PIPE_D2, PIPE_OUT_WAVES2))) { D = PIPE_D2; OW = PIPE_OUT_WAVES2; }
+        else if (smem_of(PIPE_D2) <= h->lds_max) { D = PIPE_D2; OW = PIPE_OUT_WAVES2; }
         if (D != 0) {
             a.S = D;
             a.D = D;
