@@ -12,6 +12,7 @@ SYS_DC_PERMEX, SYS_SYNC, SYS_SCIM, SYS_DC_SERIES, SYS_DC_SHUNT, SYS_DC_EXTEX, SY
 CONV_CONT_4QC, CONV_FINITE_B6, CONV_CONT_B6, CONV_FINITE_4QC = 0, 1, 2, 3
 ACT_ABC, ACT_DQ_SPACE, ACT_DQ_PROCESSOR = 0, 1, 2
 SUPPLY_IDEAL, SUPPLY_RC = 0, 1
+INIT_CONST, INIT_UNIFORM, INIT_GAUSSIAN = 0, 1, 2
 MAX_DELAY = 8
 CONV_CONT_2X4QC, CONV_FINITE_2X4QC, CONV_CONT_B6_4QC, CONV_FINITE_B6_4QC, CONV_CONT_2XB6, CONV_FINITE_2XB6 = 4, 5, 6, 7, 8, 9
 LOAD_CONST_SPEED, LOAD_POLY_STATIC = 0, 1
@@ -30,7 +31,10 @@ class GemxConfig(C.Structure):
         ("dtype", C.c_int32), ("obs_layout", C.c_int32), ("auto_reset", C.c_int32),
         ("limit_mask", C.c_uint32), ("squared_mask", C.c_uint32),
         ("action_frame", C.c_int32), ("action_delay", C.c_int32),
-        ("supply_kind", C.c_int32), ("reserved0", C.c_int32), ("supply_r", C.c_double), ("supply_c", C.c_double),
+        ("supply_kind", C.c_int32), ("init_kind", C.c_int32), ("seed", C.c_uint64),
+        ("init_lo", C.c_double * MAX_ODE), ("init_hi", C.c_double * MAX_ODE), ("init_mu", C.c_double * MAX_ODE),
+        ("init_sigma", C.c_double * MAX_ODE),
+        ("supply_r", C.c_double), ("supply_c", C.c_double),
         ("tau", C.c_double), ("interlocking_time", C.c_double), ("u_nominal", C.c_double),
         ("model", C.c_double * (MODEL_ROWS * MODEL_COLS)),
         ("torque_coef", C.c_double * 4),

@@ -212,8 +212,8 @@ class _ElectricMotor:
         self._limits = update_parameter_dict(self._default_limits, limit_values or {})
         self._nominal_values = update_parameter_dict(self._default_nominal_values, nominal_values or {})
         self._initializer = update_parameter_dict(self._default_initializer, motor_initializer or {})
-        if self._initializer.get("random_init") is not None:
-            raise NotImplementedError("random motor initialisers are not on the accelerated path yet (SURVEY.md 8f rank 4)")
+        if self._initializer.get("random_init") not in (None, "uniform", "normal", "gaussian"):
+            raise NotImplementedError(f"random_init {self._initializer.get('random_init')!r} (electric_motor.py:229-257 knows uniform / gaussian)")
         self._initial_states = dict(self._initializer["states"] or {})
 
     motor_parameter = property(lambda self: self._motor_parameter)
@@ -668,8 +668,8 @@ class _MechanicalLoad:
         self._nominal_values = {}
         self._initializer = dict(self._default_initializer)
         self._initializer.update(load_initializer or {})
-        if self._initializer.get("random_init") is not None:
-            raise NotImplementedError("random load initialisers are not on the accelerated path yet (SURVEY.md 8f rank 4)")
+        if self._initializer.get("random_init") not in (None, "uniform", "normal", "gaussian"):
+            raise NotImplementedError(f"random_init {self._initializer.get('random_init')!r} (mechanical_load.py:131-156 knows uniform / gaussian)")
         self._initial_states = dict(self._initializer.get("states", {"omega": 0.0}))
 
     j_total = property(lambda self: self._j_total)

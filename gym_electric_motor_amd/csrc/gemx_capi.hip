@@ -9,14 +9,59 @@
 
 namespace gemx {
 
-// reset: masked envs back to the initial ODE state; optional broadcast of the reset observation
+// Reset observation of ONE env from its (freshly drawn) initial state: SCMLSystem.reset 256-287 (DC systems),
+// SynchronousMotorSystem.reset 527-561, ExternallyExcitedSynchronousMotorSystem.reset 654-691 -- the systems random
+// initialisers are available for.  Converter reset voltages: 0 per 4QC, -0.5 u_sup per B6 leg.
+template <class R>
+__device__ void reset_obs_row(int sys, const DevParams<R> &P, const double *y, double eps, int nd, double *o) {
+    const double us = (double)P.u_sup;
+    if (sys == GEMX_SYS_SYNC || sys == GEMX_SYS_EESM) {
+        if (eps > kPi) eps -= kTwoPi;
+        const double c = cos(eps), s = sin(eps);
+        const double al = c * y[1] - s * y[2], be = s * y[1] + c * y[2];
+        const double ua = -0.5 * us, ual = 2.0 / 3.0 * (ua - 0.5 * ua - 0.5 * ua), ube = 2.0 / 3.0 * (0.5 * sqrt(3.0) * ua - 0.5 * sqrt(3.0) * ua);
+        o[0] = y[0];
+        o[2] = al; o[3] = -0.5 * al + 0.5 * sqrt(3.0) * be; o[4] = -0.5 * al - 0.5 * sqrt(3.0) * be;
+        o[5] = y[1]; o[6] = y[2];
+        if (sys == GEMX_SYS_SYNC) {
+            o[1] = ((double)P.tc0 + (double)P.tc1 * y[1]) * y[2];
+            o[7] = ua; o[8] = ua; o[9] = ua; o[10] = c * ual + s * ube; o[11] = -s * ual + c * ube; o[12] = eps; o[13] = us;
+        } else {  // (u_a, u_b, u_c, u_e, u_sd, u_sq): the reference's reset layout, lines 679-690
+            o[1] = ((double)P.tc0 * y[3] + (double)P.tc1 * y[1]) * y[2];
+            o[7] = y[3];
+            o[8] = ua; o[9] = ua; o[10] = ua; o[11] = 0.0; o[12] = c * ual + s * ube; o[13] = -s * ual + c * ube; o[14] = eps; o[15] = us;
+        }
+    } else {  // DC systems: [omega, torque, currents..., u (0 per converter), u_sup]
+        const int nc = nd - 1, nu = sys == GEMX_SYS_DC_EXTEX ? 2 : 1;
+        double torque = (double)P.tc0 * y[1];
+        if (sys == GEMX_SYS_DC_SERIES) torque = (double)P.tc0 * y[1] * y[1];
+        if (sys == GEMX_SYS_DC_SHUNT || sys == GEMX_SYS_DC_EXTEX) torque = (double)P.tc0 * y[1] * y[2];
+        o[0] = y[0]; o[1] = torque;
+        for (int i = 0; i < nc; ++i) o[2 + i] = y[1 + i];
+        for (int j = 0; j < nu; ++j) o[2 + nc + j] = 0.0;
+        o[2 + nc + nu] = us;
+    }
+}
+
+// reset: masked envs back to the initial ODE state (constant, or drawn per env: electric_motor.py:150-257,
+// mechanical_load.py:100-160); optional reset observation
 template <class R>
 __global__ void reset_kernel(R *state, typename Angle<R>::T *angle, const uint8_t *mask, R *obs, int64_t N, int nd, int nout,
-                             int has_angle, int obs_layout, DevParams<R> P, const R *reset_obs, unsigned char *ring, int ring_row_bytes) {
+                             int has_angle, int obs_layout, DevParams<R> P, const R *reset_obs, unsigned char *ring, int ring_row_bytes,
+                             int sys, const InitDev *rinit, uint32_t *rcnt) {
     int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= N) return;
     if (mask != nullptr && mask[env] == 0) return;
-    for (int j = 0; j < nd; ++j) state[(int64_t)j * N + env] = P.init[j];
+    double y0[GEMX_MAX_ODE];
+    for (int j = 0; j < nd; ++j) y0[j] = (double)P.init[j];
+    double eps0 = 0.0;
+    if (P.init_kind) {
+        const uint32_t count = rcnt[env] + 1u;
+        rcnt[env] = count;
+        for (int j = 0; j < nd; ++j) y0[j] = sample_init_state(rinit, env, count, j);
+        if (has_angle) eps0 = sample_init_state(rinit, env, count, nd);
+    }
+    for (int j = 0; j < nd; ++j) state[(int64_t)j * N + env] = (R)y0[j];
     if (P.rc_supply) {  // RCVoltageSupply.reset (voltage_supplies.py:108-114): capacitor loaded, the supply's clock at 0
         state[(int64_t)nd * N + env] = P.u_sup;
         state[(int64_t)(nd + 1) * N + env] = R(0);
@@ -24,11 +69,17 @@ __global__ void reset_kernel(R *state, typename Angle<R>::T *angle, const uint8_
     // DeadTimeProcessor.reset (dead_time_processor.py:63-72): the deque is refilled with the (zero) reset action
     for (int d = 0; d < P.delay; ++d)
         for (int b = 0; b < ring_row_bytes; ++b) ring[((int64_t)d * N + env) * ring_row_bytes + b] = 0;
-    if (has_angle) angle[env] = Angle<R>::from_bits(P.init_angle_rep);
+    if (has_angle) angle[env] = P.init_kind ? Angle<R>::from_rad(eps0) : Angle<R>::from_bits(P.init_angle_rep);
     if (obs != nullptr) {
+        double row[GEMX_MAX_OUT];
+        if (P.init_kind) {
+            reset_obs_row<R>(sys, P, y0, eps0, nd, row);
+            for (int j = 0; j < nout; ++j) row[j] *= (double)P.inv_lim[j];
+        }
         for (int j = 0; j < nout; ++j) {
-            if (obs_layout == GEMX_OBS_AOS) obs[env * nout + j] = reset_obs[j];
-            else obs[(int64_t)j * N + env] = reset_obs[j];
+            const R v = P.init_kind ? (R)row[j] : reset_obs[j];
+            if (obs_layout == GEMX_OBS_AOS) obs[env * nout + j] = v;
+            else obs[(int64_t)j * N + env] = v;
         }
     }
 }
@@ -138,6 +189,7 @@ template <class R> static void fill_params(const gemx_handle &h, const double *m
     for (int i = 0; i < h.nd; ++i) P.init[i] = (R)c.init_state[i];
     P.init_angle_rep = Angle<R>::to_bits(Angle<R>::from_rad(h.has_angle ? c.init_state[h.nd] : 0.0));
     P.nsteps = c.solver_nsteps;
+    P.init_kind = c.init_kind;
     P.rc_supply = c.supply_kind == GEMX_SUPPLY_RC;
     P.sup_r = (R)c.supply_r;
     P.sup_inv_rc = (R)(P.rc_supply ? 1.0 / (c.supply_r * c.supply_c) : 0.0);
@@ -246,7 +298,8 @@ template <class R> static int launch_reset(gemx_handle *h, const uint8_t *mask, 
     int64_t blocks = (h->n + 255) / 256;
     hipLaunchKernelGGL(reset_kernel<R>, dim3((unsigned)blocks), dim3(256), 0, st, (R *)h->state, (AngT *)h->angle, mask, (R *)obs, h->n,
                        h->nd, h->nout, h->has_angle, h->cfg.obs_layout, P, (const R *)h->reset_obs_dev, (unsigned char *)h->ring,
-                       h->cfg.action_delay > 0 ? (int)(h->ring_bytes / ((size_t)h->cfg.action_delay * (size_t)h->n)) : 0);
+                       h->cfg.action_delay > 0 ? (int)(h->ring_bytes / ((size_t)h->cfg.action_delay * (size_t)h->n)) : 0, h->cfg.system_kind,
+                       (const InitDev *)h->rinit_dev, h->rcnt);
     HIP_TRY(hipGetLastError());
     return GEMX_OK;
 }
@@ -361,6 +414,22 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
                                       "also SCIM); the SCIM / DFIM dq processors need a flux observer, which is not on the accelerated path",
                         cfg->action_frame);
     }
+    if (cfg->init_kind < GEMX_INIT_CONST || cfg->init_kind > GEMX_INIT_GAUSSIAN) return fail(GEMX_ERR_ARG, "unknown init_kind");
+    if (cfg->init_kind != GEMX_INIT_CONST) {
+        const int n_ode = (s == GEMX_SYS_DC_PERMEX || s == GEMX_SYS_DC_SERIES) ? 2 : ((s == GEMX_SYS_DC_SHUNT || s == GEMX_SYS_DC_EXTEX) ? 3 :
+                          (s == GEMX_SYS_SYNC ? 4 : (s == GEMX_SYS_EESM ? 5 : 6)));
+        for (int j = 0; j < n_ode; ++j) {
+            if (cfg->init_lo[j] > cfg->init_hi[j]) return fail(GEMX_ERR_ARG, "init_lo[%d] > init_hi[%d]", j, j);
+            if (cfg->init_lo[j] < cfg->init_hi[j]) {
+                if (cfg->init_kind == GEMX_INIT_GAUSSIAN && !(cfg->init_sigma[j] > 0)) return fail(GEMX_ERR_ARG, "init_sigma[%d] must be positive", j);
+                if (j > 0 && (s == GEMX_SYS_SCIM || s == GEMX_SYS_DFIM))
+                    return fail(GEMX_ERR_ARG, "random MOTOR initial states are not available for the induction-motor systems (flux limits, "
+                                              "induction_motor.py:314-364, are not on the accelerated path); the load's omega is");
+                if (j == 0 && cfg->load_kind == GEMX_LOAD_CONST_SPEED)
+                    return fail(GEMX_ERR_ARG, "a ConstantSpeedLoad has no random initial omega (constant_speed_load.py:30-38)");
+            }
+        }
+    }
     if (cfg->supply_kind != GEMX_SUPPLY_IDEAL && cfg->supply_kind != GEMX_SUPPLY_RC) return fail(GEMX_ERR_ARG, "unknown supply_kind");
     if (cfg->supply_kind == GEMX_SUPPLY_RC) {
         if (!(cfg->supply_r > 0 && cfg->supply_c > 0)) return fail(GEMX_ERR_ARG, "RC supply needs supply_r > 0 and supply_c > 0");
@@ -436,6 +505,21 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         h->ring_bytes = (size_t)cfg->action_delay * (size_t)h->n * (disc ? 1 : (size_t)h->nact_conv * es);
         if (hipMalloc(&h->ring, h->ring_bytes) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(delay ring) failed"));
     }
+    if (cfg->init_kind != GEMX_INIT_CONST) {
+        InitDev I;
+        memset(&I, 0, sizeof(I));
+        I.kind = cfg->init_kind;
+        I.n = h->nd + h->has_angle;
+        I.seed = cfg->seed;
+        for (int j = 0; j < I.n; ++j) {
+            I.lo[j] = cfg->init_lo[j]; I.hi[j] = cfg->init_hi[j]; I.mu[j] = cfg->init_mu[j]; I.sigma[j] = cfg->init_sigma[j];
+            I.constant[j] = cfg->init_state[j];
+        }
+        if (hipMalloc(&h->rinit_dev, sizeof(InitDev)) != hipSuccess || hipMalloc((void **)&h->rcnt, sizeof(uint32_t) * (size_t)h->n) != hipSuccess)
+            return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(random initialiser) failed"));
+        if (hipMemcpy(h->rinit_dev, &I, sizeof(I), hipMemcpyHostToDevice) != hipSuccess || hipMemset(h->rcnt, 0, sizeof(uint32_t) * (size_t)h->n) != hipSuccess)
+            return cleanup(fail(GEMX_ERR_DEVICE, "hipMemcpy failed"));
+    }
     if (hipMalloc((void **)&h->err, sizeof(uint32_t)) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(err) failed"));
     if (hipMalloc(&h->reset_obs_dev, es * GEMX_MAX_OUT) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(reset_obs) failed"));
     if (hipMalloc(&h->cw_dev, es * 2 * GEMX_MAX_OUT) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(cw) failed"));
@@ -480,6 +564,8 @@ int gemx_destroy(gemx_handle *h) {
     if (h->sw) (void)hipFree(h->sw);
     if (h->ring) (void)hipFree(h->ring);
     if (h->rw_dev) (void)hipFree(h->rw_dev);
+    if (h->rinit_dev) (void)hipFree(h->rinit_dev);
+    if (h->rcnt) (void)hipFree(h->rcnt);
     if (h->err) (void)hipFree(h->err);
     if (h->reset_obs_dev) (void)hipFree(h->reset_obs_dev);
     if (h->cw_dev) (void)hipFree(h->cw_dev);

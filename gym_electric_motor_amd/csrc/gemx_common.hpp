@@ -81,6 +81,7 @@ template <class R> struct DevParams {
     int64_t init_angle_rep; // initial angle in Angle<R>::T representation (bit pattern)
     int32_t nsteps, auto_reset, obs_layout;
     int32_t constr_kind;    // 0 none, 1 the system's default constraint (fast path), 2 generic weights
+    int32_t init_kind;      // != 0: initial states are drawn per reset (rinit / reset counters in KArgs)
     int32_t rc_supply;      // RCVoltageSupply: u_sup is a per-env state (rows ND, ND+1 of the state array: u, time since last update)
     R sup_r, sup_inv_rc;    // R, 1 / (R C)
     int32_t dq_processor;   // dq action frames: 0 control_space='dq' (step-start angle), 1 DqToAbcActionProcessor (advanced angle)
@@ -165,6 +166,47 @@ template <class R> __device__ __forceinline__ void t32(R al, R be, R &a, R &b, R
 
 
 // ------------------------------------------------------------------------------------------------
+// random initial states: Philox4x32-10 (Salmon et al., SC'11), counter = (env lo, env hi, reset count, block), key = seed.
+// Counter-based, so a reset needs no RNG state beyond the env's reset count.
+// ------------------------------------------------------------------------------------------------
+struct Philox {
+    static __host__ __device__ __forceinline__ void round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    }
+    static __host__ __device__ __forceinline__ void block(uint64_t seed, uint64_t env, uint32_t count, uint32_t blk, uint32_t (&out)[4]) {
+        uint32_t c[4] = {(uint32_t)env, (uint32_t)(env >> 32), count, blk};
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+        for (int r = 0; r < 10; ++r) {
+            round(c, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        for (int i = 0; i < 4; ++i) out[i] = c[i];
+    }
+    // uniform in the open interval (0, 1), 32 bits of resolution
+    static __host__ __device__ __forceinline__ double u01(uint32_t x) { return ((double)x + 0.5) * (1.0 / 4294967296.0); }
+};
+// per-state sampling description (device array read in the rare reset path only)
+struct InitDev {
+    int32_t kind, n;  // gemx_init_kind; number of ODE states incl. the angle
+    uint64_t seed;
+    double lo[GEMX_MAX_ODE], hi[GEMX_MAX_ODE], mu[GEMX_MAX_ODE], sigma[GEMX_MAX_ODE], constant[GEMX_MAX_ODE];
+};
+// the j-th initial state of (env, reset count): uniform or truncated normal by inverse CDF (reset path: fp64 throughout)
+__device__ inline double sample_init_state(const InitDev *I, int64_t env, uint32_t count, int j) {
+    if (!(I->lo[j] < I->hi[j])) return I->constant[j];
+    uint32_t r[4];
+    Philox::block(I->seed, (uint64_t)env, count, (uint32_t)(j >> 2), r);
+    const double u = Philox::u01(r[j & 3]);
+    if (I->kind == GEMX_INIT_UNIFORM) return I->lo[j] + (I->hi[j] - I->lo[j]) * u;
+    const double a = normcdf((I->lo[j] - I->mu[j]) / I->sigma[j]), b = normcdf((I->hi[j] - I->mu[j]) / I->sigma[j]);
+    double x = I->mu[j] + I->sigma[j] * normcdfinv(a + (b - a) * u);
+    return fmin(fmax(x, I->lo[j]), I->hi[j]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused reward (WeightedSumOfErrors): device-resident description, read through scalar loads when a reward is requested
 // ------------------------------------------------------------------------------------------------
 template <class R> struct RewardDev {
@@ -192,6 +234,8 @@ template <class R> struct KArgs {
     unsigned char *ring;            // [delay][N][A_conv] R | [delay][N] uint8: DeadTimeProcessor FIFO between launches
     int32_t ring_phase;             // FIFO slot of this launch's first step (global step count mod delay)
     uint32_t *err;                  // device error word (bit 0: discrete action out of range)
+    const InitDev *rinit;           // random initial states: description, per-env reset counters [N]
+    uint32_t *rcnt;
     const RewardDev<R> *rw;         // fused reward: description (nullptr: no reward), references [K][N][n_ref], output [K][N]
     const R *refs;
     R *reward;
@@ -231,6 +275,8 @@ struct gemx_handle {
     void *angle = nullptr;   // [n] int32 | double
     uint8_t *sw = nullptr;   // [sw_rows][n]
     int sw_rows = 1;
+    void *rinit_dev = nullptr;  // InitDev (random initial states)
+    uint32_t *rcnt = nullptr;   // [n] resets so far per env
     void *rw_dev = nullptr;  // RewardDev<R> (gemx_set_reward)
     int rw_n_ref = -1;       // -1: no reward installed
     const void *cur_refs = nullptr;  // set by gemx_rollout_reward around the launch

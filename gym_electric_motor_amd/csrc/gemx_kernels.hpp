@@ -804,6 +804,17 @@ __device__ __forceinline__ R supply_current(const DevParams<R> &P, const R (&y)[
     return tot;
 }
 
+// in-kernel auto-reset with random initialisers: a fresh initial state for this env, its reset counter advanced (rare path)
+template <int SYS, class R>
+__device__ __noinline__ void draw_initial_state(const KArgs<R> &a, int64_t env, R (&y)[SysTraits<SYS>::ND], typename Angle<R>::T &ang) {
+    constexpr int ND = SysTraits<SYS>::ND;
+    const uint32_t count = a.rcnt[env] + 1u;
+    a.rcnt[env] = count;
+#pragma unroll
+    for (int j = 0; j < ND; ++j) y[j] = (R)sample_init_state(a.rinit, env, count, j);
+    if (SysTraits<SYS>::HAS_ANGLE) ang = Angle<R>::from_rad(sample_init_state(a.rinit, env, count, ND));
+}
+
 // step() for the single-wave kernel
 template <class ST, int ND, int NOUT, class R>
 __device__ __forceinline__ void full_step(const DevParams<R> &P, R (&y)[ND], typename Angle<R>::T &ang, uint32_t &sw, const R (&act)[MAX_ACT],
@@ -1056,6 +1067,7 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
 #pragma unroll
             for (int j = 0; j < ND; ++j) y[j] = P.init[j];
             ang = init_ang;
+            if (P.init_kind && (int64_t)blockIdx.x * BLOCK + tid < a.N) draw_initial_state<SYS, R>(a, e, y, ang);  // (not the clamped tail lanes)
             sup[0] = P.u_sup;  // RCVoltageSupply.reset: the capacitor is loaded again, the supply's clock restarts
             sup[1] = R(0);
             for (int d = 0; d < P.delay; ++d) {  // DeadTimeProcessor.reset: the deque is refilled with the reset action
@@ -1400,6 +1412,7 @@ __global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KA
 #pragma unroll
             for (int j = 0; j < ND; ++j) y[j] = rs ? P.init[j] : y[j];
             ang = rs ? init_ang : ang;
+            if (FIFO && P.init_kind && rs) draw_initial_state<SYS, R>(a, env, y, ang);
             if (FIFO && P.delay > 0 && rs) {  // DeadTimeProcessor.reset: the deque is refilled with the (zero) reset action
                 for (int d = 0; d < P.delay; ++d) {
 #pragma unroll
@@ -1420,7 +1433,7 @@ __global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KA
 #pragma unroll
             for (int i = 0; i < NACT; ++i) an[i] = R(0);
             read_action(b, 0, an, dn);
-            if (sb == D && P.delay == 0) {
+            if (sb == D && P.delay == 0 && P.init_kind == 0) {
 #pragma unroll
                 for (int s = 0; s < D; ++s) {
                     dc = dn;
@@ -1584,6 +1597,8 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     a.ring_phase = delay > 0 ? (int)(h->steps_total % (unsigned long long)delay) : 0;
     h->steps_total += (unsigned long long)K;
     a.err = h->err;
+    a.rinit = (const InitDev *)h->rinit_dev;
+    a.rcnt = h->rcnt;
     a.rw = h->cur_reward != nullptr ? (const RewardDev<R> *)h->rw_dev : nullptr;
     a.refs = (const R *)h->cur_refs;
     a.reward = (R *)h->cur_reward;

@@ -87,7 +87,7 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
 
     def __init__(self, converter, motor, load, supply, ode_solver, tau=1e-4, calc_jacobian=None, n_envs=1, device=0,
                  dtype="float32", constraints=(), auto_reset=None, obs_layout="aos", control_space="abc", action_frame=None,
-                 action_delay=0, _defer_create=False):
+                 action_delay=0, seed=0, _defer_create=False):
         """
         Args (first six as in SCMLSystem.__init__, physical_systems.py:54-65):
             converter, motor, load, supply: component instances (this package's or the reference's).
@@ -116,6 +116,7 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             action_frame = "dq" if control_space == "dq" else "abc"
         if action_frame not in ("abc", "dq", "dq_processor"):
             raise ValueError(f"action_frame must be 'abc', 'dq' or 'dq_processor', got {action_frame!r}")
+        self._seed = int(seed) & (2**64 - 1)
         self._action_frame = action_frame
         self._action_delay = int(action_delay)
         if not 0 <= self._action_delay <= _lib.MAX_DELAY:
@@ -376,7 +377,45 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         assert len(init) == self._n_ode
         for i, v in enumerate(init):
             cfg.init_state[i] = float(v)
+        self._fill_random_init(cfg)
         return cfg
+
+    def _fill_random_init(self, cfg):
+        """Random initialisers (`motor_initializer` / `load_initializer` with random_init='uniform' | 'gaussian'): per-ODE-state
+        sampling bounds exactly as electric_motor.py:199-227 / mechanical_load.py:117-130 derive them -- upper = nominal value of the
+        state, lower = upper * state_space.low, both clipped to `interval` -- in the ODE slot order the reference fills (the VALUES of
+        the `states` dict in dict order, electric_motor.py:270-285)."""
+        pos, low = self._state_positions, np.asarray(self._state_space.low, dtype=float)
+        kinds = set()
+
+        def bounds(component, nominal_of, slot0):
+            ini = getattr(component, "initializer", None) or {}
+            dist = ini.get("random_init")
+            if dist is None:
+                return
+            kinds.add("uniform" if dist == "uniform" else "gaussian")
+            names = list((ini.get("states") or {}).keys())
+            interval = ini.get("interval")
+            mue, sigma = (ini.get("random_params") or (None, None))
+            for k_, name in enumerate(names):
+                up = float(nominal_of(name))
+                lo = up * low[pos[name]] if name in pos else -up  # epsilon etc. are system states too
+                if interval is not None:
+                    iv = np.asarray(interval, dtype=float).reshape(-1, 2)
+                    lo, up = max(lo, iv[k_][0]), min(up, iv[k_][1])
+                j = slot0 + k_
+                cfg.init_lo[j], cfg.init_hi[j] = lo, up
+                cfg.init_mu[j] = float(mue) if mue else (up - lo) / 2 + lo
+                cfg.init_sigma[j] = float(sigma) if sigma else 1.0
+
+        ld = self._mechanical_load
+        bounds(ld, lambda n: self._nominal_state[pos[n]], 0)
+        mot = self._electrical_motor
+        bounds(mot, lambda n: mot.nominal_values[n], 1)
+        if len(kinds) > 1:
+            raise ValueError("motor and load initialisers must use the same distribution on the accelerated path")
+        cfg.init_kind = {"uniform": _lib.INIT_UNIFORM, "gaussian": _lib.INIT_GAUSSIAN}[kinds.pop()] if kinds else _lib.INIT_CONST
+        cfg.seed = self._seed
 
     # ------------------------------------------------------------------ device plumbing (torch = memory + streams)
     def _create(self):

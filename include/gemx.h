@@ -75,6 +75,7 @@ typedef enum { GEMX_SOLVER_EULER = 0, GEMX_SOLVER_RK4 = 1, GEMX_SOLVER_DP5 = 2 }
 typedef enum { GEMX_F32 = 0, GEMX_F64 = 1 } gemx_dtype;
 /* observation layout: [N, S_out] rows per env (the reference contract) or [S_out, N] */
 typedef enum { GEMX_OBS_AOS = 0, GEMX_OBS_SOA = 1 } gemx_obs_layout;
+typedef enum { GEMX_INIT_CONST = 0, GEMX_INIT_UNIFORM = 1, GEMX_INIT_GAUSSIAN = 2 } gemx_init_kind;
 typedef enum { GEMX_SUPPLY_IDEAL = 0, GEMX_SUPPLY_RC = 1 } gemx_supply_kind;
 typedef enum { GEMX_ACT_ABC = 0, GEMX_ACT_DQ_SPACE = 1, GEMX_ACT_DQ_PROCESSOR = 2 } gemx_action_frame;
 #define GEMX_MAX_DELAY 8
@@ -109,7 +110,17 @@ typedef struct gemx_config {
      * reference does, on the NEW duty cycles of a continuous converter / the PREVIOUS step's final switching state of a
      * finite one.  reset() reloads the capacitor (u = u_nominal).  Not available for the finite EESM converter. */
     int32_t supply_kind;
-    int32_t reserved0;
+    /* Initial ODE state (electric_motor.py:150-257, mechanical_load.py:100-160).  GEMX_INIT_CONST: init_state below.
+     * GEMX_INIT_UNIFORM / GEMX_INIT_GAUSSIAN: every reset (gemx_reset and the in-kernel auto-reset) draws each ODE state j with
+     * init_lo[j] < init_hi[j] anew -- uniformly in [lo, hi], or from a normal(init_mu[j], init_sigma[j]) truncated to [lo, hi]
+     * (scipy.stats.truncnorm in the reference) -- from a counter-based Philox4x32-10 stream keyed by `seed` and indexed by
+     * (env, number of resets of that env, j); states with lo == hi keep init_state[j].  numpy's PCG64 streams of the reference
+     * cannot be reproduced on a device: parity is distributional (tests/test_gpu_parity.py), and exact for the state -> reset
+     * observation map.  DC, synchronous and EESM systems (the induction motors' flux limits, induction_motor.py:314-364, are
+     * not on the accelerated path); the load's omega for any system with a PolynomialStaticLoad. */
+    int32_t init_kind;
+    uint64_t seed;
+    double init_lo[GEMX_MAX_ODE], init_hi[GEMX_MAX_ODE], init_mu[GEMX_MAX_ODE], init_sigma[GEMX_MAX_ODE];
     double supply_r, supply_c;
     double tau;               /* control step, PhysicalSystem.tau */
     double interlocking_time; /* converter dead time, converters.py:35-41; must be < tau */

@@ -370,6 +370,8 @@ def main(only=None):
         main_reward()
     if not only or "supply" in only:
         main_supply()
+    if not only or "init" in only:
+        init_samples()
 
 
 def main_base():
@@ -519,6 +521,39 @@ def main_reward():
     run_case("rw_eesm_cont_cc_pow_mixed_epi_held_euler", "Cont-CC-EESM-v0", "euler", K, 1406, "held", True, "box4", record_reward=True,
              reward_function=WeightedSumOfErrors(reward_weights=dict(i_sd=0.4, i_sq=0.4, i_e=0.2), reward_power=dict(i_sd=1, i_sq=2, i_e=0.5),
                                                  gamma=0.95))
+
+
+INIT_CASES = {
+    # name: (env_id, motor_initializer, load_initializer)
+    "pmsm_sc_uniform": ("Cont-SC-PMSM-v0", dict(random_init="uniform"), dict(random_init="uniform")),
+    "permexdc_sc_gauss": ("Cont-SC-PermExDc-v0", dict(random_init="gaussian", random_params=(30.0, 40.0), interval=[[-50.0, 90.0]]),
+                          dict(random_init="gaussian", random_params=(100.0, 60.0))),
+    "extex_cc_uniform_interval": ("Cont-CC-ExtExDc-v0", dict(random_init="uniform", interval=[[-20.0, 60.0], [0.0, 10.0]]), None),
+    "eesm_sc_uniform": ("Cont-SC-EESM-v0", dict(random_init="uniform"), dict(random_init="uniform", interval=[[-100.0, 300.0]])),
+}
+
+
+def init_samples(n=4000):
+    """random initialisers.  The reference's numpy streams cannot be reproduced on a device, so the fixture holds
+    SAMPLES of the initial ODE state the reference draws (physical_system.reset() n times) for distributional tests."""
+    out = {}
+    for name, (env_id, mi, li) in INIT_CASES.items():
+        kw = dict(motor=dict(motor_initializer=mi))
+        if li is not None:
+            kw["load"] = dict(load_initializer=li)
+        env = gem.make(env_id, **kw)
+        env.reset(seed=123)
+        psys = env.physical_system.unwrapped
+        ys, obs = [], []
+        for _ in range(n):
+            o = psys.reset()
+            ys.append(np.array(psys._ode_solver.y, dtype=float))
+            obs.append(np.array(o, dtype=float))
+        out[name + "_y"] = np.asarray(ys)
+        out[name + "_obs"] = np.asarray(obs)
+        out[name + "_meta"] = np.array(json.dumps(dict(describe(env), env_id=env_id, motor_initializer=mi, load_initializer=li)))
+        print(f"init samples {name}: y mean {np.asarray(ys).mean(axis=0).round(3)} min {np.asarray(ys).min(axis=0).round(3)} max {np.asarray(ys).max(axis=0).round(3)}")
+    np.savez_compressed(os.path.join(OUT, "init_samples.npz"), **out)
 
 
 def main_supply():

@@ -15,6 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
 def _meta(name):
     return json.loads(str(np.load(os.path.join(HERE, "golden", name + ".npz"))["meta"]))
 
@@ -231,6 +234,40 @@ def test_rc_supply_config():
 
     with pytest.raises(ValueError, match="not on the accelerated path"):
         ga.make("Cont-CC-PermExDc-v0", n_envs=2, supply=AC1PhaseSupply(), _defer_create=True)
+
+
+def test_random_initialiser_bounds_match_reference_support():
+    """motor_initializer / load_initializer with random_init: the per-ODE-state sampling bounds (nominal value x state-space low,
+    clipped to `interval`) cover exactly the support of 4000 resets of the live reference (tests/golden/init_samples.npz)."""
+    d = np.load(os.path.join(GOLDEN, "init_samples.npz"))
+    cls = {"PermanentMagnetSynchronousMotor": ga.PermanentMagnetSynchronousMotor, "DcExternallyExcitedMotor": ga.DcExternallyExcitedMotor,
+           "ExternallyExcitedSynchronousMotor": ga.ExternallyExcitedSynchronousMotor, "DcPermanentlyExcitedMotor": ga.DcPermanentlyExcitedMotor}
+    for case in ("pmsm_sc_uniform", "extex_cc_uniform_interval", "eesm_sc_uniform"):
+        meta = json.loads(str(d[case + "_meta"]))
+        kw = dict(motor=cls[meta["motor"]](motor_initializer=meta["motor_initializer"]), n_envs=2, seed=5, _defer_create=True)
+        if meta["load_initializer"] is not None:
+            kw["load"] = ga.PolynomialStaticLoad(load_parameter=meta["load_parameter"], load_initializer=meta["load_initializer"])
+        ps = ga.make(meta["env_id"], **kw).physical_system
+        c, y = ps._cfg, d[case + "_y"]
+        assert c.init_kind == _lib.INIT_UNIFORM and c.seed == 5
+        for j in range(y.shape[1]):
+            lo, hi = c.init_lo[j], c.init_hi[j]
+            if hi == lo:
+                assert np.ptp(y[:, j]) == 0 and y[0, j] == c.init_state[j]
+            else:
+                assert lo <= y[:, j].min() < lo + 0.01 * (hi - lo) and hi - 0.01 * (hi - lo) < y[:, j].max() <= hi
+    # validation in gemx_create: induction-motor states and a constant-speed omega cannot be random
+    L = _lib.load()
+    h = C.c_void_p()
+    scim = ga.make("Cont-CC-SCIM-v0", n_envs=2, _defer_create=True).physical_system._cfg
+    bad = _lib.GemxConfig.from_buffer_copy(scim)
+    bad.init_kind, bad.init_lo[1], bad.init_hi[1] = _lib.INIT_UNIFORM, -1.0, 1.0
+    assert L.gemx_create(C.byref(bad), 4, 0, C.byref(h)) == -1 and b"induction" in L.gemx_last_error()
+    bad = _lib.GemxConfig.from_buffer_copy(scim)
+    bad.init_kind, bad.init_lo[0], bad.init_hi[0] = _lib.INIT_UNIFORM, 0.0, 10.0
+    assert L.gemx_create(C.byref(bad), 4, 0, C.byref(h)) == -1 and b"ConstantSpeedLoad" in L.gemx_last_error()
+    with pytest.raises(NotImplementedError):
+        ga.DcPermanentlyExcitedMotor(motor_initializer=dict(random_init="cauchy"))
 
 
 def test_multi_converter_holders():
