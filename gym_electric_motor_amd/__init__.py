@@ -29,6 +29,7 @@ from .components import (  # noqa: F401
     SynchronousReluctanceMotor,
 )
 from .envs import BatchedElectricMotorEnv, make  # noqa: F401
+from .reference_generators import BatchedWienerProcessReferenceGenerator  # noqa: F401
 from .physical_system_wrappers import DeadTimeProcessor, DqToAbcActionProcessor  # noqa: F401
 from .physical_systems import (  # noqa: F401
     BatchedDcMotorSystem,

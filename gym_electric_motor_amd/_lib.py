@@ -64,9 +64,22 @@ class GemxRewardConfig(C.Structure):
     ]
 
 
+class GemxRefgenConfig(C.Structure):
+    """Mirror of `gemx_refgen_config` (include/gemx.h)."""
+
+    _fields_ = [
+        ("struct_size", C.c_int32), ("n_ref", C.c_int32), ("seed", C.c_uint64),
+        ("episode_len_lo", C.c_int32), ("episode_len_hi", C.c_int32),
+        ("sigma_lo", C.c_double * MAX_REF), ("sigma_hi", C.c_double * MAX_REF),
+        ("margin_lo", C.c_double * MAX_REF), ("margin_hi", C.c_double * MAX_REF),
+        ("initial_lo", C.c_double * MAX_REF), ("initial_hi", C.c_double * MAX_REF),
+    ]
+
+
 EXPORTS = (
     "gemx_abi_version", "gemx_sizeof_config", "gemx_last_error", "gemx_device_count", "gemx_create", "gemx_destroy",
-    "gemx_n_envs", "gemx_n_ode", "gemx_n_out", "gemx_n_action", "gemx_action_itemsize", "gemx_n_switch_bytes", "gemx_reset_observation", "gemx_set_reward", "gemx_rollout_reward",
+    "gemx_n_envs", "gemx_n_ode", "gemx_n_out", "gemx_n_action", "gemx_action_itemsize", "gemx_n_switch_bytes", "gemx_reset_observation", "gemx_set_reward", "gemx_rollout_reward", "gemx_refgen_create", "gemx_refgen_destroy", "gemx_refgen_reset",
+    "gemx_refgen_rollout", "gemx_refgen_get_state",
     "gemx_reset", "gemx_step", "gemx_rollout", "gemx_get_state", "gemx_set_state", "gemx_get_switch_state",
     "gemx_set_switch_state", "gemx_set_steps_per_block", "gemx_last_launch", "gemx_error_flags",
 )
@@ -104,6 +117,11 @@ def load():
     L.gemx_step.argtypes = [vp, vp, vp, vp, vp]
     L.gemx_rollout.argtypes = [vp, vp, i32, vp, vp, i32, vp]
     L.gemx_set_reward.argtypes = [vp, C.POINTER(GemxRewardConfig)]
+    L.gemx_refgen_create.argtypes = [C.POINTER(GemxRefgenConfig), i64, C.c_int, C.c_int, C.POINTER(vp)]
+    L.gemx_refgen_destroy.argtypes = [vp]
+    L.gemx_refgen_reset.argtypes = [vp, vp, vp]
+    L.gemx_refgen_rollout.argtypes = [vp, vp, i32, vp, vp]
+    L.gemx_refgen_get_state.argtypes = [vp, vp, vp, vp, vp]
     L.gemx_rollout_reward.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
     L.gemx_get_state.argtypes = [vp, vp, vp]
     L.gemx_set_state.argtypes = [vp, vp, vp]

@@ -4,6 +4,7 @@ Sources (gym_electric_motor_amd/csrc):
     gemx_common.hpp, gemx_kernels.hpp   device templates
     gemx_inst.hip                       ONE instantiation unit, compiled once per (system, converter, dtype)
     gemx_capi.hip                       C ABI (include/gemx.h), validation, small kernels, dispatch
+    gemx_refgen.hip                     device-side Wiener-process reference generation (gemx_refgen_*)
 The ten instantiation units + the C-ABI unit are compiled in parallel and linked with `hipcc -shared`.
 """
 import concurrent.futures as cf
@@ -15,7 +16,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
-SOURCES = [os.path.join(CSRC, f) for f in ("gemx_common.hpp", "gemx_kernels.hpp", "gemx_inst.hip", "gemx_capi.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("gemx_common.hpp", "gemx_kernels.hpp", "gemx_inst.hip", "gemx_capi.hip", "gemx_refgen.hip")]
 HEADER = os.path.join(REPO, "include", "gemx.h")
 LIB = os.path.join(PKG_DIR, "libgemx.so")
 OBJ_DIR = os.path.join(PKG_DIR, "build")
@@ -62,6 +63,8 @@ def build_library(force=False, verbose=False, jobs=None):
                                                       "-c", os.path.join(CSRC, "gemx_inst.hip"), "-o", obj]))
     capi_obj = os.path.join(OBJ_DIR, "gemx_capi.o")
     cmds.append((capi_obj, [hipcc] + FLAGS + inc + ["-c", os.path.join(CSRC, "gemx_capi.hip"), "-o", capi_obj]))
+    refgen_obj = os.path.join(OBJ_DIR, "gemx_refgen.o")
+    cmds.append((refgen_obj, [hipcc] + FLAGS + inc + ["-c", os.path.join(CSRC, "gemx_refgen.hip"), "-o", refgen_obj]))
 
     def run(cmd):
         if verbose:

@@ -207,6 +207,31 @@ int gemx_set_reward(gemx_handle *h, const gemx_reward_config *rc);
 int gemx_rollout_reward(gemx_handle *h, const void *actions_dev, int32_t K, const void *refs_dev, void *obs_out_dev,
                         uint8_t *done_out_dev, void *reward_out_dev, void *stream);
 
+/* Device-side reference generation: N x n_ref independent WienerProcessReferenceGenerator streams
+ * (reference_generators/wiener_process_reference_generator.py:30-49 over subepisoded_reference_generator.py:66-119, combined as
+ * multiple_reference_generator.py:77-92 does): sub-episodes of int(U(episode_len_lo, episode_len_hi)) steps, per sub-episode
+ * sigma = 10 ** U(log10 sigma_lo, log10 sigma_hi), value += N(0, sigma) per step clipped to [margin_lo, margin_hi]; a reset draws the
+ * initial value from U(initial_lo, initial_hi) and starts a new sub-episode.  Counter-based Philox4x32-10 streams keyed by `seed`:
+ * chunked generation == one-shot generation; parity with the reference's numpy streams is distributional.
+ *   gemx_refgen_rollout(r, done, K, refs): refs[k, env, j] = reference the reward of control step k is computed against (what the agent
+ *   saw as "next reference" before acting); done[k, env] != 0 (optional, the physics rollout's done tensor) resets that env's generators
+ *   after step k, as `if terminated: env.reset()` does.  The tensor feeds gemx_rollout_reward directly. */
+typedef struct gemx_refgen_config {
+    int32_t struct_size; /* = sizeof(gemx_refgen_config) */
+    int32_t n_ref;       /* 1..GEMX_MAX_REF sub-generators */
+    uint64_t seed;
+    int32_t episode_len_lo, episode_len_hi; /* episode_lengths, default (500, 2000) */
+    double sigma_lo[GEMX_MAX_REF], sigma_hi[GEMX_MAX_REF];     /* sigma_range, default (1e-3, 1e-1) */
+    double margin_lo[GEMX_MAX_REF], margin_hi[GEMX_MAX_REF];   /* limit_margin in normalised units */
+    double initial_lo[GEMX_MAX_REF], initial_hi[GEMX_MAX_REF]; /* initial_range (default: the limit margin) */
+} gemx_refgen_config;
+typedef struct gemx_refgen gemx_refgen;
+int gemx_refgen_create(const gemx_refgen_config *cfg, int64_t n_envs, int device, int dtype, gemx_refgen **out);
+int gemx_refgen_destroy(gemx_refgen *r);
+int gemx_refgen_reset(gemx_refgen *r, const uint8_t *mask_dev, void *stream);
+int gemx_refgen_rollout(gemx_refgen *r, const uint8_t *done_dev, int32_t K, void *refs_out_dev, void *stream);
+int gemx_refgen_get_state(gemx_refgen *r, double *value_out_dev, double *sigma_out_dev, int32_t *left_out_dev, void *stream);
+
 /* Checkpoint / parity access to the ODE state, SoA [S_ode, N] of R in physical units (angle in rad), plus the
  * per-env packed converter switching state, 2 bits per half-bridge: [N] uint8, or [2][N] uint8 (row 0 = bits 0..7,
  * row 1 = bits 8..11) for the 6 half-bridges of GEMX_CONV_FINITE_2XB6; gemx_n_switch_bytes() = bytes per env.

@@ -372,6 +372,8 @@ def main(only=None):
         main_supply()
     if not only or "init" in only:
         init_samples()
+    if not only or "wiener" in only:
+        wiener_samples()
 
 
 def main_base():
@@ -554,6 +556,43 @@ def init_samples(n=4000):
         out[name + "_meta"] = np.array(json.dumps(dict(describe(env), env_id=env_id, motor_initializer=mi, load_initializer=li)))
         print(f"init samples {name}: y mean {np.asarray(ys).mean(axis=0).round(3)} min {np.asarray(ys).min(axis=0).round(3)} max {np.asarray(ys).max(axis=0).round(3)}")
     np.savez_compressed(os.path.join(OUT, "init_samples.npz"), **out)
+
+
+def wiener_samples(T=400000, n_reset=3000):
+    """samples of the reference's MultipleReferenceGenerator([Wiener(i_sd), Wiener(i_sq)]) of Cont-CC-PMSM-v0 for
+    distributional tests of the device-side generator: sub-episode lengths and sigmas, sigma-normalised increments, margins,
+    initial values drawn by reset()."""
+    env = gem.make("Cont-CC-PMSM-v0")
+    (state, _), _ = env.reset(seed=4242)
+    state = env.physical_system.reset()
+    rg = env.reference_generator
+    subs = rg._sub_generators
+    out = dict(names=np.array([sg._reference_state for sg in subs]), margins=np.array([sg._limit_margin for sg in subs], dtype=float),
+               sigma_range=np.array(subs[0]._sigma_range, dtype=float), episode_lengths=np.array(subs[0]._episode_len_range, dtype=float))
+    rg.reset(state)
+    vals = np.zeros((T, len(subs)))
+    sig = np.zeros((T, len(subs)))
+    lens = np.zeros((T, len(subs)), dtype=np.int64)
+    for t in range(T):
+        vals[t] = rg.get_reference_observation(state)
+        for j, sg in enumerate(subs):
+            sig[t, j] = sg._current_sigma
+            lens[t, j] = sg._current_episode_length
+    out.update(values=vals[:20000], sigma_trace=sig[:20000])
+    for j in range(len(subs)):
+        change = np.nonzero(np.diff(sig[:, j]) != 0)[0] + 1  # sub-episode starts
+        out[f"sub_sigma_{j}"] = sig[change, j]
+        out[f"sub_len_{j}"] = lens[change, j]
+        dv = np.diff(vals[:, j])
+        inside = (vals[1:, j] > out["margins"][j, 0] + 1e-12) & (vals[1:, j] < out["margins"][j, 1] - 1e-12) & (np.diff(sig[:, j]) == 0)
+        out[f"z_{j}"] = (dv / sig[1:, j])[inside][:100000]
+    init = np.zeros((n_reset, len(subs)))
+    for i in range(n_reset):
+        ref, _, _ = rg.reset(state)
+        init[i] = ref[rg.referenced_states]
+    out["initial_values"] = init
+    np.savez_compressed(os.path.join(OUT, "wiener_samples.npz"), **out)
+    print("wiener samples:", {k: np.asarray(v).shape for k, v in out.items()}, "margins", out["margins"].tolist())
 
 
 def main_supply():

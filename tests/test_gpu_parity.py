@@ -19,7 +19,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz")) if "converter_kats" not in f and "init_samples" not in f)
+CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz")) if "converter_kats" not in f and "init_samples" not in f and "wiener_samples" not in f)
 
 
 def _load(name):
@@ -612,6 +612,75 @@ def test_random_gaussian_initialiser_is_a_truncated_normal():
         a, b = (lo - mu) / sg, (hi - mu) / sg
         assert y[:, j].min() >= lo - 1e-3 and y[:, j].max() <= hi + 1e-3
         assert stats.kstest(y[:, j], stats.truncnorm(a, b, loc=mu, scale=sg).cdf).pvalue > 1e-3, j
+    env.close()
+
+
+def test_device_wiener_reference_generator_matches_reference_distribution():
+    """Device-side MultipleReferenceGenerator([Wiener(i_sd), Wiener(i_sq)]) (csrc/gemx_refgen.hip) vs samples of the live reference
+    (tests/golden/wiener_samples.npz): margins equal; initial values, sub-episode sigmas and lengths, sigma-normalised increments
+    pass two-sample KS tests; the walk is clipped to the margins; chunked == one-shot; terminations restart the generators; the
+    tensor feeds the fused reward."""
+    import torch
+    from scipy import stats
+
+    import gym_electric_motor_amd as ga
+
+    w = np.load(os.path.join(GOLDEN, "wiener_samples.npz"))
+    n, K = 4096, 700
+    env = ga.make("Cont-CC-PMSM-v0", n_envs=n)
+    ps = env.physical_system
+    gen = ga.BatchedWienerProcessReferenceGenerator(reference_states=("i_sq", "i_sd"), seed=31).set_modules(ps)
+    assert gen.reference_names == ("i_sd", "i_sq")  # state order of the physical system = column order of the reward's references
+    assert np.allclose([[gen._cfg.margin_lo[j], gen._cfg.margin_hi[j]] for j in range(2)], w["margins"], rtol=1e-14)
+    gen.reset()
+    v0, _, _ = gen.state()
+    for j in range(2):  # reset(): initial reference ~ U(initial_range = limit margin)
+        assert stats.ks_2samp(v0[j].cpu().numpy(), w["initial_values"][:, j]).pvalue > 1e-3
+    refs = gen.rollout(K)
+    torch.cuda.synchronize()
+    r = refs.double().cpu().numpy()
+    lo, hi = w["margins"][0]
+    assert r.min() >= lo - 1e-6 and r.max() <= hi + 1e-6 and (np.abs(r) > hi - 1e-6).any()  # clipped walk that does reach the margin
+    twin = ga.BatchedWienerProcessReferenceGenerator(reference_states=("i_sd", "i_sq"), seed=31).set_modules(ps)
+    twin.reset()
+    parts = torch.cat([twin.rollout(1), twin.rollout(249), twin.rollout(450)])
+    assert torch.equal(parts, refs)
+    # first sub-episode of every (env, generator): sigma, length, increments
+    g2 = ga.BatchedWienerProcessReferenceGenerator(reference_states=("i_sd", "i_sq"), seed=77).set_modules(ps)
+    g2.reset()
+    first = g2.rollout(1)
+    _, sg, left = g2.state()
+    rest = g2.rollout(450).double().cpu().numpy()
+    sg, left = sg.cpu().numpy(), left.cpu().numpy()
+    for j in range(2):
+        assert stats.ks_2samp(np.log10(sg[j]), np.log10(w[f"sub_sigma_{j}"])).pvalue > 1e-3
+        assert stats.ks_2samp((left[j] + 1).astype(float), w[f"sub_len_{j}"].astype(float)).pvalue > 1e-3
+        assert left[j].min() + 1 >= 500 and left[j].max() + 1 < 2000
+        seq = np.concatenate([first.double().cpu().numpy()[:, :, j], rest[:, :, j]])  # [451, N] all inside the first sub-episode (>= 500)
+        dz = np.diff(seq, axis=0) / sg[j][None, :]
+        inside = (seq[1:] > lo + 1e-4) & (seq[1:] < hi - 1e-4) & (seq[:-1] > lo + 1e-4) & (seq[:-1] < hi - 1e-4) & (sg[j][None, :] > 3e-3)
+        z = dz[inside][:200000]  # (fp32 storage: keep sigmas whose steps are well above the rounding of values ~0.5)
+        assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01
+        assert stats.ks_2samp(z[:20000], w[f"z_{j}"][:20000]).pvalue > 1e-3
+    # terminations: the generators of a terminated env restart (new initial value, new sub-episode)
+    done = torch.zeros((50, n), dtype=torch.uint8, device="cuda")
+    done[20, ::2] = 1
+    g3 = ga.BatchedWienerProcessReferenceGenerator(reference_states=("i_sd", "i_sq"), seed=5).set_modules(ps)
+    g3.reset()
+    r3 = g3.rollout(50, done=done).double().cpu().numpy()
+    jump = np.abs(r3[21, :, 0] - r3[20, :, 0])
+    assert np.median(jump[::2]) > 0.1 and np.median(jump[1::2]) < 0.05
+    assert stats.kstest(r3[21, ::2, 0], stats.uniform(lo, hi - lo).cdf).pvalue > 1e-4  # ~ U(margin) + one small step
+    # and the references drive the fused reward
+    ps.set_reward(reward_weights=dict(i_sd=0.5, i_sq=0.5), referenced_states=gen.reference_names)
+    acts = torch.rand((64, n, 3), device="cuda") * 2 - 1
+    obs, dn, rew = env.rollout(acts, references=refs[:64])
+    want = -(0.5 * (obs[..., ps.state_positions["i_sd"]] - refs[:64, :, 0]).abs() / 2 + 0.5 * (obs[..., ps.state_positions["i_sq"]] - refs[:64, :, 1]).abs() / 2)
+    ok = dn == 0
+    assert torch.allclose(rew[ok], want[ok], atol=2e-6)
+    gen.apply_done(dn)
+    for g_ in (gen, twin, g2, g3):
+        g_.close()
     env.close()
 
 

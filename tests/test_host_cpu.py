@@ -270,6 +270,20 @@ def test_random_initialiser_bounds_match_reference_support():
         ga.DcPermanentlyExcitedMotor(motor_initializer=dict(random_init="cauchy"))
 
 
+def test_wiener_generator_margins_match_reference():
+    """BatchedWienerProcessReferenceGenerator.set_modules derives limit margin / initial range like subepisoded_reference_generator.py:66-84."""
+    w = np.load(os.path.join(GOLDEN, "wiener_samples.npz"))
+    ps = ga.make("Cont-CC-PMSM-v0", n_envs=2, _defer_create=True).physical_system
+    gen = ga.BatchedWienerProcessReferenceGenerator(reference_states=("i_sd", "i_sq"), seed=1).set_modules(ps, _defer_create=True)
+    c = gen._cfg
+    assert np.allclose([[c.margin_lo[j], c.margin_hi[j]] for j in range(2)], w["margins"], rtol=1e-14)
+    assert np.allclose([[c.initial_lo[j], c.initial_hi[j]] for j in range(2)], w["margins"], rtol=1e-14)
+    assert [c.sigma_lo[0], c.sigma_hi[0]] == list(w["sigma_range"]) and [c.episode_len_lo, c.episode_len_hi] == [int(x) for x in w["episode_lengths"]]
+    g2 = ga.BatchedWienerProcessReferenceGenerator(reference_states="omega", limit_margin=(0.2, 0.5)).set_modules(
+        ga.make("Cont-SC-SCIM-v0", n_envs=2, _defer_create=True).physical_system, _defer_create=True)
+    assert (g2._cfg.margin_lo[0], g2._cfg.margin_hi[0]) == (-0.2, 0.5)
+
+
 def test_multi_converter_holders():
     """Cont/FiniteMultiConverter mirrors (converters.py:498-740): spaces, tau propagation, per-sub-converter dead time."""
     c = ga.ContMultiConverter(subconverters=[ga.ContB6BridgeConverter, ga.ContFourQuadrantConverter], tau=2e-4)

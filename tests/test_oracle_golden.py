@@ -14,7 +14,7 @@ import pytest
 from oracle import oracle as orc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz")) if "converter_kats" not in f and "init_samples" not in f)
+CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz")) if "converter_kats" not in f and "init_samples" not in f and "wiener_samples" not in f)
 
 
 def test_fixture_inventory():
