@@ -58,8 +58,10 @@ __global__ void reset_kernel(R *state, typename Angle<R>::T *angle, const uint8_
     if (P.init_kind) {
         const uint32_t count = rcnt[env] + 1u;
         rcnt[env] = count;
-        for (int j = 0; j < nd; ++j) y0[j] = sample_init_state(rinit, env, count, j);
-        if (has_angle) eps0 = sample_init_state(rinit, env, count, nd);
+        double u[GEMX_MAX_ODE];
+        init_uniforms(rinit, env, count, u);
+        for (int j = 0; j < nd; ++j) y0[j] = init_state_from_uniform(rinit, j, u[j]);
+        if (has_angle) eps0 = init_state_from_uniform(rinit, nd, u[nd]);
     }
     for (int j = 0; j < nd; ++j) state[(int64_t)j * N + env] = (R)y0[j];
     if (P.rc_supply) {  // RCVoltageSupply.reset (voltage_supplies.py:108-114): capacitor loaded, the supply's clock at 0
@@ -514,6 +516,10 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         for (int j = 0; j < I.n; ++j) {
             I.lo[j] = cfg->init_lo[j]; I.hi[j] = cfg->init_hi[j]; I.mu[j] = cfg->init_mu[j]; I.sigma[j] = cfg->init_sigma[j];
             I.constant[j] = cfg->init_state[j];
+            if (cfg->init_kind == GEMX_INIT_GAUSSIAN && I.lo[j] < I.hi[j]) {
+                I.cdf_lo[j] = 0.5 * erfc(-(I.lo[j] - I.mu[j]) / I.sigma[j] / sqrt(2.0));
+                I.cdf_hi[j] = 0.5 * erfc(-(I.hi[j] - I.mu[j]) / I.sigma[j] / sqrt(2.0));
+            }
         }
         if (hipMalloc(&h->rinit_dev, sizeof(InitDev)) != hipSuccess || hipMalloc((void **)&h->rcnt, sizeof(uint32_t) * (size_t)h->n) != hipSuccess)
             return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(random initialiser) failed"));

@@ -193,17 +193,54 @@ struct InitDev {
     int32_t kind, n;  // gemx_init_kind; number of ODE states incl. the angle
     uint64_t seed;
     double lo[GEMX_MAX_ODE], hi[GEMX_MAX_ODE], mu[GEMX_MAX_ODE], sigma[GEMX_MAX_ODE], constant[GEMX_MAX_ODE];
+    double cdf_lo[GEMX_MAX_ODE], cdf_hi[GEMX_MAX_ODE];  // gaussian: Phi((lo - mu) / sigma), Phi((hi - mu) / sigma), computed on the host
 };
-// the j-th initial state of (env, reset count): uniform or truncated normal by inverse CDF (reset path: fp64 throughout)
-__device__ inline double sample_init_state(const InitDev *I, int64_t env, uint32_t count, int j) {
+// inverse of the standard normal CDF: Wichura's algorithm AS 241 (PPND16, |rel err| < 1e-16) -- a few rational polynomials instead
+// of the library's normcdfinv expansion, because this code is inlined into every advance kernel's (rare) auto-reset path
+__host__ __device__ inline double inv_norm_cdf(double p) {
+    const double q = p - 0.5;
+    if (fabs(q) <= 0.425) {
+        const double r = 0.180625 - q * q;
+        const double num = (((((((2.5090809287301226727e3 * r + 3.3430575583588128105e4) * r + 6.7265770927008700853e4) * r + 4.5921953931549871457e4) * r +
+                               1.3731693765509461125e4) * r + 1.9715909503065514427e3) * r + 1.3314166789178437745e2) * r + 3.3871328727963666080e0);
+        const double den = (((((((5.2264952788528545610e3 * r + 2.8729085735721942674e4) * r + 3.9307895800092710610e4) * r + 2.1213794301586595867e4) * r +
+                               5.3941960214247511077e3) * r + 6.8718700749205790830e2) * r + 4.2313330701600911252e1) * r + 1.0);
+        return q * num / den;
+    }
+    double r = q < 0 ? p : 1.0 - p;
+    r = sqrt(-log(r));
+    double val;
+    if (r <= 5.0) {
+        r -= 1.6;
+        const double num = (((((((7.74545014278341407640e-4 * r + 2.27238449892691845833e-2) * r + 2.41780725177450611770e-1) * r + 1.27045825245236838258e0) * r +
+                               3.64784832476320460504e0) * r + 5.76949722146069140550e0) * r + 4.63033784615654529590e0) * r + 1.42343711074968357734e0);
+        const double den = (((((((1.05075007164441684324e-9 * r + 5.47593808499534494600e-4) * r + 1.51986665636164571966e-2) * r + 1.48103976427480074590e-1) * r +
+                               6.89767334985100004550e-1) * r + 1.67638483018380384940e0) * r + 2.05319162663775882187e0) * r + 1.0);
+        val = num / den;
+    } else {
+        r -= 5.0;
+        const double num = (((((((2.01033439929228813265e-7 * r + 2.71155556874348757815e-5) * r + 1.24266094738807843860e-3) * r + 2.65321895265761230930e-2) * r +
+                               2.96560571828504891230e-1) * r + 1.78482653991729133580e0) * r + 5.46378491116411436990e0) * r + 6.65790464350110377720e0);
+        const double den = (((((((2.04426310338993978564e-15 * r + 1.42151175831644588870e-7) * r + 1.84631831751005468180e-5) * r + 7.86869131145613259100e-4) * r +
+                               1.48753612908506148525e-2) * r + 1.36929880922735805310e-1) * r + 5.99832206555887937690e-1) * r + 1.0);
+        val = num / den;
+    }
+    return q < 0 ? -val : val;
+}
+// the j-th initial state from its uniform u in (0, 1): uniform in [lo, hi], or normal(mu, sigma) truncated to [lo, hi] by inverse CDF
+__device__ __forceinline__ double init_state_from_uniform(const InitDev *I, int j, double u) {
     if (!(I->lo[j] < I->hi[j])) return I->constant[j];
-    uint32_t r[4];
-    Philox::block(I->seed, (uint64_t)env, count, (uint32_t)(j >> 2), r);
-    const double u = Philox::u01(r[j & 3]);
     if (I->kind == GEMX_INIT_UNIFORM) return I->lo[j] + (I->hi[j] - I->lo[j]) * u;
-    const double a = normcdf((I->lo[j] - I->mu[j]) / I->sigma[j]), b = normcdf((I->hi[j] - I->mu[j]) / I->sigma[j]);
-    double x = I->mu[j] + I->sigma[j] * normcdfinv(a + (b - a) * u);
+    const double x = I->mu[j] + I->sigma[j] * inv_norm_cdf(I->cdf_lo[j] + (I->cdf_hi[j] - I->cdf_lo[j]) * u);
     return fmin(fmax(x, I->lo[j]), I->hi[j]);
+}
+// all (<= 8) uniforms of one (env, reset count): two Philox blocks
+__device__ __forceinline__ void init_uniforms(const InitDev *I, int64_t env, uint32_t count, double (&u)[GEMX_MAX_ODE]) {
+    uint32_t r0[4], r1[4];
+    Philox::block(I->seed, (uint64_t)env, count, 0u, r0);
+    Philox::block(I->seed, (uint64_t)env, count, 1u, r1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { u[i] = Philox::u01(r0[i]); u[4 + i] = Philox::u01(r1[i]); }
 }
 
 // ------------------------------------------------------------------------------------------------

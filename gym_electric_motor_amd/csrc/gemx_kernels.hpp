@@ -806,13 +806,15 @@ __device__ __forceinline__ R supply_current(const DevParams<R> &P, const R (&y)[
 
 // in-kernel auto-reset with random initialisers: a fresh initial state for this env, its reset counter advanced (rare path)
 template <int SYS, class R>
-__device__ __noinline__ void draw_initial_state(const KArgs<R> &a, int64_t env, R (&y)[SysTraits<SYS>::ND], typename Angle<R>::T &ang) {
+__device__ __forceinline__ void draw_initial_state(const KArgs<R> &a, int64_t env, R (&y)[SysTraits<SYS>::ND], typename Angle<R>::T &ang) {
     constexpr int ND = SysTraits<SYS>::ND;
     const uint32_t count = a.rcnt[env] + 1u;
     a.rcnt[env] = count;
+    double u[GEMX_MAX_ODE];
+    init_uniforms(a.rinit, env, count, u);
 #pragma unroll
-    for (int j = 0; j < ND; ++j) y[j] = (R)sample_init_state(a.rinit, env, count, j);
-    if (SysTraits<SYS>::HAS_ANGLE) ang = Angle<R>::from_rad(sample_init_state(a.rinit, env, count, ND));
+    for (int j = 0; j < ND; ++j) y[j] = (R)init_state_from_uniform(a.rinit, j, u[j]);
+    if (SysTraits<SYS>::HAS_ANGLE) ang = Angle<R>::from_rad(init_state_from_uniform(a.rinit, ND, u[ND]));
 }
 
 // step() for the single-wave kernel
@@ -913,10 +915,12 @@ __device__ __forceinline__ void reward_fetch(const KArgs<R> &a, int k0, int nr, 
 // reference env (<= 3 referenced states); further weighted states take the slow path through memory.
 template <class R> struct RewardRegs {
     static constexpr int HOT = 4;
-    int32_t n_term, col[HOT], kind[HOT];
+    int32_t n_term, general, col[HOT], kind[HOT];
     R coef[HOT], inv_len[HOT], power[HOT], bias, violation_reward;
     __device__ __forceinline__ void load(const RewardDev<R> *w) {
         n_term = w->n_term;
+        general = 0;
+        for (int t = 0; t < w->n_term; ++t) general |= w->kind[t] == 3;
 #pragma unroll
         for (int t = 0; t < HOT; ++t) {
             col[t] = w->col[t]; kind[t] = w->kind[t]; coef[t] = w->coef[t]; inv_len[t] = w->inv_len[t]; power[t] = w->power[t];
@@ -925,9 +929,11 @@ template <class R> struct RewardRegs {
         violation_reward = w->violation_reward;
     }
 };
-template <class R> __device__ __forceinline__ R reward_term(R o, R ref, R inv_len, int kind, R power, R coef) {
+// GENERAL: reward_power other than 1 or 2 allowed (pow(): a ~300-instruction expansion, so it must not be unrolled per term)
+template <bool GENERAL, class R> __device__ __forceinline__ R reward_term(R o, R ref, R inv_len, int kind, R power, R coef) {
     const R dlt = fabs(o - ref) * inv_len;
-    const R p = kind == 1 ? dlt : (kind == 2 ? dlt * dlt : pow(dlt, power));
+    R p = kind == 2 ? dlt * dlt : dlt;
+    if (GENERAL && kind == 3) p = pow(dlt, power);
     return coef * p;
 }
 template <int NOUT, int RB, class R>
@@ -943,12 +949,20 @@ __device__ __forceinline__ void reward_apply(const KArgs<R> &a, const RewardRegs
         if (s < nr) {
             const int row = row0 + s;  // row of the ring / done ring
             R acc = R(0);
+            if (!W.general) {
 #pragma unroll
-            for (int t = 0; t < HOT; ++t) {  // terms < n_ref are the referenced states (reference column t), the others compare with 0
-                if (t < W.n_term) acc += reward_term<R>(obs_at(row, W.col[t]), t < GEMX_MAX_REF ? rv[s][t] : R(0), W.inv_len[t], W.kind[t], W.power[t], W.coef[t]);
+                for (int t = 0; t < HOT; ++t) {  // terms < n_ref are the referenced states (reference column t), the others compare with 0
+                    if (t < W.n_term) acc += reward_term<false, R>(obs_at(row, W.col[t]), t < GEMX_MAX_REF ? rv[s][t] : R(0), W.inv_len[t], W.kind[t], W.power[t], W.coef[t]);
+                }
             }
-            for (int t = HOT; t < W.n_term; ++t)
-                acc += reward_term<R>(obs_at(row, a.rw->col[t]), R(0), a.rw->inv_len[t], a.rw->kind[t], a.rw->power[t], a.rw->coef[t]);
+            // slow path through memory: terms beyond the hot ones, and EVERY term when some reward_power is not 1 or 2 (one pow() site)
+#pragma nounroll
+            for (int t = W.general ? 0 : HOT; t < W.n_term; ++t) {
+                R ref = R(0);
+#pragma unroll
+                for (int j = 0; j < GEMX_MAX_REF; ++j) ref = (t == j) ? rv[s][j] : ref;
+                acc += reward_term<true, R>(obs_at(row, a.rw->col[t]), ref, a.rw->inv_len[t], a.rw->kind[t], a.rw->power[t], a.rw->coef[t]);
+            }
             const R wse = W.bias - acc;
             const R r = donebuf[row * BLOCK + tid] ? W.violation_reward : wse;  // (1 - v) * wse + v * violation_reward, v in {0, 1}
             if (valid) a.reward[(int64_t)(k0 + s) * N + env] = r;
@@ -1412,7 +1426,6 @@ __global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KA
 #pragma unroll
             for (int j = 0; j < ND; ++j) y[j] = rs ? P.init[j] : y[j];
             ang = rs ? init_ang : ang;
-            if (FIFO && P.init_kind && rs) draw_initial_state<SYS, R>(a, env, y, ang);
             if (FIFO && P.delay > 0 && rs) {  // DeadTimeProcessor.reset: the deque is refilled with the (zero) reset action
                 for (int d = 0; d < P.delay; ++d) {
 #pragma unroll
@@ -1433,22 +1446,22 @@ __global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KA
 #pragma unroll
             for (int i = 0; i < NACT; ++i) an[i] = R(0);
             read_action(b, 0, an, dn);
-            if (sb == D && P.delay == 0 && P.init_kind == 0) {
-#pragma unroll
+            if (sb == D && P.delay == 0) {
+                // branch-free basic blocks of FOUR steps (unrolling all twelve makes basic blocks of up to ~8000 instructions for the
+                // heavier systems, on which the instruction scheduler's compile time explodes; the run time is the same)
+#pragma unroll 4
                 for (int s = 0; s < D; ++s) {
                     dc = dn;
 #pragma unroll
                     for (int i = 0; i < NACT; ++i) ac[i] = an[i];
-                    if (s + 1 < D) read_action(b, s + 1, an, dn);  // one step ahead: its LDS latency hides behind this step
+                    read_action(b, s + 1 < D ? s + 1 : s, an, dn);  // one step ahead: its LDS latency hides behind this step
                     one_step(std::false_type{}, ac, dc, hb + (size_t)s * BLOCK * NHT);
                 }
-            } else {  // tail block, or a DeadTimeProcessor queue is configured
-#pragma unroll
-                for (int s = 0; s < D; ++s) {
-                    if (s < sb) {
-                        read_action(b, s, ac, dc);
-                        one_step(std::true_type{}, ac, dc, hb + (size_t)s * BLOCK * NHT);
-                    }
+            } else {  // tail block or DeadTimeProcessor queue: ONE rolled copy of the run-time-checked step
+#pragma nounroll
+                for (int s = 0; s < sb; ++s) {
+                    read_action(b, s, ac, dc);
+                    one_step(std::true_type{}, ac, dc, hb + (size_t)s * BLOCK * NHT);
                 }
             }
             __syncthreads();  // publishes hand-off block b; wave 1 is done reading block b-1 (other half)
@@ -1629,8 +1642,12 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     const int64_t blocks = (h->n + BLOCK - 1) / BLOCK;
     // two-wave pipelined kernel for small N (the chip is not full: a single wave per SIMD is issue-bound)
     const bool pipe_ok = h->use_pipe != 0 && K >= 2 && obs_every && a.coop && a.obs_vec && (h->n % BLOCK) == 0 &&
-                         params_of<R>(h).constr_kind <= 1 && h->cfg.solver_nsteps == 1 && h->cfg.supply_kind == GEMX_SUPPLY_IDEAL;
-    if (pipe_ok) {
+                         params_of<R>(h).constr_kind <= 1 && h->cfg.solver_nsteps == 1 && h->cfg.supply_kind == GEMX_SUPPLY_IDEAL &&
+                         h->cfg.init_kind == GEMX_INIT_CONST;  // (the fp64 Philox / inverse-CDF code of random initialisers would cost the
+                                                               // pipelined kernels ~50 VGPRs, i.e. half their residency at large N)
+    // (fp32 only: the fp64 build is a diagnostic of the same device functions and takes the single-wave kernel, which keeps its
+    // translation units three times smaller)
+    if constexpr (sizeof(R) == 4) if (pipe_ok) {
         using ST = Stepper<SYS, conv_base<CONV>(), LOAD, SOLVER, IL, R>;
         constexpr int NHT = SysTraits<SYS>::ND + (SysTraits<SYS>::HAS_ANGLE ? 1 : 0) + ST::NH + 1;
         // hand-off depth: 8 steps per barrier when one resident round of workgroups covers N, else 4 (half the LDS ->
