@@ -1318,6 +1318,12 @@ __global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KA
     R *fifo = hand + 2 * (size_t)D * BLOCK * NHT;  // DeadTimeProcessor FIFO [delay][64][NACTC], touched by the integrator wave only
     // action staging buffer [2][D][64 * action bytes], filled by global -> LDS direct loads of the integrator wave
     unsigned char *actb = reinterpret_cast<unsigned char *>(fifo + (size_t)P.delay * BLOCK * NACTC);
+    // fused reward: reference rows [3][D][64 * n_ref] R, staged global -> LDS by the integrator wave one block ahead, read by the output
+    // waves one block behind (hence three buffers).  The output waves thus issue NO global loads: a load would make them wait, through
+    // the in-order vmcnt, for all their older observation stores once per block.
+    constexpr int ACTB_BYTES = 2 * ((D + 3) / 4 * 4) * BLOCK * (DISCRETE ? 1 : NACT * (int)sizeof(R));
+    R *refb = reinterpret_cast<R *>(actb + ACTB_BYTES);
+    const int n_ref = a.rw != nullptr ? a.rw->n_ref : 0;
     auto steps_of = [&](int b) { return (K - b * D) < D ? (K - b * D) : D; };
 
     if (wave == 0) {
@@ -1378,6 +1384,19 @@ __global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KA
                 }
             }
         };
+        auto stage_refs = [&](int b) {  // rows of 64 * n_ref references, 64 consecutive dwords per instruction
+            const int sb = steps_of(b);
+            const int dwords = n_ref * (int)(sizeof(R) / 4);  // per env
+            R *dst = refb + (size_t)(b % 3) * D * BLOCK * n_ref;
+            for (int s = 0; s < D; ++s) {
+                const int row = s < sb ? s : sb - 1;
+                const unsigned char *src = reinterpret_cast<const unsigned char *>(a.refs + (((int64_t)b * D + row) * N + blk0) * n_ref);
+                for (int i = 0; i < dwords; ++i)
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + i * 256 + tid * 4),
+                                                     (void __attribute__((address_space(3))) *)(reinterpret_cast<unsigned char *>(dst + (size_t)s * BLOCK * n_ref) + i * 256),
+                                                     4, 0, 0);
+            }
+        };
         auto read_action = [&](int b, int s, R (&dst)[NACT], uint32_t &ddst) {
             const unsigned char *row = actb + ((size_t)(b & 1) * DP + s) * ROWB;
             if (DISCRETE) ddst = row[tid];
@@ -1434,13 +1453,17 @@ __global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KA
             }
         };
         stage_actions(0);
+        if (n_ref > 0) stage_refs(0);
         for (int b = 0; b < nb; ++b) {
             const int sb = steps_of(b);
             R *hb = hand + (size_t)(b & 1) * D * BLOCK * NHT + (size_t)tid * NHT;
             // block b's actions (and, the first time, the state) have landed: staged a whole block ago.  Only THEN issue the next
             // block's staging loads -- they go to the other half of the buffer, which nobody reads during this block.
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-            if (b + 1 < nb) stage_actions(b + 1);
+            if (b + 1 < nb) {
+                stage_actions(b + 1);
+                if (n_ref > 0) stage_refs(b + 1);
+            }
             R an[NACT], ac[NACT];
             uint32_t dn = 0, dc = 0;
 #pragma unroll
@@ -1523,7 +1546,7 @@ __global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KA
             const int sb = steps_of(pb);
             return sb - r0 < RPW ? (sb - r0 < 0 ? 0 : sb - r0) : RPW;
         };
-        R rv[RPW][GEMX_MAX_REF];  // fused reward: this wave's references of the next block to process
+
         auto process = [&](int pb) {
             const int nr = rows_of(pb);
             if (nr <= 0) return;
@@ -1546,17 +1569,22 @@ __global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KA
                 }
             }
             if (a.rw != nullptr) {
-                // references of this block were fetched a whole block ago; the next block's are issued before this block's stores.
-                // The description is (re)read from the scalar cache once per block, so that its ~25 SGPRs are live only here
+                // this block's references are in LDS (staged by the integrator wave); the description is (re)read from the scalar
+                // cache once per block, so that its ~25 SGPRs are live only here
                 RewardRegs<R> WR;
                 WR.load(a.rw);
+                R rv[RPW][GEMX_MAX_REF];
+                const R *rb = refb + ((size_t)(pb % 3) * D + r0) * BLOCK * n_ref + (size_t)tid * n_ref;
+#pragma unroll
+                for (int s = 0; s < RPW; ++s) {
+#pragma unroll
+                    for (int j = 0; j < GEMX_MAX_REF; ++j) rv[s][j] = (s < nr && j < n_ref) ? rb[(size_t)s * BLOCK * n_ref + j] : R(0);
+                }
                 reward_apply<NOUT, RPW, R>(a, WR, ring, donebuf, pb * D + r0, r0, nr, tid, env, true, rv);
-                if (pb + 1 < nb) reward_fetch<RPW, R>(a, (pb + 1) * D + r0, rows_of(pb + 1), env, rv);
             }
             flush_rings<NOUT, R>(a, ring + (size_t)r0 * BLOCK * NOUT, donebuf + (size_t)r0 * BLOCK, pb * D + r0, nr, tid, blk0, BLOCK, true,
                                  true, env);
         };
-        if (a.rw != nullptr) reward_fetch<RPW, R>(a, r0, rows_of(0), env, rv);
         for (int b = 0; b < nb; ++b) {
             if (b >= 1) process(b - 1);
             __syncthreads();
@@ -1656,6 +1684,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             size_t b = (size_t)D * BLOCK * h->nout * sizeof(R) + (size_t)D * BLOCK + 2 * (size_t)D * BLOCK * NHT * sizeof(R);
             b += (size_t)delay * BLOCK * conv_nact_c<CONV>() * sizeof(R);  // DeadTimeProcessor FIFO
             b += 2 * (size_t)((D + 3) / 4 * 4) * BLOCK * ABYTES;           // action staging (global -> LDS direct)
+            if (h->cur_reward != nullptr) b += 3 * (size_t)D * BLOCK * h->rw_n_ref * sizeof(R);  // reference staging for the fused reward
             return (b + 15) & ~(size_t)15;
         };
         auto resident = [&](int D, int OW) {
