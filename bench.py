@@ -174,8 +174,8 @@ def cpu_baseline(w, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="pmsm")
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--chunk", type=int, default=500, help="control steps fused into one launch")
