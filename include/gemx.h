@@ -232,7 +232,8 @@ int gemx_refgen_reset(gemx_refgen *r, const uint8_t *mask_dev, void *stream);
 int gemx_refgen_rollout(gemx_refgen *r, const uint8_t *done_dev, int32_t K, void *refs_out_dev, void *stream);
 int gemx_refgen_get_state(gemx_refgen *r, double *value_out_dev, double *sigma_out_dev, int32_t *left_out_dev, void *stream);
 
-/* Checkpoint / parity access to the ODE state, SoA [S_ode, N] of R in physical units (angle in rad), plus the
+/* Checkpoint / parity access to the ODE state, SoA [S_ode, N] of R in physical units (angle in rad; the fp32 build keeps the
+ * angle as a 32-bit fraction of a turn internally, so a get/set round trip rounds it to fp32 radians, ~1e-7 rad), plus the
  * per-env packed converter switching state, 2 bits per half-bridge: [N] uint8, or [2][N] uint8 (row 0 = bits 0..7,
  * row 1 = bits 8..11) for the 6 half-bridges of GEMX_CONV_FINITE_2XB6; gemx_n_switch_bytes() = bytes per env.
  * Step counters are not exported. */

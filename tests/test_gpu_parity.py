@@ -742,6 +742,54 @@ def test_single_env_numpy_contract_and_state_roundtrip():
     dc.close()
 
 
+@pytest.mark.parametrize("name", ["extex_fin_free_held_til_euler", "eesm_fin_free_held_euler", "dfim_fin_free_uniform_til_euler",
+                                  "dfim_cont_free_held_euler", "rc_pmsm_fin_free_held_euler", "pmsm_cont_dqproc_dead2_free_held_euler"])
+def test_single_env_reference_contract_for_the_widened_systems(name):
+    """n_envs == 1, numpy in / numpy out, exactly as the reference's PhysicalSystem is driven by ElectricMotorEnvironment.step
+    (core.py:344): the golden trajectory reproduced step by step with the reference's own action objects (MultiDiscrete arrays,
+    Box arrays), plus get_state / set_state / switching-state round trip and last_only rollouts."""
+    import torch
+
+    d, meta = _load(name)
+    env = _make_from_meta(meta, 1, dtype="float64")
+    ps = env.physical_system
+    r = ps.reset()
+    assert isinstance(r, np.ndarray) and np.abs(r - d["reset_state"]).max() < 1e-12
+    K = 300
+    for k in range(K):
+        a = d["actions"][k]
+        a = int(a) if np.ndim(a) == 0 else np.asarray(a)  # Discrete -> int, MultiDiscrete / Box -> array
+        s = ps.simulate(a)
+        assert isinstance(s, np.ndarray) and s.dtype == np.float64 and s.shape == (len(meta["state_names"]),)
+        err = np.abs(s - d["states"][k])
+        if "epsilon" in meta["state_names"]:
+            i = meta["state_names"].index("epsilon")
+            err[i] = min(err[i], 2.0 - err[i])
+        assert err.max() < 1e-9, (k, err.max())
+    assert ps.k == K
+    env.close()
+    # state round trip and last_only on a small batch (fp32)
+    env = _make_from_meta(meta, 5, dtype="float32")
+    ps = env.physical_system
+    acts = torch.as_tensor(np.repeat(d["actions"][:40].reshape(40, 1, -1), 5, axis=1)).cuda()
+    if ps._discrete and d["actions"].ndim == 1:
+        acts = acts.reshape(40, 5)
+    o1, _ = env.rollout(acts[:20])
+    st, sw = ps.get_state(), ps.get_switch_state()
+    o2, d2 = env.rollout(acts[20:])
+    if meta["supply"] != "RCVoltageSupply" and not meta.get("dead_time_steps"):  # (supply state / action queue are not part of get_state)
+        ps.set_state(st)
+        ps.set_switch_state(sw)
+        o3, _ = env.rollout(acts[20:])
+        # (the fp32 path keeps the angle as a 32-bit turn fraction; get_state reports it in fp32 radians, i.e. rounded to ~1e-7 rad)
+        assert torch.allclose(o2, o3, atol=2e-6, rtol=0)
+        ps.set_state(st)
+        ps.set_switch_state(sw)
+        ol, dl = env.rollout(acts[20:], last_only=True)
+        assert torch.equal(ol, o3[-1]) and torch.equal(dl.bool(), d2.bool().any(dim=0))
+    env.close()
+
+
 def test_episodic_auto_reset_matches_oracle_loop():
     """done -> restart from the reset state on the next step (`if terminated: env.reset()`), per env."""
     import torch
