@@ -191,6 +191,8 @@ template <class R> static void fill_params(const gemx_handle &h, const double *m
     for (int i = 0; i < h.nd; ++i) P.init[i] = (R)c.init_state[i];
     P.init_angle_rep = Angle<R>::to_bits(Angle<R>::from_rad(h.has_angle ? c.init_state[h.nd] : 0.0));
     P.nsteps = c.solver_nsteps;
+    P.lin = (const R *)h.linmap_dev;
+    P.lin_on = 0;  // enabled by the first launch of a linable instantiation (launch_advance_t)
     P.init_kind = c.init_kind;
     P.rc_supply = c.supply_kind == GEMX_SUPPLY_RC;
     P.sup_r = (R)c.supply_r;
@@ -491,6 +493,8 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         if (ev) h->steps_per_block = atoi(ev);
         ev = getenv("GEMX_PIPE");
         if (ev) h->use_pipe = atoi(ev);
+        ev = getenv("GEMX_LINMAP");  // 0: never use the one-step map of the electrical subsystem (A/B runs)
+        if (ev && atoi(ev) == 0) h->linmap_state = -1;
 
     }
     host_reset_obs(*h, m);
@@ -526,6 +530,7 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         if (hipMemcpy(h->rinit_dev, &I, sizeof(I), hipMemcpyHostToDevice) != hipSuccess || hipMemset(h->rcnt, 0, sizeof(uint32_t) * (size_t)h->n) != hipSuccess)
             return cleanup(fail(GEMX_ERR_DEVICE, "hipMemcpy failed"));
     }
+    if (hipMalloc(&h->linmap_dev, sizeof(double) * 64) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(linmap) failed"));
     if (hipMalloc((void **)&h->err, sizeof(uint32_t)) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(err) failed"));
     if (hipMalloc(&h->reset_obs_dev, es * GEMX_MAX_OUT) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(reset_obs) failed"));
     if (hipMalloc(&h->cw_dev, es * 2 * GEMX_MAX_OUT) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(cw) failed"));
@@ -571,6 +576,7 @@ int gemx_destroy(gemx_handle *h) {
     if (h->ring) (void)hipFree(h->ring);
     if (h->rw_dev) (void)hipFree(h->rw_dev);
     if (h->rinit_dev) (void)hipFree(h->rinit_dev);
+    if (h->linmap_dev) (void)hipFree(h->linmap_dev);
     if (h->rcnt) (void)hipFree(h->rcnt);
     if (h->err) (void)hipFree(h->err);
     if (h->reset_obs_dev) (void)hipFree(h->reset_obs_dev);

@@ -81,6 +81,8 @@ template <class R> struct DevParams {
     int64_t init_angle_rep; // initial angle in Angle<R>::T representation (bit pattern)
     int32_t nsteps, auto_reset, obs_layout;
     int32_t constr_kind;    // 0 none, 1 the system's default constraint (fast path), 2 generic weights
+    const R *lin;           // constant-speed loads: the solver's one-step map of the (linear) electrical subsystem at omega = init[0]:
+    int32_t lin_on;         //   x1 = Phi x0 + S g, Phi [NM][NM] then S [NM][NG] (built once per handle by linmap_kernel)
     int32_t init_kind;      // != 0: initial states are drawn per reset (rinit / reset counters in KArgs)
     int32_t rc_supply;      // RCVoltageSupply: u_sup is a per-env state (rows ND, ND+1 of the state array: u, time since last update)
     R sup_r, sup_inv_rc;    // R, 1 / (R C)
@@ -312,6 +314,8 @@ struct gemx_handle {
     void *angle = nullptr;   // [n] int32 | double
     uint8_t *sw = nullptr;   // [sw_rows][n]
     int sw_rows = 1;
+    void *linmap_dev = nullptr;  // one-step map of the electrical subsystem (constant-speed loads), R[64]
+    int linmap_state = 0;        // 0: not built yet, 1: built and enabled, -1: not applicable
     void *rinit_dev = nullptr;  // InitDev (random initial states)
     uint32_t *rcnt = nullptr;   // [n] resets so far per env
     void *rw_dev = nullptr;  // RewardDev<R> (gemx_set_reward)

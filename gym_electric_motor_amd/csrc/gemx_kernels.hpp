@@ -52,6 +52,9 @@ template <class R> struct Elec<GEMX_SYS_DC_PERMEX, R> {
     static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[MAX_U]) { return Pre{P.m[0] * w + P.m[2] * u[0]}; }
     static __device__ __forceinline__ void f(const DevParams<R> &P, const Pre &p, const R (&x)[1], R (&dx)[1]) { dx[0] = p.b + P.m[1] * x[0]; }
     static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[1]) { return P.tc0 * x[0]; }  // line 67-69
+    static constexpr int NG = 1;  // affine part g of f(x) = A x + g: its first NG rows are non-zero
+    static __device__ __forceinline__ void get_b(const Pre &p, R (&g)[NG]) { g[0] = p.b; }
+    static __device__ __forceinline__ Pre set_b(Pre p, const R (&g)[NG]) { p.b = g[0]; return p; }
 };
 template <class R> struct Elec<GEMX_SYS_DC_SERIES, R> {  // dc_series_motor.py:68-83: di = (-(r_a+r_e) i - l_e' omega i + u) / (l_a+l_e)
     static constexpr int NM = 1;
@@ -59,6 +62,9 @@ template <class R> struct Elec<GEMX_SYS_DC_SERIES, R> {  // dc_series_motor.py:6
     static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[MAX_U]) { return Pre{P.m[0] + P.m[1] * w, P.m[2] * u[0]}; }
     static __device__ __forceinline__ void f(const DevParams<R> &, const Pre &p, const R (&x)[1], R (&dx)[1]) { dx[0] = p.b + p.a * x[0]; }
     static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[1]) { return P.tc0 * x[0] * x[0]; }  // line 74-76
+    static constexpr int NG = 1;
+    static __device__ __forceinline__ void get_b(const Pre &p, R (&g)[NG]) { g[0] = p.b; }
+    static __device__ __forceinline__ Pre set_b(Pre p, const R (&g)[NG]) { p.b = g[0]; return p; }
 };
 template <class R> struct Elec<GEMX_SYS_DC_SHUNT, R> {  // dc_motor.py:96-127 with u_a = u_e = u (dc_shunt_motor.py:72-74)
     static constexpr int NM = 2;
@@ -69,6 +75,9 @@ template <class R> struct Elec<GEMX_SYS_DC_SHUNT, R> {  // dc_motor.py:96-127 wi
         dx[1] = p.be + P.m[3] * x[1];
     }
     static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[2]) { return P.tc0 * x[0] * x[1]; }  // dc_motor.py:106-108
+    static constexpr int NG = 2;
+    static __device__ __forceinline__ void get_b(const Pre &p, R (&g)[NG]) { g[0] = p.ba; g[1] = p.be; }
+    static __device__ __forceinline__ Pre set_b(Pre p, const R (&g)[NG]) { p.ba = g[0]; p.be = g[1]; return p; }
 };
 template <class R> struct Elec<GEMX_SYS_DC_EXTEX, R> {  // dc_motor.py:96-127 with separately fed armature / excitation circuits
     static constexpr int NM = 2;
@@ -79,6 +88,9 @@ template <class R> struct Elec<GEMX_SYS_DC_EXTEX, R> {  // dc_motor.py:96-127 wi
         dx[1] = p.be + P.m[3] * x[1];
     }
     static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[2]) { return P.tc0 * x[0] * x[1]; }  // dc_motor.py:106-108
+    static constexpr int NG = 2;
+    static __device__ __forceinline__ void get_b(const Pre &p, R (&g)[NG]) { g[0] = p.ba; g[1] = p.be; }
+    static __device__ __forceinline__ Pre set_b(Pre p, const R (&g)[NG]) { p.ba = g[0]; p.be = g[1]; return p; }
 };
 template <class R> struct Elec<GEMX_SYS_EESM, R> {  // externally_excited_synchronous_motor.py:69-113, 133-136; x = i_sd, i_sq, i_e
     static constexpr int NM = 3;
@@ -92,6 +104,9 @@ template <class R> struct Elec<GEMX_SYS_EESM, R> {  // externally_excited_synchr
         dx[2] = p.be + P.m[9] * x[0] + P.m[10] * x[2] + p.w13 * x[1];
     }
     static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[3]) { return (P.tc0 * x[2] + P.tc1 * x[0]) * x[1]; }
+    static constexpr int NG = 3;
+    static __device__ __forceinline__ void get_b(const Pre &p, R (&g)[NG]) { g[0] = p.bd; g[1] = p.bq; g[2] = p.be; }
+    static __device__ __forceinline__ Pre set_b(Pre p, const R (&g)[NG]) { p.bd = g[0]; p.bq = g[1]; p.be = g[2]; return p; }
 };
 template <class R> struct Elec<GEMX_SYS_SYNC, R> {  // permanent_magnet_synchronous_motor.py:107-119, 134-139
     static constexpr int NM = 2;
@@ -104,6 +119,9 @@ template <class R> struct Elec<GEMX_SYS_SYNC, R> {  // permanent_magnet_synchron
         dx[1] = p.bq + P.m[4] * x[1] + p.wqd * x[0];
     }
     static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[2]) { return (P.tc0 + P.tc1 * x[0]) * x[1]; }
+    static constexpr int NG = 2;
+    static __device__ __forceinline__ void get_b(const Pre &p, R (&g)[NG]) { g[0] = p.bd; g[1] = p.bq; }
+    static __device__ __forceinline__ Pre set_b(Pre p, const R (&g)[NG]) { p.bd = g[0]; p.bq = g[1]; return p; }
 };
 template <class R> struct Elec<GEMX_SYS_SCIM, R> {  // induction_motor.py:236-248, 287-312
     static constexpr int NM = 4;
@@ -118,6 +136,9 @@ template <class R> struct Elec<GEMX_SYS_SCIM, R> {  // induction_motor.py:236-24
         dx[3] = P.m[11] * x[1] + P.m[12] * x[3] + p.w13 * x[2];
     }
     static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[4]) { return P.tc0 * (x[2] * x[1] - x[3] * x[0]); }
+    static constexpr int NG = 2;
+    static __device__ __forceinline__ void get_b(const Pre &p, R (&g)[NG]) { g[0] = p.ba; g[1] = p.bb; }
+    static __device__ __forceinline__ Pre set_b(Pre p, const R (&g)[NG]) { p.ba = g[0]; p.bb = g[1]; return p; }
 };
 
 template <class R> struct Elec<GEMX_SYS_DFIM, R> {  // the SCIM matrix with live rotor-voltage columns; u = u_s alpha/beta, u_r alpha/beta
@@ -134,6 +155,9 @@ template <class R> struct Elec<GEMX_SYS_DFIM, R> {  // the SCIM matrix with live
         dx[3] = p.bd + P.m[11] * x[1] + P.m[12] * x[3] + p.w13 * x[2];
     }
     static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[4]) { return P.tc0 * (x[2] * x[1] - x[3] * x[0]); }
+    static constexpr int NG = 4;
+    static __device__ __forceinline__ void get_b(const Pre &p, R (&g)[NG]) { g[0] = p.ba; g[1] = p.bb; g[2] = p.bc; g[3] = p.bd; }
+    static __device__ __forceinline__ Pre set_b(Pre p, const R (&g)[NG]) { p.ba = g[0]; p.bb = g[1]; p.bc = g[2]; p.bd = g[3]; return p; }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -208,12 +232,41 @@ __device__ __forceinline__ R rk_step(R (&z)[NZ], R h, F &&rhs) {
 // integrate one segment of length h with `nsteps` sub-steps (EulerSolver(nsteps), solvers.py:103-122).
 // y = [omega, motor states].  Returns the angle increment  pole * int(omega dt)  of the scheme.
 // ------------------------------------------------------------------------------------------------
-template <int SYS, int LOAD, int SOLVER, class R, bool NS1 = false>
+// LIN (constant-speed load, one segment of length tau, omega == init[0]): with omega fixed the electrical subsystem is LINEAR with
+// constant coefficients, x' = A x + g (g constant over the step), and one step of ANY explicit Runge-Kutta scheme is the affine map
+// x1 = Phi x0 + S g with Phi = R(hA), S = h (R(hA) - I)(hA)^-1 (R = the scheme's stability polynomial).  P.lin holds Phi and S as
+// linmap_kernel obtained them by pushing unit vectors through rk_step itself; a step is then NM*(NM+NG) FMAs instead of 4 (RK4) or
+// 6 (DP5) right-hand sides plus stage combinations.  Same polynomial, so same result up to rounding.
+template <int SYS, int LOAD, int SOLVER, class R, bool NS1 = false, bool LIN = false>
 __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<SYS>::ND], const R (&u)[MAX_U], R h) {
     using E = Elec<SYS, R>;
     constexpr int NM = E::NM;
     const int ns = NS1 ? 1 : P.nsteps;     // NS1: the caller guarantees solver_nsteps == 1 (branch-free code)
     const R hs = NS1 ? h : h * P.inv_ns;
+    if (LIN) {
+        constexpr int NG = E::NG;
+        R g[NG], x[NM];
+        E::get_b(E::prep(P, y[0], u), g);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) x[i] = y[1 + i];
+        for (int s = 0; s < ns; ++s) {
+            R xn[NM];
+#pragma unroll
+            for (int r = 0; r < NM; ++r) {
+                R acc = P.lin[NM * NM + r * NG] * g[0];
+#pragma unroll
+                for (int i = 1; i < NG; ++i) acc += P.lin[NM * NM + r * NG + i] * g[i];
+#pragma unroll
+                for (int c = 0; c < NM; ++c) acc += P.lin[r * NM + c] * x[c];
+                xn[r] = acc;
+            }
+#pragma unroll
+            for (int r = 0; r < NM; ++r) x[r] = xn[r];
+        }
+#pragma unroll
+        for (int i = 0; i < NM; ++i) y[1 + i] = x[i];
+        return P.pole * y[0] * h;
+    }
     if (LOAD == GEMX_LOAD_CONST_SPEED) {
         // omega is constant (constant_speed_load.py:40-42): integrate the electrical states only; every scheme's
         // quadrature weights sum to one, so the angle increment is exactly pole * omega * h.
@@ -366,7 +419,7 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
         if (SYS == GEMX_SYS_DC_EXTEX) return y[1 + j];
         return SYS == GEMX_SYS_DC_SHUNT ? y[1] + y[ND - 1] : y[1];
     }
-    template <bool NS1 = false>
+    template <bool NS1 = false, bool LIN = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[ND], AngT &, uint32_t &sw, const R (&act)[MAX_ACT], uint32_t dact,
                                                    R (&ho)[NH]) {
         R u[MAX_U] = {R(0), R(0), R(0), R(0)};
@@ -378,7 +431,7 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
                 const R i = i_in(y, j);
                 u[j] = (cont_leg<IL, R>(P, d0, i) - cont_leg<IL, R>(P, d1, i)) * P.u_sup;  // both sub-converters see the same i (line 483)
             }
-            integrate<SYS, LOAD, SOLVER, R, NS1>(P, y, u, P.tau);
+            integrate<SYS, LOAD, SOLVER, R, NS1, LIN>(P, y, u, P.tau);
         } else {  // Finite-4QC: action -> (leg0, leg1) sub-actions [1,1,2,2] / [1,2,1,2] (converters.py:360-361)
             uint32_t legs = 0;
 #pragma unroll
@@ -406,7 +459,7 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
                     }
                     u[j] = (v0 - v1) * P.u_sup;
                 }
-                integrate<SYS, LOAD, SOLVER, R, NS1>(P, y, u, h);
+                integrate<SYS, LOAD, SOLVER, R, NS1, LIN>(P, y, u, h);
             };
             if (IL) {
                 segment(two ? P.t_il : P.tau);
@@ -458,7 +511,7 @@ struct Stepper<GEMX_SYS_DC_EXTEX, CONV, LOAD, SOLVER, IL, R> : DcStepper<GEMX_SY
 template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_SYNC, CONV, LOAD, SOLVER, IL, R> {
     using AngT = typename Angle<R>::T;
     static constexpr int NH = 7;  // ho: sin, cos of the last segment-start angle, u_a, u_b, u_c, u_sd, u_sq
-    template <bool NS1 = false>
+    template <bool NS1 = false, bool LIN = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[3], AngT &ang, uint32_t &sw, const R (&act)[MAX_ACT],
                                                    uint32_t dact, R (&ho)[NH]) {
         R s, c;
@@ -482,7 +535,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             t23(ua, ub, uc, ual, ube);
             u[0] = c * ual + s * ube;  // Q^-1(., eps): u_dq frozen at the segment-start angle (line 501/511)
             u[1] = -s * ual + c * ube;
-            const R deps = integrate<GEMX_SYS_SYNC, LOAD, SOLVER, R, NS1>(P, y, u, h);
+            const R deps = integrate<GEMX_SYS_SYNC, LOAD, SOLVER, R, NS1, LIN>(P, y, u, h);
             ang = Angle<R>::advance(ang, deps);
         };
         if (IL) {
@@ -533,7 +586,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     using AngT = typename Angle<R>::T;
     static constexpr int NH = 8;  // ho: sin, cos of the step-start angle, u_a, u_b, u_c, u_sd, u_sq, u_e
     static constexpr int B6 = CONV == GEMX_CONV_CONT_B6_4QC ? GEMX_CONV_CONT_B6 : GEMX_CONV_FINITE_B6;
-    template <bool NS1 = false>
+    template <bool NS1 = false, bool LIN = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[4], AngT &ang, uint32_t &, const R (&act)[MAX_ACT],
                                                    uint32_t dact, R (&ho)[NH]) {
         R s, c;
@@ -551,7 +604,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
         u[0] = c * ual + s * ube;  // Q^-1(., eps) at the step-start angle (line 643)
         u[1] = -s * ual + c * ube;
         u[2] = ue;
-        const R deps = integrate<GEMX_SYS_EESM, LOAD, SOLVER, R, NS1>(P, y, u, P.tau);
+        const R deps = integrate<GEMX_SYS_EESM, LOAD, SOLVER, R, NS1, LIN>(P, y, u, P.tau);
         ang = Angle<R>::advance(ang, deps);
         ho[0] = s; ho[1] = c; ho[2] = ua; ho[3] = ub; ho[4] = uc; ho[5] = u[0]; ho[6] = u[1]; ho[7] = ue;
     }
@@ -593,7 +646,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     using AngT = typename Angle<R>::T;
     static constexpr int NH = 7;  // ho: sin, cos of the last segment-start field angle, u_a, u_b, u_c, u_alpha, u_beta
     static __device__ __forceinline__ void field_angle(R pa, R pb, R &s, R &c) { flux_angle<R>(pa, pb, s, c); }
-    template <bool NS1 = false>
+    template <bool NS1 = false, bool LIN = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[5], AngT &ang, uint32_t &sw, const R (&act)[MAX_ACT],
                                                    uint32_t dact, R (&ho)[NH]) {
         R s, c;
@@ -611,7 +664,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             if (IL) t32(y[1], y[2], ia, ib, ic);  // i_in = T32(i_alphabeta) (line 780/792)
             b6_voltages<CONV, IL, R>(P, act, dact, legs, ia, ib, ic, ua, ub, uc);
             t23(ua, ub, uc, u[0], u[1]);  // u_alphabeta constant over the segment (line 788/799)
-            const R deps = integrate<GEMX_SYS_SCIM, LOAD, SOLVER, R, NS1>(P, y, u, h);
+            const R deps = integrate<GEMX_SYS_SCIM, LOAD, SOLVER, R, NS1, LIN>(P, y, u, h);
             ang = Angle<R>::advance(ang, deps);
         };
         if (IL) {
@@ -664,7 +717,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     //     u_sa, u_sb, u_sc; u_rd, u_re, u_rf (rotor-fixed three-phase frame)
     static constexpr int NH = 10;
     static constexpr int B6 = CONV == GEMX_CONV_CONT_2XB6 ? GEMX_CONV_CONT_B6 : GEMX_CONV_FINITE_B6;
-    template <bool NS1 = false>
+    template <bool NS1 = false, bool LIN = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[5], AngT &ang, uint32_t &sw, const R (&act)[MAX_ACT],
                                                    uint32_t dact, R (&ho)[NH]) {
         R sf, cf, se, ce;
@@ -692,7 +745,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             t23(urd, ure, urf, urg, urh);
             u[2] = ce * urg - se * urh;
             u[3] = se * urg + ce * urh;
-            const R deps = integrate<GEMX_SYS_DFIM, LOAD, SOLVER, R, NS1>(P, y, u, h);
+            const R deps = integrate<GEMX_SYS_DFIM, LOAD, SOLVER, R, NS1, LIN>(P, y, u, h);
             ang = Angle<R>::advance(ang, deps);
         };
         if (IL) {
@@ -818,12 +871,49 @@ __device__ __forceinline__ void draw_initial_state(const KArgs<R> &a, int64_t en
 }
 
 // step() for the single-wave kernel
-template <class ST, int ND, int NOUT, class R>
+template <class ST, int ND, int NOUT, class R, bool LIN = false>
 __device__ __forceinline__ void full_step(const DevParams<R> &P, R (&y)[ND], typename Angle<R>::T &ang, uint32_t &sw, const R (&act)[MAX_ACT],
                                           uint32_t dact, R (&obs)[NOUT]) {
     R ho[ST::NH];
-    ST::advance(P, y, ang, sw, act, dact, ho);
+    ST::template advance<false, LIN>(P, y, ang, sw, act, dact, ho);
     ST::observe(P, y, ang, ho, obs);
+}
+// instantiations whose electrical subsystem can be stepped by the precomputed one-step map (see integrate<..., LIN>)
+template <int LOAD, int SOLVER, bool IL, class R> constexpr bool linable() {
+    return LOAD == GEMX_LOAD_CONST_SPEED && !IL && SOLVER != GEMX_SOLVER_EULER && sizeof(R) == 4;
+}
+// the map is valid for a wave if every lane's omega equals init[0] (then it stays so: a ConstantSpeedLoad never changes omega, and a
+// reset puts init[0] back); omega set to something else through gemx_set_state falls back to the stage-by-stage solver
+template <int LOAD, int SOLVER, bool IL, class R> __device__ __forceinline__ bool lin_usable(const DevParams<R> &P, R omega) {
+    if (!linable<LOAD, SOLVER, IL, R>()) return false;
+    return P.lin_on && __all(omega == P.init[0]);
+}
+// builds the map for one handle: Phi's columns are rk_step(e_j) with g = 0, S's columns rk_step(0) with g = e_i
+template <int SYS, int SOLVER, class R> __global__ void linmap_kernel(DevParams<R> P, R *out) {
+    using E = Elec<SYS, R>;
+    constexpr int NM = E::NM, NG = E::NG;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const R hs = P.tau * P.inv_ns;
+    const R u0[MAX_U] = {R(0), R(0), R(0), R(0)};
+    R zg[NG];
+    for (int i = 0; i < NG; ++i) zg[i] = R(0);
+    const typename E::Pre pre0 = E::set_b(E::prep(P, P.init[0], u0), zg);
+    for (int j = 0; j < NM; ++j) {
+        R x[NM];
+        for (int i = 0; i < NM; ++i) x[i] = i == j ? R(1) : R(0);
+        auto rhs = [&](const R (&xx)[NM], R (&dx)[NM]) { E::f(P, pre0, xx, dx); };
+        rk_step<SOLVER, NM, R>(x, hs, rhs);
+        for (int r = 0; r < NM; ++r) out[r * NM + j] = x[r];
+    }
+    for (int i = 0; i < NG; ++i) {
+        R gi[NG], x[NM];
+        for (int k = 0; k < NG; ++k) gi[k] = k == i ? R(1) : R(0);
+        for (int k = 0; k < NM; ++k) x[k] = R(0);
+        const typename E::Pre prei = E::set_b(pre0, gi);
+        auto rhs = [&](const R (&xx)[NM], R (&dx)[NM]) { E::f(P, prei, xx, dx); };
+        rk_step<SOLVER, NM, R>(x, hs, rhs);
+        for (int r = 0; r < NM; ++r) out[NM * NM + r * NG + i] = x[r];
+    }
 }
 
 // ConstraintMonitor with merge 'max' over LimitConstraint / SquaredConstraint; terminated = violation >= 1
@@ -997,7 +1087,7 @@ template <bool COOP, int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R>
 __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTraits<SYS>::ND], typename Angle<R>::T &ang, uint32_t &sw,
                                               R (&obs)[SysTraits<SYS>::NOUT], uint32_t &done_or, uint32_t &bad_action, R *ring,
                                               const unsigned char *atile, unsigned char *donebuf, int k0, int sb, int tid,
-                                              int64_t e, typename Angle<R>::T init_ang, R *fifo, int &slot, R (&sup)[2]) {
+                                              int64_t e, typename Angle<R>::T init_ang, R *fifo, int &slot, R (&sup)[2], bool lin_ok) {
     constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
     constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
     constexpr int ABYTES = DISCRETE ? 1 : NACT * (int)sizeof(R);
@@ -1073,7 +1163,8 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
             sup[1] = P.tau;
             PL.u_sup = sup[0];
         }
-        full_step<ST, ND, NOUT, R>(PL, y, ang, sw, act, dact, obs);
+        if (linable<LOAD, SOLVER, IL, R>() && lin_ok) full_step<ST, ND, NOUT, R, linable<LOAD, SOLVER, IL, R>()>(PL, y, ang, sw, act, dact, obs);
+        else full_step<ST, ND, NOUT, R, false>(PL, y, ang, sw, act, dact, obs);
         const bool done = constraint_done<ST, NOUT, R>(P, obs);
         done_or |= done ? 1u : 0u;
         pdone = done;
@@ -1156,6 +1247,7 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
         if (conv_sw_bytes<CONV>() == 2) sw |= (uint32_t)a.sw[N + e] << 8;
     }
     const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
+    const bool lin_ok = lin_usable<LOAD, SOLVER, IL, R>(P, y[0]);  // wave-uniform
     R sup[2] = {P.u_sup, R(0)};  // RCVoltageSupply: capacitor voltage, time since the supply's last update
     if (P.rc_supply) {
         sup[0] = a.state[(int64_t)ND * N + e];
@@ -1221,8 +1313,8 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
 
         // 2. compute: no global memory traffic in here when coop
         const unsigned char *atile = actbuf + (size_t)half * S * ROWB;
-        if (coop) compute_block<true, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot, sup);
-        else compute_block<false, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot, sup);
+        if (coop) compute_block<true, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot, sup, lin_ok);
+        else compute_block<false, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot, sup, lin_ok);
         __syncthreads();
 
         // 3. park the prefetched tile
@@ -1348,6 +1440,8 @@ __global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KA
                 fifo[((size_t)d * BLOCK + tid) * NACTC + i] = DISCRETE ? (R)a.ring[gi] : reinterpret_cast<const R *>(a.ring)[gi];
             }
         }
+        constexpr bool LINABLE = linable<LOAD, SOLVER, IL, R>();
+        const bool lin_ok = lin_usable<LOAD, SOLVER, IL, R>(P, y[0]);  // wave-uniform
         const bool check_default = P.constr_kind == 1;
         const bool auto_reset = P.auto_reset != 0;
         uint32_t bad_action = 0;
@@ -1429,7 +1523,9 @@ __global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KA
             }
             if (conv_dq<CONV>() && !P.dq_processor) dq_action_stage<SYS, CONV, R>(P, y, ang, act);
             R ho[NH];
-            ST::template advance<true>(P, y, ang, sw, act, dact, ho);  // launcher guarantees solver_nsteps == 1
+            // launcher guarantees solver_nsteps == 1; LINABLE instantiations take the one-step map whenever it is valid for this wave
+            if (LINABLE && (!FIFO || lin_ok)) ST::template advance<true, LINABLE>(P, y, ang, sw, act, dact, ho);
+            else ST::template advance<true, false>(P, y, ang, sw, act, dact, ho);
             const bool done = ST::state_done(P, y, ho) & check_default;
 #pragma unroll
             for (int j = 0; j < ND; ++j) row[j] = y[j];
@@ -1469,7 +1565,7 @@ __global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KA
 #pragma unroll
             for (int i = 0; i < NACT; ++i) an[i] = R(0);
             read_action(b, 0, an, dn);
-            if (sb == D && P.delay == 0) {
+            if (sb == D && P.delay == 0 && (!LINABLE || lin_ok)) {
                 // branch-free basic blocks of FOUR steps (unrolling all twelve makes basic blocks of up to ~8000 instructions for the
                 // heavier systems, on which the instruction scheduler's compile time explodes; the run time is the same)
 #pragma unroll 4
@@ -1638,6 +1734,17 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     a.ring_phase = delay > 0 ? (int)(h->steps_total % (unsigned long long)delay) : 0;
     h->steps_total += (unsigned long long)K;
     a.err = h->err;
+    if (h->linmap_state == 0) {  // once per handle: the electrical subsystem's one-step map (constant-speed loads)
+        h->linmap_state = -1;
+        // (random initialisers may draw omega per episode: those handles keep the stage-by-stage solver)
+        if constexpr (linable<LOAD, SOLVER, IL, R>()) if (h->cfg.init_kind == GEMX_INIT_CONST) {
+            hipLaunchKernelGGL((linmap_kernel<SYS, SOLVER, R>), dim3(1), dim3(64), 0, st, params_of<R>(h), (R *)h->linmap_dev);
+            GEMX_HIP_TRY(hipGetLastError());
+            h->linmap_state = 1;
+            h->pf.lin_on = 1;
+        }
+    }
+    a.P = params_of<R>(h);
     a.rinit = (const InitDev *)h->rinit_dev;
     a.rcnt = h->rcnt;
     a.rw = h->cur_reward != nullptr ? (const RewardDev<R> *)h->rw_dev : nullptr;
