@@ -81,12 +81,13 @@ EXPORTS = (
     "gemx_n_envs", "gemx_n_ode", "gemx_n_out", "gemx_n_action", "gemx_action_itemsize", "gemx_n_switch_bytes", "gemx_reset_observation", "gemx_set_reward", "gemx_rollout_reward", "gemx_refgen_create", "gemx_refgen_destroy", "gemx_refgen_reset",
     "gemx_refgen_rollout", "gemx_refgen_get_state",
     "gemx_reset", "gemx_step", "gemx_rollout", "gemx_get_state", "gemx_set_state", "gemx_get_switch_state",
-    "gemx_set_switch_state", "gemx_set_steps_per_block", "gemx_last_launch", "gemx_error_flags",
+    "gemx_set_switch_state", "gemx_set_steps_per_block", "gemx_last_launch", "gemx_error_flags", "gemx_debug_read",
 )
 
 
 def library_path():
-    return _build.LIB
+    """In-tree libgemx.so; GEMX_LIBRARY names another build of the SAME library (A/B runs of kernel variants)."""
+    return os.environ.get("GEMX_LIBRARY") or _build.LIB
 
 
 def load():

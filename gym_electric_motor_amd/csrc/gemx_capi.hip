@@ -374,6 +374,7 @@ extern "C" {
 
 int gemx_abi_version(void) { return GEMX_ABI_VERSION; }
 int gemx_sizeof_config(void) { return (int)sizeof(gemx_config); }
+int gemx_debug_read(gemx_handle *h, unsigned long long *out, int n) { return (int)hipMemcpy(out, (char *)h->err + 64, n * 8, hipMemcpyDeviceToHost); }
 const char *gemx_last_error(void) { return g_err; }
 
 int gemx_device_count(void) {
@@ -531,7 +532,7 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
             return cleanup(fail(GEMX_ERR_DEVICE, "hipMemcpy failed"));
     }
     if (hipMalloc(&h->linmap_dev, sizeof(double) * 64) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(linmap) failed"));
-    if (hipMalloc((void **)&h->err, sizeof(uint32_t)) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(err) failed"));
+    if (hipMalloc((void **)&h->err, 4096) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(err) failed"));
     if (hipMalloc(&h->reset_obs_dev, es * GEMX_MAX_OUT) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(reset_obs) failed"));
     if (hipMalloc(&h->cw_dev, es * 2 * GEMX_MAX_OUT) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(cw) failed"));
     {
@@ -549,7 +550,7 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
     }
     fill_params<float>(*h, m, pole, h->pf);
     fill_params<double>(*h, m, pole, h->pd);
-    if (hipMemset(h->sw, 0, (size_t)h->n * h->sw_rows) != hipSuccess || hipMemset(h->err, 0, sizeof(uint32_t)) != hipSuccess)
+    if (hipMemset(h->sw, 0, (size_t)h->n * h->sw_rows) != hipSuccess || hipMemset(h->err, 0, 4096) != hipSuccess)
         return cleanup(fail(GEMX_ERR_DEVICE, "hipMemset failed"));
     if (cfg->dtype == GEMX_F64) {
         if (hipMemcpy(h->reset_obs_dev, h->reset_obs, sizeof(double) * GEMX_MAX_OUT, hipMemcpyHostToDevice) != hipSuccess)

@@ -1383,7 +1383,8 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
 // constraint kind none/default, S a multiple of PIPE_D.
 // ------------------------------------------------------------------------------------------------
 template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R, int D, int OW>
-__global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KArgs<R> a) {
+__global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advance_pipe_kernel(const KArgs<R> a) {
+    constexpr int LW = pipe_loader_waves(D);  // 1: a loader wave stages actions / references instead of the integrator
     constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
     constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
     constexpr bool HAS_ANGLE = SysTraits<SYS>::HAS_ANGLE;
@@ -1418,6 +1419,51 @@ __global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KA
     const int n_ref = a.rw != nullptr ? a.rw->n_ref : 0;
     auto steps_of = [&](int b) { return (K - b * D) < D ? (K - b * D) : D; };
 
+    // Action staging: global memory -> LDS DIRECTLY (`global_load_lds_dword`: each lane's dword lands at M0 + 4 * lane, no VGPR
+    // destination), one block ahead, double-buffered.  Staging through registers instead put up to D*NACT pending-load VGPRs
+    // into the unrolled steps, and whenever the register allocator placed one of them next to an operand of a packed
+    // instruction (v_pk_* read register PAIRS) the compiler had to insert `s_waitcnt vmcnt(0)` in the middle of the block
+    // (measured 150 -> 164 us per 500-step launch).  The integrator reads its action of a step from LDS one step ahead.
+    constexpr int ABYTES = DISCRETE ? 1 : NACT * (int)sizeof(R);
+    constexpr int ROWB = BLOCK * ABYTES;  // bytes of one 64-env action row (contiguous in the [K][N][A] tensor)
+    constexpr int DP = ROWB == 64 ? (D + 3) / 4 * 4 : D;  // rows per buffer half (uint8 rows are staged four at a time)
+    auto stage_actions = [&](int b) {
+        const int sb = steps_of(b);
+        unsigned char *dst = actb + (size_t)(b & 1) * DP * ROWB;
+        const unsigned char *src = a.actions + ((int64_t)b * D * N + blk0) * ABYTES;
+        if (ROWB == 64) {  // uint8 actions: 16 lanes cover a row, so one instruction stages four rows
+#pragma unroll
+            for (int j = 0; j < (D + 3) / 4; ++j) {
+                int row = 4 * j + (tid >> 4);
+                row = row < sb ? row : sb - 1;  // tail block: re-read the last valid row
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + (int64_t)row * N + (tid & 15) * 4),
+                                                 (void __attribute__((address_space(3))) *)(dst + (size_t)j * 256), 4, 0, 0);
+            }
+        } else {  // ROWB is a multiple of 256 bytes: each instruction moves 64 consecutive dwords of a row
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                const int row = s < sb ? s : sb - 1;
+#pragma unroll
+                for (int i = 0; i < ROWB / 256; ++i)
+                    __builtin_amdgcn_global_load_lds(
+                        (const void __attribute__((address_space(1))) *)(src + (int64_t)row * N * ABYTES + i * 256 + tid * 4),
+                        (void __attribute__((address_space(3))) *)(dst + (size_t)s * ROWB + i * 256), 4, 0, 0);
+            }
+        }
+    };
+    auto stage_refs = [&](int b) {  // rows of 64 * n_ref references, 64 consecutive dwords per instruction
+        const int sb = steps_of(b);
+        const int dwords = n_ref * (int)(sizeof(R) / 4);  // per env
+        R *dst = refb + (size_t)(b % 3) * D * BLOCK * n_ref;
+        for (int s = 0; s < D; ++s) {
+            const int row = s < sb ? s : sb - 1;
+            const unsigned char *src = reinterpret_cast<const unsigned char *>(a.refs + (((int64_t)b * D + row) * N + blk0) * n_ref);
+            for (int i = 0; i < dwords; ++i)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + i * 256 + tid * 4),
+                                                 (void __attribute__((address_space(3))) *)(reinterpret_cast<unsigned char *>(dst + (size_t)s * BLOCK * n_ref) + i * 256),
+                                                 4, 0, 0);
+        }
+    };
     if (wave == 0) {
         // ------------------------------------------------------------------ integrator
         R y[ND];
@@ -1446,51 +1492,6 @@ __global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KA
         const bool auto_reset = P.auto_reset != 0;
         uint32_t bad_action = 0;
 
-        // Action staging: global memory -> LDS DIRECTLY (`global_load_lds_dword`: each lane's dword lands at M0 + 4 * lane, no VGPR
-        // destination), one block ahead, double-buffered.  Staging through registers instead put up to D*NACT pending-load VGPRs
-        // into the unrolled steps, and whenever the register allocator placed one of them next to an operand of a packed
-        // instruction (v_pk_* read register PAIRS) the compiler had to insert `s_waitcnt vmcnt(0)` in the middle of the block
-        // (measured 150 -> 164 us per 500-step launch).  The integrator reads its action of a step from LDS one step ahead.
-        constexpr int ABYTES = DISCRETE ? 1 : NACT * (int)sizeof(R);
-        constexpr int ROWB = BLOCK * ABYTES;  // bytes of one 64-env action row (contiguous in the [K][N][A] tensor)
-        constexpr int DP = ROWB == 64 ? (D + 3) / 4 * 4 : D;  // rows per buffer half (uint8 rows are staged four at a time)
-        auto stage_actions = [&](int b) {
-            const int sb = steps_of(b);
-            unsigned char *dst = actb + (size_t)(b & 1) * DP * ROWB;
-            const unsigned char *src = a.actions + ((int64_t)b * D * N + blk0) * ABYTES;
-            if (ROWB == 64) {  // uint8 actions: 16 lanes cover a row, so one instruction stages four rows
-#pragma unroll
-                for (int j = 0; j < (D + 3) / 4; ++j) {
-                    int row = 4 * j + (tid >> 4);
-                    row = row < sb ? row : sb - 1;  // tail block: re-read the last valid row
-                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + (int64_t)row * N + (tid & 15) * 4),
-                                                     (void __attribute__((address_space(3))) *)(dst + (size_t)j * 256), 4, 0, 0);
-                }
-            } else {  // ROWB is a multiple of 256 bytes: each instruction moves 64 consecutive dwords of a row
-#pragma unroll
-                for (int s = 0; s < D; ++s) {
-                    const int row = s < sb ? s : sb - 1;
-#pragma unroll
-                    for (int i = 0; i < ROWB / 256; ++i)
-                        __builtin_amdgcn_global_load_lds(
-                            (const void __attribute__((address_space(1))) *)(src + (int64_t)row * N * ABYTES + i * 256 + tid * 4),
-                            (void __attribute__((address_space(3))) *)(dst + (size_t)s * ROWB + i * 256), 4, 0, 0);
-                }
-            }
-        };
-        auto stage_refs = [&](int b) {  // rows of 64 * n_ref references, 64 consecutive dwords per instruction
-            const int sb = steps_of(b);
-            const int dwords = n_ref * (int)(sizeof(R) / 4);  // per env
-            R *dst = refb + (size_t)(b % 3) * D * BLOCK * n_ref;
-            for (int s = 0; s < D; ++s) {
-                const int row = s < sb ? s : sb - 1;
-                const unsigned char *src = reinterpret_cast<const unsigned char *>(a.refs + (((int64_t)b * D + row) * N + blk0) * n_ref);
-                for (int i = 0; i < dwords; ++i)
-                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + i * 256 + tid * 4),
-                                                     (void __attribute__((address_space(3))) *)(reinterpret_cast<unsigned char *>(dst + (size_t)s * BLOCK * n_ref) + i * 256),
-                                                     4, 0, 0);
-            }
-        };
         auto read_action = [&](int b, int s, R (&dst)[NACT], uint32_t &ddst) {
             const unsigned char *row = actb + ((size_t)(b & 1) * DP + s) * ROWB;
             if (DISCRETE) ddst = row[tid];
@@ -1550,13 +1551,22 @@ __global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KA
         };
         stage_actions(0);
         if (n_ref > 0) stage_refs(0);
+#ifdef GEMX_TIMING
+        unsigned long long tv = 0, tc = 0, tw = 0, T0 = clock64(), W0 = wall_clock64(), t0, t0b, t1, t2;
+#endif
         for (int b = 0; b < nb; ++b) {
+#ifdef GEMX_TIMING
+            t0 = clock64();
+#endif
             const int sb = steps_of(b);
             R *hb = hand + (size_t)(b & 1) * D * BLOCK * NHT + (size_t)tid * NHT;
             // block b's actions (and, the first time, the state) have landed: staged a whole block ago.  Only THEN issue the next
             // block's staging loads -- they go to the other half of the buffer, which nobody reads during this block.
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-            if (b + 1 < nb) {
+#ifdef GEMX_TIMING
+            t0b = clock64();
+#endif
+            if (LW == 0 && b + 1 < nb) {
                 stage_actions(b + 1);
                 if (n_ref > 0) stage_refs(b + 1);
             }
@@ -1583,8 +1593,21 @@ __global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KA
                     one_step(std::true_type{}, ac, dc, hb + (size_t)s * BLOCK * NHT);
                 }
             }
+#ifdef GEMX_TIMING
+            t1 = clock64();
+#endif
             __syncthreads();  // publishes hand-off block b; wave 1 is done reading block b-1 (other half)
+#ifdef GEMX_TIMING
+            t2 = clock64();
+            tv += t0b - t0; tc += t1 - t0b; tw += t2 - t1;
+#endif
         }
+#ifdef GEMX_TIMING
+        if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 37)) {
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64) + (blockIdx.x ? 16 : 0);
+            dbg[0] = tv; dbg[1] = tc; dbg[2] = tw; dbg[3] = clock64() - T0; dbg[4] = wall_clock64() - W0; dbg[5] = nb;
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < ND; ++j) a.state[(int64_t)j * N + env] = y[j];
         if (HAS_ANGLE) a.angle[env] = ang;
@@ -1602,6 +1625,38 @@ __global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KA
             }
         }
         if (bad_action) atomicOr(a.err, 1u);
+    } else if (LW != 0 && wave == 1 + OW) {
+        // ------------------------------------------------------------------ loader
+        // The staging loads of block b+1 are issued and awaited HERE while the integrator works on block b.  Issued by the
+        // integrator they queue, in the CU's vector-memory path, behind the output waves' observation stores, and the integrator
+        // -- the one wave whose instruction stream sets the launch time at small N -- stalled at their issue for ~1300 of its
+        // ~7600 cycles per 12-step block (s_memtime probe, 16384 envs; profiles/r01f_pipe_probe.md).
+#ifdef GEMX_TIMING
+        unsigned long long tl = 0, tb = 0;
+#endif
+        for (int b = 0; b < nb; ++b) {
+#ifdef GEMX_TIMING
+            const unsigned long long l0 = clock64();
+#endif
+            if (b + 1 < nb) {
+                stage_actions(b + 1);
+                if (n_ref > 0) stage_refs(b + 1);
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): landed in LDS before the barrier publishes it
+            }
+#ifdef GEMX_TIMING
+            const unsigned long long l1 = clock64();
+#endif
+            __syncthreads();
+#ifdef GEMX_TIMING
+            tl += l1 - l0; tb += clock64() - l1;
+#endif
+        }
+#ifdef GEMX_TIMING
+        if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 37)) {
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64) + (blockIdx.x ? 16 : 0);
+            dbg[12] = tl; dbg[13] = tb;
+        }
+#endif
     } else {
         // ------------------------------------------------------------------ output + stores
         const bool aos = P.obs_layout == GEMX_OBS_AOS;
@@ -1681,11 +1736,29 @@ __global__ __launch_bounds__((1 + OW) * BLOCK) void advance_pipe_kernel(const KA
             flush_rings<NOUT, R>(a, ring + (size_t)r0 * BLOCK * NOUT, donebuf + (size_t)r0 * BLOCK, pb * D + r0, nr, tid, blk0, BLOCK, true,
                                  true, env);
         };
+#ifdef GEMX_TIMING
+        unsigned long long tp = 0, tq = 0;
+#endif
         for (int b = 0; b < nb; ++b) {
+#ifdef GEMX_TIMING
+            const unsigned long long q0 = clock64();
+#endif
             if (b >= 1) process(b - 1);
+#ifdef GEMX_TIMING
+            const unsigned long long q1 = clock64();
+#endif
             __syncthreads();
+#ifdef GEMX_TIMING
+            tp += q1 - q0; tq += clock64() - q1;
+#endif
         }
         process(nb - 1);
+#ifdef GEMX_TIMING
+        if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 37)) {
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64) + (blockIdx.x ? 16 : 0);
+            dbg[6 + 2 * (wave - 1)] = tp; dbg[7 + 2 * (wave - 1)] = tq;
+        }
+#endif
     }
 }
 
@@ -1796,7 +1869,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         };
         auto resident = [&](int D, int OW) {
             int64_t w = (int64_t)(h->lds_max / smem_of(D));
-            const int64_t wmax = 32 / (1 + OW);
+            const int64_t wmax = 32 / (1 + OW + pipe_loader_waves(D));
             return (w > wmax ? wmax : w) * (int64_t)h->n_cu;
         };
         // one resident round of the 4-wave shape if N is that small, else the 3-wave shape at ANY N: measured at 131072 and 1048576
@@ -1816,9 +1889,10 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                 GEMX_HIP_TRY(hipFuncSetAttribute((const void *)pkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max));
                 pattr_set[D == PIPE_D] = true;
             }
-            hipLaunchKernelGGL(pkern, dim3((unsigned)blocks), dim3((1 + OW) * BLOCK), psmem, st, a);
+            const int threads = (1 + OW + pipe_loader_waves(D)) * BLOCK;
+            hipLaunchKernelGGL(pkern, dim3((unsigned)blocks), dim3(threads), psmem, st, a);
             GEMX_HIP_TRY(hipGetLastError());
-            h->ll = {1, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), D, (1 + OW) * BLOCK, K, D, (long long)blocks, psmem};
+            h->ll = {1, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), D, threads, K, D, (long long)blocks, psmem};
             return GEMX_OK;
         }
     }

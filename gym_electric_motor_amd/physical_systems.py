@@ -74,6 +74,19 @@ class SquaredConstraint:
         self.states = tuple(states)
 
 
+def _device_index(device):
+    """GPU ordinal from 0, "0", "cuda", "cuda:1" or a torch.device."""
+    if isinstance(device, int):
+        return device
+    name = str(device)
+    if name.isdigit():
+        return int(name)
+    kind, _, idx = name.partition(":")
+    if kind != "cuda":
+        raise ValueError(f"device must be a GPU ordinal or 'cuda[:i]' (there is no CPU path), got {device!r}")
+    return int(idx) if idx else 0
+
+
 class BatchedSCMLSystem(_PhysicalSystemBase):
     """N independent Supply-Converter-Motor-Load systems stepped in lockstep on one MI355X."""
 
@@ -128,7 +141,7 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         self._ode_solver = ode_solver
         self.control_space = control_space
         self._n_envs = int(n_envs)
-        self._device = int(device)
+        self._device = _device_index(device)
         self._dtype_name = {"float32": "float32", "float64": "float64", "f32": "float32", "f64": "float64"}[str(dtype).replace("torch.", "")]
         self._obs_layout = obs_layout
         # line 83: load.set_j_rotor(j_rotor).  The reference's set_j_rotor ADDS to j_total (mechanical_load.py:188-193),

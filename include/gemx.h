@@ -153,6 +153,9 @@ typedef struct gemx_handle gemx_handle;
 int gemx_abi_version(void);
 int gemx_sizeof_config(void);
 const char *gemx_last_error(void);
+/* Diagnostics: per-wave cycle counts of the pipelined kernel's last launch (integrator / output / loader waves of workgroups 0 and
+ * 37), filled only by a library compiled with -DGEMX_TIMING (all zeros otherwise); read by tools/pipe_timing_probe.py. */
+int gemx_debug_read(gemx_handle *h, unsigned long long *out, int n);
 /* number of visible HIP devices (0 => the library cannot run; callers must fail loudly) */
 int gemx_device_count(void);
 

@@ -1,0 +1,33 @@
+"""Scratch probe (needs a -DGEMX_TIMING build): per-wave cycle breakdown of the pipelined kernel."""
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import gym_electric_motor_amd as ga
+from gym_electric_motor_amd import _lib
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+env_id = sys.argv[3] if len(sys.argv) > 3 else "Finite-CC-PMSM-v0"
+env = ga.make(env_id, n_envs=n, device="cuda:0", ode_solver=ga.RK4Solver(), tau=1e-4)
+ps = env.physical_system
+env.reset()
+if "Finite" in env_id:
+    act = torch.randint(0, 8, (K, n), dtype=torch.uint8, device="cuda:0")
+else:
+    act = torch.rand((K, n, 3), device="cuda:0") * 2 - 1
+for _ in range(5):
+    ps.rollout(act)
+torch.cuda.synchronize()
+L = _lib.load()
+L.gemx_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+buf = (C.c_ulonglong * 32)()
+L.gemx_debug_read(ps._handle, buf, 32)
+print(L.gemx_last_launch(ps._handle))
+for base in (0, 16):
+    tv, tc, tw, tot, wall, nb = buf[base:base + 6]
+    outs = buf[base + 6:base + 12]
+    print(f"blk{'0' if base == 0 else '37'}: nb={nb} total={tot} cyc wall={wall} (100MHz ticks => {wall*10} ns, clock={tot/(wall*10+1e-9):.3f} GHz)")
+    print(f"   integrator per block: vmwait={tv/nb:.0f} compute={tc/nb:.0f} barrier={tw/nb:.0f} cycles")
+    for w in range(3):
+        print(f"   out wave {w}: process={outs[2*w]/nb:.0f} barrier={outs[2*w+1]/nb:.0f}")
+    print(f"   loader: stage+wait={buf[base+12]/nb:.0f} barrier={buf[base+13]/nb:.0f}")
