@@ -114,9 +114,19 @@ template <> struct Angle<float> {
     }
     static __device__ __forceinline__ float wrapped(T a) { return (float)a * kRadPerCount; }  // [-pi, pi]
     static __device__ __forceinline__ float to_rad(T a) { return wrapped(a); }
-    // sin/cos of a fixed-point angle: quadrant from the top bits, Cephes single-precision minimax
-    // polynomials on [-pi/4, pi/4] (abs error < 1.2e-7); ~20 VALU ops for both, no range-reduction branches.
+    // sin/cos of a fixed-point angle with the hardware's V_SIN_F32 / V_COS_F32, whose argument is in REVOLUTIONS: the count times
+    // 2^-32 is the argument, no range reduction at all.  Measured on gfx950 over 2^22 angles (tools/microbench_hwsin.hip): max abs
+    // error 1.8e-7 for both, i.e. that of the single-precision minimax polynomials used before (1.2e-7, ~28 VALU instructions with
+    // the quadrant logic) at 4 instructions -- two of them quarter-rate.
+    // Its errors are not centred, though (mean s^2+c^2-1 = -6.4e-8 against -1e-9, rms 4.5e-8 against 2.4e-8), and the doubly fed
+    // induction motor system, whose field-oriented transforms amplify angle noise ~1000x, keeps the polynomials (sincos_precise).
     static __device__ __forceinline__ void sincos(T a, float &s, float &c) {
+        const float x = (float)a * 2.3283064365386963e-10f;  // [-0.5, 0.5) revolutions
+        s = __builtin_amdgcn_sinf(x);
+        c = __builtin_amdgcn_cosf(x);
+    }
+    // quadrant from the top bits, Cephes single-precision minimax polynomials on [-pi/4, pi/4] (abs error < 1.2e-7)
+    static __device__ __forceinline__ void sincos_precise(T a, float &s, float &c) {
         uint32_t ua = (uint32_t)a + 0x20000000u;                    // + 1/8 turn
         uint32_t q = ua >> 30;                                      // quadrant 0..3
         int32_t r = (int32_t)(ua & 0x3FFFFFFFu) - 0x20000000;       // [-2^29, 2^29) counts == [-pi/4, pi/4)
@@ -146,6 +156,7 @@ template <> struct Angle<double> {
     }
     static __device__ __forceinline__ double to_rad(T a) { return a; }
     static __device__ __forceinline__ void sincos(T a, double &s, double &c) { ::sincos(a, &s, &c); }
+    static __device__ __forceinline__ void sincos_precise(T a, double &s, double &c) { ::sincos(a, &s, &c); }
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -246,7 +246,8 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
     if (LIN) {
         constexpr int NG = E::NG;
         R g[NG], x[NM];
-        E::get_b(E::prep(P, y[0], u), g);
+        const R om = P.init[0];  // == y[0] in every lane (lin_usable); wave-uniform, so everything derived from it is loop-invariant
+        E::get_b(E::prep(P, om, u), g);
 #pragma unroll
         for (int i = 0; i < NM; ++i) x[i] = y[1 + i];
         for (int s = 0; s < ns; ++s) {
@@ -265,7 +266,7 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
         }
 #pragma unroll
         for (int i = 0; i < NM; ++i) y[1 + i] = x[i];
-        return P.pole * y[0] * h;
+        return P.pole * om * h;
     }
     if (LOAD == GEMX_LOAD_CONST_SPEED) {
         // omega is constant (constant_speed_load.py:40-42): integrate the electrical states only; every scheme's
@@ -722,7 +723,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
                                                    uint32_t dact, R (&ho)[NH]) {
         R sf, cf, se, ce;
         SC::field_angle(y[3], y[4], sf, cf);
-        Angle<R>::sincos(ang, se, ce);
+        Angle<R>::sincos_precise(ang, se, ce);
         uint32_t legs = 0;
         bool two = false;
         if (IL && CONV == GEMX_CONV_FINITE_2XB6) {  // flat action = a_stator + 8 * a_rotor; 6 half-bridges, 2 bits each
@@ -752,7 +753,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             segment(two ? P.t_il : P.tau);
             if (two) {
                 SC::field_angle(y[3], y[4], sf, cf);  // lines 978-979
-                Angle<R>::sincos(ang, se, ce);
+                Angle<R>::sincos_precise(ang, se, ce);
                 segment(P.tau - P.t_il);
             }
         } else {
