@@ -24,7 +24,7 @@ STAMP = LIB + ".sha256"  # next to the library (the object directory does not tr
 
 # (system_kind, converter_kind) pairs on the accelerated path; each for fp32 (0) and fp64 (1)
 UNITS = [(0, 0), (1, 1), (1, 2), (2, 1), (2, 2), (0, 3), (3, 0), (3, 3), (4, 0), (4, 3), (5, 4), (5, 5), (6, 6), (6, 7), (7, 8), (7, 9), (1, 10), (2, 10), (6, 11)]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-Wno-unused-variable"]
 
 
 def hipcc_path():

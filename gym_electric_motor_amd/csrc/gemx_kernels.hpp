@@ -983,6 +983,100 @@ __device__ __forceinline__ void flush_rings(const KArgs<R> &a, const R *ring, co
     }
 }
 
+// The pipelined kernel's output waves, full blocks: the same RPW rows (AoS, 16-byte aligned, full 64-env workgroup) with ALL their LDS
+// reads issued before the first store and wave-uniform row addresses (k0 must be uniform).  flush_rings' per-row chain -- 3 reads,
+// wait, 3 stores, a predicated 4th read, wait, store -- exposes the LDS latency twice per row: ~380 cycles per row on an otherwise idle
+// chip, where the stores themselves issue at 23 cycles each (tools/microbench_store.hip).  Lanes past the end of a row's last,
+// partial chunk repeat the row's final chunk (same address, same data) instead of branching around the store.
+template <int NOUT, int RPW, class R>
+__device__ __forceinline__ void flush_rows_pipe(const KArgs<R> &a, const R *ring, const unsigned char *donebuf, int k0, int tid, int64_t blk0) {
+    constexpr int VEC = 16 / sizeof(R);
+    constexpr int ROWV = BLOCK * NOUT / VEC;            // 16-byte chunks per row
+    constexpr int NV = (ROWV + BLOCK - 1) / BLOCK;      // chunks per lane
+    static_assert((BLOCK * NOUT) % VEC == 0, "rows are whole 16-byte chunks");
+    using V = typename std::conditional<sizeof(R) == 4, float4, double2>::type;
+    const int64_t N = a.N;
+    // (named variables, not arrays: the optimiser puts a [RPW][NV] array of 16-byte values into scratch memory, and the scratch
+    // loads' vmcnt(0) then waits for every observation store in flight)
+    static_assert(RPW <= 4 && NV <= 6, "flush_rows_pipe: named buffers");
+    auto chunk = [&](int i) { const int c = tid + i * BLOCK; return c > ROWV - 1 ? ROWV - 1 : c; };
+    const int c0 = chunk(0), c1 = chunk(1), c2 = chunk(2), c3 = chunk(3), c4 = chunk(4), c5 = chunk(5);
+    const V *lv = reinterpret_cast<const V *>(ring);
+    constexpr int RS = BLOCK * NOUT / VEC;  // chunks per ring row
+    V b00, b01, b02, b03, b04, b05;
+    V b10, b11, b12, b13, b14, b15;
+    V b20, b21, b22, b23, b24, b25;
+    V b30, b31, b32, b33, b34, b35;
+    if constexpr (0 < RPW && 0 < NV) b00 = lv[0 * RS + c0];
+    if constexpr (0 < RPW && 1 < NV) b01 = lv[0 * RS + c1];
+    if constexpr (0 < RPW && 2 < NV) b02 = lv[0 * RS + c2];
+    if constexpr (0 < RPW && 3 < NV) b03 = lv[0 * RS + c3];
+    if constexpr (0 < RPW && 4 < NV) b04 = lv[0 * RS + c4];
+    if constexpr (0 < RPW && 5 < NV) b05 = lv[0 * RS + c5];
+    if constexpr (1 < RPW && 0 < NV) b10 = lv[1 * RS + c0];
+    if constexpr (1 < RPW && 1 < NV) b11 = lv[1 * RS + c1];
+    if constexpr (1 < RPW && 2 < NV) b12 = lv[1 * RS + c2];
+    if constexpr (1 < RPW && 3 < NV) b13 = lv[1 * RS + c3];
+    if constexpr (1 < RPW && 4 < NV) b14 = lv[1 * RS + c4];
+    if constexpr (1 < RPW && 5 < NV) b15 = lv[1 * RS + c5];
+    if constexpr (2 < RPW && 0 < NV) b20 = lv[2 * RS + c0];
+    if constexpr (2 < RPW && 1 < NV) b21 = lv[2 * RS + c1];
+    if constexpr (2 < RPW && 2 < NV) b22 = lv[2 * RS + c2];
+    if constexpr (2 < RPW && 3 < NV) b23 = lv[2 * RS + c3];
+    if constexpr (2 < RPW && 4 < NV) b24 = lv[2 * RS + c4];
+    if constexpr (2 < RPW && 5 < NV) b25 = lv[2 * RS + c5];
+    if constexpr (3 < RPW && 0 < NV) b30 = lv[3 * RS + c0];
+    if constexpr (3 < RPW && 1 < NV) b31 = lv[3 * RS + c1];
+    if constexpr (3 < RPW && 2 < NV) b32 = lv[3 * RS + c2];
+    if constexpr (3 < RPW && 3 < NV) b33 = lv[3 * RS + c3];
+    if constexpr (3 < RPW && 4 < NV) b34 = lv[3 * RS + c4];
+    if constexpr (3 < RPW && 5 < NV) b35 = lv[3 * RS + c5];
+    if constexpr (0 < RPW) {
+        V *gv = reinterpret_cast<V *>(a.obs + ((int64_t)(k0 + 0) * N + blk0) * NOUT);
+        if constexpr (0 < NV) gv[c0] = b00;
+        if constexpr (1 < NV) gv[c1] = b01;
+        if constexpr (2 < NV) gv[c2] = b02;
+        if constexpr (3 < NV) gv[c3] = b03;
+        if constexpr (4 < NV) gv[c4] = b04;
+        if constexpr (5 < NV) gv[c5] = b05;
+    }
+    if constexpr (1 < RPW) {
+        V *gv = reinterpret_cast<V *>(a.obs + ((int64_t)(k0 + 1) * N + blk0) * NOUT);
+        if constexpr (0 < NV) gv[c0] = b10;
+        if constexpr (1 < NV) gv[c1] = b11;
+        if constexpr (2 < NV) gv[c2] = b12;
+        if constexpr (3 < NV) gv[c3] = b13;
+        if constexpr (4 < NV) gv[c4] = b14;
+        if constexpr (5 < NV) gv[c5] = b15;
+    }
+    if constexpr (2 < RPW) {
+        V *gv = reinterpret_cast<V *>(a.obs + ((int64_t)(k0 + 2) * N + blk0) * NOUT);
+        if constexpr (0 < NV) gv[c0] = b20;
+        if constexpr (1 < NV) gv[c1] = b21;
+        if constexpr (2 < NV) gv[c2] = b22;
+        if constexpr (3 < NV) gv[c3] = b23;
+        if constexpr (4 < NV) gv[c4] = b24;
+        if constexpr (5 < NV) gv[c5] = b25;
+    }
+    if constexpr (3 < RPW) {
+        V *gv = reinterpret_cast<V *>(a.obs + ((int64_t)(k0 + 3) * N + blk0) * NOUT);
+        if constexpr (0 < NV) gv[c0] = b30;
+        if constexpr (1 < NV) gv[c1] = b31;
+        if constexpr (2 < NV) gv[c2] = b32;
+        if constexpr (3 < NV) gv[c3] = b33;
+        if constexpr (4 < NV) gv[c4] = b34;
+        if constexpr (5 < NV) gv[c5] = b35;
+    }
+    if (a.done != nullptr) {  // done rows are 64 contiguous bytes: 4 x 16-byte chunks per row
+        static_assert(RPW * (BLOCK / 16) <= BLOCK, "one pass");
+        if (tid < RPW * (BLOCK / 16)) {
+            const int row = tid >> 2, col = tid & 3;
+            *reinterpret_cast<uint4 *>(a.done + (int64_t)(k0 + row) * N + blk0 + col * 16) =
+                *reinterpret_cast<const uint4 *>(donebuf + row * BLOCK + col * 16);
+        }
+    }
+}
+
 // Fused reward (WeightedSumOfErrors.reward, weighted_sum_of_errors.py:125-129) of staged observation rows of one 64-env
 // workgroup, from the LDS ring and the caller's reference tensor.  One lane = one env.  Two halves, so that the reference
 // loads can be issued long before they are needed (their latency is never on the critical path):
@@ -1395,7 +1489,9 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
     constexpr int NHT = ND + (HAS_ANGLE ? 1 : 0) + NH + 1;  // hand-off row: y, angle bits, ho, done
 
     const DevParams<R> &P = a.P;
-    const int wave = threadIdx.x >> 6;
+    // readfirstlane: the wave index is wave-uniform, but the compiler cannot know that of a value derived from threadIdx -- without
+    // it every row address of the output waves (k0 = pb * D + ow * RPW) is 64-bit per-lane VALU arithmetic (v_mad_u64_u32 chains)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int tid = threadIdx.x & (BLOCK - 1);
     const int64_t blk0 = (int64_t)blockIdx.x * BLOCK;
     const int64_t env = blk0 + tid;
@@ -1699,6 +1795,9 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             return sb - r0 < RPW ? (sb - r0 < 0 ? 0 : sb - r0) : RPW;
         };
 
+#ifdef GEMX_TIMING
+        unsigned long long tflush = 0;
+#endif
         auto process = [&](int pb) {
             const int nr = rows_of(pb);
             if (nr <= 0) return;
@@ -1720,6 +1819,9 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                     }
                 }
             }
+#ifdef GEMX_TIMING
+            const unsigned long long f0 = clock64();
+#endif
             if (a.rw != nullptr) {
                 // this block's references are in LDS (staged by the integrator wave); the description is (re)read from the scalar
                 // cache once per block, so that its ~25 SGPRs are live only here
@@ -1734,8 +1836,12 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                 }
                 reward_apply<NOUT, RPW, R>(a, WR, ring, donebuf, pb * D + r0, r0, nr, tid, env, true, rv);
             }
-            flush_rings<NOUT, R>(a, ring + (size_t)r0 * BLOCK * NOUT, donebuf + (size_t)r0 * BLOCK, pb * D + r0, nr, tid, blk0, BLOCK, true,
-                                 true, env);
+            if (aos && nr == RPW) flush_rows_pipe<NOUT, RPW, R>(a, ring + (size_t)r0 * BLOCK * NOUT, donebuf + (size_t)r0 * BLOCK, pb * D + r0, tid, blk0);
+            else flush_rings<NOUT, R>(a, ring + (size_t)r0 * BLOCK * NOUT, donebuf + (size_t)r0 * BLOCK, pb * D + r0, nr, tid, blk0, BLOCK, true,
+                                      true, env);
+#ifdef GEMX_TIMING
+            tflush += clock64() - f0;
+#endif
         };
 #ifdef GEMX_TIMING
         unsigned long long tp = 0, tq = 0;
@@ -1758,6 +1864,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
         if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 37)) {
             unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64) + (blockIdx.x ? 16 : 0);
             dbg[6 + 2 * (wave - 1)] = tp; dbg[7 + 2 * (wave - 1)] = tq;
+            if (wave == 1) dbg[14] = tflush;
         }
 #endif
     }

@@ -28,6 +28,7 @@ for base in (0, 16):
     outs = buf[base + 6:base + 12]
     print(f"blk{'0' if base == 0 else '37'}: nb={nb} total={tot} cyc wall={wall} (100MHz ticks => {wall*10} ns, clock={tot/(wall*10+1e-9):.3f} GHz)")
     print(f"   integrator per block: vmwait={tv/nb:.0f} compute={tc/nb:.0f} barrier={tw/nb:.0f} cycles")
-    for w in range(3):
+    for w in range(3):  # (first three output waves)
         print(f"   out wave {w}: process={outs[2*w]/nb:.0f} barrier={outs[2*w+1]/nb:.0f}")
+    print(f"   out wave 0: of which reward + flush={buf[base+14]/nb:.0f}")
     print(f"   loader: stage+wait={buf[base+12]/nb:.0f} barrier={buf[base+13]/nb:.0f}")
