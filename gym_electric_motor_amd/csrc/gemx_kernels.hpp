@@ -411,6 +411,7 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
     static constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NC = ND - 1;
     static constexpr int NU = SYS == GEMX_SYS_DC_EXTEX ? 2 : 1;  // converter output voltages
     static constexpr int NH = NU;                                // ho: u [V]
+    static constexpr int NVT = 0;                                // no per-action voltage table (see the synchronous machines)
     static constexpr bool CONT = CONV == GEMX_CONV_CONT_4QC || CONV == GEMX_CONV_CONT_2X4QC;
     static_assert((CONV == GEMX_CONV_CONT_2X4QC || CONV == GEMX_CONV_FINITE_2X4QC) == (NU == 2), "system / converter width mismatch");
     // i_in = motor.i_in(currents): the current (dc_permanently_excited_motor.py:77-79, dc_series_motor.py:85-87),
@@ -420,9 +421,9 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
         if (SYS == GEMX_SYS_DC_EXTEX) return y[1 + j];
         return SYS == GEMX_SYS_DC_SHUNT ? y[1] + y[ND - 1] : y[1];
     }
-    template <bool NS1 = false, bool LIN = false>
+    template <bool NS1 = false, bool LIN = false, bool TAB = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[ND], AngT &, uint32_t &sw, const R (&act)[MAX_ACT], uint32_t dact,
-                                                   R (&ho)[NH]) {
+                                                   R (&ho)[NH], const R * = nullptr) {
         R u[MAX_U] = {R(0), R(0), R(0), R(0)};
         if (CONT) {
 #pragma unroll
@@ -512,9 +513,19 @@ struct Stepper<GEMX_SYS_DC_EXTEX, CONV, LOAD, SOLVER, IL, R> : DcStepper<GEMX_SY
 template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_SYNC, CONV, LOAD, SOLVER, IL, R> {
     using AngT = typename Angle<R>::T;
     static constexpr int NH = 7;  // ho: sin, cos of the last segment-start angle, u_a, u_b, u_c, u_sd, u_sq
-    template <bool NS1 = false, bool LIN = false>
+    // Finite-B6C without dead time and with an ideal supply: the bridge's output is a function of the action index alone, so the
+    // pipelined kernel keeps it in an 8-entry LDS table (u_a, u_b, u_c, u_alpha, u_beta per switching state), computed ONCE per launch
+    // with the very code below, instead of decoding the action and Clarke-transforming it in every step.
+    static constexpr int NVT = (CONV == GEMX_CONV_FINITE_B6 && !IL) ? 5 : 0;
+    static __device__ __forceinline__ void action_entry(const DevParams<R> &P, uint32_t dact, R (&e)[8]) {
+        const R zero[MAX_ACT] = {R(0), R(0), R(0), R(0), R(0), R(0)};
+        b6_voltages<CONV, false, R>(P, zero, dact, 0u, R(0), R(0), R(0), e[0], e[1], e[2]);
+        t23(e[0], e[1], e[2], e[3], e[4]);
+        e[5] = e[6] = e[7] = R(0);
+    }
+    template <bool NS1 = false, bool LIN = false, bool TAB = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[3], AngT &ang, uint32_t &sw, const R (&act)[MAX_ACT],
-                                                   uint32_t dact, R (&ho)[NH]) {
+                                                   uint32_t dact, R (&ho)[NH], const R *tab = nullptr) {
         R s, c;
         Angle<R>::sincos(ang, s, c);
         uint32_t legs = 0;
@@ -531,9 +542,13 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
                 const R ial = c * y[1] - s * y[2], ibe = s * y[1] + c * y[2];
                 t32(ial, ibe, ia, ib, ic);
             }
-            b6_voltages<CONV, IL, R>(P, act, dact, legs, ia, ib, ic, ua, ub, uc);
             R ual, ube;
-            t23(ua, ub, uc, ual, ube);
+            if (TAB) {  // this action's table entry (action_entry)
+                ua = tab[0]; ub = tab[1]; uc = tab[2]; ual = tab[3]; ube = tab[4];
+            } else {
+                b6_voltages<CONV, IL, R>(P, act, dact, legs, ia, ib, ic, ua, ub, uc);
+                t23(ua, ub, uc, ual, ube);
+            }
             u[0] = c * ual + s * ube;  // Q^-1(., eps): u_dq frozen at the segment-start angle (line 501/511)
             u[1] = -s * ual + c * ube;
             const R deps = integrate<GEMX_SYS_SYNC, LOAD, SOLVER, R, NS1, LIN>(P, y, u, h);
@@ -586,10 +601,11 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
 template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_EESM, CONV, LOAD, SOLVER, IL, R> {
     using AngT = typename Angle<R>::T;
     static constexpr int NH = 8;  // ho: sin, cos of the step-start angle, u_a, u_b, u_c, u_sd, u_sq, u_e
+    static constexpr int NVT = 0;
     static constexpr int B6 = CONV == GEMX_CONV_CONT_B6_4QC ? GEMX_CONV_CONT_B6 : GEMX_CONV_FINITE_B6;
-    template <bool NS1 = false, bool LIN = false>
+    template <bool NS1 = false, bool LIN = false, bool TAB = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[4], AngT &ang, uint32_t &, const R (&act)[MAX_ACT],
-                                                   uint32_t dact, R (&ho)[NH]) {
+                                                   uint32_t dact, R (&ho)[NH], const R * = nullptr) {
         R s, c;
         Angle<R>::sincos(ang, s, c);
         R ua, ub, uc, ue, u[MAX_U] = {R(0), R(0), R(0), R(0)};
@@ -646,10 +662,11 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
 template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_SCIM, CONV, LOAD, SOLVER, IL, R> {
     using AngT = typename Angle<R>::T;
     static constexpr int NH = 7;  // ho: sin, cos of the last segment-start field angle, u_a, u_b, u_c, u_alpha, u_beta
+    static constexpr int NVT = 0;
     static __device__ __forceinline__ void field_angle(R pa, R pb, R &s, R &c) { flux_angle<R>(pa, pb, s, c); }
-    template <bool NS1 = false, bool LIN = false>
+    template <bool NS1 = false, bool LIN = false, bool TAB = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[5], AngT &ang, uint32_t &sw, const R (&act)[MAX_ACT],
-                                                   uint32_t dact, R (&ho)[NH]) {
+                                                   uint32_t dact, R (&ho)[NH], const R * = nullptr) {
         R s, c;
         field_angle(y[3], y[4], s, c);
         uint32_t legs = 0;
@@ -717,10 +734,11 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     // ho: sin, cos of the last segment-start field angle; sin, cos of the last segment-start electrical angle;
     //     u_sa, u_sb, u_sc; u_rd, u_re, u_rf (rotor-fixed three-phase frame)
     static constexpr int NH = 10;
+    static constexpr int NVT = 0;
     static constexpr int B6 = CONV == GEMX_CONV_CONT_2XB6 ? GEMX_CONV_CONT_B6 : GEMX_CONV_FINITE_B6;
-    template <bool NS1 = false, bool LIN = false>
+    template <bool NS1 = false, bool LIN = false, bool TAB = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[5], AngT &ang, uint32_t &sw, const R (&act)[MAX_ACT],
-                                                   uint32_t dact, R (&ho)[NH]) {
+                                                   uint32_t dact, R (&ho)[NH], const R * = nullptr) {
         R sf, cf, se, ce;
         SC::field_angle(y[3], y[4], sf, cf);
         Angle<R>::sincos_precise(ang, se, ce);
@@ -1514,6 +1532,9 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
     constexpr int ACTB_BYTES = 2 * ((D + 3) / 4 * 4) * BLOCK * (DISCRETE ? 1 : NACT * (int)sizeof(R));
     R *refb = reinterpret_cast<R *>(actb + ACTB_BYTES);
     const int n_ref = a.rw != nullptr ? a.rw->n_ref : 0;
+    // per-action voltage table [NACTIONS][8] R of steppers that have one (ST::NVT > 0), read by the integrator wave only
+    constexpr bool USE_TAB = ST::NVT > 0 && DISCRETE;
+    R *vtab = refb + 3 * (size_t)D * BLOCK * n_ref;
     auto steps_of = [&](int b) { return (K - b * D) < D ? (K - b * D) : D; };
 
     // Action staging: global memory -> LDS DIRECTLY (`global_load_lds_dword`: each lane's dword lands at M0 + 4 * lane, no VGPR
@@ -1588,6 +1609,14 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
         const bool check_default = P.constr_kind == 1;
         const bool auto_reset = P.auto_reset != 0;
         uint32_t bad_action = 0;
+        if constexpr (USE_TAB) {  // (written and read by this wave only: LDS operations of one wave complete in order)
+            if (tid < ConvTraits<CONV>::NACTIONS) {
+                R e[8];
+                ST::action_entry(P, (uint32_t)tid, e);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vtab[tid * 8 + j] = e[j];
+            }
+        }
 
         auto read_action = [&](int b, int s, R (&dst)[NACT], uint32_t &ddst) {
             const unsigned char *row = actb + ((size_t)(b & 1) * DP + s) * ROWB;
@@ -1599,8 +1628,9 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
         };
         // `fifo_possible` (a std::bool_constant): false_type compiles the DeadTimeProcessor queue out, so that the fully
         // unrolled blocks of the common case stay ONE branch-free basic block; true_type keeps the wave-uniform run-time test
-        auto one_step = [&](auto fifo_possible, const R (&act_in)[NACT], uint32_t dact, R *row) {
+        auto one_step = [&](auto fifo_possible, const R (&act_in)[NACT], uint32_t dact, R *row, const R *tab) {
             constexpr bool FIFO = decltype(fifo_possible)::value;
+            constexpr bool TAB = USE_TAB && !FIFO;  // the unrolled blocks take the action's table entry
             R act[MAX_ACT];
 #pragma unroll
             for (int i = 0; i < MAX_ACT; ++i) act[i] = i < NACT ? act_in[i] : R(0);
@@ -1622,8 +1652,12 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             if (conv_dq<CONV>() && !P.dq_processor) dq_action_stage<SYS, CONV, R>(P, y, ang, act);
             R ho[NH];
             // launcher guarantees solver_nsteps == 1; LINABLE instantiations take the one-step map whenever it is valid for this wave
-            if (LINABLE && (!FIFO || lin_ok)) ST::template advance<true, LINABLE>(P, y, ang, sw, act, dact, ho);
-            else ST::template advance<true, false>(P, y, ang, sw, act, dact, ho);
+            if constexpr (TAB) {
+                ST::template advance<true, LINABLE, true>(P, y, ang, sw, act, dact, ho, tab);
+            } else {
+                if (LINABLE && (!FIFO || lin_ok)) ST::template advance<true, LINABLE>(P, y, ang, sw, act, dact, ho);
+                else ST::template advance<true, false>(P, y, ang, sw, act, dact, ho);
+            }
             const bool done = ST::state_done(P, y, ho) & check_default;
 #pragma unroll
             for (int j = 0; j < ND; ++j) row[j] = y[j];
@@ -1667,7 +1701,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                 stage_actions(b + 1);
                 if (n_ref > 0) stage_refs(b + 1);
             }
-            R an[NACT], ac[NACT];
+            R an[NACT], ac[NACT] = {};
             uint32_t dn = 0, dc = 0;
 #pragma unroll
             for (int i = 0; i < NACT; ++i) an[i] = R(0);
@@ -1675,19 +1709,44 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             if (sb == D && P.delay == 0 && (!LINABLE || lin_ok)) {
                 // branch-free basic blocks of FOUR steps (unrolling all twelve makes basic blocks of up to ~8000 instructions for the
                 // heavier systems, on which the instruction scheduler's compile time explodes; the run time is the same)
-#pragma unroll 4
-                for (int s = 0; s < D; ++s) {
-                    dc = dn;
+                if constexpr (USE_TAB) {
+                    // two-deep software pipeline: step s runs on table entry ec; the entry of step s+1 and the action of step s+2 are
+                    // in flight (each LDS read has a whole step to land)
+                    constexpr uint32_t AMASK = (uint32_t)(ConvTraits<CONV>::NACTIONS - 1);
+                    auto fetch_entry = [&](uint32_t d, R (&e)[8]) {
+                        const R *src = vtab + (size_t)(d & AMASK) * 8;
 #pragma unroll
-                    for (int i = 0; i < NACT; ++i) ac[i] = an[i];
-                    read_action(b, s + 1 < D ? s + 1 : s, an, dn);  // one step ahead: its LDS latency hides behind this step
-                    one_step(std::false_type{}, ac, dc, hb + (size_t)s * BLOCK * NHT);
+                        for (int j = 0; j < 8; ++j) e[j] = j < ST::NVT ? src[j] : R(0);
+                    };
+                    R en[8], ec[8];
+                    uint32_t dnn = 0;
+                    fetch_entry(dn, en);
+                    read_action(b, 1, an, dnn);
+#pragma unroll 4
+                    for (int s = 0; s < D; ++s) {
+                        dc = dn;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ec[j] = en[j];
+                        dn = dnn;
+                        fetch_entry(dn, en);
+                        read_action(b, s + 2 < D ? s + 2 : D - 1, an, dnn);
+                        one_step(std::false_type{}, ac, dc, hb + (size_t)s * BLOCK * NHT, ec);
+                    }
+                } else {
+#pragma unroll 4
+                    for (int s = 0; s < D; ++s) {
+                        dc = dn;
+#pragma unroll
+                        for (int i = 0; i < NACT; ++i) ac[i] = an[i];
+                        read_action(b, s + 1 < D ? s + 1 : s, an, dn);  // one step ahead: its LDS latency hides behind this step
+                        one_step(std::false_type{}, ac, dc, hb + (size_t)s * BLOCK * NHT, nullptr);
+                    }
                 }
             } else {  // tail block or DeadTimeProcessor queue: ONE rolled copy of the run-time-checked step
 #pragma nounroll
                 for (int s = 0; s < sb; ++s) {
                     read_action(b, s, ac, dc);
-                    one_step(std::true_type{}, ac, dc, hb + (size_t)s * BLOCK * NHT);
+                    one_step(std::true_type{}, ac, dc, hb + (size_t)s * BLOCK * NHT, nullptr);
                 }
             }
 #ifdef GEMX_TIMING
@@ -1973,6 +2032,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             b += (size_t)delay * BLOCK * conv_nact_c<CONV>() * sizeof(R);  // DeadTimeProcessor FIFO
             b += 2 * (size_t)((D + 3) / 4 * 4) * BLOCK * ABYTES;           // action staging (global -> LDS direct)
             if (h->cur_reward != nullptr) b += 3 * (size_t)D * BLOCK * h->rw_n_ref * sizeof(R);  // reference staging for the fused reward
+            if (ST::NVT > 0 && ConvTraits<CONV>::DISCRETE) b += (size_t)ConvTraits<CONV>::NACTIONS * 8 * sizeof(R);  // per-action voltage table
             return (b + 15) & ~(size_t)15;
         };
         auto resident = [&](int D, int OW) {
