@@ -601,14 +601,9 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
 template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_EESM, CONV, LOAD, SOLVER, IL, R> {
     using AngT = typename Angle<R>::T;
     static constexpr int NH = 8;  // ho: sin, cos of the step-start angle, u_a, u_b, u_c, u_sd, u_sq, u_e
-    static constexpr int NVT = 0;
     static constexpr int B6 = CONV == GEMX_CONV_CONT_B6_4QC ? GEMX_CONV_CONT_B6 : GEMX_CONV_FINITE_B6;
-    template <bool NS1 = false, bool LIN = false, bool TAB = false>
-    static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[4], AngT &ang, uint32_t &, const R (&act)[MAX_ACT],
-                                                   uint32_t dact, R (&ho)[NH], const R * = nullptr) {
-        R s, c;
-        Angle<R>::sincos(ang, s, c);
-        R ua, ub, uc, ue, u[MAX_U] = {R(0), R(0), R(0), R(0)};
+    // converter output of a flat action index: u_a, u_b, u_c, u_e (the multi-converter has no dead time here)
+    static __device__ __forceinline__ void voltages(const DevParams<R> &P, const R (&act)[MAX_ACT], uint32_t dact, R &ua, R &ub, R &uc, R &ue) {
         b6_voltages<B6, false, R>(P, act, dact & 7u, 0u, R(0), R(0), R(0), ua, ub, uc);
         if (CONV == GEMX_CONV_CONT_B6_4QC) {  // converters.py:481-491 with t_il = 0
             ue = (clip01(R(0.5) * (act[3] + R(1))) - clip01(R(-0.5) * (act[3] - R(1)))) * P.u_sup;
@@ -616,8 +611,28 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             const uint32_t a1 = (dact >> 3) & 3u;
             ue = (((a1 & 2u) ? R(0) : R(1)) - ((a1 & 1u) ? R(0) : R(1))) * P.u_sup;
         }
+    }
+    // per-action voltage table of the pipelined kernel (32 entries: u_a, u_b, u_c, u_alpha, u_beta, u_e), as for Stepper<GEMX_SYS_SYNC>
+    static constexpr int NVT = CONV == GEMX_CONV_FINITE_B6_4QC ? 6 : 0;
+    static __device__ __forceinline__ void action_entry(const DevParams<R> &P, uint32_t dact, R (&e)[8]) {
+        const R zero[MAX_ACT] = {R(0), R(0), R(0), R(0), R(0), R(0)};
+        voltages(P, zero, dact, e[0], e[1], e[2], e[5]);
+        t23(e[0], e[1], e[2], e[3], e[4]);
+        e[6] = e[7] = R(0);
+    }
+    template <bool NS1 = false, bool LIN = false, bool TAB = false>
+    static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[4], AngT &ang, uint32_t &, const R (&act)[MAX_ACT],
+                                                   uint32_t dact, R (&ho)[NH], const R *tab = nullptr) {
+        R s, c;
+        Angle<R>::sincos(ang, s, c);
+        R ua, ub, uc, ue, u[MAX_U] = {R(0), R(0), R(0), R(0)};
         R ual, ube;
-        t23(ua, ub, uc, ual, ube);
+        if (TAB) {
+            ua = tab[0]; ub = tab[1]; uc = tab[2]; ual = tab[3]; ube = tab[4]; ue = tab[5];
+        } else {
+            voltages(P, act, dact, ua, ub, uc, ue);
+            t23(ua, ub, uc, ual, ube);
+        }
         u[0] = c * ual + s * ube;  // Q^-1(., eps) at the step-start angle (line 643)
         u[1] = -s * ual + c * ube;
         u[2] = ue;
@@ -662,11 +677,18 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
 template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_SCIM, CONV, LOAD, SOLVER, IL, R> {
     using AngT = typename Angle<R>::T;
     static constexpr int NH = 7;  // ho: sin, cos of the last segment-start field angle, u_a, u_b, u_c, u_alpha, u_beta
-    static constexpr int NVT = 0;
+    // per-action voltage table of the pipelined kernel, as for the synchronous machines (Stepper<GEMX_SYS_SYNC>::action_entry)
+    static constexpr int NVT = (CONV == GEMX_CONV_FINITE_B6 && !IL) ? 5 : 0;
+    static __device__ __forceinline__ void action_entry(const DevParams<R> &P, uint32_t dact, R (&e)[8]) {
+        const R zero[MAX_ACT] = {R(0), R(0), R(0), R(0), R(0), R(0)};
+        b6_voltages<CONV, false, R>(P, zero, dact, 0u, R(0), R(0), R(0), e[0], e[1], e[2]);
+        t23(e[0], e[1], e[2], e[3], e[4]);
+        e[5] = e[6] = e[7] = R(0);
+    }
     static __device__ __forceinline__ void field_angle(R pa, R pb, R &s, R &c) { flux_angle<R>(pa, pb, s, c); }
     template <bool NS1 = false, bool LIN = false, bool TAB = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[5], AngT &ang, uint32_t &sw, const R (&act)[MAX_ACT],
-                                                   uint32_t dact, R (&ho)[NH], const R * = nullptr) {
+                                                   uint32_t dact, R (&ho)[NH], const R *tab = nullptr) {
         R s, c;
         field_angle(y[3], y[4], s, c);
         uint32_t legs = 0;
@@ -680,8 +702,12 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
         auto segment = [&](R h) {
             R ia = R(0), ib = R(0), ic = R(0);
             if (IL) t32(y[1], y[2], ia, ib, ic);  // i_in = T32(i_alphabeta) (line 780/792)
-            b6_voltages<CONV, IL, R>(P, act, dact, legs, ia, ib, ic, ua, ub, uc);
-            t23(ua, ub, uc, u[0], u[1]);  // u_alphabeta constant over the segment (line 788/799)
+            if (TAB) {  // this action's table entry
+                ua = tab[0]; ub = tab[1]; uc = tab[2]; u[0] = tab[3]; u[1] = tab[4];
+            } else {
+                b6_voltages<CONV, IL, R>(P, act, dact, legs, ia, ib, ic, ua, ub, uc);
+                t23(ua, ub, uc, u[0], u[1]);  // u_alphabeta constant over the segment (line 788/799)
+            }
             const R deps = integrate<GEMX_SYS_SCIM, LOAD, SOLVER, R, NS1, LIN>(P, y, u, h);
             ang = Angle<R>::advance(ang, deps);
         };
