@@ -178,7 +178,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="pmsm")
     ap.add_argument("--envs-per-gpu", type=int, default=None)
-    ap.add_argument("--chunk", type=int, default=500, help="control steps fused into one launch")
+    ap.add_argument("--chunk", type=int, default=1000, help="control steps fused into one launch")
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / single_step / at_scale legs")
     args = ap.parse_args()
 

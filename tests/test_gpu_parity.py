@@ -851,3 +851,47 @@ def test_masked_reset():
     st = ps.get_state().cpu().numpy()
     assert np.all(st[:, ::2] == 0.0) and np.any(st[:, 1::2] != 0.0)
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id, K", [("Finite-CC-PMSM-v0", 96), ("Cont-CC-PMSM-v0", 53), ("Finite-CC-EESM-v0", 48), ("Finite-CC-SCIM-v0", 40)])
+def test_one_step_map_equals_stage_solver_and_is_dropped_when_omega_differs(env_id, K, monkeypatch):
+    """ConstantSpeedLoad + RK4: the electrical subsystem is stepped by the precomputed affine map x1 = Phi x0 + S g (integrate<LIN>).
+    (1) Same rollout with GEMX_LINMAP=0 (RK4 stage by stage): equal up to fp32 rounding of the same polynomial (<= 2e-5 of each
+    column's scale).  (2) After set_state() moved omega away from init[0] in the first wave only, the
+    map (built for init[0]) is not valid there: that wave must fall back by itself -- again equal to the stage solver."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    def run(linmap, perturb):
+        monkeypatch.setenv("GEMX_LINMAP", linmap)
+        env = ga.make(env_id, n_envs=128, ode_solver=ga.RK4Solver(), constraints=())
+        ps = env.physical_system
+        env.reset()
+        g = torch.Generator(device="cuda").manual_seed(7)
+        if ps._discrete:
+            nflat = int(np.prod(ps.action_space.nvec)) if hasattr(ps.action_space, "nvec") else int(ps.action_space.n)
+            acts = torch.randint(0, nflat, (K, 128), device="cuda", generator=g, dtype=torch.uint8)
+        else:
+            acts = torch.rand((K, 128, ps._n_act), device="cuda", generator=g) * 2 - 1
+        if perturb:
+            st = ps.get_state()
+            st[0, :64] *= 0.5  # omega of the first wave
+            ps.set_state(st)
+        obs, _ = env.rollout(acts)
+        first = obs.double().cpu().numpy()
+        # chunked + single-step continuation stays bit-identical whichever solver the wave takes
+        o2, _ = env.rollout(acts[:7])
+        o3 = [ps.simulate(acts[7 + i]).clone() for i in range(3)]
+        env.close()
+        return first, o2.double().cpu().numpy(), torch.stack(o3).double().cpu().numpy()
+
+    for perturb in (False, True):
+        a, a2, a3 = run("1", perturb)
+        b, b2, b3 = run("0", perturb)
+        for x, y in ((a, b), (a2, b2), (a3, b3)):
+            scale = np.maximum(np.abs(y).max(axis=(0, 1)), 1e-3)
+            assert (np.abs(x - y) / scale).max() < 2e-5
+        if perturb:  # the perturbation took: the first wave runs at half the (constant) speed of the untouched one
+            assert abs(a[-1, 64, 0]) > 1e-3 and abs(a[-1, 0, 0] - 0.5 * a[-1, 64, 0]) < 1e-6
