@@ -641,10 +641,12 @@ int gemx_set_reward(gemx_handle *h, const gemx_reward_config *rc) {
     if (h->cfg.dtype == GEMX_F64) {
         RewardDev<double> W;
         build_reward(h, rc, W);
+        reward_hot_from(W, h->rh_d);
         HIP_TRY(hipMemcpy(h->rw_dev, &W, sizeof(W), hipMemcpyHostToDevice));
     } else {
         RewardDev<float> W;
         build_reward(h, rc, W);
+        reward_hot_from(W, h->rh_f);
         HIP_TRY(hipMemcpy(h->rw_dev, &W, sizeof(W), hipMemcpyHostToDevice));
     }
     h->rw_n_ref = rc->n_ref;

@@ -270,11 +270,40 @@ template <class R> struct RewardDev {
     R bias, violation_reward;
 };
 
+// The first GEMX_REWARD_HOT terms by value, inside the kernel arguments: kernel arguments are read with SCALAR loads (lgkmcnt).  Read
+// through the device pointer (KArgs::rw) the same words are VECTOR loads with a uniform address -- the compiler cannot prove that the
+// kernel's own stores do not alias them -- and their `s_waitcnt vmcnt(0)` waits, vmcnt retiring in order, for every observation store
+// the wave has in flight: ~5000 cycles per block in the pipelined kernel's output waves (s_memtime probe).
+constexpr int GEMX_REWARD_HOT = 4;
+template <class R> struct RewardHot {
+    int32_t n_ref, n_term, general;  // general: some term has a power other than 1 or 2 (pow() path through KArgs::rw)
+    int32_t col[GEMX_REWARD_HOT], kind[GEMX_REWARD_HOT];  // unused terms: column 0, kind 1, weight 0
+    R coef[GEMX_REWARD_HOT], inv_len[GEMX_REWARD_HOT], power[GEMX_REWARD_HOT];
+    R bias, violation_reward;
+};
+template <class R> inline void reward_hot_from(const RewardDev<R> &W, RewardHot<R> &H) {
+    H.n_ref = W.n_ref;
+    H.n_term = W.n_term;
+    H.general = 0;
+    for (int t = 0; t < W.n_term; ++t) H.general |= W.kind[t] == 3;
+    for (int t = 0; t < GEMX_REWARD_HOT; ++t) {
+        const bool used = t < W.n_term;
+        H.col[t] = used ? W.col[t] : 0;
+        H.kind[t] = used ? W.kind[t] : 1;
+        H.coef[t] = used ? W.coef[t] : R(0);
+        H.inv_len[t] = used ? W.inv_len[t] : R(0);
+        H.power[t] = used ? W.power[t] : R(1);
+    }
+    H.bias = W.bias;
+    H.violation_reward = W.violation_reward;
+}
+
 // ------------------------------------------------------------------------------------------------
 // kernel arguments
 // ------------------------------------------------------------------------------------------------
 template <class R> struct KArgs {
     DevParams<R> P;
+    RewardHot<R> rh;                // valid when rw != nullptr
     R *state;                       // [ND][N]
     typename Angle<R>::T *angle;    // [N] (systems with an angle)
     uint8_t *sw;                    // [rows][N] packed leg states, 2 bits per half-bridge (finite converters with interlocking)
@@ -333,6 +362,8 @@ struct gemx_handle {
     void *rinit_dev = nullptr;  // InitDev (random initial states)
     uint32_t *rcnt = nullptr;   // [n] resets so far per env
     void *rw_dev = nullptr;  // RewardDev<R> (gemx_set_reward)
+    gemx::RewardHot<float> rh_f = {};   // its first terms by value (kernel argument)
+    gemx::RewardHot<double> rh_d = {};
     int rw_n_ref = -1;       // -1: no reward installed
     const void *cur_refs = nullptr;  // set by gemx_rollout_reward around the launch
     void *cur_reward = nullptr;

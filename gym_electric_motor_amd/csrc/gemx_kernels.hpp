@@ -1128,7 +1128,7 @@ __device__ __forceinline__ void flush_rows_pipe(const KArgs<R> &a, const R *ring
 //   reward_apply: reward of those rows -> reward tensor.
 template <int RB, class R>
 __device__ __forceinline__ void reward_fetch(const KArgs<R> &a, int k0, int nr, int64_t e, R (&rv)[RB][GEMX_MAX_REF]) {
-    const int n_ref = a.rw->n_ref;
+    const int n_ref = a.rh.n_ref;
     const int64_t N = a.N;
 #pragma unroll
     for (int s = 0; s < RB; ++s) {
@@ -1143,25 +1143,25 @@ __device__ __forceinline__ void reward_fetch(const KArgs<R> &a, int k0, int nr, 
 // (stores to the reward tensor could alias the description as far as the compiler knows).  The first HOT terms cover every
 // reference env (<= 3 referenced states); further weighted states take the slow path through memory.
 template <class R> struct RewardRegs {
-    static constexpr int HOT = 4;
+    static constexpr int HOT = GEMX_REWARD_HOT;
     int32_t n_term, general, col[HOT], kind[HOT];
     R coef[HOT], inv_len[HOT], power[HOT], bias, violation_reward;
-    __device__ __forceinline__ void load(const RewardDev<R> *w) {
-        n_term = w->n_term;
-        general = 0;
-        for (int t = 0; t < w->n_term; ++t) general |= w->kind[t] == 3;
+    // from the kernel arguments (scalar loads, see RewardHot); unused hot terms carry weight 0, so the hot path has no per-term branch
+    __device__ __forceinline__ void load(const RewardHot<R> &w) {
+        n_term = w.n_term;
+        general = w.general;
 #pragma unroll
         for (int t = 0; t < HOT; ++t) {
-            col[t] = w->col[t]; kind[t] = w->kind[t]; coef[t] = w->coef[t]; inv_len[t] = w->inv_len[t]; power[t] = w->power[t];
+            col[t] = w.col[t]; kind[t] = w.kind[t]; coef[t] = w.coef[t]; inv_len[t] = w.inv_len[t]; power[t] = w.power[t];
         }
-        bias = w->bias;
-        violation_reward = w->violation_reward;
+        bias = w.bias;
+        violation_reward = w.violation_reward;
     }
 };
 // GENERAL: reward_power other than 1 or 2 allowed (pow(): a ~300-instruction expansion, so it must not be unrolled per term)
 template <bool GENERAL, class R> __device__ __forceinline__ R reward_term(R o, R ref, R inv_len, int kind, R power, R coef) {
     const R dlt = fabs(o - ref) * inv_len;
-    R p = kind == 2 ? dlt * dlt : dlt;
+    R p = dlt * (kind == 2 ? dlt : R(1));  // (a select, not a branch: dlt * 1 == dlt exactly)
     if (GENERAL && kind == 3) p = pow(dlt, power);
     return coef * p;
 }
@@ -1173,6 +1173,17 @@ __device__ __forceinline__ void reward_apply(const KArgs<R> &a, const RewardRegs
     const int64_t N = a.N;
     const bool aos = a.P.obs_layout == GEMX_OBS_AOS;
     auto obs_at = [&](int row, int c) { return aos ? ring[((size_t)row * BLOCK + tid) * NOUT + c] : ring[((size_t)row * NOUT + c) * BLOCK + tid]; };
+    // the hot terms' observations and the done bytes of ALL rows first: RB * (HOT + 1) LDS reads in flight at once instead of one
+    // exposed LDS latency per term (the output waves spent ~1250 cycles per row here, s_memtime probe)
+    R oh[RB][HOT];
+    unsigned char dn[RB];
+#pragma unroll
+    for (int s = 0; s < RB; ++s) {
+        const int row = row0 + (s < nr ? s : 0);
+#pragma unroll
+        for (int t = 0; t < HOT; ++t) oh[s][t] = obs_at(row, W.col[t]);
+        dn[s] = donebuf[row * BLOCK + tid];
+    }
 #pragma unroll
     for (int s = 0; s < RB; ++s) {
         if (s < nr) {
@@ -1180,9 +1191,8 @@ __device__ __forceinline__ void reward_apply(const KArgs<R> &a, const RewardRegs
             R acc = R(0);
             if (!W.general) {
 #pragma unroll
-                for (int t = 0; t < HOT; ++t) {  // terms < n_ref are the referenced states (reference column t), the others compare with 0
-                    if (t < W.n_term) acc += reward_term<false, R>(obs_at(row, W.col[t]), t < GEMX_MAX_REF ? rv[s][t] : R(0), W.inv_len[t], W.kind[t], W.power[t], W.coef[t]);
-                }
+                for (int t = 0; t < HOT; ++t)  // terms < n_ref are the referenced states (reference column t), the others compare with 0
+                    acc += reward_term<false, R>(oh[s][t], t < GEMX_MAX_REF ? rv[s][t] : R(0), W.inv_len[t], W.kind[t], W.power[t], W.coef[t]);
             }
             // slow path through memory: terms beyond the hot ones, and EVERY term when some reward_power is not 1 or 2 (one pow() site)
 #pragma nounroll
@@ -1193,7 +1203,7 @@ __device__ __forceinline__ void reward_apply(const KArgs<R> &a, const RewardRegs
                 acc += reward_term<true, R>(obs_at(row, a.rw->col[t]), ref, a.rw->inv_len[t], a.rw->kind[t], a.rw->power[t], a.rw->coef[t]);
             }
             const R wse = W.bias - acc;
-            const R r = donebuf[row * BLOCK + tid] ? W.violation_reward : wse;  // (1 - v) * wse + v * violation_reward, v in {0, 1}
+            const R r = dn[s] ? W.violation_reward : wse;  // (1 - v) * wse + v * violation_reward, v in {0, 1}
             if (valid) a.reward[(int64_t)(k0 + s) * N + env] = r;
         }
     }
@@ -1207,7 +1217,7 @@ __device__ __forceinline__ void reward_rows(const KArgs<R> &a, const R *ring, co
     constexpr int RB = REWARD_RB;
     const int64_t e = valid ? env : a.N - 1;
     RewardRegs<R> W;
-    W.load(a.rw);
+    W.load(a.rh);
     R rb[RB][GEMX_MAX_REF];
     auto cnt = [&](int s0) { return nr - s0 < RB ? (nr - s0 < 0 ? 0 : nr - s0) : RB; };
     for (int s0 = 0; s0 < nr; s0 += 2 * RB) {
@@ -1557,7 +1567,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
     // the in-order vmcnt, for all their older observation stores once per block.
     constexpr int ACTB_BYTES = 2 * ((D + 3) / 4 * 4) * BLOCK * (DISCRETE ? 1 : NACT * (int)sizeof(R));
     R *refb = reinterpret_cast<R *>(actb + ACTB_BYTES);
-    const int n_ref = a.rw != nullptr ? a.rw->n_ref : 0;
+    const int n_ref = a.rw != nullptr ? a.rh.n_ref : 0;
     // per-action voltage table [NACTIONS][8] R of steppers that have one (ST::NVT > 0), read by the integrator wave only
     constexpr bool USE_TAB = ST::NVT > 0 && DISCRETE;
     R *vtab = refb + 3 * (size_t)D * BLOCK * n_ref;
@@ -1911,15 +1921,27 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                 // this block's references are in LDS (staged by the integrator wave); the description is (re)read from the scalar
                 // cache once per block, so that its ~25 SGPRs are live only here
                 RewardRegs<R> WR;
-                WR.load(a.rw);
+                WR.load(a.rh);
                 R rv[RPW][GEMX_MAX_REF];
                 const R *rb = refb + ((size_t)(pb % 3) * D + r0) * BLOCK * n_ref + (size_t)tid * n_ref;
+                // unconditional loads from clamped addresses + selects: a conditional load compiles to one scalar branch per element
+                auto fetch_refs = [&](int nrr) {
 #pragma unroll
-                for (int s = 0; s < RPW; ++s) {
+                    for (int s = 0; s < RPW; ++s) {
 #pragma unroll
-                    for (int j = 0; j < GEMX_MAX_REF; ++j) rv[s][j] = (s < nr && j < n_ref) ? rb[(size_t)s * BLOCK * n_ref + j] : R(0);
+                        for (int j = 0; j < GEMX_MAX_REF; ++j) {
+                            const R v = rb[(size_t)(s < nrr ? s : 0) * BLOCK * n_ref + (j < n_ref ? j : 0)];
+                            rv[s][j] = (s < nrr && j < n_ref) ? v : R(0);
+                        }
+                    }
+                };
+                if (nr == RPW) {  // full block: the row count is a compile-time constant in this copy
+                    fetch_refs(RPW);
+                    reward_apply<NOUT, RPW, R>(a, WR, ring, donebuf, pb * D + r0, r0, RPW, tid, env, true, rv);
+                } else {
+                    fetch_refs(nr);
+                    reward_apply<NOUT, RPW, R>(a, WR, ring, donebuf, pb * D + r0, r0, nr, tid, env, true, rv);
                 }
-                reward_apply<NOUT, RPW, R>(a, WR, ring, donebuf, pb * D + r0, r0, nr, tid, env, true, rv);
             }
             if (aos && nr == RPW) flush_rows_pipe<NOUT, RPW, R>(a, ring + (size_t)r0 * BLOCK * NOUT, donebuf + (size_t)r0 * BLOCK, pb * D + r0, tid, blk0);
             else flush_rings<NOUT, R>(a, ring + (size_t)r0 * BLOCK * NOUT, donebuf + (size_t)r0 * BLOCK, pb * D + r0, nr, tid, blk0, BLOCK, true,
@@ -2014,6 +2036,8 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     a.rinit = (const InitDev *)h->rinit_dev;
     a.rcnt = h->rcnt;
     a.rw = h->cur_reward != nullptr ? (const RewardDev<R> *)h->rw_dev : nullptr;
+    if constexpr (sizeof(R) == 4) a.rh = h->rh_f;
+    else a.rh = h->rh_d;
     a.refs = (const R *)h->cur_refs;
     a.reward = (R *)h->cur_reward;
     a.N = h->n;

@@ -15,8 +15,16 @@ if "Finite" in env_id:
     act = torch.randint(0, 8, (K, n), dtype=torch.uint8, device="cuda:0")
 else:
     act = torch.rand((K, n, 3), device="cuda:0") * 2 - 1
+refs = rew = None
+if os.environ.get("PROBE_REWARD"):
+    ps.set_reward(reward_weights=dict(i_sd=0.5, i_sq=0.5), referenced_states=("i_sd", "i_sq"))
+    refs = torch.rand((K, n, 2), device="cuda:0") * 2 - 1
+    rew = torch.empty((K, n), device="cuda:0")
 for _ in range(5):
-    ps.rollout(act)
+    if refs is None:
+        ps.rollout(act)
+    else:
+        ps.rollout(act, references=refs, reward_out=rew)
 torch.cuda.synchronize()
 L = _lib.load()
 L.gemx_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
