@@ -9,7 +9,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/${TAG}_bench.log 2>&1
 tail -1 $OUT/${TAG}_bench.log > $OUT/${TAG}_bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $R/bench.py --no-extras --steps 4000 --warmup 1000 > /tmp/ks.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $R/bench.py --no-extras > /tmp/ks.log 2>&1
+grep "^{\"metric\"" /tmp/ks.log | tail -1 > $OUT/${TAG}_bench_under_rocprof.json
 cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --no-extras --steps 3000 --warmup 1000 > /tmp/pmc_$c.log 2>&1
