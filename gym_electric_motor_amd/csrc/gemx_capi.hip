@@ -494,6 +494,8 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         if (ev) h->steps_per_block = atoi(ev);
         ev = getenv("GEMX_PIPE");
         if (ev) h->use_pipe = atoi(ev);
+        ev = getenv("GEMX_PIPE_SHAPE");
+        if (ev) h->pipe_shape = atoi(ev);
         ev = getenv("GEMX_LINMAP");  // 0: never use the one-step map of the electrical subsystem (A/B runs)
         if (ev && atoi(ev) == 0) h->linmap_state = -1;
 

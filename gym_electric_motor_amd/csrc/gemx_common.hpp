@@ -333,6 +333,8 @@ constexpr int MAX_STEPS_PER_BLOCK = 32;
 //   < 4, 2>: up to ~2 rounds of 4 resident workgroups per CU (a third of the LDS per workgroup).
 constexpr int PIPE_D = 12, PIPE_OUT_WAVES = 3;
 constexpr int PIPE_D2 = 4, PIPE_OUT_WAVES2 = 2;
+// shallow shape: half the LDS of <4, 2> again, for the N at which only IT fits all workgroups into one resident round
+constexpr int PIPE_D3 = 2, PIPE_OUT_WAVES3 = 2;
 // both shapes carry a LOADER wave that stages actions / references global -> LDS (0: the integrator wave stages them itself).  Measured
 // at 131072 envs over all motor families (same box A/B): -5 .. +22 %, the heavier steppers and the continuous-action ones gain most
 constexpr int pipe_loader_waves(int) { return 1; }
@@ -382,6 +384,7 @@ struct gemx_handle {
     struct LastLaunch { int pipe, sys, conv, load, solver, il, real_size, d, threads, k, s; long long blocks; size_t lds; };
     LastLaunch ll = {};            // most recent advance launch (formatted lazily by gemx_last_launch)
     mutable char last_launch[256] = "";
+    int pipe_shape = -1;      // GEMX_PIPE_SHAPE=0/1/2 forces <12,3> / <4,2> / <2,2> whenever it fits (tests: every shape on small N)
     int use_pipe = -1;        // pipelined kernel: -1 / 1 whenever eligible (default), 0 never (GEMX_PIPE=0: A/B and bit-identity tests)
 };
 

@@ -1350,7 +1350,9 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
 //      with 16-byte-per-lane stores; the stores drain while the next block computes.
 // ------------------------------------------------------------------------------------------------
 template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R>
-__global__ __launch_bounds__(BLOCK) void advance_kernel(const KArgs<R> a) {
+// (waves_per_eu: at least two waves per SIMD, i.e. at most 256 VGPRs -- the general kernel of the synchronous machines sits right at
+// that edge (255 .. 258 depending on what else is inlined), and 258 would halve its residency; the DFIM's needs ~280 either way)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SYS == GEMX_SYS_DFIM ? 1 : 2))) void advance_kernel(const KArgs<R> a) {
     constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
     constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
     constexpr int ABYTES = DISCRETE ? 1 : NACT * (int)sizeof(R);  // action bytes per env and step
@@ -2093,19 +2095,31 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         // one resident round of the 4-wave shape if N is that small, else the 3-wave shape at ANY N: measured at 131072 and 1048576
         // envs over all motor families (profiles/r01d_matrix.md) it is on par with or ahead of the single-wave kernel (PMSM
         // 1M envs: 100 vs 86 G env-steps/s) -- the split keeps stores fire-and-forget and the integrator free of vmcnt waits
-        int D = 0, OW = 0;
-        if (smem_of(PIPE_D) <= h->lds_max && blocks <= resident(PIPE_D, PIPE_OUT_WAVES)) { D = PIPE_D; OW = PIPE_OUT_WAVES; }
-        else if (smem_of(PIPE_D2) <= h->lds_max) { D = PIPE_D2; OW = PIPE_OUT_WAVES2; }
+        int D = 0, OW = 0, shape = 0;
+        if (smem_of(PIPE_D) <= h->lds_max && blocks <= resident(PIPE_D, PIPE_OUT_WAVES)) { D = PIPE_D; OW = PIPE_OUT_WAVES; shape = 0; }
+        else if (SysTraits<SYS>::NOUT >= 14 && smem_of(PIPE_D3) <= h->lds_max && blocks <= resident(PIPE_D3, PIPE_OUT_WAVES3) &&
+                 blocks > resident(PIPE_D2, PIPE_OUT_WAVES2) && 2 * blocks <= 3 * resident(PIPE_D2, PIPE_OUT_WAVES2)) {
+            // (three-phase machines only: the DC machines' light steppers lose with the shallow shape -- ExtExDc 131072 envs 133 -> 104 G)
+            // one resident round with the shallow shape where <4, 2> would run one round plus a tail of at most half a round: SCIM,
+            // 65536 envs (BASELINE config 4) 49 -> 67 G env-steps/s.  Everywhere else <4, 2> is 5-20 % ahead of <2, 2> (fewer barriers,
+            // fewer waves per SIMD): PMSM finite at 131072 envs = two FULL rounds of <4, 2>: 89-92 G against 79 G in one round of <2, 2>
+            D = PIPE_D3; OW = PIPE_OUT_WAVES3; shape = 2;
+        } else if (smem_of(PIPE_D2) <= h->lds_max) { D = PIPE_D2; OW = PIPE_OUT_WAVES2; shape = 1; }
+        if (h->pipe_shape >= 0 && h->pipe_shape <= 2) {  // forced shape (tests)
+            const int fd[3] = {PIPE_D, PIPE_D2, PIPE_D3}, fo[3] = {PIPE_OUT_WAVES, PIPE_OUT_WAVES2, PIPE_OUT_WAVES3};
+            if (smem_of(fd[h->pipe_shape]) <= h->lds_max) { shape = h->pipe_shape; D = fd[shape]; OW = fo[shape]; }
+        }
         if (D != 0) {
             a.S = D;
             a.D = D;
             const size_t psmem = smem_of(D);
-            auto pkern = D == PIPE_D ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES>
-                                     : advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2>;
-            static bool pattr_set[2] = {false, false};
-            if (!pattr_set[D == PIPE_D]) {
+            auto pkern = shape == 0   ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES>
+                         : shape == 1 ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2>
+                                      : advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D3, PIPE_OUT_WAVES3>;
+            static bool pattr_set[3] = {false, false, false};
+            if (!pattr_set[shape]) {
                 GEMX_HIP_TRY(hipFuncSetAttribute((const void *)pkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max));
-                pattr_set[D == PIPE_D] = true;
+                pattr_set[shape] = true;
             }
             const int threads = (1 + OW + pipe_loader_waves(D)) * BLOCK;
             hipLaunchKernelGGL(pkern, dim3((unsigned)blocks), dim3(threads), psmem, st, a);
