@@ -31,9 +31,9 @@ namespace gemx {
 // load: d(omega)/dt (constant_speed_load.py:40-42; polynomial_static_load.py:62-66, 87-99)
 // ------------------------------------------------------------------------------------------------
 template <class R> __device__ __forceinline__ R poly_load_ode(const DevParams<R> &P, R omega, R torque) {
-    R sign = sgn(omega);
-    R a = fabs(omega) > P.omega_lim ? sign * P.la : P.lin_factor * omega;
-    R tl = sign * P.lc * omega * omega + P.lb * omega + a;
+    // sign(w) * c * w^2 = c * w * |w|; sign(w) * a only matters where |w| > limit >= 0, i.e. w != 0: copysign(1, w) (one v_bfi) does
+    const R a = fabs(omega) > P.omega_lim ? copysign(R(1), omega) * P.la : P.lin_factor * omega;
+    const R tl = P.lc * (omega * fabs(omega)) + P.lb * omega + a;
     return (torque - tl) * P.inv_j;
 }
 
@@ -366,10 +366,12 @@ __device__ __forceinline__ void b6_voltages(const DevParams<R> &P, const R (&act
 }
 
 // cos/sin of the rotor-flux angle eps_fs = atan2(psi_b, psi_a) (calculate_field_angle, physical_systems.py:765-769) without atan2
+__device__ __forceinline__ float rsqrt_r(float x) { return __frsqrt_rn(x); }  // V_RSQ_F32, 1 ulp (an IEEE division is ~12 instructions)
+__device__ __forceinline__ double rsqrt_r(double x) { return 1.0 / sqrt(x); }
 template <class R> __device__ __forceinline__ void flux_angle(R pa, R pb, R &s, R &c) {
     R n2 = pa * pa + pb * pb;
     if (n2 < R(1e-30)) { pa *= R(1e18); pb *= R(1e18); n2 = pa * pa + pb * pb; }
-    const R rn = n2 > R(0) ? R(1) / sqrt(n2) : R(0);
+    const R rn = n2 > R(0) ? rsqrt_r(n2) : R(0);
     c = n2 > R(0) ? pa * rn : R(1);  // atan2(0, 0) = 0
     s = pb * rn;
 }
