@@ -1530,19 +1530,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SYS == GE
 }
 
 // ------------------------------------------------------------------------------------------------
-// Two-wave pipelined variant for small N (<= 2 workgroups per CU), where a single wave per SIMD is bound by its own
-// instruction issue rate (~4.7 cycles per instruction, PMC): the control step is split across the two waves of a
-// 128-thread workgroup that serve the SAME 64 envs,
-//   wave 0 (integrator): actions (global -> registers, one block ahead) -> converter -> ODE integration -> default
-//                        constraint -> auto-reset -> hand-off row to LDS.  It issues no stores before its epilogue, so
-//                        its vmcnt waits only cover action loads issued a whole block earlier, and it never READS LDS.
-//   wave 1 (output):     hand-off row -> observation row -> LDS ring -> 16-byte stores to HBM.  It issues no global
-//                        loads, so it never waits on vmcnt: its stores are fire-and-forget.
-// They meet at ONE s_barrier per block of D = PIPE_D control steps; the hand-off buffer is double-buffered so wave 1
-// works on block b-1 while wave 0 integrates block b.  Full blocks are completely unrolled and branch-free in both
-// waves (one long basic block for the scheduler).
+// Pipelined variant: a single wave per SIMD is bound by its own instruction issue rate (one VALU instruction per >= 4.5 cycles,
+// tools/microbench_issue.hip), so the control step is split across the 1 + OW + 1 waves of a workgroup that serve the SAME 64 envs:
+//   wave 0 (integrator):   action (LDS staging buffer / per-action voltage table, read one and two steps ahead) -> converter -> ODE
+//                          integration -> default constraint -> auto-reset -> hand-off row to LDS.  No global memory instruction
+//                          between its prologue and its epilogue.
+//   waves 1..OW (output):  hand-off row -> observation row -> LDS ring -> fused reward -> 16-byte non-temporal stores to HBM.  They
+//                          issue no global loads, so they never wait on vmcnt: their stores are fire-and-forget.
+//   last wave (loader):    the NEXT block's actions / reward references global -> LDS (global_load_lds), awaited here: issued by the
+//                          integrator they queued behind the output waves' stores and stalled it at their issue.
+// They meet at ONE s_barrier per block of D control steps; the hand-off buffer is double-buffered so the output waves work on block
+// b-1 while the integrator runs block b and the loader fetches block b+1.  Full blocks are unrolled into branch-free basic blocks of
+// four steps.  Shapes <D, OW>: <12, 3>, <4, 2>, <2, 2> (launch_advance_t picks by N and LDS footprint).
 // Preconditions (checked by the launcher): full 64-env workgroups, 16-byte aligned tensors (coop), obs_every, K >= 2,
-// constraint kind none/default, S a multiple of PIPE_D.
+// constraint kind none/default, one solver sub-step, ideal supply, constant initialiser.
 // ------------------------------------------------------------------------------------------------
 template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R, int D, int OW>
 __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advance_pipe_kernel(const KArgs<R> a) {
@@ -2078,7 +2079,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     smem = (smem + 15) & ~(size_t)15;
     smem += (size_t)delay * BLOCK * conv_nact_c<CONV>() * sizeof(R);  // DeadTimeProcessor FIFO
     const int64_t blocks = (h->n + BLOCK - 1) / BLOCK;
-    // two-wave pipelined kernel for small N (the chip is not full: a single wave per SIMD is issue-bound)
+    // pipelined kernel (integrator / output / loader waves) whenever the launch qualifies
     const bool pipe_ok = h->use_pipe != 0 && K >= 2 && obs_every && a.coop && a.obs_vec && (h->n % BLOCK) == 0 &&
                          params_of<R>(h).constr_kind <= 1 && h->cfg.solver_nsteps == 1 && h->cfg.supply_kind == GEMX_SUPPLY_IDEAL &&
                          h->cfg.init_kind == GEMX_INIT_CONST;  // (the fp64 Philox / inverse-CDF code of random initialisers would cost the
@@ -2088,8 +2089,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     if constexpr (sizeof(R) == 4) if (pipe_ok) {
         using ST = Stepper<SYS, conv_base<CONV>(), LOAD, SOLVER, IL, R>;
         constexpr int NHT = SysTraits<SYS>::ND + (SysTraits<SYS>::HAS_ANGLE ? 1 : 0) + ST::NH + 1;
-        // hand-off depth: 8 steps per barrier when one resident round of workgroups covers N, else 4 (half the LDS ->
-        // twice the resident workgroups).  Small-N regime only: at most two rounds of resident workgroups.
+        // LDS footprint of one workgroup at hand-off depth D (steps per barrier): ring + done ring + double-buffered hand-off rows + ...
         auto smem_of = [&](int D) {
             size_t b = (size_t)D * BLOCK * h->nout * sizeof(R) + (size_t)D * BLOCK + 2 * (size_t)D * BLOCK * NHT * sizeof(R);
             b += (size_t)delay * BLOCK * conv_nact_c<CONV>() * sizeof(R);  // DeadTimeProcessor FIFO
