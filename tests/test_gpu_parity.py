@@ -914,3 +914,46 @@ def test_all_three_pipelined_shapes_are_bit_identical(name, monkeypatch):
     _, _, obs, done = _run_golden(name, "float32", n_envs=128)
     for o, d in outs:
         assert np.array_equal(o, obs) and np.array_equal(d, done)
+
+
+@pytest.mark.gpu
+def test_single_step_launches_replay_from_a_hip_graph_bit_identically():
+    """simulate() enqueues one kernel on the current stream and never synchronises: a closed loop (policy -> step) captured with
+    torch.cuda.CUDAGraph (hipGraph) and replayed continues the simulation exactly like the eager loop (examples/hip_graph_closed_loop.py)."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    def make():
+        env = ga.make("Cont-CC-PMSM-v0", n_envs=256, ode_solver=ga.RK4Solver())
+        obs, _ = env.reset()
+        return env, env.physical_system, obs
+
+    gain = torch.tensor([[0.5, -0.25, 0.75]], device="cuda")
+    cols = torch.tensor([5, 6, 2], device="cuda")
+
+    def loop(ps, obs, action, steps, trace):
+        for _ in range(steps):
+            torch.mul(torch.tanh(obs.index_select(1, cols) * 3.0 + 0.1), gain, out=action)
+            obs = ps.simulate(action)
+            if trace is not None:
+                trace.append(obs.clone())
+        return obs
+
+    env1, ps1, obs1 = make()
+    a1 = torch.zeros((256, 3), device="cuda")
+    eager = []
+    loop(ps1, obs1, a1, 4 + 3 * 8, eager)
+    env2, ps2, obs2 = make()
+    a2 = torch.zeros((256, 3), device="cuda")
+    loop(ps2, obs2, a2, 4, None)  # warm-up outside the capture (lazy one-time work of the handle)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        loop(ps2, obs2, a2, 8, None)
+    for r in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(obs2, eager[4 + 8 * (r + 1) - 1])
+    env1.close()
+    env2.close()
