@@ -987,8 +987,11 @@ __device__ __forceinline__ void flush_rings(const KArgs<R> &a, const R *ring, co
                                             int64_t blk0, int rows, bool full, bool valid, int64_t env) {
     constexpr int VEC = 16 / sizeof(R);
     constexpr int ROWV = BLOCK * NOUT / VEC;
-    using V = typename std::conditional<sizeof(R) == 4, float4, double2>::type;
+    typedef float v4f_t __attribute__((ext_vector_type(4)));
+    typedef double v2d_t __attribute__((ext_vector_type(2)));
+    using V = typename std::conditional<sizeof(R) == 4, v4f_t, v2d_t>::type;
     const int64_t N = a.N;
+    const bool stream_out = a.K > 1;  // rollouts: non-temporal stores (see flush_rows_pipe); a single step's row is read next by the policy
     if (a.P.obs_layout == GEMX_OBS_AOS) {
         if (a.obs_vec) {
             const int nvec = rows * NOUT / VEC;  // == ROWV for full blocks
@@ -999,7 +1002,11 @@ __device__ __forceinline__ void flush_rings(const KArgs<R> &a, const R *ring, co
 #pragma unroll
                 for (int i = 0; i < (ROWV + BLOCK - 1) / BLOCK; ++i) {
                     const int idx = tid + i * BLOCK;
-                    if (idx < nvec) gv[idx] = lv[idx];
+                    if (idx < nvec) {
+                        const V v = lv[idx];
+                        if (stream_out) __builtin_nontemporal_store(v, &gv[idx]);
+                        else gv[idx] = v;
+                    }
                 }
                 for (int idx = nvec * VEC + tid; idx < rows * NOUT; idx += BLOCK)
                     a.obs[((int64_t)(k0 + s) * N + blk0) * NOUT + idx] = ring[(size_t)s * BLOCK * NOUT + idx];
