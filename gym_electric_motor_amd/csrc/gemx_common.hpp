@@ -333,6 +333,8 @@ constexpr int MAX_STEPS_PER_BLOCK = 32;
 //   < 4, 2>: up to ~2 rounds of 4 resident workgroups per CU (a third of the LDS per workgroup).
 constexpr int PIPE_D = 12, PIPE_OUT_WAVES = 3;
 constexpr int PIPE_D2 = 4, PIPE_OUT_WAVES2 = 2;
+// deep shape with six output waves: launches that evaluate the fused reward, whose output waves otherwise bound the launch
+constexpr int PIPE_OUT_WAVES_RW = 6;
 // shallow shape: half the LDS of <4, 2> again, for the N at which only IT fits all workgroups into one resident round
 constexpr int PIPE_D3 = 2, PIPE_OUT_WAVES3 = 2;
 // both shapes carry a LOADER wave that stages actions / references global -> LDS (0: the integrator wave stages them itself).  Measured

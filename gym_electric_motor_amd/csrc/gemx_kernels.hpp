@@ -2114,7 +2114,10 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         // envs over all motor families (profiles/r01d_matrix.md) it is on par with or ahead of the single-wave kernel (PMSM
         // 1M envs: 100 vs 86 G env-steps/s) -- the split keeps stores fire-and-forget and the integrator free of vmcnt waits
         int D = 0, OW = 0, shape = 0;
-        if (smem_of(PIPE_D) <= h->lds_max && blocks <= resident(PIPE_D, PIPE_OUT_WAVES)) { D = PIPE_D; OW = PIPE_OUT_WAVES; shape = 0; }
+        if (smem_of(PIPE_D) <= h->lds_max && blocks <= resident(PIPE_D, PIPE_OUT_WAVES)) {
+            D = PIPE_D; OW = PIPE_OUT_WAVES; shape = 0;
+            if (h->cur_reward != nullptr) { OW = PIPE_OUT_WAVES_RW; shape = 3; }  // (eight waves: still one workgroup per CU)
+        }
         else if (SysTraits<SYS>::NOUT >= 14 && smem_of(PIPE_D3) <= h->lds_max && blocks <= resident(PIPE_D3, PIPE_OUT_WAVES3) &&
                  blocks > resident(PIPE_D2, PIPE_OUT_WAVES2) && 2 * blocks <= 3 * resident(PIPE_D2, PIPE_OUT_WAVES2)) {
             // (three-phase machines only: the DC machines' light steppers lose with the shallow shape -- ExtExDc 131072 envs 133 -> 104 G)
@@ -2123,8 +2126,8 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             // fewer waves per SIMD): PMSM finite at 131072 envs = two FULL rounds of <4, 2>: 89-92 G against 79 G in one round of <2, 2>
             D = PIPE_D3; OW = PIPE_OUT_WAVES3; shape = 2;
         } else if (smem_of(PIPE_D2) <= h->lds_max) { D = PIPE_D2; OW = PIPE_OUT_WAVES2; shape = 1; }
-        if (h->pipe_shape >= 0 && h->pipe_shape <= 2) {  // forced shape (tests)
-            const int fd[3] = {PIPE_D, PIPE_D2, PIPE_D3}, fo[3] = {PIPE_OUT_WAVES, PIPE_OUT_WAVES2, PIPE_OUT_WAVES3};
+        if (h->pipe_shape >= 0 && h->pipe_shape <= 3) {  // forced shape (tests)
+            const int fd[4] = {PIPE_D, PIPE_D2, PIPE_D3, PIPE_D}, fo[4] = {PIPE_OUT_WAVES, PIPE_OUT_WAVES2, PIPE_OUT_WAVES3, PIPE_OUT_WAVES_RW};
             if (smem_of(fd[h->pipe_shape]) <= h->lds_max) { shape = h->pipe_shape; D = fd[shape]; OW = fo[shape]; }
         }
         if (D != 0) {
@@ -2133,8 +2136,9 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             const size_t psmem = smem_of(D);
             auto pkern = shape == 0   ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES>
                          : shape == 1 ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2>
-                                      : advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D3, PIPE_OUT_WAVES3>;
-            static bool pattr_set[3] = {false, false, false};
+                         : shape == 2 ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D3, PIPE_OUT_WAVES3>
+                                      : advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES_RW>;
+            static bool pattr_set[4] = {false, false, false, false};
             if (!pattr_set[shape]) {
                 GEMX_HIP_TRY(hipFuncSetAttribute((const void *)pkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max));
                 pattr_set[shape] = true;

@@ -900,12 +900,12 @@ def test_one_step_map_equals_stage_solver_and_is_dropped_when_omega_differs(env_
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["pmsm_epi_held_tau1e-4_euler", "scim_epi_uniform_euler", "permexdc_epi_held_euler", "eesm_fin_epi_held_tau1e-4_euler",
                                   "dfim_fin_epi_held_tau1e-4_euler", "extex_cont_epi_held_euler"])
-def test_all_three_pipelined_shapes_are_bit_identical(name, monkeypatch):
+def test_all_pipelined_shapes_are_bit_identical(name, monkeypatch):
     """<12 steps, 3 output waves>, <4, 2> and <2, 2> (chosen by N in production, forced here with GEMX_PIPE_SHAPE) and the single-wave
     kernel give the same bits on the same inputs; K of the fixtures is not a multiple of any D, so every shape runs a tail block."""
     monkeypatch.setenv("GEMX_PIPE", "1")
     outs = []
-    for shape in ("0", "1", "2"):
+    for shape in ("0", "1", "2", "3"):  # 3: <12 steps, 6 output waves>, the shape of launches with the fused reward
         monkeypatch.setenv("GEMX_PIPE_SHAPE", shape)
         _, _, obs, done = _run_golden(name, "float32", n_envs=128)
         outs.append((obs, done))
