@@ -1661,6 +1661,9 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                 fifo[((size_t)d * BLOCK + tid) * NACTC + i] = DISCRETE ? (R)a.ring[gi] : reinterpret_cast<const R *>(a.ring)[gi];
             }
         }
+        R pop[NACTC];  // DeadTimeProcessor: the queue entry the next step pops, read one step ahead
+#pragma unroll
+        for (int i = 0; i < NACTC; ++i) pop[i] = P.delay > 0 ? fifo[((size_t)slot * BLOCK + tid) * NACTC + i] : R(0);
         constexpr bool LINABLE = linable<LOAD, SOLVER, IL, R>();
         const bool lin_ok = lin_usable<LOAD, SOLVER, IL, R>(P, y[0]);  // wave-uniform
         const bool check_default = P.constr_kind == 1;
@@ -1695,16 +1698,26 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             // action stage, exactly as in compute_block(): [DqToAbcActionProcessor [DeadTimeProcessor [system(control_space)]]]
             if (conv_dq<CONV>() && P.dq_processor) dq_action_stage<SYS, CONV, R>(P, y, ang, act);
             if (FIFO && P.delay > 0) {
+                // the value popped in THIS step was read a step ago (`pop`); push the new one, then read the next step's pop -- the
+                // slot after this one, or what was just pushed when the queue is one deep -- so that its LDS latency hides behind this step
                 R *f = fifo + ((size_t)slot * BLOCK + tid) * NACTC;
+                slot = slot + 1 == P.delay ? 0 : slot + 1;
+                const R *fn = fifo + ((size_t)slot * BLOCK + tid) * NACTC;
+                const bool one_deep = P.delay == 1;
                 if (DISCRETE) {
-                    const uint32_t old = (uint32_t)f[0];
-                    f[0] = (R)dact;
-                    dact = old;
+                    const R pushed = (R)dact;
+                    f[0] = pushed;
+                    dact = (uint32_t)pop[0];
+                    pop[0] = one_deep ? pushed : fn[0];
                 } else {
 #pragma unroll
-                    for (int i = 0; i < NACTC; ++i) { const R old = f[i]; f[i] = act[i]; act[i] = old; }
+                    for (int i = 0; i < NACTC; ++i) {
+                        const R pushed = act[i];
+                        f[i] = pushed;
+                        act[i] = pop[i];
+                        pop[i] = one_deep ? pushed : fn[i];
+                    }
                 }
-                slot = slot + 1 == P.delay ? 0 : slot + 1;
             }
             if (conv_dq<CONV>() && !P.dq_processor) dq_action_stage<SYS, CONV, R>(P, y, ang, act);
             R ho[NH];
@@ -1730,11 +1743,15 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
 #pragma unroll
             for (int j = 0; j < ND; ++j) y[j] = rs ? P.init[j] : y[j];
             ang = rs ? init_ang : ang;
-            if (FIFO && P.delay > 0 && rs) {  // DeadTimeProcessor.reset: the deque is refilled with the (zero) reset action
-                for (int d = 0; d < P.delay; ++d) {
+            if (FIFO && P.delay > 0) {  // DeadTimeProcessor.reset: the deque is refilled with the (zero) reset action
+                if (rs) {
+                    for (int d = 0; d < P.delay; ++d) {
 #pragma unroll
-                    for (int i = 0; i < NACTC; ++i) fifo[((size_t)d * BLOCK + tid) * NACTC + i] = R(0);
+                        for (int i = 0; i < NACTC; ++i) fifo[((size_t)d * BLOCK + tid) * NACTC + i] = R(0);
+                    }
                 }
+#pragma unroll
+                for (int i = 0; i < NACTC; ++i) pop[i] = rs ? R(0) : pop[i];
             }
         };
         stage_actions(0);
@@ -1800,9 +1817,13 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                     }
                 }
             } else {  // tail block or DeadTimeProcessor queue: ONE rolled copy of the run-time-checked step
+                // (the action of step s+1 is read from LDS before step s runs, as in the unrolled blocks: `an` / `dn` hold row 0 already)
 #pragma nounroll
                 for (int s = 0; s < sb; ++s) {
-                    read_action(b, s, ac, dc);
+                    dc = dn;
+#pragma unroll
+                    for (int i = 0; i < NACT; ++i) ac[i] = an[i];
+                    read_action(b, s + 1 < sb ? s + 1 : s, an, dn);
                     one_step(std::true_type{}, ac, dc, hb + (size_t)s * BLOCK * NHT, nullptr);
                 }
             }
