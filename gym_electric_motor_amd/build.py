@@ -5,7 +5,7 @@ Sources (gym_electric_motor_amd/csrc):
     gemx_inst.hip                       ONE instantiation unit, compiled once per (system, converter, dtype)
     gemx_capi.hip                       C ABI (include/gemx.h), validation, small kernels, dispatch
     gemx_refgen.hip                     device-side Wiener-process reference generation (gemx_refgen_*)
-The ten instantiation units + the C-ABI unit are compiled in parallel and linked with `hipcc -shared`.
+The 38 instantiation units (19 system/converter pairs x fp32, fp64) + the C-ABI and refgen units are compiled in parallel and linked with `hipcc -shared`.
 """
 import concurrent.futures as cf
 import hashlib
