@@ -2065,13 +2065,23 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     h->steps_total += (unsigned long long)K;
     a.err = h->err;
     if (h->linmap_state == 0) {  // once per handle: the electrical subsystem's one-step map (constant-speed loads)
-        h->linmap_state = -1;
         // (random initialisers may draw omega per episode: those handles keep the stage-by-stage solver)
-        if constexpr (linable<LOAD, SOLVER, IL, R>()) if (h->cfg.init_kind == GEMX_INIT_CONST) {
-            hipLaunchKernelGGL((linmap_kernel<SYS, SOLVER, R>), dim3(1), dim3(64), 0, st, params_of<R>(h), (R *)h->linmap_dev);
-            GEMX_HIP_TRY(hipGetLastError());
-            h->linmap_state = 1;
-            h->pf.lin_on = 1;
+        if constexpr (linable<LOAD, SOLVER, IL, R>()) {
+            hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(st, &capturing);
+            if (h->cfg.init_kind != GEMX_INIT_CONST) {
+                h->linmap_state = -1;
+            } else if (capturing == hipStreamCaptureStatusNone) {
+                // built and COMPLETED here, so that later launches on any stream (or from a captured graph) find it; a first launch
+                // that is itself being captured into a graph goes without the map and leaves the attempt to the next eager launch
+                hipLaunchKernelGGL((linmap_kernel<SYS, SOLVER, R>), dim3(1), dim3(64), 0, st, params_of<R>(h), (R *)h->linmap_dev);
+                GEMX_HIP_TRY(hipGetLastError());
+                GEMX_HIP_TRY(hipStreamSynchronize(st));
+                h->linmap_state = 1;
+                h->pf.lin_on = 1;
+            }
+        } else {
+            h->linmap_state = -1;
         }
     }
     a.P = params_of<R>(h);
