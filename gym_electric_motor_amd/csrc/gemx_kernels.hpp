@@ -1694,7 +1694,10 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             R act[MAX_ACT];
 #pragma unroll
             for (int i = 0; i < MAX_ACT; ++i) act[i] = i < NACT ? act_in[i] : R(0);
-            if (DISCRETE) { bad_action |= dact >= (uint32_t)ConvTraits<CONV>::NACTIONS; dact &= (uint32_t)(ConvTraits<CONV>::NACTIONS - 1); }
+            if (DISCRETE) {  // (with a loader wave the range check is ITS job: three instructions less in every step of this wave)
+                if (LW == 0) bad_action |= dact >= (uint32_t)ConvTraits<CONV>::NACTIONS;
+                dact &= (uint32_t)(ConvTraits<CONV>::NACTIONS - 1);
+            }
             // action stage, exactly as in compute_block(): [DqToAbcActionProcessor [DeadTimeProcessor [system(control_space)]]]
             if (conv_dq<CONV>() && P.dq_processor) dq_action_stage<SYS, CONV, R>(P, y, ang, act);
             if (FIFO && P.delay > 0) {
@@ -1756,6 +1759,10 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
         };
         stage_actions(0);
         if (n_ref > 0) stage_refs(0);
+        if (LW != 0 && DISCRETE) {  // block 0 has landed and is visible to the loader wave, which validates the action indices
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+        }
 #ifdef GEMX_TIMING
         unsigned long long tv = 0, tc = 0, tw = 0, T0 = clock64(), W0 = wall_clock64(), t0, t0b, t1, t2;
 #endif
@@ -1865,9 +1872,13 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
         // integrator they queue, in the CU's vector-memory path, behind the output waves' observation stores, and the integrator
         // -- the one wave whose instruction stream sets the launch time at small N -- stalled at their issue for ~1300 of its
         // ~7600 cycles per 12-step block (s_memtime probe, 16384 envs; profiles/r01f_pipe_probe.md).
+        // It also validates discrete actions (converters.py:204-206: an index outside the action space is an error): block b's rows
+        // are in LDS -- block 0 behind the initial barrier, the others staged and awaited here one iteration earlier.
 #ifdef GEMX_TIMING
         unsigned long long tl = 0, tb = 0;
 #endif
+        uint32_t bad = 0;
+        if (DISCRETE) __syncthreads();
         for (int b = 0; b < nb; ++b) {
 #ifdef GEMX_TIMING
             const unsigned long long l0 = clock64();
@@ -1875,8 +1886,13 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             if (b + 1 < nb) {
                 stage_actions(b + 1);
                 if (n_ref > 0) stage_refs(b + 1);
-                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): landed in LDS before the barrier publishes it
             }
+            if (DISCRETE) {
+                const unsigned char *rows = actb + (size_t)(b & 1) * DP * ROWB;
+                const int sb = steps_of(b);
+                for (int s = 0; s < sb; ++s) bad |= (uint32_t)rows[(size_t)s * ROWB + tid] >= (uint32_t)ConvTraits<CONV>::NACTIONS;
+            }
+            if (b + 1 < nb) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): landed in LDS before the barrier publishes it
 #ifdef GEMX_TIMING
             const unsigned long long l1 = clock64();
 #endif
@@ -1885,6 +1901,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             tl += l1 - l0; tb += clock64() - l1;
 #endif
         }
+        if (bad) atomicOr(a.err, 1u);
 #ifdef GEMX_TIMING
         if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 37)) {
             unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64) + (blockIdx.x ? 16 : 0);
@@ -1995,6 +2012,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
 #ifdef GEMX_TIMING
         unsigned long long tp = 0, tq = 0;
 #endif
+        if (LW != 0 && DISCRETE) __syncthreads();  // (the integrator's and the loader's initial barrier)
         for (int b = 0; b < nb; ++b) {
 #ifdef GEMX_TIMING
             const unsigned long long q0 = clock64();

@@ -836,6 +836,31 @@ def test_invalid_discrete_action_is_flagged():
     env.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("where", [None, (0, 5), (17, 100), (29, 127)])
+@pytest.mark.parametrize("shape", ["0", "1", "2"])
+def test_invalid_discrete_action_in_a_rollout_is_flagged(where, shape, monkeypatch):
+    """Pipelined kernels: the LOADER wave validates the staged action rows (first block, a middle block, the tail block)."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    monkeypatch.setenv("GEMX_PIPE_SHAPE", shape)
+    env = ga.make("Finite-CC-PMSM-v0", n_envs=128)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    acts = torch.randint(0, 8, (30, 128), device="cuda", generator=g, dtype=torch.uint8)
+    if where is not None:
+        acts[where[0], where[1]] = 8 + 3 * where[0]
+    env.rollout(acts)
+    assert "advance_pipe_kernel" in env.physical_system.last_launch()
+    if where is None:
+        env.physical_system.check_errors()
+    else:
+        with pytest.raises(AssertionError):
+            env.physical_system.check_errors()
+    env.close()
+
+
 def test_masked_reset():
     import torch
 
