@@ -414,6 +414,7 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
     static constexpr int NU = SYS == GEMX_SYS_DC_EXTEX ? 2 : 1;  // converter output voltages
     static constexpr int NH = NU;                                // ho: u [V]
     static constexpr int NVT = 0;                                // no per-action voltage table (see the synchronous machines)
+    static constexpr int row_slot(int j) { return j; }           // hand-off row of the pipelined kernel: logical index -> LDS slot
     static constexpr bool CONT = CONV == GEMX_CONV_CONT_4QC || CONV == GEMX_CONV_CONT_2X4QC;
     static_assert((CONV == GEMX_CONV_CONT_2X4QC || CONV == GEMX_CONV_FINITE_2X4QC) == (NU == 2), "system / converter width mismatch");
     // i_in = motor.i_in(currents): the current (dc_permanently_excited_motor.py:77-79, dc_series_motor.py:85-87),
@@ -519,6 +520,14 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     // pipelined kernel keeps it in an 8-entry LDS table (u_a, u_b, u_c, u_alpha, u_beta per switching state), computed ONCE per launch
     // with the very code below, instead of decoding the action and Clarke-transforming it in every step.
     static constexpr int NVT = (CONV == GEMX_CONV_FINITE_B6 && !IL) ? 5 : 0;
+    // Hand-off row of the pipelined kernel, logical order [omega, i_sd, i_sq, eps, sin, cos, u_a, u_b, u_c, u_sd, u_sq, done] -> LDS
+    // slots grouped the way the integrator's registers come out of its instructions, so that the three ds_write_b128 need (almost) no
+    // v_mov packing: [i_sd, i_sq (a v_pk_fma result pair), omega, eps | sin, cos (V_SIN / V_COS), u_sd, u_sq (pair) | u_a, u_b, u_c
+    // (the table entry's quad), done]
+    static constexpr int row_slot(int j) {
+        constexpr int slot[12] = {2, 0, 1, 3, 4, 5, 8, 9, 10, 6, 7, 11};
+        return slot[j];
+    }
     static __device__ __forceinline__ void action_entry(const DevParams<R> &P, uint32_t dact, R (&e)[8]) {
         const R zero[MAX_ACT] = {R(0), R(0), R(0), R(0), R(0), R(0)};
         b6_voltages<CONV, false, R>(P, zero, dact, 0u, R(0), R(0), R(0), e[0], e[1], e[2]);
@@ -616,6 +625,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     }
     // per-action voltage table of the pipelined kernel (32 entries: u_a, u_b, u_c, u_alpha, u_beta, u_e), as for Stepper<GEMX_SYS_SYNC>
     static constexpr int NVT = CONV == GEMX_CONV_FINITE_B6_4QC ? 6 : 0;
+    static constexpr int row_slot(int j) { return j; }
     static __device__ __forceinline__ void action_entry(const DevParams<R> &P, uint32_t dact, R (&e)[8]) {
         const R zero[MAX_ACT] = {R(0), R(0), R(0), R(0), R(0), R(0)};
         voltages(P, zero, dact, e[0], e[1], e[2], e[5]);
@@ -681,6 +691,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     static constexpr int NH = 7;  // ho: sin, cos of the last segment-start field angle, u_a, u_b, u_c, u_alpha, u_beta
     // per-action voltage table of the pipelined kernel, as for the synchronous machines (Stepper<GEMX_SYS_SYNC>::action_entry)
     static constexpr int NVT = (CONV == GEMX_CONV_FINITE_B6 && !IL) ? 5 : 0;
+    static constexpr int row_slot(int j) { return j; }
     static __device__ __forceinline__ void action_entry(const DevParams<R> &P, uint32_t dact, R (&e)[8]) {
         const R zero[MAX_ACT] = {R(0), R(0), R(0), R(0), R(0), R(0)};
         b6_voltages<CONV, false, R>(P, zero, dact, 0u, R(0), R(0), R(0), e[0], e[1], e[2]);
@@ -763,6 +774,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     //     u_sa, u_sb, u_sc; u_rd, u_re, u_rf (rotor-fixed three-phase frame)
     static constexpr int NH = 10;
     static constexpr int NVT = 0;
+    static constexpr int row_slot(int j) { return j; }
     static constexpr int B6 = CONV == GEMX_CONV_CONT_2XB6 ? GEMX_CONV_CONT_B6 : GEMX_CONV_FINITE_B6;
     template <bool NS1 = false, bool LIN = false, bool TAB = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[5], AngT &ang, uint32_t &sw, const R (&act)[MAX_ACT],
@@ -1733,15 +1745,15 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             }
             const bool done = ST::state_done(P, y, ho) & check_default;
 #pragma unroll
-            for (int j = 0; j < ND; ++j) row[j] = y[j];
+            for (int j = 0; j < ND; ++j) row[ST::row_slot(j)] = y[j];
             if (HAS_ANGLE) {
                 R bits;
                 memcpy(&bits, &ang, sizeof(R));
-                row[ND] = bits;
+                row[ST::row_slot(ND)] = bits;
             }
 #pragma unroll
-            for (int j = 0; j < NH; ++j) row[ND + (HAS_ANGLE ? 1 : 0) + j] = ho[j];
-            row[NHT - 1] = done ? R(1) : R(0);
+            for (int j = 0; j < NH; ++j) row[ST::row_slot(ND + (HAS_ANGLE ? 1 : 0) + j)] = ho[j];
+            row[ST::row_slot(NHT - 1)] = done ? R(1) : R(0);
             const bool rs = done & auto_reset;  // `if terminated: env.reset()`; switching state survives
 #pragma unroll
             for (int j = 0; j < ND; ++j) y[j] = rs ? P.init[j] : y[j];
@@ -1914,15 +1926,15 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
         auto one_row = [&](const R (&row)[NHT], int rs) {
             R y[ND], ho[NH], obs[NOUT];
 #pragma unroll
-            for (int j = 0; j < ND; ++j) y[j] = row[j];
+            for (int j = 0; j < ND; ++j) y[j] = row[ST::row_slot(j)];
             AngT ang = AngT(0);
             if (HAS_ANGLE) {
-                const R bits = row[ND];
+                const R bits = row[ST::row_slot(ND)];
                 memcpy(&ang, &bits, sizeof(R));
             }
 #pragma unroll
-            for (int j = 0; j < NH; ++j) ho[j] = row[ND + (HAS_ANGLE ? 1 : 0) + j];
-            const R dn = row[NHT - 1];
+            for (int j = 0; j < NH; ++j) ho[j] = row[ST::row_slot(ND + (HAS_ANGLE ? 1 : 0) + j)];
+            const R dn = row[ST::row_slot(NHT - 1)];
             ST::observe(P, y, ang, ho, obs);
             if (aos) {
 #pragma unroll
