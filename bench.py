@@ -4,29 +4,40 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" = one control step (PhysicalSystem.simulate) of ALL envs of the job.  Default workload = BASELINE.json
-configs[2], the config the metric ("batched PMSM") is quoted on: Finite-CC-PMSM-v0 (Finite-B6C + dq transform),
-16384 envs per GPU, RK4, fp32, default SquaredConstraint(i_sd, i_sq) done mask with in-kernel auto-reset,
-uniformly random discrete actions resident in HBM (synthetic).  tau = 1e-4 as the metric line states (the env's
-own default is 1e-5; the arithmetic, hence the throughput, does not depend on tau).
+One bench "step" = ONE launch of the fused hot path (`gemx_rollout`) over one batch of synthetic input: `--steps-per-launch`
+(default 1000) control steps (PhysicalSystem.simulate) of ALL envs of the job, every step's observation row [N, S_out] and done byte
+written to HBM.  So `--steps 20 --warmup 5` = 20 timed launches after 5 untimed ones, `ms_per_step` = milliseconds per launch and
+`value` = total envs x steps_per_launch x steps / wall time.  (Round 1 mapped `--steps` to control steps, which made the driver's
+`--steps 20` a single 20-step launch: launch-latency bound, 5 % of the HBM roofline; the kernel needs ~200 us launches to show its
+steady state.)
 
-Timed region: exactly K steps = ceil(K / chunk) launches of the fused advance kernel (`gemx_rollout`, chunk
-steps per launch, every step's observation row [N, S_out] and done byte written to HBM), bracketed by barrier +
-torch.cuda.synchronize() on both sides; wall time = max over ranks; value = total envs * K / wall time.
-Multi-GPU: envs are independent -> each rank steps its own shard, no data-path collective ("scaling": "weak").
+Default workload = BASELINE.json configs[2], the config the metric ("batched PMSM") is quoted on: Finite-CC-PMSM-v0 (Finite-B6C +
+dq transform), 16384 envs per GPU, RK4, fp32, default SquaredConstraint(i_sd, i_sq) done mask with in-kernel auto-reset, uniformly
+random discrete actions resident in HBM (synthetic).  tau = 1e-4 as the metric line states (the env's own default is 1e-5; the
+arithmetic, hence the throughput, does not depend on tau).
 
-Extra objects in the JSON line:
-  roofline     : HBM roofline of the dominant kernel (advance_kernel): algorithmic bytes per launch / mean launch
-                 duration measured here with HIP events on the launch stream; peak = 8000 GB/s (MI355X spec).
-  cpu_baseline : oracle/gemx_oracle.c (scalar fp64 restatement of the reference algorithm, "port") timed on ONE host
-                 core on a bounded sample of the same workload.
-  single_step  : the same workload advanced by one launch per control step (closed-loop RL usage), informational.
-  at_scale     : the same kernel at a larger batch (what the chip does when it is full), informational.
+Timed region: exactly K launches bracketed by barrier + torch.cuda.synchronize() on both sides; wall time = max over ranks.
+Multi-GPU: envs are independent -> each rank steps its own shard, no data-path collective ("scaling": "weak").  Without WORLD_SIZE in
+the environment `--gpus N` (N > 1) spawns its own N ranks (torch.multiprocessing, one per GPU, RCCL on 127.0.0.1).
+`--gather chunk|step` additionally times the batched-return path: one RCCL all-gather of each launch's [K, n_local, S_out]
+observation chunk (+ done bytes) / of every step's [n_local, S_out] rows; reported under "gather" beside the gather-off `value`.
+
+Extra objects in the JSON line (rank 0):
+  roofline            HBM roofline of the dominant kernel: algorithmic bytes per launch / mean launch duration measured HERE with HIP
+                      events on the launch stream around the K timed launches; peak = 8000 GB/s (MI355X spec); traffic = PMC-measured
+                      HBM bytes per launch of this exact (workload, envs, steps_per_launch) from profiles/hbm_traffic.json.
+  cpu_baseline        oracle/gemx_oracle.c (scalar fp64 restatement, "port") timed on ONE host core on a bounded sample of the same
+                      workload, plus the REFERENCE's own Python path as recorded by tools/cpu_reference_bench.py (fields, not prose).
+  headline_no_linmap  the same launches with GEMX_LINMAP=0 (RK4 evaluated stage by stage instead of through the one-step affine map).
+  single_step / single_step_graph   one launch per control step (closed-loop RL usage), eager and replayed from a HIP graph.
+  configs             BASELINE configs 2 and 4 (PermExDc 4096 envs Euler; SCIM 65536 envs RK4) through the same measurement.
+  at_scale            the headline kernel with the chip full (1M envs).
 """
 import argparse
 import json
 import math
 import os
+import socket
 import sys
 import time
 
@@ -69,76 +80,113 @@ def make_actions(torch, ps, K, n, device, seed):
     return torch.rand((K, n, ps._n_act), device=device, generator=g, dtype=torch.float32) * 2 - 1
 
 
-def run_fused(torch, env, acts, obs, done, K, chunk, events=False):
-    """K steps as ceil(K/chunk) launches.  With events: ONE pair of HIP events on the launch stream around the run of full-chunk
-    launches (an event pair per launch adds two marker packets, ~10 us, to every 140-us kernel) -> (e0, e1, n_full_launches)."""
-    n_full = K // chunk
-    e0 = e1 = None
-    k = i = 0
-    while k < K:
-        c = min(chunk, K - k)
-        if events and i == 0:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-        env.rollout(acts[k % acts.shape[0] : k % acts.shape[0] + c], obs_out=obs[:c], done_out=done[:c])
-        i += 1
-        if events and i == n_full:
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record()
-        k += c
-    return (e0, e1, n_full) if events else None
+class Timed:
+    """wall seconds (max over ranks), mean device ms per launch (HIP events on the launch stream)."""
+
+    def __init__(self, wall, launch_ms):
+        self.wall, self.launch_ms = wall, launch_ms
 
 
-def measure(torch, dist, env, w, n_local, K, W, chunk, device, world, seed):
+def measure(torch, dist, env, n_local, steps, warmup, spl, device, world, seed, gather="off", gd=None):
+    """`warmup` untimed + `steps` timed launches of `spl` control steps each.  gather: off | chunk | step (see module docstring)."""
     ps = env.physical_system
-    chunk = max(1, min(chunk, K))
-    acts = make_actions(torch, ps, chunk * max(1, min(4, math.ceil(K / chunk))), n_local, device, seed)
-    obs = torch.empty((chunk, n_local, ps._n_out), dtype=torch.float32, device=device)
-    done = torch.empty((chunk, n_local), dtype=torch.uint8, device=device)
+    n_act_bufs = max(1, min(4, steps))
+    acts = make_actions(torch, ps, spl * n_act_bufs, n_local, device, seed)
+    obs = torch.empty((spl, n_local, ps._n_out), dtype=torch.float32, device=device)
+    done = torch.empty((spl, n_local), dtype=torch.uint8, device=device)
     env.reset()
-    run_fused(torch, env, acts, obs, done, W, chunk)  # warmup (untimed)
+
+    def launch(i):
+        a0 = (i % n_act_bufs) * spl
+        if gather == "step":  # batched return after EVERY control step: one launch + one all-gather per step
+            for k in range(spl):
+                o = ps.simulate(acts[a0 + k])
+                gd.gather_observations(o, ps.done)
+        else:
+            env.rollout(acts[a0 : a0 + spl], obs_out=obs, done_out=done)
+            if gather == "chunk":
+                gd.gather_rollout(obs, done)
+
+    for i in range(warmup):
+        launch(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev = run_fused(torch, env, acts, obs, done, K, chunk, events=True)
+    e0.record()
+    for i in range(steps):
+        launch(i)
+    e1.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        if dist.get_backend() == "gloo":
+            t = torch.tensor([dt], dtype=torch.float64)
+        else:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    e0, e1, n_full = ev
-    launch_ms = e0.elapsed_time(e1) / n_full if n_full else dt * 1e3 / max(1, math.ceil(K / chunk))
-    assert torch.isfinite(obs).all()
-    return dt, launch_ms, chunk
+    if gather != "step":
+        assert torch.isfinite(obs).all()
+    return Timed(dt, e0.elapsed_time(e1) / steps)
 
 
-def measure_single_step(torch, env, w, n_local, K, W, device, seed):
+def measure_single_step(torch, env, n_local, K, W, device, seed, graph_steps=0):
+    """One gemx_step launch per control step.  graph_steps > 0: `graph_steps` launches captured into ONE HIP graph and replayed."""
     ps = env.physical_system
-    Ka = min(K, 256)
+    Ka = 256
     acts = make_actions(torch, ps, Ka, n_local, device, seed)
     env.reset()
     for k in range(W):
         ps.simulate(acts[k % Ka])
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for k in range(K):
-        ps.simulate(acts[k % Ka])
-    e1.record()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return dt, e0.elapsed_time(e1) / K
+    if graph_steps:
+        S = min(graph_steps, Ka)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for k in range(3):
+                ps.simulate(acts[k])
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for k in range(S):
+                ps.simulate(acts[k])
+        torch.cuda.synchronize()
+        reps = max(1, K // S)
+        graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(reps):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n = reps * S
+    else:
+        t0 = time.perf_counter()
+        e0.record()
+        for k in range(K):
+            ps.simulate(acts[k % Ka])
+        e1.record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n = K
+    assert torch.isfinite(ps._obs).all()
+    return dt / n, e0.elapsed_time(e1) / n, n
 
 
 def cpu_baseline(w, budget_s=12.0):
-    """The oracle (scalar fp64 C restatement of the reference algorithm) on ONE host core, bounded sample."""
+    """The oracle (scalar fp64 C restatement of the reference algorithm) on ONE host core, bounded sample; beside it the reference's
+    own Python path as tools/cpu_reference_bench.py recorded it in the build container (profiles/cpu_reference.json)."""
     import numpy as np
 
     from oracle import oracle as orc
@@ -165,23 +213,38 @@ def cpu_baseline(w, budget_s=12.0):
     t0 = time.perf_counter()
     orc.rollout_many(p, a)
     dt = time.perf_counter() - t0
-    return dict(value=n_env2 * K / dt, unit="env-steps/s", cores=1, kind="port",
-                sample=f"{n_env2} envs x {K} steps of the same workload ({w['env_id']}, {w['solver']}, episodic) through "
-                       f"oracle/gemx_oracle.c (fp64, gcc -O2), {dt:.1f} s on 1 of {os.cpu_count()} host cores; the reference's own "
-                       "Python path measured 8.7e3 (dopri5) / 1.2e4 (Euler) env-steps/s on 1 core (BASELINE.md)")
+    out = dict(value=n_env2 * K / dt, unit="env-steps/s", cores=1, kind="port", host_cores=os.cpu_count(),
+               sample=f"{n_env2} envs x {K} steps of the same workload ({w['env_id']}, {w['solver']}, episodic) through "
+                      f"oracle/gemx_oracle.c (fp64, gcc -O2), {dt:.1f} s on 1 of {os.cpu_count()} host cores")
+    ref_path = os.path.join(REPO, "profiles", "cpu_reference.json")
+    if os.path.exists(ref_path):
+        try:
+            ref = json.load(open(ref_path))
+            out["reference"] = {"source": "profiles/cpu_reference.json (tools/cpu_reference_bench.py: the reference's own Python path, "
+                                          "timed in the build container, which has /root/reference; the GPU box has not)",
+                                "host": ref.get("host"), "env_steps_per_s": ref.get("results", {}).get(w["env_id"])}
+        except Exception as e:  # a malformed record must not kill the bench line
+            out["reference"] = {"error": repr(e)}
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)
-    ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="pmsm")
-    ap.add_argument("--envs-per-gpu", type=int, default=None)
-    ap.add_argument("--chunk", type=int, default=1000, help="control steps fused into one launch")
-    ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / single_step / at_scale legs")
-    args = ap.parse_args()
+def roofline_of(w, n_local, spl, launch_ms, kernel_desc, workload_key):
+    b_step = bytes_per_env_step_fused(w)
+    launch_bytes = n_local * (spl * b_step + 2 * 4 * w["s_ode"])
+    achieved = launch_bytes / (launch_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(f"{workload_key}:{n_local}:{spl}")
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic, "kernel": kernel_desc, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": launch_bytes,
+            "bytes_per_env_step": b_step}
 
+
+def worker(args, rank, world, local_rank, backend):
     import torch
     import torch.distributed as dist
 
@@ -189,73 +252,77 @@ def main():
     from gym_electric_motor_amd import distributed as gd
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
-    rank, world, local_rank = gd.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev if args.oversubscribe else local_rank
+    if dev_index >= ndev:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {ndev} are visible; run with --gpus <= {ndev}, or pass "
+                         "--oversubscribe to put several ranks on one GPU (gloo control plane; a functional check, not a measurement)")
+    device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     w = dict(WORKLOADS[args.workload], key=args.workload)
-    n_local = args.envs_per_gpu or w["envs"]
+    n_local = args.envs_per_gpu or (32768 if (args.workload == "pmsm" and world == 8) else w["envs"])  # BASELINE config 5: 8 x 32768
     n_total = n_local * world
-    K, W = args.steps, args.warmup
+    K, W, spl = args.steps, args.warmup, args.steps_per_launch
 
-    env = make_env(ga, w, n_local, local_rank)
-    dt, launch_ms, chunk = measure(torch, dist, env, w, n_local, K, W, args.chunk, device, world, seed=1234 + rank)
+    env = make_env(ga, w, n_local, dev_index)
+    t = measure(torch, dist, env, n_local, K, W, spl, device, world, seed=1234 + rank)
     kernel_desc = env.physical_system.last_launch()
+    same_shard = None
+    if n_local != w["envs"] and args.envs_per_gpu is None:  # --gpus 8 default = BASELINE config 5 (8 x 32768): also the N=1 shard size
+        env_s = make_env(ga, w, w["envs"], dev_index)
+        ts = measure(torch, dist, env_s, w["envs"], K, W, spl, device, world, seed=1234 + rank)
+        env_s.close()
+        same_shard = {"envs_per_gpu": w["envs"], "value": w["envs"] * world * spl * K / ts.wall, "unit": "env-steps/s",
+                      "ms_per_step": ts.wall / K * 1e3, "note": "same per-GPU shard as the --gpus 1/2/4 lines (strict weak scaling)"}
+    gathered = None
+    if args.gather != "off" and world > 1 and backend == "gloo":
+        gathered = {"skipped": "oversubscribed ranks run a gloo control plane; the device all-gather needs RCCL (one rank per GPU)"}
+    elif args.gather != "off":
+        modes = ["chunk", "step"] if args.gather == "both" else [args.gather]
+        gathered = {}
+        for mode in modes:
+            Kg = K if mode == "chunk" else max(1, min(K, 2))
+            spl_g = spl if mode == "chunk" else min(spl, 200)
+            tg = measure(torch, dist, env, n_local, Kg, min(W, 2), spl_g, device, world, seed=4321 + rank, gather=mode, gd=gd)
+            per_call = n_local * (spl_g if mode == "chunk" else 1) * (4 * w["s_out"] + 1)
+            gathered[mode] = {"value": n_total * spl_g * Kg / tg.wall, "unit": "env-steps/s", "steps": Kg, "steps_per_launch": spl_g,
+                              "ms_per_step": tg.wall / Kg * 1e3, "bytes_gathered_per_rank_per_call": per_call * world,
+                              "collective": f"{backend} all_gather_into_tensor, world {world}"}
     env.close()
 
     if rank == 0:
-        b_step = bytes_per_env_step_fused(w)
-        launch_bytes = n_local * (chunk * b_step + 2 * 4 * w["s_ode"])
-        achieved = launch_bytes / (launch_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(f"{args.workload}:{n_local}:{chunk}")
-            except Exception:
-                traffic = None
         out = {
             "metric": "env-steps/sec (batched PMSM, tau=1e-4)" if args.workload == "pmsm" else f"env-steps/sec ({args.workload})",
-            "value": n_total * K / dt,
+            "value": n_total * spl * K / t.wall,
             "unit": "env-steps/s",
             "n_gpus": world,
             "steps": K,
             "warmup": W,
-            "ms_per_step": dt / K * 1e3,
+            "ms_per_step": t.wall / K * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{w['desc']}; {n_local} envs/GPU x {world} GPU(s); fused rollout, {chunk} steps/launch, "
-                                   "obs [K,N,14] rows + done bytes written every step",
+            "config": {"workload": f"{w['desc']}; {n_local} envs/GPU x {world} GPU(s); one bench step = one fused launch of {spl} control "
+                                   "steps, obs [K,N,S_out] rows + done bytes written for every control step",
                        "env_id": w["env_id"], "envs_per_gpu": n_local, "solver": w["solver"], "tau": w["tau"],
-                       "steps_per_launch": chunk, "parallelism": f"env-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "kernel": kernel_desc, "launch_ms": launch_ms,
-                         "algorithmic_bytes_per_launch": launch_bytes, "bytes_per_env_step": b_step},
+                       "steps_per_launch": spl, "control_steps_timed": spl * K,
+                       "parallelism": f"env-sharded x{world}, no data-path collective", "world_size": world,
+                       "backend": (backend if world > 1 else None), "oversubscribed": bool(args.oversubscribe and world > ndev)},
+            "roofline": roofline_of(w, n_local, spl, t.launch_ms, kernel_desc, args.workload),
         }
+        if gathered is not None:
+            out["gather"] = gathered
+        if same_shard is not None:
+            out["same_shard_as_n1"] = same_shard
         if not args.no_extras and world == 1:
-            out["cpu_baseline"] = cpu_baseline(w)
-            # closed-loop usage: one launch per control step
-            env1 = make_env(ga, w, n_local, local_rank)
-            Ks = min(K, 2000)
-            dts, ms1 = measure_single_step(torch, env1, w, n_local, Ks, min(W, 100), device, seed=99)
-            env1.close()
-            b1 = bytes_per_env_step_single(w)
-            out["single_step"] = {"value": n_local * Ks / dts, "unit": "env-steps/s", "ms_per_step": dts / Ks * 1e3,
-                                  "device_ms_per_step": ms1, "achieved_GBps": n_local * b1 / (ms1 * 1e-3) / 1e9,
-                                  "bytes_per_env_step": b1, "note": "one gemx_step launch per control step (launch-bound at this N)"}
-            # the same kernel with the chip full
-            n_big = 2 ** 20
-            c_big = 100
-            envb = make_env(ga, w, n_big, local_rank)
-            dtb, msb, c_big = measure(torch, dist, envb, w, n_big, 2 * c_big, c_big, c_big, device, 1, seed=7)
-            envb.close()
-            bb = n_big * (c_big * b_step + 2 * 4 * w["s_ode"])
-            out["at_scale"] = {"envs": n_big, "steps_per_launch": c_big, "value": n_big * 2 * c_big / dtb, "unit": "env-steps/s",
-                               "launch_ms": msb, "achieved_GBps": bb / (msb * 1e-3) / 1e9, "frac_of_peak": bb / (msb * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+            extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out)
         elif not args.no_extras:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
@@ -263,6 +330,105 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out):
+    """Rank 0, N = 1 only: the CPU baseline and the informational legs (each bounded to a few seconds)."""
+    out["cpu_baseline"] = cpu_baseline(w)
+    # the same launches without the one-step affine map (general stage-by-stage RK4)
+    os.environ["GEMX_LINMAP"] = "0"
+    try:
+        env0 = make_env(ga, w, n_local, dev_index)
+        t0 = measure(torch, dist, env0, n_local, min(args.steps, 10), 2, spl, device, 1, seed=77)
+        desc0 = env0.physical_system.last_launch()
+        env0.close()
+    finally:
+        del os.environ["GEMX_LINMAP"]
+    r0 = roofline_of(w, n_local, spl, t0.launch_ms, desc0, args.workload + "/nolinmap")
+    out["headline_no_linmap"] = {"value": n_local * spl * min(args.steps, 10) / t0.wall, "unit": "env-steps/s", "launch_ms": t0.launch_ms,
+                                 "achieved_GBps": r0["achieved"], "frac_of_peak": r0["frac"], "env": "GEMX_LINMAP=0"}
+    # closed-loop usage: one launch per control step, eager and from a HIP graph
+    b1 = bytes_per_env_step_single(w)
+    env1 = make_env(ga, w, n_local, dev_index)
+    host_s, dev_ms, n1 = measure_single_step(torch, env1, n_local, 2000, 100, device, seed=99)
+    out["single_step"] = {"value": n_local / host_s, "unit": "env-steps/s", "ms_per_step": host_s * 1e3, "device_ms_per_step": dev_ms,
+                          "achieved_GBps": n_local * b1 / (dev_ms * 1e-3) / 1e9, "bytes_per_env_step": b1, "steps": n1,
+                          "note": "one gemx_step launch per control step, eager"}
+    host_s, dev_ms, n1 = measure_single_step(torch, env1, n_local, 4096, 100, device, seed=99, graph_steps=64)
+    out["single_step_graph"] = {"value": n_local / host_s, "unit": "env-steps/s", "ms_per_step": host_s * 1e3, "device_ms_per_step": dev_ms,
+                                "achieved_GBps": n_local * b1 / (dev_ms * 1e-3) / 1e9, "bytes_per_env_step": b1, "steps": n1,
+                                "note": "64 gemx_step launches captured into one HIP graph (torch.cuda.CUDAGraph) and replayed"}
+    env1.close()
+    # BASELINE configs 2 and 4 through the same measurement
+    out["configs"] = {}
+    for key in ("permexdc", "scim"):
+        if key == args.workload:
+            continue
+        wc = dict(WORKLOADS[key], key=key)
+        envc = make_env(ga, wc, wc["envs"], dev_index)
+        tc = measure(torch, dist, envc, wc["envs"], 10, 3, spl, device, 1, seed=5)
+        rc = roofline_of(wc, wc["envs"], spl, tc.launch_ms, envc.physical_system.last_launch(), key)
+        envc.close()
+        out["configs"][key] = {"workload": wc["desc"], "envs": wc["envs"], "steps_per_launch": spl, "value": wc["envs"] * spl * 10 / tc.wall,
+                               "unit": "env-steps/s", "roofline": rc}
+    # the headline kernel with the chip full
+    n_big, c_big = 2 ** 20, 100
+    envb = make_env(ga, w, n_big, dev_index)
+    tb = measure(torch, dist, envb, n_big, 4, 2, c_big, device, 1, seed=7)
+    envb.close()
+    bb = n_big * (c_big * bytes_per_env_step_fused(w) + 2 * 4 * w["s_ode"])
+    out["at_scale"] = {"envs": n_big, "steps_per_launch": c_big, "value": n_big * 4 * c_big / tb.wall, "unit": "env-steps/s",
+                       "launch_ms": tb.launch_ms, "achieved_GBps": bb / (tb.launch_ms * 1e-3) / 1e9,
+                       "frac_of_peak": bb / (tb.launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+
+
+def _spawned(local_rank, args, world, port, backend):
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    worker(args, local_rank, world, local_rank, backend)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20, help="timed launches (one bench step = one fused launch)")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed launches")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="pmsm")
+    ap.add_argument("--envs-per-gpu", type=int, default=None)
+    ap.add_argument("--steps-per-launch", "--chunk", dest="steps_per_launch", type=int, default=1000,
+                    help="control steps fused into one launch")
+    ap.add_argument("--gather", choices=["off", "chunk", "step", "both"], default="off",
+                    help="also time the batched-return path: all-gather of each launch's observation chunk / of every step's rows")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="allow more ranks than visible GPUs (ranks share GPUs, gloo control plane): functional check only")
+    ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / single_step / configs / at_scale legs")
+    args = ap.parse_args()
+    if args.steps < 1 or args.warmup < 0 or args.steps_per_launch < 2:
+        raise SystemExit("bench.py: --steps >= 1, --warmup >= 0, --steps-per-launch >= 2")
+
+    world_env = os.environ.get("WORLD_SIZE")
+    backend = "gloo" if args.oversubscribe else "nccl"
+    if world_env is not None:  # launched by torchrun / the driver: one rank per process already
+        world = int(world_env)
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+        worker(args, int(os.environ.get("RANK", "0")), world, int(os.environ.get("LOCAL_RANK", "0")), backend)
+    elif args.gpus == 1:
+        worker(args, 0, 1, 0, backend)
+    else:  # self-spawn: one process per GPU
+        import torch
+        import torch.multiprocessing as mp
+
+        ndev = torch.cuda.device_count()
+        if args.gpus > ndev and not args.oversubscribe:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible; pass --oversubscribe to share GPUs between "
+                             "ranks (gloo control plane; a functional check, not a measurement)")
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        mp.spawn(_spawned, args=(args, args.gpus, port, backend), nprocs=args.gpus, join=True)
 
 
 if __name__ == "__main__":

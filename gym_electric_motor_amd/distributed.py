@@ -77,6 +77,28 @@ def gather_observations(obs_local, done_local=None, n_total=None, group=None):
     return obs_all, done_all
 
 
+def gather_rollout(obs_chunk, done_chunk=None, group=None):
+    """All-gather one fused launch's outputs: `[K, n_local, S_out]` observation chunks (+ `[K, n_local]` done bytes) of every rank
+    -> `[W, K, n_local, S_out]` (+ `[W, K, n_local]`) on every rank, RANK-MAJOR and zero-copy: row `[r, k, i]` is env
+    `shard_range(n_total, r, W)[0] + i` at control step k.  (Interleaving the shards into `[K, n_total, S_out]` would cost a second
+    pass over W times the chunk; a consumer that needs that view indexes `[:, k]` instead.)  All ranks must hold equally sized shards
+    (bench.py / make_sharded with n_total % W == 0); unequal shards go through gather_observations per step."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return obs_chunk.unsqueeze(0), (done_chunk.unsqueeze(0) if done_chunk is not None else None)
+    world = dist.get_world_size(group)
+
+    def _gather(x):
+        x = x.contiguous()
+        out = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out.view((world * x.shape[0],) + tuple(x.shape[1:])), x, group=group)
+        return out
+
+    return _gather(obs_chunk), (_gather(done_chunk) if done_chunk is not None else None)
+
+
 def make_sharded(env_id, n_envs_total, rank, world, device, **kwargs):
     """This rank's shard of a `n_envs_total`-env batched environment."""
     from .envs import make

@@ -1,21 +1,36 @@
 #!/bin/bash
 # Collects the judged artefacts of one round on the GPU box (run through gpurun from the repo root):
-#   tools/collect_profiles.sh r01f   ->  gpurun_out/<tag>_*
+#   tools/collect_profiles.sh r02a [quick]  ->  gpurun_out/<tag>_*
+# bench.py: one bench step = one fused launch of 1000 control steps; default 20 timed launches after 5.
 set -u
 TAG=${1:-rXX}
+QUICK=${2:-}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/${TAG}_bench.log 2>&1
 tail -1 $OUT/${TAG}_bench.log > $OUT/${TAG}_bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $R/bench.py --no-extras > /tmp/ks.log 2>&1
-grep "^{\"metric\"" /tmp/ks.log | tail -1 > $OUT/${TAG}_bench_under_rocprof.json
-cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --no-extras --steps 3000 --warmup 1000 > /tmp/pmc_$c.log 2>&1
-  python $R/tools/pmc_sum.py /tmp/pmc_$c advance >> $OUT/${TAG}_pmc_raw.txt
+for WL in pmsm permexdc scim; do
+  rm -rf /tmp/ks_$WL
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$WL -- python $R/bench.py --no-extras --workload $WL > /tmp/ks_$WL.log 2>&1
+  grep "^{\"metric\"" /tmp/ks_$WL.log | tail -1 > $OUT/${TAG}_bench_under_rocprof_$WL.json
+  cp $(find /tmp/ks_$WL -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats_$WL.csv
 done
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d /tmp/pmc_sq -- python $R/bench.py --no-extras --steps 3000 --warmup 1000 > /tmp/pmc_sq.log 2>&1
-python $R/tools/pmc_sum.py /tmp/pmc_sq advance >> $OUT/${TAG}_pmc_raw.txt
+# a SHORT launch (20 control steps per launch): kernel-trace durations vs the HIP-event figure
+rm -rf /tmp/ks_short
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_short -- python $R/bench.py --no-extras --steps-per-launch 20 --steps 200 --warmup 20 > /tmp/ks_short.log 2>&1
+grep "^{\"metric\"" /tmp/ks_short.log | tail -1 > $OUT/${TAG}_bench_under_rocprof_short20.json
+cp $(find /tmp/ks_short -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats_short20.csv
+[ "$QUICK" = "quick" ] && exit 0
+for WL in pmsm permexdc scim; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_$c
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --no-extras --workload $WL --steps 5 --warmup 2 > /tmp/pmc_$c.log 2>&1
+    echo "$WL $c $(python $R/tools/pmc_sum.py /tmp/pmc_$c advance)" >> $OUT/${TAG}_pmc_raw.txt
+  done
+done
+rm -rf /tmp/pmc_sq
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d /tmp/pmc_sq -- python $R/bench.py --no-extras --steps 5 --warmup 2 > /tmp/pmc_sq.log 2>&1
+echo "pmsm SQ $(python $R/tools/pmc_sum.py /tmp/pmc_sq advance)" >> $OUT/${TAG}_pmc_raw.txt
 python $R/tools/bench_matrix.py > $OUT/${TAG}_matrix.md 2>/dev/null
