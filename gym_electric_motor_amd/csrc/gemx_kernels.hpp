@@ -992,25 +992,27 @@ template <class ST, int NOUT, class R> __device__ __forceinline__ bool constrain
 
 extern __shared__ __attribute__((aligned(16))) unsigned char gemx_smem[];
 
-// Flush `sb` observation rows / done rows (control steps k0 .. k0+sb-1) of one 64-env workgroup from the LDS rings to
+// Flush `sb` observation rows / done rows (control steps k0 .. k0+sb-1) of one EB-env workgroup from the LDS rings to
 // the caller's tensors: 16-byte-per-lane stores over each row's contiguous span (AoS) or coalesced dword stores (SoA).
-template <int NOUT, class R>
+// EB = envs per workgroup (ring row length): BLOCK for the single-wave kernel, 16 / 32 / 64 for the pipelined one; `tid` is the lane.
+template <int NOUT, class R, int EB = BLOCK>
 __device__ __forceinline__ void flush_rings(const KArgs<R> &a, const R *ring, const unsigned char *donebuf, int k0, int sb, int tid,
                                             int64_t blk0, int rows, bool full, bool valid, int64_t env) {
     constexpr int VEC = 16 / sizeof(R);
-    constexpr int ROWV = BLOCK * NOUT / VEC;
+    constexpr int ROWV = EB * NOUT / VEC;
     typedef float v4f_t __attribute__((ext_vector_type(4)));
     typedef double v2d_t __attribute__((ext_vector_type(2)));
     using V = typename std::conditional<sizeof(R) == 4, v4f_t, v2d_t>::type;
     const int64_t N = a.N;
     const bool stream_out = a.K > 1;  // rollouts: non-temporal stores (see flush_rows_pipe); a single step's row is read next by the policy
+    const int el = tid < EB ? tid : EB - 1;  // this lane's env slot (lanes beyond EB duplicate the last env of the workgroup)
     if (a.P.obs_layout == GEMX_OBS_AOS) {
         if (a.obs_vec) {
             const int nvec = rows * NOUT / VEC;  // == ROWV for full blocks
 #pragma unroll 2
             for (int s = 0; s < sb; ++s) {
                 V *gv = reinterpret_cast<V *>(a.obs + ((int64_t)(k0 + s) * N + blk0) * NOUT);
-                const V *lv = reinterpret_cast<const V *>(ring + (size_t)s * BLOCK * NOUT);
+                const V *lv = reinterpret_cast<const V *>(ring + (size_t)s * EB * NOUT);
 #pragma unroll
                 for (int i = 0; i < (ROWV + BLOCK - 1) / BLOCK; ++i) {
                     const int idx = tid + i * BLOCK;
@@ -1021,29 +1023,30 @@ __device__ __forceinline__ void flush_rings(const KArgs<R> &a, const R *ring, co
                     }
                 }
                 for (int idx = nvec * VEC + tid; idx < rows * NOUT; idx += BLOCK)
-                    a.obs[((int64_t)(k0 + s) * N + blk0) * NOUT + idx] = ring[(size_t)s * BLOCK * NOUT + idx];
+                    a.obs[((int64_t)(k0 + s) * N + blk0) * NOUT + idx] = ring[(size_t)s * EB * NOUT + idx];
             }
         } else {
             for (int s = 0; s < sb; ++s)
                 for (int idx = tid; idx < rows * NOUT; idx += BLOCK)
-                    a.obs[((int64_t)(k0 + s) * N + blk0) * NOUT + idx] = ring[(size_t)s * BLOCK * NOUT + idx];
+                    a.obs[((int64_t)(k0 + s) * N + blk0) * NOUT + idx] = ring[(size_t)s * EB * NOUT + idx];
         }
     } else if (valid) {
         for (int s = 0; s < sb; ++s) {
 #pragma unroll
-            for (int j = 0; j < NOUT; ++j) a.obs[((int64_t)(k0 + s) * NOUT + j) * N + env] = ring[(s * NOUT + j) * BLOCK + tid];
+            for (int j = 0; j < NOUT; ++j) a.obs[((int64_t)(k0 + s) * NOUT + j) * N + env] = ring[(s * NOUT + j) * EB + el];
         }
     }
     if (a.done != nullptr) {
-        if (a.coop && full) {  // done rows are 64 contiguous bytes: 4 x 16-byte chunks per row
-            const int nchunk = sb * (BLOCK / 16);
+        if (a.coop && full) {  // done rows are EB contiguous bytes: EB / 16 chunks of 16 bytes per row
+            constexpr int CPD = EB / 16;
+            const int nchunk = sb * CPD;
             for (int idx = tid; idx < nchunk; idx += BLOCK) {
-                const int row = idx >> 2, col = idx & 3;
+                const int row = idx / CPD, col = idx - row * CPD;
                 *reinterpret_cast<uint4 *>(a.done + (int64_t)(k0 + row) * N + blk0 + col * 16) =
-                    *reinterpret_cast<const uint4 *>(donebuf + row * BLOCK + col * 16);
+                    *reinterpret_cast<const uint4 *>(donebuf + row * EB + col * 16);
             }
         } else if (valid) {
-            for (int s = 0; s < sb; ++s) a.done[(int64_t)(k0 + s) * N + env] = donebuf[s * BLOCK + tid];
+            for (int s = 0; s < sb; ++s) a.done[(int64_t)(k0 + s) * N + env] = donebuf[s * EB + el];
         }
     }
 }
@@ -1053,12 +1056,12 @@ __device__ __forceinline__ void flush_rings(const KArgs<R> &a, const R *ring, co
 // wait, 3 stores, a predicated 4th read, wait, store -- exposes the LDS latency twice per row: ~380 cycles per row on an otherwise idle
 // chip, where the stores themselves issue at 23 cycles each (tools/microbench_store.hip).  Lanes past the end of a row's last,
 // partial chunk repeat the row's final chunk (same address, same data) instead of branching around the store.
-template <int NOUT, int RPW, class R>
+template <int NOUT, int RPW, class R, int EB = BLOCK>
 __device__ __forceinline__ void flush_rows_pipe(const KArgs<R> &a, const R *ring, const unsigned char *donebuf, int k0, int tid, int64_t blk0) {
     constexpr int VEC = 16 / sizeof(R);
-    constexpr int ROWV = BLOCK * NOUT / VEC;            // 16-byte chunks per row
+    constexpr int ROWV = EB * NOUT / VEC;               // 16-byte chunks per row (EB envs)
     constexpr int NV = (ROWV + BLOCK - 1) / BLOCK;      // chunks per lane
-    static_assert((BLOCK * NOUT) % VEC == 0, "rows are whole 16-byte chunks");
+    static_assert((EB * NOUT) % VEC == 0, "rows are whole 16-byte chunks");
     typedef float v4f_t __attribute__((ext_vector_type(4)));
     typedef double v2d_t __attribute__((ext_vector_type(2)));
     using V = typename std::conditional<sizeof(R) == 4, v4f_t, v2d_t>::type;
@@ -1074,7 +1077,7 @@ __device__ __forceinline__ void flush_rows_pipe(const KArgs<R> &a, const R *ring
     auto chunk = [&](int i) { const int c = tid + i * BLOCK; return c > ROWV - 1 ? ROWV - 1 : c; };
     const int c0 = chunk(0), c1 = chunk(1), c2 = chunk(2), c3 = chunk(3), c4 = chunk(4), c5 = chunk(5);
     const V *lv = reinterpret_cast<const V *>(ring);
-    constexpr int RS = BLOCK * NOUT / VEC;  // chunks per ring row
+    constexpr int RS = EB * NOUT / VEC;  // chunks per ring row
     V b00, b01, b02, b03, b04, b05;
     V b10, b11, b12, b13, b14, b15;
     V b20, b21, b22, b23, b24, b25;
@@ -1139,12 +1142,13 @@ __device__ __forceinline__ void flush_rows_pipe(const KArgs<R> &a, const R *ring
         if constexpr (4 < NV) GEMX_ROW_STORE(&gv[c4], b34);
         if constexpr (5 < NV) GEMX_ROW_STORE(&gv[c5], b35);
     }
-    if (a.done != nullptr) {  // done rows are 64 contiguous bytes: 4 x 16-byte chunks per row
-        static_assert(RPW * (BLOCK / 16) <= BLOCK, "one pass");
+    if (a.done != nullptr) {  // done rows are EB contiguous bytes: EB / 16 chunks of 16 bytes per row
+        constexpr int CPD = EB / 16;
+        static_assert(RPW * CPD <= BLOCK, "one pass");
         typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
-        if (tid < RPW * (BLOCK / 16)) {
-            const int row = tid >> 2, col = tid & 3;
-            __builtin_nontemporal_store(*reinterpret_cast<const v4u_t *>(donebuf + row * BLOCK + col * 16),
+        if (tid < RPW * CPD) {
+            const int row = tid / CPD, col = tid - row * CPD;
+            __builtin_nontemporal_store(*reinterpret_cast<const v4u_t *>(donebuf + row * EB + col * 16),
                                         reinterpret_cast<v4u_t *>(a.done + (int64_t)(k0 + row) * N + blk0 + col * 16));
         }
     }
@@ -1195,14 +1199,15 @@ template <bool GENERAL, class R> __device__ __forceinline__ R reward_term(R o, R
     if (GENERAL && kind == 3) p = pow(dlt, power);
     return coef * p;
 }
-template <int NOUT, int RB, class R>
+template <int NOUT, int RB, class R, int EB = BLOCK>
 __device__ __forceinline__ void reward_apply(const KArgs<R> &a, const RewardRegs<R> &W, const R *ring, const unsigned char *donebuf, int k0,
                                              int row0, int nr, int tid, int64_t env, bool valid, const R (&rv)[RB][GEMX_MAX_REF]) {
     constexpr int HOT = RewardRegs<R>::HOT;
     static_assert(HOT >= GEMX_MAX_REF, "referenced states must be hot terms");
     const int64_t N = a.N;
     const bool aos = a.P.obs_layout == GEMX_OBS_AOS;
-    auto obs_at = [&](int row, int c) { return aos ? ring[((size_t)row * BLOCK + tid) * NOUT + c] : ring[((size_t)row * NOUT + c) * BLOCK + tid]; };
+    const int el = tid < EB ? tid : EB - 1;
+    auto obs_at = [&](int row, int c) { return aos ? ring[((size_t)row * EB + el) * NOUT + c] : ring[((size_t)row * NOUT + c) * EB + el]; };
     // the hot terms' observations and the done bytes of ALL rows first: RB * (HOT + 1) LDS reads in flight at once instead of one
     // exposed LDS latency per term (the output waves spent ~1250 cycles per row here, s_memtime probe)
     R oh[RB][HOT];
@@ -1212,7 +1217,7 @@ __device__ __forceinline__ void reward_apply(const KArgs<R> &a, const RewardRegs
         const int row = row0 + (s < nr ? s : 0);
 #pragma unroll
         for (int t = 0; t < HOT; ++t) oh[s][t] = obs_at(row, W.col[t]);
-        dn[s] = donebuf[row * BLOCK + tid];
+        dn[s] = donebuf[row * EB + el];
     }
 #pragma unroll
     for (int s = 0; s < RB; ++s) {

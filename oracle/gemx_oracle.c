@@ -28,6 +28,13 @@
  * split.  The golden vectors recorded from the live scipy path pin this restatement to ~1e-12.
  * ORC_SOLVER_DP5_FIXED is ONE Dormand-Prince step of size (t_end - t), 5th-order solution, no error control
  * (what the adaptive code does whenever its first trial step is accepted).
+ * ORC_SOLVER_IVP_RK45 restates scipy.integrate.solve_ivp(method='RK45') as ScipySolveIvpSolver drives it
+ * (physical_systems/solvers.py:187-219: a FRESH solve_ivp call per integrate(), t_eval=[t]): scipy/integrate/_ivp/rk.py
+ * RungeKutta._step_impl + common.py select_initial_step (Hairer II.4 starting step, error_estimator_order 4, SAFETY 0.9,
+ * MIN_FACTOR 0.2, MAX_FACTOR 10, rms norm, scale = atol + max(|y|, |y_new|) rtol), defaults rtol 1e-3 / atol 1e-6.
+ * ORC_SOLVER_RK4_KINK / ORC_SOLVER_DP5_KINK restate what the HIP kernels do for a PolynomialStaticLoad (they have no
+ * counterpart in the reference): one fixed step per control step, split where omega is predicted to reach a kink of the
+ * load torque (|omega| = omega_lim), see integrate_kink().
  */
 #include <math.h>
 #include <stdint.h>
@@ -42,7 +49,8 @@ enum { ORC_CONV_CONT_4QC = 0, ORC_CONV_FINITE_B6 = 1, ORC_CONV_CONT_B6 = 2, ORC_
        ORC_CONV_CONT_2XB6 = 8, ORC_CONV_FINITE_2XB6 = 9 };
 #define ORC_IS_DC(s) ((s) == ORC_SYS_DC_PERMEX || (s) == ORC_SYS_DC_SERIES || (s) == ORC_SYS_DC_SHUNT || (s) == ORC_SYS_DC_EXTEX)
 enum { ORC_LOAD_CONST_SPEED = 0, ORC_LOAD_POLY_STATIC = 1 };
-enum { ORC_SOLVER_EULER = 0, ORC_SOLVER_RK4 = 1, ORC_SOLVER_DOPRI5 = 2, ORC_SOLVER_DP5_FIXED = 3 };
+enum { ORC_SOLVER_EULER = 0, ORC_SOLVER_RK4 = 1, ORC_SOLVER_DOPRI5 = 2, ORC_SOLVER_DP5_FIXED = 3, ORC_SOLVER_IVP_RK45 = 4,
+       ORC_SOLVER_RK4_KINK = 5, ORC_SOLVER_DP5_KINK = 6 };
 
 #define ORC_MAX_ODE 8
 #define ORC_MAX_OUT 24
@@ -66,6 +74,7 @@ typedef struct orc_params {
     double limits[ORC_MAX_OUT];
     double init[ORC_MAX_ODE]; /* initial ODE state [omega, motor states...] */
     double sup_r, sup_c;      /* RCVoltageSupply supply_parameter R, C */
+    double rtol, atol;        /* ORC_SOLVER_IVP_RK45: solve_ivp tolerances (0 -> scipy's defaults 1e-3 / 1e-6) */
 } orc_params;
 
 typedef struct orc_env {
@@ -334,9 +343,170 @@ static void dopri5_adaptive(const orc_params *p, orc_env *e, double t_end) {
     e->t = last ? t_end : x;
 }
 
+/* scipy.integrate.solve_ivp(fun, [t, t_end], y, t_eval=[t_end], method='RK45', rtol, atol) as ScipySolveIvpSolver.integrate
+ * calls it (solvers.py:207-219): a new RK45 object per call -> select_initial_step every control step. */
+static double rms_scaled(int n, const double *x, const double *scale) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += (x[i] / scale[i]) * (x[i] / scale[i]);
+    return sqrt(s) / sqrt((double)n);
+}
+static void ivp_rk45(const orc_params *p, orc_env *e, double t_end) {
+    const double rtol = p->rtol > 0 ? p->rtol : 1e-3, atol = p->atol > 0 ? p->atol : 1e-6;
+    const double SAFETY = 0.9, MIN_FACTOR = 0.2, MAX_FACTOR = 10.0;
+    int n = n_ode(p);
+    double t = e->t;
+    /* REFERENCE QUIRK (reproduced): SCMLSystem._system_equation returns the SAME pre-allocated array on every call
+     * (physical_systems.py:219-236, `_system_eq_placeholder`), and scipy's RK45 keeps `self.f = fun(t, y)` WITHOUT copying.
+     * `self.f` therefore always reads as the MOST RECENT right-hand-side evaluation: select_initial_step's probe f(y0 + h0 f0)
+     * replaces f(y0) before the first step uses it as stage 1 (and makes d2 = |f1 - f0| = 0), and a rejected attempt leaves
+     * f(t + h, y_new_rejected) behind as stage 1 of the retry.  `last` is that aliased buffer. */
+    double last[ORC_MAX_ODE], k1[ORC_MAX_ODE], k2[ORC_MAX_ODE], k3[ORC_MAX_ODE], k4[ORC_MAX_ODE], k5[ORC_MAX_ODE], k6[ORC_MAX_ODE];
+    double y1[ORC_MAX_ODE], yt[ORC_MAX_ODE], scale[ORC_MAX_ODE], tmp[ORC_MAX_ODE];
+    double *y = e->y;
+    if (t_end == t) return;
+    system_equation(p, e, y, last); /* RK45.__init__: self.f = self.fun(self.t, self.y) */
+    /* common.py select_initial_step (order = error_estimator_order = 4, max_step = inf, direction = +1) */
+    double h_abs;
+    {
+        double interval = fabs(t_end - t);
+        for (int i = 0; i < n; ++i) scale[i] = atol + fabs(y[i]) * rtol;
+        double d0 = rms_scaled(n, y, scale), d1 = rms_scaled(n, last, scale);
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = fmin(h0, interval);
+        for (int i = 0; i < n; ++i) y1[i] = y[i] + h0 * last[i];
+        system_equation(p, e, y1, last); /* f1 -- and, through the alias, f0 */
+        double d2 = 0.0;                 /* norm((f1 - f0) / scale) / h0 with f0 aliasing f1 */
+        double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / fmax(d1, d2), 1.0 / 5.0);
+        h_abs = fmin(fmin(100.0 * h0, h1), interval);
+    }
+    while (t != t_end) { /* solve_ivp's loop: solver.step() until t == t_bound */
+        double min_step = 10.0 * fabs(nextafter(t, INFINITY) - t);
+        if (h_abs < min_step) h_abs = min_step;
+        int accepted = 0, rejected = 0;
+        double t_new = t, h = 0.0;
+        while (!accepted) {
+            if (h_abs < min_step) return; /* TOO_SMALL_STEP */
+            h = h_abs;
+            t_new = t + h;
+            if (t_new - t_end > 0) t_new = t_end;
+            h = t_new - t;
+            h_abs = fabs(h);
+            /* rk.py rk_step with the Dormand-Prince tableau of RK45; K[0] = f copies whatever the aliased buffer holds NOW */
+            for (int i = 0; i < n; ++i) k1[i] = last[i];
+            for (int i = 0; i < n; ++i) yt[i] = y[i] + h * (1.0 / 5.0 * k1[i]);
+            system_equation(p, e, yt, k2);
+            for (int i = 0; i < n; ++i) yt[i] = y[i] + h * (3.0 / 40.0 * k1[i] + 9.0 / 40.0 * k2[i]);
+            system_equation(p, e, yt, k3);
+            for (int i = 0; i < n; ++i) yt[i] = y[i] + h * (44.0 / 45.0 * k1[i] - 56.0 / 15.0 * k2[i] + 32.0 / 9.0 * k3[i]);
+            system_equation(p, e, yt, k4);
+            for (int i = 0; i < n; ++i)
+                yt[i] = y[i] + h * (19372.0 / 6561.0 * k1[i] - 25360.0 / 2187.0 * k2[i] + 64448.0 / 6561.0 * k3[i] - 212.0 / 729.0 * k4[i]);
+            system_equation(p, e, yt, k5);
+            for (int i = 0; i < n; ++i)
+                yt[i] = y[i] + h * (9017.0 / 3168.0 * k1[i] - 355.0 / 33.0 * k2[i] + 46732.0 / 5247.0 * k3[i] + 49.0 / 176.0 * k4[i] -
+                                    5103.0 / 18656.0 * k5[i]);
+            system_equation(p, e, yt, k6);
+            for (int i = 0; i < n; ++i)
+                y1[i] = y[i] + h * (35.0 / 384.0 * k1[i] + 500.0 / 1113.0 * k3[i] + 125.0 / 192.0 * k4[i] - 2187.0 / 6784.0 * k5[i] +
+                                    11.0 / 84.0 * k6[i]);
+            system_equation(p, e, y1, last); /* f_new = K[6] */
+            for (int i = 0; i < n; ++i) {
+                scale[i] = atol + fmax(fabs(y[i]), fabs(y1[i])) * rtol;
+                tmp[i] = h * (-71.0 / 57600.0 * k1[i] + 71.0 / 16695.0 * k3[i] - 71.0 / 1920.0 * k4[i] + 17253.0 / 339200.0 * k5[i] -
+                              22.0 / 525.0 * k6[i] + 1.0 / 40.0 * last[i]);
+            }
+            double err = rms_scaled(n, tmp, scale);
+            if (err < 1.0) {
+                double factor = err == 0.0 ? MAX_FACTOR : fmin(MAX_FACTOR, SAFETY * pow(err, -0.2));
+                if (rejected) factor = fmin(1.0, factor);
+                h_abs *= factor;
+                accepted = 1;
+            } else {
+                h_abs *= fmax(MIN_FACTOR, SAFETY * pow(err, -0.2));
+                rejected = 1;
+            }
+        }
+        t = t_new;
+        for (int i = 0; i < n; ++i) y[i] = y1[i];
+    }
+    e->t = t_end;
+}
+
+/* What the HIP kernels do for a PolynomialStaticLoad (gemx_kernels.hpp integrate<>): the load torque's constant term is the
+ * saturation clamp(J / tau_decay * omega, -a, a) (polynomial_static_load.py:87-92), i.e. the right-hand side has kinks at
+ * |omega| = omega_lim, where a fixed step loses its order (scipy's adaptive solvers split their steps there).  A control step is
+ * therefore cut at the instants omega is PREDICTED (first order, from d omega / dt at the start of the piece) to reach the next
+ * kink in its direction of travel; each piece is one step of the scheme.  At most 3 pieces. */
+static void fixed_step(const orc_params *p, orc_env *e, int dp5, double h) {
+    int n = n_ode(p);
+    double k1[ORC_MAX_ODE], k2[ORC_MAX_ODE], k3[ORC_MAX_ODE], k4[ORC_MAX_ODE], k5[ORC_MAX_ODE], k6[ORC_MAX_ODE], yt[ORC_MAX_ODE];
+    system_equation(p, e, e->y, k1);
+    if (!dp5) {
+        for (int i = 0; i < n; ++i) yt[i] = e->y[i] + 0.5 * h * k1[i];
+        system_equation(p, e, yt, k2);
+        for (int i = 0; i < n; ++i) yt[i] = e->y[i] + 0.5 * h * k2[i];
+        system_equation(p, e, yt, k3);
+        for (int i = 0; i < n; ++i) yt[i] = e->y[i] + h * k3[i];
+        system_equation(p, e, yt, k4);
+        for (int i = 0; i < n; ++i) e->y[i] = e->y[i] + h / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+        return;
+    }
+    for (int i = 0; i < n; ++i) yt[i] = e->y[i] + h * (1.0 / 5.0) * k1[i];
+    system_equation(p, e, yt, k2);
+    for (int i = 0; i < n; ++i) yt[i] = e->y[i] + h * (3.0 / 40.0 * k1[i] + 9.0 / 40.0 * k2[i]);
+    system_equation(p, e, yt, k3);
+    for (int i = 0; i < n; ++i) yt[i] = e->y[i] + h * (44.0 / 45.0 * k1[i] - 56.0 / 15.0 * k2[i] + 32.0 / 9.0 * k3[i]);
+    system_equation(p, e, yt, k4);
+    for (int i = 0; i < n; ++i)
+        yt[i] = e->y[i] + h * (19372.0 / 6561.0 * k1[i] - 25360.0 / 2187.0 * k2[i] + 64448.0 / 6561.0 * k3[i] - 212.0 / 729.0 * k4[i]);
+    system_equation(p, e, yt, k5);
+    for (int i = 0; i < n; ++i)
+        yt[i] = e->y[i] + h * (9017.0 / 3168.0 * k1[i] - 355.0 / 33.0 * k2[i] + 46732.0 / 5247.0 * k3[i] + 49.0 / 176.0 * k4[i] -
+                               5103.0 / 18656.0 * k5[i]);
+    system_equation(p, e, yt, k6);
+    for (int i = 0; i < n; ++i)
+        e->y[i] = e->y[i] + h * (35.0 / 384.0 * k1[i] + 500.0 / 1113.0 * k3[i] + 125.0 / 192.0 * k4[i] - 2187.0 / 6784.0 * k5[i] +
+                                 11.0 / 84.0 * k6[i]);
+}
+static void integrate_kink(const orc_params *p, orc_env *e, int dp5, double t_end) {
+    const int MAX_PIECES = 3;
+    double rem = t_end - e->t;
+    const double h_total = rem;
+    const double lim = p->load == ORC_LOAD_POLY_STATIC ? p->load_a / p->j_total * p->tau_decay : 0.0;
+    for (int piece = 0; piece < MAX_PIECES && rem > 0.0; ++piece) {
+        double h = rem;
+        if (p->load == ORC_LOAD_POLY_STATIC && lim > 0.0 && piece + 1 < MAX_PIECES) {
+            double k1[ORC_MAX_ODE];
+            system_equation(p, e, e->y, k1);
+            const double w = e->y[0], dw = k1[0];
+            /* next kink in the direction of travel, strictly ahead of omega */
+            const double margin = 1e-6 * lim;
+            double b = 0.0;
+            int have = 0;
+            if (dw > 0.0) {
+                if (w < -lim - margin) { b = -lim; have = 1; }
+                else if (w < lim - margin) { b = lim; have = 1; }
+            } else if (dw < 0.0) {
+                if (w > lim + margin) { b = lim; have = 1; }
+                else if (w > -lim + margin) { b = -lim; have = 1; }
+            }
+            if (have) {
+                const double tc = (b - w) / dw;
+                if (tc < rem * 0.999) h = fmax(tc, h_total * (1.0 / 64.0));
+                if (h > rem) h = rem;
+            }
+        }
+        fixed_step(p, e, dp5, h);
+        rem -= h;
+    }
+    if (rem > 0.0) fixed_step(p, e, dp5, rem);
+}
+
 static void integrate(const orc_params *p, orc_env *e, double t_end) {
     int n = n_ode(p);
     if (p->solver == ORC_SOLVER_DOPRI5) { dopri5_adaptive(p, e, t_end); return; }
+    if (p->solver == ORC_SOLVER_IVP_RK45) { ivp_rk45(p, e, t_end); return; }
+    if (p->solver == ORC_SOLVER_RK4_KINK || p->solver == ORC_SOLVER_DP5_KINK) { integrate_kink(p, e, p->solver == ORC_SOLVER_DP5_KINK, t_end); return; }
     double k1[ORC_MAX_ODE], k2[ORC_MAX_ODE], k3[ORC_MAX_ODE], k4[ORC_MAX_ODE], k5[ORC_MAX_ODE], k6[ORC_MAX_ODE],
         yt[ORC_MAX_ODE];
     if (p->solver == ORC_SOLVER_EULER) {

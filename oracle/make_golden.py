@@ -45,6 +45,8 @@ def make_solver(name):
         return ref_solvers.EulerSolver(nsteps=4)
     if name == "dopri5":
         return ref_solvers.ScipyOdeSolver()  # the default of all 54 envs
+    if name == "ivp":  # BASELINE config 1: solve_ivp with its defaults (method RK45, rtol 1e-3, atol 1e-6)
+        return ref_solvers.ScipySolveIvpSolver()
     if name == "ivp_tight":
         return ref_solvers.ScipySolveIvpSolver(rtol=1e-10, atol=1e-12)
     raise KeyError(name)
@@ -374,6 +376,22 @@ def main(only=None):
         init_samples()
     if not only or "wiener" in only:
         wiener_samples()
+    if not only or "r02" in only:
+        main_r02()
+
+
+def main_r02():
+    """Round 2: BASELINE config 1's solver (ScipySolveIvpSolver, solvers.py:187-219) and the bench's own configuration (PMSM,
+    tau = 1e-4, uniformly random switching, default constraint, reset on done) under the reference's default solver."""
+    dc, pmsm = "Cont-CC-PermExDc-v0", "Finite-CC-PMSM-v0"
+    run_case("permexdc_free_uniform_10k_ivp", dc, "ivp", 10000, 1234, "uniform", False, "box1", every=10)
+    run_case("permexdc_free_uniform_10k_ivp_tight", dc, "ivp_tight", 10000, 1234, "uniform", False, "box1", every=10)
+    run_case("permexdc_epi_held_ivp", dc, "ivp", 2000, 1236, "held", True, "box1")
+    run_case("pmsm_free_held_ivp", pmsm, "ivp", 2000, 1235, "held", False, "disc8")
+    run_case("scim_free_held_ivp", "Cont-SC-SCIM-v0", "ivp", 2000, 1235, "held", False, "box3")
+    run_case("pmsm_epi_uniform_tau1e-4_dopri5", pmsm, "dopri5", 6000, 1290, "uniform", True, "disc8", tau=1e-4)
+    run_case("pmsm_epi_uniform_tau1e-4_euler", pmsm, "euler", 6000, 1290, "uniform", True, "disc8", tau=1e-4)
+    run_case("scim_epi_held_dopri5", "Cont-SC-SCIM-v0", "dopri5", 4000, 1291, "held", True, "box3")
 
 
 def main_base():

@@ -17,7 +17,7 @@ SYS_DC, SYS_PMSM, SYS_SCIM, SYS_DC_SERIES, SYS_DC_SHUNT, SYS_DC_EXTEX, SYS_EESM,
 CONV_C4QC, CONV_FB6, CONV_CB6, CONV_F4QC = 0, 1, 2, 3
 CONV_C2X4QC, CONV_F2X4QC, CONV_CB6_4QC, CONV_FB6_4QC, CONV_C2XB6, CONV_F2XB6 = 4, 5, 6, 7, 8, 9  # Cont/FiniteMultiConverter of two sub-converters
 LOAD_CONST, LOAD_POLY = 0, 1
-SOLVER_EULER, SOLVER_RK4, SOLVER_DOPRI5, SOLVER_DP5_FIXED = 0, 1, 2, 3
+SOLVER_EULER, SOLVER_RK4, SOLVER_DOPRI5, SOLVER_DP5_FIXED, SOLVER_IVP_RK45, SOLVER_RK4_KINK, SOLVER_DP5_KINK = 0, 1, 2, 3, 4, 5, 6
 
 MAX_ODE, MAX_OUT = 8, 24
 
@@ -34,6 +34,7 @@ class OrcParams(C.Structure):
         ("limits", C.c_double * MAX_OUT),
         ("init", C.c_double * MAX_ODE),
         ("sup_r", C.c_double), ("sup_c", C.c_double),
+        ("rtol", C.c_double), ("atol", C.c_double),
     ]
 
 
@@ -76,7 +77,12 @@ _DC_MOTOR_SYS = {"DcPermanentlyExcitedMotor": SYS_DC, "DcSeriesMotor": SYS_DC_SE
                  "DcExternallyExcitedMotor": SYS_DC_EXTEX}
 _LOAD = {"ConstantSpeedLoad": LOAD_CONST, "PolynomialStaticLoad": LOAD_POLY}
 _SOLVER = {"euler": (SOLVER_EULER, 1), "euler4": (SOLVER_EULER, 4), "rk4": (SOLVER_RK4, 1), "rk4x4": (SOLVER_RK4, 4), "rk4x8": (SOLVER_RK4, 8),
-           "dopri5": (SOLVER_DOPRI5, 1), "ivp_tight": (SOLVER_DOPRI5, 1), "dp5_fixed": (SOLVER_DP5_FIXED, 1)}
+           "dopri5": (SOLVER_DOPRI5, 1), "dp5_fixed": (SOLVER_DP5_FIXED, 1),
+           # scipy.integrate.solve_ivp(method="RK45") as ScipySolveIvpSolver drives it (solvers.py:187-219); tolerances below
+           "ivp": (SOLVER_IVP_RK45, 1), "ivp_tight": (SOLVER_IVP_RK45, 1),
+           # what the HIP kernels do for a PolynomialStaticLoad: a fixed step split at the load's kinks (no reference counterpart)
+           "rk4_kink": (SOLVER_RK4_KINK, 1), "dp5_kink": (SOLVER_DP5_KINK, 1)}
+_IVP_TOL = {"ivp": (1e-3, 1e-6), "ivp_tight": (1e-10, 1e-12)}  # solve_ivp defaults | oracle/make_golden.py:make_solver("ivp_tight")
 _MP_KEYS = {SYS_DC: ("r_a", "l_a", "psi_e"), SYS_PMSM: ("p", "l_d", "l_q", "r_s", "psi_p"),
             SYS_SCIM: ("p", "l_m", "l_sigs", "l_sigr", "r_s", "r_r"),
             SYS_DC_SERIES: ("r_a", "r_e", "l_a", "l_e", "l_e_prime"), SYS_DC_SHUNT: ("r_a", "r_e", "l_a", "l_e", "l_e_prime"),
@@ -109,6 +115,7 @@ def params_from_meta(meta, solver=None, episodic=None):
     p.converter = _CONV[meta["converter"]]
     p.load = _LOAD[meta["load"]]
     p.solver, p.nsteps = _SOLVER[solver or meta["solver"]]
+    p.rtol, p.atol = _IVP_TOL.get(solver or meta["solver"], (0.0, 0.0))
     epi = meta.get("episodic", False) if episodic is None else episodic
     if epi:
         p.limit_mask, p.squared_mask = default_masks(meta)

@@ -38,7 +38,17 @@ def _worker(rank, world, port, n_total, out_dir):
     done = (torch.arange(lo, hi) % 3 == 0).to(torch.uint8)
     all_obs, all_done = gdd.gather_observations(obs, done, n_total=n_total)
     all_obs2, _ = gdd.gather_observations(obs, None)  # sizes discovered by a collective
-    torch.save((all_obs, all_done, all_obs2), os.path.join(out_dir, f"r{rank}.pt"))
+    # chunk form: what one fused launch of K control steps writes on every rank -- obs [K, n_local, S_out] f32, done [K, n_local] u8
+    # (equal shards only: the bench / make_sharded shapes); entry [k, i, j] encodes (step, global env, column)
+    chunk = None
+    if n_total % w == 0:
+        K, S = 5, 14
+        g = torch.arange(lo, hi, dtype=torch.float32)
+        oc = (torch.arange(K, dtype=torch.float32).reshape(K, 1, 1) * 1000 + g.reshape(1, -1, 1) + torch.arange(S, dtype=torch.float32).reshape(1, 1, S) / 100).contiguous()
+        dc = ((torch.arange(K).reshape(K, 1) + torch.arange(lo, hi).reshape(1, -1)) % 2).to(torch.uint8).contiguous()
+        chunk = gdd.gather_rollout(oc, dc)
+        assert chunk[0].shape == (w, K, hi - lo, S) and chunk[0].dtype == torch.float32 and chunk[1].shape == (w, K, hi - lo) and chunk[1].dtype == torch.uint8
+    torch.save((all_obs, all_done, all_obs2, chunk), os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -52,6 +62,17 @@ def test_gather_observations_gloo_world2(tmp_path, n_total):
     mp.spawn(_worker, args=(2, port, n_total, str(tmp_path)), nprocs=2, join=True)
     expect = torch.arange(n_total, dtype=torch.float32).reshape(-1, 1).repeat(1, 14)
     for r in range(2):
-        all_obs, all_done, all_obs2 = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
+        all_obs, all_done, all_obs2, chunk = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
         assert torch.equal(all_obs, expect) and torch.equal(all_obs2, expect)
         assert torch.equal(all_done, (torch.arange(n_total) % 3 == 0).to(torch.uint8))
+        if n_total % 2 == 0:  # rank-major chunk gather: [W, K, n_local, S_out] -> [K, n_total, S_out] must be the global batch
+            oc, dc = chunk
+            W, K, nl, S = oc.shape
+            full = oc.permute(1, 0, 2, 3).reshape(K, W * nl, S)
+            want = (torch.arange(K, dtype=torch.float32).reshape(K, 1, 1) * 1000 + torch.arange(n_total, dtype=torch.float32).reshape(1, -1, 1) +
+                    torch.arange(S, dtype=torch.float32).reshape(1, 1, S) / 100)
+            assert torch.equal(full, want)
+            dfull = dc.permute(1, 0, 2).reshape(K, W * nl)
+            assert torch.equal(dfull, ((torch.arange(K).reshape(K, 1) + torch.arange(n_total).reshape(1, -1)) % 2).to(torch.uint8))
+        else:
+            assert chunk is None

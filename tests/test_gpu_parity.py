@@ -4,8 +4,8 @@ golden vectors recorded from the live reference.
 Tolerances (normalised states are O(1); angle compared on the circle):
   * same integrator, GPU fp64 vs oracle/reference fp64 ............ 1e-9 abs
   * same integrator, GPU fp32 vs reference fp64 .................... 1e-4 rel (north star; observed ~1e-6)
-  * GPU fixed-step RK4 / DP5 fp32 vs reference default dopri5 ...... 1e-4 rel (2e-4 for SCIM + PolynomialStaticLoad,
-    whose kinks make scipy's adaptive controller split steps)
+  * GPU RK4 / DP5 fp32 vs reference default dopri5 ................. 1e-4 rel, every system (the device solvers split a step at the
+    kinks of the PolynomialStaticLoad, where scipy's adaptive controller splits its own)
   * done masks: exact, except steps whose constraint margin is < 1e-5 in the reference
   * "rel" = max |got - ref| of a column / max(|ref| range of that column, 1e-3)
 """
@@ -117,25 +117,60 @@ def _run_golden(name, dtype, solver=None, n_envs=70):
     return d, meta, obs0, done[:, 0]
 
 
+def _constraint_margin(meta, d):
+    """|constraint value - 1| of the env's default constraint on the reference's (every-step) states."""
+    assert meta["every"] == 1
+    s = d["states"]
+    names = meta["state_names"]
+    if meta["system"] == "ExternallyExcitedSynchronousMotorSystem":
+        return np.minimum(np.abs(s[:, names.index("i_sd")] ** 2 + s[:, names.index("i_sq")] ** 2 - 1.0),
+                          np.abs(np.abs(s[:, names.index("i_e")]) - 1.0))
+    if meta["system"] == "DcMotorSystem" and meta["motor"] in ("DcShuntMotor", "DcExternallyExcitedMotor"):
+        return np.minimum(np.abs(np.abs(s[:, names.index("i_a")]) - 1.0), np.abs(np.abs(s[:, names.index("i_e")]) - 1.0))
+    if meta["system"] == "DcMotorSystem":
+        return np.abs(np.abs(s[:, names.index("i")]) - 1.0)
+    return np.abs(s[:, names.index("i_sd")] ** 2 + s[:, names.index("i_sq")] ** 2 - 1.0)
+
+
 def _check_done(meta, d, got_done, ref_states_full=None):
     ref_done = d["terminated"]
     if np.array_equal(got_done, ref_done):
         return
     # tolerate flips only where the reference's constraint margin is tiny; needs every-step states
-    assert meta["every"] == 1
-    s = d["states"]
-    names = meta["state_names"]
-    if meta["system"] == "ExternallyExcitedSynchronousMotorSystem":
-        margin = np.minimum(np.abs(s[:, names.index("i_sd")] ** 2 + s[:, names.index("i_sq")] ** 2 - 1.0),
-                            np.abs(np.abs(s[:, names.index("i_e")]) - 1.0))
-    elif meta["system"] == "DcMotorSystem" and meta["motor"] in ("DcShuntMotor", "DcExternallyExcitedMotor"):
-        margin = np.minimum(np.abs(np.abs(s[:, names.index("i_a")]) - 1.0), np.abs(np.abs(s[:, names.index("i_e")]) - 1.0))
-    elif meta["system"] == "DcMotorSystem":
-        margin = np.abs(np.abs(s[:, names.index("i")]) - 1.0)
-    else:
-        margin = np.abs(s[:, names.index("i_sd")] ** 2 + s[:, names.index("i_sq")] ** 2 - 1.0)
+    margin = _constraint_margin(meta, d)
     first = int(np.argmax(got_done != ref_done))
     assert margin[first] < 1e-5, f"done mask differs at step {first} with margin {margin[first]:.3e}"
+
+
+def compare_trajectory(meta, d, obs, done, min_fraction=0.0):
+    """Whole-trajectory comparison of one env's device rollout with a recorded reference run, EPISODE BY EPISODE: both sides restart
+    from the reset state on the step after a termination, so as long as the done masks agree every episode is compared, not just the
+    first.  A done flip is accepted only where the reference's constraint margin is < 1e-5 (fp32 vs fp64 at the boundary); from there
+    on the two runs are out of phase for good (same action sequence, different episode starts), so the comparison ends at the flip.
+    Returns (worst rel err, max abs err, worst column, description of the done-mask comparison)."""
+    names = meta["state_names"]
+    idx, ref, ref_done = d["state_index"], d["states"], d["terminated"]
+    K = len(ref_done)
+    n_cmp, dmsg = K, "free run"
+    if meta["episodic"]:
+        if np.array_equal(done, ref_done):
+            dmsg = f"identical, {int(ref_done.sum())} terminations"
+        else:
+            first = int(np.argmax(done != ref_done))
+            margin = _constraint_margin(meta, d)[first]
+            assert margin < 1e-5, f"done mask differs at step {first} with margin {margin:.3e}"
+            n_cmp = first + 1  # the state returned by step `first` is still the same episode on both sides
+            dmsg = f"flip at step {first} (reference margin {margin:.1e}): {n_cmp}/{K} steps, {int(ref_done[:first].sum())} terminations compared"
+    assert n_cmp >= min_fraction * K, dmsg
+    sel = idx < n_cmp
+    diff = np.abs(obs[idx[sel]] - ref[sel])
+    if "epsilon" in names:
+        i = names.index("epsilon")
+        diff[:, i] = np.minimum(diff[:, i], 2.0 - diff[:, i])
+    scale = np.maximum(np.abs(ref).max(axis=0), 1e-3)
+    per_col = diff.max(axis=0) / scale
+    j = int(np.argmax(per_col))
+    return float(per_col[j]), float(diff.max()), names[j], dmsg
 
 
 SAME_SOLVER = [c for c in CASES if c.endswith("euler") or c.endswith("euler4")]
@@ -167,16 +202,9 @@ def test_fp32_fixed_step_matches_reference_default_dopri5(name, solver):
     if meta0["env_id"].endswith("SC-SynRM-v0"):
         solver += "x8"  # tiny inertia: one step per tau is 1e-3 off the adaptive reference solver, 8 sub-steps restore 1e-4
     d, meta, obs, done = _run_golden(name, "float32", solver=solver)
-    if meta["episodic"]:
-        # after the first termination mismatch trajectories legitimately diverge; compare up to the first done (column
-        # ranges from the whole run: the first episode can be a few steps long, with omega / epsilon still ~1e-6)
-        n = int(np.argmax(d["terminated"])) if d["terminated"].any() else len(d["terminated"])
-        n = max(n, 1)
-        rel, _ = _rel_err(obs[:n], d["states"][:n], meta["state_names"], scale_ref=d["states"])
-    else:
-        rel, _ = _rel_err(obs[d["state_index"]], d["states"], meta["state_names"])
-    tol = 2e-4 if (meta["system"].startswith("SquirrelCage") and meta["load"] == "PolynomialStaticLoad") else 1e-4
-    assert rel < tol, rel
+    # north-star tolerance for EVERY system (round 1 held SCIM + PolynomialStaticLoad to 2e-4); episodic runs episode by episode
+    rel, _, col, dmsg = compare_trajectory(meta, d, obs, done)
+    assert rel < 1e-4, (rel, col, dmsg)
 
 
 def test_ref_data_npz_on_gpu():
@@ -188,22 +216,53 @@ def test_ref_data_npz_on_gpu():
         assert not done.any()
 
 
+def test_fixed_step_rk4_matches_reference_solve_ivp_path():
+    """BASELINE config 1's solver: ScipySolveIvpSolver (solvers.py:187-219).  At rtol 1e-10 / atol 1e-12 it is the exact solution to
+    ~1e-9, so GPU RK4 / DP5 fp32 must agree within the 1e-4 contract over 10 k steps.  (With its DEFAULT tolerances the reference's
+    solve_ivp path is itself 5e-4 off its own default solver -- rtol 1e-3 plus the aliased-RHS quirk restated in
+    oracle/gemx_oracle.c:ivp_rk45 -- so that fixture pins the oracle, not the device.)"""
+    for solver in ("rk4", "dp5"):
+        d, meta, obs, done = _run_golden("permexdc_free_uniform_10k_ivp_tight", "float32", solver=solver)
+        rel, _, col, _ = compare_trajectory(meta, d, obs, done)
+        assert rel < 1e-4, (solver, rel, col)
+
+
+@pytest.mark.parametrize("mode", ["pipe0", "shape0", "shape1", "shape2", "shape3"])
+def test_bench_configuration_episodic_rk4_against_reference_default_solver(mode, monkeypatch):
+    """The bench's own instantiation -- Finite-CC-PMSM-v0, tau 1e-4, RK4 through the one-step affine map + per-action voltage table,
+    default constraint + in-kernel auto-reset, uniformly random switching -- against the reference's default solver (dopri5) over 6000
+    steps / ~109 episodes, through every pipelined shape and the single-wave kernel: done masks with the margin guard, trajectories
+    episode by episode (not just up to the first termination)."""
+    if mode == "pipe0":
+        monkeypatch.setenv("GEMX_PIPE", "0")
+    else:
+        monkeypatch.setenv("GEMX_PIPE", "1")
+        monkeypatch.setenv("GEMX_PIPE_SHAPE", mode[-1])
+    d, meta, obs, done = _run_golden("pmsm_epi_uniform_tau1e-4_dopri5", "float32", solver="rk4", n_envs=128)
+    assert d["terminated"].sum() > 50
+    rel, _, col, dmsg = compare_trajectory(meta, d, obs, done, min_fraction=0.5)
+    assert rel < 1e-4, (rel, col, dmsg)
+
+
 @pytest.mark.parametrize("env_id, n_envs, solver", [
     ("Cont-CC-PermExDc-v0", 4096, "euler"),   # BASELINE config 2
-    ("Finite-CC-PMSM-v0", 16384, "rk4"),      # BASELINE config 3
+    ("Finite-CC-PMSM-v0", 16384, "rk4"),      # BASELINE config 3 (the bench headline: one-step map + voltage table + <12, 3> shape)
     ("Cont-SC-SCIM-v0", 65536, "rk4"),        # BASELINE config 4
 ])
 def test_full_size_configs_against_oracle(env_id, n_envs, solver):
-    """BASELINE.json sizes: per-env random actions; a sample of envs is checked against the fp64 oracle with the
-    SAME integrator, all envs for finiteness, and step-by-step simulate() == fused rollout() bit for bit."""
+    """BASELINE.json sizes exactly as bench.py runs them: default constraints + in-kernel auto-reset, tau = 1e-4, per-env random
+    actions, K = 1000 control steps in ONE fused launch.  64 sampled envs (first / last lanes of workgroups, both halves of the
+    grid) are checked step by step against the fp64 oracle with the SAME integrator -- trajectories episode by episode, done masks
+    exactly (flips only within 1e-5 of the constraint boundary) -- all envs for finiteness and a plausible termination count, and
+    step-by-step simulate() == the fused rollout bit for bit."""
     import torch
 
     import gym_electric_motor_amd as ga
     from oracle import oracle as orc
 
-    K = 200
+    K = 1000
     sol = ga.EulerSolver() if solver == "euler" else ga.RK4Solver()
-    env = ga.make(env_id, n_envs=n_envs, ode_solver=sol, constraints=())
+    env = ga.make(env_id, n_envs=n_envs, ode_solver=sol, tau=1e-4)
     ps = env.physical_system
     g = torch.Generator(device="cuda").manual_seed(1234)
     if ps._discrete:
@@ -212,28 +271,45 @@ def test_full_size_configs_against_oracle(env_id, n_envs, solver):
         acts = torch.rand((K, n_envs, ps._n_act), device="cuda", generator=g) * 2 - 1
     obs, done = env.rollout(acts)
     torch.cuda.synchronize()
+    assert "advance_pipe_kernel" in ps.last_launch()  # the kernel the bench measures
     assert torch.isfinite(obs).all()
-    # single-step path must give the same bits as the fused path
-    env2 = ga.make(env_id, n_envs=n_envs, ode_solver=sol, constraints=())
-    for k in range(5):
+    # single-step path must give the same bits as the fused path (incl. the auto-reset)
+    env2 = ga.make(env_id, n_envs=n_envs, ode_solver=sol, tau=1e-4)
+    for k in range(40):
         o = env2.physical_system.simulate(acts[k])
-        assert torch.equal(o, obs[k])
+        assert torch.equal(o, obs[k]) and torch.equal(env2.physical_system.done, done[k])
     env2.close()
-    golden = {"Cont-CC-PermExDc-v0": "permexdc_free_held_euler", "Finite-CC-PMSM-v0": "pmsm_free_held_euler",
-              "Cont-SC-SCIM-v0": "scim_free_held_euler"}[env_id]
+    golden = {"Cont-CC-PermExDc-v0": "permexdc_epi_held_euler", "Finite-CC-PMSM-v0": "pmsm_epi_held_tau1e-4_euler",
+              "Cont-SC-SCIM-v0": "scim_epi_uniform_euler"}[env_id]
     _, meta = _load(golden)
-    p = orc.params_from_meta(meta, solver=solver, episodic=False)
-    a_host = acts.cpu().numpy().astype(np.float64)
-    o_host = obs.double().cpu().numpy()
-    worst = 0.0
-    for j in (0, 1, 63, 64, n_envs // 2 + 17, n_envs - 1):
+    meta = dict(meta, tau=1e-4)
+    p = orc.params_from_meta(meta, solver=solver, episodic=True)
+    names = meta["state_names"]
+    rng = np.random.default_rng(7)
+    sample = sorted(set([0, 1, 63, 64, 127, n_envs // 2 - 1, n_envs // 2, n_envs // 2 + 17, n_envs - 64, n_envs - 1]) |
+                    set(int(x) for x in rng.integers(0, n_envs, 54)))
+    assert len(sample) >= 60
+    idx = torch.as_tensor(sample, device="cuda")
+    a_host = acts[:, idx].cpu().numpy().astype(np.float64)
+    o_host = obs[:, idx].double().cpu().numpy()
+    d_host = done[:, idx].cpu().numpy().astype(bool)
+    worst, n_term, n_flip, n_cmp = 0.0, 0, 0, 0
+    for c, j in enumerate(sample):
         e = orc.OracleEnv(p)
         e.reset()
-        ref, _ = e.rollout(a_host[:, j])
-        rel, _ = _rel_err(o_host[:, j], ref, meta["state_names"])
+        ref, rdone = e.rollout(a_host[:, c], auto_reset=True)
+        d = {"state_index": np.arange(K), "states": ref, "terminated": rdone}
+        rel, _, col, dmsg = compare_trajectory(dict(meta, every=1, episodic=True), d, o_host[:, c], d_host[:, c])
+        assert rel < 1e-4, (j, rel, col, dmsg)
         worst = max(worst, rel)
+        n_term += int(rdone.sum())
+        n_flip += "flip" in dmsg
+    total_done = int(done.sum().item())
     env.close()
-    assert worst < 1e-4, worst
+    assert n_term > len(sample)            # every sampled env terminated (and restarted) more than once on average
+    assert n_flip <= len(sample) // 8      # boundary flips are the exception
+    assert abs(total_done / n_envs - n_term / len(sample)) < 0.25 * n_term / len(sample)  # all envs: same termination rate as the sample
+    print(f"{env_id} N={n_envs} {solver}: worst rel err {worst:.2e} over {len(sample)} envs x {K} steps, {n_term} terminations, {n_flip} flips")
 
 
 @pytest.mark.parametrize("env_id, golden, til", [
