@@ -673,16 +673,21 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         return obs_out, done_out, reward_out
 
     def reset(self, mask=None, *_):
-        """PhysicalSystem.reset (core.py:678-685).  mask: optional [N] bool/uint8 selecting the envs to reset."""
+        """PhysicalSystem.reset (core.py:678-685).  mask: optional [N] bool/uint8 selecting the envs to reset.
+        Returns the reset observation(s): rows of envs outside `mask` keep the observation of their last step."""
         torch = _torch()
         m = None
         if mask is not None and not (self._n_envs == 1 and not torch.is_tensor(mask) and np.ndim(mask) == 0):
             m = torch.as_tensor(mask).to(device=self._tdev, dtype=torch.uint8).contiguous()
+        # the kernel writes the reset observation of every env it resets into the internal buffer (masked-out rows untouched)
         _lib.check(self._L.gemx_reset(self._handle, C.c_void_p(m.data_ptr()) if m is not None else None,
-                                      C.c_void_p(self._obs.data_ptr()) if m is None else None, self._stream()))
+                                      C.c_void_p(self._obs.data_ptr()), self._stream()))
         if m is None:
             self._k = 0
         if self._n_envs == 1:
+            if self._cfg.init_kind != _lib.INIT_CONST:
+                # random initialisers: the observation of the state the kernel just drew, not the constant initial state's
+                return self._obs.reshape(-1).double().cpu().numpy()
             return self._reset_obs.copy()
         return self._obs
 

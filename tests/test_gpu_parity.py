@@ -948,9 +948,13 @@ def test_masked_reset():
     env.rollout(a)
     mask = torch.zeros(100, dtype=torch.uint8, device="cuda")
     mask[::2] = 1
-    ps.reset(mask)
+    last = ps.simulate(a[0]).clone()
+    o = ps.reset(mask)
     st = ps.get_state().cpu().numpy()
     assert np.all(st[:, ::2] == 0.0) and np.any(st[:, 1::2] != 0.0)
+    # returned observations: reset rows show the reset state, the others keep their last step's row
+    ro = torch.as_tensor(ps.reset_observation, dtype=torch.float32, device="cuda")
+    assert torch.equal(o[::2], ro.expand(50, -1)) and torch.equal(o[1::2], last[1::2])
     env.close()
 
 

@@ -8,13 +8,14 @@ from gym_electric_motor_amd import _lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 env_id = sys.argv[3] if len(sys.argv) > 3 else "Finite-CC-PMSM-v0"
-env = ga.make(env_id, n_envs=n, device="cuda:0", ode_solver=ga.RK4Solver(), tau=1e-4)
+solver = ga.EulerSolver() if os.environ.get("PROBE_SOLVER", "rk4") == "euler" else ga.RK4Solver()
+env = ga.make(env_id, n_envs=n, device="cuda:0", ode_solver=solver, tau=1e-4)
 ps = env.physical_system
 env.reset()
 if "Finite" in env_id:
     act = torch.randint(0, 8, (K, n), dtype=torch.uint8, device="cuda:0")
 else:
-    act = torch.rand((K, n, 3), device="cuda:0") * 2 - 1
+    act = torch.rand((K, n, ps._n_act), device="cuda:0") * 2 - 1
 refs = rew = None
 if os.environ.get("PROBE_REWARD"):
     ps.set_reward(reward_weights=dict(i_sd=0.5, i_sq=0.5), referenced_states=("i_sd", "i_sq"))
