@@ -222,16 +222,13 @@ class _ElectricMotor:
     initializer = property(lambda self: self._initializer)
 
     def _update_limits(self, limits_d=None, nominal_d=None):
-        """electric_motor.py:296-317: replace missing (0) limits / nominal values."""
-        limits_d = dict(limits_d or {})
-        nominal_d = dict(nominal_d or {})
-        limits_d.update(dict(omega=self._default_limits["omega"]))
-        for qty, lim in limits_d.items():
-            if self._limits.get(qty, 0) == 0:
-                self._limits[qty] = lim
-        for entry in self._limits.keys():
-            if self._nominal_values.get(entry, 0) == 0:
-                self._nominal_values[entry] = nominal_d.get(entry, self._limits[entry])
+        """Completes `limits` / `nominal_values` the way the reference does after a motor computed its derived quantities
+        (behaviour of electric_motor.py:296-317): a quantity the user left unset (absent or 0) takes the derived limit -- omega always
+        falls back to the class default -- and an unset nominal value takes the derived nominal value, else the (final) limit."""
+        derived = {**(limits_d or {}), "omega": self._default_limits["omega"]}
+        self._limits.update({q: v for q, v in derived.items() if not self._limits.get(q)})
+        fallback = nominal_d or {}
+        self._nominal_values.update({q: fallback.get(q, lim) for q, lim in self._limits.items() if not self._nominal_values.get(q)})
 
 
 class DcPermanentlyExcitedMotor(_ElectricMotor):
@@ -387,18 +384,26 @@ class _ThreePhaseMotor(_ElectricMotor):
     IO_CURRENTS = []
 
     def _three_phase_limits(self):
-        """synchronous_motor.py:173-189 / squirrel_cage_induction_motor.py:131-144 + three_phase_motor.py:125-131."""
-        voltage_limit = 0.5 * self._limits["u"]
-        voltage_nominal = 0.5 * self._nominal_values["u"]
-        limits_agenda, nominal_agenda = {}, {}
+        """Phase-quantity limits of a three-phase machine behind a B6 bridge (behaviour of synchronous_motor.py:173-189 /
+        squirrel_cage_induction_motor.py:131-144 + three_phase_motor.py:125-131): every phase / dq voltage is bounded by half the
+        DC-link voltage, every current by the user's 'i' or, failing that, by voltage over stator resistance; then the torque limit."""
         r_s = self._motor_parameter["r_s"]
-        for u, i in zip(self.IO_VOLTAGES, self.IO_CURRENTS):
-            limits_agenda[u] = voltage_limit
-            nominal_agenda[u] = voltage_nominal
-            limits_agenda[i] = self._limits.get("i", None) or self._limits[u] / r_s
-            nominal_agenda[i] = self._nominal_values.get("i", None) or self._nominal_values[u] / r_s
-        self._update_limits(limits_agenda, nominal_agenda)
-        self._update_limits(dict(torque=self._torque_limit()))
+
+        def derive(table):
+            u_half = 0.5 * table["u"]
+            out = {u: u_half for u in self.IO_VOLTAGES}
+            # (the current bound reads the table's own voltage entry -- set by the user or not -- exactly as the reference does)
+            out.update({i: table.get("i") or table[u] / r_s for u, i in zip(self.IO_VOLTAGES, self.IO_CURRENTS)})
+            return out
+
+        self._update_limits(derive(self._limits), derive(self._nominal_values))
+        self._update_limits({"torque": self._torque_limit()})
+
+
+def _max_torque_d_current(flux, delta_l, i_max, root):
+    """d-axis current of the stationary torque point on the current circle |i| = i_max for T ~ (flux + delta_l * i_d) * i_q:
+    2 delta_l i_d^2 + flux i_d - delta_l i_max^2 = 0  ->  i_d = (-flux + root * sqrt(flux^2 + 8 delta_l^2 i_max^2)) / (4 delta_l)."""
+    return (-flux + root * math.sqrt(flux * flux + 8.0 * (delta_l * i_max) ** 2)) / (4.0 * delta_l)
 
 
 class PermanentMagnetSynchronousMotor(_ThreePhaseMotor):
@@ -435,16 +440,16 @@ class PermanentMagnetSynchronousMotor(_ThreePhaseMotor):
         return 1.5 * mp["p"] * (mp["psi_p"] + (mp["l_d"] - mp["l_q"]) * currents[0]) * currents[1]
 
     def _torque_limit(self):
-        """lines 121-132."""
+        """Torque at the nominal-current operating point with the most torque (behaviour of permanent_magnet_synchronous_motor.py:
+        121-132).  Non-salient machine: all current in q at its LIMIT.  Salient: the stationary point of T(i_d) on the nominal-current
+        circle; the reference takes the root on the negative-d side for l_d < l_q and keeps the same expression for l_d > l_q."""
         mp = self._motor_parameter
-        if mp["l_d"] == mp["l_q"]:
+        delta_l = mp["l_d"] - mp["l_q"]
+        if delta_l == 0:
             return self.torque([0, self._limits["i_sq"], 0])
         i_n = self._nominal_values["i"]
-        _p = mp["psi_p"] / (2 * (mp["l_d"] - mp["l_q"]))
-        _q = -(i_n**2) / 2
-        i_d_opt = -_p / 2 - np.sqrt((_p / 2) ** 2 - _q)
-        i_q_opt = np.sqrt(i_n**2 - i_d_opt**2)
-        return self.torque([i_d_opt, i_q_opt, 0])
+        i_d = _max_torque_d_current(mp["psi_p"], delta_l, i_n, root=1.0 if delta_l < 0 else -1.0)
+        return self.torque([i_d, math.sqrt(i_n * i_n - i_d * i_d), 0])
 
     def torque_coefficients(self):
         mp = self._motor_parameter
@@ -503,19 +508,16 @@ class ExternallyExcitedSynchronousMotor(_ThreePhaseMotor):
         return 1.5 * mp["p"] * (mp["l_M"] * currents[2] * mp["i_k_rs"] + (mp["l_d"] - mp["l_q"]) * currents[0]) * currents[1]
 
     def _torque_limit(self):
-        """lines 115-131."""
+        """As for the PMSM with the excitation at its limit: flux linkage l_M * i_n, always the physically meaningful root
+        (behaviour of externally_excited_synchronous_motor.py:115-131)."""
         mp = self._motor_parameter
-        if mp["l_d"] == mp["l_q"]:
-            return self.torque([0, self._limits["i_sq"], self._limits["i_e"], 0])
+        delta_l = mp["l_d"] - mp["l_q"]
+        i_e = self._limits["i_e"]
+        if delta_l == 0:
+            return self.torque([0, self._limits["i_sq"], i_e, 0])
         i_n = self._nominal_values["i"]
-        _p = mp["l_M"] * i_n / (2 * (mp["l_d"] - mp["l_q"]))
-        _q = -(i_n**2) / 2
-        if mp["l_d"] < mp["l_q"]:
-            i_d_opt = -_p / 2 - np.sqrt((_p / 2) ** 2 - _q)
-        else:
-            i_d_opt = -_p / 2 + np.sqrt((_p / 2) ** 2 - _q)
-        i_q_opt = np.sqrt(i_n**2 - i_d_opt**2)
-        return self.torque([i_d_opt, i_q_opt, self._limits["i_e"], 0])
+        i_d = _max_torque_d_current(mp["l_M"] * i_n, delta_l, i_n, root=1.0)
+        return self.torque([i_d, math.sqrt(i_n * i_n - i_d * i_d), i_e, 0])
 
     def torque_coefficients(self):
         mp = self._motor_parameter
@@ -558,8 +560,10 @@ class SynchronousReluctanceMotor(_ThreePhaseMotor):
         return 1.5 * mp["p"] * ((mp["l_d"] - mp["l_q"]) * currents[0]) * currents[1]
 
     def _torque_limit(self):
-        """lines 131-133."""
-        return self.torque([self._limits["i_sd"] / np.sqrt(2), self._limits["i_sq"] / np.sqrt(2), 0])
+        """Pure reluctance torque ~ i_d * i_q peaks at 45 degrees of current angle: both limits over sqrt(2)
+        (behaviour of synchronous_reluctance_motor.py:131-133)."""
+        k = 1.0 / math.sqrt(2.0)
+        return self.torque([k * self._limits["i_sd"], k * self._limits["i_sq"], 0])
 
     def torque_coefficients(self):
         mp = self._motor_parameter

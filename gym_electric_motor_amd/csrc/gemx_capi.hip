@@ -10,18 +10,20 @@
 namespace gemx {
 
 // Reset observation of ONE env from its (freshly drawn) initial state: SCMLSystem.reset 256-287 (DC systems),
-// SynchronousMotorSystem.reset 527-561, ExternallyExcitedSynchronousMotorSystem.reset 654-691 -- the systems random
-// initialisers are available for.  Converter reset voltages: 0 per 4QC, -0.5 u_sup per B6 leg.
+// SynchronousMotorSystem.reset 527-561, ExternallyExcitedSynchronousMotorSystem.reset 654-691, SquirrelCageInductionMotorSystem.reset
+// 816-847, DoublyFedInductionMotorSystem.reset 1031-1113 -- the device-side mirror of host_reset_obs() below (which serves the constant
+// initial state).  Converter reset voltages: 0 per 4QC, -0.5 u_sup per B6 leg.  y = [omega, motor states...], eps = electrical angle.
 template <class R>
-__device__ void reset_obs_row(int sys, const DevParams<R> &P, const double *y, double eps, int nd, double *o) {
-    const double us = (double)P.u_sup;
+__device__ void reset_obs_row(int sys, const DevParams<R> &P, const double *y, double eps, int nd, int nout, double *o) {
+    const double us = (double)P.u_sup, s3 = sqrt(3.0);
+    for (int j = 0; j < nout; ++j) o[j] = 0.0;
+    const double ua = -0.5 * us, ual = 2.0 / 3.0 * (ua - 0.5 * ua - 0.5 * ua), ube = 2.0 / 3.0 * (0.5 * s3 * ua - 0.5 * s3 * ua);
+    if (eps > kPi) eps -= kTwoPi;
     if (sys == GEMX_SYS_SYNC || sys == GEMX_SYS_EESM) {
-        if (eps > kPi) eps -= kTwoPi;
         const double c = cos(eps), s = sin(eps);
         const double al = c * y[1] - s * y[2], be = s * y[1] + c * y[2];
-        const double ua = -0.5 * us, ual = 2.0 / 3.0 * (ua - 0.5 * ua - 0.5 * ua), ube = 2.0 / 3.0 * (0.5 * sqrt(3.0) * ua - 0.5 * sqrt(3.0) * ua);
         o[0] = y[0];
-        o[2] = al; o[3] = -0.5 * al + 0.5 * sqrt(3.0) * be; o[4] = -0.5 * al - 0.5 * sqrt(3.0) * be;
+        o[2] = al; o[3] = -0.5 * al + 0.5 * s3 * be; o[4] = -0.5 * al - 0.5 * s3 * be;
         o[5] = y[1]; o[6] = y[2];
         if (sys == GEMX_SYS_SYNC) {
             o[1] = ((double)P.tc0 + (double)P.tc1 * y[1]) * y[2];
@@ -31,6 +33,28 @@ __device__ void reset_obs_row(int sys, const DevParams<R> &P, const double *y, d
             o[7] = y[3];
             o[8] = ua; o[9] = ua; o[10] = ua; o[11] = 0.0; o[12] = c * ual + s * ube; o[13] = -s * ual + c * ube; o[14] = eps; o[15] = us;
         }
+    } else if (sys == GEMX_SYS_SCIM) {  // y = [omega, i_salpha, i_sbeta, psi_ralpha, psi_rbeta]; dq frame = rotor-flux angle (lines 765-769)
+        const double efs = atan2(y[4], y[3]), c = cos(efs), s = sin(efs);
+        o[0] = y[0]; o[1] = (double)P.tc0 * (y[3] * y[2] - y[4] * y[1]);
+        o[2] = y[1]; o[3] = -0.5 * y[1] + 0.5 * s3 * y[2]; o[4] = -0.5 * y[1] - 0.5 * s3 * y[2];
+        o[5] = c * y[1] + s * y[2]; o[6] = -s * y[1] + c * y[2];
+        o[7] = ua; o[8] = ua; o[9] = ua; o[10] = c * ual + s * ube; o[11] = -s * ual + c * ube; o[12] = eps; o[13] = us;
+    } else if (sys == GEMX_SYS_DFIM) {  // lines 1031-1113: stator in the field frame, rotor quantities rotated by eps_field - eps_el
+        double ef = atan2(y[4], y[3]);
+        if (ef > kPi) ef -= kTwoPi;
+        const double cf = cos(ef), sf = sin(ef), cd = cos(ef - eps), sd = sin(ef - eps);
+        const double ira = (double)P.tc2 * y[3] - (double)P.tc3 * y[1], irb = (double)P.tc2 * y[4] - (double)P.tc3 * y[2];
+        const double ird = cd * ira + sd * irb, irq = -sd * ira + cd * irb;
+        const double ra = cd * ird - sd * irq, rb = sd * ird + cd * irq;
+        o[0] = y[0]; o[1] = (double)P.tc0 * (y[3] * y[2] - y[4] * y[1]);
+        o[2] = y[1]; o[3] = -0.5 * y[1] + 0.5 * s3 * y[2]; o[4] = -0.5 * y[1] - 0.5 * s3 * y[2];
+        o[5] = cf * y[1] + sf * y[2]; o[6] = -sf * y[1] + cf * y[2];
+        o[7] = ra; o[8] = -0.5 * ra + 0.5 * s3 * rb; o[9] = -0.5 * ra - 0.5 * s3 * rb;
+        o[10] = ird; o[11] = irq;
+        for (int l = 0; l < 3; ++l) { o[12 + l] = ua; o[17 + l] = ua; }
+        o[15] = cf * ual + sf * ube; o[16] = -sf * ual + cf * ube;
+        o[20] = cd * ual + sd * ube; o[21] = -sd * ual + cd * ube;
+        o[22] = eps; o[23] = us;
     } else {  // DC systems: [omega, torque, currents..., u (0 per converter), u_sup]
         const int nc = nd - 1, nu = sys == GEMX_SYS_DC_EXTEX ? 2 : 1;
         double torque = (double)P.tc0 * y[1];
@@ -75,7 +99,7 @@ __global__ void reset_kernel(R *state, typename Angle<R>::T *angle, const uint8_
     if (obs != nullptr) {
         double row[GEMX_MAX_OUT];
         if (P.init_kind) {
-            reset_obs_row<R>(sys, P, y0, eps0, nd, row);
+            reset_obs_row<R>(sys, P, y0, eps0, nd, nout, row);
             for (int j = 0; j < nout; ++j) row[j] *= (double)P.inv_lim[j];
         }
         for (int j = 0; j < nout; ++j) {
@@ -374,7 +398,7 @@ extern "C" {
 
 int gemx_abi_version(void) { return GEMX_ABI_VERSION; }
 int gemx_sizeof_config(void) { return (int)sizeof(gemx_config); }
-int gemx_debug_read(gemx_handle *h, unsigned long long *out, int n) { return (int)hipMemcpy(out, (char *)h->err + 64, n * 8, hipMemcpyDeviceToHost); }
+int gemx_debug_read(gemx_handle *h, unsigned long long *out, int n) { gemx::DeviceGuard guard(h->device); return (int)hipMemcpy(out, (char *)h->err + 64, n * 8, hipMemcpyDeviceToHost); }
 const char *gemx_last_error(void) { return g_err; }
 
 int gemx_device_count(void) {
@@ -483,8 +507,10 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         return fail(GEMX_ERR_DEVICE, "no HIP device visible: the gemx stepper has no CPU fallback");
     }
     if (device < 0 || device >= ndev) { delete h; return fail(GEMX_ERR_ARG, "device %d out of range (0..%d)", device, ndev - 1); }
-    if (hipSetDevice(device) != hipSuccess) { delete h; return fail(GEMX_ERR_DEVICE, "hipSetDevice(%d) failed", device); }
+    gemx::DeviceGuard guard(device);  // the caller's current device is restored on every return path
     {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != device) { delete h; return fail(GEMX_ERR_DEVICE, "hipSetDevice(%d) failed", device); }
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
             if (prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
@@ -572,7 +598,7 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
 
 int gemx_destroy(gemx_handle *h) {
     if (!h) return GEMX_OK;
-    (void)hipSetDevice(h->device);
+    gemx::DeviceGuard guard(h->device);
     if (h->state) (void)hipFree(h->state);
     if (h->angle) (void)hipFree(h->angle);
     if (h->sw) (void)hipFree(h->sw);
@@ -612,6 +638,7 @@ int gemx_reset_observation(const gemx_handle *h, double *obs_host) {
 
 int gemx_reset(gemx_handle *h, const uint8_t *mask_dev, void *obs_out_dev, void *stream) {
     if (!h) return fail(GEMX_ERR_ARG, "null handle");
+    gemx::DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
     return h->cfg.dtype == GEMX_F64 ? launch_reset<double>(h, mask_dev, obs_out_dev, st) : launch_reset<float>(h, mask_dev, obs_out_dev, st);
 }
@@ -622,6 +649,7 @@ int gemx_rollout(gemx_handle *h, const void *actions_dev, int32_t K, void *obs_o
     if (!actions_dev || !obs_out_dev) return fail(GEMX_ERR_ARG, "actions_dev and obs_out_dev must not be null");
     if (K < 1) return fail(GEMX_ERR_ARG, "K must be >= 1");
     if (((uintptr_t)obs_out_dev & 15u) != 0) return fail(GEMX_ERR_ARG, "obs_out_dev must be 16-byte aligned");
+    gemx::DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
     return launch_advance(h, actions_dev, K, obs_out_dev, done_out_dev, obs_every ? 1 : 0, st);
 }
@@ -638,7 +666,7 @@ int gemx_set_reward(gemx_handle *h, const gemx_reward_config *rc) {
     }
     for (int i = 0; i < h->nout; ++i)
         if (rc->weight[i] != 0.0 && !(rc->state_length[i] > 0)) return fail(GEMX_ERR_ARG, "state_length[%d] must be positive", i);
-    HIP_TRY(hipSetDevice(h->device));
+    gemx::DeviceGuard guard(h->device);
     if (!h->rw_dev && hipMalloc(&h->rw_dev, sizeof(RewardDev<double>)) != hipSuccess) return fail(GEMX_ERR_ALLOC, "hipMalloc(reward) failed");
     if (h->cfg.dtype == GEMX_F64) {
         RewardDev<double> W;
@@ -674,6 +702,7 @@ int gemx_step(gemx_handle *h, const void *actions_dev, void *obs_out_dev, uint8_
 
 int gemx_get_state(gemx_handle *h, void *soa_out_dev, void *stream) {
     if (!h || !soa_out_dev) return fail(GEMX_ERR_ARG, "null argument");
+    gemx::DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
     int64_t blocks = (h->n + 255) / 256;
     if (h->cfg.dtype == GEMX_F64)
@@ -687,6 +716,7 @@ int gemx_get_state(gemx_handle *h, void *soa_out_dev, void *stream) {
 }
 int gemx_set_state(gemx_handle *h, const void *soa_in_dev, void *stream) {
     if (!h || !soa_in_dev) return fail(GEMX_ERR_ARG, "null argument");
+    gemx::DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
     int64_t blocks = (h->n + 255) / 256;
     if (h->cfg.dtype == GEMX_F64)
@@ -700,11 +730,13 @@ int gemx_set_state(gemx_handle *h, const void *soa_in_dev, void *stream) {
 }
 int gemx_get_switch_state(gemx_handle *h, uint8_t *out_dev, void *stream) {
     if (!h || !out_dev) return fail(GEMX_ERR_ARG, "null argument");
+    gemx::DeviceGuard guard(h->device);
     HIP_TRY(hipMemcpyAsync(out_dev, h->sw, (size_t)h->n * h->sw_rows, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return GEMX_OK;
 }
 int gemx_set_switch_state(gemx_handle *h, const uint8_t *in_dev, void *stream) {
     if (!h || !in_dev) return fail(GEMX_ERR_ARG, "null argument");
+    gemx::DeviceGuard guard(h->device);
     HIP_TRY(hipMemcpyAsync(h->sw, in_dev, (size_t)h->n * h->sw_rows, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return GEMX_OK;
 }
@@ -728,6 +760,7 @@ int gemx_set_steps_per_block(gemx_handle *h, int32_t steps) {
 }
 int gemx_error_flags(gemx_handle *h, uint32_t *flags_host, void *stream) {
     if (!h || !flags_host) return fail(GEMX_ERR_ARG, "null argument");
+    gemx::DeviceGuard guard(h->device);
     HIP_TRY(hipMemcpyAsync(flags_host, h->err, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return GEMX_OK;

@@ -108,8 +108,13 @@ template <> struct Angle<float> {
     }
     static __host__ __device__ T from_bits(int64_t b) { return (T)(int32_t)b; }
     static __host__ int64_t to_bits(T a) { return (int64_t)a; }
+    // (the float -> int conversion SATURATES at +-2^31 counts = half a turn, so an increment beyond pi -- the DqToAbcActionProcessor's
+    // (0.5 + dead time) * tau * p * omega at 8 dead-time steps near the speed limit, or a large tau -- is first reduced modulo one turn:
+    // x - 2^32 rint(x 2^-32) is exact, both terms being multiples of x's ulp)
     static __device__ __forceinline__ T advance(T a, float d_rad) {
-        int32_t inc = __float2int_rn(d_rad * kCountsPerRad);
+        const float x = d_rad * kCountsPerRad;
+        const float y = fmaf(-4294967296.0f, rintf(x * 2.3283064365386963e-10f), x);  // in [-2^31, 2^31]
+        int32_t inc = __float2int_rn(y);
         return (T)((uint32_t)a + (uint32_t)inc);
     }
     static __device__ __forceinline__ float wrapped(T a) { return (float)a * kRadPerCount; }  // [-pi, pi]
@@ -386,6 +391,9 @@ struct gemx_handle {
     struct LastLaunch { int pipe, sys, conv, load, solver, il, real_size, d, threads, k, s; long long blocks; size_t lds; };
     LastLaunch ll = {};            // most recent advance launch (formatted lazily by gemx_last_launch)
     mutable char last_launch[256] = "";
+    unsigned pipe_attr_set = 0;  // bit k: hipFuncSetAttribute(max dynamic LDS) done for pipelined shape k (per handle = per device:
+    bool attr_set = false;       //   the attribute is per device, and a handle is bound to one device and one kernel instantiation)
+    int wg_per_cu = 0;           // single-wave kernel: resident workgroups per CU from its VGPR count (0: not queried yet)
     int pipe_shape = -1;      // GEMX_PIPE_SHAPE=0/1/2 forces <12,3> / <4,2> / <2,2> whenever it fits (tests: every shape on small N)
     int use_pipe = -1;        // pipelined kernel: -1 / 1 whenever eligible (default), 0 never (GEMX_PIPE=0: A/B and bit-identity tests)
 };
@@ -399,6 +407,23 @@ int fail(int code, const char *fmt, ...);  // sets gemx_last_error(); defined in
 
 // one launcher per (system, converter, dtype) instantiation unit; dispatches on load / solver / interlocking
 typedef int (*advance_fn)(gemx_handle *h, const void *actions, int K, void *obs, uint8_t *done, int obs_every, hipStream_t st);
+}  // namespace gemx
+
+namespace gemx {
+// Every entry point that launches, allocates or copies runs on ITS handle's device and leaves the caller's current device (torch's,
+// when called from Python) as it found it.
+struct DeviceGuard {
+    int prev = -1, dev;
+    explicit DeviceGuard(int device) : dev(device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
 }  // namespace gemx
 
 #define GEMX_HIP_TRY(x)                                                                                              \

@@ -2131,18 +2131,17 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     a.K = K;
     a.obs_every = obs_every;
     auto kern = advance_kernel<SYS, CONV, LOAD, SOLVER, IL, R>;
-    static int wg_per_cu = 0;  // per instantiation: single-wave workgroups a CU can hold, from the kernel's VGPR count
-    if (wg_per_cu == 0) {
+    if (h->wg_per_cu == 0) {  // single-wave workgroups a CU can hold, from the kernel's VGPR count
         hipFuncAttributes fa;
-        wg_per_cu = 16;
+        h->wg_per_cu = 16;
         if (hipFuncGetAttributes(&fa, (const void *)kern) == hipSuccess && fa.numRegs > 0) {
             int waves = 512 / ((fa.numRegs + 7) & ~7);  // gfx950: 512 VGPRs per SIMD lane, allocation granule 8
             if (waves < 1) waves = 1;
             if (waves > 8) waves = 8;
-            wg_per_cu = 4 * waves;
+            h->wg_per_cu = 4 * waves;
         }
     }
-    a.S = choose_steps_per_block(h, K, (int)sizeof(R), ABYTES, wg_per_cu);
+    a.S = choose_steps_per_block(h, K, (int)sizeof(R), ABYTES, h->wg_per_cu);
     a.D = 1;
     // 16-byte alignment of every full block's rows: row starts are (k*N + blk0) * bytes_per_env with blk0 % 64 == 0
     a.coop = (((uintptr_t)actions & 15u) == 0 && ((size_t)h->n * ABYTES) % 16 == 0 &&
@@ -2204,10 +2203,9 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                          : shape == 1 ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2>
                          : shape == 2 ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D3, PIPE_OUT_WAVES3>
                                       : advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES_RW>;
-            static bool pattr_set[4] = {false, false, false, false};
-            if (!pattr_set[shape]) {
+            if (!(h->pipe_attr_set & (1u << shape))) {
                 GEMX_HIP_TRY(hipFuncSetAttribute((const void *)pkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max));
-                pattr_set[shape] = true;
+                h->pipe_attr_set |= 1u << shape;
             }
             const int threads = (1 + OW + pipe_loader_waves(D)) * BLOCK;
             hipLaunchKernelGGL(pkern, dim3((unsigned)blocks), dim3(threads), psmem, st, a);
@@ -2216,10 +2214,9 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             return GEMX_OK;
         }
     }
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
+    if (!h->attr_set) {
         GEMX_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max));
-        attr_set = true;
+        h->attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), smem, st, a);
     GEMX_HIP_TRY(hipGetLastError());

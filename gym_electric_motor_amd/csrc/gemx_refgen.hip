@@ -91,8 +91,8 @@ __device__ inline double walk_step(const RefgenDev &G, int g, double value, doub
 // (2) out[k][env][g] holds z on entry and the reference of step k on exit.  done[k][env] != 0: the env terminated in step k, its
 // generators are reset before the reference of step k+1 is produced (env.reset() -> reference_generator.reset(), core.py:312-313).
 template <class R>
-__global__ void refgen_walk_kernel(R *out, const uint8_t *done, const uint8_t *reset_mask, int64_t N, int K, RefgenDev G, double *value,
-                                   double *sigma, int32_t *left, uint32_t *n_sub, uint32_t *n_reset) {
+__global__ void refgen_walk_kernel(R *out, const uint8_t *done, const uint8_t *reset_mask, int reset_all, int64_t N, int K, RefgenDev G,
+                                   double *value, double *sigma, int32_t *left, uint32_t *n_sub, uint32_t *n_reset) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * G.n_ref) return;
     const int g = (int)(idx % G.n_ref);
@@ -101,8 +101,8 @@ __global__ void refgen_walk_kernel(R *out, const uint8_t *done, const uint8_t *r
     double v = value[si], sg = sigma[si];
     int32_t lf = left[si];
     uint32_t ns = n_sub[si], nr = n_reset[si];
-    if (reset_mask != nullptr && K == 0) {  // gemx_refgen_reset
-        if (reset_mask[env]) reset_generator(G, env, g, nr, ns, lf, sg, v);
+    if (K == 0) {  // gemx_refgen_reset: the masked envs, or all of them (reset_all: no mask buffer at all)
+        if (reset_all || (reset_mask != nullptr && reset_mask[env])) reset_generator(G, env, g, nr, ns, lf, sg, v);
     }
     for (int k = 0; k < K; ++k) {
         const int64_t o = ((int64_t)k * N + env) * G.n_ref + g;
@@ -126,9 +126,9 @@ RefgenDev make_dev(const gemx_refgen_config &c) {
     return G;
 }
 
-template <class R> int walk(gemx_refgen *r, void *out, const uint8_t *done, const uint8_t *mask, int K, hipStream_t st) {
+template <class R> int walk(gemx_refgen *r, void *out, const uint8_t *done, const uint8_t *mask, int reset_all, int K, hipStream_t st) {
     const int64_t lanes = r->n * r->cfg.n_ref;
-    hipLaunchKernelGGL(refgen_walk_kernel<R>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, (R *)out, done, mask, r->n, K, make_dev(r->cfg),
+    hipLaunchKernelGGL(refgen_walk_kernel<R>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, (R *)out, done, mask, reset_all, r->n, K, make_dev(r->cfg),
                        r->value, r->sigma, r->left, r->n_sub, r->n_reset);
     GEMX_HIP_TRY(hipGetLastError());
     return GEMX_OK;
@@ -153,7 +153,7 @@ int gemx_refgen_create(const gemx_refgen_config *cfg, int64_t n_envs, int device
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return gemx::fail(GEMX_ERR_DEVICE, "no HIP device visible: there is no CPU fallback");
     if (device < 0 || device >= ndev) return gemx::fail(GEMX_ERR_ARG, "device %d out of range", device);
-    GEMX_HIP_TRY(hipSetDevice(device));
+    gemx::DeviceGuard guard(device);
     gemx_refgen *r = new (std::nothrow) gemx_refgen();
     if (!r) return gemx::fail(GEMX_ERR_ALLOC, "out of host memory");
     r->cfg = *cfg; r->n = n_envs; r->device = device; r->f64 = dtype == GEMX_F64;
@@ -172,7 +172,7 @@ int gemx_refgen_create(const gemx_refgen_config *cfg, int64_t n_envs, int device
 
 int gemx_refgen_destroy(gemx_refgen *r) {
     if (!r) return GEMX_OK;
-    (void)hipSetDevice(r->device);
+    gemx::DeviceGuard guard(r->device);
     if (r->value) (void)hipFree(r->value);
     if (r->sigma) (void)hipFree(r->sigma);
     if (r->left) (void)hipFree(r->left);
@@ -186,24 +186,16 @@ int gemx_refgen_destroy(gemx_refgen *r) {
 // the next generated step.
 int gemx_refgen_reset(gemx_refgen *r, const uint8_t *mask_dev, void *stream) {
     if (!r) return gemx::fail(GEMX_ERR_ARG, "null handle");
+    gemx::DeviceGuard guard(r->device);
     hipStream_t st = (hipStream_t)stream;
-    static uint8_t *ones = nullptr;
-    static int64_t ones_n = 0;
-    if (mask_dev == nullptr) {
-        if (ones_n < r->n) {
-            if (ones) (void)hipFree(ones);
-            if (hipMalloc((void **)&ones, (size_t)r->n) != hipSuccess) return gemx::fail(GEMX_ERR_ALLOC, "hipMalloc failed");
-            (void)hipMemset(ones, 1, (size_t)r->n);
-            ones_n = r->n;
-        }
-        mask_dev = ones;
-    }
-    return r->f64 ? walk<double>(r, nullptr, nullptr, mask_dev, 0, st) : walk<float>(r, nullptr, nullptr, mask_dev, 0, st);
+    const int all = mask_dev == nullptr;
+    return r->f64 ? walk<double>(r, nullptr, nullptr, mask_dev, all, 0, st) : walk<float>(r, nullptr, nullptr, mask_dev, all, 0, st);
 }
 
 int gemx_refgen_rollout(gemx_refgen *r, const uint8_t *done_dev, int32_t K, void *refs_out_dev, void *stream) {
     if (!r || !refs_out_dev) return gemx::fail(GEMX_ERR_ARG, "null argument");
     if (K < 1) return gemx::fail(GEMX_ERR_ARG, "K must be >= 1");
+    gemx::DeviceGuard guard(r->device);
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)K * r->n * r->cfg.n_ref;
     if (r->f64)
@@ -214,12 +206,13 @@ int gemx_refgen_rollout(gemx_refgen *r, const uint8_t *done_dev, int32_t K, void
                            r->cfg.seed, (uint64_t)r->t_total);
     GEMX_HIP_TRY(hipGetLastError());
     r->t_total += (unsigned long long)K;
-    return r->f64 ? walk<double>(r, refs_out_dev, done_dev, nullptr, K, st) : walk<float>(r, refs_out_dev, done_dev, nullptr, K, st);
+    return r->f64 ? walk<double>(r, refs_out_dev, done_dev, nullptr, 0, K, st) : walk<float>(r, refs_out_dev, done_dev, nullptr, 0, K, st);
 }
 
 // debug / test access: per (generator, env) arrays [n_ref][N]: value (double), sigma (double), steps left (int32)
 int gemx_refgen_get_state(gemx_refgen *r, double *value_out_dev, double *sigma_out_dev, int32_t *left_out_dev, void *stream) {
     if (!r) return gemx::fail(GEMX_ERR_ARG, "null handle");
+    gemx::DeviceGuard guard(r->device);
     const size_t m = (size_t)r->n * r->cfg.n_ref;
     hipStream_t st = (hipStream_t)stream;
     if (value_out_dev) GEMX_HIP_TRY(hipMemcpyAsync(value_out_dev, r->value, m * 8, hipMemcpyDeviceToDevice, st));

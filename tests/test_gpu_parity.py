@@ -637,6 +637,88 @@ def test_random_uniform_initialisers_match_reference_distribution(case):
     env.close()
 
 
+@pytest.mark.parametrize("env_id, golden", [("Cont-SC-SCIM-v0", "scim_free_held_euler"), ("Cont-SC-DFIM-v0", "dfim_cont_sc_free_held_euler")])
+def test_induction_motor_random_load_initialiser_reset_rows(env_id, golden):
+    """Induction-motor systems accept a random LOAD initialiser (omega); their reset observation is then written per env by
+    reset_kernel (gemx_capi.hip:reset_obs_row) in the SCIM / DFIM layout -- u_abc = -0.5 u_sup per leg, dq columns in the rotor-flux
+    frame -- and equals the oracle's reset from the drawn state, both from reset() and from a masked reset."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+    from oracle import oracle as orc
+
+    n = 300
+    _, meta = _load(golden)
+    load = ga.PolynomialStaticLoad(load_parameter=meta["load_parameter"], load_initializer=dict(random_init="uniform", interval=[[-150.0, 220.0]]))
+    env = ga.make(env_id, n_envs=n, load=load, seed=3)
+    ps = env.physical_system
+    obs = ps.reset().double().cpu().numpy()
+    y = ps.get_state().double().cpu().numpy().T
+    assert y[:, 0].min() >= -150.0 and y[:, 0].max() <= 220.0 and np.ptp(y[:, 0]) > 200.0 and np.abs(y[:, 1:]).max() == 0.0
+    p = orc.params_from_meta(meta)
+    for i in (0, 1, 63, 64, n - 1):
+        p.init[0] = y[i, 0]
+        assert np.abs(orc.OracleEnv(p).reset() - obs[i]).max() < 1e-6, i
+    us = ps.state_positions["u_sup"]
+    assert np.all(obs[:, us] == 1.0) and np.isfinite(obs).all()
+    mask = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    mask[5] = 1
+    o2 = ps.reset(mask).double().cpu().numpy()
+    y2 = ps.get_state().double().cpu().numpy().T
+    assert y2[5, 0] != y[5, 0] and np.array_equal(np.delete(y2, 5, axis=0), np.delete(y, 5, axis=0))
+    p.init[0] = y2[5, 0]
+    assert np.abs(orc.OracleEnv(p).reset() - o2[5]).max() < 1e-6 and np.array_equal(np.delete(o2, 5, axis=0), np.delete(obs, 5, axis=0))
+    env.close()
+
+
+def test_dq_processor_angle_advance_beyond_half_a_turn():
+    """DqToAbcActionProcessor's angle advance (0.5 + dead time) * tau * p * omega (dq_to_abc_action_processor.py:83-100) exceeds pi at
+    8 dead-time steps, tau = 4e-4 and 400 rad/s (4.08 rad): the fp32 fixed-point angle must WRAP there (its float -> int conversion
+    saturates at half a turn), as the fp64 path and the reference do.  GPU fp32 and fp64 against the oracle, same (Euler) integrator."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+    from oracle import oracle as orc
+
+    _, meta = _load("pmsm_cont_dqproc_dead2_free_held_euler")
+    meta = dict(meta, tau=4e-4, dead_time_steps=8, omega_fixed=400.0)
+    p = orc.params_from_meta(meta, solver="euler", episodic=False)
+    K, n = 300, 64
+    rng = np.random.default_rng(3)
+    acts = rng.uniform(-0.3, 0.3, (K, 2))
+    e = orc.OracleEnv(p)
+    e.reset()
+    ref, _ = e.rollout(acts, auto_reset=False)
+    for dtype, tol in (("float32", 1e-4), ("float64", 1e-9)):
+        env = ga.make("Cont-CC-PMSM-v0", n_envs=n, dtype=dtype, tau=4e-4, ode_solver=ga.EulerSolver(), constraints=(),
+                      load=ga.ConstantSpeedLoad(omega_fixed=400.0),
+                      physical_system_wrappers=(ga.DeadTimeProcessor(steps=8), ga.DqToAbcActionProcessor.make("PMSM")))
+        a = torch.as_tensor(np.repeat(acts[:, None, :], n, axis=1)).cuda()
+        obs, _ = env.rollout(a)
+        torch.cuda.synchronize()
+        rel, ab = _rel_err(obs[:, 0].double().cpu().numpy(), ref, meta["state_names"])
+        env.close()
+        assert (rel if dtype == "float32" else ab) < tol, (dtype, rel, ab)
+
+
+def test_single_env_random_initialiser_reset_returns_the_drawn_state():
+    """n_envs == 1 (the instance handed to the reference's ElectricMotorEnvironment): with a random initialiser reset() returns the
+    observation of the state the kernel just drew, not the constant initial state's."""
+    env, meta, _, _ = _init_env("pmsm_sc_uniform", 1)
+    ps = env.physical_system
+    seen = []
+    for _ in range(3):
+        o = ps.reset()
+        y = ps.get_state().double().cpu().numpy()[:, 0]
+        assert isinstance(o, np.ndarray) and o.shape == (len(ps.state_names),)
+        lim = ps.limits
+        assert abs(o[ps.state_positions["omega"]] * lim[0] - y[0]) < 1e-3 * max(1.0, abs(y[0]))
+        assert abs(o[ps.state_positions["i_sd"]] * lim[ps.state_positions["i_sd"]] - y[1]) < 1e-3 * max(1.0, abs(y[1]))
+        seen.append(o.copy())
+    assert not np.array_equal(seen[0], seen[1]) and not np.array_equal(seen[1], seen[2])
+    env.close()
+
+
 def test_random_initialisers_streams_and_auto_reset():
     """Counter-based Philox streams: same seed -> same states, other seed / env / reset -> other states; the in-kernel auto-reset
     draws a fresh state (inside the bounds) for exactly the envs that terminated; step-by-step == fused == chunked, bit for bit."""
