@@ -32,6 +32,10 @@ def main():
     print("| fixture | env | K | reference solver | device solver | worst rel err | column | max abs err | done masks |")
     print("|---|---|---|---|---|---|---|---|---|")
     worst = {}
+    kinds = {"euler": "same solver (Euler)", "euler4": "same solver (Euler)", "dopri5": "vs reference default solver (scipy dopri5)",
+             "ivp_tight": "vs ScipySolveIvpSolver(rtol=1e-10, atol=1e-12)",
+             "ivp": "vs ScipySolveIvpSolver() at its default rtol 1e-3 (informational: see the note below)"}
+    notes = []
     for name in T.CASES:
         d, meta = T._load(name)
         if not args.all and meta["env_id"] not in base:
@@ -48,14 +52,27 @@ def main():
             d, meta, obs, done = T._run_golden(name, "float32", solver=solver)
             rel, ab, col, dmsg = T.compare_trajectory(meta, d, obs, done)
             print(f"| {name} | {meta['env_id']} | {len(d['terminated'])} | {meta['solver']} | {solver} | {rel:.2e} | {col} | {ab:.2e} | {dmsg} |", flush=True)
-            key = (meta["env_id"], "same solver" if meta["solver"].startswith("euler") else "vs default dopri5 / solve_ivp")
+            key = (meta["env_id"], kinds[meta["solver"]])
             if rel > worst.get(key, (0, ""))[0]:
                 worst[key] = (rel, f"{name} / {solver} / {col}")
+        if meta["solver"] == "ivp":  # how far the reference's solve_ivp path is from the reference's OWN default solver (CPU, fp64 oracle)
+            from oracle import oracle as orc
+
+            e = orc.OracleEnv(orc.params_from_meta(meta, solver="dopri5"))
+            e.reset()
+            o, dn = e.rollout(d["actions"])
+            r2, _, c2, _ = T.compare_trajectory(meta, d, o, dn)
+            notes.append(f"* `{name}`: fp64 oracle with the reference's default dopri5 vs this solve_ivp fixture: {r2:.2e} ({c2})")
     print()
     print("| env | comparison | worst rel err | where |")
     print("|---|---|---|---|")
     for (env_id, kind), (rel, where) in sorted(worst.items()):
         print(f"| {env_id} | {kind} | {rel:.2e} | {where} |")
+    print()
+    print("Note on the default-tolerance solve_ivp fixtures: that reference path (rtol 1e-3, plus the aliased right-hand-side buffer restated in "
+          "oracle/gemx_oracle.c:ivp_rk45) is itself this far from the reference's own default solver, so it pins the ORACLE (to 1e-10, "
+          "tests/test_oracle_golden.py), not the device; the 1e-4 contract is held against dopri5 and against solve_ivp at tight tolerances:")
+    print("\n".join(notes))
 
 
 if __name__ == "__main__":
