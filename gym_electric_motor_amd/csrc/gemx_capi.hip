@@ -522,6 +522,8 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         if (ev) h->use_pipe = atoi(ev);
         ev = getenv("GEMX_PIPE_SHAPE");
         if (ev) h->pipe_shape = atoi(ev);
+        ev = getenv("GEMX_STEP_KERNEL");
+        if (ev) h->use_step_kernel = atoi(ev);
         ev = getenv("GEMX_LINMAP");  // 0: never use the one-step map of the electrical subsystem (A/B runs)
         if (ev && atoi(ev) == 0) h->linmap_state = -1;
 
@@ -743,7 +745,10 @@ int gemx_set_switch_state(gemx_handle *h, const uint8_t *in_dev, void *stream) {
 const char *gemx_last_launch(const gemx_handle *h) {
     if (!h) return "";
     const auto &l = h->ll;
-    if (l.pipe)
+    if (l.pipe == 2)
+        snprintf(h->last_launch, sizeof(h->last_launch), "gemx::step_kernel<sys=%d,conv=%d,load=%d,solver=%d,il=%d,%s> grid=%lld x %d threads, K=1", l.sys, l.conv,
+                 l.load, l.solver, l.il, l.real_size == 4 ? "f32" : "f64", l.blocks, l.threads);
+    else if (l.pipe)
         snprintf(h->last_launch, sizeof(h->last_launch),
                  "gemx::advance_pipe_kernel<sys=%d,conv=%d,load=%d,solver=%d,il=%d,%s,D=%d> grid=%lld x %d threads, lds=%zu B, K=%d", l.sys,
                  l.conv, l.load, l.solver, l.il, l.real_size == 4 ? "f32" : "f64", l.d, l.blocks, l.threads, l.lds, l.k);

@@ -395,6 +395,7 @@ struct gemx_handle {
     bool attr_set = false;       //   the attribute is per device, and a handle is bound to one device and one kernel instantiation)
     int wg_per_cu = 0;           // single-wave kernel: resident workgroups per CU from its VGPR count (0: not queried yet)
     int pipe_shape = -1;      // GEMX_PIPE_SHAPE=0/1/2 forces <12,3> / <4,2> / <2,2> whenever it fits (tests: every shape on small N)
+    int use_step_kernel = 1;  // K = 1 launches take step_kernel (GEMX_STEP_KERNEL=0: advance_kernel, for A/B runs and bit-identity tests)
     int use_pipe = -1;        // pipelined kernel: -1 / 1 whenever eligible (default), 0 never (GEMX_PIPE=0: A/B and bit-identity tests)
 };
 

@@ -1399,6 +1399,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SYS == GE
     using AngT = typename Angle<R>::T;
     using V = typename std::conditional<sizeof(R) == 4, float4, double2>::type;
 
+#ifdef GEMX_TIMING
+    const unsigned long long pT0 = clock64(), pW0 = wall_clock64();
+    unsigned long long pT1 = 0, pT2 = 0, pT3 = 0;
+#endif
     const DevParams<R> &P = a.P;
     const int tid = threadIdx.x;
     const int64_t blk0 = (int64_t)blockIdx.x * BLOCK;
@@ -1483,6 +1487,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SYS == GE
     // same counter every I/O block would wait for the previous block's whole flush burst instead of overlapping it.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // gfx9 encoding: vmcnt(0), expcnt/lgkmcnt untouched
     __syncthreads();
+#ifdef GEMX_TIMING
+    pT1 = clock64();
+#endif
 
     uint32_t done_or = 0, bad_action = 0;
     R obs[NOUT];
@@ -1502,6 +1509,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SYS == GE
         if (coop) compute_block<true, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot, sup, lin_ok);
         else compute_block<false, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot, sup, lin_ok);
         __syncthreads();
+#ifdef GEMX_TIMING
+        if (k0 == 0) pT2 = clock64();
+#endif
 
         // 3. park the prefetched tile
         if (coop && sb_next > 0) GEMX_TILE_PARK(half ^ 1, sb_next);
@@ -1549,8 +1559,162 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SYS == GE
         }
     }
     if (bad_action && valid) atomicOr(a.err, 1u);
+#ifdef GEMX_TIMING
+    pT3 = clock64();
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // the stores have left the CU
+    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) {
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64) + 32 + (blockIdx.x ? 8 : 0);
+        dbg[0] = pT1 - pT0; dbg[1] = pT2 - pT1; dbg[2] = pT3 - pT2; dbg[3] = clock64() - pT3; dbg[4] = pW0; dbg[5] = wall_clock64();
+    }
+#endif
 #undef GEMX_TILE_LOAD
 #undef GEMX_TILE_PARK
+}
+
+// ------------------------------------------------------------------------------------------------
+// K = 1 (gemx_step, the closed-loop path: a policy between every two control steps).  Such a launch runs every instruction ONCE, so
+// its time is latency, not throughput.  Through advance_kernel a step took 4.4 us inside the kernel (s_memtime probe, PMSM, 16384
+// envs): 3200 cycles until the state had arrived, 4600 for the one control step (the action was loaded only then: a second trip to
+// HBM; a step of the fused rollout takes ~350 cycles), 2200 for LDS ring -> barrier -> 16-byte stores -> barrier -> state stores.
+// step_kernel does the same step with ONE batch of loads (state, angle, leg states, supply state, action, FIFO slot -- all issued
+// before the first wait), no LDS, no barrier, and the observation row stored straight from the lane's registers (a row is
+// NOUT * sizeof(R) contiguous bytes, so consecutive lanes still cover whole cache lines).  Same device functions as the other two
+// kernels: bit-identical results (tests).
+// ------------------------------------------------------------------------------------------------
+template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R>
+__global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs<R> a) {
+    constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
+    constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
+    constexpr int NACTC = conv_nact_c<CONV>();
+    constexpr bool USE_SW = conv_has_legs<CONV>() && IL;
+    using AngT = typename Angle<R>::T;
+    using ST = Stepper<SYS, conv_base<CONV>(), LOAD, SOLVER, IL, R>;
+    const DevParams<R> &P = a.P;
+    const int64_t N = a.N;
+    const int64_t env = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool valid = env < N;
+    const int64_t e = valid ? env : N - 1;  // tail lanes recompute the last env; their stores are masked
+
+    // ---- one batch of loads
+    R y[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) y[j] = a.state[(int64_t)j * N + e];
+    AngT ang = AngT(0);
+    if (SysTraits<SYS>::HAS_ANGLE) ang = a.angle[e];
+    uint32_t sw = 0;
+    if (USE_SW) {
+        sw = a.sw[e];
+        if (conv_sw_bytes<CONV>() == 2) sw |= (uint32_t)a.sw[N + e] << 8;
+    }
+    R sup[2] = {P.u_sup, R(0)};
+    if (P.rc_supply) {
+        sup[0] = a.state[(int64_t)ND * N + e];
+        sup[1] = a.state[(int64_t)(ND + 1) * N + e];
+    }
+    R act[MAX_ACT];
+#pragma unroll
+    for (int i = 0; i < MAX_ACT; ++i) act[i] = R(0);
+    uint32_t dact = 0;
+    if (DISCRETE) dact = a.actions[e];
+    else {
+#pragma unroll
+        for (int i = 0; i < NACT; ++i) act[i] = reinterpret_cast<const R *>(a.actions)[e * NACT + i];
+    }
+    // DeadTimeProcessor (dead_time_processor.py:74-85): this step's slot of the env's FIFO (global step count mod delay)
+    R popped[NACTC];
+#pragma unroll
+    for (int i = 0; i < NACTC; ++i) popped[i] = R(0);
+    const int64_t slot0 = ((int64_t)a.ring_phase * N + e) * NACTC;
+    if (P.delay > 0) {
+#pragma unroll
+        for (int i = 0; i < NACTC; ++i) popped[i] = DISCRETE ? (R)a.ring[slot0 + i] : reinterpret_cast<const R *>(a.ring)[slot0 + i];
+    }
+    const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
+    const bool lin_ok = lin_usable<LOAD, SOLVER, IL, R>(P, y[0]);  // wave-uniform
+
+    // ---- the control step, exactly as compute_block() does it
+    uint32_t bad_action = 0;
+    if (DISCRETE) { bad_action = dact >= (uint32_t)ConvTraits<CONV>::NACTIONS; dact &= (uint32_t)(ConvTraits<CONV>::NACTIONS - 1); }
+    if (conv_dq<CONV>() && P.dq_processor) dq_action_stage<SYS, CONV, R>(P, y, ang, act);
+    if (P.delay > 0) {  // swap with the FIFO slot
+        if (DISCRETE) {
+            if (valid) a.ring[slot0] = (unsigned char)dact;
+            dact = (uint32_t)popped[0];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NACTC; ++i) {
+                if (valid) reinterpret_cast<R *>(a.ring)[slot0 + i] = act[i];
+                act[i] = popped[i];
+            }
+        }
+    }
+    if (conv_dq<CONV>() && !P.dq_processor) dq_action_stage<SYS, CONV, R>(P, y, ang, act);
+    DevParams<R> PL = P;  // per-lane view: only u_sup differs between lanes (RCVoltageSupply)
+    if (P.rc_supply) {
+        const R isup = supply_current<SYS, conv_base<CONV>(), R>(P, y, ang, sw, act);
+        sup[0] = sup[0] + (P.u_sup - sup[0] - P.sup_r * isup) * P.sup_inv_rc * sup[1];
+        sup[1] = P.tau;
+        PL.u_sup = sup[0];
+    }
+    R obs[NOUT];
+    if (linable<LOAD, SOLVER, IL, R>() && lin_ok) full_step<ST, ND, NOUT, R, linable<LOAD, SOLVER, IL, R>()>(PL, y, ang, sw, act, dact, obs);
+    else full_step<ST, ND, NOUT, R, false>(PL, y, ang, sw, act, dact, obs);
+    const bool done = constraint_done<ST, NOUT, R>(P, obs);
+    if (done && P.auto_reset) {  // `if terminated: env.reset()`; switching state survives (converters.py:45-54)
+#pragma unroll
+        for (int j = 0; j < ND; ++j) y[j] = P.init[j];
+        ang = init_ang;
+        if (P.init_kind && valid) draw_initial_state<SYS, R>(a, e, y, ang);
+        sup[0] = P.u_sup;
+        sup[1] = R(0);
+        if (valid) {
+            for (int d = 0; d < P.delay; ++d) {  // DeadTimeProcessor.reset: the deque is refilled with the reset action
+#pragma unroll
+                for (int i = 0; i < NACTC; ++i) {
+                    const int64_t gi = ((int64_t)d * N + e) * NACTC + i;
+                    if (DISCRETE) a.ring[gi] = 0;
+                    else reinterpret_cast<R *>(a.ring)[gi] = R(0);
+                }
+            }
+        }
+    }
+
+    // ---- stores
+    if (valid) {
+        if (P.obs_layout == GEMX_OBS_AOS) {
+            R *row = a.obs + env * NOUT;
+            constexpr int W = (NOUT * sizeof(R)) % 16 == 0 ? 16 / sizeof(R) : ((NOUT * sizeof(R)) % 8 == 0 ? 8 / sizeof(R) : 1);  // row alignment
+            typedef R vec_t __attribute__((ext_vector_type(W)));
+            if constexpr (W > 1) {
+#pragma unroll
+                for (int j = 0; j < NOUT; j += W) {
+                    vec_t v;
+#pragma unroll
+                    for (int q = 0; q < W; ++q) v[q] = obs[j + q];
+                    *reinterpret_cast<vec_t *>(row + j) = v;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NOUT; ++j) row[j] = obs[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) a.obs[(int64_t)j * N + env] = obs[j];
+        }
+        if (a.done != nullptr) a.done[env] = done ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) a.state[(int64_t)j * N + env] = y[j];
+        if (SysTraits<SYS>::HAS_ANGLE) a.angle[env] = ang;
+        if (USE_SW) {
+            a.sw[env] = (uint8_t)sw;
+            if (conv_sw_bytes<CONV>() == 2) a.sw[N + env] = (uint8_t)(sw >> 8);
+        }
+        if (P.rc_supply) {
+            a.state[(int64_t)ND * N + env] = sup[0];
+            a.state[(int64_t)(ND + 1) * N + env] = sup[1];
+        }
+        if (bad_action) atomicOr(a.err, 1u);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2213,6 +2377,12 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             h->ll = {1, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), D, threads, K, D, (long long)blocks, psmem};
             return GEMX_OK;
         }
+    }
+    if (K == 1 && h->cur_reward == nullptr && h->use_step_kernel != 0) {  // the closed-loop path: see step_kernel
+        hipLaunchKernelGGL((step_kernel<SYS, CONV, LOAD, SOLVER, IL, R>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
+        GEMX_HIP_TRY(hipGetLastError());
+        h->ll = {2, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), 0, BLOCK, K, 1, (long long)blocks, 0};
+        return GEMX_OK;
     }
     if (!h->attr_set) {
         GEMX_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max));

@@ -491,7 +491,17 @@ static void integrate_kink(const orc_params *p, orc_env *e, int dp5, double t_en
                 else if (w > -lim + margin) { b = -lim; have = 1; }
             }
             if (have) {
-                const double tc = (b - w) / dw;
+                /* second-order prediction of the crossing time: omega(t) ~ w + dw t + 0.5 ddw t^2, with the torque's slope taken from an
+                 * Euler look-ahead of the motor states over the rest of the step and the load's own slope in the current region */
+                double yt[ORC_MAX_ODE];
+                const int n = n_ode(p);
+                for (int i = 0; i < n; ++i) yt[i] = e->y[i] + rem * k1[i];
+                const double dT = (motor_torque(p, yt + 1) - motor_torque(p, e->y + 1)) / rem;
+                const double slope = p->load_b + (fabs(w) <= lim ? p->j_total / p->tau_decay : 0.0) + 2.0 * p->load_c * fabs(w);
+                const double ddw = (dT - slope * dw) / p->j_total;
+                const double disc = dw * dw + 2.0 * ddw * (b - w);
+                double tc = 2.0 * rem;
+                if (disc >= 0.0) tc = 2.0 * (b - w) / (dw + copysign(sqrt(disc), dw));
                 if (tc < rem * 0.999) h = fmax(tc, h_total * (1.0 / 64.0));
                 if (h > rem) h = rem;
             }

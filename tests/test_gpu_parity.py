@@ -720,6 +720,66 @@ def test_single_env_random_initialiser_reset_returns_the_drawn_state():
     env.close()
 
 
+@pytest.mark.parametrize("case", ["pmsm_fin_til", "permexdc_rc", "dfim_fin_til", "scim_dq", "pmsm_dead3", "pmsm_dqproc_dead2", "pmsm_random_init",
+                                  "extex_fin_soa", "eesm_f64"])
+def test_step_kernel_is_bit_identical_to_the_rollout_kernels(case, monkeypatch):
+    """gemx_step launches step_kernel (one batch of loads, no LDS, rows stored from registers); GEMX_STEP_KERNEL=0 sends the same call
+    through advance_kernel.  Same observations, done masks and final ODE / switching state, bit for bit, on a batch with a tail
+    workgroup, for every feature the single step supports: converter dead time, RC supply, two-byte leg state, dq action frames,
+    DeadTimeProcessor queue (+ its refill on auto-reset), random initialisers, SoA observations, fp64."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    n, K = 200, 48
+    kw, env_id, dtype = {}, "Finite-CC-PMSM-v0", "float32"
+    if case == "pmsm_fin_til":
+        kw = dict(converter=dict(interlocking_time=1e-6))
+    elif case == "permexdc_rc":
+        env_id, kw = "Cont-CC-PermExDc-v0", dict(supply=ga.RCVoltageSupply(u_nominal=60.0, supply_parameter=dict(R=0.05, C=4e-3)))
+    elif case == "dfim_fin_til":
+        env_id = "Finite-CC-DFIM-v0"
+        kw = dict(converter=ga.FiniteMultiConverter(subconverters=[ga.FiniteB6BridgeConverter(interlocking_time=1e-6), ga.FiniteB6BridgeConverter(interlocking_time=1e-6)]))
+    elif case == "scim_dq":
+        env_id, kw = "Cont-SC-SCIM-v0", dict(control_space="dq")
+    elif case == "pmsm_dead3":
+        kw = dict(physical_system_wrappers=(ga.DeadTimeProcessor(steps=3),), tau=1e-4)
+    elif case == "pmsm_dqproc_dead2":
+        env_id, kw = "Cont-SC-PMSM-v0", dict(physical_system_wrappers=(ga.DeadTimeProcessor(steps=2), ga.DqToAbcActionProcessor.make("PMSM")))
+    elif case == "extex_fin_soa":
+        env_id, kw = "Finite-CC-ExtExDc-v0", dict(obs_layout="soa")
+    elif case == "eesm_f64":
+        env_id, dtype = "Cont-CC-EESM-v0", "float64"
+
+    def run(step_kernel):
+        monkeypatch.setenv("GEMX_STEP_KERNEL", step_kernel)
+        if case == "pmsm_random_init":
+            env = _init_env("pmsm_sc_uniform", n, seed=5, ode_solver=ga.RK4Solver())[0]
+        else:
+            env = ga.make(env_id, n_envs=n, ode_solver=ga.RK4Solver(), dtype=dtype, **kw)
+        ps = env.physical_system
+        g = torch.Generator(device="cuda").manual_seed(11)
+        if ps._discrete:
+            nflat = int(np.prod(ps.action_space.nvec)) if hasattr(ps.action_space, "nvec") else int(ps.action_space.n)
+            acts = torch.randint(0, nflat, (K, n), device="cuda", generator=g, dtype=torch.uint8)
+        else:
+            acts = (torch.rand((K, n, ps._n_act), device="cuda", generator=g, dtype=torch.float64) * 2 - 1).to(ps._tdtype)
+        out = []
+        for k in range(K):
+            o = ps.simulate(acts[k])
+            out.append((o.clone(), ps.done.clone()))
+        assert ("step_kernel" in ps.last_launch()) == (step_kernel == "1")
+        res = (torch.stack([o for o, _ in out]), torch.stack([d for _, d in out]), ps.get_state(), ps.get_switch_state())
+        env.close()
+        return res
+
+    a, b = run("1"), run("0")
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    if case in ("permexdc_rc", "pmsm_dead3", "pmsm_random_init"):
+        assert a[1].any()  # these terminate and auto-reset within the 48 steps: the reset path of both kernels is compared too
+
+
 def test_random_initialisers_streams_and_auto_reset():
     """Counter-based Philox streams: same seed -> same states, other seed / env / reset -> other states; the in-kernel auto-reset
     draws a fresh state (inside the bounds) for exactly the envs that terminated; step-by-step == fused == chunked, bit for bit."""

@@ -41,3 +41,15 @@ for base in (0, 16):
         print(f"   out wave {w}: process={outs[2*w]/nb:.0f} barrier={outs[2*w+1]/nb:.0f}")
     print(f"   out wave 0: of which reward + flush={buf[base+14]/nb:.0f}")
     print(f"   loader: stage+wait={buf[base+12]/nb:.0f} barrier={buf[base+13]/nb:.0f}")
+
+if os.environ.get("PROBE_STEP"):  # K = 1 (gemx_step -> advance_kernel): cycles per phase of workgroup 0 / the last workgroup, wall span
+    for _ in range(20):
+        ps.simulate(act[0])
+    torch.cuda.synchronize()
+    buf2 = (C.c_ulonglong * 48)()
+    L.gemx_debug_read(ps._handle, buf2, 48)
+    print(L.gemx_last_launch(ps._handle))
+    for name, base in (("first wg", 32), ("last wg ", 40)):
+        ld, comp, flush, drain, w0, w1 = buf2[base:base + 6]
+        print(f"   {name}: load+sync={ld} compute+sync={comp} flush+state stores issued={flush} store drain={drain} cycles; in-kernel wall {10*(w1-w0)} ns")
+    print(f"   first wg entry -> last wg exit: {10 * (buf2[45] - buf2[36])} ns; last wg entered {10 * (buf2[44] - buf2[36])} ns after the first")
