@@ -6,7 +6,7 @@ import os
 from . import build as _build
 
 MAX_ODE, MAX_OUT, MODEL_ROWS, MODEL_COLS = 8, 24, 5, 11
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 SYS_DC_PERMEX, SYS_SYNC, SYS_SCIM, SYS_DC_SERIES, SYS_DC_SHUNT, SYS_DC_EXTEX, SYS_EESM, SYS_DFIM = 0, 1, 2, 3, 4, 5, 6, 7
 CONV_CONT_4QC, CONV_FINITE_B6, CONV_CONT_B6, CONV_FINITE_4QC = 0, 1, 2, 3
@@ -17,6 +17,7 @@ MAX_DELAY = 8
 CONV_CONT_2X4QC, CONV_FINITE_2X4QC, CONV_CONT_B6_4QC, CONV_FINITE_B6_4QC, CONV_CONT_2XB6, CONV_FINITE_2XB6 = 4, 5, 6, 7, 8, 9
 LOAD_CONST_SPEED, LOAD_POLY_STATIC = 0, 1
 SOLVER_EULER, SOLVER_RK4, SOLVER_DP5 = 0, 1, 2
+SOLVER_SPLIT_KINKS = 1
 F32, F64 = 0, 1
 OBS_AOS, OBS_SOA = 0, 1
 
@@ -27,7 +28,7 @@ class GemxConfig(C.Structure):
     _fields_ = [
         ("struct_size", C.c_int32), ("abi_version", C.c_int32),
         ("system_kind", C.c_int32), ("converter_kind", C.c_int32), ("load_kind", C.c_int32),
-        ("solver_kind", C.c_int32), ("solver_nsteps", C.c_int32),
+        ("solver_kind", C.c_int32), ("solver_nsteps", C.c_int32), ("solver_flags", C.c_int32),
         ("dtype", C.c_int32), ("obs_layout", C.c_int32), ("auto_reset", C.c_int32),
         ("limit_mask", C.c_uint32), ("squared_mask", C.c_uint32),
         ("action_frame", C.c_int32), ("action_delay", C.c_int32),

@@ -182,18 +182,22 @@ class EulerSolver:
 
 class RK4Solver:
     """Classical 4th-order Runge-Kutta with `nsteps` sub-steps per integration segment.  The reference has no
-    RK4; its like-for-like CPU counterpart is the default scipy dopri5 path."""
+    RK4; its like-for-like CPU counterpart is the default scipy dopri5 path.
+    split_kinks: cut every step where omega is predicted to reach a kink of a PolynomialStaticLoad's torque (|omega| = a tau_decay / J),
+    as the reference's adaptive default solver does by rejecting such steps (include/gemx.h: GEMX_SOLVER_SPLIT_KINKS)."""
 
-    def __init__(self, nsteps=1):
+    def __init__(self, nsteps=1, split_kinks=False):
         self._nsteps = int(nsteps)
+        self._split_kinks = bool(split_kinks)
 
 
 class DormandPrince5Solver:
     """One fixed Dormand-Prince 5th-order step per sub-step: what the reference's default
-    scipy.integrate.ode('dopri5') (solvers.py:139-184) computes whenever its trial step is accepted."""
+    scipy.integrate.ode('dopri5') (solvers.py:139-184) computes whenever its trial step is accepted.  split_kinks: see RK4Solver."""
 
-    def __init__(self, nsteps=1):
+    def __init__(self, nsteps=1, split_kinks=False):
         self._nsteps = int(nsteps)
+        self._split_kinks = bool(split_kinks)
 
 
 # ------------------------------------------------------------------------------------------------- motors

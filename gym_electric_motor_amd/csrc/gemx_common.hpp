@@ -89,6 +89,7 @@ template <class R> struct DevParams {
     int32_t dq_processor;   // dq action frames: 0 control_space='dq' (step-start angle), 1 DqToAbcActionProcessor (advanced angle)
     int32_t delay;          // DeadTimeProcessor steps
     R dq_adv;               // (0.5 + delay) * tau * pole: angle advance per rad/s of omega
+    int32_t kink_split;     // GEMX_SOLVER_SPLIT_KINKS: steps are cut at the PolynomialStaticLoad's kinks (integrate<>)
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -165,10 +165,10 @@ template <class R> struct Elec<GEMX_SYS_DFIM, R> {  // the SCIM matrix with live
 // (used for the angle when omega = z[0] is dynamic).  SOLVER: Euler (solvers.py:124-136), classical RK4,
 // Dormand-Prince 5th-order solution without error control.
 // ------------------------------------------------------------------------------------------------
+// rk_step_k1: the same step with the first stage k1 = F(z) already evaluated by the caller (who may need it to choose h).
 template <int SOLVER, int NZ, class R, class F>
-__device__ __forceinline__ R rk_step(R (&z)[NZ], R h, F &&rhs) {
-    R k1[NZ], zt[NZ];
-    rhs(z, k1);
+__device__ __forceinline__ R rk_step_k1(R (&z)[NZ], const R (&k1)[NZ], R h, F &&rhs) {
+    R zt[NZ];
     if (SOLVER == GEMX_SOLVER_EULER) {
         const R q = z[0];
 #pragma unroll
@@ -226,6 +226,12 @@ __device__ __forceinline__ R rk_step(R (&z)[NZ], R h, F &&rhs) {
                                R(2187.0 / 6784.0) * k5[i] + R(11.0 / 84.0) * k6[i]);
         return q;
     }
+}
+template <int SOLVER, int NZ, class R, class F>
+__device__ __forceinline__ R rk_step(R (&z)[NZ], R h, F &&rhs) {
+    R k1[NZ];
+    rhs(z, k1);
+    return rk_step_k1<SOLVER, NZ, R>(z, k1, h, rhs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -296,13 +302,62 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
 #pragma unroll
             for (int i = 0; i < NM; ++i) dz[1 + i] = dx[i];
         };
-        R wsum = R(0);
-        if (NS1 || ns == 1) {
-            wsum = rk_step<SOLVER, NM + 1, R>(y, hs, rhs);
-        } else {
-            for (int s = 0; s < ns; ++s) wsum += rk_step<SOLVER, NM + 1, R>(y, hs, rhs);
+        if (!P.kink_split) {
+            R wsum = R(0);
+            if (NS1 || ns == 1) {
+                wsum = rk_step<SOLVER, NM + 1, R>(y, hs, rhs);
+            } else {
+                for (int s = 0; s < ns; ++s) wsum += rk_step<SOLVER, NM + 1, R>(y, hs, rhs);
+            }
+            return P.pole * hs * wsum;
         }
-        return P.pole * hs * wsum;
+        // GEMX_SOLVER_SPLIT_KINKS (PolynomialStaticLoad only).  The load torque's constant term is the saturation
+        // clamp(J / tau_decay * omega, -a, a) (polynomial_static_load.py:87-92): the right-hand side has kinks at |omega| = omega_lim, where
+        // a fixed step loses its order -- the reference's adaptive default solver rejects and splits exactly those steps.  Each (sub-)step
+        // is cut at the instants omega is PREDICTED to reach the next kink in its direction of travel (second order: d omega/dt from the
+        // first stage, the torque's slope from an Euler look-ahead of the motor states, the load's own slope in the current region);
+        // each piece is one step of the scheme, at most three pieces.  Lanes that are done ride along with h = 0 (z + 0 k = z).
+        // Restated in fp64 by oracle/gemx_oracle.c:integrate_kink.
+        R deps = R(0);
+        const R lim = P.omega_lim, margin = R(1e-6) * lim;
+        for (int s = 0; s < ns; ++s) {
+            R rem = hs;
+#pragma nounroll
+            for (int piece = 0; piece < 3; ++piece) {
+                R k1[NM + 1];
+                rhs(y, k1);
+                R h = rem;
+                if (piece < 2) {
+                    const R w = y[0], dw = k1[0];
+                    R b = R(0);
+                    bool have = false;
+                    if (dw > R(0)) {
+                        if (w < -lim - margin) { b = -lim; have = true; }
+                        else if (w < lim - margin) { b = lim; have = true; }
+                    } else if (dw < R(0)) {
+                        if (w > lim + margin) { b = lim; have = true; }
+                        else if (w > -lim + margin) { b = -lim; have = true; }
+                    }
+                    if (have & (rem > R(0))) {
+                        R x0[NM], x1[NM];
+#pragma unroll
+                        for (int i = 0; i < NM; ++i) { x0[i] = y[1 + i]; x1[i] = y[1 + i] + rem * k1[1 + i]; }
+                        const R dT = (E::torque(P, x1) - E::torque(P, x0)) / rem;
+                        const R slope = P.lb + (fabs(w) <= lim ? P.lin_factor : R(0)) + R(2) * P.lc * fabs(w);
+                        const R ddw = (dT - slope * dw) * P.inv_j;
+                        const R disc = dw * dw + R(2) * ddw * (b - w);
+                        R tc = R(2) * rem;
+                        if (disc >= R(0)) tc = R(2) * (b - w) / (dw + copysign(sqrt(disc), dw));
+                        if (tc < rem * R(0.999)) h = fmax(tc, hs * R(1.0 / 64.0));
+                        if (h > rem) h = rem;
+                    }
+                }
+                deps += (P.pole * h) * rk_step_k1<SOLVER, NM + 1, R>(y, k1, h, rhs);
+                rem -= h;
+                if (!__any(rem > R(0))) break;  // wave-uniform
+            }
+        }
+        return deps;
     }
 }
 

@@ -351,6 +351,7 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             raise ValueError(f"converter {type(self._converter).__name__} does not fit {type(self).__name__} with a "
                              f"{type(self._electrical_motor).__name__}: it is not on the accelerated path")
         cfg.solver_kind, cfg.solver_nsteps = self._solver_kind()
+        cfg.solver_flags = _lib.SOLVER_SPLIT_KINKS if getattr(self._ode_solver, "_split_kinks", False) else 0
         cfg.dtype = _lib.F64 if self._dtype_name == "float64" else _lib.F32
         cfg.obs_layout = {"aos": _lib.OBS_AOS, "soa": _lib.OBS_SOA}[self._obs_layout]
         cfg.auto_reset = int(self._auto_reset)

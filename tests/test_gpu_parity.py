@@ -33,7 +33,8 @@ def _make_from_meta(meta, n_envs, solver=None, dtype="float32", episodic=None, o
     solver = solver or meta["solver"]
     sol = {"euler": ga.EulerSolver(), "euler4": ga.EulerSolver(nsteps=4), "rk4": ga.RK4Solver(), "rk4x4": ga.RK4Solver(nsteps=4),
            "rk4x8": ga.RK4Solver(nsteps=8), "dp5x8": ga.DormandPrince5Solver(nsteps=8),
-           "dopri5": ga.DormandPrince5Solver(), "dp5": ga.DormandPrince5Solver()}[solver]
+           "dopri5": ga.DormandPrince5Solver(), "dp5": ga.DormandPrince5Solver(),
+           "rk4k": ga.RK4Solver(split_kinks=True), "dp5k": ga.DormandPrince5Solver(split_kinks=True)}[solver]
     kw = dict(n_envs=n_envs, ode_solver=sol, tau=meta["tau"], dtype=dtype, obs_layout=obs_layout, auto_reset=auto_reset)
     if "MultiConverter" in meta["converter"]:
         # Cont/FiniteMultiConverter: the dead time lives in the sub-converters (a dict override would only reach the holder)
@@ -205,6 +206,58 @@ def test_fp32_fixed_step_matches_reference_default_dopri5(name, solver):
     # north-star tolerance for EVERY system (round 1 held SCIM + PolynomialStaticLoad to 2e-4); episodic runs episode by episode
     rel, _, col, dmsg = compare_trajectory(meta, d, obs, done)
     assert rel < 1e-4, (rel, col, dmsg)
+
+
+SCIM_POLY_DOPRI = [c for c in DOPRI if c.startswith("scim_") and "constspeed" not in c]
+
+
+@pytest.mark.parametrize("name", SCIM_POLY_DOPRI + ["pmsm_sc_free_held_dopri5", "permexdc_sc_free_held_dopri5", "refdata_cont_sc_permexdc_dopri5"])
+@pytest.mark.parametrize("solver", ["rk4k", "dp5k"])
+def test_split_kinks_tracks_the_reference_adaptive_solver(name, solver):
+    """GEMX_SOLVER_SPLIT_KINKS (RK4Solver / DormandPrince5Solver(split_kinks=True)): steps cut at the PolynomialStaticLoad's kinks, the
+    device's stand-in for scipy dopri5's step-size control.  fp32 against the reference's default-solver trajectories: 3e-5 (plain
+    fixed steps: up to 7.2e-5 on the same fixtures, profiles/r02_parity.md); fp64 against the oracle's restatement of the same
+    algorithm (oracle/gemx_oracle.c:integrate_kink): 1e-9."""
+    from oracle import oracle as orc
+
+    d, meta, obs, done = _run_golden(name, "float32", solver=solver)
+    rel, _, col, dmsg = compare_trajectory(meta, d, obs, done)
+    assert rel < 3e-5, (rel, col, dmsg)
+    if name.startswith("scim_free") or name.startswith("pmsm_sc"):
+        d, meta, obs64, _ = _run_golden(name, "float64", solver=solver)
+        e = orc.OracleEnv(orc.params_from_meta(meta, solver={"rk4k": "rk4_kink", "dp5k": "dp5_kink"}[solver], episodic=False))
+        e.reset()
+        ref, _ = e.rollout(d["actions"])
+        _, ab = _rel_err(obs64, ref, meta["state_names"])
+        assert ab < 1e-9, ab
+
+
+@pytest.mark.parametrize("name", ["scim_epi_uniform_euler", "synrm_cont_sc_epi_held_euler"])
+def test_split_kinks_is_bit_identical_across_kernels(name, monkeypatch):
+    """The piece loop (wave-level: lanes that are done ride along with h = 0) gives the same bits in the single-wave kernel, every
+    pipelined shape and step-by-step through step_kernel."""
+    import torch
+
+    outs = []
+    for env in ({"GEMX_PIPE": "0"}, {"GEMX_PIPE": "1", "GEMX_PIPE_SHAPE": "0"}, {"GEMX_PIPE": "1", "GEMX_PIPE_SHAPE": "1"},
+                {"GEMX_PIPE": "1", "GEMX_PIPE_SHAPE": "2"}):
+        for k in ("GEMX_PIPE", "GEMX_PIPE_SHAPE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        _, meta, obs, done = _run_golden(name, "float32", solver="rk4k", n_envs=128)
+        outs.append((obs, done))
+    for o, dn in outs[1:]:
+        assert np.array_equal(o, outs[0][0]) and np.array_equal(dn, outs[0][1])
+    d, meta = _load(name)
+    env = _make_from_meta(meta, 128, solver="rk4k", auto_reset=True)
+    ps = env.physical_system
+    acts = torch.as_tensor(np.repeat(d["actions"][:60].reshape(60, 1, -1), 128, axis=1)).cuda()
+    for k in range(60):
+        o = ps.simulate(acts[k])
+        assert np.array_equal(o[0].double().cpu().numpy(), outs[0][0][k])
+    assert "step_kernel" in ps.last_launch()
+    env.close()
 
 
 def test_ref_data_npz_on_gpu():

@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--all", action="store_true", help="every fixture, not only the three BASELINE envs")
-    ap.add_argument("--solvers", default="rk4,dp5")
+    ap.add_argument("--solvers", default="rk4,dp5,rk4k,dp5k", help="device solvers run against the dopri5 / solve_ivp fixtures (k: split_kinks=True)")
     args = ap.parse_args()
     import test_gpu_parity as T
 
@@ -52,7 +52,7 @@ def main():
             d, meta, obs, done = T._run_golden(name, "float32", solver=solver)
             rel, ab, col, dmsg = T.compare_trajectory(meta, d, obs, done)
             print(f"| {name} | {meta['env_id']} | {len(d['terminated'])} | {meta['solver']} | {solver} | {rel:.2e} | {col} | {ab:.2e} | {dmsg} |", flush=True)
-            key = (meta["env_id"], kinds[meta["solver"]])
+            key = (meta["env_id"], kinds[meta["solver"]] + (" -- device solver with split_kinks" if solver.endswith("k") else ""))
             if rel > worst.get(key, (0, ""))[0]:
                 worst[key] = (rel, f"{name} / {solver} / {col}")
         if meta["solver"] == "ivp":  # how far the reference's solve_ivp path is from the reference's OWN default solver (CPU, fp64 oracle)
