@@ -30,7 +30,8 @@ Extra objects in the JSON line (rank 0):
                       workload, plus the REFERENCE's own Python path as recorded by tools/cpu_reference_bench.py (fields, not prose).
   headline_no_linmap  the same launches with GEMX_LINMAP=0 (RK4 evaluated stage by stage instead of through the one-step affine map).
   single_step / single_step_graph   one launch per control step (closed-loop RL usage), eager and replayed from a HIP graph.
-  configs             BASELINE configs 2 and 4 (PermExDc 4096 envs Euler; SCIM 65536 envs RK4) through the same measurement.
+  configs             BASELINE configs 2 and 4 (PermExDc 4096 envs Euler; SCIM 65536 envs RK4; the latter also with split_kinks) through
+                      the same measurement.
   at_scale            the headline kernel with the chip full (1M envs).
 """
 import argparse
@@ -68,8 +69,8 @@ def bytes_per_env_step_single(w):
     return bytes_per_env_step_fused(w) + 2 * 4 * w["s_ode"]
 
 
-def make_env(ga, w, n_envs, device):
-    sol = ga.EulerSolver() if w["solver"] == "euler" else ga.RK4Solver()
+def make_env(ga, w, n_envs, device, split_kinks=False):
+    sol = ga.EulerSolver() if w["solver"] == "euler" else ga.RK4Solver(split_kinks=split_kinks)
     return ga.make(w["env_id"], n_envs=n_envs, device=device, ode_solver=sol, tau=w["tau"])
 
 
@@ -371,6 +372,13 @@ def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out):
         envc.close()
         out["configs"][key] = {"workload": wc["desc"], "envs": wc["envs"], "steps_per_launch": spl, "value": wc["envs"] * spl * 10 / tc.wall,
                                "unit": "env-steps/s", "roofline": rc}
+        if key == "scim":  # the same config with RK4Solver(split_kinks=True): steps cut at the PolynomialStaticLoad's kinks (accuracy option)
+            envk = make_env(ga, wc, wc["envs"], dev_index, split_kinks=True)
+            tk = measure(torch, dist, envk, wc["envs"], 10, 3, spl, device, 1, seed=5)
+            rk = roofline_of(wc, wc["envs"], spl, tk.launch_ms, envk.physical_system.last_launch(), key + "/split_kinks")
+            envk.close()
+            out["configs"]["scim_split_kinks"] = {"workload": wc["desc"] + ", RK4Solver(split_kinks=True)", "envs": wc["envs"], "steps_per_launch": spl,
+                                                  "value": wc["envs"] * spl * 10 / tk.wall, "unit": "env-steps/s", "roofline": rk}
     # the headline kernel with the chip full
     n_big, c_big = 2 ** 20, 100
     envb = make_env(ga, w, n_big, dev_index)

@@ -581,7 +581,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     // (the table entry's quad), done]
     static constexpr int row_slot(int j) {
         constexpr int slot[12] = {2, 0, 1, 3, 4, 5, 8, 9, 10, 6, 7, 11};
-        return slot[j];
+        return j < 12 ? slot[j] : j;  // (entry 12: the per-lane supply voltage of the FULL variant)
     }
     static __device__ __forceinline__ void action_entry(const DevParams<R> &P, uint32_t dact, R (&e)[8]) {
         const R zero[MAX_ACT] = {R(0), R(0), R(0), R(0), R(0), R(0)};
@@ -982,6 +982,19 @@ __device__ __forceinline__ void draw_initial_state(const KArgs<R> &a, int64_t en
 #pragma unroll
     for (int j = 0; j < ND; ++j) y[j] = (R)init_state_from_uniform(a.rinit, j, u[j]);
     if (SysTraits<SYS>::HAS_ANGLE) ang = Angle<R>::from_rad(init_state_from_uniform(a.rinit, ND, u[ND]));
+}
+
+// the same draw with the env's reset counter held in a register (pipelined kernel: no global memory traffic besides the description)
+template <int SYS, class R>
+__device__ __forceinline__ void draw_initial_state_cnt(const InitDev *rinit, int64_t env, uint32_t &count, R (&y)[SysTraits<SYS>::ND],
+                                                       typename Angle<R>::T &ang) {
+    constexpr int ND = SysTraits<SYS>::ND;
+    count += 1u;
+    double u[GEMX_MAX_ODE];
+    init_uniforms(rinit, env, count, u);
+#pragma unroll
+    for (int j = 0; j < ND; ++j) y[j] = (R)init_state_from_uniform(rinit, j, u[j]);
+    if (SysTraits<SYS>::HAS_ANGLE) ang = Angle<R>::from_rad(init_state_from_uniform(rinit, ND, u[ND]));
 }
 
 // step() for the single-wave kernel
@@ -1786,9 +1799,13 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs<R> a) {
 // b-1 while the integrator runs block b and the loader fetches block b+1.  Full blocks are unrolled into branch-free basic blocks of
 // four steps.  Shapes <D, OW>: <12, 3>, <4, 2>, <2, 2> (launch_advance_t picks by N and LDS footprint).
 // Preconditions (checked by the launcher): full 64-env workgroups, 16-byte aligned tensors (coop), obs_every, K >= 2,
-// constraint kind none/default, one solver sub-step, ideal supply, constant initialiser.
+// constraint kind none/default, one solver sub-step; RC supply / random initialisers: the FULL instantiation only.
 // ------------------------------------------------------------------------------------------------
-template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R, int D, int OW>
+// FULL = true: the variant that also serves an RCVoltageSupply (per-lane supply voltage: two more registers of state in the integrator
+// and one more hand-off value, from which the output waves take the u_sup column) and random initialisers (the rare auto-reset path
+// draws the new state in the integrator wave, reset counter in a register).  One extra instantiation (shape <4, 2>) instead of
+// burdening the common ones with the registers of that code (the fp64 Philox / inverse-CDF draw alone costs ~50 VGPRs).
+template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R, int D, int OW, bool FULL = false>
 __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advance_pipe_kernel(const KArgs<R> a) {
     constexpr int LW = pipe_loader_waves(D);  // 1: a loader wave stages actions / references instead of the integrator
     constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
@@ -1797,7 +1814,8 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
     using AngT = typename Angle<R>::T;
     using ST = Stepper<SYS, conv_base<CONV>(), LOAD, SOLVER, IL, R>;
     constexpr int NH = ST::NH;
-    constexpr int NHT = ND + (HAS_ANGLE ? 1 : 0) + NH + 1;  // hand-off row: y, angle bits, ho, done
+    constexpr int NDONE = ND + (HAS_ANGLE ? 1 : 0) + NH;    // hand-off row: y, angle bits, ho, done[, supply voltage]
+    constexpr int NHT = NDONE + 1 + (FULL ? 1 : 0);
 
     const DevParams<R> &P = a.P;
     // readfirstlane: the wave index is wave-uniform, but the compiler cannot know that of a value derived from threadIdx -- without
@@ -1889,6 +1907,15 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             if (conv_sw_bytes<CONV>() == 2) sw |= (uint32_t)a.sw[N + env] << 8;
         }
         const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
+        R sup[2] = {P.u_sup, R(0)};  // RCVoltageSupply: capacitor voltage, time since the supply's last update (FULL)
+        uint32_t rcount = 0;         // random initialisers: resets of this env so far (FULL)
+        if constexpr (FULL) {
+            if (P.rc_supply) {
+                sup[0] = a.state[(int64_t)ND * N + env];
+                sup[1] = a.state[(int64_t)(ND + 1) * N + env];
+            }
+            if (P.init_kind) rcount = a.rcnt[env];
+        }
         int slot = a.ring_phase;
         for (int d = 0; d < P.delay; ++d) {
 #pragma unroll
@@ -1961,11 +1988,28 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             if (conv_dq<CONV>() && !P.dq_processor) dq_action_stage<SYS, CONV, R>(P, y, ang, act);
             R ho[NH];
             // launcher guarantees solver_nsteps == 1; LINABLE instantiations take the one-step map whenever it is valid for this wave
-            if constexpr (TAB) {
-                ST::template advance<true, LINABLE, true>(P, y, ang, sw, act, dact, ho, tab);
+            auto run_advance = [&](const DevParams<R> &Q) {
+                if constexpr (TAB) {
+                    ST::template advance<true, LINABLE, true>(Q, y, ang, sw, act, dact, ho, tab);
+                } else {
+                    if (LINABLE && (!FIFO || lin_ok)) ST::template advance<true, LINABLE>(Q, y, ang, sw, act, dact, ho);
+                    else ST::template advance<true, false>(Q, y, ang, sw, act, dact, ho);
+                }
+            };
+            R usup_lane = P.u_sup;
+            if constexpr (FULL) {
+                // RCVoltageSupply, exactly as in compute_block(): one explicit Euler step of the supply's own state before the converter
+                DevParams<R> PL = P;  // per-lane view of the parameters: only u_sup differs between lanes
+                if (P.rc_supply) {
+                    const R isup = supply_current<SYS, conv_base<CONV>(), R>(P, y, ang, sw, act);
+                    sup[0] = sup[0] + (P.u_sup - sup[0] - P.sup_r * isup) * P.sup_inv_rc * sup[1];
+                    sup[1] = P.tau;
+                    PL.u_sup = sup[0];
+                }
+                usup_lane = PL.u_sup;
+                run_advance(PL);
             } else {
-                if (LINABLE && (!FIFO || lin_ok)) ST::template advance<true, LINABLE>(P, y, ang, sw, act, dact, ho);
-                else ST::template advance<true, false>(P, y, ang, sw, act, dact, ho);
+                run_advance(P);
             }
             const bool done = ST::state_done(P, y, ho) & check_default;
 #pragma unroll
@@ -1977,11 +2021,17 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             }
 #pragma unroll
             for (int j = 0; j < NH; ++j) row[ST::row_slot(ND + (HAS_ANGLE ? 1 : 0) + j)] = ho[j];
-            row[ST::row_slot(NHT - 1)] = done ? R(1) : R(0);
+            row[ST::row_slot(NDONE)] = done ? R(1) : R(0);
+            if constexpr (FULL) row[ST::row_slot(NDONE + 1)] = usup_lane;
             const bool rs = done & auto_reset;  // `if terminated: env.reset()`; switching state survives
 #pragma unroll
             for (int j = 0; j < ND; ++j) y[j] = rs ? P.init[j] : y[j];
             ang = rs ? init_ang : ang;
+            if constexpr (FULL) {
+                if (rs && P.init_kind) draw_initial_state_cnt<SYS, R>(a.rinit, env, rcount, y, ang);  // (rare: exec-masked, skipped wave-wide)
+                sup[0] = rs ? P.u_sup : sup[0];  // RCVoltageSupply.reset: the capacitor is loaded again, the supply's clock restarts
+                sup[1] = rs ? R(0) : sup[1];
+            }
             if (FIFO && P.delay > 0) {  // DeadTimeProcessor.reset: the deque is refilled with the (zero) reset action
                 if (rs) {
                     for (int d = 0; d < P.delay; ++d) {
@@ -2092,6 +2142,13 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             a.sw[env] = (uint8_t)sw;
             if (conv_sw_bytes<CONV>() == 2) a.sw[N + env] = (uint8_t)(sw >> 8);
         }
+        if constexpr (FULL) {
+            if (P.rc_supply) {
+                a.state[(int64_t)ND * N + env] = sup[0];
+                a.state[(int64_t)(ND + 1) * N + env] = sup[1];
+            }
+            if (P.init_kind) a.rcnt[env] = rcount;
+        }
         for (int d = 0; d < P.delay; ++d) {
 #pragma unroll
             for (int i = 0; i < NACTC; ++i) {
@@ -2158,8 +2215,9 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             }
 #pragma unroll
             for (int j = 0; j < NH; ++j) ho[j] = row[ST::row_slot(ND + (HAS_ANGLE ? 1 : 0) + j)];
-            const R dn = row[ST::row_slot(NHT - 1)];
+            const R dn = row[ST::row_slot(NDONE)];
             ST::observe(P, y, ang, ho, obs);
+            if constexpr (FULL) obs[NOUT - 1] = row[ST::row_slot(NDONE + 1)] * P.inv_lim[NOUT - 1];  // u_sup column: this lane's supply voltage
             if (aos) {
 #pragma unroll
                 for (int j = 0; j < NOUT; ++j) ring[(rs * BLOCK + tid) * NOUT + j] = obs[j];
@@ -2372,14 +2430,14 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     const int64_t blocks = (h->n + BLOCK - 1) / BLOCK;
     // pipelined kernel (integrator / output / loader waves) whenever the launch qualifies
     const bool pipe_ok = h->use_pipe != 0 && K >= 2 && obs_every && a.coop && a.obs_vec && (h->n % BLOCK) == 0 &&
-                         params_of<R>(h).constr_kind <= 1 && h->cfg.solver_nsteps == 1 && h->cfg.supply_kind == GEMX_SUPPLY_IDEAL &&
-                         h->cfg.init_kind == GEMX_INIT_CONST;  // (the fp64 Philox / inverse-CDF code of random initialisers would cost the
-                                                               // pipelined kernels ~50 VGPRs, i.e. half their residency at large N)
+                         params_of<R>(h).constr_kind <= 1 && h->cfg.solver_nsteps == 1;
+    // RC supply / random initialisers: the FULL instantiation (shape <4, 2> only; see advance_pipe_kernel)
+    const bool need_full = h->cfg.supply_kind != GEMX_SUPPLY_IDEAL || h->cfg.init_kind != GEMX_INIT_CONST;
     // (fp32 only: the fp64 build is a diagnostic of the same device functions and takes the single-wave kernel, which keeps its
     // translation units three times smaller)
     if constexpr (sizeof(R) == 4) if (pipe_ok) {
         using ST = Stepper<SYS, conv_base<CONV>(), LOAD, SOLVER, IL, R>;
-        constexpr int NHT = SysTraits<SYS>::ND + (SysTraits<SYS>::HAS_ANGLE ? 1 : 0) + ST::NH + 1;
+        const int NHT = SysTraits<SYS>::ND + (SysTraits<SYS>::HAS_ANGLE ? 1 : 0) + ST::NH + 1 + (need_full ? 1 : 0);
         // LDS footprint of one workgroup at hand-off depth D (steps per barrier): ring + done ring + double-buffered hand-off rows + ...
         auto smem_of = [&](int D) {
             size_t b = (size_t)D * BLOCK * h->nout * sizeof(R) + (size_t)D * BLOCK + 2 * (size_t)D * BLOCK * NHT * sizeof(R);
@@ -2414,6 +2472,13 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             const int fd[4] = {PIPE_D, PIPE_D2, PIPE_D3, PIPE_D}, fo[4] = {PIPE_OUT_WAVES, PIPE_OUT_WAVES2, PIPE_OUT_WAVES3, PIPE_OUT_WAVES_RW};
             if (smem_of(fd[h->pipe_shape]) <= h->lds_max) { shape = h->pipe_shape; D = fd[shape]; OW = fo[shape]; }
         }
+        if (need_full) {  // one instantiation serves these handles
+            // ~180 VGPRs = two resident workgroups per CU: ahead of the single-wave kernel while the batch is a few resident rounds
+            // (PMSM + RC supply, same box: 33.9 vs 14.0 G env-steps/s at 16384 envs, 59.6 vs 26.2 at 32768, 61.6 vs 47.2 at 65536), behind
+            // it beyond (63.8 vs 70.1 at 131072; random initialisers: 28 vs 16 / 28 vs 30 / 28 vs 43) -- tools/ab_full_variant.py
+            if (smem_of(PIPE_D2) <= h->lds_max && blocks <= 4 * (int64_t)h->n_cu) { D = PIPE_D2; OW = PIPE_OUT_WAVES2; shape = 4; }
+            else D = 0;
+        }
         if (D != 0) {
             a.S = D;
             a.D = D;
@@ -2421,7 +2486,8 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             auto pkern = shape == 0   ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES>
                          : shape == 1 ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2>
                          : shape == 2 ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D3, PIPE_OUT_WAVES3>
-                                      : advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES_RW>;
+                         : shape == 3 ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES_RW>
+                                      : advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2, true>;
             if (!(h->pipe_attr_set & (1u << shape))) {
                 GEMX_HIP_TRY(hipFuncSetAttribute((const void *)pkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max));
                 h->pipe_attr_set |= 1u << shape;

@@ -833,6 +833,59 @@ def test_step_kernel_is_bit_identical_to_the_rollout_kernels(case, monkeypatch):
         assert a[1].any()  # these terminate and auto-reset within the 48 steps: the reset path of both kernels is compared too
 
 
+@pytest.mark.parametrize("name", ["rc_pmsm_fin_til_epi_uniform_tau1e-4_euler", "rc_permexdc_cont_free_held_euler", "rc_eesm_cont_epi_held_euler",
+                                  "rc_dfim_fin_free_uniform_euler", "rc_scim_cont_sc_free_held_dopri5", "init:pmsm_sc_uniform", "init:extex_cc_uniform_interval"])
+def test_full_pipelined_variant_matches_single_wave_kernel(name, monkeypatch):
+    """RCVoltageSupply and random initialisers ride the pipelined kernel too (its FULL instantiation: per-lane supply voltage handed
+    to the output waves, draws in the integrator's reset path): bit-identical to the single-wave kernel (GEMX_PIPE=0) on 128 envs --
+    observations incl. the u_sup column, done masks, final ODE + supply state, and the random streams after in-kernel auto-resets."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    n = 128
+
+    def run(pipe):
+        monkeypatch.setenv("GEMX_PIPE", pipe)
+        if name.startswith("init:"):
+            env = _init_env(name[5:], n, seed=9, ode_solver=ga.RK4Solver())[0]
+            ps = env.physical_system
+            g = torch.Generator(device="cuda").manual_seed(3)
+            K = 300
+            if ps._discrete:
+                acts = torch.randint(0, 8, (K, n), device="cuda", generator=g, dtype=torch.uint8)
+            else:
+                acts = torch.rand((K, n, ps._n_act), device="cuda", generator=g) * 2 - 1
+        else:
+            d, meta = _load(name)
+            env = _make_from_meta(meta, n, auto_reset=True)
+            ps = env.physical_system
+            acts = d["actions"]
+            K = acts.shape[0]
+            acts = torch.as_tensor(np.repeat(acts.reshape(K, 1, -1), n, axis=1))
+            if ps._discrete and d["actions"].ndim == 1:
+                acts = acts.reshape(K, n)
+            acts = acts.cuda()
+            # per-env variation, so that lanes differ: scale continuous actions / rotate discrete ones by the env index
+            if ps._discrete and d["actions"].ndim == 1:
+                acts = ((acts.long() + torch.arange(n, device="cuda").reshape(1, n)) % int(ps.action_space.n)).to(torch.uint8)
+            elif not ps._discrete:
+                acts = acts * torch.linspace(0.3, 1.0, n, device="cuda", dtype=acts.dtype).reshape(1, n, 1)
+        obs, done = env.rollout(acts)
+        kern = ps.last_launch()
+        obs2, done2 = env.rollout(acts[:37])  # a second, shorter launch continues from the stored state (supply state / reset counters)
+        res = (obs, done, obs2, done2, ps.get_state())
+        env.close()
+        return res, kern
+
+    (a, ka), (b, kb) = run("1"), run("0")
+    assert "advance_pipe_kernel" in ka and "advance_kernel" in kb
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    if name.startswith("init:") or "epi" in name:
+        assert a[1].any()
+
+
 def test_random_initialisers_streams_and_auto_reset():
     """Counter-based Philox streams: same seed -> same states, other seed / env / reset -> other states; the in-kernel auto-reset
     draws a fresh state (inside the bounds) for exactly the envs that terminated; step-by-step == fused == chunked, bit for bit."""
