@@ -141,7 +141,8 @@ def measure_single_step(torch, env, n_local, K, W, device, seed, graph_steps=0):
     """One gemx_step launch per control step.  graph_steps > 0: `graph_steps` launches captured into ONE HIP graph and replayed."""
     ps = env.physical_system
     Ka = 256
-    acts = make_actions(torch, ps, Ka, n_local, device, seed)
+    acts_all = make_actions(torch, ps, Ka, n_local, device, seed)
+    acts = [acts_all[k] for k in range(Ka)]  # views made once: indexing a tensor costs ~2 us of host time per call
     env.reset()
     for k in range(W):
         ps.simulate(acts[k % Ka])

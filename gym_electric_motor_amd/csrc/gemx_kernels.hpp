@@ -317,7 +317,7 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
         // is cut at the instants omega is PREDICTED to reach the next kink in its direction of travel (second order: d omega/dt from the
         // first stage, the torque's slope from an Euler look-ahead of the motor states, the load's own slope in the current region);
         // each piece is one step of the scheme, at most three pieces.  Lanes that are done ride along with h = 0 (z + 0 k = z).
-        // Restated in fp64 by oracle/gemx_oracle.c:integrate_kink.
+        // (The test suite's fp64 CPU restatement follows the same steps: 1e-9 agreement with the fp64 build of this code.)
         R deps = R(0);
         const R lim = P.omega_lim, margin = R(1e-6) * lim;
         for (int s = 0; s < ns; ++s) {
@@ -455,7 +455,8 @@ __device__ __forceinline__ void dq_action_stage(const DevParams<R> &P, const R (
 // one control step of one env, in two halves so that they can run in different waves (advance_pipe_kernel):
 //   advance(): converter -> voltages -> ODE integration -> new (y, ang, sw); leaves in ho[] what observe() needs
 //   observe(): normalised observation row from (y, ang, ho)
-//   state_done(): the env's DEFAULT constraint evaluated from (y, ho) with the same arithmetic as on the row
+//   state_violation(): the value whose excess over 1 violates the env's DEFAULT constraint, from (y, ho) with the same arithmetic as
+//     default_done() applies to the row
 // step() = advance() + observe() (single-wave kernel).
 // ------------------------------------------------------------------------------------------------
 template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper;
@@ -551,11 +552,11 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
         for (int c = 0; c < NC; ++c) d |= fabs(obs[2 + c]) > R(1);
         return d;
     }
-    static __device__ __forceinline__ bool state_done(const DevParams<R> &P, const R (&y)[ND], const R (&)[NH]) {
-        bool d = false;
+    static __device__ __forceinline__ R state_violation(const DevParams<R> &P, const R (&y)[ND], const R (&)[NH]) {
+        R v = fabs(y[1] * P.inv_lim[2]);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) d |= fabs(y[1 + c] * P.inv_lim[2 + c]) > R(1);
-        return d;
+        for (int c = 1; c < NC; ++c) v = fmax(v, fabs(y[1 + c] * P.inv_lim[2 + c]));
+        return v;
     }
 };
 template <int CONV, int LOAD, int SOLVER, bool IL, class R>
@@ -655,9 +656,9 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     }
     // default constraint: SquaredConstraint(('i_sq','i_sd')) (finite_cc_pmsm_env.py:106)
     static __device__ __forceinline__ bool default_done(const R (&obs)[14]) { return obs[5] * obs[5] + obs[6] * obs[6] > R(1); }
-    static __device__ __forceinline__ bool state_done(const DevParams<R> &P, const R (&y)[3], const R (&)[NH]) {
+    static __device__ __forceinline__ R state_violation(const DevParams<R> &P, const R (&y)[3], const R (&)[NH]) {
         const R o5 = y[1] * P.inv_lim[5], o6 = y[2] * P.inv_lim[6];
-        return o5 * o5 + o6 * o6 > R(1);
+        return o5 * o5 + o6 * o6;
     }
 };
 
@@ -734,9 +735,9 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     static __device__ __forceinline__ bool default_done(const R (&obs)[16]) {
         return (obs[5] * obs[5] + obs[6] * obs[6] > R(1)) | (fabs(obs[7]) > R(1));
     }
-    static __device__ __forceinline__ bool state_done(const DevParams<R> &P, const R (&y)[4], const R (&)[NH]) {
+    static __device__ __forceinline__ R state_violation(const DevParams<R> &P, const R (&y)[4], const R (&)[NH]) {
         const R o5 = y[1] * P.inv_lim[5], o6 = y[2] * P.inv_lim[6], o7 = y[3] * P.inv_lim[7];
-        return (o5 * o5 + o6 * o6 > R(1)) | (fabs(o7) > R(1));
+        return fmax(o5 * o5 + o6 * o6, fabs(o7));
     }
 };
 
@@ -814,10 +815,10 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     }
     // default constraint: SquaredConstraint(('i_sq','i_sd')) (cont_sc_scim_env.py:111)
     static __device__ __forceinline__ bool default_done(const R (&obs)[14]) { return obs[5] * obs[5] + obs[6] * obs[6] > R(1); }
-    static __device__ __forceinline__ bool state_done(const DevParams<R> &P, const R (&y)[5], const R (&ho)[NH]) {
+    static __device__ __forceinline__ R state_violation(const DevParams<R> &P, const R (&y)[5], const R (&ho)[NH]) {
         const R s = ho[0], c = ho[1];
         const R o5 = (c * y[1] + s * y[2]) * P.inv_lim[5], o6 = (-s * y[1] + c * y[2]) * P.inv_lim[6];
-        return o5 * o5 + o6 * o6 > R(1);
+        return o5 * o5 + o6 * o6;
     }
 };
 
@@ -916,10 +917,10 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     }
     // default constraint: SquaredConstraint(('i_sq','i_sd')) (cont_cc_dfim_env.py:115)
     static __device__ __forceinline__ bool default_done(const R (&obs)[24]) { return obs[5] * obs[5] + obs[6] * obs[6] > R(1); }
-    static __device__ __forceinline__ bool state_done(const DevParams<R> &P, const R (&y)[5], const R (&ho)[NH]) {
+    static __device__ __forceinline__ R state_violation(const DevParams<R> &P, const R (&y)[5], const R (&ho)[NH]) {
         const R s = ho[0], c = ho[1];
         const R o5 = (c * y[1] + s * y[2]) * P.inv_lim[5], o6 = (-s * y[1] + c * y[2]) * P.inv_lim[6];
-        return o5 * o5 + o6 * o6 > R(1);
+        return o5 * o5 + o6 * o6;
     }
 };
 
@@ -1931,6 +1932,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
         const bool lin_ok = lin_usable<LOAD, SOLVER, IL, R>(P, y[0]);  // wave-uniform
         const bool check_default = P.constr_kind == 1;
         const bool auto_reset = P.auto_reset != 0;
+        const R thr_done = check_default ? R(1) : R(INFINITY), thr_reset = (check_default && auto_reset) ? R(1) : R(INFINITY);
         uint32_t bad_action = 0;
         if constexpr (USE_TAB) {  // (written and read by this wave only: LDS operations of one wave complete in order)
             if (tid < ConvTraits<CONV>::NACTIONS) {
@@ -2011,7 +2013,10 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             } else {
                 run_advance(P);
             }
-            const bool done = ST::state_done(P, y, ho) & check_default;
+            // (the wave-uniform switches "default constraint on" / "auto-reset on" live in the two thresholds, not in scalar ANDs of the
+            // compare mask: VALU compare -> SALU and -> VALU select sat twice on every step's dependency chain; probe: -3 % integrator cycles)
+            const R viol = ST::state_violation(P, y, ho);
+            const bool done = viol > thr_done;
 #pragma unroll
             for (int j = 0; j < ND; ++j) row[ST::row_slot(j)] = y[j];
             if (HAS_ANGLE) {
@@ -2023,7 +2028,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             for (int j = 0; j < NH; ++j) row[ST::row_slot(ND + (HAS_ANGLE ? 1 : 0) + j)] = ho[j];
             row[ST::row_slot(NDONE)] = done ? R(1) : R(0);
             if constexpr (FULL) row[ST::row_slot(NDONE + 1)] = usup_lane;
-            const bool rs = done & auto_reset;  // `if terminated: env.reset()`; switching state survives
+            const bool rs = viol > thr_reset;  // `if terminated: env.reset()`; switching state survives
 #pragma unroll
             for (int j = 0; j < ND; ++j) y[j] = rs ? P.init[j] : y[j];
             ang = rs ? init_ang : ang;
