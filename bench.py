@@ -27,7 +27,8 @@ Extra objects in the JSON line (rank 0):
                       events on the launch stream around the K timed launches; peak = 8000 GB/s (MI355X spec); traffic = PMC-measured
                       HBM bytes per launch of this exact (workload, envs, steps_per_launch) from profiles/hbm_traffic.json.
   cpu_baseline        oracle/gemx_oracle.c (scalar fp64 restatement, "port") timed on ONE host core on a bounded sample of the same
-                      workload, plus the REFERENCE's own Python path as recorded by tools/cpu_reference_bench.py (fields, not prose).
+                      workload (`all_cores`: the same port with one thread per host core), plus the REFERENCE's own Python path as
+                      recorded by tools/cpu_reference_bench.py (fields, not prose).
   headline_no_linmap  the same launches with GEMX_LINMAP=0 (RK4 evaluated stage by stage instead of through the one-step affine map).
   single_step / single_step_graph   one launch per control step (closed-loop RL usage), eager and replayed from a HIP graph.
   configs             BASELINE configs 2 and 4 (PermExDc 4096 envs Euler; SCIM 65536 envs RK4; the latter also with split_kinks) through
@@ -215,7 +216,20 @@ def cpu_baseline(w, budget_s=12.0):
     t0 = time.perf_counter()
     orc.rollout_many(p, a)
     dt = time.perf_counter() - t0
-    out = dict(value=n_env2 * K / dt, unit="env-steps/s", cores=1, kind="port", host_cores=os.cpu_count(),
+    # the same port on ALL host cores: one thread per core (ctypes releases the GIL; orc_rollout_many keeps its state on the stack),
+    # each with its own slice of envs, ~3 s of work per thread
+    import concurrent.futures as cf
+
+    cores = os.cpu_count() or 1
+    per = max(64, int(n_env2 * K / dt * 3.0 / K))
+    slices = [acts(per, K) for _ in range(min(cores, 8))]  # (a few distinct action tensors, reused: host memory stays small)
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(lambda i: orc.rollout_many(p, slices[i % len(slices)]), range(cores)))
+    dt_all = time.perf_counter() - t0
+    all_cores = dict(value=cores * per * K / dt_all, unit="env-steps/s", cores=cores,
+                     sample=f"{cores} threads x {per} envs x {K} steps, {dt_all:.1f} s")
+    out = dict(value=n_env2 * K / dt, unit="env-steps/s", cores=1, kind="port", host_cores=os.cpu_count(), all_cores=all_cores,
                sample=f"{n_env2} envs x {K} steps of the same workload ({w['env_id']}, {w['solver']}, episodic) through "
                       f"oracle/gemx_oracle.c (fp64, gcc -O2), {dt:.1f} s on 1 of {os.cpu_count()} host cores")
     ref_path = os.path.join(REPO, "profiles", "cpu_reference.json")

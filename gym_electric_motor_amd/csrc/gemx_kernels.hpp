@@ -1917,19 +1917,32 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             }
             if (P.init_kind) rcount = a.rcnt[env];
         }
+        constexpr bool LINABLE = linable<LOAD, SOLVER, IL, R>();
+        const bool lin_ok = lin_usable<LOAD, SOLVER, IL, R>(P, y[0]);  // wave-uniform
+        // DeadTimeProcessor, two representations of the same queue (both leave the same [delay][N] ring in HBM):
+        //   FIFO:    an LDS ring per lane, swapped every step (the rolled, run-time-checked copy of the step);
+        //   DELAYED: no queue at all -- the converter sees the action row staged `delay` steps EARLIER (rows before the block: `carry`,
+        //            the last `delay` rows of the previous block / of the HBM ring), zeroed while fewer than `delay` steps have passed
+        //            since the env's last reset (`since`).  It keeps the unrolled, table-driven blocks; deep shape only, and not
+        //            behind a DqToAbcActionProcessor, whose transform (a function of the state at SUBMISSION time) precedes the queue.
+        constexpr bool CAN_DELAY = D == PIPE_D && !FULL;
+        const uint32_t delay_u = (uint32_t)P.delay;
+        const bool delayed = CAN_DELAY && P.delay > 0 && !(conv_dq<CONV>() && P.dq_processor) && (!LINABLE || lin_ok);  // wave-uniform
+        uint32_t since = delay_u;  // DELAYED: control steps since this env's last reset, saturating at `delay` (the HBM ring holds zeros already)
         int slot = a.ring_phase;
         for (int d = 0; d < P.delay; ++d) {
+            // FIFO: slot d of the ring; DELAYED: carry row d = the entry popped d steps from now = ring slot (phase + d) mod delay
+            int src = d;
+            if (delayed) { src = a.ring_phase + d; src = src >= P.delay ? src - P.delay : src; }
 #pragma unroll
             for (int i = 0; i < NACTC; ++i) {
-                const int64_t gi = ((int64_t)d * N + env) * NACTC + i;
+                const int64_t gi = ((int64_t)src * N + env) * NACTC + i;
                 fifo[((size_t)d * BLOCK + tid) * NACTC + i] = DISCRETE ? (R)a.ring[gi] : reinterpret_cast<const R *>(a.ring)[gi];
             }
         }
-        R pop[NACTC];  // DeadTimeProcessor: the queue entry the next step pops, read one step ahead
+        R pop[NACTC];  // FIFO: the queue entry the next step pops, read one step ahead
 #pragma unroll
-        for (int i = 0; i < NACTC; ++i) pop[i] = P.delay > 0 ? fifo[((size_t)slot * BLOCK + tid) * NACTC + i] : R(0);
-        constexpr bool LINABLE = linable<LOAD, SOLVER, IL, R>();
-        const bool lin_ok = lin_usable<LOAD, SOLVER, IL, R>(P, y[0]);  // wave-uniform
+        for (int i = 0; i < NACTC; ++i) pop[i] = (P.delay > 0 && !delayed) ? fifo[((size_t)slot * BLOCK + tid) * NACTC + i] : R(0);
         const bool check_default = P.constr_kind == 1;
         const bool auto_reset = P.auto_reset != 0;
         const R thr_done = check_default ? R(1) : R(INFINITY), thr_reset = (check_default && auto_reset) ? R(1) : R(INFINITY);
@@ -1953,8 +1966,12 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
         };
         // `fifo_possible` (a std::bool_constant): false_type compiles the DeadTimeProcessor queue out, so that the fully
         // unrolled blocks of the common case stay ONE branch-free basic block; true_type keeps the wave-uniform run-time test
-        auto one_step = [&](auto fifo_possible, const R (&act_in)[NACT], uint32_t dact, R *row, const R *tab) {
-            constexpr bool FIFO = decltype(fifo_possible)::value;
+        // `mode` (a std::integral_constant): 0 compiles the DeadTimeProcessor queue out, so that the fully unrolled blocks of the common
+        // case stay ONE branch-free basic block; 1 = the FIFO representation with its wave-uniform run-time tests; 2 = DELAYED (the
+        // caller hands in the delayed, already masked action: only the `since` count is kept here)
+        auto one_step = [&](auto mode, const R (&act_in)[NACT], uint32_t dact, R *row, const R *tab) {
+            constexpr int MODE = decltype(mode)::value;
+            constexpr bool FIFO = MODE == 1;
             constexpr bool TAB = USE_TAB && !FIFO;  // the unrolled blocks take the action's table entry
             R act[MAX_ACT];
 #pragma unroll
@@ -2037,6 +2054,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                 sup[0] = rs ? P.u_sup : sup[0];  // RCVoltageSupply.reset: the capacitor is loaded again, the supply's clock restarts
                 sup[1] = rs ? R(0) : sup[1];
             }
+            if constexpr (MODE == 2) since = rs ? 0u : (since < delay_u ? since + 1u : delay_u);
             if (FIFO && P.delay > 0) {  // DeadTimeProcessor.reset: the deque is refilled with the (zero) reset action
                 if (rs) {
                     for (int d = 0; d < P.delay; ++d) {
@@ -2077,23 +2095,43 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             uint32_t dn = 0, dc = 0;
 #pragma unroll
             for (int i = 0; i < NACT; ++i) an[i] = R(0);
-            read_action(b, 0, an, dn);
-            if (sb == D && P.delay == 0 && (!LINABLE || lin_ok)) {
-                // branch-free basic blocks of FOUR steps (unrolling all twelve makes basic blocks of up to ~8000 instructions for the
-                // heavier systems, on which the instruction scheduler's compile time explodes; the run time is the same)
+            // DELAYED: the row the converter sees at step s of this block was staged `delay` steps earlier
+            auto read_delayed = [&](int s, R (&dst)[NACT], uint32_t &ddst) {
+                if (s >= P.delay) {
+                    read_action(b, s - P.delay, dst, ddst);
+                } else {
+                    const R *c = fifo + ((size_t)s * BLOCK + tid) * NACTC;
+                    if (DISCRETE) ddst = (uint32_t)c[0];
+                    else {
+#pragma unroll
+                        for (int i = 0; i < NACT; ++i) dst[i] = c[i];
+                    }
+                }
+            };
+            [[maybe_unused]] constexpr uint32_t AMASK = DISCRETE ? (uint32_t)(ConvTraits<CONV>::NACTIONS - 1) : 0u;
+            [[maybe_unused]] auto fetch_entry = [&](uint32_t d, R (&e)[8]) {
+                const R *src = vtab + (size_t)(d & AMASK) * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = j < ST::NVT ? src[j] : R(0);
+            };
+            // full block, unrolled into branch-free basic blocks of FOUR steps (unrolling all twelve makes basic blocks of up to ~8000
+            // instructions for the heavier systems, on which the instruction scheduler's compile time explodes; the run time is the same)
+            auto run_block = [&](auto delayed_tag) {
+                constexpr bool DEL = decltype(delayed_tag)::value;
+                using Mode = std::integral_constant<int, DEL ? 2 : 0>;
+                auto rd = [&](int s, R (&dst)[NACT], uint32_t &ddst) {
+                    if constexpr (DEL) read_delayed(s, dst, ddst);
+                    else read_action(b, s, dst, ddst);
+                };
+                rd(0, an, dn);
                 if constexpr (USE_TAB) {
                     // two-deep software pipeline: step s runs on table entry ec; the entry of step s+1 and the action of step s+2 are
                     // in flight (each LDS read has a whole step to land)
-                    constexpr uint32_t AMASK = (uint32_t)(ConvTraits<CONV>::NACTIONS - 1);
-                    auto fetch_entry = [&](uint32_t d, R (&e)[8]) {
-                        const R *src = vtab + (size_t)(d & AMASK) * 8;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) e[j] = j < ST::NVT ? src[j] : R(0);
-                    };
-                    R en[8], ec[8];
+                    R en[8], ec[8], e0[8];
                     uint32_t dnn = 0;
+                    if constexpr (DEL) fetch_entry(0u, e0);  // the zero action's entry, for the steps right after a reset
                     fetch_entry(dn, en);
-                    read_action(b, 1, an, dnn);
+                    rd(1, an, dnn);
 #pragma unroll 4
                     for (int s = 0; s < D; ++s) {
                         dc = dn;
@@ -2101,8 +2139,13 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                         for (int j = 0; j < 8; ++j) ec[j] = en[j];
                         dn = dnn;
                         fetch_entry(dn, en);
-                        read_action(b, s + 2 < D ? s + 2 : D - 1, an, dnn);
-                        one_step(std::false_type{}, ac, dc, hb + (size_t)s * BLOCK * NHT, ec);
+                        rd(s + 2 < D ? s + 2 : D - 1, an, dnn);
+                        if constexpr (DEL) {
+                            const bool queued = since >= delay_u;  // else: the refilled (zero) reset action
+#pragma unroll
+                            for (int j = 0; j < ST::NVT; ++j) ec[j] = queued ? ec[j] : e0[j];
+                        }
+                        one_step(Mode{}, ac, dc, hb + (size_t)s * BLOCK * NHT, ec);
                     }
                 } else {
 #pragma unroll 4
@@ -2110,19 +2153,73 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                         dc = dn;
 #pragma unroll
                         for (int i = 0; i < NACT; ++i) ac[i] = an[i];
-                        read_action(b, s + 1 < D ? s + 1 : s, an, dn);  // one step ahead: its LDS latency hides behind this step
-                        one_step(std::false_type{}, ac, dc, hb + (size_t)s * BLOCK * NHT, nullptr);
+                        rd(s + 1 < D ? s + 1 : s, an, dn);  // one step ahead: its LDS latency hides behind this step
+                        if constexpr (DEL) {
+                            const bool queued = since >= delay_u;
+                            dc = queued ? dc : 0u;
+#pragma unroll
+                            for (int i = 0; i < NACT; ++i) ac[i] = queued ? ac[i] : R(0);
+                        }
+                        one_step(Mode{}, ac, dc, hb + (size_t)s * BLOCK * NHT, nullptr);
                     }
                 }
-            } else {  // tail block or DeadTimeProcessor queue: ONE rolled copy of the run-time-checked step
-                // (the action of step s+1 is read from LDS before step s runs, as in the unrolled blocks: `an` / `dn` hold row 0 already)
+            };
+            if (sb == D && P.delay == 0 && (!LINABLE || lin_ok)) {
+                run_block(std::false_type{});
+            } else if (CAN_DELAY && delayed) {
+                if constexpr (CAN_DELAY) {
+                    if (sb == D) {
+                        run_block(std::true_type{});
+                    } else {  // tail block: the same steps, rolled
+                        R ect[8] = {};
+#pragma nounroll
+                        for (int s = 0; s < sb; ++s) {
+                            read_delayed(s, ac, dc);
+                            const bool queued = since >= delay_u;
+                            dc = queued ? dc : 0u;
+#pragma unroll
+                            for (int i = 0; i < NACT; ++i) ac[i] = queued ? ac[i] : R(0);
+                            if constexpr (USE_TAB) fetch_entry(dc, ect);
+                            one_step(std::integral_constant<int, 2>{}, ac, dc, hb + (size_t)s * BLOCK * NHT, ect);
+                        }
+                    }
+                    // carry <- the last `delay` rows submitted so far (ascending: entry j + sb is read before it is overwritten)
+                    for (int j = 0; j < P.delay; ++j) {
+                        const int idx = j + sb - P.delay;
+                        R *c = fifo + ((size_t)j * BLOCK + tid) * NACTC;
+                        R v[NACTC];
+#pragma unroll
+                        for (int i = 0; i < NACTC; ++i) v[i] = R(0);
+                        if (idx >= 0) {
+                            R t[NACT];
+                            uint32_t td = 0;
+#pragma unroll
+                            for (int i = 0; i < NACT; ++i) t[i] = R(0);
+                            read_action(b, idx, t, td);
+                            if (DISCRETE) v[0] = (R)(td & AMASK);
+                            else {
+#pragma unroll
+                                for (int i = 0; i < NACT; ++i) v[i] = t[i];
+                            }
+                        } else {
+                            const R *o = fifo + ((size_t)(j + sb) * BLOCK + tid) * NACTC;
+#pragma unroll
+                            for (int i = 0; i < NACTC; ++i) v[i] = o[i];
+                        }
+#pragma unroll
+                        for (int i = 0; i < NACTC; ++i) c[i] = v[i];
+                    }
+                }
+            } else {  // tail block or DeadTimeProcessor FIFO: ONE rolled copy of the run-time-checked step
+                // (the action of step s+1 is read from LDS before step s runs, as in the unrolled blocks)
+                read_action(b, 0, an, dn);
 #pragma nounroll
                 for (int s = 0; s < sb; ++s) {
                     dc = dn;
 #pragma unroll
                     for (int i = 0; i < NACT; ++i) ac[i] = an[i];
                     read_action(b, s + 1 < sb ? s + 1 : s, an, dn);
-                    one_step(std::true_type{}, ac, dc, hb + (size_t)s * BLOCK * NHT, nullptr);
+                    one_step(std::integral_constant<int, 1>{}, ac, dc, hb + (size_t)s * BLOCK * NHT, nullptr);
                 }
             }
 #ifdef GEMX_TIMING
@@ -2154,11 +2251,22 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             }
             if (P.init_kind) a.rcnt[env] = rcount;
         }
+        int phase_end = 0;
+        if (P.delay > 0) phase_end = (a.ring_phase + K) % P.delay;
         for (int d = 0; d < P.delay; ++d) {
+            // FIFO: slot d as it stands.  DELAYED: carry row d is the entry popped d steps after this launch -> ring slot (phase_end + d)
+            // mod delay; entries submitted before the env's last reset are the refilled zero action
+            int dst = d;
+            bool keep = true;
+            if (delayed) {
+                dst = phase_end + d;
+                dst = dst >= P.delay ? dst - P.delay : dst;
+                keep = (uint32_t)d + since >= delay_u;
+            }
 #pragma unroll
             for (int i = 0; i < NACTC; ++i) {
-                const int64_t gi = ((int64_t)d * N + env) * NACTC + i;
-                const R v = fifo[((size_t)d * BLOCK + tid) * NACTC + i];
+                const int64_t gi = ((int64_t)dst * N + env) * NACTC + i;
+                const R v = keep ? fifo[((size_t)d * BLOCK + tid) * NACTC + i] : R(0);
                 if (DISCRETE) a.ring[gi] = (unsigned char)(uint32_t)v;
                 else reinterpret_cast<R *>(a.ring)[gi] = v;
             }

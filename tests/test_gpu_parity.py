@@ -886,6 +886,60 @@ def test_full_pipelined_variant_matches_single_wave_kernel(name, monkeypatch):
         assert a[1].any()
 
 
+@pytest.mark.parametrize("env_id, delay, kw", [
+    ("Finite-CC-PMSM-v0", 3, dict(tau=1e-4)), ("Finite-CC-PMSM-v0", 8, dict(tau=1e-4)), ("Finite-CC-PMSM-v0", 1, dict(tau=1e-4)),
+    ("Cont-CC-PermExDc-v0", 2, {}), ("Cont-SC-SCIM-v0", 1, dict(control_space="dq")), ("Finite-CC-DFIM-v0", 2, {}), ("Finite-CC-EESM-v0", 5, dict(tau=1e-4)),
+    ("Finite-CC-ShuntDc-v0", 4, {}),
+])
+def test_delayed_read_deadtime_queue_matches_the_fifo_representation(env_id, delay, kw, monkeypatch):
+    """DeadTimeProcessor in the pipelined kernel's deep shape: no queue, but the action row staged `delay` steps earlier, zeroed while
+    fewer than `delay` steps have passed since the env's reset (table-driven, unrolled blocks stay).  Bit-identical to the single-wave
+    kernel's explicit FIFO: one launch, uneven chunks (the ring in HBM hands the pending entries over, incl. K < delay and resets right
+    before a launch boundary), and a continuation after the chunks; per-env random actions, default constraints + auto-reset."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    n, K = 256, 173
+
+    def mk(pipe):
+        monkeypatch.setenv("GEMX_PIPE", pipe)
+        monkeypatch.setenv("GEMX_PIPE_SHAPE", "0")
+        return ga.make(env_id, n_envs=n, ode_solver=ga.RK4Solver(), physical_system_wrappers=(ga.DeadTimeProcessor(steps=delay),), **kw)
+
+    env = mk("1")
+    ps = env.physical_system
+    g = torch.Generator(device="cuda").manual_seed(4)
+    if ps._discrete:
+        nflat = int(np.prod(ps.action_space.nvec)) if hasattr(ps.action_space, "nvec") else int(ps.action_space.n)
+        acts = torch.randint(0, nflat, (K + 40, n), device="cuda", generator=g, dtype=torch.uint8)
+    else:
+        acts = torch.rand((K + 40, n, ps._n_act), device="cuda", generator=g) * 2 - 1
+    obs, done = env.rollout(acts[:K])
+    assert "advance_pipe_kernel" in ps.last_launch()
+    if "DFIM" not in env_id:  # (the DFIM's hand-off rows do not fit the deep shape: it keeps the FIFO representation, compared all the same)
+        assert "D=12" in ps.last_launch()
+    obs_c, done_c = env.rollout(acts[K:])  # continuation from the ring the launch left behind
+    ref = mk("0")
+    robs, rdone = ref.rollout(acts[:K])
+    assert "advance_kernel" in ref.physical_system.last_launch()
+    robs_c, rdone_c = ref.rollout(acts[K:])
+    assert torch.equal(obs, robs) and torch.equal(done, rdone) and torch.equal(obs_c, robs_c) and torch.equal(done_c, rdone_c)
+    e2 = mk("1")
+    parts, k0 = [], 0
+    for kk in (1, 7, 2, 30, 13, 24, 96):  # 1 and 2: fewer steps than some queues are deep; 24 = two full blocks; 96 = eight
+        parts.append(e2.rollout(acts[k0:k0 + kk]))
+        k0 += kk
+    assert k0 == K
+    assert torch.equal(torch.cat([p[0] for p in parts]), obs) and torch.equal(torch.cat([p[1] for p in parts]), done)
+    o2, d2 = e2.rollout(acts[K:])
+    assert torch.equal(o2, obs_c) and torch.equal(d2, done_c)
+    if "PMSM" in env_id or "EESM" in env_id or "ShuntDc" in env_id or "PermExDc" in env_id:
+        assert done.any()  # resets happened: the zero-action window after a reset was exercised
+    for e in (env, ref, e2):
+        e.close()
+
+
 def test_random_initialisers_streams_and_auto_reset():
     """Counter-based Philox streams: same seed -> same states, other seed / env / reset -> other states; the in-kernel auto-reset
     draws a fresh state (inside the bounds) for exactly the envs that terminated; step-by-step == fused == chunked, bit for bit."""

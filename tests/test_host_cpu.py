@@ -409,3 +409,29 @@ def test_config_struct_header_binding_and_docs_agree():
         assert [g[0] for g in cls_._fields_] == [name for _, name, _ in f2], struct
         for (gn, gt), (t, name, n) in zip(cls_._fields_, f2):
             assert C.sizeof(gt) == C.sizeof(ct[t]) * (n or 1), (struct, gn)
+
+
+def test_bench_cli_contract_without_a_gpu():
+    """bench.py: the driver's flags parse; impossible requests fail with a message, not a traceback; the workload table carries the
+    algorithmic bytes per env-step of SURVEY.md 8(d) (25 / 58 / 69 B fused, 41 / 90 / 117 B single step)."""
+    import subprocess
+    import sys
+
+    if REPO not in sys.path:
+        sys.path.insert(0, REPO)
+    import bench
+
+    assert [bench.bytes_per_env_step_fused(dict(w)) for w in (bench.WORKLOADS["permexdc"], bench.WORKLOADS["pmsm"], bench.WORKLOADS["scim"])] == [25, 58, 69]
+    assert [bench.bytes_per_env_step_single(dict(w)) for w in (bench.WORKLOADS["permexdc"], bench.WORKLOADS["pmsm"], bench.WORKLOADS["scim"])] == [41, 90, 117]
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "0"], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "--steps >= 1" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+    import torch
+
+    if not torch.cuda.is_available():  # self-spawn without enough GPUs: a clear message
+        r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=env)
+        assert r.returncode != 0 and "GPU(s) visible" in r.stderr

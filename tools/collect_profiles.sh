@@ -30,7 +30,9 @@ for WL in pmsm permexdc scim; do
     echo "$WL $c $(python $R/tools/pmc_sum.py /tmp/pmc_$c advance)" >> $OUT/${TAG}_pmc_raw.txt
   done
 done
-rm -rf /tmp/pmc_sq
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d /tmp/pmc_sq -- python $R/bench.py --no-extras --steps 5 --warmup 2 > /tmp/pmc_sq.log 2>&1
-echo "pmsm SQ $(python $R/tools/pmc_sum.py /tmp/pmc_sq advance)" >> $OUT/${TAG}_pmc_raw.txt
+for WL in pmsm scim permexdc; do
+  rm -rf /tmp/pmc_sq
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d /tmp/pmc_sq -- python $R/bench.py --no-extras --workload $WL --steps 5 --warmup 2 > /tmp/pmc_sq.log 2>&1
+  python $R/tools/pmc_sum.py /tmp/pmc_sq advance | sed "s/^/$WL SQ /" >> $OUT/${TAG}_pmc_raw.txt
+done
 python $R/tools/bench_matrix.py > $OUT/${TAG}_matrix.md 2>/dev/null
