@@ -346,6 +346,11 @@ constexpr int PIPE_D3 = 2, PIPE_OUT_WAVES3 = 2;
 // both shapes carry a LOADER wave that stages actions / references global -> LDS (0: the integrator wave stages them itself).  Measured
 // at 131072 envs over all motor families (same box A/B): -5 .. +22 %, the heavier steppers and the continuous-action ones gain most
 constexpr int pipe_loader_waves(int) { return 1; }
+// rows of the pipelined kernel's per-lane action queue in LDS: `delay` (FIFO / carry rows), or D + delay where the queue of TRANSFORMED
+// actions behind a DqToAbcActionProcessor is kept as a row buffer indexed by the step of the block (deep shape only)
+__host__ __device__ constexpr int pipe_queue_rows(int D, int delay, bool dq_processor, bool full) {
+    return (D == PIPE_D && !full && dq_processor && delay > 0) ? D + delay : delay;
+}
 // chunks per lane needed to stage MAX_STEPS_PER_BLOCK steps of a row made of `cpr` 16-byte chunks
 __host__ __device__ constexpr int act_chunks(int cpr) {
     return (MAX_STEPS_PER_BLOCK * cpr + BLOCK - 1) / BLOCK < MAX_ACT_CHUNKS ? (MAX_STEPS_PER_BLOCK * cpr + BLOCK - 1) / BLOCK : MAX_ACT_CHUNKS;

@@ -244,7 +244,7 @@ __device__ __forceinline__ R rk_step(R (&z)[NZ], R h, F &&rhs) {
 // linmap_kernel obtained them by pushing unit vectors through rk_step itself; a step is then NM*(NM+NG) FMAs instead of 4 (RK4) or
 // 6 (DP5) right-hand sides plus stage combinations.  Same polynomial, so same result up to rounding.
 template <int SYS, int LOAD, int SOLVER, class R, bool NS1 = false, bool LIN = false>
-__device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<SYS>::ND], const R (&u)[MAX_U], R h) {
+__device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<SYS>::ND], const R (&u)[MAX_U], R h, const R *linr = nullptr) {
     using E = Elec<SYS, R>;
     constexpr int NM = E::NM;
     const int ns = NS1 ? 1 : P.nsteps;     // NS1: the caller guarantees solver_nsteps == 1 (branch-free code)
@@ -252,6 +252,10 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
     if (LIN) {
         constexpr int NG = E::NG;
         R g[NG], x[NM];
+        // the map's coefficients: from the caller's registers when it preloaded them (lin_preload), else through the device pointer --
+        // which, inside a rolled step loop, is TWO vector loads and a full trip to memory on every step (they cannot be hoisted out of the
+        // `lin_ok` branch): the run-time-checked copies of the step spent 680 of their 1190 cycles per step there (s_memtime probe)
+        const R *L = linr != nullptr ? linr : P.lin;
         const R om = P.init[0];  // == y[0] in every lane (lin_usable); wave-uniform, so everything derived from it is loop-invariant
         E::get_b(E::prep(P, om, u), g);
 #pragma unroll
@@ -260,11 +264,11 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
             R xn[NM];
 #pragma unroll
             for (int r = 0; r < NM; ++r) {
-                R acc = P.lin[NM * NM + r * NG] * g[0];
+                R acc = L[NM * NM + r * NG] * g[0];
 #pragma unroll
-                for (int i = 1; i < NG; ++i) acc += P.lin[NM * NM + r * NG + i] * g[i];
+                for (int i = 1; i < NG; ++i) acc += L[NM * NM + r * NG + i] * g[i];
 #pragma unroll
-                for (int c = 0; c < NM; ++c) acc += P.lin[r * NM + c] * x[c];
+                for (int c = 0; c < NM; ++c) acc += L[r * NM + c] * x[c];
                 xn[r] = acc;
             }
 #pragma unroll
@@ -482,7 +486,7 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
     }
     template <bool NS1 = false, bool LIN = false, bool TAB = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[ND], AngT &, uint32_t &sw, const R (&act)[MAX_ACT], uint32_t dact,
-                                                   R (&ho)[NH], const R * = nullptr) {
+                                                   R (&ho)[NH], const R * = nullptr, const R *linr = nullptr) {
         R u[MAX_U] = {R(0), R(0), R(0), R(0)};
         if (CONT) {
 #pragma unroll
@@ -492,7 +496,7 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
                 const R i = i_in(y, j);
                 u[j] = (cont_leg<IL, R>(P, d0, i) - cont_leg<IL, R>(P, d1, i)) * P.u_sup;  // both sub-converters see the same i (line 483)
             }
-            integrate<SYS, LOAD, SOLVER, R, NS1, LIN>(P, y, u, P.tau);
+            integrate<SYS, LOAD, SOLVER, R, NS1, LIN>(P, y, u, P.tau, linr);
         } else {  // Finite-4QC: action -> (leg0, leg1) sub-actions [1,1,2,2] / [1,2,1,2] (converters.py:360-361)
             uint32_t legs = 0;
 #pragma unroll
@@ -520,7 +524,7 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
                     }
                     u[j] = (v0 - v1) * P.u_sup;
                 }
-                integrate<SYS, LOAD, SOLVER, R, NS1, LIN>(P, y, u, h);
+                integrate<SYS, LOAD, SOLVER, R, NS1, LIN>(P, y, u, h, linr);
             };
             if (IL) {
                 segment(two ? P.t_il : P.tau);
@@ -592,7 +596,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     }
     template <bool NS1 = false, bool LIN = false, bool TAB = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[3], AngT &ang, uint32_t &sw, const R (&act)[MAX_ACT],
-                                                   uint32_t dact, R (&ho)[NH], const R *tab = nullptr) {
+                                                   uint32_t dact, R (&ho)[NH], const R *tab = nullptr, const R *linr = nullptr) {
         R s, c;
         Angle<R>::sincos(ang, s, c);
         uint32_t legs = 0;
@@ -618,7 +622,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             }
             u[0] = c * ual + s * ube;  // Q^-1(., eps): u_dq frozen at the segment-start angle (line 501/511)
             u[1] = -s * ual + c * ube;
-            const R deps = integrate<GEMX_SYS_SYNC, LOAD, SOLVER, R, NS1, LIN>(P, y, u, h);
+            const R deps = integrate<GEMX_SYS_SYNC, LOAD, SOLVER, R, NS1, LIN>(P, y, u, h, linr);
             ang = Angle<R>::advance(ang, deps);
         };
         if (IL) {
@@ -690,7 +694,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     }
     template <bool NS1 = false, bool LIN = false, bool TAB = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[4], AngT &ang, uint32_t &, const R (&act)[MAX_ACT],
-                                                   uint32_t dact, R (&ho)[NH], const R *tab = nullptr) {
+                                                   uint32_t dact, R (&ho)[NH], const R *tab = nullptr, const R *linr = nullptr) {
         R s, c;
         Angle<R>::sincos(ang, s, c);
         R ua, ub, uc, ue, u[MAX_U] = {R(0), R(0), R(0), R(0)};
@@ -704,7 +708,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
         u[0] = c * ual + s * ube;  // Q^-1(., eps) at the step-start angle (line 643)
         u[1] = -s * ual + c * ube;
         u[2] = ue;
-        const R deps = integrate<GEMX_SYS_EESM, LOAD, SOLVER, R, NS1, LIN>(P, y, u, P.tau);
+        const R deps = integrate<GEMX_SYS_EESM, LOAD, SOLVER, R, NS1, LIN>(P, y, u, P.tau, linr);
         ang = Angle<R>::advance(ang, deps);
         ho[0] = s; ho[1] = c; ho[2] = ua; ho[3] = ub; ho[4] = uc; ho[5] = u[0]; ho[6] = u[1]; ho[7] = ue;
     }
@@ -757,7 +761,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     static __device__ __forceinline__ void field_angle(R pa, R pb, R &s, R &c) { flux_angle<R>(pa, pb, s, c); }
     template <bool NS1 = false, bool LIN = false, bool TAB = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[5], AngT &ang, uint32_t &sw, const R (&act)[MAX_ACT],
-                                                   uint32_t dact, R (&ho)[NH], const R *tab = nullptr) {
+                                                   uint32_t dact, R (&ho)[NH], const R *tab = nullptr, const R *linr = nullptr) {
         R s, c;
         field_angle(y[3], y[4], s, c);
         uint32_t legs = 0;
@@ -777,7 +781,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
                 b6_voltages<CONV, IL, R>(P, act, dact, legs, ia, ib, ic, ua, ub, uc);
                 t23(ua, ub, uc, u[0], u[1]);  // u_alphabeta constant over the segment (line 788/799)
             }
-            const R deps = integrate<GEMX_SYS_SCIM, LOAD, SOLVER, R, NS1, LIN>(P, y, u, h);
+            const R deps = integrate<GEMX_SYS_SCIM, LOAD, SOLVER, R, NS1, LIN>(P, y, u, h, linr);
             ang = Angle<R>::advance(ang, deps);
         };
         if (IL) {
@@ -834,7 +838,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     static constexpr int B6 = CONV == GEMX_CONV_CONT_2XB6 ? GEMX_CONV_CONT_B6 : GEMX_CONV_FINITE_B6;
     template <bool NS1 = false, bool LIN = false, bool TAB = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[5], AngT &ang, uint32_t &sw, const R (&act)[MAX_ACT],
-                                                   uint32_t dact, R (&ho)[NH], const R * = nullptr) {
+                                                   uint32_t dact, R (&ho)[NH], const R * = nullptr, const R *linr = nullptr) {
         R sf, cf, se, ce;
         SC::field_angle(y[3], y[4], sf, cf);
         Angle<R>::sincos_precise(ang, se, ce);
@@ -860,7 +864,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             t23(urd, ure, urf, urg, urh);
             u[2] = ce * urg - se * urh;
             u[3] = se * urg + ce * urh;
-            const R deps = integrate<GEMX_SYS_DFIM, LOAD, SOLVER, R, NS1, LIN>(P, y, u, h);
+            const R deps = integrate<GEMX_SYS_DFIM, LOAD, SOLVER, R, NS1, LIN>(P, y, u, h, linr);
             ang = Angle<R>::advance(ang, deps);
         };
         if (IL) {
@@ -1001,9 +1005,9 @@ __device__ __forceinline__ void draw_initial_state_cnt(const InitDev *rinit, int
 // step() for the single-wave kernel
 template <class ST, int ND, int NOUT, class R, bool LIN = false>
 __device__ __forceinline__ void full_step(const DevParams<R> &P, R (&y)[ND], typename Angle<R>::T &ang, uint32_t &sw, const R (&act)[MAX_ACT],
-                                          uint32_t dact, R (&obs)[NOUT]) {
+                                          uint32_t dact, R (&obs)[NOUT], const R *linr = nullptr) {
     R ho[ST::NH];
-    ST::template advance<false, LIN>(P, y, ang, sw, act, dact, ho);
+    ST::template advance<false, LIN>(P, y, ang, sw, act, dact, ho, nullptr, linr);
     ST::observe(P, y, ang, ho, obs);
 }
 // instantiations whose electrical subsystem can be stepped by the precomputed one-step map (see integrate<..., LIN>)
@@ -1015,6 +1019,12 @@ template <int LOAD, int SOLVER, bool IL, class R> constexpr bool linable() {
 template <int LOAD, int SOLVER, bool IL, class R> __device__ __forceinline__ bool lin_usable(const DevParams<R> &P, R omega) {
     if (!linable<LOAD, SOLVER, IL, R>()) return false;
     return P.lin_on && __all(omega == P.init[0]);
+}
+// the map's NM * (NM + NG) coefficients into registers, once per kernel (see integrate<..., LIN>)
+template <int SYS, class R> constexpr int lin_count() { return Elec<SYS, R>::NM * (Elec<SYS, R>::NM + Elec<SYS, R>::NG); }
+template <int SYS, class R> __device__ __forceinline__ void lin_preload(const DevParams<R> &P, bool lin_ok, R (&c)[lin_count<SYS, R>()]) {
+#pragma unroll
+    for (int i = 0; i < lin_count<SYS, R>(); ++i) c[i] = lin_ok ? P.lin[i] : R(0);
 }
 // builds the map for one handle: Phi's columns are rk_step(e_j) with g = 0, S's columns rk_step(0) with g = e_i
 template <int SYS, int SOLVER, class R> __global__ void linmap_kernel(DevParams<R> P, R *out) {
@@ -1340,7 +1350,8 @@ template <bool COOP, int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R>
 __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTraits<SYS>::ND], typename Angle<R>::T &ang, uint32_t &sw,
                                               R (&obs)[SysTraits<SYS>::NOUT], uint32_t &done_or, uint32_t &bad_action, R *ring,
                                               const unsigned char *atile, unsigned char *donebuf, int k0, int sb, int tid,
-                                              int64_t e, typename Angle<R>::T init_ang, R *fifo, int &slot, R (&sup)[2], bool lin_ok) {
+                                              int64_t e, typename Angle<R>::T init_ang, R *fifo, int &slot, R (&sup)[2], bool lin_ok,
+                                              const R (&linc)[lin_count<SYS, R>()]) {
     constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
     constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
     constexpr int ABYTES = DISCRETE ? 1 : NACT * (int)sizeof(R);
@@ -1416,7 +1427,7 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
             sup[1] = P.tau;
             PL.u_sup = sup[0];
         }
-        if (linable<LOAD, SOLVER, IL, R>() && lin_ok) full_step<ST, ND, NOUT, R, linable<LOAD, SOLVER, IL, R>()>(PL, y, ang, sw, act, dact, obs);
+        if (linable<LOAD, SOLVER, IL, R>() && lin_ok) full_step<ST, ND, NOUT, R, linable<LOAD, SOLVER, IL, R>()>(PL, y, ang, sw, act, dact, obs, linc);
         else full_step<ST, ND, NOUT, R, false>(PL, y, ang, sw, act, dact, obs);
         const bool done = constraint_done<ST, NOUT, R>(P, obs);
         done_or |= done ? 1u : 0u;
@@ -1507,6 +1518,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SYS == GE
     }
     const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
     const bool lin_ok = lin_usable<LOAD, SOLVER, IL, R>(P, y[0]);  // wave-uniform
+    R linc[lin_count<SYS, R>()];  // the one-step map's coefficients, in registers for the whole launch (drained with the prologue loads)
+    lin_preload<SYS, R>(P, linable<LOAD, SOLVER, IL, R>() && lin_ok, linc);
     R sup[2] = {P.u_sup, R(0)};  // RCVoltageSupply: capacitor voltage, time since the supply's last update
     if (P.rc_supply) {
         sup[0] = a.state[(int64_t)ND * N + e];
@@ -1575,8 +1588,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SYS == GE
 
         // 2. compute: no global memory traffic in here when coop
         const unsigned char *atile = actbuf + (size_t)half * S * ROWB;
-        if (coop) compute_block<true, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot, sup, lin_ok);
-        else compute_block<false, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot, sup, lin_ok);
+        if (coop) compute_block<true, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot, sup, lin_ok, linc);
+        else compute_block<false, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot, sup, lin_ok, linc);
         __syncthreads();
 #ifdef GEMX_TIMING
         if (k0 == 0) pT2 = clock64();
@@ -1837,7 +1850,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
     constexpr int NACTC = conv_nact_c<CONV>();
     R *fifo = hand + 2 * (size_t)D * BLOCK * NHT;  // DeadTimeProcessor FIFO [delay][64][NACTC], touched by the integrator wave only
     // action staging buffer [2][D][64 * action bytes], filled by global -> LDS direct loads of the integrator wave
-    unsigned char *actb = reinterpret_cast<unsigned char *>(fifo + (size_t)P.delay * BLOCK * NACTC);
+    unsigned char *actb = reinterpret_cast<unsigned char *>(fifo + (size_t)pipe_queue_rows(D, P.delay, conv_dq<CONV>() && P.dq_processor, FULL) * BLOCK * NACTC);
     // fused reward: reference rows [3][D][64 * n_ref] R, staged global -> LDS by the integrator wave one block ahead, read by the output
     // waves one block behind (hence three buffers).  The output waves thus issue NO global loads: a load would make them wait, through
     // the in-order vmcnt, for all their older observation stores once per block.
@@ -1925,15 +1938,19 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
         //            the last `delay` rows of the previous block / of the HBM ring), zeroed while fewer than `delay` steps have passed
         //            since the env's last reset (`since`).  It keeps the unrolled, table-driven blocks; deep shape only, and not
         //            behind a DqToAbcActionProcessor, whose transform (a function of the state at SUBMISSION time) precedes the queue.
+        R linc[lin_count<SYS, R>()];
+        lin_preload<SYS, R>(P, LINABLE && lin_ok, linc);
         constexpr bool CAN_DELAY = D == PIPE_D && !FULL;
         const uint32_t delay_u = (uint32_t)P.delay;
-        const bool delayed = CAN_DELAY && P.delay > 0 && !(conv_dq<CONV>() && P.dq_processor) && (!LINABLE || lin_ok);  // wave-uniform
+        const bool delayed_any = CAN_DELAY && P.delay > 0 && (!LINABLE || lin_ok);                          // wave-uniform
+        const bool delayed_t = delayed_any && conv_dq<CONV>() && P.dq_processor;  // queue of TRANSFORMED actions (row buffer, see one_step)
+        const bool delayed = delayed_any && !delayed_t;                           // delayed read of the staged raw rows
         uint32_t since = delay_u;  // DELAYED: control steps since this env's last reset, saturating at `delay` (the HBM ring holds zeros already)
         int slot = a.ring_phase;
         for (int d = 0; d < P.delay; ++d) {
             // FIFO: slot d of the ring; DELAYED: carry row d = the entry popped d steps from now = ring slot (phase + d) mod delay
             int src = d;
-            if (delayed) { src = a.ring_phase + d; src = src >= P.delay ? src - P.delay : src; }
+            if (delayed_any) { src = a.ring_phase + d; src = src >= P.delay ? src - P.delay : src; }
 #pragma unroll
             for (int i = 0; i < NACTC; ++i) {
                 const int64_t gi = ((int64_t)src * N + env) * NACTC + i;
@@ -1942,7 +1959,13 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
         }
         R pop[NACTC];  // FIFO: the queue entry the next step pops, read one step ahead
 #pragma unroll
-        for (int i = 0; i < NACTC; ++i) pop[i] = (P.delay > 0 && !delayed) ? fifo[((size_t)slot * BLOCK + tid) * NACTC + i] : R(0);
+        for (int i = 0; i < NACTC; ++i) pop[i] = (P.delay > 0 && !delayed_any) ? fifo[((size_t)slot * BLOCK + tid) * NACTC + i] : R(0);
+        // DELAYED_T (mode 3): row r of the queue buffer holds the converter-side action of step r of the current block; the processor's
+        // output of step s goes to row s + delay.  qpre = row s, read one step ahead; tprev = the previous step's output (queue one deep:
+        // that IS row s, and its LDS round trip would sit on the chain)
+        R qpre[NACTC], tprev[NACTC];
+#pragma unroll
+        for (int i = 0; i < NACTC; ++i) { qpre[i] = delayed_t ? fifo[(size_t)tid * NACTC + i] : R(0); tprev[i] = qpre[i]; }
         const bool check_default = P.constr_kind == 1;
         const bool auto_reset = P.auto_reset != 0;
         const R thr_done = check_default ? R(1) : R(INFINITY), thr_reset = (check_default && auto_reset) ? R(1) : R(INFINITY);
@@ -1969,7 +1992,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
         // `mode` (a std::integral_constant): 0 compiles the DeadTimeProcessor queue out, so that the fully unrolled blocks of the common
         // case stay ONE branch-free basic block; 1 = the FIFO representation with its wave-uniform run-time tests; 2 = DELAYED (the
         // caller hands in the delayed, already masked action: only the `since` count is kept here)
-        auto one_step = [&](auto mode, const R (&act_in)[NACT], uint32_t dact, R *row, const R *tab) {
+        auto one_step = [&](auto mode, const R (&act_in)[NACT], uint32_t dact, R *row, const R *tab, R *qw = nullptr, const R *qn = nullptr) {
             constexpr int MODE = decltype(mode)::value;
             constexpr bool FIFO = MODE == 1;
             constexpr bool TAB = USE_TAB && !FIFO;  // the unrolled blocks take the action's table entry
@@ -1981,7 +2004,24 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                 dact &= (uint32_t)(ConvTraits<CONV>::NACTIONS - 1);
             }
             // action stage, exactly as in compute_block(): [DqToAbcActionProcessor [DeadTimeProcessor [system(control_space)]]]
+            R qnext[NACTC];
+            if constexpr (MODE == 3) {
+#pragma unroll
+                for (int i = 0; i < NACTC; ++i) qnext[i] = qn[i];  // row s + 1 (written at least one step ago unless the queue is one deep)
+            }
             if (conv_dq<CONV>() && P.dq_processor) dq_action_stage<SYS, CONV, R>(P, y, ang, act);
+            if constexpr (MODE == 3) {
+                const bool one_deep = P.delay == 1, queued = since >= delay_u;
+#pragma unroll
+                for (int i = 0; i < NACTC; ++i) {
+                    const R t = act[i];
+                    qw[i] = t;                                   // row s + delay
+                    const R q = one_deep ? tprev[i] : qpre[i];   // row s
+                    tprev[i] = t;
+                    act[i] = queued ? q : R(0);                  // (the refilled zero action right after a reset)
+                    qpre[i] = qnext[i];
+                }
+            }
             if (FIFO && P.delay > 0) {
                 // the value popped in THIS step was read a step ago (`pop`); push the new one, then read the next step's pop -- the
                 // slot after this one, or what was just pushed when the queue is one deep -- so that its LDS latency hides behind this step
@@ -2009,9 +2049,9 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             // launcher guarantees solver_nsteps == 1; LINABLE instantiations take the one-step map whenever it is valid for this wave
             auto run_advance = [&](const DevParams<R> &Q) {
                 if constexpr (TAB) {
-                    ST::template advance<true, LINABLE, true>(Q, y, ang, sw, act, dact, ho, tab);
+                    ST::template advance<true, LINABLE, true>(Q, y, ang, sw, act, dact, ho, tab, linc);
                 } else {
-                    if (LINABLE && (!FIFO || lin_ok)) ST::template advance<true, LINABLE>(Q, y, ang, sw, act, dact, ho);
+                    if (LINABLE && (!FIFO || lin_ok)) ST::template advance<true, LINABLE>(Q, y, ang, sw, act, dact, ho, nullptr, linc);
                     else ST::template advance<true, false>(Q, y, ang, sw, act, dact, ho);
                 }
             };
@@ -2054,7 +2094,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                 sup[0] = rs ? P.u_sup : sup[0];  // RCVoltageSupply.reset: the capacitor is loaded again, the supply's clock restarts
                 sup[1] = rs ? R(0) : sup[1];
             }
-            if constexpr (MODE == 2) since = rs ? 0u : (since < delay_u ? since + 1u : delay_u);
+            if constexpr (MODE == 2 || MODE == 3) since = rs ? 0u : (since < delay_u ? since + 1u : delay_u);
             if (FIFO && P.delay > 0) {  // DeadTimeProcessor.reset: the deque is refilled with the (zero) reset action
                 if (rs) {
                     for (int d = 0; d < P.delay; ++d) {
@@ -2210,6 +2250,37 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                         for (int i = 0; i < NACTC; ++i) c[i] = v[i];
                     }
                 }
+            } else if (CAN_DELAY && delayed_t) {
+                if constexpr (CAN_DELAY && conv_dq<CONV>()) {
+                    auto qrow = [&](int r) { return fifo + ((size_t)r * BLOCK + tid) * NACTC; };
+                    using Mode3 = std::integral_constant<int, 3>;
+                    read_action(b, 0, an, dn);
+                    if (sb == D) {
+#pragma unroll 4
+                        for (int s = 0; s < D; ++s) {
+#pragma unroll
+                            for (int i = 0; i < NACT; ++i) ac[i] = an[i];
+                            read_action(b, s + 1 < D ? s + 1 : s, an, dn);
+                            one_step(Mode3{}, ac, 0u, hb + (size_t)s * BLOCK * NHT, nullptr, qrow(s + P.delay), qrow(s + 1));
+                        }
+                    } else {
+#pragma nounroll
+                        for (int s = 0; s < sb; ++s) {
+#pragma unroll
+                            for (int i = 0; i < NACT; ++i) ac[i] = an[i];
+                            read_action(b, s + 1 < sb ? s + 1 : s, an, dn);
+                            one_step(Mode3{}, ac, 0u, hb + (size_t)s * BLOCK * NHT, nullptr, qrow(s + P.delay), qrow(s + 1));
+                        }
+                    }
+                    // rows sb .. sb + delay - 1 (the pending entries) move to the front; qpre / tprev already hold row sb
+                    for (int j = 0; j < P.delay; ++j) {
+                        R v[NACTC];
+#pragma unroll
+                        for (int i = 0; i < NACTC; ++i) v[i] = qrow(sb + j)[i];
+#pragma unroll
+                        for (int i = 0; i < NACTC; ++i) qrow(j)[i] = v[i];
+                    }
+                }
             } else {  // tail block or DeadTimeProcessor FIFO: ONE rolled copy of the run-time-checked step
                 // (the action of step s+1 is read from LDS before step s runs, as in the unrolled blocks)
                 read_action(b, 0, an, dn);
@@ -2258,7 +2329,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             // mod delay; entries submitted before the env's last reset are the refilled zero action
             int dst = d;
             bool keep = true;
-            if (delayed) {
+            if (delayed_any) {
                 dst = phase_end + d;
                 dst = dst >= P.delay ? dst - P.delay : dst;
                 keep = (uint32_t)d + since >= delay_u;
@@ -2554,7 +2625,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         // LDS footprint of one workgroup at hand-off depth D (steps per barrier): ring + done ring + double-buffered hand-off rows + ...
         auto smem_of = [&](int D) {
             size_t b = (size_t)D * BLOCK * h->nout * sizeof(R) + (size_t)D * BLOCK + 2 * (size_t)D * BLOCK * NHT * sizeof(R);
-            b += (size_t)delay * BLOCK * conv_nact_c<CONV>() * sizeof(R);  // DeadTimeProcessor FIFO
+            b += (size_t)pipe_queue_rows(D, delay, conv_dq<CONV>() && h->pf.dq_processor != 0, need_full) * BLOCK * conv_nact_c<CONV>() * sizeof(R);  // DeadTimeProcessor queue
             b += 2 * (size_t)((D + 3) / 4 * 4) * BLOCK * ABYTES;           // action staging (global -> LDS direct)
             if (h->cur_reward != nullptr) b += 3 * (size_t)D * BLOCK * h->rw_n_ref * sizeof(R);  // reference staging for the fused reward
             if (ST::NVT > 0 && ConvTraits<CONV>::DISCRETE) b += (size_t)ConvTraits<CONV>::NACTIONS * 8 * sizeof(R);  // per-action voltage table

@@ -890,6 +890,9 @@ def test_full_pipelined_variant_matches_single_wave_kernel(name, monkeypatch):
     ("Finite-CC-PMSM-v0", 3, dict(tau=1e-4)), ("Finite-CC-PMSM-v0", 8, dict(tau=1e-4)), ("Finite-CC-PMSM-v0", 1, dict(tau=1e-4)),
     ("Cont-CC-PermExDc-v0", 2, {}), ("Cont-SC-SCIM-v0", 1, dict(control_space="dq")), ("Finite-CC-DFIM-v0", 2, {}), ("Finite-CC-EESM-v0", 5, dict(tau=1e-4)),
     ("Finite-CC-ShuntDc-v0", 4, {}),
+    # behind a DqToAbcActionProcessor the queue holds TRANSFORMED actions: a row buffer indexed by the step of the block
+    ("Cont-CC-PMSM-v0", 1, dict(dqproc="PMSM")), ("Cont-CC-PMSM-v0", 2, dict(dqproc="PMSM", tau=1e-4)), ("Cont-CC-PMSM-v0", 8, dict(dqproc="PMSM")),
+    ("Cont-SC-PMSM-v0", 3, dict(dqproc="PMSM")), ("Cont-CC-SynRM-v0", 2, dict(dqproc="PMSM")), ("Cont-CC-EESM-v0", 2, dict(dqproc="EESM")),
 ])
 def test_delayed_read_deadtime_queue_matches_the_fifo_representation(env_id, delay, kw, monkeypatch):
     """DeadTimeProcessor in the pipelined kernel's deep shape: no queue, but the action row staged `delay` steps earlier, zeroed while
@@ -902,10 +905,14 @@ def test_delayed_read_deadtime_queue_matches_the_fifo_representation(env_id, del
 
     n, K = 256, 173
 
+    kw = dict(kw)
+    dqproc = kw.pop("dqproc", None)
+    wrappers = (ga.DeadTimeProcessor(steps=delay),) + ((ga.DqToAbcActionProcessor.make(dqproc),) if dqproc else ())
+
     def mk(pipe):
         monkeypatch.setenv("GEMX_PIPE", pipe)
         monkeypatch.setenv("GEMX_PIPE_SHAPE", "0")
-        return ga.make(env_id, n_envs=n, ode_solver=ga.RK4Solver(), physical_system_wrappers=(ga.DeadTimeProcessor(steps=delay),), **kw)
+        return ga.make(env_id, n_envs=n, ode_solver=ga.RK4Solver(), physical_system_wrappers=wrappers, **kw)
 
     env = mk("1")
     ps = env.physical_system
@@ -917,8 +924,8 @@ def test_delayed_read_deadtime_queue_matches_the_fifo_representation(env_id, del
         acts = torch.rand((K + 40, n, ps._n_act), device="cuda", generator=g) * 2 - 1
     obs, done = env.rollout(acts[:K])
     assert "advance_pipe_kernel" in ps.last_launch()
-    if "DFIM" not in env_id:  # (the DFIM's hand-off rows do not fit the deep shape: it keeps the FIFO representation, compared all the same)
-        assert "D=12" in ps.last_launch()
+    if "DFIM" not in env_id and "EESM-v0" not in env_id:  # (their hand-off rows do not fit the deep shape: they keep the FIFO
+        assert "D=12" in ps.last_launch()                   # representation, compared all the same)
     obs_c, done_c = env.rollout(acts[K:])  # continuation from the ring the launch left behind
     ref = mk("0")
     robs, rdone = ref.rollout(acts[:K])
