@@ -28,7 +28,7 @@ Extra objects in the JSON line (rank 0):
                       HBM bytes per launch of this exact (workload, envs, steps_per_launch) from profiles/hbm_traffic.json.
   cpu_baseline        oracle/gemx_oracle.c (scalar fp64 restatement, "port") timed on ONE host core on a bounded sample of the same
                       workload (`all_cores`: the same port on up to 32 host cores), plus the REFERENCE's own Python path as
-                      recorded by tools/cpu_reference_bench.py (fields, not prose).
+                      recorded by oracle/cpu_reference_bench.py (fields, not prose).
   headline_no_linmap  the same launches with GEMX_LINMAP=0 (RK4 evaluated stage by stage instead of through the one-step affine map).
   single_step / single_step_graph   one launch per control step (closed-loop RL usage), eager and replayed from a HIP graph.
   configs             BASELINE configs 2 and 4 (PermExDc 4096 envs Euler; SCIM 65536 envs RK4; the latter also with split_kinks) through
@@ -189,7 +189,7 @@ def measure_single_step(torch, env, n_local, K, W, device, seed, graph_steps=0):
 
 def cpu_baseline(w, budget_s=12.0):
     """The oracle (scalar fp64 C restatement of the reference algorithm) on ONE host core, bounded sample; beside it the reference's
-    own Python path as tools/cpu_reference_bench.py recorded it in the build container (profiles/cpu_reference.json)."""
+    own Python path as oracle/cpu_reference_bench.py recorded it in the build container (profiles/cpu_reference.json)."""
     import numpy as np
 
     from oracle import oracle as orc
@@ -241,7 +241,7 @@ def cpu_baseline(w, budget_s=12.0):
     if os.path.exists(ref_path):
         try:
             ref = json.load(open(ref_path))
-            out["reference"] = {"source": "profiles/cpu_reference.json (tools/cpu_reference_bench.py: the reference's own Python path, "
+            out["reference"] = {"source": "profiles/cpu_reference.json (oracle/cpu_reference_bench.py: the reference's own Python path, "
                                           "timed in the build container, which has /root/reference; the GPU box has not)",
                                 "host": ref.get("host"), "env_steps_per_s": ref.get("results", {}).get(w["env_id"])}
         except Exception as e:  # a malformed record must not kill the bench line

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times the REFERENCE's own CPU path (gym-electric-motor 3.0.2, unmodified, imported from /root/reference) on this box's host cores.
 
-    MPLBACKEND=Agg python tools/cpu_reference_bench.py [--steps 10000] [--out profiles/cpu_reference.json]
+    MPLBACKEND=Agg python oracle/cpu_reference_bench.py [--steps 10000] [--out profiles/cpu_reference.json]
 
 BASELINE.json configs[0] / SURVEY.md 8(d) "CPU baseline beside it": for each of the three configured env ids and each solver
 {reference default scipy dopri5, EulerSolver, ScipySolveIvpSolver() (solve_ivp RK45, solvers.py:187-219)}

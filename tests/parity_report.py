@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Observed worst parity error per BASELINE config (GPU fp32 through the C ABI vs the reference's recorded trajectories).
 
-    python tools/parity_report.py [--all] > profiles/<round>_parity.md        (on the GPU box)
+    python tests/parity_report.py [--all] > profiles/<round>_parity.md        (on the GPU box)
 
 For every golden fixture of the three BASELINE envs (Cont-CC-PermExDc-v0, Finite-CC-PMSM-v0, Cont-SC-SCIM-v0): the fixture's own
 solver where the device has it (Euler), and every device solver against the reference's DEFAULT solver (scipy dopri5) fixtures.
@@ -18,7 +18,7 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-sys.path.insert(0, os.path.join(REPO, "tests"))
+sys.path.insert(0, os.path.join(REPO, "tests"))  # (this file lives in tests/: it is test infrastructure, like the oracle it uses)
 
 
 def main():
