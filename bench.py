@@ -31,8 +31,8 @@ Extra objects in the JSON line (rank 0):
                       recorded by oracle/cpu_reference_bench.py (fields, not prose).
   headline_no_linmap  the same launches with GEMX_LINMAP=0 (RK4 evaluated stage by stage instead of through the one-step affine map).
   single_step / single_step_graph   one launch per control step (closed-loop RL usage), eager and replayed from a HIP graph.
-  configs             BASELINE configs 2 and 4 (PermExDc 4096 envs Euler; SCIM 65536 envs RK4; the latter also with split_kinks) through
-                      the same measurement.
+  configs             BASELINE configs 2 and 4 (PermExDc 4096 envs Euler; SCIM 65536 envs RK4 with the env's PolynomialStaticLoad -- also
+                      with split_kinks -- and with the ConstantSpeedLoad BASELINE.json names) through the same measurement.
   at_scale            the headline kernel with the chip full (1M envs).
 """
 import argparse
@@ -57,6 +57,10 @@ WORKLOADS = {
                      desc="Cont-CC-PermExDc-v0 (Cont-4QC), Euler, fp32, tau=1e-4, default constraint + auto-reset"),
     "scim": dict(env_id="Cont-SC-SCIM-v0", envs=65536, solver="rk4", tau=1e-4, a_bytes=12, s_ode=6, s_out=14,
                  desc="Cont-SC-SCIM-v0 (Cont-B6C, PolynomialStaticLoad), RK4, fp32, tau=1e-4, default constraint + auto-reset"),
+    # BASELINE.json configs[3] as written: "5-state induction motor + ConstantSpeedLoad" (the env id's own default load is the
+    # PolynomialStaticLoad of the "scim" workload above; SURVEY.md 8(d) C4 names both)
+    "scim_constspeed": dict(env_id="Cont-SC-SCIM-v0", envs=65536, solver="rk4", tau=1e-4, a_bytes=12, s_ode=6, s_out=14, const_speed=100.0,
+                            desc="Cont-SC-SCIM-v0 (Cont-B6C) with ConstantSpeedLoad(omega_fixed=100), RK4, fp32, tau=1e-4, default constraint + auto-reset"),
 }
 
 
@@ -72,7 +76,10 @@ def bytes_per_env_step_single(w):
 
 def make_env(ga, w, n_envs, device, split_kinks=False):
     sol = ga.EulerSolver() if w["solver"] == "euler" else ga.RK4Solver(split_kinks=split_kinks)
-    return ga.make(w["env_id"], n_envs=n_envs, device=device, ode_solver=sol, tau=w["tau"])
+    kw = {}
+    if w.get("const_speed") is not None:
+        kw["load"] = ga.ConstantSpeedLoad(omega_fixed=w["const_speed"])
+    return ga.make(w["env_id"], n_envs=n_envs, device=device, ode_solver=sol, tau=w["tau"], **kw)
 
 
 def make_actions(torch, ps, K, n, device, seed):
@@ -382,7 +389,7 @@ def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out):
     env1.close()
     # BASELINE configs 2 and 4 through the same measurement
     out["configs"] = {}
-    for key in ("permexdc", "scim"):
+    for key in ("permexdc", "scim", "scim_constspeed"):
         if key == args.workload:
             continue
         wc = dict(WORKLOADS[key], key=key)

@@ -300,7 +300,8 @@ def test_bench_configuration_episodic_rk4_against_reference_default_solver(mode,
 @pytest.mark.parametrize("env_id, n_envs, solver", [
     ("Cont-CC-PermExDc-v0", 4096, "euler"),   # BASELINE config 2
     ("Finite-CC-PMSM-v0", 16384, "rk4"),      # BASELINE config 3 (the bench headline: one-step map + voltage table + <12, 3> shape)
-    ("Cont-SC-SCIM-v0", 65536, "rk4"),        # BASELINE config 4
+    ("Cont-SC-SCIM-v0", 65536, "rk4"),        # BASELINE config 4 with the env's own PolynomialStaticLoad
+    ("Cont-SC-SCIM-v0:constspeed", 65536, "rk4"),  # BASELINE config 4 as BASELINE.json words it: + ConstantSpeedLoad (one-step map)
 ])
 def test_full_size_configs_against_oracle(env_id, n_envs, solver):
     """BASELINE.json sizes exactly as bench.py runs them: default constraints + in-kernel auto-reset, tau = 1e-4, per-env random
@@ -315,7 +316,14 @@ def test_full_size_configs_against_oracle(env_id, n_envs, solver):
 
     K = 1000
     sol = ga.EulerSolver() if solver == "euler" else ga.RK4Solver()
-    env = ga.make(env_id, n_envs=n_envs, ode_solver=sol, tau=1e-4)
+    env_id, _, variant = env_id.partition(":")
+    golden = {"Cont-CC-PermExDc-v0": "permexdc_epi_held_euler", "Finite-CC-PMSM-v0": "pmsm_epi_held_tau1e-4_euler",
+              "Cont-SC-SCIM-v0": "scim_epi_uniform_euler"}[env_id]
+    if variant == "constspeed":
+        golden = "scim_constspeed_free_held_euler"
+    _, meta = _load(golden)
+    mkw = dict(load=ga.ConstantSpeedLoad(omega_fixed=meta["omega_fixed"])) if variant == "constspeed" else {}
+    env = ga.make(env_id, n_envs=n_envs, ode_solver=sol, tau=1e-4, **mkw)
     ps = env.physical_system
     g = torch.Generator(device="cuda").manual_seed(1234)
     if ps._discrete:
@@ -327,14 +335,11 @@ def test_full_size_configs_against_oracle(env_id, n_envs, solver):
     assert "advance_pipe_kernel" in ps.last_launch()  # the kernel the bench measures
     assert torch.isfinite(obs).all()
     # single-step path must give the same bits as the fused path (incl. the auto-reset)
-    env2 = ga.make(env_id, n_envs=n_envs, ode_solver=sol, tau=1e-4)
+    env2 = ga.make(env_id, n_envs=n_envs, ode_solver=sol, tau=1e-4, **mkw)
     for k in range(40):
         o = env2.physical_system.simulate(acts[k])
         assert torch.equal(o, obs[k]) and torch.equal(env2.physical_system.done, done[k])
     env2.close()
-    golden = {"Cont-CC-PermExDc-v0": "permexdc_epi_held_euler", "Finite-CC-PMSM-v0": "pmsm_epi_held_tau1e-4_euler",
-              "Cont-SC-SCIM-v0": "scim_epi_uniform_euler"}[env_id]
-    _, meta = _load(golden)
     meta = dict(meta, tau=1e-4)
     p = orc.params_from_meta(meta, solver=solver, episodic=True)
     names = meta["state_names"]

@@ -11,7 +11,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/${TAG}_bench.log 2>&1
 tail -1 $OUT/${TAG}_bench.log > $OUT/${TAG}_bench.json
-for WL in pmsm permexdc scim; do
+for WL in pmsm permexdc scim scim_constspeed; do
   rm -rf /tmp/ks_$WL
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$WL -- python $R/bench.py --no-extras --workload $WL > /tmp/ks_$WL.log 2>&1
   grep "^{\"metric\"" /tmp/ks_$WL.log | tail -1 > $OUT/${TAG}_bench_under_rocprof_$WL.json
@@ -23,7 +23,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_short -- python 
 grep "^{\"metric\"" /tmp/ks_short.log | tail -1 > $OUT/${TAG}_bench_under_rocprof_short20.json
 cp $(find /tmp/ks_short -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats_short20.csv
 [ "$QUICK" = "quick" ] && exit 0
-for WL in pmsm permexdc scim; do
+for WL in pmsm permexdc scim scim_constspeed; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_$c
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --no-extras --workload $WL --steps 5 --warmup 2 > /tmp/pmc_$c.log 2>&1

@@ -14,7 +14,7 @@ import re
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ENVS = {"pmsm": 16384, "permexdc": 4096, "scim": 65536}
+ENVS = {"pmsm": 16384, "permexdc": 4096, "scim": 65536, "scim_constspeed": 65536}
 
 
 def main():
