@@ -73,6 +73,23 @@ def main():
           "oracle/gemx_oracle.c:ivp_rk45) is itself this far from the reference's own default solver, so it pins the ORACLE (to 1e-10, "
           "tests/test_oracle_golden.py), not the device; the 1e-4 contract is held against dopri5 and against solve_ivp at tight tolerances:")
     print("\n".join(notes))
+    # BASELINE sizes exactly as bench.py launches them: the full-size parity test's own summary lines
+    import contextlib
+    import io
+
+    print()
+    print("## BASELINE sizes as bench.py launches them (tests/test_gpu_parity.py::test_full_size_configs_against_oracle)")
+    print()
+    print("Default constraints + in-kernel auto-reset, tau 1e-4, per-env random actions, 1000 control steps in ONE fused launch, GPU fp32 vs the fp64 "
+          "oracle with the SAME integrator on 62-64 sampled envs (trajectories episode by episode, done masks exact), all envs checked for finiteness "
+          "and termination rate, step-by-step simulate() == fused rollout bit for bit:")
+    print()
+    for env_id, n, solver in (("Cont-CC-PermExDc-v0", 4096, "euler"), ("Finite-CC-PMSM-v0", 16384, "rk4"), ("Cont-SC-SCIM-v0", 65536, "rk4"),
+                              ("Cont-SC-SCIM-v0:constspeed", 65536, "rk4")):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            T.test_full_size_configs_against_oracle(env_id, n, solver)
+        print("* " + (env_id.split(":")[1] + ": " if ":" in env_id else "") + buf.getvalue().strip())
 
 
 if __name__ == "__main__":
