@@ -476,6 +476,19 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
     static constexpr int NVT = 0;                                // no per-action voltage table (see the synchronous machines)
     static constexpr int row_slot(int j) { return j; }           // hand-off row of the pipelined kernel: logical index -> LDS slot
     static constexpr bool CONT = CONV == GEMX_CONV_CONT_4QC || CONV == GEMX_CONV_CONT_2X4QC;
+    // leg states a finite converter WITHOUT dead time is left in by the action `dact` (what the IL code stores in `sw`): needed by the
+    // RC supply's i_sup of the next step when the dead-time-free instantiation serves the handle
+    static __device__ __forceinline__ uint32_t legs_of(uint32_t dact) {
+        uint32_t legs = 0;
+        if (!CONT) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                const uint32_t aj = (dact >> (2 * j)) & 3u;
+                legs |= (((aj & 2u) ? 2u : 1u) | (((aj & 1u) ? 2u : 1u) << 2)) << (4 * j);
+            }
+        }
+        return legs;
+    }
     static_assert((CONV == GEMX_CONV_CONT_2X4QC || CONV == GEMX_CONV_FINITE_2X4QC) == (NU == 2), "system / converter width mismatch");
     // i_in = motor.i_in(currents): the current (dc_permanently_excited_motor.py:77-79, dc_series_motor.py:85-87),
     // i_a + i_e for the shunt motor (dc_shunt_motor.py:68-70), [i_a, i_e] for the externally excited motor
@@ -576,6 +589,7 @@ struct Stepper<GEMX_SYS_DC_EXTEX, CONV, LOAD, SOLVER, IL, R> : DcStepper<GEMX_SY
 template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_SYNC, CONV, LOAD, SOLVER, IL, R> {
     using AngT = typename Angle<R>::T;
     static constexpr int NH = 7;  // ho: sin, cos of the last segment-start angle, u_a, u_b, u_c, u_sd, u_sq
+    static __device__ __forceinline__ uint32_t legs_of(uint32_t dact) { return CONV == GEMX_CONV_FINITE_B6 ? b6_subactions(dact) : 0u; }
     // Finite-B6C without dead time and with an ideal supply: the bridge's output is a function of the action index alone, so the
     // pipelined kernel keeps it in an 8-entry LDS table (u_a, u_b, u_c, u_alpha, u_beta per switching state), computed ONCE per launch
     // with the very code below, instead of decoding the action and Clarke-transforming it in every step.
@@ -672,6 +686,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
 template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_EESM, CONV, LOAD, SOLVER, IL, R> {
     using AngT = typename Angle<R>::T;
     static constexpr int NH = 8;  // ho: sin, cos of the step-start angle, u_a, u_b, u_c, u_sd, u_sq, u_e
+    static __device__ __forceinline__ uint32_t legs_of(uint32_t) { return 0u; }  // (no RC supply behind the finite EESM converter: gemx_create)
     static constexpr int B6 = CONV == GEMX_CONV_CONT_B6_4QC ? GEMX_CONV_CONT_B6 : GEMX_CONV_FINITE_B6;
     // converter output of a flat action index: u_a, u_b, u_c, u_e (the multi-converter has no dead time here)
     static __device__ __forceinline__ void voltages(const DevParams<R> &P, const R (&act)[MAX_ACT], uint32_t dact, R &ua, R &ub, R &uc, R &ue) {
@@ -749,6 +764,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
 template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_SCIM, CONV, LOAD, SOLVER, IL, R> {
     using AngT = typename Angle<R>::T;
     static constexpr int NH = 7;  // ho: sin, cos of the last segment-start field angle, u_a, u_b, u_c, u_alpha, u_beta
+    static __device__ __forceinline__ uint32_t legs_of(uint32_t dact) { return CONV == GEMX_CONV_FINITE_B6 ? b6_subactions(dact) : 0u; }
     // per-action voltage table of the pipelined kernel, as for the synchronous machines (Stepper<GEMX_SYS_SYNC>::action_entry)
     static constexpr int NVT = (CONV == GEMX_CONV_FINITE_B6 && !IL) ? 5 : 0;
     static constexpr int row_slot(int j) { return j; }
@@ -833,6 +849,9 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     // ho: sin, cos of the last segment-start field angle; sin, cos of the last segment-start electrical angle;
     //     u_sa, u_sb, u_sc; u_rd, u_re, u_rf (rotor-fixed three-phase frame)
     static constexpr int NH = 10;
+    static __device__ __forceinline__ uint32_t legs_of(uint32_t dact) {
+        return CONV == GEMX_CONV_FINITE_2XB6 ? (b6_subactions(dact & 7u) | (b6_subactions((dact >> 3) & 7u) << 6)) : 0u;
+    }
     static constexpr int NVT = 0;
     static constexpr int row_slot(int j) { return j; }
     static constexpr int B6 = CONV == GEMX_CONV_CONT_2XB6 ? GEMX_CONV_CONT_B6 : GEMX_CONV_FINITE_B6;
@@ -1429,6 +1448,7 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
         }
         if (linable<LOAD, SOLVER, IL, R>() && lin_ok) full_step<ST, ND, NOUT, R, linable<LOAD, SOLVER, IL, R>()>(PL, y, ang, sw, act, dact, obs, linc);
         else full_step<ST, ND, NOUT, R, false>(PL, y, ang, sw, act, dact, obs);
+        if (!IL && conv_has_legs<CONV>() && P.rc_supply) sw = ST::legs_of(dact);  // (the IL code keeps `sw` itself)
         const bool done = constraint_done<ST, NOUT, R>(P, obs);
         done_or |= done ? 1u : 0u;
         pdone = done;
@@ -1511,7 +1531,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SYS == GE
     AngT ang = AngT(0);
     if (SysTraits<SYS>::HAS_ANGLE) ang = a.angle[e];
     uint32_t sw = 0;
-    constexpr bool USE_SW = conv_has_legs<CONV>() && IL;
+    const bool USE_SW = conv_has_legs<CONV>() && (IL || P.rc_supply);  // leg states: dead time, or the RC supply's i_sup
     if (USE_SW) {
         sw = a.sw[e];
         if (conv_sw_bytes<CONV>() == 2) sw |= (uint32_t)a.sw[N + e] << 8;
@@ -1668,10 +1688,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs<R> a) {
     constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
     constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
     constexpr int NACTC = conv_nact_c<CONV>();
-    constexpr bool USE_SW = conv_has_legs<CONV>() && IL;
     using AngT = typename Angle<R>::T;
     using ST = Stepper<SYS, conv_base<CONV>(), LOAD, SOLVER, IL, R>;
     const DevParams<R> &P = a.P;
+    const bool USE_SW = conv_has_legs<CONV>() && (IL || P.rc_supply);
     const int64_t N = a.N;
     const int64_t env = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool valid = env < N;
@@ -1741,6 +1761,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs<R> a) {
     R obs[NOUT];
     if (linable<LOAD, SOLVER, IL, R>() && lin_ok) full_step<ST, ND, NOUT, R, linable<LOAD, SOLVER, IL, R>()>(PL, y, ang, sw, act, dact, obs);
     else full_step<ST, ND, NOUT, R, false>(PL, y, ang, sw, act, dact, obs);
+    if (!IL && conv_has_legs<CONV>() && P.rc_supply) sw = ST::legs_of(dact);
     const bool done = constraint_done<ST, NOUT, R>(P, obs);
     if (done && P.auto_reset) {  // `if terminated: env.reset()`; switching state survives (converters.py:45-54)
 #pragma unroll
@@ -1858,7 +1879,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
     R *refb = reinterpret_cast<R *>(actb + ACTB_BYTES);
     const int n_ref = a.rw != nullptr ? a.rh.n_ref : 0;
     // per-action voltage table [NACTIONS][8] R of steppers that have one (ST::NVT > 0), read by the integrator wave only
-    constexpr bool USE_TAB = ST::NVT > 0 && DISCRETE;
+    constexpr bool USE_TAB = ST::NVT > 0 && DISCRETE && !FULL;  // (FULL: the supply voltage may differ per lane; the table is built from the uniform one)
     R *vtab = refb + 3 * (size_t)D * BLOCK * n_ref;
     auto steps_of = [&](int b) { return (K - b * D) < D ? (K - b * D) : D; };
 
@@ -1915,7 +1936,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
         AngT ang = AngT(0);
         if (HAS_ANGLE) ang = a.angle[env];
         uint32_t sw = 0;
-        constexpr bool USE_SW = conv_has_legs<CONV>() && IL;
+        const bool USE_SW = conv_has_legs<CONV>() && (IL || (FULL && P.rc_supply));
         if (USE_SW) {
             sw = a.sw[env];
             if (conv_sw_bytes<CONV>() == 2) sw |= (uint32_t)a.sw[N + env] << 8;
@@ -2067,6 +2088,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                 }
                 usup_lane = PL.u_sup;
                 run_advance(PL);
+                if (!IL && conv_has_legs<CONV>() && P.rc_supply) sw = ST::legs_of(dact);
             } else {
                 run_advance(P);
             }
@@ -2657,10 +2679,12 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             if (smem_of(fd[h->pipe_shape]) <= h->lds_max) { shape = h->pipe_shape; D = fd[shape]; OW = fo[shape]; }
         }
         if (need_full) {  // one instantiation serves these handles
-            // ~180 VGPRs = two resident workgroups per CU: ahead of the single-wave kernel while the batch is a few resident rounds
-            // (PMSM + RC supply, same box: 33.9 vs 14.0 G env-steps/s at 16384 envs, 59.6 vs 26.2 at 32768, 61.6 vs 47.2 at 65536), behind
-            // it beyond (63.8 vs 70.1 at 131072; random initialisers: 28 vs 16 / 28 vs 30 / 28 vs 43) -- tools/ab_full_variant.py
-            if (smem_of(PIPE_D2) <= h->lds_max && blocks <= 4 * (int64_t)h->n_cu) { D = PIPE_D2; OW = PIPE_OUT_WAVES2; shape = 4; }
+            // ~180 VGPRs = two resident workgroups per CU.  RC supply: ahead of the single-wave kernel at every size (PMSM finite, same box:
+            // 52 vs 14 G env-steps/s at 16384 envs, 89 vs 26 at 32768, 89 vs 47 at 65536).  Random initialisers (the fp64 draw sits in the
+            // integrator's reset path): ahead up to 32768 envs (28 vs 16), level at 65536, behind beyond (28 vs 43 at 131072) --
+            // tools/ab_full_variant.py
+            const bool fits_n = h->cfg.init_kind == GEMX_INIT_CONST || blocks <= 4 * (int64_t)h->n_cu;
+            if (smem_of(PIPE_D2) <= h->lds_max && fits_n) { D = PIPE_D2; OW = PIPE_OUT_WAVES2; shape = 4; }
             else D = 0;
         }
         if (D != 0) {
@@ -2703,8 +2727,9 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
 // IL = false only exists for fp32 (the product path); the fp64 diagnostic build always takes the general code.
 template <int SYS, int CONV, class R>
 int launch_advance_unit(gemx_handle *h, const void *actions, int K, void *obs, uint8_t *done, int obs_every, hipStream_t st) {
-    // finite converters behind an RC supply need the leg states of the previous step (i_sup): the IL code keeps them
-    const bool il = sizeof(R) == 8 || h->cfg.interlocking_time > 0.0 || (h->cfg.supply_kind == GEMX_SUPPLY_RC && ConvTraits<CONV>::DISCRETE);
+    // (finite converters behind an RC supply need the leg states of the previous step for i_sup: the dead-time-free instantiation
+    // keeps them too, from Stepper::legs_of -- so an RC supply no longer forces the slower IL code)
+    const bool il = sizeof(R) == 8 || h->cfg.interlocking_time > 0.0;
     const int ld = h->cfg.load_kind, sv = h->cfg.solver_kind;
 #define GEMX_CASE(LD, SV)                                                                                                  \
     if (ld == LD && sv == SV) {                                                                                            \

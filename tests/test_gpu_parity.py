@@ -778,8 +778,8 @@ def test_single_env_random_initialiser_reset_returns_the_drawn_state():
     env.close()
 
 
-@pytest.mark.parametrize("case", ["pmsm_fin_til", "permexdc_rc", "dfim_fin_til", "scim_dq", "pmsm_dead3", "pmsm_dqproc_dead2", "pmsm_random_init",
-                                  "extex_fin_soa", "eesm_f64"])
+@pytest.mark.parametrize("case", ["pmsm_fin_til", "permexdc_rc", "pmsm_fin_rc", "dfim_fin_rc", "dfim_fin_til", "scim_dq", "pmsm_dead3", "pmsm_dqproc_dead2",
+                                  "pmsm_random_init", "extex_fin_soa", "eesm_f64"])
 def test_step_kernel_is_bit_identical_to_the_rollout_kernels(case, monkeypatch):
     """gemx_step launches step_kernel (one batch of loads, no LDS, rows stored from registers); GEMX_STEP_KERNEL=0 sends the same call
     through advance_kernel.  Same observations, done masks and final ODE / switching state, bit for bit, on a batch with a tail
@@ -795,6 +795,10 @@ def test_step_kernel_is_bit_identical_to_the_rollout_kernels(case, monkeypatch):
         kw = dict(converter=dict(interlocking_time=1e-6))
     elif case == "permexdc_rc":
         env_id, kw = "Cont-CC-PermExDc-v0", dict(supply=ga.RCVoltageSupply(u_nominal=60.0, supply_parameter=dict(R=0.05, C=4e-3)))
+    elif case == "pmsm_fin_rc":  # finite converter behind an RC supply: leg states tracked by the dead-time-free code (Stepper::legs_of)
+        kw = dict(supply=ga.RCVoltageSupply(u_nominal=420.0, supply_parameter=dict(R=0.5, C=2e-3)), tau=1e-4)
+    elif case == "dfim_fin_rc":  # two bytes of leg state
+        env_id, kw = "Finite-CC-DFIM-v0", dict(supply=ga.RCVoltageSupply(u_nominal=420.0, supply_parameter=dict(R=2.0, C=4e-3)))
     elif case == "dfim_fin_til":
         env_id = "Finite-CC-DFIM-v0"
         kw = dict(converter=ga.FiniteMultiConverter(subconverters=[ga.FiniteB6BridgeConverter(interlocking_time=1e-6), ga.FiniteB6BridgeConverter(interlocking_time=1e-6)]))
@@ -834,7 +838,7 @@ def test_step_kernel_is_bit_identical_to_the_rollout_kernels(case, monkeypatch):
     a, b = run("1"), run("0")
     for x, y in zip(a, b):
         assert torch.equal(x, y)
-    if case in ("permexdc_rc", "pmsm_dead3", "pmsm_random_init"):
+    if case in ("permexdc_rc", "pmsm_fin_rc", "pmsm_dead3", "pmsm_random_init"):
         assert a[1].any()  # these terminate and auto-reset within the 48 steps: the reset path of both kernels is compared too
 
 
