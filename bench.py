@@ -17,6 +17,12 @@ random discrete actions resident in HBM (synthetic).  tau = 1e-4 as the metric l
 arithmetic, hence the throughput, does not depend on tau).
 
 Timed region: exactly K launches bracketed by barrier + torch.cuda.synchronize() on both sides; wall time = max over ranks.
+Clock settling: an MI355X coming out of idle runs the first ~20 ms of a load below its sustained clock (measured per launch, headline
+kernel, `tools/clock_settle_probe.py` -> profiles/r02g_clock_settle.md: 170 us for the first ten launches, 195-205 us for the next
+twenty, 153 us from the ~100th launch on; an idle gap of >= 10 ms starts this over) -- and `--warmup 5 --steps 20` is 5 ms of work.
+Every leg therefore runs `--settle-ms` (default 60) of the SAME launches untimed before its W warm-up launches, so that `value` is the
+sustained rate a training run sees; the figure for the same W / K straight from an idle GPU is reported beside it as `cold_start`
+(`--settle-ms 0` makes it the headline again).
 Multi-GPU: envs are independent -> each rank steps its own shard, no data-path collective ("scaling": "weak").  Without WORLD_SIZE in
 the environment `--gpus N` (N > 1) spawns its own N ranks (torch.multiprocessing, one per GPU, RCCL on 127.0.0.1).
 `--gather chunk|step` additionally times the batched-return path: one RCCL all-gather of each launch's [K, n_local, S_out]
@@ -96,8 +102,9 @@ class Timed:
         self.wall, self.launch_ms = wall, launch_ms
 
 
-def measure(torch, dist, env, n_local, steps, warmup, spl, device, world, seed, gather="off", gd=None):
-    """`warmup` untimed + `steps` timed launches of `spl` control steps each.  gather: off | chunk | step (see module docstring)."""
+def measure(torch, dist, env, n_local, steps, warmup, spl, device, world, seed, gather="off", gd=None, settle_ms=0.0):
+    """`warmup` untimed + `steps` timed launches of `spl` control steps each, after `settle_ms` of the same launches (clock governor, see
+    module docstring).  gather: off | chunk | step."""
     ps = env.physical_system
     n_act_bufs = max(1, min(4, steps))
     acts = make_actions(torch, ps, spl * n_act_bufs, n_local, device, seed)
@@ -116,6 +123,14 @@ def measure(torch, dist, env, n_local, steps, warmup, spl, device, world, seed, 
             if gather == "chunk":
                 gd.gather_rollout(obs, done)
 
+    if settle_ms > 0:
+        t_end, i = time.perf_counter() + settle_ms * 1e-3, 0
+        while time.perf_counter() < t_end:
+            for _ in range(4):  # (plain launches: a wall-clock-bounded loop must not contain collectives)
+                a0 = (i % n_act_bufs) * spl
+                env.rollout(acts[a0 : a0 + spl], obs_out=obs, done_out=done)
+                i += 1
+            torch.cuda.synchronize()
     for i in range(warmup):
         launch(i)
     torch.cuda.synchronize()
@@ -145,13 +160,18 @@ def measure(torch, dist, env, n_local, steps, warmup, spl, device, world, seed, 
     return Timed(dt, e0.elapsed_time(e1) / steps)
 
 
-def measure_single_step(torch, env, n_local, K, W, device, seed, graph_steps=0):
+def measure_single_step(torch, env, n_local, K, W, device, seed, graph_steps=0, settle_ms=0.0):
     """One gemx_step launch per control step.  graph_steps > 0: `graph_steps` launches captured into ONE HIP graph and replayed."""
     ps = env.physical_system
     Ka = 256
     acts_all = make_actions(torch, ps, Ka, n_local, device, seed)
     acts = [acts_all[k] for k in range(Ka)]  # views made once: indexing a tensor costs ~2 us of host time per call
     env.reset()
+    t_end = time.perf_counter() + settle_ms * 1e-3
+    while time.perf_counter() < t_end:
+        for k in range(256):
+            ps.simulate(acts[k])
+        torch.cuda.synchronize()
     for k in range(W):
         ps.simulate(acts[k % Ka])
     torch.cuda.synchronize()
@@ -173,6 +193,11 @@ def measure_single_step(torch, env, n_local, K, W, device, seed, graph_steps=0):
         reps = max(1, K // S)
         graph.replay()
         torch.cuda.synchronize()
+        t_end = time.perf_counter() + settle_ms * 1e-3
+        while time.perf_counter() < t_end:
+            for _ in range(16):
+                graph.replay()
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         e0.record()
         for _ in range(reps):
@@ -297,13 +322,15 @@ def worker(args, rank, world, local_rank, backend):
     n_total = n_local * world
     K, W, spl = args.steps, args.warmup, args.steps_per_launch
 
+    S = args.settle_ms
     env = make_env(ga, w, n_local, dev_index)
-    t = measure(torch, dist, env, n_local, K, W, spl, device, world, seed=1234 + rank)
+    t_cold = measure(torch, dist, env, n_local, K, W, spl, device, world, seed=1234 + rank) if S > 0 else None  # straight from idle
+    t = measure(torch, dist, env, n_local, K, W, spl, device, world, seed=1234 + rank, settle_ms=S)
     kernel_desc = env.physical_system.last_launch()
     same_shard = None
     if n_local != w["envs"] and args.envs_per_gpu is None:  # --gpus 8 default = BASELINE config 5 (8 x 32768): also the N=1 shard size
         env_s = make_env(ga, w, w["envs"], dev_index)
-        ts = measure(torch, dist, env_s, w["envs"], K, W, spl, device, world, seed=1234 + rank)
+        ts = measure(torch, dist, env_s, w["envs"], K, W, spl, device, world, seed=1234 + rank, settle_ms=S)
         env_s.close()
         same_shard = {"envs_per_gpu": w["envs"], "value": w["envs"] * world * spl * K / ts.wall, "unit": "env-steps/s",
                       "ms_per_step": ts.wall / K * 1e3, "note": "same per-GPU shard as the --gpus 1/2/4 lines (strict weak scaling)"}
@@ -316,7 +343,7 @@ def worker(args, rank, world, local_rank, backend):
         for mode in modes:
             Kg = K if mode == "chunk" else max(1, min(K, 2))
             spl_g = spl if mode == "chunk" else min(spl, 200)
-            tg = measure(torch, dist, env, n_local, Kg, min(W, 2), spl_g, device, world, seed=4321 + rank, gather=mode, gd=gd)
+            tg = measure(torch, dist, env, n_local, Kg, min(W, 2), spl_g, device, world, seed=4321 + rank, gather=mode, gd=gd, settle_ms=S)
             per_call = n_local * (spl_g if mode == "chunk" else 1) * (4 * w["s_out"] + 1)
             gathered[mode] = {"value": n_total * spl_g * Kg / tg.wall, "unit": "env-steps/s", "steps": Kg, "steps_per_launch": spl_g,
                               "ms_per_step": tg.wall / Kg * 1e3, "bytes_gathered_per_rank_per_call": per_call * world,
@@ -340,11 +367,16 @@ def worker(args, rank, world, local_rank, backend):
             "config": {"workload": f"{w['desc']}; {n_local} envs/GPU x {world} GPU(s); one bench step = one fused launch of {spl} control "
                                    "steps, obs [K,N,S_out] rows + done bytes written for every control step",
                        "env_id": w["env_id"], "envs_per_gpu": n_local, "solver": w["solver"], "tau": w["tau"],
-                       "steps_per_launch": spl, "control_steps_timed": spl * K,
+                       "steps_per_launch": spl, "control_steps_timed": spl * K, "clock_settle_ms": S,
                        "parallelism": f"env-sharded x{world}, no data-path collective", "world_size": world,
                        "backend": (backend if world > 1 else None), "oversubscribed": bool(args.oversubscribe and world > ndev)},
             "roofline": roofline_of(w, n_local, spl, t.launch_ms, kernel_desc, args.workload),
         }
+        if t_cold is not None:
+            rcold = roofline_of(w, n_local, spl, t_cold.launch_ms, kernel_desc, args.workload)
+            out["cold_start"] = {"value": n_total * spl * K / t_cold.wall, "unit": "env-steps/s", "ms_per_step": t_cold.wall / K * 1e3,
+                                 "roofline_frac": rcold["frac"],
+                                 "note": f"the same {W} + {K} launches straight from an idle GPU, no clock settling (module docstring)"}
         if gathered is not None:
             out["gather"] = gathered
         if same_shard is not None:
@@ -367,7 +399,7 @@ def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out):
     os.environ["GEMX_LINMAP"] = "0"
     try:
         env0 = make_env(ga, w, n_local, dev_index)
-        t0 = measure(torch, dist, env0, n_local, min(args.steps, 10), 2, spl, device, 1, seed=77)
+        t0 = measure(torch, dist, env0, n_local, min(args.steps, 10), 2, spl, device, 1, seed=77, settle_ms=args.settle_ms)
         desc0 = env0.physical_system.last_launch()
         env0.close()
     finally:
@@ -378,11 +410,11 @@ def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out):
     # closed-loop usage: one launch per control step, eager and from a HIP graph
     b1 = bytes_per_env_step_single(w)
     env1 = make_env(ga, w, n_local, dev_index)
-    host_s, dev_ms, n1 = measure_single_step(torch, env1, n_local, 2000, 100, device, seed=99)
+    host_s, dev_ms, n1 = measure_single_step(torch, env1, n_local, 2000, 100, device, seed=99, settle_ms=args.settle_ms)
     out["single_step"] = {"value": n_local / host_s, "unit": "env-steps/s", "ms_per_step": host_s * 1e3, "device_ms_per_step": dev_ms,
                           "achieved_GBps": n_local * b1 / (dev_ms * 1e-3) / 1e9, "bytes_per_env_step": b1, "steps": n1,
                           "note": "one gemx_step launch per control step, eager"}
-    host_s, dev_ms, n1 = measure_single_step(torch, env1, n_local, 4096, 100, device, seed=99, graph_steps=64)
+    host_s, dev_ms, n1 = measure_single_step(torch, env1, n_local, 4096, 100, device, seed=99, graph_steps=64, settle_ms=args.settle_ms)
     out["single_step_graph"] = {"value": n_local / host_s, "unit": "env-steps/s", "ms_per_step": host_s * 1e3, "device_ms_per_step": dev_ms,
                                 "achieved_GBps": n_local * b1 / (dev_ms * 1e-3) / 1e9, "bytes_per_env_step": b1, "steps": n1,
                                 "note": "64 gemx_step launches captured into one HIP graph (torch.cuda.CUDAGraph) and replayed"}
@@ -394,14 +426,14 @@ def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out):
             continue
         wc = dict(WORKLOADS[key], key=key)
         envc = make_env(ga, wc, wc["envs"], dev_index)
-        tc = measure(torch, dist, envc, wc["envs"], 10, 3, spl, device, 1, seed=5)
+        tc = measure(torch, dist, envc, wc["envs"], 10, 3, spl, device, 1, seed=5, settle_ms=args.settle_ms)
         rc = roofline_of(wc, wc["envs"], spl, tc.launch_ms, envc.physical_system.last_launch(), key)
         envc.close()
         out["configs"][key] = {"workload": wc["desc"], "envs": wc["envs"], "steps_per_launch": spl, "value": wc["envs"] * spl * 10 / tc.wall,
                                "unit": "env-steps/s", "roofline": rc}
         if key == "scim":  # the same config with RK4Solver(split_kinks=True): steps cut at the PolynomialStaticLoad's kinks (accuracy option)
             envk = make_env(ga, wc, wc["envs"], dev_index, split_kinks=True)
-            tk = measure(torch, dist, envk, wc["envs"], 10, 3, spl, device, 1, seed=5)
+            tk = measure(torch, dist, envk, wc["envs"], 10, 3, spl, device, 1, seed=5, settle_ms=args.settle_ms)
             rk = roofline_of(wc, wc["envs"], spl, tk.launch_ms, envk.physical_system.last_launch(), key + "/split_kinks")
             envk.close()
             out["configs"]["scim_split_kinks"] = {"workload": wc["desc"] + ", RK4Solver(split_kinks=True)", "envs": wc["envs"], "steps_per_launch": spl,
@@ -409,7 +441,7 @@ def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out):
     # the headline kernel with the chip full
     n_big, c_big = 2 ** 20, 100
     envb = make_env(ga, w, n_big, dev_index)
-    tb = measure(torch, dist, envb, n_big, 4, 2, c_big, device, 1, seed=7)
+    tb = measure(torch, dist, envb, n_big, 4, 2, c_big, device, 1, seed=7, settle_ms=args.settle_ms)
     envb.close()
     bb = n_big * (c_big * bytes_per_env_step_fused(w) + 2 * 4 * w["s_ode"])
     out["at_scale"] = {"envs": n_big, "steps_per_launch": c_big, "value": n_big * 4 * c_big / tb.wall, "unit": "env-steps/s",
@@ -437,10 +469,12 @@ def main():
                     help="also time the batched-return path: all-gather of each launch's observation chunk / of every step's rows")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="allow more ranks than visible GPUs (ranks share GPUs, gloo control plane): functional check only")
+    ap.add_argument("--settle-ms", type=float, default=60.0,
+                    help="untimed launches of the same workload for this long before each leg's warm-up (clock governor; 0 = off)")
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / single_step / configs / at_scale legs")
     args = ap.parse_args()
-    if args.steps < 1 or args.warmup < 0 or args.steps_per_launch < 2:
-        raise SystemExit("bench.py: --steps >= 1, --warmup >= 0, --steps-per-launch >= 2")
+    if args.steps < 1 or args.warmup < 0 or args.steps_per_launch < 2 or args.settle_ms < 0:
+        raise SystemExit("bench.py: --steps >= 1, --warmup >= 0, --steps-per-launch >= 2, --settle-ms >= 0")
 
     world_env = os.environ.get("WORLD_SIZE")
     backend = "gloo" if args.oversubscribe else "nccl"

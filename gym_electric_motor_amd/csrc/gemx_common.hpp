@@ -169,6 +169,17 @@ template <> struct Angle<double> {
 // small math helpers
 // ------------------------------------------------------------------------------------------------
 template <class R> __device__ __forceinline__ R clip01(R x) { return fmin(fmax(x, R(0)), R(1)); }
+// duty cycles of the continuous converters, clip(0.5 (a + 1)) and clip(-0.5 (a - 1)) (converters.py:489-490, 900-902), each as ONE fused
+// multiply-add with the clamp modifier: scaling by a power of two commutes with rounding and |a + 1| is never subnormal, so
+// fma(a, 0.5, 0.5) == 0.5 * fl(a + 1) bit for bit
+template <class R> __device__ __forceinline__ R duty_pos(R a) {
+    if constexpr (sizeof(R) == 4) return clip01(__builtin_fmaf(a, 0.5f, 0.5f));
+    else return clip01(__builtin_fma(a, 0.5, 0.5));
+}
+template <class R> __device__ __forceinline__ R duty_neg(R a) {
+    if constexpr (sizeof(R) == 4) return clip01(__builtin_fmaf(a, -0.5f, 0.5f));
+    else return clip01(__builtin_fma(a, -0.5, 0.5));
+}
 template <class R> __device__ __forceinline__ R sgn(R x) { return x > R(0) ? R(1) : (x < R(0) ? R(-1) : R(0)); }  // np.sign
 
 // Clarke / inverse Clarke (three_phase_motor.py:18-28, 31-54) and Park rotation (56-88)

@@ -407,9 +407,9 @@ template <int CONV, bool IL, class R, int A0 = 0>
 __device__ __forceinline__ void b6_voltages(const DevParams<R> &P, const R (&act)[MAX_ACT], uint32_t dact, uint32_t legs, R ia, R ib, R ic,
                                             R &ua, R &ub, R &uc) {
     if (CONV == GEMX_CONV_CONT_B6) {  // converters.py:888-903
-        ua = (cont_leg<IL, R>(P, clip01(R(0.5) * (act[A0] + R(1))), ia) - R(0.5)) * P.u_sup;
-        ub = (cont_leg<IL, R>(P, clip01(R(0.5) * (act[A0 + 1] + R(1))), ib) - R(0.5)) * P.u_sup;
-        uc = (cont_leg<IL, R>(P, clip01(R(0.5) * (act[A0 + 2] + R(1))), ic) - R(0.5)) * P.u_sup;
+        ua = (cont_leg<IL, R>(P, duty_pos(act[A0]), ia) - R(0.5)) * P.u_sup;
+        ub = (cont_leg<IL, R>(P, duty_pos(act[A0 + 1]), ib) - R(0.5)) * P.u_sup;
+        uc = (cont_leg<IL, R>(P, duty_pos(act[A0 + 2]), ic) - R(0.5)) * P.u_sup;
     } else {  // converters.py:816-823
         const R hu = R(0.5) * P.u_sup;
         if (!IL) {  // every leg follows its sub-action immediately: upper rail iff the action bit is set
@@ -504,8 +504,8 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
         if (CONT) {
 #pragma unroll
             for (int j = 0; j < NU; ++j) {
-                const R d0 = clip01(R(0.5) * (act[j] + R(1)));
-                const R d1 = clip01(R(-0.5) * (act[j] - R(1)));
+                const R d0 = duty_pos(act[j]);
+                const R d1 = duty_neg(act[j]);
                 const R i = i_in(y, j);
                 u[j] = (cont_leg<IL, R>(P, d0, i) - cont_leg<IL, R>(P, d1, i)) * P.u_sup;  // both sub-converters see the same i (line 483)
             }
@@ -692,7 +692,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     static __device__ __forceinline__ void voltages(const DevParams<R> &P, const R (&act)[MAX_ACT], uint32_t dact, R &ua, R &ub, R &uc, R &ue) {
         b6_voltages<B6, false, R>(P, act, dact & 7u, 0u, R(0), R(0), R(0), ua, ub, uc);
         if (CONV == GEMX_CONV_CONT_B6_4QC) {  // converters.py:481-491 with t_il = 0
-            ue = (clip01(R(0.5) * (act[3] + R(1))) - clip01(R(-0.5) * (act[3] - R(1)))) * P.u_sup;
+            ue = (duty_pos(act[3]) - duty_neg(act[3])) * P.u_sup;
         } else {  // Finite-4QC sub-actions [1,1,2,2] / [1,2,1,2] (converters.py:360-361), flat action = a_b6 + 8 * a_4qc
             const uint32_t a1 = (dact >> 3) & 3u;
             ue = (((a1 & 2u) ? R(0) : R(1)) - ((a1 & 1u) ? R(0) : R(1))) * P.u_sup;
@@ -963,12 +963,12 @@ template <class R> __device__ __forceinline__ R fin_leg_i_sup(uint32_t st, R i) 
 }
 template <bool FIN, class R> __device__ __forceinline__ R qc4_i_sup(const DevParams<R> &P, R a, uint32_t legs, R i) {
     if (FIN) return fin_leg_i_sup<R>(legs & 3u, i) + fin_leg_i_sup<R>((legs >> 2) & 3u, -i);
-    return cont_leg_i_sup<R>(P, clip01(R(0.5) * (a + R(1))), i) + cont_leg_i_sup<R>(P, clip01(R(-0.5) * (a - R(1))), -i);
+    return cont_leg_i_sup<R>(P, duty_pos(a), i) + cont_leg_i_sup<R>(P, duty_neg(a), -i);
 }
 template <bool FIN, class R> __device__ __forceinline__ R b6_i_sup(const DevParams<R> &P, R a0, R a1, R a2, uint32_t legs, R ia, R ib, R ic) {
     if (FIN) return fin_leg_i_sup<R>(legs & 3u, ia) + fin_leg_i_sup<R>((legs >> 2) & 3u, ib) + fin_leg_i_sup<R>((legs >> 4) & 3u, ic);
-    return cont_leg_i_sup<R>(P, clip01(R(0.5) * (a0 + R(1))), ia) + cont_leg_i_sup<R>(P, clip01(R(0.5) * (a1 + R(1))), ib) +
-           cont_leg_i_sup<R>(P, clip01(R(0.5) * (a2 + R(1))), ic);
+    return cont_leg_i_sup<R>(P, duty_pos(a0), ia) + cont_leg_i_sup<R>(P, duty_pos(a1), ib) +
+           cont_leg_i_sup<R>(P, duty_pos(a2), ic);
 }
 template <int SYS, int CONV, class R>
 __device__ __forceinline__ R supply_current(const DevParams<R> &P, const R (&y)[SysTraits<SYS>::ND], typename Angle<R>::T ang, uint32_t sw,
@@ -2108,8 +2108,11 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             row[ST::row_slot(NDONE)] = done ? R(1) : R(0);
             if constexpr (FULL) row[ST::row_slot(NDONE + 1)] = usup_lane;
             const bool rs = viol > thr_reset;  // `if terminated: env.reset()`; switching state survives
+            // every copy of the step but the FIFO one runs only while the one-step map is valid for this wave (`lin_ok`), i.e. while every
+            // lane's omega IS init[0] and stays so: putting it back is a no-op there
+            constexpr bool OMEGA_FIXED = LINABLE && MODE != 1;
 #pragma unroll
-            for (int j = 0; j < ND; ++j) y[j] = rs ? P.init[j] : y[j];
+            for (int j = OMEGA_FIXED ? 1 : 0; j < ND; ++j) y[j] = rs ? P.init[j] : y[j];
             ang = rs ? init_ang : ang;
             if constexpr (FULL) {
                 if (rs && P.init_kind) draw_initial_state_cnt<SYS, R>(a.rinit, env, rcount, y, ang);  // (rare: exec-masked, skipped wave-wide)

@@ -21,12 +21,18 @@ if os.environ.get("PROBE_REWARD"):
     ps.set_reward(reward_weights=dict(i_sd=0.5, i_sq=0.5), referenced_states=("i_sd", "i_sq"))
     refs = torch.rand((K, n, 2), device="cuda:0") * 2 - 1
     rew = torch.empty((K, n), device="cuda:0")
-for _ in range(5):
+reps = int(os.environ.get("PROBE_REPS", "5"))  # (a long train of launches shows the power-limited steady state of bench.py)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for r in range(reps):
+    if r == reps // 2:
+        e0.record()
     if refs is None:
         ps.rollout(act)
     else:
         ps.rollout(act, references=refs, reward_out=rew)
+e1.record()
 torch.cuda.synchronize()
+print(f"HIP events: {1e3 * e0.elapsed_time(e1) / (reps - reps // 2):.1f} us per launch over the last {reps - reps // 2} of {reps} launches")
 L = _lib.load()
 L.gemx_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 buf = (C.c_ulonglong * 32)()
