@@ -357,6 +357,7 @@ constexpr int PIPE_D3 = 2, PIPE_OUT_WAVES3 = 2;
 // both shapes carry a LOADER wave that stages actions / references global -> LDS (0: the integrator wave stages them itself).  Measured
 // at 131072 envs over all motor families (same box A/B): -5 .. +22 %, the heavier steppers and the continuous-action ones gain most
 constexpr int pipe_loader_waves(int) { return 1; }
+constexpr int PIPE_ACT_BUFS = 2;  // action staging buffers of the pipelined kernel: the loader wave runs one block ahead
 // rows of the pipelined kernel's per-lane action queue in LDS: `delay` (FIFO / carry rows), or D + delay where the queue of TRANSFORMED
 // actions behind a DqToAbcActionProcessor is kept as a row buffer indexed by the step of the block (deep shape only)
 __host__ __device__ constexpr int pipe_queue_rows(int D, int delay, bool dq_processor, bool full) {

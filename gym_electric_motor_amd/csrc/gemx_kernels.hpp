@@ -1875,7 +1875,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
     // fused reward: reference rows [3][D][64 * n_ref] R, staged global -> LDS by the integrator wave one block ahead, read by the output
     // waves one block behind (hence three buffers).  The output waves thus issue NO global loads: a load would make them wait, through
     // the in-order vmcnt, for all their older observation stores once per block.
-    constexpr int ACTB_BYTES = 2 * ((D + 3) / 4 * 4) * BLOCK * (DISCRETE ? 1 : NACT * (int)sizeof(R));
+    constexpr int ACTB_BYTES = PIPE_ACT_BUFS * ((D + 3) / 4 * 4) * BLOCK * (DISCRETE ? 1 : NACT * (int)sizeof(R));
     R *refb = reinterpret_cast<R *>(actb + ACTB_BYTES);
     const int n_ref = a.rw != nullptr ? a.rh.n_ref : 0;
     // per-action voltage table [NACTIONS][8] R of steppers that have one (ST::NVT > 0), read by the integrator wave only
@@ -1890,29 +1890,24 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
     // (measured 150 -> 164 us per 500-step launch).  The integrator reads its action of a step from LDS one step ahead.
     constexpr int ABYTES = DISCRETE ? 1 : NACT * (int)sizeof(R);
     constexpr int ROWB = BLOCK * ABYTES;  // bytes of one 64-env action row (contiguous in the [K][N][A] tensor)
-    constexpr int DP = ROWB == 64 ? (D + 3) / 4 * 4 : D;  // rows per buffer half (uint8 rows are staged four at a time)
+    constexpr int DP = ROWB == 64 ? (D + 3) / 4 * 4 : D;  // rows per buffer half (uint8: padded to whole 256-byte groups of four rows)
+    // one instruction moves 64 sixteen-byte units (`global_load_lds_dwordx4`, gfx950): the block's D rows of ROWB bytes are contiguous in LDS,
+    // so unit q = 64 j + lane of instruction j belongs to row q / U at byte 16 (q % U).  (Dword-wide staging took ROWB / 256 instructions per
+    // row -- 36 per block for three-phase duty cycles, each a 256-byte request with a row stride of N * ABYTES between them.)
+    constexpr int U16 = ROWB / 16, NU16 = D * U16, NSTAGE = (NU16 + 63) / 64;
     auto stage_actions = [&](int b) {
         const int sb = steps_of(b);
-        unsigned char *dst = actb + (size_t)(b & 1) * DP * ROWB;
+        unsigned char *dst = actb + (size_t)(b % PIPE_ACT_BUFS) * DP * ROWB;
         const unsigned char *src = a.actions + ((int64_t)b * D * N + blk0) * ABYTES;
-        if (ROWB == 64) {  // uint8 actions: 16 lanes cover a row, so one instruction stages four rows
 #pragma unroll
-            for (int j = 0; j < (D + 3) / 4; ++j) {
-                int row = 4 * j + (tid >> 4);
-                row = row < sb ? row : sb - 1;  // tail block: re-read the last valid row
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + (int64_t)row * N + (tid & 15) * 4),
-                                                 (void __attribute__((address_space(3))) *)(dst + (size_t)j * 256), 4, 0, 0);
-            }
-        } else {  // ROWB is a multiple of 256 bytes: each instruction moves 64 consecutive dwords of a row
-#pragma unroll
-            for (int s = 0; s < D; ++s) {
-                const int row = s < sb ? s : sb - 1;
-#pragma unroll
-                for (int i = 0; i < ROWB / 256; ++i)
-                    __builtin_amdgcn_global_load_lds(
-                        (const void __attribute__((address_space(1))) *)(src + (int64_t)row * N * ABYTES + i * 256 + tid * 4),
-                        (void __attribute__((address_space(3))) *)(dst + (size_t)s * ROWB + i * 256), 4, 0, 0);
-            }
+        for (int j = 0; j < NSTAGE; ++j) {
+            const int q = j * 64 + tid;
+            int row = q / U16;
+            const int col = q - row * U16;
+            row = row < sb ? row : sb - 1;  // tail block: re-read the last valid row
+            if (NU16 % 64 == 0 || q < NU16)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + (int64_t)row * N * ABYTES + col * 16),
+                                                 (void __attribute__((address_space(3))) *)(dst + (size_t)j * 1024), 16, 0, 0);
         }
     };
     auto stage_refs = [&](int b) {  // rows of 64 * n_ref references, 64 consecutive dwords per instruction
@@ -2001,7 +1996,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
         }
 
         auto read_action = [&](int b, int s, R (&dst)[NACT], uint32_t &ddst) {
-            const unsigned char *row = actb + ((size_t)(b & 1) * DP + s) * ROWB;
+            const unsigned char *row = actb + ((size_t)(b % PIPE_ACT_BUFS) * DP + s) * ROWB;
             if (DISCRETE) ddst = row[tid];
             else {
 #pragma unroll
@@ -2138,7 +2133,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             __syncthreads();
         }
 #ifdef GEMX_TIMING
-        unsigned long long tv = 0, tc = 0, tw = 0, T0 = clock64(), W0 = wall_clock64(), t0, t0b, t1, t2;
+        unsigned long long tv = 0, tc = 0, tw = 0, tlong = 0, T0 = clock64(), W0 = wall_clock64(), t0, t0b, t1, t2;
 #endif
         for (int b = 0; b < nb; ++b) {
 #ifdef GEMX_TIMING
@@ -2325,12 +2320,17 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
 #ifdef GEMX_TIMING
             t2 = clock64();
             tv += t0b - t0; tc += t1 - t0b; tw += t2 - t1;
+            tlong += (t2 - t1) > 1000 ? 1 : 0;
+            if (blockIdx.x == 0 && tid == 0 && b >= 100 && b < 148) {  // barrier trace of blocks 100..147 (arrive, release) per wave
+                unsigned long long *tr = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64) + 64 + 0 * 96 + 2 * (b - 100);
+                tr[0] = t1; tr[1] = t2;
+            }
 #endif
         }
 #ifdef GEMX_TIMING
         if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 37)) {
             unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64) + (blockIdx.x ? 16 : 0);
-            dbg[0] = tv; dbg[1] = tc; dbg[2] = tw; dbg[3] = clock64() - T0; dbg[4] = wall_clock64() - W0; dbg[5] = nb;
+            dbg[0] = tv; dbg[1] = tc; dbg[2] = tw; dbg[3] = clock64() - T0; dbg[4] = wall_clock64() - W0; dbg[5] = (unsigned long long)nb | (tlong << 32);
         }
 #endif
 #pragma unroll
@@ -2381,6 +2381,9 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
 #endif
         uint32_t bad = 0;
         if (DISCRETE) __syncthreads();
+        // (Staging TWO blocks ahead through a third buffer was tried in round 2 -- the s_memtime probe shows this wave's loads taking longer
+        // than the integrator's block in the shallow shapes -- and changed nothing, same box, over all motor families:
+        // profiles/r02h_loader_depth.md.)
         for (int b = 0; b < nb; ++b) {
 #ifdef GEMX_TIMING
             const unsigned long long l0 = clock64();
@@ -2390,7 +2393,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                 if (n_ref > 0) stage_refs(b + 1);
             }
             if (DISCRETE) {
-                const unsigned char *rows = actb + (size_t)(b & 1) * DP * ROWB;
+                const unsigned char *rows = actb + (size_t)(b % PIPE_ACT_BUFS) * DP * ROWB;
                 const int sb = steps_of(b);
                 for (int s = 0; s < sb; ++s) bad |= (uint32_t)rows[(size_t)s * ROWB + tid] >= (uint32_t)ConvTraits<CONV>::NACTIONS;
             }
@@ -2401,6 +2404,10 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             __syncthreads();
 #ifdef GEMX_TIMING
             tl += l1 - l0; tb += clock64() - l1;
+            if (blockIdx.x == 0 && tid == 0 && b >= 100 && b < 148) {  // barrier trace of blocks 100..147 (arrive, release) per wave
+                unsigned long long *tr = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64) + 64 + 3 * 96 + 2 * (b - 100);
+                tr[0] = l1; tr[1] = clock64();
+            }
 #endif
         }
         if (bad) atomicOr(a.err, 1u);
@@ -2513,7 +2520,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
 #endif
         };
 #ifdef GEMX_TIMING
-        unsigned long long tp = 0, tq = 0;
+        unsigned long long tp = 0, tq = 0, pmax = 0, pg2 = 0, pg3 = 0;
 #endif
         if (LW != 0 && DISCRETE) __syncthreads();  // (the integrator's and the loader's initial barrier)
         for (int b = 0; b < nb; ++b) {
@@ -2527,6 +2534,11 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             __syncthreads();
 #ifdef GEMX_TIMING
             tp += q1 - q0; tq += clock64() - q1;
+            pmax = (q1 - q0) > pmax ? (q1 - q0) : pmax; pg2 += (q1 - q0) > 2000; pg3 += (q1 - q0) > 3000;
+            if (blockIdx.x == 0 && tid == 0 && b >= 100 && b < 148) {  // barrier trace of blocks 100..147 (arrive, release) per wave
+                unsigned long long *tr = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64) + 64 + (wave < 3 ? wave : 2) * 96 + 2 * (b - 100);
+                tr[0] = q1; tr[1] = clock64();
+            }
 #endif
         }
         process(nb - 1);
@@ -2534,7 +2546,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
         if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 37)) {
             unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64) + (blockIdx.x ? 16 : 0);
             dbg[6 + 2 * (wave - 1)] = tp; dbg[7 + 2 * (wave - 1)] = tq;
-            if (wave == 1) dbg[14] = tflush;
+            if (wave == 1) { dbg[14] = tflush; dbg[15] = (pmax << 40) | (pg3 << 20) | pg2; }
         }
 #endif
     }
@@ -2651,7 +2663,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         auto smem_of = [&](int D) {
             size_t b = (size_t)D * BLOCK * h->nout * sizeof(R) + (size_t)D * BLOCK + 2 * (size_t)D * BLOCK * NHT * sizeof(R);
             b += (size_t)pipe_queue_rows(D, delay, conv_dq<CONV>() && h->pf.dq_processor != 0, need_full) * BLOCK * conv_nact_c<CONV>() * sizeof(R);  // DeadTimeProcessor queue
-            b += 2 * (size_t)((D + 3) / 4 * 4) * BLOCK * ABYTES;           // action staging (global -> LDS direct)
+            b += PIPE_ACT_BUFS * (size_t)((D + 3) / 4 * 4) * BLOCK * ABYTES;  // action staging (global -> LDS direct, one block ahead)
             if (h->cur_reward != nullptr) b += 3 * (size_t)D * BLOCK * h->rw_n_ref * sizeof(R);  // reference staging for the fused reward
             if (ST::NVT > 0 && ConvTraits<CONV>::DISCRETE) b += (size_t)ConvTraits<CONV>::NACTIONS * 8 * sizeof(R);  // per-action voltage table
             return (b + 15) & ~(size_t)15;

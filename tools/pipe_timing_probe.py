@@ -40,13 +40,25 @@ L.gemx_debug_read(ps._handle, buf, 32)
 print(L.gemx_last_launch(ps._handle))
 for base in (0, 16):
     tv, tc, tw, tot, wall, nb = buf[base:base + 6]
+    nlong, nb = nb >> 32, nb & 0xFFFFFFFF
     outs = buf[base + 6:base + 12]
     print(f"blk{'0' if base == 0 else '37'}: nb={nb} total={tot} cyc wall={wall} (100MHz ticks => {wall*10} ns, clock={tot/(wall*10+1e-9):.3f} GHz)")
     print(f"   integrator per block: vmwait={tv/nb:.0f} compute={tc/nb:.0f} barrier={tw/nb:.0f} cycles")
     for w in range(3):  # (first three output waves)
         print(f"   out wave {w}: process={outs[2*w]/nb:.0f} barrier={outs[2*w+1]/nb:.0f}")
     print(f"   out wave 0: of which reward + flush={buf[base+14]/nb:.0f}")
+    v = buf[base + 15]
+    print(f"   integrator: {nlong} of {nb} barrier waits > 1000 cycles; out wave 0: longest block {v >> 40} cycles, {v & 0xFFFFF} blocks > 2000, {(v >> 20) & 0xFFFFF} > 3000")
     print(f"   loader: stage+wait={buf[base+12]/nb:.0f} barrier={buf[base+13]/nb:.0f}")
+
+if os.environ.get("PROBE_TRACE"):  # barrier trace of workgroup 0, blocks 100..147: per wave (arrive, release), relative to the first arrival
+    big = (C.c_ulonglong * 448)()
+    L.gemx_debug_read(ps._handle, big, 448)
+    tr = [[(big[64 + w * 96 + 2 * i], big[64 + w * 96 + 2 * i + 1]) for i in range(48)] for w in range(4)]
+    t00 = min(t[0][0] for t in tr if t[0][0])
+    print("block: integrator(arrive,release) out0 out1 loader   [cycles since the trace began]")
+    for i in range(48):
+        print(f"{100 + i}: " + "  ".join(f"({tr[w][i][0] - t00:6d},{tr[w][i][1] - t00:6d})" for w in range(4)))
 
 if os.environ.get("PROBE_STEP"):  # K = 1 (gemx_step -> advance_kernel): cycles per phase of workgroup 0 / the last workgroup, wall span
     for _ in range(20):
