@@ -526,6 +526,8 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         if (ev) h->pipe_shape = atoi(ev);
         ev = getenv("GEMX_STEP_KERNEL");
         if (ev) h->use_step_kernel = atoi(ev);
+        ev = getenv("GEMX_DC_STREAM");  // 0: never take dc_stream_kernel; 2: at any N (A/B runs and bit-identity tests)
+        if (ev) h->use_dc_stream = atoi(ev);
         ev = getenv("GEMX_LINMAP");  // 0: never use the one-step map of the electrical subsystem (A/B runs)
         if (ev && atoi(ev) == 0) h->linmap_state = -1;
 
@@ -644,7 +646,9 @@ int gemx_reset(gemx_handle *h, const uint8_t *mask_dev, void *obs_out_dev, void 
     if (!h) return fail(GEMX_ERR_ARG, "null handle");
     gemx::DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
-    return h->cfg.dtype == GEMX_F64 ? launch_reset<double>(h, mask_dev, obs_out_dev, st) : launch_reset<float>(h, mask_dev, obs_out_dev, st);
+    const int rc = h->cfg.dtype == GEMX_F64 ? launch_reset<double>(h, mask_dev, obs_out_dev, st) : launch_reset<float>(h, mask_dev, obs_out_dev, st);
+    if (rc == GEMX_OK && mask_dev == nullptr && h->cfg.init_kind == GEMX_INIT_CONST) h->omega_is_init = true;  // every env is at init again
+    return rc;
 }
 
 int gemx_rollout(gemx_handle *h, const void *actions_dev, int32_t K, void *obs_out_dev, uint8_t *done_out_dev, int32_t obs_every,
@@ -730,6 +734,7 @@ int gemx_set_state(gemx_handle *h, const void *soa_in_dev, void *stream) {
         hipLaunchKernelGGL(set_state_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (float *)h->state, (int32_t *)h->angle,
                            (const float *)soa_in_dev, h->n, h->nd, h->has_angle);
     HIP_TRY(hipGetLastError());
+    h->omega_is_init = false;  // (dc_stream_kernel assumes omega == init[0]; the next full reset restores that)
     return GEMX_OK;
 }
 int gemx_get_switch_state(gemx_handle *h, uint8_t *out_dev, void *stream) {
@@ -747,7 +752,11 @@ int gemx_set_switch_state(gemx_handle *h, const uint8_t *in_dev, void *stream) {
 const char *gemx_last_launch(const gemx_handle *h) {
     if (!h) return "";
     const auto &l = h->ll;
-    if (l.pipe == 2)
+    if (l.pipe == 3)
+        snprintf(h->last_launch, sizeof(h->last_launch),
+                 "gemx::dc_stream_kernel<sys=%d,conv=%d,solver=%d,f32,D=%d> grid=%lld x %d threads, lds=%zu B, K=%d", l.sys, l.conv, l.solver, l.d,
+                 l.blocks, l.threads, l.lds, l.k);
+    else if (l.pipe == 2)
         snprintf(h->last_launch, sizeof(h->last_launch), "gemx::step_kernel<sys=%d,conv=%d,load=%d,solver=%d,il=%d,%s> grid=%lld x %d threads, K=1", l.sys, l.conv,
                  l.load, l.solver, l.il, l.real_size == 4 ? "f32" : "f64", l.blocks, l.threads);
     else if (l.pipe)

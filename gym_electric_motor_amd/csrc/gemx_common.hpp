@@ -415,6 +415,9 @@ struct gemx_handle {
     int pipe_shape = -1;      // GEMX_PIPE_SHAPE=0/1/2 forces <12,3> / <4,2> / <2,2> whenever it fits (tests: every shape on small N)
     int use_step_kernel = 1;  // K = 1 launches take step_kernel (GEMX_STEP_KERNEL=0: advance_kernel, for A/B runs and bit-identity tests)
     int use_pipe = -1;        // pipelined kernel: -1 / 1 whenever eligible (default), 0 never (GEMX_PIPE=0: A/B and bit-identity tests)
+    int use_dc_stream = 1;    // dc_stream_kernel: 1 when eligible and N <= 64 * CUs (default), 2 at any N, 0 never (GEMX_DC_STREAM)
+    bool dcs_attr_set = false;
+    bool omega_is_init = true;  // every env's omega equals init[0] (constant-speed loads): false between gemx_set_state and the next full reset
 };
 
 namespace gemx {

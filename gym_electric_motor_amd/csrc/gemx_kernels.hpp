@@ -365,6 +365,51 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
     }
 }
 
+// The constant-speed electrical step (one sub-step of length tau) split at its state-independent part, for dc_stream_kernel: elec_input() is
+// everything that depends on (omega, u) only, elec_apply() advances x with it.  Together they are integrate<SYS, CONST_SPEED, SOLVER, R,
+// NS1 = true, LIN>() operation by operation (same expressions in the same order: bit-identical results, asserted by the tests).
+template <int SYS, class R, bool LIN>
+__device__ __forceinline__ void elec_input(const DevParams<R> &P, R om, const R (&u)[MAX_U], const R *L, R (&in)[Elec<SYS, R>::NM]) {
+    using E = Elec<SYS, R>;
+    constexpr int NM = E::NM, NG = E::NG;
+    static_assert(NG == NM, "the DC machines' affine part has one entry per state");
+    R g[NG];
+    E::get_b(E::prep(P, om, u), g);
+#pragma unroll
+    for (int r = 0; r < NM; ++r) {
+        if (LIN) {
+            R acc = L[NM * NM + r * NG] * g[0];
+#pragma unroll
+            for (int i = 1; i < NG; ++i) acc += L[NM * NM + r * NG + i] * g[i];
+            in[r] = acc;
+        } else {
+            in[r] = g[r];
+        }
+    }
+}
+template <int SYS, int SOLVER, class R, bool LIN>
+__device__ __forceinline__ void elec_apply(const DevParams<R> &P, R om, R (&x)[Elec<SYS, R>::NM], const R (&in)[Elec<SYS, R>::NM], const R *L) {
+    using E = Elec<SYS, R>;
+    constexpr int NM = E::NM;
+    if (LIN) {
+        R xn[NM];
+#pragma unroll
+        for (int r = 0; r < NM; ++r) {
+            R acc = in[r];
+#pragma unroll
+            for (int c = 0; c < NM; ++c) acc += L[r * NM + c] * x[c];
+            xn[r] = acc;
+        }
+#pragma unroll
+        for (int r = 0; r < NM; ++r) x[r] = xn[r];
+    } else {
+        const R zu[MAX_U] = {R(0), R(0), R(0), R(0)};
+        const typename E::Pre pre = E::set_b(E::prep(P, om, zu), in);  // (the omega-only entries; the affine part is the pre-wave's)
+        auto rhs = [&](const R (&xx)[NM], R (&dx)[NM]) { E::f(P, pre, xx, dx); };
+        rk_step<SOLVER, NM, R>(x, P.tau, rhs);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // converters: phase voltages for one segment
 // ------------------------------------------------------------------------------------------------
@@ -496,6 +541,18 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
     static __device__ __forceinline__ R i_in(const R (&y)[ND], int j) {
         if (SYS == GEMX_SYS_DC_EXTEX) return y[1 + j];
         return SYS == GEMX_SYS_DC_SHUNT ? y[1] + y[ND - 1] : y[1];
+    }
+    // converter output WITHOUT dead time: a function of the action alone (dc_stream_kernel evaluates it off the integrator's wave)
+    static __device__ __forceinline__ void input_voltages(const DevParams<R> &P, const R (&act)[MAX_ACT], uint32_t dact, R (&u)[MAX_U]) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            if (CONT) {
+                u[j] = (duty_pos(act[j]) - duty_neg(act[j])) * P.u_sup;
+            } else {  // Finite-4QC: action -> (leg0, leg1) sub-actions [1,1,2,2] / [1,2,1,2] (converters.py:360-361); 1 = upper rail
+                const uint32_t aj = (dact >> (2 * j)) & 3u;
+                u[j] = (((aj & 2u) ? R(0) : R(1)) - ((aj & 1u) ? R(0) : R(1))) * P.u_sup;
+            }
+        }
     }
     template <bool NS1 = false, bool LIN = false, bool TAB = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[ND], AngT &, uint32_t &sw, const R (&act)[MAX_ACT], uint32_t dact,
@@ -2553,6 +2610,371 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
 }
 
 // ------------------------------------------------------------------------------------------------
+// dc_stream_kernel: small batches of the DC machines behind a constant-speed load (BASELINE config 2: Cont-CC-PermExDc-v0, 4096 envs).
+//
+// A launch takes at least K times what ONE wave needs per control step, and in advance_pipe_kernel that wave carries the
+// converter stage, the solver, the constraint, the reset and a 16-byte hand-off write: 150 cycles per step for a one-state motor.  Here the
+// step's recurrence is all the integrator wave keeps.  With omega constant and no dead time the electrical right-hand side is
+// f(x) = A x + g(u_k), and g(u_k) does not depend on the state, so
+//   * PRE waves (DCS_PRE of them, alternating groups of four steps) load the action rows DCS_PREFETCH blocks ahead straight into registers,
+//     run the converter stage and Elec::prep, and leave the step's input term (elec_input(): g, or S g of the one-step map) and the
+//     voltages in LDS;
+//   * the INTEGRATOR wave reads the input terms of four steps with one 16-byte LDS read, applies the solver (elec_apply(): a 1-state Euler
+//     step is two FMAs), decides the reset, and hands over NOTHING but the new motor states, four steps per 16-byte write;
+//   * OUTPUT waves (DCS_OUT) one block behind rebuild the rest -- observation row, done flag: the same device functions on the same
+//     values as everywhere else -- and store each lane's row directly (rows are 20-28 bytes; transposing a group of rows through LDS
+//     into aligned 16-byte units was tried: 1600 -> 1900 cycles per block for this wave); the done bytes of four steps leave in ONE store
+//     (ballots, lane l writes bytes 4 (l % 16) .. + 3 of step l / 16).
+// LDS rows are [group of 4 steps][lane][step in group][value]: 16 bytes per lane and value.  One s_barrier per block of DCS_D steps.
+// Every value is produced by the code the other kernels run (prep / rk_step / observe / state_violation), so the results are
+// bit-identical to theirs; the tests assert it.  Preconditions beyond the pipelined kernel's (checked by the launcher): DC machine,
+// ConstantSpeedLoad, no dead time of either kind, ideal supply, constant initial state, no fused reward, AoS observations, and
+// omega == init[0] in every env (gemx_set_state clears that until the next full reset).
+// ------------------------------------------------------------------------------------------------
+// Waves of a workgroup go to the CU's four SIMDs round robin, so the waves whose index is a multiple of four would share the integrator's
+// SIMD and its issue slots: they are launched and end at once (a wave that has ended no longer counts at the barrier).  Integrator = wave 0,
+// pre waves = 1, 2, output waves = 3, 5, 6, 7.
+constexpr int DCS_D = 32, DCS_PRE = 2, DCS_OUT = 4, DCS_WAVES = 8, DCS_PREFETCH = 3;
+constexpr int dcs_output_index(int wave) { return wave - 1 - DCS_PRE - (wave > 4 ? 1 : 0); }
+static_assert(dcs_output_index(3) == 0 && dcs_output_index(DCS_WAVES - 1) == DCS_OUT - 1, "wave roles");
+template <int SYS, int CONV> constexpr size_t dcs_smem_bytes() {
+    constexpr int NM = SysTraits<SYS>::ND - 1, NU = SYS == GEMX_SYS_DC_EXTEX ? 2 : 1;
+    return (size_t)DCS_D * BLOCK * sizeof(float) * (3 * NM + 3 * NU + 2 * NM);
+}
+template <int SYS, int CONV, int SOLVER, class R>
+__global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArgs<R> a) {
+    constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NM = ND - 1, NACT = ConvTraits<CONV>::NACT;
+    constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
+    constexpr int D = DCS_D, NGR = D / 4;  // steps, groups of four steps per block
+    using ST = Stepper<SYS, CONV, GEMX_LOAD_CONST_SPEED, SOLVER, false, R>;
+    using AngT = typename Angle<R>::T;
+    constexpr int NU = ST::NU;
+    constexpr bool LINABLE = linable<GEMX_LOAD_CONST_SPEED, SOLVER, false, R>();
+    static_assert(sizeof(R) == 4 && !SysTraits<SYS>::HAS_ANGLE && D % 4 == 0, "fp32 DC machines");
+
+    const DevParams<R> &P = a.P;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tid = threadIdx.x & (BLOCK - 1);
+    // (32 envs per workgroup on twice as many CUs was tried for the output waves' sake: their time per row does not go down with the
+    // active lanes of a store -- 1650 cycles per 32-step block either way -- and the exec masking around the stores cost 20 %.)
+    const int64_t N = a.N, blk0 = (int64_t)blockIdx.x * BLOCK, env = blk0 + tid;
+    const int K = a.K, nb = (K + D - 1) / D;
+    auto steps_of = [&](int b) { return (K - b * D) < D ? (K - b * D) : D; };
+    // LDS: input terms [3][NGR][64][4][NM] | voltages [3][NGR][64][4][NU] | new motor states [2][NGR][64][4][NM]
+    R *gin = reinterpret_cast<R *>(gemx_smem);
+    R *uu = gin + 3 * (size_t)D * BLOCK * NM;
+    R *hand = uu + 3 * (size_t)D * BLOCK * NU;
+    const R om = P.init[0];  // == omega of every env (launcher); a ConstantSpeedLoad never changes it, a reset puts it back
+    const bool lin_ok = LINABLE && P.lin_on != 0;  // wave-uniform
+    R linc[lin_count<SYS, R>()];
+    lin_preload<SYS, R>(P, lin_ok, linc);
+    const bool check_default = P.constr_kind == 1;
+    const R thr_done = check_default ? R(1) : R(INFINITY), thr_reset = (check_default && P.auto_reset != 0) ? R(1) : R(INFINITY);
+
+    if (wave == 0) {
+        // ------------------------------------------------------------------ integrator: the recurrence and nothing else
+        R x[NM];
+#pragma unroll
+        for (int i = 0; i < NM; ++i) x[i] = a.state[(int64_t)(1 + i) * N + env];
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) here, once: otherwise the compiler parks the wait for x inside the step loop
+        auto one_step = [&](auto lin_tag, const R *in_, R *out_) {  // (lin_tag: a std::bool_constant, so that the step has no branch)
+            constexpr bool LIN = decltype(lin_tag)::value;
+            R in[NM];
+#pragma unroll
+            for (int i = 0; i < NM; ++i) in[i] = in_[i];
+            elec_apply<SYS, SOLVER, R, LIN>(P, om, x, in, LIN ? linc : nullptr);
+            R y[ND];
+            y[0] = om;
+#pragma unroll
+            for (int i = 0; i < NM; ++i) { y[1 + i] = x[i]; out_[i] = x[i]; }
+            const R ho[ST::NH] = {};
+            const bool rs = ST::state_violation(P, y, ho) > thr_reset;  // `if terminated: env.reset()`
+#pragma unroll
+            for (int i = 0; i < NM; ++i) x[i] = rs ? P.init[1 + i] : x[i];
+        };
+        auto run_block = [&](auto lin_tag, int b) {
+            const int sb = steps_of(b);
+            const R *gb = gin + ((size_t)(b % 3) * NGR * BLOCK + tid) * 4 * NM;
+            R *hb = hand + ((size_t)(b & 1) * NGR * BLOCK + tid) * 4 * NM;
+            if (sb == D) {  // whole block: a group's input terms are read two groups ahead (a step is far shorter than an LDS round trip)
+                R in4[3][4 * NM], out4[4 * NM];
+                auto fetch = [&](int g, R (&dst)[4 * NM]) {
+#pragma unroll
+                    for (int i = 0; i < 4 * NM; ++i) dst[i] = gb[(size_t)g * BLOCK * 4 * NM + i];
+                };
+                fetch(0, in4[0]);
+                fetch(1, in4[1]);
+#pragma unroll
+                for (int g = 0; g < NGR; ++g) {
+                    if (g + 2 < NGR) fetch(g + 2, in4[(g + 2) % 3]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) one_step(lin_tag, &in4[g % 3][j * NM], &out4[j * NM]);
+#pragma unroll
+                    for (int i = 0; i < 4 * NM; ++i) hb[(size_t)g * BLOCK * 4 * NM + i] = out4[i];
+                }
+            } else {
+#pragma nounroll
+                for (int s = 0; s < sb; ++s) {
+                    const size_t o = ((size_t)(s >> 2) * BLOCK * 4 + (s & 3)) * NM;
+                    R in[NM], out[NM];
+#pragma unroll
+                    for (int i = 0; i < NM; ++i) in[i] = gb[o + i];
+                    one_step(lin_tag, in, out);
+#pragma unroll
+                    for (int i = 0; i < NM; ++i) hb[o + i] = out[i];
+                }
+            }
+        };
+#ifdef GEMX_TIMING
+        unsigned long long tc = 0, tw = 0, T0 = clock64(), W0 = wall_clock64();
+#endif
+        __syncthreads();  // block 0's input terms are in LDS
+        for (int b = 0; b < nb; ++b) {
+#ifdef GEMX_TIMING
+            const unsigned long long t0 = clock64();
+#endif
+            if (LINABLE && lin_ok) run_block(std::bool_constant<LINABLE>{}, b);
+            else run_block(std::false_type{}, b);
+#ifdef GEMX_TIMING
+            const unsigned long long t1 = clock64();
+#endif
+            __syncthreads();  // publishes the states of block b; the pre waves have block b + 1 ready
+#ifdef GEMX_TIMING
+            tc += t1 - t0; tw += clock64() - t1;
+#endif
+        }
+#ifdef GEMX_TIMING
+        if (tid == 0 && blockIdx.x == 0) {
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64);
+            dbg[0] = 0; dbg[1] = tc; dbg[2] = tw; dbg[3] = clock64() - T0; dbg[4] = wall_clock64() - W0; dbg[5] = nb;
+        }
+#endif
+#pragma unroll
+        for (int i = 0; i < NM; ++i) a.state[(int64_t)(1 + i) * N + env] = x[i];
+    } else if ((wave & 3) == 0) {
+        return;  // (keeps SIMD 0 to the integrator)
+    } else if (wave <= DCS_PRE) {
+        // ------------------------------------------------------------------ pre: actions -> converter -> input term, DCS_PREFETCH blocks ahead
+        constexpr int GP = NGR / DCS_PRE, RP = 4 * GP;  // groups / rows per pre wave and block: groups j * DCS_PRE + pw
+        static_assert(NGR % DCS_PRE == 0, "groups per pre wave");
+        const int pw = wave - 1;
+        uint32_t bad = 0;
+        struct Rows { R f[RP][NACT]; uint32_t d[RP]; };
+        constexpr int ABYTES = DISCRETE ? 1 : NACT * (int)sizeof(R);
+        const int64_t rowb = N * ABYTES, bstride = (int64_t)D * rowb;
+        const unsigned char *abase = a.actions + ((int64_t)(4 * pw) * N + env) * ABYTES;  // this lane's entry of this wave's first row
+        auto load_rows = [&](auto clamp_tag, int bb, Rows &v) {
+            const unsigned char *p0 = abase + (int64_t)bb * bstride;
+#pragma unroll
+            for (int j = 0; j < RP; ++j) {
+                const int r = (j >> 2) * 4 * DCS_PRE + (j & 3);  // row within the block, relative to this wave's first row
+                const unsigned char *p = p0 + (int64_t)r * rowb;
+                if constexpr (decltype(clamp_tag)::value) {  // rows past the end of the rollout: the last valid row again
+                    int64_t k = (int64_t)bb * D + 4 * pw + r;
+                    k = k < K ? k : K - 1;
+                    p = a.actions + (k * N + env) * ABYTES;
+                }
+                if (DISCRETE) v.d[j] = *p;
+                else {
+#pragma unroll
+                    for (int i = 0; i < NACT; ++i) v.f[j][i] = reinterpret_cast<const R *>(p)[i];
+                }
+            }
+        };
+        auto load = [&](int bb, Rows &v) {  // (ONE wave-uniform branch around the loads, both sides loading the same registers)
+            if ((bb + 1) * D <= K) load_rows(std::false_type{}, bb, v);
+            else load_rows(std::true_type{}, bb, v);
+        };
+        auto convert_t = [&](auto lin_tag, int bb, const Rows &v) {
+            constexpr bool LIN = decltype(lin_tag)::value;
+            R *gb = gin + ((size_t)(bb % 3) * NGR * BLOCK + tid) * 4 * NM;
+            R *ub = uu + ((size_t)(bb % 3) * NGR * BLOCK + tid) * 4 * NU;
+#pragma unroll
+            for (int jg = 0; jg < GP; ++jg) {
+                const int g = jg * DCS_PRE + pw;
+                R in4[4 * NM], u4[4 * NU];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int j = jg * 4 + s4;
+                    R act[MAX_ACT] = {R(0), R(0), R(0), R(0), R(0), R(0)};
+                    uint32_t dact = 0;
+                    if (DISCRETE) {
+                        dact = v.d[j];
+                        bad |= ((int64_t)bb * D + 4 * g + s4 < K) & (dact >= (uint32_t)ConvTraits<CONV>::NACTIONS);
+                        dact &= (uint32_t)(ConvTraits<CONV>::NACTIONS - 1);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NACT; ++i) act[i] = v.f[j][i];
+                    }
+                    R u[MAX_U] = {R(0), R(0), R(0), R(0)};
+                    ST::input_voltages(P, act, dact, u);
+                    R in[NM];
+                    elec_input<SYS, R, LIN>(P, om, u, LIN ? linc : nullptr, in);
+#pragma unroll
+                    for (int i = 0; i < NM; ++i) in4[s4 * NM + i] = in[i];
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) u4[s4 * NU + i] = u[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4 * NM; ++i) gb[(size_t)g * BLOCK * 4 * NM + i] = in4[i];
+#pragma unroll
+                for (int i = 0; i < 4 * NU; ++i) ub[(size_t)g * BLOCK * 4 * NU + i] = u4[i];
+            }
+        };
+        auto convert = [&](int bb, const Rows &v) {
+            if (LINABLE && lin_ok) convert_t(std::bool_constant<LINABLE>{}, bb, v);
+            else convert_t(std::false_type{}, bb, v);
+        };
+        // NPF register sets: block b + NPF is requested while block b + 1 is converted.  Loads and conversions are issued UNCONDITIONALLY --
+        // blocks past the end re-read the last row and convert into a buffer nobody reads any more: inside a conditional the compiler's
+        // vmcnt bookkeeping falls back to waiting for the loads it has just issued.
+        constexpr int NPF = DCS_PREFETCH;
+#ifdef GEMX_TIMING
+        unsigned long long ptl = 0, ptb = 0;
+#endif
+        Rows S_[NPF];
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) load(q, S_[q]);
+        convert(0, S_[0]);
+        __syncthreads();
+        auto iteration = [&](int b, Rows &free_set, const Rows &next_set, bool fetch) {
+#ifdef GEMX_TIMING
+            const unsigned long long l0 = clock64();
+#endif
+            if (fetch) load(b + NPF, free_set);  // (compile-time constant at both call sites)
+            convert(b + 1, next_set);
+#ifdef GEMX_TIMING
+            const unsigned long long l1 = clock64();
+#endif
+            __syncthreads();
+#ifdef GEMX_TIMING
+            ptl += l1 - l0; ptb += clock64() - l1;
+#endif
+        };
+        int b0 = 0;
+        for (; b0 + NPF <= nb; b0 += NPF) {  // iteration b: set b % NPF is free (block b was converted an iteration ago)
+#pragma unroll
+            for (int q = 0; q < NPF; ++q) iteration(b0 + q, S_[q], S_[(q + 1) % NPF], true);
+        }
+#pragma unroll
+        for (int q = 0; q < NPF - 1; ++q)  // the last nb % NPF iterations: nothing left to request
+            if (b0 + q < nb) iteration(b0 + q, S_[q], S_[(q + 1) % NPF], false);
+#ifdef GEMX_TIMING
+        if (tid == 0 && blockIdx.x == 0 && pw == 0) {
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64);
+            dbg[12] = ptl; dbg[13] = ptb;
+        }
+#endif
+        if (bad) atomicOr(a.err, 1u);
+    } else {
+        // ------------------------------------------------------------------ output: observation row + done flag, one block behind
+        constexpr int GPW = NGR / DCS_OUT;  // groups per output wave and block: groups j * DCS_OUT + ow
+        static_assert(NGR % DCS_OUT == 0, "groups per output wave");
+        const int ow = dcs_output_index(wave);
+        struct __attribute__((packed, aligned(4))) Row { R v[NOUT]; };
+        const bool has_done = a.done != nullptr;
+        auto observe_row = [&](const R *xr, const R *ur, R (&obs)[NOUT]) -> bool {
+            R y[ND], ho[ST::NH];
+            y[0] = om;
+#pragma unroll
+            for (int i = 0; i < NM; ++i) y[1 + i] = xr[i];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) ho[i] = ur[i];
+            ST::observe(P, y, AngT(0), ho, obs);
+            return ST::state_violation(P, y, ho) > thr_done;
+        };
+        auto emit = [&](const R *xr, const R *ur, R *orow) -> bool {  // (tail blocks: the lane's row straight from registers)
+            R obs[NOUT];
+            const bool done = observe_row(xr, ur, obs);
+            Row row;
+#pragma unroll
+            for (int i = 0; i < NOUT; ++i) row.v[i] = obs[i];
+            *reinterpret_cast<Row *>(orow) = row;
+            return done;
+        };
+        R *obase = a.obs + ((int64_t)(4 * ow) * N + env) * NOUT;  // this lane's row of this wave's first step
+        const int64_t ostride = N * NOUT;
+        // done bytes of a group of four steps in ONE store: lane l writes bytes 4 (l % 16) .. + 3 of step l / 16
+        const int dq = tid >> 4, dc = tid & 15;
+        uint8_t *dlane = has_done ? a.done + (int64_t)(4 * ow + dq) * N + blk0 + 4 * dc : nullptr;
+        auto process = [&](int pb) {
+            const int sb = steps_of(pb);
+            const R *hb = hand + ((size_t)(pb & 1) * NGR * BLOCK + tid) * 4 * NM;
+            const R *ub = uu + ((size_t)(pb % 3) * NGR * BLOCK + tid) * 4 * NU;
+            R *ob = obase + (int64_t)pb * D * ostride;
+            if (sb == D) {  // whole block: all LDS reads of this wave's groups first, then row after row without a branch
+                R xs[GPW][4 * NM], us[GPW][4 * NU];
+#pragma unroll
+                for (int jg = 0; jg < GPW; ++jg) {
+                    const int g = jg * DCS_OUT + ow;
+#pragma unroll
+                    for (int i = 0; i < 4 * NM; ++i) xs[jg][i] = hb[(size_t)g * BLOCK * 4 * NM + i];
+#pragma unroll
+                    for (int i = 0; i < 4 * NU; ++i) us[jg][i] = ub[(size_t)g * BLOCK * 4 * NU + i];
+                }
+#pragma unroll
+                for (int jg = 0; jg < GPW; ++jg) {
+                    const int r0 = 4 * jg * DCS_OUT;  // first row of the group, relative to this wave's first row
+                    unsigned long long m[4];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+                        m[s4] = __ballot(emit(&xs[jg][s4 * NM], &us[jg][s4 * NU], ob + (int64_t)(r0 + s4) * ostride));
+                    if (has_done) {
+                        const unsigned long long mq = dq == 0 ? m[0] : (dq == 1 ? m[1] : (dq == 2 ? m[2] : m[3]));
+                        const uint32_t nib = (uint32_t)(mq >> (4 * dc)) & 15u;
+                        const uint32_t bytes = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
+                        *reinterpret_cast<uint32_t *>(dlane + ((int64_t)pb * D + r0) * N) = bytes;
+                    }
+                }
+            } else {
+#pragma nounroll
+                for (int jg = 0; jg < GPW; ++jg) {
+                    const int g = jg * DCS_OUT + ow;
+#pragma nounroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int r = 4 * g + s4;  // row within the block
+                        if (r < sb) {
+                            R xr[NM], ur[NU];
+#pragma unroll
+                            for (int i = 0; i < NM; ++i) xr[i] = hb[(size_t)g * BLOCK * 4 * NM + s4 * NM + i];
+#pragma unroll
+                            for (int i = 0; i < NU; ++i) ur[i] = ub[(size_t)g * BLOCK * 4 * NU + s4 * NU + i];
+                            const int64_t k = (int64_t)pb * D + r;
+                            const bool done = emit(xr, ur, a.obs + (k * N + env) * NOUT);
+                            if (has_done) a.done[k * N + env] = done ? 1 : 0;
+                        }
+                    }
+                }
+            }
+        };
+        __syncthreads();
+#ifdef GEMX_TIMING
+        unsigned long long tp = 0, tq = 0;
+#endif
+        for (int b = 0; b < nb; ++b) {
+#ifdef GEMX_TIMING
+            const unsigned long long q0 = clock64();
+#endif
+            if (b >= 1) process(b - 1);
+#ifdef GEMX_TIMING
+            const unsigned long long q1 = clock64();
+#endif
+            __syncthreads();
+#ifdef GEMX_TIMING
+            tp += q1 - q0; tq += clock64() - q1;
+#endif
+        }
+        process(nb - 1);
+#ifdef GEMX_TIMING
+        if (tid == 0 && blockIdx.x == 0 && ow < 3) {
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64);
+            dbg[6 + 2 * ow] = tp; dbg[7 + 2 * ow] = tq;
+        }
+#endif
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host launcher
 // ------------------------------------------------------------------------------------------------
 // I/O block depth S (control steps staged in LDS between global-memory bursts): as deep as the LDS allows for the
@@ -2656,6 +3078,31 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     const bool need_full = h->cfg.supply_kind != GEMX_SUPPLY_IDEAL || h->cfg.init_kind != GEMX_INIT_CONST;
     // (fp32 only: the fp64 build is a diagnostic of the same device functions and takes the single-wave kernel, which keeps its
     // translation units three times smaller)
+    // small batches of the DC machines behind a constant-speed load: dc_stream_kernel, up to one workgroup per TWO CUs (8192 envs): there it
+    // already writes 5 TB/s, and beyond the pipelined kernel's 16-byte-aligned row stores use the write path better (same-box sweep,
+    // PermExDc, us per 1000 steps at 4096 / 8192 / 12288 / 16384 envs: 39 / 41 / 88 / 94 against 71 / 72 / 72 / 72; tools/ab_dc_stream.py)
+    if constexpr (sizeof(R) == 4 && LOAD == GEMX_LOAD_CONST_SPEED && !IL &&
+                  (SYS == GEMX_SYS_DC_PERMEX || SYS == GEMX_SYS_DC_SERIES || SYS == GEMX_SYS_DC_SHUNT || SYS == GEMX_SYS_DC_EXTEX)) {
+        const bool dcs_ok = pipe_ok && h->use_dc_stream != 0 && !need_full && delay == 0 && h->cur_reward == nullptr && h->omega_is_init &&
+                            params_of<R>(h).obs_layout == GEMX_OBS_AOS && params_of<R>(h).t_il == R(0) &&
+                            (h->use_dc_stream > 1 || 2 * blocks <= (int64_t)h->n_cu) && dcs_smem_bytes<SYS, CONV>() <= h->lds_max;
+        if (dcs_ok) {
+            auto dkern = dc_stream_kernel<SYS, CONV, SOLVER, R>;
+            if (!h->dcs_attr_set) {
+                GEMX_HIP_TRY(hipFuncSetAttribute((const void *)dkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max));
+                h->dcs_attr_set = true;
+            }
+            a.S = DCS_D;
+            a.D = DCS_D;
+            // (more than half the LDS: ONE workgroup per CU, else the dispatcher stacks two on one CU while others idle and their
+            // integrator waves share issue slots -- 41 -> 88 us per 1000 steps between 8192 and 12288 envs)
+            const size_t dneed = dcs_smem_bytes<SYS, CONV>(), dhalf = (size_t)h->lds_max / 2 + 1024, dsmem = dneed > dhalf ? dneed : dhalf;
+            hipLaunchKernelGGL(dkern, dim3((unsigned)blocks), dim3(DCS_WAVES * BLOCK), dsmem, st, a);
+            GEMX_HIP_TRY(hipGetLastError());
+            h->ll = {3, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), DCS_D, DCS_WAVES * BLOCK, K, DCS_D, (long long)blocks, dsmem};
+            return GEMX_OK;
+        }
+    }
     if constexpr (sizeof(R) == 4) if (pipe_ok) {
         using ST = Stepper<SYS, conv_base<CONV>(), LOAD, SOLVER, IL, R>;
         const int NHT = SysTraits<SYS>::ND + (SysTraits<SYS>::HAS_ANGLE ? 1 : 0) + ST::NH + 1 + (need_full ? 1 : 0);

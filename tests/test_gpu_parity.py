@@ -332,7 +332,8 @@ def test_full_size_configs_against_oracle(env_id, n_envs, solver):
         acts = torch.rand((K, n_envs, ps._n_act), device="cuda", generator=g) * 2 - 1
     obs, done = env.rollout(acts)
     torch.cuda.synchronize()
-    assert "advance_pipe_kernel" in ps.last_launch()  # the kernel the bench measures
+    # the kernel the bench measures (BASELINE config 2, a small batch of a DC machine behind a constant-speed load: dc_stream_kernel)
+    assert ("dc_stream_kernel" if "PermExDc" in env_id else "advance_pipe_kernel") in ps.last_launch()
     assert torch.isfinite(obs).all()
     # single-step path must give the same bits as the fused path (incl. the auto-reset)
     env2 = ga.make(env_id, n_envs=n_envs, ode_solver=sol, tau=1e-4, **mkw)
@@ -414,7 +415,8 @@ def test_multi_converter_envs_per_env_actions_against_oracle(env_id, golden, til
         acts = torch.rand((K, n_envs, ps._n_act), device="cuda", generator=g) * 2 - 1
     obs, _ = env.rollout(acts)
     torch.cuda.synchronize()
-    assert "advance_pipe_kernel" in ps.last_launch()
+    # (the ExtExDc envs here sit behind a ConstantSpeedLoad without dead time: a small batch of them takes dc_stream_kernel)
+    assert ("dc_stream_kernel" if ("ExtExDc" in env_id and not til) else "advance_pipe_kernel") in ps.last_launch()
     assert torch.isfinite(obs).all()
     env2 = mk()
     for k in range(4):
@@ -1381,3 +1383,86 @@ def test_single_step_launches_replay_from_a_hip_graph_bit_identically():
         assert torch.equal(obs2, eager[4 + 8 * (r + 1) - 1])
     env1.close()
     env2.close()
+
+
+@pytest.mark.parametrize("env_id", ["Cont-CC-PermExDc-v0", "Finite-CC-PermExDc-v0", "Cont-CC-SeriesDc-v0", "Finite-SC-SeriesDc-v0", "Cont-CC-ShuntDc-v0",
+                                    "Finite-CC-ShuntDc-v0", "Cont-CC-ExtExDc-v0", "Finite-CC-ExtExDc-v0"])
+@pytest.mark.parametrize("solver", ["euler", "rk4", "rk4_nolinmap", "dp5"])
+def test_dc_stream_kernel_is_bit_identical_to_the_pipelined_kernel(env_id, solver, monkeypatch):
+    """Small batches of the DC machines behind a ConstantSpeedLoad take dc_stream_kernel (pre waves: converter + input term; integrator:
+    the recurrence alone; output waves: observation row + done flag, stored from registers).  It calls the device functions the other
+    kernels call on the same values: observations, done masks and the final state are bit-identical to advance_pipe_kernel's -- over
+    launches with whole blocks, a tail block, fewer steps than a block, continuation across launches, and auto-resets (random actions
+    drive the currents over their limits).  After gemx_set_state (omega may differ from its initial value) the general kernels serve
+    the handle until the next full reset."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    n = 192
+    sol = dict(euler=ga.EulerSolver, rk4=ga.RK4Solver, rk4_nolinmap=ga.RK4Solver, dp5=ga.DormandPrince5Solver)[solver]
+
+    def run(stream):
+        monkeypatch.setenv("GEMX_DC_STREAM", stream)
+        if solver == "rk4_nolinmap":
+            monkeypatch.setenv("GEMX_LINMAP", "0")
+        else:
+            monkeypatch.delenv("GEMX_LINMAP", raising=False)
+        env = ga.make(env_id, n_envs=n, ode_solver=sol(), tau=1e-4, load=ga.ConstantSpeedLoad(omega_fixed=60.0))
+        ps = env.physical_system
+        env.reset()
+        g = torch.Generator(device="cuda").manual_seed(23)
+        outs, kernels = [], []
+        for K in (120, 57, 24, 25, 7, 2):
+            if ps._discrete:
+                nflat = int(np.prod(ps.action_space.nvec)) if hasattr(ps.action_space, "nvec") else int(ps.action_space.n)
+                acts = torch.randint(0, nflat, (K, n), device="cuda", generator=g, dtype=torch.uint8)
+            else:
+                acts = torch.rand((K, n, ps._n_act), device="cuda", generator=g, dtype=torch.float32) * 3 - 1.5  # (beyond the duty-cycle clip too)
+            obs, done = env.rollout(acts)
+            outs += [obs.cpu().numpy().copy(), done.cpu().numpy().copy()]
+            kernels.append(ps.last_launch())
+        outs.append(ps.get_state().cpu().numpy().copy())
+        # omega moved away from its initial value: the general kernels until the next full reset
+        y = ps.get_state().clone()
+        y[0] += 1.0
+        ps.set_state(y)
+        acts = torch.zeros((30, n), device="cuda", dtype=torch.uint8) if ps._discrete else torch.zeros((30, n, ps._n_act), device="cuda")
+        obs, done = env.rollout(acts)
+        outs += [obs.cpu().numpy().copy(), done.cpu().numpy().copy()]
+        kernels.append(ps.last_launch())
+        env.reset()
+        obs, done = env.rollout(acts)
+        outs += [obs.cpu().numpy().copy(), done.cpu().numpy().copy()]
+        kernels.append(ps.last_launch())
+        env.close()
+        return outs, kernels
+
+    a, ka = run("1")
+    b, kb = run("0")
+    assert all("dc_stream_kernel" in k for k in ka[:6]) and "dc_stream_kernel" not in ka[6] and "dc_stream_kernel" in ka[7], ka
+    assert not any("dc_stream_kernel" in k for k in kb), kb
+    if "PermExDc" in env_id:
+        assert a[1].any(), "the rollout should contain terminations"
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x, y), (i, np.abs(x.astype(np.float64) - y.astype(np.float64)).max())
+
+
+def test_dc_stream_kernel_flags_an_invalid_discrete_action():
+    """the pre waves validate discrete action indices as the loader wave of the pipelined kernel does (converters.py:204-206)"""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    env = ga.make("Finite-CC-PermExDc-v0", n_envs=128, ode_solver=ga.EulerSolver(), tau=1e-4)
+    ps = env.physical_system
+    env.reset()
+    acts = torch.randint(0, 4, (50, 128), device="cuda", dtype=torch.uint8)
+    env.rollout(acts)
+    assert "dc_stream_kernel" in ps.last_launch()
+    ps.check_errors()
+    acts[37, 99] = 4
+    env.rollout(acts)
+    with pytest.raises(Exception):
+        ps.check_errors()
+    env.close()
