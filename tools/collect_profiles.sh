@@ -11,13 +11,14 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/${TAG}_bench.log 2>&1
 tail -1 $OUT/${TAG}_bench.log > $OUT/${TAG}_bench.json
+ksub() { [ "$1" = permexdc ] && echo dc_stream || echo advance; }  # the dominant kernel of a workload (config 2: dc_stream_kernel)
 for WL in pmsm permexdc scim scim_constspeed; do
   rm -rf /tmp/ks_$WL
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$WL -- python $R/bench.py --no-extras --workload $WL > /tmp/ks_$WL.log 2>&1
   grep "^{\"metric\"" /tmp/ks_$WL.log | tail -1 > $OUT/${TAG}_bench_under_rocprof_$WL.json
   cp $(find /tmp/ks_$WL -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats_$WL.csv
   # (the stats file averages over the settle and warm-up launches too: the timed region = the last 20 dispatches of the trace)
-  python $R/tools/trace_tail_stats.py /tmp/ks_$WL advance 20 > $OUT/${TAG}_bench_kernel_timed_region_$WL.txt 2>&1
+  python $R/tools/trace_tail_stats.py /tmp/ks_$WL $(ksub $WL) 20 > $OUT/${TAG}_bench_kernel_timed_region_$WL.txt 2>&1
 done
 # a SHORT launch (20 control steps per launch): kernel-trace durations vs the HIP-event figure
 rm -rf /tmp/ks_short
@@ -29,12 +30,12 @@ for WL in pmsm permexdc scim scim_constspeed; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_$c
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --no-extras --workload $WL --steps 5 --warmup 2 --settle-ms 0 > /tmp/pmc_$c.log 2>&1
-    echo "$WL $c $(python $R/tools/pmc_sum.py /tmp/pmc_$c advance)" >> $OUT/${TAG}_pmc_raw.txt
+    echo "$WL $c $(python $R/tools/pmc_sum.py /tmp/pmc_$c $(ksub $WL))" >> $OUT/${TAG}_pmc_raw.txt
   done
 done
 for WL in pmsm scim permexdc; do
   rm -rf /tmp/pmc_sq
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d /tmp/pmc_sq -- python $R/bench.py --no-extras --workload $WL --steps 5 --warmup 2 --settle-ms 0 > /tmp/pmc_sq.log 2>&1
-  python $R/tools/pmc_sum.py /tmp/pmc_sq advance | sed "s/^/$WL SQ /" >> $OUT/${TAG}_pmc_raw.txt
+  python $R/tools/pmc_sum.py /tmp/pmc_sq $(ksub $WL) | sed "s/^/$WL SQ /" >> $OUT/${TAG}_pmc_raw.txt
 done
 python $R/tools/bench_matrix.py > $OUT/${TAG}_matrix.md 2>/dev/null

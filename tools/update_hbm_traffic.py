@@ -23,7 +23,7 @@ def main():
     vals = {}
     for line in open(raw):
         m = re.match(r"(\w+) (FETCH_SIZE|WRITE_SIZE) .*?(FETCH_SIZE|WRITE_SIZE)\s+([0-9.]+)\s+\((\d+) dispatches\)", line.strip())
-        if m and "advance" in line:
+        if m and ("advance" in line or "dc_stream" in line):
             vals.setdefault(m.group(1), {})[m.group(2)] = float(m.group(4))
     path = os.path.join(REPO, "profiles", "hbm_traffic.json")
     out = json.load(open(path)) if os.path.exists(path) else {}
