@@ -1466,3 +1466,34 @@ def test_dc_stream_kernel_flags_an_invalid_discrete_action():
     with pytest.raises(Exception):
         ps.check_errors()
     env.close()
+
+
+DC_STREAM_GOLDEN = ["permexdc_epi_held_euler", "permexdc_epi_uniform_euler", "permexdc_free_uniform_10k_euler", "permexdc_free_held_euler",
+                    "permexdc_fin_epi_held_euler", "permexdc_fin_free_held_euler", "extex_cont_epi_held_euler", "extex_cont_free_uniform_euler",
+                    "extex_fin_epi_held_euler", "extex_fin_free_uniform_euler"]
+
+
+@pytest.mark.parametrize("name", [c for c in DC_STREAM_GOLDEN if c in CASES])
+def test_dc_stream_kernel_matches_reference_trajectories(name):
+    """The reference's own recorded runs of the DC machines behind a ConstantSpeedLoad (same integrator: Euler), at a batch size that
+    takes dc_stream_kernel: fp32 within 1e-4 of the reference, episode by episode, exact done masks (margin-guarded)."""
+    import torch
+
+    d, meta = _load(name)
+    n_envs = 128
+    env = _make_from_meta(meta, n_envs, dtype="float32", auto_reset=True)
+    ps = env.physical_system
+    acts = d["actions"]
+    K = acts.shape[0]
+    a = torch.as_tensor(np.repeat(acts.reshape(K, 1, -1), n_envs, axis=1))
+    if ps._discrete and acts.ndim == 1:
+        a = a.reshape(K, n_envs)
+    obs, done = env.rollout(a.cuda())
+    torch.cuda.synchronize()
+    assert "dc_stream_kernel" in ps.last_launch(), ps.last_launch()
+    obs = obs.double().cpu().numpy()
+    done = done.cpu().numpy().astype(bool)
+    env.close()
+    assert np.array_equal(obs[:, 0], obs[:, n_envs - 1]) and np.array_equal(done[:, 0], done[:, 77])
+    rel, ab, col, dmsg = compare_trajectory(meta, d, obs[:, 0], done[:, 0], min_fraction=0.5)
+    assert rel < 1e-4, (rel, ab, col, dmsg)
