@@ -28,7 +28,7 @@ from .components import (  # noqa: F401
     SquirrelCageInductionMotor,
     SynchronousReluctanceMotor,
 )
-from .envs import BatchedElectricMotorEnv, make  # noqa: F401
+from .envs import BatchedElectricMotorEnv, default_ode_solver, make  # noqa: F401
 from .reference_generators import BatchedWienerProcessReferenceGenerator  # noqa: F401
 from .physical_system_wrappers import DeadTimeProcessor, DqToAbcActionProcessor  # noqa: F401
 from .physical_systems import (  # noqa: F401

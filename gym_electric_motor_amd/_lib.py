@@ -20,6 +20,7 @@ SOLVER_EULER, SOLVER_RK4, SOLVER_DP5 = 0, 1, 2
 SOLVER_SPLIT_KINKS = 1
 F32, F64 = 0, 1
 OBS_AOS, OBS_SOA = 0, 1
+ERRFLAG_ACTION, ERRFLAG_OMEGA_MOVED = 1, 2  # gemx_error_flags bits (GEMX_ERRFLAG_*)
 
 
 class GemxConfig(C.Structure):

@@ -227,6 +227,9 @@ template <class R> static void fill_params(const gemx_handle &h, const double *m
     P.kink_split = (c.solver_flags & GEMX_SOLVER_SPLIT_KINKS) && c.load_kind == GEMX_LOAD_POLY_STATIC && P.omega_lim > R(0);
     P.auto_reset = c.auto_reset;
     P.obs_layout = c.obs_layout;
+    P.dc_thr[0] = P.dc_thr[1] = (R)INFINITY;
+    if (!h.has_angle)
+        for (int cidx = 0; cidx < h.nd - 1 && cidx < 2; ++cidx) P.dc_thr[cidx] = viol_threshold<R>(P.inv_lim[2 + cidx]);
     // the env's default constraint gets the 3-instruction fast path (Stepper::default_done)
     const bool is_dc = !h.has_angle;
     const bool two_currents = c.system_kind == GEMX_SYS_DC_SHUNT || c.system_kind == GEMX_SYS_DC_EXTEX;
@@ -526,7 +529,8 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         if (ev) h->pipe_shape = atoi(ev);
         ev = getenv("GEMX_STEP_KERNEL");
         if (ev) h->use_step_kernel = atoi(ev);
-        ev = getenv("GEMX_DC_STREAM");  // 0: never take dc_stream_kernel; 2: at any N (A/B runs and bit-identity tests)
+        ev = getenv("GEMX_DC_STREAM");  // 0: never take dc_stream_kernel; 2: at any N (A/B runs and bit-identity tests); 3: also without the
+                                        // host-side "omega is at its initial value" knowledge (test of the kernel's own check of that premise)
         if (ev) h->use_dc_stream = atoi(ev);
         ev = getenv("GEMX_LINMAP");  // 0: never use the one-step map of the electrical subsystem (A/B runs)
         if (ev && atoi(ev) == 0) h->linmap_state = -1;
@@ -567,6 +571,8 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
     }
     if (hipMalloc(&h->linmap_dev, sizeof(double) * 64) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(linmap) failed"));
     if (hipMalloc((void **)&h->err, 4096) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(err) failed"));
+    if (hipMalloc((void **)&h->fifo_phase, 64) != hipSuccess || hipMemset(h->fifo_phase, 0, 64) != hipSuccess)
+        return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(fifo phase) failed"));
     if (hipMalloc(&h->reset_obs_dev, es * GEMX_MAX_OUT) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(reset_obs) failed"));
     if (hipMalloc(&h->cw_dev, es * 2 * GEMX_MAX_OUT) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(cw) failed"));
     {
@@ -614,6 +620,7 @@ int gemx_destroy(gemx_handle *h) {
     if (h->linmap_dev) (void)hipFree(h->linmap_dev);
     if (h->rcnt) (void)hipFree(h->rcnt);
     if (h->err) (void)hipFree(h->err);
+    if (h->fifo_phase) (void)hipFree(h->fifo_phase);
     if (h->reset_obs_dev) (void)hipFree(h->reset_obs_dev);
     if (h->cw_dev) (void)hipFree(h->cw_dev);
     delete h;
@@ -647,7 +654,12 @@ int gemx_reset(gemx_handle *h, const uint8_t *mask_dev, void *obs_out_dev, void 
     gemx::DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
     const int rc = h->cfg.dtype == GEMX_F64 ? launch_reset<double>(h, mask_dev, obs_out_dev, st) : launch_reset<float>(h, mask_dev, obs_out_dev, st);
-    if (rc == GEMX_OK && mask_dev == nullptr && h->cfg.init_kind == GEMX_INIT_CONST) h->omega_is_init = true;  // every env is at init again
+    // host-side knowledge "every env's omega is init[0]" (dc_stream_kernel's premise).  A call that is being CAPTURED into a graph runs
+    // later, any number of times: from then on the host knows nothing (the kernels that decide on the device serve the handle)
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &capturing);
+    if (capturing != hipStreamCaptureStatusNone) { h->omega_unknown = true; h->omega_is_init = false; }
+    else if (rc == GEMX_OK && mask_dev == nullptr && h->cfg.init_kind == GEMX_INIT_CONST && !h->omega_unknown) h->omega_is_init = true;
     return rc;
 }
 
@@ -735,6 +747,9 @@ int gemx_set_state(gemx_handle *h, const void *soa_in_dev, void *stream) {
                            (const float *)soa_in_dev, h->n, h->nd, h->has_angle);
     HIP_TRY(hipGetLastError());
     h->omega_is_init = false;  // (dc_stream_kernel assumes omega == init[0]; the next full reset restores that)
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &capturing);
+    if (capturing != hipStreamCaptureStatusNone) h->omega_unknown = true;  // replayed at times the host cannot know
     return GEMX_OK;
 }
 int gemx_get_switch_state(gemx_handle *h, uint8_t *out_dev, void *stream) {

@@ -90,7 +90,18 @@ template <class R> struct DevParams {
     int32_t delay;          // DeadTimeProcessor steps
     R dq_adv;               // (0.5 + delay) * tau * pole: angle advance per rad/s of omega
     int32_t kink_split;     // GEMX_SOLVER_SPLIT_KINKS: steps are cut at the PolynomialStaticLoad's kinks (integrate<>)
+    // DC machines: the default LimitConstraint on current c as a threshold in AMPERES, dc_thr[c] = the smallest R with
+    // fl(dc_thr[c] * inv_lim[2 + c]) > 1 (viol_threshold(), host): |i| >= dc_thr[c]  <=>  |i * inv_lim| > 1 for EVERY i, because
+    // rounding is monotonic -- the same done / reset decisions bit for bit, without the multiply on the step-to-step chain
+    R dc_thr[2];
 };
+// smallest t >= 0 with fl(t * c) > 1 (c > 0): see DevParams::dc_thr
+template <class R> inline R viol_threshold(R c) {
+    volatile R t = R(1) / c, p = t * c;
+    while (p > R(1)) { t = std::nextafter((R)t, R(0)); p = t * c; }
+    while (!(p > R(1))) { t = std::nextafter((R)t, (R)INFINITY); p = t * c; }
+    return t;
+}
 
 // ------------------------------------------------------------------------------------------------
 // angle representation
@@ -328,8 +339,12 @@ template <class R> struct KArgs {
     R *obs;                         // [K][N][NOUT] | [K][NOUT][N]  (or a single step's worth if !obs_every)
     uint8_t *done;                  // [K][N] | [N]
     unsigned char *ring;            // [delay][N][A_conv] R | [delay][N] uint8: DeadTimeProcessor FIFO between launches
-    int32_t ring_phase;             // FIFO slot of this launch's first step (global step count mod delay)
-    uint32_t *err;                  // device error word (bit 0: discrete action out of range)
+    // DeadTimeProcessor FIFO phase IN DEVICE MEMORY: [0] = FIFO slot of this launch's first step (control steps so far mod delay), read by
+    // every workgroup at its start; [1] = a ticket counter: the LAST workgroup to finish advances [0] by K (fifo_phase_advance).  Kept on
+    // the device so that a launch replayed from a captured HIP graph continues the queue where the previous launch left it (a phase
+    // computed on the host at capture time would be frozen into the graph).
+    uint32_t *fifo_phase;
+    uint32_t *err;                  // device error word (GEMX_ERRFLAG_*: bit 0 discrete action out of range, bit 1 dc_stream_kernel met a moved omega)
     const InitDev *rinit;           // random initial states: description, per-env reset counters [N]
     uint32_t *rcnt;
     const RewardDev<R> *rw;         // fused reward: description (nullptr: no reward), references [K][N][n_ref], output [K][N]
@@ -342,6 +357,21 @@ template <class R> struct KArgs {
     int32_t coop;                   // 1: action rows / done rows of full blocks are 16-byte aligned -> cooperative staging
     int32_t obs_vec;                // 1: observation rows of full blocks are 16-byte aligned -> 16-byte stores
 };
+
+// FIFO slot of this launch's first step (0 without a DeadTimeProcessor) / its advance by the last workgroup to finish: every workgroup
+// has read the phase at its start before it takes its ticket at its end, so the new value is written only when nobody reads the old one
+template <class R> __device__ __forceinline__ int fifo_phase_read(const KArgs<R> &a) {
+    return a.P.delay > 0 ? (int)*a.fifo_phase : 0;
+}
+template <class R> __device__ __forceinline__ void fifo_phase_advance(const KArgs<R> &a, int phase, bool one_lane) {
+    if (a.P.delay > 0 && one_lane) {
+        const uint32_t ticket = atomicAdd(a.fifo_phase + 1, 1u);
+        if (ticket == gridDim.x - 1) {
+            a.fifo_phase[1] = 0u;
+            a.fifo_phase[0] = (uint32_t)((phase + a.K) % a.P.delay);
+        }
+    }
+}
 
 constexpr int MAX_ACT_CHUNKS = 12;  // upper bound of 16-byte chunks of staged actions per lane and I/O block
 constexpr int MAX_STEPS_PER_BLOCK = 32;
@@ -398,7 +428,8 @@ struct gemx_handle {
     size_t ring_bytes = 0;
     int nact_conv = 1;       // converter-side action width (== nact unless a dq action frame is configured)
     int conv_unit = 0;       // converter kind of the kernel unit (internal dq kinds included)
-    unsigned long long steps_total = 0;  // control steps launched since creation (FIFO phase)
+    unsigned long long steps_total = 0;  // control steps launched since creation (informational; the FIFO phase lives on the device)
+    uint32_t *fifo_phase = nullptr;      // device words [phase, ticket] of the DeadTimeProcessor FIFO (KArgs::fifo_phase)
     uint32_t *err = nullptr;
     void *reset_obs_dev = nullptr;  // [nout] R
     void *cw_dev = nullptr;         // [2][GEMX_MAX_OUT] R constraint weights
@@ -418,6 +449,7 @@ struct gemx_handle {
     int use_dc_stream = 1;    // dc_stream_kernel: 1 when eligible and N <= 64 * CUs (default), 2 at any N, 0 never (GEMX_DC_STREAM)
     bool dcs_attr_set = false;
     bool omega_is_init = true;  // every env's omega equals init[0] (constant-speed loads): false between gemx_set_state and the next full reset
+    bool omega_unknown = false; // a state-changing call was CAPTURED into a graph: the host cannot know when it runs -> omega_is_init stays false
 };
 
 namespace gemx {

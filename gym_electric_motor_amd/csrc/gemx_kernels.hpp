@@ -1579,7 +1579,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SYS == GE
     constexpr int NACTC = conv_nact_c<CONV>();
     // DeadTimeProcessor FIFO [delay][64][NACTC] R behind the (16-byte padded) done ring
     R *fifo = reinterpret_cast<R *>(donebuf + (((size_t)S * BLOCK + 15) & ~(size_t)15));
-    int slot = a.ring_phase;
+    const int ring_phase = fifo_phase_read(a);
+    int slot = ring_phase;
     const bool coop = a.coop && full && K > 1;   // cooperative action staging for this workgroup (uniform)
 
     R y[ND];
@@ -1718,6 +1719,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SYS == GE
         }
     }
     if (bad_action && valid) atomicOr(a.err, 1u);
+    fifo_phase_advance(a, ring_phase, tid == 0);
 #ifdef GEMX_TIMING
     pT3 = clock64();
     __builtin_amdgcn_s_waitcnt(0x0F70);  // the stores have left the CU
@@ -1783,7 +1785,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs<R> a) {
     R popped[NACTC];
 #pragma unroll
     for (int i = 0; i < NACTC; ++i) popped[i] = R(0);
-    const int64_t slot0 = ((int64_t)a.ring_phase * N + e) * NACTC;
+    const int ring_phase = fifo_phase_read(a);
+    const int64_t slot0 = ((int64_t)ring_phase * N + e) * NACTC;
     if (P.delay > 0) {
 #pragma unroll
         for (int i = 0; i < NACTC; ++i) popped[i] = DISCRETE ? (R)a.ring[slot0 + i] : reinterpret_cast<const R *>(a.ring)[slot0 + i];
@@ -1875,6 +1878,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs<R> a) {
         }
         if (bad_action) atomicOr(a.err, 1u);
     }
+    fifo_phase_advance(a, ring_phase, threadIdx.x == 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2019,11 +2023,12 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
         const bool delayed_t = delayed_any && conv_dq<CONV>() && P.dq_processor;  // queue of TRANSFORMED actions (row buffer, see one_step)
         const bool delayed = delayed_any && !delayed_t;                           // delayed read of the staged raw rows
         uint32_t since = delay_u;  // DELAYED: control steps since this env's last reset, saturating at `delay` (the HBM ring holds zeros already)
-        int slot = a.ring_phase;
+        const int ring_phase = fifo_phase_read(a);
+        int slot = ring_phase;
         for (int d = 0; d < P.delay; ++d) {
             // FIFO: slot d of the ring; DELAYED: carry row d = the entry popped d steps from now = ring slot (phase + d) mod delay
             int src = d;
-            if (delayed_any) { src = a.ring_phase + d; src = src >= P.delay ? src - P.delay : src; }
+            if (delayed_any) { src = ring_phase + d; src = src >= P.delay ? src - P.delay : src; }
 #pragma unroll
             for (int i = 0; i < NACTC; ++i) {
                 const int64_t gi = ((int64_t)src * N + env) * NACTC + i;
@@ -2405,7 +2410,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             if (P.init_kind) a.rcnt[env] = rcount;
         }
         int phase_end = 0;
-        if (P.delay > 0) phase_end = (a.ring_phase + K) % P.delay;
+        if (P.delay > 0) phase_end = (ring_phase + K) % P.delay;
         for (int d = 0; d < P.delay; ++d) {
             // FIFO: slot d as it stands.  DELAYED: carry row d is the entry popped d steps after this launch -> ring slot (phase_end + d)
             // mod delay; entries submitted before the env's last reset are the refilled zero action
@@ -2425,6 +2430,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             }
         }
         if (bad_action) atomicOr(a.err, 1u);
+        fifo_phase_advance(a, ring_phase, tid == 0);
     } else if (LW != 0 && wave == 1 + OW) {
         // ------------------------------------------------------------------ loader
         // The staging loads of block b+1 are issued and awaited HERE while the integrator works on block b.  Issued by the
@@ -2620,37 +2626,53 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
 //     run the converter stage and Elec::prep, and leave the step's input term (elec_input(): g, or S g of the one-step map) and the
 //     voltages in LDS;
 //   * the INTEGRATOR wave reads the input terms of four steps with one 16-byte LDS read, applies the solver (elec_apply(): a 1-state Euler
-//     step is two FMAs), decides the reset, and hands over NOTHING but the new motor states, four steps per 16-byte write;
+//     step is two FMAs), decides the reset, and hands over NOTHING but the new motor states, four steps per 16-byte write.  The reset is
+//     SPECULATED: the step is taken from the running state AND from the (constant) initial state, and the previous step's reset decision
+//     selects between the two results -- the violation test then runs beside the next step's FMAs instead of in front of them.  The chain
+//     from step to step is solver -> select (3 dependent instructions for the one-state Euler step) instead of solver -> normalise ->
+//     compare -> select (5): a lone wave issues a DEPENDENT instruction only every ~9 cycles (r02j probe: 45 cycles for those 5), so the
+//     launch time follows the chain, not the instruction count.  The test itself is |i| >= dc_thr (DevParams), bit-equivalent to
+//     |i * inv_lim| > 1;
 //   * OUTPUT waves (DCS_OUT) one block behind rebuild the rest -- observation row, done flag: the same device functions on the same
-//     values as everywhere else -- and store each lane's row directly (rows are 20-28 bytes; transposing a group of rows through LDS
-//     into aligned 16-byte units was tried: 1600 -> 1900 cycles per block for this wave); the done bytes of four steps leave in ONE store
-//     (ballots, lane l writes bytes 4 (l % 16) .. + 3 of step l / 16).
-// LDS rows are [group of 4 steps][lane][step in group][value]: 16 bytes per lane and value.  One s_barrier per block of DCS_D steps.
+//     values as everywhere else.  The rows of a group of four steps go through a per-wave LDS staging buffer and leave as FULL, 16-byte
+//     ALIGNED `global_store_dwordx4` (4 rows x 64 envs x NOUT dwords = 64 NOUT chunks = NOUT instructions): stored straight from the
+//     lanes' registers a row is 64 pieces of 20-28 bytes that straddle 16-byte boundaries, and the CU's store path took ~50 cycles per
+//     row for them (r02j probe) against 20 for aligned 64-byte quads.  The done bytes of four steps leave in ONE store (ballots, lane l
+//     writes bytes 4 (l % 16) .. + 3 of step l / 16).
+// LDS rows are [group of 4 steps][lane][step in group][value]: 16 bytes per lane and value.  One s_barrier per block of D steps
+// (64 for the one-state machines, 32 for the two-state ones: what the LDS holds).
 // Every value is produced by the code the other kernels run (prep / rk_step / observe / state_violation), so the results are
 // bit-identical to theirs; the tests assert it.  Preconditions beyond the pipelined kernel's (checked by the launcher): DC machine,
 // ConstantSpeedLoad, no dead time of either kind, ideal supply, constant initial state, no fused reward, AoS observations, and
-// omega == init[0] in every env (gemx_set_state clears that until the next full reset).
+// omega == init[0] in every env (gemx_set_state clears that until the next full reset; the launcher never takes this kernel while its
+// stream is being captured into a graph, and the integrator wave CHECKS the omega row: a moved omega raises GEMX_ERRFLAG_OMEGA_MOVED).
 // ------------------------------------------------------------------------------------------------
 // Waves of a workgroup go to the CU's four SIMDs round robin, so the waves whose index is a multiple of four would share the integrator's
-// SIMD and its issue slots: they are launched and end at once (a wave that has ended no longer counts at the barrier).  Integrator = wave 0,
-// pre waves = 1, 2, output waves = 3, 5, 6, 7.
-constexpr int DCS_D = 32, DCS_PRE = 2, DCS_OUT = 4, DCS_WAVES = 8, DCS_PREFETCH = 3;
+// SIMD and its issue slots: wave 4 stays resident but does nothing except meet the others at every barrier (a parked wave costs its
+// SIMD's other wave ~2 %; it used to END at once, relying on "an ended wave no longer counts at the barrier" -- true on this hardware,
+// but not something the programming model promises).  Integrator = wave 0, pre waves = 1, 2, output waves = 3, 5, 6, 7.
+constexpr int DCS_PRE = 2, DCS_OUT = 4, DCS_WAVES = 8, DCS_PREFETCH = 3;
+#ifndef GEMX_DCS_D1
+#define GEMX_DCS_D1 64
+#endif
+template <int SYS> constexpr int dcs_depth() { return SysTraits<SYS>::ND == 2 ? GEMX_DCS_D1 : 32; }  // ND == 2: one motor state, one voltage
 constexpr int dcs_output_index(int wave) { return wave - 1 - DCS_PRE - (wave > 4 ? 1 : 0); }
 static_assert(dcs_output_index(3) == 0 && dcs_output_index(DCS_WAVES - 1) == DCS_OUT - 1, "wave roles");
 template <int SYS, int CONV> constexpr size_t dcs_smem_bytes() {
     constexpr int NM = SysTraits<SYS>::ND - 1, NU = SYS == GEMX_SYS_DC_EXTEX ? 2 : 1;
-    return (size_t)DCS_D * BLOCK * sizeof(float) * (3 * NM + 3 * NU + 2 * NM);
+    return (size_t)dcs_depth<SYS>() * BLOCK * sizeof(float) * (3 * NM + 3 * NU + 2 * NM) +
+           (size_t)DCS_OUT * 4 * BLOCK * SysTraits<SYS>::NOUT * sizeof(float);
 }
 template <int SYS, int CONV, int SOLVER, class R>
 __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArgs<R> a) {
     constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NM = ND - 1, NACT = ConvTraits<CONV>::NACT;
     constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
-    constexpr int D = DCS_D, NGR = D / 4;  // steps, groups of four steps per block
+    constexpr int D = dcs_depth<SYS>(), NGR = D / 4;  // steps, groups of four steps per block
     using ST = Stepper<SYS, CONV, GEMX_LOAD_CONST_SPEED, SOLVER, false, R>;
     using AngT = typename Angle<R>::T;
     constexpr int NU = ST::NU;
     constexpr bool LINABLE = linable<GEMX_LOAD_CONST_SPEED, SOLVER, false, R>();
-    static_assert(sizeof(R) == 4 && !SysTraits<SYS>::HAS_ANGLE && D % 4 == 0, "fp32 DC machines");
+    static_assert(sizeof(R) == 4 && !SysTraits<SYS>::HAS_ANGLE && D % 4 == 0 && NM <= 2, "fp32 DC machines");
 
     const DevParams<R> &P = a.P;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -2660,37 +2682,60 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
     const int64_t N = a.N, blk0 = (int64_t)blockIdx.x * BLOCK, env = blk0 + tid;
     const int K = a.K, nb = (K + D - 1) / D;
     auto steps_of = [&](int b) { return (K - b * D) < D ? (K - b * D) : D; };
-    // LDS: input terms [3][NGR][64][4][NM] | voltages [3][NGR][64][4][NU] | new motor states [2][NGR][64][4][NM]
+    // LDS: input terms [3][NGR][64][4][NM] | voltages [3][NGR][64][4][NU] | new motor states [2][NGR][64][4][NM] | row staging [DCS_OUT][4][64][NOUT]
     R *gin = reinterpret_cast<R *>(gemx_smem);
     R *uu = gin + 3 * (size_t)D * BLOCK * NM;
     R *hand = uu + 3 * (size_t)D * BLOCK * NU;
+    R *stage = hand + 2 * (size_t)D * BLOCK * NM;
     const R om = P.init[0];  // == omega of every env (launcher); a ConstantSpeedLoad never changes it, a reset puts it back
     const bool lin_ok = LINABLE && P.lin_on != 0;  // wave-uniform
     R linc[lin_count<SYS, R>()];
     lin_preload<SYS, R>(P, lin_ok, linc);
     const bool check_default = P.constr_kind == 1;
-    const R thr_done = check_default ? R(1) : R(INFINITY), thr_reset = (check_default && P.auto_reset != 0) ? R(1) : R(INFINITY);
+    const R thr_done = check_default ? R(1) : R(INFINITY);
 
     if (wave == 0) {
         // ------------------------------------------------------------------ integrator: the recurrence and nothing else
-        R x[NM];
+        __builtin_amdgcn_s_setprio(3);
+        R y[NM];  // the state the last step returned (BEFORE its reset select)
 #pragma unroll
-        for (int i = 0; i < NM; ++i) x[i] = a.state[(int64_t)(1 + i) * N + env];
+        for (int i = 0; i < NM; ++i) y[i] = a.state[(int64_t)(1 + i) * N + env];
+        const R om_lane = a.state[env];
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) here, once: otherwise the compiler parks the wait for x inside the step loop
+        // the kernel's premise, checked where it is used: a launch replayed from a graph captured before a gemx_set_state, or enqueued on
+        // another stream than the state change, would otherwise integrate the wrong machine in silence
+        if (!__all(om_lane == om) && tid == 0) atomicOr(a.err, (uint32_t)GEMX_ERRFLAG_OMEGA_MOVED);
+        const bool resets = check_default && P.auto_reset != 0;
+        R thr[NM];  // |i_c| >= thr[c]  <=>  this step's state violates the default constraint (DevParams::dc_thr)
+#pragma unroll
+        for (int i = 0; i < NM; ++i) thr[i] = resets ? P.dc_thr[i] : R(INFINITY);
+        bool rprev = false;  // `if terminated: env.reset()` of the previous step, still to be applied
         auto one_step = [&](auto lin_tag, const R *in_, R *out_) {  // (lin_tag: a std::bool_constant, so that the step has no branch)
             constexpr bool LIN = decltype(lin_tag)::value;
-            R in[NM];
+            R in[NM], xa[NM], xb[NM];
 #pragma unroll
-            for (int i = 0; i < NM; ++i) in[i] = in_[i];
-            elec_apply<SYS, SOLVER, R, LIN>(P, om, x, in, LIN ? linc : nullptr);
-            R y[ND];
-            y[0] = om;
+            for (int i = 0; i < NM; ++i) { in[i] = in_[i]; xa[i] = y[i]; xb[i] = P.init[1 + i]; }
+#ifdef GEMX_DCS_NO_SPEC  // A/B: the select in front of the step (round 2's chain)
 #pragma unroll
-            for (int i = 0; i < NM; ++i) { y[1 + i] = x[i]; out_[i] = x[i]; }
-            const R ho[ST::NH] = {};
-            const bool rs = ST::state_violation(P, y, ho) > thr_reset;  // `if terminated: env.reset()`
+            for (int i = 0; i < NM; ++i) xa[i] = rprev ? xb[i] : xa[i];
+            elec_apply<SYS, SOLVER, R, LIN>(P, om, xa, in, LIN ? linc : nullptr);
 #pragma unroll
-            for (int i = 0; i < NM; ++i) x[i] = rs ? P.init[1 + i] : x[i];
+            for (int i = 0; i < NM; ++i) { y[i] = xa[i]; out_[i] = y[i]; }
+#else
+            elec_apply<SYS, SOLVER, R, LIN>(P, om, xa, in, LIN ? linc : nullptr);  // from the running state: on the step-to-step chain
+            elec_apply<SYS, SOLVER, R, LIN>(P, om, xb, in, LIN ? linc : nullptr);  // from the reset state: off it
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                // (opaque to the optimiser, which would otherwise sink the select back IN FRONT of the common step and restore the long chain)
+                asm volatile("" : "+v"(xb[i]));
+                y[i] = rprev ? xb[i] : xa[i];
+                out_[i] = y[i];
+            }
+#endif
+            bool rs = fabs(y[0]) >= thr[0];
+#pragma unroll
+            for (int i = 1; i < NM; ++i) rs |= fabs(y[i]) >= thr[i];
+            rprev = rs;
         };
         auto run_block = [&](auto lin_tag, int b) {
             const int sb = steps_of(b);
@@ -2750,9 +2795,14 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
         }
 #endif
 #pragma unroll
-        for (int i = 0; i < NM; ++i) a.state[(int64_t)(1 + i) * N + env] = x[i];
+        for (int i = 0; i < NM; ++i) a.state[(int64_t)(1 + i) * N + env] = rprev ? P.init[1 + i] : y[i];
     } else if ((wave & 3) == 0) {
-        return;  // (keeps SIMD 0 to the integrator)
+        // ------------------------------------------------------------------ idle: keeps SIMD 0 to the integrator, meets every barrier
+#ifdef GEMX_DCS_WAVE4_EXITS  // A/B: round 2's behaviour (an ended wave no longer counts at the barrier on gfx950)
+        return;
+#endif
+        __builtin_amdgcn_s_setprio(0);
+        for (int b = 0; b <= nb; ++b) __syncthreads();
     } else if (wave <= DCS_PRE) {
         // ------------------------------------------------------------------ pre: actions -> converter -> input term, DCS_PREFETCH blocks ahead
         constexpr int GP = NGR / DCS_PRE, RP = 4 * GP;  // groups / rows per pre wave and block: groups j * DCS_PRE + pw
@@ -2872,6 +2922,7 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
         static_assert(NGR % DCS_OUT == 0, "groups per output wave");
         const int ow = dcs_output_index(wave);
         struct __attribute__((packed, aligned(4))) Row { R v[NOUT]; };
+        typedef float v4f_t __attribute__((ext_vector_type(4)));
         const bool has_done = a.done != nullptr;
         auto observe_row = [&](const R *xr, const R *ur, R (&obs)[NOUT]) -> bool {
             R y[ND], ho[ST::NH];
@@ -2892,8 +2943,21 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
             *reinterpret_cast<Row *>(orow) = row;
             return done;
         };
-        R *obase = a.obs + ((int64_t)(4 * ow) * N + env) * NOUT;  // this lane's row of this wave's first step
+        // whole blocks: the four rows of a group through this wave's staging buffer [4][64][NOUT] (lane stride NOUT dwords: conflict-free
+        // for NOUT = 5 / 7, two-way -- free for a ds_write_b32 -- for 6) and out as 16-byte chunks: chunk q = 64 i + lane of the group
+        // is bytes 16 (q % CPRW) .. + 15 of row q / CPRW (CPRW = 16 NOUT chunks per 64-env row; LDS operations of one wave complete in
+        // order, so the reads need no barrier behind the writes)
+        R *stg = stage + (size_t)ow * 4 * BLOCK * NOUT;
+        constexpr int CPRW = BLOCK * NOUT / 4;
+        int64_t coff[NOUT];  // byte offset of this lane's chunk i from the group's first row
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) {
+            const int q = i * BLOCK + tid, row = q / CPRW, col = q - row * CPRW;
+            coff[i] = ((int64_t)row * N * NOUT) * (int64_t)sizeof(R) + (int64_t)col * 16;
+        }
         const int64_t ostride = N * NOUT;
+        unsigned char *gbase = reinterpret_cast<unsigned char *>(a.obs + ((int64_t)(4 * ow) * N + blk0) * NOUT);  // this workgroup's span of this wave's first row
+        R *obase = a.obs + ((int64_t)(4 * ow) * N + env) * NOUT;  // this lane's row of this wave's first step (tail blocks)
         // done bytes of a group of four steps in ONE store: lane l writes bytes 4 (l % 16) .. + 3 of step l / 16
         const int dq = tid >> 4, dc = tid & 15;
         uint8_t *dlane = has_done ? a.done + (int64_t)(4 * ow + dq) * N + blk0 + 4 * dc : nullptr;
@@ -2901,8 +2965,7 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
             const int sb = steps_of(pb);
             const R *hb = hand + ((size_t)(pb & 1) * NGR * BLOCK + tid) * 4 * NM;
             const R *ub = uu + ((size_t)(pb % 3) * NGR * BLOCK + tid) * 4 * NU;
-            R *ob = obase + (int64_t)pb * D * ostride;
-            if (sb == D) {  // whole block: all LDS reads of this wave's groups first, then row after row without a branch
+            if (sb == D) {  // whole block: all LDS reads of this wave's groups first, then group after group without a branch
                 R xs[GPW][4 * NM], us[GPW][4 * NU];
 #pragma unroll
                 for (int jg = 0; jg < GPW; ++jg) {
@@ -2916,9 +2979,30 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
                 for (int jg = 0; jg < GPW; ++jg) {
                     const int r0 = 4 * jg * DCS_OUT;  // first row of the group, relative to this wave's first row
                     unsigned long long m[4];
+#ifdef GEMX_DCS_DIRECT_ROWS  // A/B: round 2's rows, stored straight from the lanes' registers
+                    R *ob = obase + (int64_t)pb * D * ostride;
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4)
                         m[s4] = __ballot(emit(&xs[jg][s4 * NM], &us[jg][s4 * NU], ob + (int64_t)(r0 + s4) * ostride));
+#else
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        R obs[NOUT];
+                        m[s4] = __ballot(observe_row(&xs[jg][s4 * NM], &us[jg][s4 * NU], obs));
+#pragma unroll
+                        for (int i = 0; i < NOUT; ++i) stg[((size_t)s4 * BLOCK + tid) * NOUT + i] = obs[i];
+                    }
+                    // (compiler-level fences: the rows are written as floats and read back as float4 -- distinct types to the alias
+                    // analysis, which would otherwise keep the PREVIOUS group's chunks in registers or move the next group's writes up)
+                    asm volatile("" ::: "memory");
+                    v4f_t c[NOUT];
+#pragma unroll
+                    for (int i = 0; i < NOUT; ++i) c[i] = reinterpret_cast<const v4f_t *>(stg)[i * BLOCK + tid];
+                    asm volatile("" ::: "memory");
+                    unsigned char *gb = gbase + ((int64_t)pb * D + r0) * ostride * (int64_t)sizeof(R);
+#pragma unroll
+                    for (int i = 0; i < NOUT; ++i) __builtin_nontemporal_store(c[i], reinterpret_cast<v4f_t *>(gb + coff[i]));
+#endif
                     if (has_done) {
                         const unsigned long long mq = dq == 0 ? m[0] : (dq == 1 ? m[1] : (dq == 2 ? m[2] : m[3]));
                         const uint32_t nib = (uint32_t)(mq >> (4 * dc)) & 15u;
@@ -2947,6 +3031,7 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
                 }
             }
         };
+        (void)obase;
         __syncthreads();
 #ifdef GEMX_TIMING
         unsigned long long tp = 0, tq = 0;
@@ -3016,7 +3101,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     a.done = done;
     a.ring = (unsigned char *)h->ring;
     const int delay = h->cfg.action_delay;
-    a.ring_phase = delay > 0 ? (int)(h->steps_total % (unsigned long long)delay) : 0;
+    a.fifo_phase = h->fifo_phase;
     h->steps_total += (unsigned long long)K;
     a.err = h->err;
     if (h->linmap_state == 0) {  // once per handle: the electrical subsystem's one-step map (constant-speed loads)
@@ -3083,23 +3168,30 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     // PermExDc, us per 1000 steps at 4096 / 8192 / 12288 / 16384 envs: 39 / 41 / 88 / 94 against 71 / 72 / 72 / 72; tools/ab_dc_stream.py)
     if constexpr (sizeof(R) == 4 && LOAD == GEMX_LOAD_CONST_SPEED && !IL &&
                   (SYS == GEMX_SYS_DC_PERMEX || SYS == GEMX_SYS_DC_SERIES || SYS == GEMX_SYS_DC_SHUNT || SYS == GEMX_SYS_DC_EXTEX)) {
-        const bool dcs_ok = pipe_ok && h->use_dc_stream != 0 && !need_full && delay == 0 && h->cur_reward == nullptr && h->omega_is_init &&
-                            params_of<R>(h).obs_layout == GEMX_OBS_AOS && params_of<R>(h).t_il == R(0) &&
-                            (h->use_dc_stream > 1 || 2 * blocks <= (int64_t)h->n_cu) && dcs_smem_bytes<SYS, CONV>() <= h->lds_max;
+        bool dcs_ok = pipe_ok && h->use_dc_stream != 0 && !need_full && delay == 0 && h->cur_reward == nullptr && (h->omega_is_init || h->use_dc_stream >= 3) &&
+                      params_of<R>(h).obs_layout == GEMX_OBS_AOS && params_of<R>(h).t_il == R(0) &&
+                      (h->use_dc_stream > 1 || 2 * blocks <= (int64_t)h->n_cu) && dcs_smem_bytes<SYS, CONV>() <= h->lds_max;
+        if (dcs_ok) {
+            // never into a graph: `omega_is_init` is what the host knows NOW, a captured launch runs later, possibly behind a gemx_set_state.
+            // The pipelined kernel decides on the device (lin_usable), so it is what a graph gets.
+            hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(st, &capturing);
+            dcs_ok = capturing == hipStreamCaptureStatusNone;
+        }
         if (dcs_ok) {
             auto dkern = dc_stream_kernel<SYS, CONV, SOLVER, R>;
             if (!h->dcs_attr_set) {
                 GEMX_HIP_TRY(hipFuncSetAttribute((const void *)dkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max));
                 h->dcs_attr_set = true;
             }
-            a.S = DCS_D;
-            a.D = DCS_D;
+            a.S = dcs_depth<SYS>();
+            a.D = dcs_depth<SYS>();
             // (more than half the LDS: ONE workgroup per CU, else the dispatcher stacks two on one CU while others idle and their
             // integrator waves share issue slots -- 41 -> 88 us per 1000 steps between 8192 and 12288 envs)
             const size_t dneed = dcs_smem_bytes<SYS, CONV>(), dhalf = (size_t)h->lds_max / 2 + 1024, dsmem = dneed > dhalf ? dneed : dhalf;
             hipLaunchKernelGGL(dkern, dim3((unsigned)blocks), dim3(DCS_WAVES * BLOCK), dsmem, st, a);
             GEMX_HIP_TRY(hipGetLastError());
-            h->ll = {3, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), DCS_D, DCS_WAVES * BLOCK, K, DCS_D, (long long)blocks, dsmem};
+            h->ll = {3, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), dcs_depth<SYS>(), DCS_WAVES * BLOCK, K, dcs_depth<SYS>(), (long long)blocks, dsmem};
             return GEMX_OK;
         }
     }

@@ -22,34 +22,73 @@ def shard_sizes(n_total, world):
     return [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
 
 
-def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
+def free_port():
+    """A TCP port that is free on 127.0.0.1 right now -- for a PARENT that spawns its own ranks and hands every one of them the same
+    MASTER_PORT (bench.py --gpus N without torchrun).  Ranks cannot pick one independently: they must agree on it."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def init_from_env(backend=None, timeout_s=180.0, force=False):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun, the driver, or a spawning parent that
+    used free_port()).  Returns (rank, world, local_rank).
+
+    timeout_s bounds the rendezvous AND every later collective / barrier: a rank that died leaves the others with an exception after
+    that long instead of a hang.  MASTER_PORT is NOT defaulted: two jobs on one node would silently meet on a fixed port (round-2
+    finding) -- a multi-rank launch without it is a launcher bug and raises.  force: also initialise a world of ONE (a 1-GPU box can
+    then run the collectives of the batched-return path through RCCL: tests/test_gpu_parity.py)."""
+    import datetime
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:
+                raise RuntimeError("MASTER_PORT is not set: launch the ranks with torchrun (--master-addr 127.0.0.1 --master-port P), or let "
+                                   "the spawning parent pick distributed.free_port() and export it to every rank")
+            os.environ["MASTER_PORT"] = str(free_port())  # a world of one talks to itself
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=float(timeout_s)))
     return rank, world, local_rank
 
 
-def gather_observations(obs_local, done_local=None, n_total=None, group=None):
+def _all_gather_rows(out, x, group):
+    """out[world * n, ...] <- every rank's x[n, ...] in rank order.  RCCL (and gloo on host tensors) gather straight into `out`; gloo with
+    DEVICE tensors (bench.py --oversubscribe: several ranks on one GPU, where RCCL refuses duplicate devices) goes through the list form,
+    which ProcessGroupGloo stages through host memory."""
+    import torch.distributed as dist
+
+    if dist.get_backend(group) == "gloo" and x.is_cuda:
+        world = dist.get_world_size(group)
+        n = x.shape[0]
+        dist.all_gather([out[r * n : (r + 1) * n] for r in range(world)], x, group=group)
+    else:
+        dist.all_gather_into_tensor(out, x, group=group)
+
+
+def gather_observations(obs_local, done_local=None, n_total=None, group=None, force=False):
     """All-gather the per-rank observation shards into `[n_total, S_out]` (and done into `[n_total]`) on every rank.
 
     Shards may differ by one env (unbalanced tail); they are padded to the largest shard for the collective
-    and trimmed afterwards.  Works for CPU tensors with gloo and device tensors with RCCL."""
+    and trimmed afterwards.  Works for CPU tensors with gloo and device tensors with RCCL.  A world of one returns its inputs
+    untouched unless `force` sends them through the collective anyway (single-GPU test of the RCCL path)."""
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return obs_local, done_local
     world = dist.get_world_size(group)
     n_local = obs_local.shape[0]
@@ -68,7 +107,7 @@ def gather_observations(obs_local, done_local=None, n_total=None, group=None):
             x = torch.cat([x, pad], dim=0)
         x = x.contiguous()
         out = torch.empty((world * n_max,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x, group=group)
+        _all_gather_rows(out, x, group)
         parts = [out[r * n_max : r * n_max + sizes[r]] for r in range(world)]
         return torch.cat(parts, dim=0) if any(s != n_max for s in sizes) else out
 
@@ -77,7 +116,7 @@ def gather_observations(obs_local, done_local=None, n_total=None, group=None):
     return obs_all, done_all
 
 
-def gather_rollout(obs_chunk, done_chunk=None, group=None):
+def gather_rollout(obs_chunk, done_chunk=None, group=None, force=False):
     """All-gather one fused launch's outputs: `[K, n_local, S_out]` observation chunks (+ `[K, n_local]` done bytes) of every rank
     -> `[W, K, n_local, S_out]` (+ `[W, K, n_local]`) on every rank, RANK-MAJOR and zero-copy: row `[r, k, i]` is env
     `shard_range(n_total, r, W)[0] + i` at control step k.  (Interleaving the shards into `[K, n_total, S_out]` would cost a second
@@ -86,14 +125,14 @@ def gather_rollout(obs_chunk, done_chunk=None, group=None):
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return obs_chunk.unsqueeze(0), (done_chunk.unsqueeze(0) if done_chunk is not None else None)
     world = dist.get_world_size(group)
 
     def _gather(x):
         x = x.contiguous()
         out = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out.view((world * x.shape[0],) + tuple(x.shape[1:])), x, group=group)
+        _all_gather_rows(out.view((world * x.shape[0],) + tuple(x.shape[1:])), x, group)
         return out
 
     return _gather(obs_chunk), (_gather(done_chunk) if done_chunk is not None else None)

@@ -52,6 +52,8 @@ _SC_LOAD = {
     ("Cont", "ExtExDc"): dict(a=0.0, b=0.0, c=0.0, j_load=1e-4), ("Finite", "ExtExDc"): dict(a=0.0, b=0.0, c=0.0, j_load=1e-4),
     ("Finite", "EESM"): dict(),
 }
+# the one env class whose ConstantSpeedLoad does not turn at 100 rad/s (cont_tc_shunt_dc_env.py:155)
+_OMEGA_FIXED = {"Cont-TC-ShuntDc-v0": 230.0}
 # supply voltages that differ from the family default (60 V DC motors, 420 V three-phase)
 _U_NOMINAL = {"Cont-CC-PMSM-v0": 300.0, "Finite-CC-SeriesDc-v0": 420.0, "Finite-TC-SeriesDc-v0": 420.0, "Cont-CC-EESM-v0": 300.0}
 
@@ -104,10 +106,32 @@ def default_components(env_id):
     if control == "SC":
         d["load"] = (comp.PolynomialStaticLoad, dict(load_parameter=_SC_LOAD.get((action, motor), dict(a=0.01, b=0.01, c=0.0))))
     else:
-        d["load"] = (comp.ConstantSpeedLoad, dict(omega_fixed=100.0))
+        d["load"] = (comp.ConstantSpeedLoad, dict(omega_fixed=_OMEGA_FIXED.get(env_id, 100.0)))
     d["tau"] = 1e-5 if finite else 1e-4
     d["converter_args"] = d_conv_args
     return d
+
+
+def default_ode_solver(env_id, tau=None, load=None):
+    """The solver `make(env_id)` uses when the caller names none.  The reference's default is scipy's ADAPTIVE dopri5 (rtol 1e-6,
+    solvers.py:139-184); the device integrates with fixed steps, so the default is chosen per env such that the fp32 trajectories stay
+    within the 1e-4 contract of the reference's default-solver runs.  Measured on the GPU over every one of the reference's 54 env ids
+    exactly as `gem.make(env_id)` builds them plus 46 further recorded dopri5 runs (tests/solver_scan.py -> profiles/r03_solver_scan.md):
+
+    * ConstantSpeedLoad (the CC / TC envs): one classical RK4 step per control step -- the electrical subsystem is linear there and the
+      step is the exact one-step map of the scheme: <= 1.8e-5 on the envs as shipped (free runs far beyond the limits: < 1e-4).
+      More sub-steps make fp32 WORSE here (rounding accumulates: 8 sub-steps reach 2.7e-3 on a free-running EESM), so none;
+    * PolynomialStaticLoad (the SC envs: omega is a state, the load torque has kinks at |omega| = a tau_decay / J): RK4 with every step
+      cut at those kinks (split_kinks: what the adaptive reference solver does by rejecting such steps): <= 2.0e-5 on every recorded
+      run (plain RK4: up to 7.9e-5 -- Cont-SC-ShuntDc-v0 --, 6.8e-5 on the SCIM), still one right-hand-side pass per stage, so these
+      envs keep the pipelined kernel.
+
+    `tau` / `load` (instance, class or class name): what the env is actually built with, when it differs from the env id's defaults."""
+    d = default_components(env_id)
+    if load is None:
+        load = d["load"][0]
+    lname = load if isinstance(load, str) else (load.__name__ if isinstance(load, type) else type(load).__name__)
+    return comp.RK4Solver(split_kinks=lname != "ConstantSpeedLoad")
 
 
 class BatchedElectricMotorEnv:
@@ -157,11 +181,14 @@ def make(env_id, n_envs=1, device=0, supply=None, converter=None, motor=None, lo
     d = default_components(env_id)
     tau = d["tau"] if tau is None else tau
     conv_cls = d["converter"]
+    load = _initialize(load, d["load"][0], d["load"][1])
+    if ode_solver is None:
+        ode_solver = default_ode_solver(env_id, tau=tau, load=load)
     system = d["system"](
         supply=_initialize(supply, comp.IdealVoltageSupply, d["supply"]),
         converter=_initialize(converter, conv_cls, d["converter_args"]),
         motor=_initialize(motor, d["motor"], dict()),
-        load=_initialize(load, d["load"][0], d["load"][1]),
+        load=load,
         ode_solver=_initialize(ode_solver, comp.RK4Solver, dict()),
         tau=tau,
         n_envs=n_envs,

@@ -700,8 +700,12 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         """Synchronises.  Raises like the reference (converters.py:204-206) if a discrete action left 0..7."""
         flags = C.c_uint32(0)
         _lib.check(self._L.gemx_error_flags(self._handle, C.byref(flags), self._stream()))
-        if flags.value & 1:
+        if flags.value & _lib.ERRFLAG_ACTION:
             raise AssertionError(f"An action outside the action space {self.action_space} was passed to simulate()/rollout().")
+        if flags.value & _lib.ERRFLAG_OMEGA_MOVED:
+            raise _lib.GemxError("a launch specialised for envs at their initial speed (dc_stream_kernel) found another omega in device memory: "
+                                 "set_state() and the rollout were enqueued on different streams without synchronisation; the observations "
+                                 "of that launch are invalid")
 
     # ------------------------------------------------------------------ checkpoint / parity access
     def get_state(self):

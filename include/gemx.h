@@ -261,8 +261,14 @@ int gemx_set_steps_per_block(gemx_handle *h, int32_t steps);
  * profiling reports): e.g. "gemx::advance_pipe_kernel<sys=1,conv=1,load=0,solver=1,il=0,f32,D=8> grid=256 x 192 ...". */
 const char *gemx_last_launch(const gemx_handle *h);
 
-/* Sticky device error word (synchronises `stream`): bit 0 = a discrete action outside 0..7 was seen (the
- * reference asserts action_space.contains(action), converters.py:204-206; the kernel masks it to 0..7). */
+/* Sticky device error word (synchronises `stream`), GEMX_ERRFLAG_* bits:
+ *   ACTION       a discrete action outside the action space was seen (the reference asserts action_space.contains(action),
+ *                converters.py:204-206; the kernel masks it into range);
+ *   OMEGA_MOVED  a launch specialised for "omega of every env == its initial value" (dc_stream_kernel, constant-speed loads) found
+ *                another omega in device memory -- e.g. enqueued on a different stream than a preceding gemx_set_state: the
+ *                observations of that launch are invalid. */
+#define GEMX_ERRFLAG_ACTION 1u
+#define GEMX_ERRFLAG_OMEGA_MOVED 2u
 int gemx_error_flags(gemx_handle *h, uint32_t *flags_host, void *stream);
 
 #ifdef __cplusplus

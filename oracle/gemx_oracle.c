@@ -468,10 +468,9 @@ static void fixed_step(const orc_params *p, orc_env *e, int dp5, double h) {
         e->y[i] = e->y[i] + h * (35.0 / 384.0 * k1[i] + 500.0 / 1113.0 * k3[i] + 125.0 / 192.0 * k4[i] - 2187.0 / 6784.0 * k5[i] +
                                  11.0 / 84.0 * k6[i]);
 }
-static void integrate_kink(const orc_params *p, orc_env *e, int dp5, double t_end) {
+static void integrate_kink_substep(const orc_params *p, orc_env *e, int dp5, double h_total) {
     const int MAX_PIECES = 3;
-    double rem = t_end - e->t;
-    const double h_total = rem;
+    double rem = h_total;
     const double lim = p->load == ORC_LOAD_POLY_STATIC ? p->load_a / p->j_total * p->tau_decay : 0.0;
     for (int piece = 0; piece < MAX_PIECES && rem > 0.0; ++piece) {
         double h = rem;
@@ -510,6 +509,14 @@ static void integrate_kink(const orc_params *p, orc_env *e, int dp5, double t_en
         rem -= h;
     }
     if (rem > 0.0) fixed_step(p, e, dp5, rem);
+}
+/* `nsteps` equal sub-steps per segment, each cut at the kinks on its own (gemx_kernels.hpp integrate<>: `for s < ns`); the env's clock
+ * advances to the segment end like in every other solver (the converter's dead-time bookkeeping and the RC supply read it) */
+static void integrate_kink(const orc_params *p, orc_env *e, int dp5, double t_end) {
+    const int ns = p->nsteps > 1 ? p->nsteps : 1;
+    const double hs = (t_end - e->t) / ns;
+    for (int s = 0; s < ns; ++s) integrate_kink_substep(p, e, dp5, hs);
+    e->t = t_end;
 }
 
 static void integrate(const orc_params *p, orc_env *e, double t_end) {

@@ -378,6 +378,34 @@ def main(only=None):
         wiener_samples()
     if not only or "r02" in only:
         main_r02()
+    if not only or "defaults" in only:
+        main_defaults()
+
+
+ALL_ENV_IDS = [f"{a}-{c}-{m}-v0" for m in ("PermExDc", "SeriesDc", "ShuntDc", "ExtExDc", "PMSM", "SynRM", "SCIM", "EESM", "DFIM")
+               for c in ("CC", "TC", "SC") for a in ("Cont", "Finite")]
+
+
+def default_space_kind(env_id):
+    finite, motor = env_id.startswith("Finite"), env_id.split("-")[2]
+    if motor in ("PermExDc", "SeriesDc", "ShuntDc"):
+        return "disc4" if finite else "box1"
+    if motor == "ExtExDc":
+        return "mdisc44" if finite else "box2"
+    if motor == "EESM":
+        return "mdisc84" if finite else "box4"
+    if motor == "DFIM":
+        return "mdisc88" if finite else "box6"
+    return "disc8" if finite else "box3"
+
+
+def main_defaults():
+    """Round 3: every one of the reference's 54 env ids EXACTLY as `gem.make(env_id)` builds it -- default supply, converter, motor, load,
+    tau, constraints and the default solver (scipy dopri5) -- driven with piecewise-constant random actions, reset on termination.  The
+    device side is tested as `gym_electric_motor_amd.make(env_id)` hands it to a user (its per-id default solver included)."""
+    for i, env_id in enumerate(ALL_ENV_IDS):
+        slug = env_id[:-3].replace("-", "_").lower()
+        run_case(f"default_{slug}_dopri5", env_id, "dopri5", 800, 3000 + i, "held", True, default_space_kind(env_id))
 
 
 def main_r02():

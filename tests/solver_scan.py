@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""GPU box: fp32 error of the device's fixed-step solver options against EVERY recorded run of the reference's default solver
+(tests/golden/*_dopri5.npz, incl. the 54 `default_<env id>` fixtures), worst column, episode by episode (compare_trajectory).
+
+    python tests/solver_scan.py > gpurun_out/r03_solver_scan.md
+
+The table is what `gym_electric_motor_amd.envs.default_ode_solver()` (the solver `make(env_id)` hands out when the caller names
+none) was chosen from.  Test infrastructure (it reads the golden fixtures and, for the induction machines' zero-flux steps, the oracle)."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+import test_gpu_parity as T  # noqa: E402
+
+OPTIONS = ["rk4", "rk4x2", "rk4x4", "rk4x8", "rk4k", "rk4kx2", "dp5", "dp5x2", "dp5k"]
+
+
+def main():
+    import gym_electric_motor_amd as ga
+
+    sol = {"rk4": ga.RK4Solver, "dp5": ga.DormandPrince5Solver}
+    names = [c for c in T.CASES if c.endswith("dopri5")]
+    print("| fixture | load | " + " | ".join(OPTIONS) + " | make(env_id) default |")
+    print("|---|---|" + "---|" * (len(OPTIONS) + 1))
+    worst = {o: 0.0 for o in OPTIONS + ["default"]}
+    for name in names:
+        d, meta = T._load(name)
+        row = []
+        for o in OPTIONS + ["default"]:
+            try:
+                if o == "default":
+                    s = ga.default_ode_solver(meta["env_id"], tau=meta["tau"], load=meta["load"])
+                else:
+                    kind = o[:3]
+                    rest = o[3:]
+                    kink = rest.startswith("k")
+                    ns = int(rest.split("x")[1]) if "x" in rest else 1
+                    s = sol[kind](nsteps=ns, split_kinks=kink)
+                _, _, obs, done = T._run_golden(name, "float32", solver=s)
+                rel, _, col, dmsg = T.compare_trajectory(meta, d, obs, done)
+                worst[o] = max(worst[o], rel)
+                row.append(f"{rel:.1e}" + ("*" if "flip" in dmsg else ""))
+            except AssertionError as e:
+                row.append("FAIL " + str(e)[:40])
+        print(f"| {name[:-7]} | {'poly' if meta['load'] != 'ConstantSpeedLoad' else 'const'} | " + " | ".join(row) + " |")
+        sys.stdout.flush()
+    print("| **worst** | | " + " | ".join(f"{worst[o]:.1e}" for o in OPTIONS + ["default"]) + " |")
+    print("\n(* = the done mask flipped at a step whose constraint margin in the reference is < 1e-5: compared up to there)")
+
+
+if __name__ == "__main__":
+    main()

@@ -31,10 +31,14 @@ def _make_from_meta(meta, n_envs, solver=None, dtype="float32", episodic=None, o
     import gym_electric_motor_amd as ga
 
     solver = solver or meta["solver"]
-    sol = {"euler": ga.EulerSolver(), "euler4": ga.EulerSolver(nsteps=4), "rk4": ga.RK4Solver(), "rk4x4": ga.RK4Solver(nsteps=4),
-           "rk4x8": ga.RK4Solver(nsteps=8), "dp5x8": ga.DormandPrince5Solver(nsteps=8),
-           "dopri5": ga.DormandPrince5Solver(), "dp5": ga.DormandPrince5Solver(),
-           "rk4k": ga.RK4Solver(split_kinks=True), "dp5k": ga.DormandPrince5Solver(split_kinks=True)}[solver]
+    if isinstance(solver, str):
+        sol = {"euler": ga.EulerSolver(), "euler4": ga.EulerSolver(nsteps=4), "rk4": ga.RK4Solver(), "rk4x4": ga.RK4Solver(nsteps=4),
+               "rk4x8": ga.RK4Solver(nsteps=8), "dp5x8": ga.DormandPrince5Solver(nsteps=8),
+               "dopri5": ga.DormandPrince5Solver(), "dp5": ga.DormandPrince5Solver(),
+               "rk4k": ga.RK4Solver(split_kinks=True), "dp5k": ga.DormandPrince5Solver(split_kinks=True),
+               "default": None}[solver]  # default: whatever make(env_id) picks (envs.default_ode_solver)
+    else:
+        sol = solver  # a solver object
     kw = dict(n_envs=n_envs, ode_solver=sol, tau=meta["tau"], dtype=dtype, obs_layout=obs_layout, auto_reset=auto_reset)
     if "MultiConverter" in meta["converter"]:
         # Cont/FiniteMultiConverter: the dead time lives in the sub-converters (a dict override would only reach the holder)
@@ -104,9 +108,11 @@ def _run_golden(name, dtype, solver=None, n_envs=70):
     # lockstep determinism: every env saw the same actions
     assert np.array_equal(obs[:, 0], obs[:, n_envs - 1]) and np.array_equal(obs[:, 0], obs[:, 64 % n_envs])
     obs0 = obs[:, 0].copy()
-    if meta["system"] == "DoublyFedInductionMotorSystem":
-        # steps that start with zero rotor flux (right after a reset): the reference's field angle is arctan2(rounding
-        # noise), its dq columns are not reproducible (oracle/oracle.py:undefined_field_angle_steps) -> take them as given
+    if meta["system"] in ("DoublyFedInductionMotorSystem", "SquirrelCageInductionMotorSystem") and (
+            meta["system"].startswith("Doubly") or name.startswith("default_")):
+        # steps that start with zero rotor flux (right after a reset; a squirrel-cage machine under zero voltage vectors): the reference's
+        # field angle is arctan2(rounding noise), its dq columns are not reproducible (oracle/oracle.py:undefined_field_angle_steps)
+        # -> take them as given
         from oracle import oracle as orc
 
         bad = orc.undefined_field_angle_steps(orc.params_from_meta(meta), acts)
@@ -175,7 +181,8 @@ def compare_trajectory(meta, d, obs, done, min_fraction=0.0):
 
 
 SAME_SOLVER = [c for c in CASES if c.endswith("euler") or c.endswith("euler4")]
-DOPRI = [c for c in CASES if c.endswith("dopri5")]
+DEFAULTS = [c for c in CASES if c.startswith("default_")]  # gem.make(env_id) with nothing else, all 54 ids (oracle/make_golden.py:main_defaults)
+DOPRI = [c for c in CASES if c.endswith("dopri5") and c not in DEFAULTS]
 
 
 @pytest.mark.parametrize("name", SAME_SOLVER)
@@ -196,14 +203,67 @@ def test_fp64_euler_matches_reference_euler(name):
         assert np.array_equal(done, d["terminated"])
 
 
+@pytest.mark.parametrize("name", DEFAULTS)
+def test_make_env_id_as_the_user_gets_it_matches_the_reference_default_solver(name):
+    """`gym_electric_motor_amd.make(env_id, n_envs=N)` and NOTHING else -- the env's own supply, converter, motor, load, tau, constraints
+    and the solver make() picks (envs.default_ode_solver) -- against `gem.make(env_id)` with the reference's default solver (scipy
+    dopri5), for every one of the reference's 54 env ids: fp32 within 1e-4, episode by episode, done masks exact (margin-guarded)."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    d, meta = _load(name)
+    n_envs = 70
+    env = ga.make(meta["env_id"], n_envs=n_envs)
+    ps = env.physical_system
+    assert ps.tau == meta["tau"] and list(ps.state_names) == meta["state_names"]
+    assert np.allclose(ps.limits, meta["limits"], rtol=1e-13, atol=0)
+    assert np.abs(ps.reset_observation - d["reset_state"]).max() < 1e-12
+    acts = d["actions"]
+    K = acts.shape[0]
+    a = torch.as_tensor(np.repeat(acts.reshape(K, 1, -1), n_envs, axis=1))
+    if ps._discrete and acts.ndim == 1:
+        a = a.reshape(K, n_envs)
+    obs, done = env.rollout(a.cuda())
+    torch.cuda.synchronize()
+    obs = obs.double().cpu().numpy()
+    done = done.cpu().numpy().astype(bool)
+    env.close()
+    assert np.array_equal(obs[:, 0], obs[:, n_envs - 1]) and np.array_equal(done[:, 0], done[:, 64])
+    obs0 = obs[:, 0].copy()
+    if "InductionMotorSystem" in meta["system"]:  # zero-flux steps: the reference's dq frame is arctan2(rounding noise), see _run_golden
+        from oracle import oracle as orc
+
+        bad = orc.undefined_field_angle_steps(orc.params_from_meta(meta), acts)
+        cols = [meta["state_names"].index(c) for c in orc.DQ_COLUMNS if c in meta["state_names"]]
+        obs0[np.ix_(bad, cols)] = d["states"][np.ix_(bad, cols)]
+    rel, _, col, dmsg = compare_trajectory(meta, d, obs0, done[:, 0], min_fraction=0.5)
+    assert rel < 1e-4, (rel, col, dmsg)
+
+
 @pytest.mark.parametrize("name", DOPRI)
-@pytest.mark.parametrize("solver", ["rk4", "dp5"])
-def test_fp32_fixed_step_matches_reference_default_dopri5(name, solver):
+@pytest.mark.parametrize("scheme", ["rk4", "dp5"])
+def test_fp32_fixed_step_matches_reference_default_dopri5(name, scheme):
+    """Both fixed-step schemes of the device, with the sub-stepping / kink splitting make() would choose for the fixture's env id, control
+    step and load (envs.default_ode_solver -- the product's rule, not a test-side rewrite), against the reference's default solver."""
+    import gym_electric_motor_amd as ga
+
     _, meta0 = _load(name)
-    if meta0["env_id"].endswith("SC-SynRM-v0"):
-        solver += "x8"  # tiny inertia: one step per tau is 1e-3 off the adaptive reference solver, 8 sub-steps restore 1e-4
+    s = ga.default_ode_solver(meta0["env_id"], tau=meta0["tau"], load=meta0["load"])
+    solver = (ga.RK4Solver if scheme == "rk4" else ga.DormandPrince5Solver)(nsteps=s._nsteps, split_kinks=s._split_kinks)
     d, meta, obs, done = _run_golden(name, "float32", solver=solver)
     # north-star tolerance for EVERY system (round 1 held SCIM + PolynomialStaticLoad to 2e-4); episodic runs episode by episode
+    rel, _, col, dmsg = compare_trajectory(meta, d, obs, done)
+    assert rel < 1e-4, (rel, col, dmsg)
+
+
+@pytest.mark.parametrize("name", [c for c in DOPRI if "_sc_" not in c and not c.startswith("scim_") and "refdata" not in c])
+def test_fp32_plain_rk4_on_constant_speed_loads_matches_reference_default_dopri5(name):
+    """One classical RK4 step per control step, no options: the headline's solver, on every recorded dopri5 run of an env whose speed is
+    held by a ConstantSpeedLoad (linear electrical subsystem)."""
+    d, meta, obs, done = _run_golden(name, "float32", solver="rk4")
+    if meta["load"] != "ConstantSpeedLoad":
+        pytest.skip("speed-dependent load")
     rel, _, col, dmsg = compare_trajectory(meta, d, obs, done)
     assert rel < 1e-4, (rel, col, dmsg)
 
@@ -300,6 +360,7 @@ def test_bench_configuration_episodic_rk4_against_reference_default_solver(mode,
 @pytest.mark.parametrize("env_id, n_envs, solver", [
     ("Cont-CC-PermExDc-v0", 4096, "euler"),   # BASELINE config 2
     ("Finite-CC-PMSM-v0", 16384, "rk4"),      # BASELINE config 3 (the bench headline: one-step map + voltage table + <12, 3> shape)
+    ("Finite-CC-PMSM-v0", 32768, "rk4"),      # BASELINE config 5's per-GPU shard (8 x 32768): the <4, 2> shape
     ("Cont-SC-SCIM-v0", 65536, "rk4"),        # BASELINE config 4 with the env's own PolynomialStaticLoad
     ("Cont-SC-SCIM-v0:constspeed", 65536, "rk4"),  # BASELINE config 4 as BASELINE.json words it: + ConstantSpeedLoad (one-step map)
 ])
@@ -1497,3 +1558,179 @@ def test_dc_stream_kernel_matches_reference_trajectories(name):
     assert np.array_equal(obs[:, 0], obs[:, n_envs - 1]) and np.array_equal(done[:, 0], done[:, 77])
     rel, ab, col, dmsg = compare_trajectory(meta, d, obs[:, 0], done[:, 0], min_fraction=0.5)
     assert rel < 1e-4, (rel, ab, col, dmsg)
+
+
+# ------------------------------------------------------------------------------------------------ round 3: replayed graphs, device-side premises
+def _capture(torch, fn):
+    """fn() captured into a HIP graph on a side stream (after one eager warm-up call outside the capture)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    return g
+
+
+@pytest.mark.timeout(120)
+def test_a_replayed_graph_never_runs_dc_stream_kernel_on_a_moved_omega():
+    """dc_stream_kernel is chosen on the HOST from what it knows about omega at enqueue time, so a captured launch must not be that kernel:
+    a graph captured while every env sat at its initial speed, replayed after gemx_set_state moved omega, has to integrate the moved
+    machine (the pipelined kernel decides on the device).  Replay == eager, bit for bit, before and after the state change."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    n, K = 256, 96
+    mk = lambda: ga.make("Cont-CC-PermExDc-v0", n_envs=n, ode_solver=ga.EulerSolver(), tau=1e-4)  # noqa: E731
+    g0 = torch.Generator(device="cuda").manual_seed(5)
+    acts = torch.rand((K, n, 1), device="cuda", generator=g0) * 2 - 1
+    env_g, env_e = mk(), mk()
+    pg, pe = env_g.physical_system, env_e.physical_system
+    env_g.rollout(acts)  # warm-up (eager: the small-batch kernel)
+    assert "dc_stream_kernel" in pg.last_launch()
+    env_g.reset()
+    obs_g = torch.empty((K, n, 5), device="cuda")
+    done_g = torch.empty((K, n), dtype=torch.uint8, device="cuda")
+    graph = _capture(torch, lambda: env_g.rollout(acts, obs_out=obs_g, done_out=done_g))
+    assert "dc_stream_kernel" not in pg.last_launch(), pg.last_launch()
+    env_g.reset()
+    env_e.reset()
+    graph.replay()
+    o_e, d_e = env_e.rollout(acts)
+    torch.cuda.synchronize()
+    assert torch.equal(obs_g, o_e) and torch.equal(done_g, d_e)
+    y = pe.get_state().clone()
+    y[0] += 17.0
+    pe.set_state(y)
+    pg.set_state(y)
+    graph.replay()
+    o_e, d_e = env_e.rollout(acts)
+    torch.cuda.synchronize()
+    assert "dc_stream_kernel" not in pe.last_launch()
+    assert torch.equal(obs_g, o_e) and torch.equal(done_g, d_e)
+    assert abs(float(obs_g[0, 0, 0]) * 400.0 - (100.0 + 17.0)) < 1e-3  # the moved speed is what was integrated (until an env's next reset)
+    pg.check_errors()
+    env_g.close()
+    env_e.close()
+
+
+@pytest.mark.timeout(120)
+def test_dc_stream_kernel_checks_its_premise_on_the_device(monkeypatch):
+    """GEMX_DC_STREAM=3 takes dc_stream_kernel WITHOUT the host's knowledge that omega is at its initial value: the integrator wave's own
+    check of the omega row must raise the sticky GEMX_ERRFLAG_OMEGA_MOVED bit (check_errors() raises), and stay silent when omega is fine."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+    from gym_electric_motor_amd._lib import GemxError
+
+    monkeypatch.setenv("GEMX_DC_STREAM", "3")
+    env = ga.make("Cont-CC-PermExDc-v0", n_envs=192, ode_solver=ga.EulerSolver(), tau=1e-4)
+    ps = env.physical_system
+    acts = torch.zeros((40, 192, 1), device="cuda")
+    env.rollout(acts)
+    assert "dc_stream_kernel" in ps.last_launch()
+    ps.check_errors()
+    y = ps.get_state().clone()
+    y[0, 100] += 1.0  # ONE env of the second workgroup
+    ps.set_state(y)
+    env.rollout(acts)
+    assert "dc_stream_kernel" in ps.last_launch()
+    with pytest.raises(GemxError):
+        ps.check_errors()
+    env.close()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("env_id, delay, K", [("Finite-CC-PMSM-v0", 3, 7), ("Cont-CC-PMSM-v0", 2, 5), ("Cont-CC-PermExDc-v0", 3, 1)])
+def test_dead_time_queue_phase_survives_graph_replay(env_id, delay, K):
+    """The DeadTimeProcessor FIFO's slot of a launch's first step (control steps so far mod delay) lives in DEVICE memory and is advanced
+    by the kernels themselves, so a K-step launch replayed from a graph (K not a multiple of the delay) continues the queue where the
+    previous replay left it: replay r == the r-th eager launch, bit for bit (a phase computed on the host would be frozen at capture)."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    n, R = 192, 5
+    mk = lambda: ga.make(env_id, n_envs=n, ode_solver=ga.RK4Solver(), tau=1e-4, physical_system_wrappers=(ga.DeadTimeProcessor(steps=delay),))  # noqa: E731
+    env_g, env_e = mk(), mk()
+    pg, pe = env_g.physical_system, env_e.physical_system
+    g0 = torch.Generator(device="cuda").manual_seed(11)
+    if pg._discrete:
+        acts = torch.randint(0, 8, (K, n), device="cuda", generator=g0, dtype=torch.uint8)
+    else:
+        acts = torch.rand((K, n, pg._n_act), device="cuda", generator=g0) * 2 - 1
+    nout = pg._n_out
+    if K == 1:
+        run_g = lambda: pg.simulate(acts[0])  # noqa: E731
+        run_e = lambda: pe.simulate(acts[0]).clone()  # noqa: E731
+        out_g = pg._obs
+    else:
+        out_g = torch.empty((K, n, nout), device="cuda")
+        dn_g = torch.empty((K, n), dtype=torch.uint8, device="cuda")
+        run_g = lambda: env_g.rollout(acts, obs_out=out_g, done_out=dn_g)  # noqa: E731
+        run_e = lambda: env_e.rollout(acts)[0]  # noqa: E731
+    run_g()  # warm-up outside the capture, then both sides from the reset state
+    env_g.reset()
+    env_e.reset()
+    torch.cuda.synchronize()
+    graph = _capture(torch, run_g)
+    env_g.reset()
+    for r in range(R):
+        graph.replay()
+        ref = run_e()
+        torch.cuda.synchronize()
+        assert torch.equal(out_g.reshape(ref.shape), ref), (r, float((out_g.reshape(ref.shape) - ref).abs().max()))
+    env_g.close()
+    env_e.close()
+
+
+_RCCL_WORLD1 = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch
+import torch.distributed as dist
+import gym_electric_motor_amd as ga
+from gym_electric_motor_amd import distributed as gd
+
+rank, world, local = gd.init_from_env(backend="nccl", timeout_s=120, force=True)
+assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+n, K = 4096, 50
+env = gd.make_sharded("Finite-CC-PMSM-v0", n, rank, world, device=local, ode_solver=ga.RK4Solver(), tau=1e-4)
+assert env.shard == (0, n)
+g = torch.Generator(device="cuda").manual_seed(3)
+acts = torch.randint(0, 8, (K, n), device="cuda", generator=g, dtype=torch.uint8)
+obs, done = env.rollout(acts)
+# the batched-return path, forced down the collective branch although the world is one rank: RCCL moves the real rollout outputs
+go, gdn = gd.gather_rollout(obs, done, force=True)
+assert go.shape == (1, K, n, 14) and gdn.shape == (1, K, n) and go.data_ptr() != obs.data_ptr()
+assert torch.equal(go[0], obs) and torch.equal(gdn[0], done)
+o1 = env.physical_system.simulate(acts[0])
+a1, d1 = gd.gather_observations(o1, env.physical_system.done, force=True)
+assert a1.shape == (n, 14) and a1.data_ptr() != o1.data_ptr() and torch.equal(a1, o1) and torch.equal(d1, env.physical_system.done)
+a2, _ = gd.gather_observations(o1, None, n_total=n, force=True)
+assert torch.equal(a2, o1)
+dist.barrier()
+torch.cuda.synchronize()
+env.close()
+dist.destroy_process_group()
+print("RCCL_WORLD1_OK", int(done.sum()))
+'''
+
+
+@pytest.mark.timeout(300)
+def test_rccl_gather_of_real_rollout_outputs_in_a_world_of_one():
+    """The multi-GPU path as far as ONE GPU allows (SURVEY.md 8e): torch.distributed initialised with backend "nccl" (= RCCL) and a
+    world of one rank, this rank's shard stepped by the kernels, and `gather_rollout` / `gather_observations` FORCED down their
+    collective branch on the real rollout outputs -- RCCL's all-gather returns the shard bit for bit in a fresh tensor.  (Own
+    process: the process group must not outlive the test.)"""
+    import subprocess
+    import sys
+
+    from gym_electric_motor_amd.distributed import free_port
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, "-c", _RCCL_WORLD1 % repo], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

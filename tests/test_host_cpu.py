@@ -84,6 +84,38 @@ def test_host_metadata_matches_reference(env_id, golden):
     assert list(cfg.limits)[: len(meta["limits"])] == [float(x) for x in ps.limits]  # the config carries the system's limits verbatim
 
 
+ALL_ENV_IDS = [f"{a}-{c}-{m}-v0" for m in ("PermExDc", "SeriesDc", "ShuntDc", "ExtExDc", "PMSM", "SynRM", "SCIM", "EESM", "DFIM")
+               for c in ("CC", "TC", "SC") for a in ("Cont", "Finite")]
+
+
+@pytest.mark.parametrize("env_id", ALL_ENV_IDS)
+def test_every_env_id_is_built_like_the_reference_builds_it(env_id):
+    """All 54 ids: what `make(env_id)` assembles (names, limits, nominal values, model constants, inertia, load parameters, control step,
+    supply, converter and its dead time, the load's speed / initial speed) against what the reference's `gem.make(env_id)` reported when
+    oracle/make_golden.py:main_defaults recorded it.  (Round 3 found Cont-TC-ShuntDc-v0's omega_fixed = 230 this way.)"""
+    meta = _meta("default_" + env_id[:-3].replace("-", "_").lower() + "_dopri5")
+    assert meta["env_id"] == env_id
+    ps = ga.make(env_id, n_envs=8, _defer_create=True).physical_system
+    assert list(ps.state_names) == meta["state_names"]
+    assert np.allclose(ps.limits, meta["limits"], rtol=1e-13, atol=0)
+    assert np.allclose(ps.nominal_state, meta["nominal_state"], rtol=1e-13, atol=0)
+    assert np.allclose(np.asarray(ps.electrical_motor._model_constants), np.asarray(meta["model_constants"]), rtol=1e-15, atol=0)
+    assert ps.mechanical_load.j_total == pytest.approx(meta["j_total"], rel=1e-15)
+    assert ps.tau == meta["tau"] and ps.supply.u_nominal == meta["u_nominal"]
+    assert type(ps.mechanical_load).__name__ == meta["load"] and type(ps.electrical_motor).__name__ == meta["motor"]
+    assert type(ps.converter).__name__ == meta["converter"].split("[")[0] and ps._interlocking_time() == meta["interlocking_time"]
+    cfg = ps._cfg
+    if meta["load"] == "ConstantSpeedLoad":
+        assert cfg.init_state[0] == meta["omega_fixed"]
+    else:
+        lp = meta["load_parameter"]
+        assert (cfg.load_a, cfg.load_b, cfg.load_c, cfg.tau_decay) == (lp["a"], lp["b"], lp["c"], meta["tau_decay"]) and cfg.init_state[0] == 0.0
+    assert type(ps).__name__ == "Batched" + meta["system"]
+    # the solver a user gets without naming one (envs.default_ode_solver): classical RK4, kink splitting exactly for the speed-dependent loads
+    assert cfg.solver_kind == _lib.SOLVER_RK4 and cfg.solver_nsteps == 1
+    assert cfg.solver_flags == (0 if meta["load"] == "ConstantSpeedLoad" else _lib.SOLVER_SPLIT_KINKS)
+
+
 def test_default_constraints_become_masks():
     dc = ga.make("Cont-CC-PermExDc-v0", n_envs=2, _defer_create=True).physical_system
     assert dc._cfg.limit_mask == 1 << dc.state_positions["i"] and dc._cfg.squared_mask == 0 and dc._cfg.auto_reset == 1

@@ -39,6 +39,15 @@ def test_oracle_reproduces_reference_trajectory(name):
         assert bad.sum() <= 2 * (1 + d["terminated"].sum())  # only the first two steps of an episode can be affected
         cols = [meta["state_names"].index(c) for c in orc.DQ_COLUMNS if c in meta["state_names"]]
         diff[np.ix_(bad, cols)] = 0.0
+    if meta["system"] == "SquirrelCageInductionMotorSystem" and name.startswith("default_"):
+        # a squirrel-cage machine at rest under ZERO voltage vectors (finite converter, actions 0 / 7) stays at rest -- except for the
+        # ~1e-17 of rounding noise np.matmul leaves in the reference's Clarke transform of (u, u, u); the first active vector then
+        # finds a field angle of arctan2(noise).  Same corner as above: the dq columns of steps that START with zero flux are given
+        bad = orc.undefined_field_angle_steps(orc.params_from_meta(meta), d["actions"])[d["state_index"]]
+        cols = [meta["state_names"].index(c) for c in orc.DQ_COLUMNS if c in meta["state_names"]]
+        really = (diff[:, cols].max(axis=1) > 1e-9) & bad
+        assert really.sum() <= 2 * (1 + d["terminated"].sum())  # at most the first active steps of an episode differ
+        diff[np.ix_(bad, cols)] = 0.0
     assert diff.max() < 1e-9, diff.max()  # observed <= 1e-12 except Cont-SC-SynRM (tiny inertia: rounding amplified to 4e-10)
     assert np.array_equal(done, d["terminated"])
 
@@ -72,10 +81,7 @@ def test_fixed_step_rk4_close_to_reference_default_solver(name):
     """The reference has no RK4; classical RK4 must stay within the 1e-4 relative contract of the
     reference's default dopri5 path (observed <= 8e-5, worst case SCIM + PolynomialStaticLoad kinks)."""
     d, meta = orc.load_golden(name)
-    # Cont-SC-SynRM (J = 0.81e-3 kg m^2, speed loop time constants ~ tau): one RK4 step per tau is 1e-3 off the adaptive
-    # reference solver; 8 sub-steps (RK4Solver(nsteps=8)) restore the 1e-4 contract
-    solver = "rk4x8" if meta["env_id"].endswith("SC-SynRM-v0") else "rk4"
-    env = orc.OracleEnv(orc.params_from_meta(meta, solver=solver, episodic=False))
+    env = orc.OracleEnv(orc.params_from_meta(meta, solver="rk4", episodic=False))
     if meta["episodic"]:
         pytest.skip("episodic runs compared solver-for-solver only")
     env.reset()
@@ -111,6 +117,28 @@ def test_polynomial_static_load_kat(omega, expected):
     p.load = orc.LOAD_POLY
     p.j_total, p.load_a, p.load_b, p.load_c, p.tau_decay = 1e-4, 0.01, 0.02, 0.03, 1e-3
     assert abs(orc.lib().orc_kat_poly_load(p, float(omega), 2.0) - expected) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["rc_scim_cont_sc_free_held_dopri5", "pmsm_free_held_til_dopri5", "scim_free_held_dopri5",
+                                  "default_cont_sc_synrm_dopri5", "default_cont_sc_shuntdc_dopri5"])
+@pytest.mark.parametrize("solver, nsteps, tol", [("rk4_kink", 1, 3e-5), ("rk4_kink", 2, 1.5e-5), ("dp5_kink", 1, 1.5e-5)])
+def test_kink_split_restatement_tracks_the_reference_default_solver(name, solver, nsteps, tol):
+    """The oracle's restatement of the device's split_kinks stepping (integrate_kink) against recorded dopri5 runs -- on purpose also
+    behind an RCVoltageSupply and with converter dead time, whose bookkeeping reads the env's clock: integrate_kink used to leave
+    that clock where it was (advisor finding, round 2: 4e-2 on the RC fixture), and it now honours `nsteps` like the kernels do."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_parity import compare_trajectory
+
+    d, meta = orc.load_golden(name)
+    p = orc.params_from_meta(meta, solver=solver)
+    p.nsteps = nsteps
+    env = orc.OracleEnv(p)
+    env.reset()
+    obs, done = env.rollout(d["actions"], auto_reset=True)
+    rel, _, col, dmsg = compare_trajectory(meta, d, obs, done)
+    assert rel < tol, (rel, col, dmsg)
 
 
 @pytest.mark.parametrize(
