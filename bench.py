@@ -55,6 +55,101 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md); 6290 GB/s measured float4 copy
 
+class Telemetry:
+    """Shader clock / memory clock / socket power / temperature of ONE GPU from the amdgpu hwmon files in sysfs (microseconds per read),
+    located through the device's PCI bus id (hipDeviceGetPCIBusId).  Everything is best effort: a box that hides sysfs yields
+    {"available": False, "reason": ...} and the bench goes on."""
+
+    def __init__(self, dev_index):
+        self.dir, self.reason = None, None
+        try:
+            import ctypes as C
+            import glob
+
+            import torch  # noqa: F401  (loads the HIP runtime)
+
+            hip = None
+            for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+                try:
+                    hip = C.CDLL(name)
+                    break
+                except OSError:
+                    continue
+            bus = None
+            if hip is not None:
+                buf = C.create_string_buffer(64)
+                if hip.hipDeviceGetPCIBusId(buf, 64, int(dev_index)) == 0:
+                    bus = buf.value.decode().lower()
+            cands = []
+            if bus:
+                cands = glob.glob(f"/sys/bus/pci/devices/{bus}/hwmon/hwmon*")
+            if not cands:  # fall back: the dev_index-th card that exposes a shader clock (PCI order)
+                cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+                if len(cards) > dev_index:
+                    cands = glob.glob(os.path.join(os.path.dirname(cards[dev_index]), "hwmon", "hwmon*"))
+                    self.reason = "PCI bus id lookup failed: card chosen by order"
+            if cands:
+                self.dir = cands[0]
+                self.bus = bus
+            else:
+                self.reason = "no amdgpu hwmon directory visible in sysfs"
+        except Exception as e:  # pragma: no cover
+            self.reason = repr(e)
+
+    def _read(self, name, scale):
+        try:
+            with open(os.path.join(self.dir, name)) as fh:
+                return float(fh.read().strip()) * scale
+        except Exception:
+            return None
+
+    def sample(self):
+        if self.dir is None:
+            return None
+        return {"sclk_mhz": self._read("freq1_input", 1e-6), "mclk_mhz": self._read("freq2_input", 1e-6),
+                "power_w": self._read("power1_input", 1e-6) or self._read("power1_average", 1e-6), "temp_c": self._read("temp2_input", 1e-3)}
+
+    def describe(self):
+        return {"available": self.dir is not None, "source": self.dir, "pci_bus_id": getattr(self, "bus", None), "note": self.reason}
+
+
+class Sampler:
+    """Background sampling of Telemetry while a leg runs (period ~20 ms): median / min / max of every quantity."""
+
+    def __init__(self, tele, period_s=0.02):
+        import threading
+
+        self.tele, self.period, self.rows, self._stop = tele, period_s, [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            r = self.tele.sample()
+            if r:
+                self.rows.append(r)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self.tele.dir is not None:
+            self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._t.is_alive():
+            self._t.join(timeout=1.0)
+
+    def summary(self):
+        if not self.rows:
+            return None
+        out = {"samples": len(self.rows)}
+        for k in self.rows[0]:
+            v = sorted(x[k] for x in self.rows if x[k] is not None)
+            if v:
+                out[k] = {"median": v[len(v) // 2], "min": v[0], "max": v[-1]}
+        return out
+
+
 WORKLOADS = {
     # name: env_id, envs/GPU, solver, tau, action bytes per env-step, S_ode, S_out
     "pmsm": dict(env_id="Finite-CC-PMSM-v0", envs=16384, solver="rk4", tau=1e-4, a_bytes=1, s_ode=4, s_out=14,
@@ -102,9 +197,15 @@ class Timed:
         self.wall, self.launch_ms = wall, launch_ms
 
 
-def measure(torch, dist, env, n_local, steps, warmup, spl, device, world, seed, gather="off", gd=None, settle_ms=0.0):
+def median_of(ts):
+    """the Timed with the median wall time of a list of repeats"""
+    return sorted(ts, key=lambda t: t.wall)[len(ts) // 2]
+
+
+def measure(torch, dist, env, n_local, steps, warmup, spl, device, world, seed, gather="off", gd=None, settle_ms=0.0, repeats=1):
     """`warmup` untimed + `steps` timed launches of `spl` control steps each, after `settle_ms` of the same launches (clock governor, see
-    module docstring).  gather: off | chunk | step."""
+    module docstring).  gather: off | chunk | step.  repeats > 1: the timed region (exactly `steps` launches between barrier +
+    synchronize on both sides) is run that many times back to back; returns the list of Timed (repeats == 1: the one Timed)."""
     ps = env.physical_system
     n_act_bufs = max(1, min(4, steps))
     acts = make_actions(torch, ps, spl * n_act_bufs, n_local, device, seed)
@@ -133,31 +234,100 @@ def measure(torch, dist, env, n_local, steps, warmup, spl, device, world, seed, 
             torch.cuda.synchronize()
     for i in range(warmup):
         launch(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for i in range(steps):
-        launch(i)
-    e1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        if dist.get_backend() == "gloo":
-            t = torch.tensor([dt], dtype=torch.float64)
-        else:
-            t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    out = []
+    for _ in range(max(1, repeats)):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for i in range(steps):
+            launch(i)
+        e1.record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            if dist.get_backend() == "gloo":
+                t = torch.tensor([dt], dtype=torch.float64)
+            else:
+                t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        out.append(Timed(dt, e0.elapsed_time(e1) / steps))
     if gather != "step":
         assert torch.isfinite(obs).all()
-    return Timed(dt, e0.elapsed_time(e1) / steps)
+    return out if repeats > 1 else out[0]
+
+
+def measure_sustained(torch, env, n_local, spl, device, seed, seconds, tele, launch_ms_hint):
+    """>= `seconds` of back-to-back launches (no host synchronisation inside), clocks / power sampled meanwhile: does the rate of the
+    3-ms timed window hold when the chip has time to reach its power / thermal limits?"""
+    ps = env.physical_system
+    acts = make_actions(torch, ps, spl * 2, n_local, device, seed)
+    obs = torch.empty((spl, n_local, ps._n_out), dtype=torch.float32, device=device)
+    done = torch.empty((spl, n_local), dtype=torch.uint8, device=device)
+    env.reset()
+    n = max(8, int(math.ceil(seconds / (launch_ms_hint * 1e-3))))
+    for i in range(8):
+        env.rollout(acts[(i % 2) * spl : (i % 2 + 1) * spl], obs_out=obs, done_out=done)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with Sampler(tele) as smp:
+        t0 = time.perf_counter()
+        e0.record()
+        for i in range(n):
+            env.rollout(acts[(i % 2) * spl : (i % 2 + 1) * spl], obs_out=obs, done_out=done)
+        e1.record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return dt, e0.elapsed_time(e1) / n, n, smp.summary()
+
+
+def measure_traffic_pmc(args, workload, timeout_s=150):
+    """HBM bytes per launch of the dominant kernel, MEASURED IN THIS RUN: two child runs of this script under `rocprofv3 --pmc`
+    (FETCH_SIZE and WRITE_SIZE in separate passes -- they do not fit one: 3 + 2 TCC slots), per the guide's HBM section:
+    counters in KiB, FETCH_SIZE doubled on gfx950 (it tallies 128-byte requests at 64 bytes), WRITE_SIZE as reported.
+    Returns (bytes per launch | None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None, "rocprofv3 not found"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="gemx_pmc_", dir="/tmp")
+        cmd = [rp, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--no-extras", "--no-pmc", "--workload", workload, "--steps", "3", "--warmup", "1", "--settle-ms", "0", "--repeats", "1",
+               "--steps-per-launch", str(args.steps_per_launch)]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            acc = {}
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for r in csv.DictReader(open(f)):
+                    kn = r["Kernel_Name"]
+                    if ("advance" in kn or "dc_stream" in kn) and r["Counter_Name"] == counter:
+                        a = acc.setdefault(kn, [0.0, set()])
+                        a[0] += float(r["Counter_Value"])
+                        a[1].add(r["Dispatch_Id"])
+            if not acc:
+                return None, f"no {counter} rows for the stepping kernels (rocprofv3 pass failed?)"
+            kn = max(acc, key=lambda k: acc[k][0])  # the dominant kernel
+            vals[counter] = acc[kn][0] / max(1, len(acc[kn][1]))
+        except Exception as e:
+            return None, f"{counter} pass failed: {e!r}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
+            "passes, 4 launches each), (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch")
 
 
 def measure_single_step(torch, env, n_local, K, W, device, seed, graph_steps=0, settle_ms=0.0):
@@ -281,20 +451,21 @@ def cpu_baseline(w, budget_s=12.0):
     return out
 
 
-def roofline_of(w, n_local, spl, launch_ms, kernel_desc, workload_key):
+def roofline_of(w, n_local, spl, launch_ms, kernel_desc, workload_key, traffic=None, traffic_source=None):
     b_step = bytes_per_env_step_fused(w)
     launch_bytes = n_local * (spl * b_step + 2 * 4 * w["s_ode"])
     achieved = launch_bytes / (launch_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(f"{workload_key}:{n_local}:{spl}")
-        except Exception:
-            traffic = None
+    if traffic is None:  # not measured in this run: the last builder-run collection (tools/update_hbm_traffic.py)
+        tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{workload_key}:{n_local}:{spl}")
+                traffic_source = "profiles/hbm_traffic.json (rocprofv3 --pmc passes of an earlier collection)" if traffic is not None else None
+            except Exception:
+                traffic = None
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": traffic, "kernel": kernel_desc, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": launch_bytes,
-            "bytes_per_env_step": b_step}
+            "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_desc, "launch_ms": launch_ms,
+            "algorithmic_bytes_per_launch": launch_bytes, "bytes_per_env_step": b_step}
 
 
 def worker(args, rank, world, local_rank, backend):
@@ -313,9 +484,13 @@ def worker(args, rank, world, local_rank, backend):
     device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
+        import datetime
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if "MASTER_PORT" not in os.environ:
+            raise SystemExit("bench.py: WORLD_SIZE > 1 without MASTER_PORT (torchrun sets it; --gpus N without torchrun picks a free port)")
+        # a rank that dies leaves the others with an exception after --dist-timeout seconds instead of a hang in a barrier
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.dist_timeout))
 
     w = dict(WORKLOADS[args.workload], key=args.workload)
     n_local = args.envs_per_gpu or (32768 if (args.workload == "pmsm" and world == 8) else w["envs"])  # BASELINE config 5: 8 x 32768
@@ -323,9 +498,14 @@ def worker(args, rank, world, local_rank, backend):
     K, W, spl = args.steps, args.warmup, args.steps_per_launch
 
     S = args.settle_ms
+    tele = Telemetry(dev_index)
     env = make_env(ga, w, n_local, dev_index)
     t_cold = measure(torch, dist, env, n_local, K, W, spl, device, world, seed=1234 + rank) if S > 0 else None  # straight from idle
-    t = measure(torch, dist, env, n_local, K, W, spl, device, world, seed=1234 + rank, settle_ms=S)
+    tele_before = tele.sample()
+    reps = measure(torch, dist, env, n_local, K, W, spl, device, world, seed=1234 + rank, settle_ms=S, repeats=max(1, args.repeats))
+    reps = reps if isinstance(reps, list) else [reps]
+    tele_after = tele.sample()
+    t = median_of(reps)
     kernel_desc = env.physical_system.last_launch()
     same_shard = None
     if n_local != w["envs"] and args.envs_per_gpu is None:  # --gpus 8 default = BASELINE config 5 (8 x 32768): also the N=1 shard size
@@ -335,9 +515,7 @@ def worker(args, rank, world, local_rank, backend):
         same_shard = {"envs_per_gpu": w["envs"], "value": w["envs"] * world * spl * K / ts.wall, "unit": "env-steps/s",
                       "ms_per_step": ts.wall / K * 1e3, "note": "same per-GPU shard as the --gpus 1/2/4 lines (strict weak scaling)"}
     gathered = None
-    if args.gather != "off" and world > 1 and backend == "gloo":
-        gathered = {"skipped": "oversubscribed ranks run a gloo control plane; the device all-gather needs RCCL (one rank per GPU)"}
-    elif args.gather != "off":
+    if args.gather != "off":  # (gloo, i.e. --oversubscribe: the same collectives staged through host memory -- functional, not a measurement)
         modes = ["chunk", "step"] if args.gather == "both" else [args.gather]
         gathered = {}
         for mode in modes:
@@ -371,7 +549,18 @@ def worker(args, rank, world, local_rank, backend):
                        "parallelism": f"env-sharded x{world}, no data-path collective", "world_size": world,
                        "backend": (backend if world > 1 else None), "oversubscribed": bool(args.oversubscribe and world > ndev)},
             "roofline": roofline_of(w, n_local, spl, t.launch_ms, kernel_desc, args.workload),
+            "repeats": {"n": len(reps), "note": f"the timed region ({K} launches) run {len(reps)} times back to back; value / ms_per_step / roofline = the MEDIAN region",
+                        "values": [n_total * spl * K / r.wall for r in reps], "launch_ms": [r.launch_ms for r in reps],
+                        "roofline_frac_min": min(roofline_of(w, n_local, spl, r.launch_ms, kernel_desc, args.workload)["frac"] for r in reps),
+                        "roofline_frac_max": max(roofline_of(w, n_local, spl, r.launch_ms, kernel_desc, args.workload)["frac"] for r in reps)},
+            "telemetry": dict(tele.describe(), before=tele_before, after=tele_after),
         }
+        if not args.no_pmc and world == 1:
+            tr, note = measure_traffic_pmc(args, args.workload)
+            if tr is not None:
+                out["roofline"] = roofline_of(w, n_local, spl, t.launch_ms, kernel_desc, args.workload, traffic=tr, traffic_source=note)
+            else:
+                out["roofline"]["traffic_source"] = f"{out['roofline'].get('traffic_source')}; in-run PMC pass unavailable: {note}"
         if t_cold is not None:
             rcold = roofline_of(w, n_local, spl, t_cold.launch_ms, kernel_desc, args.workload)
             out["cold_start"] = {"value": n_total * spl * K / t_cold.wall, "unit": "env-steps/s", "ms_per_step": t_cold.wall / K * 1e3,
@@ -382,7 +571,7 @@ def worker(args, rank, world, local_rank, backend):
         if same_shard is not None:
             out["same_shard_as_n1"] = same_shard
         if not args.no_extras and world == 1:
-            extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out)
+            extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out, tele)
         elif not args.no_extras:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
@@ -392,7 +581,27 @@ def worker(args, rank, world, local_rank, backend):
         dist.destroy_process_group()
 
 
-def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out):
+def leg(torch, dist, ga, args, key, device, dev_index, spl, tele, envs=None, split_kinks=False, steps=10, repeats=3, seed=5):
+    """One informational leg through the same measurement as the headline: `repeats` timed regions of `steps` launches, MEDIAN reported,
+    min / max beside it, clocks / power before and after."""
+    wc = dict(WORKLOADS[key], key=key)
+    n = envs or wc["envs"]
+    env = make_env(ga, wc, n, dev_index, split_kinks=split_kinks)
+    before = tele.sample()
+    reps = measure(torch, dist, env, n, steps, 3, spl, device, 1, seed=seed, settle_ms=args.settle_ms, repeats=repeats)
+    reps = reps if isinstance(reps, list) else [reps]
+    after = tele.sample()
+    desc = env.physical_system.last_launch()
+    env.close()
+    tm = median_of(reps)
+    fr = [roofline_of(wc, n, spl, r.launch_ms, desc, key)["frac"] for r in reps]
+    return {"workload": wc["desc"] + (", RK4Solver(split_kinks=True)" if split_kinks else ""), "envs": n, "steps_per_launch": spl,
+            "value": n * spl * steps / tm.wall, "unit": "env-steps/s", "roofline": roofline_of(wc, n, spl, tm.launch_ms, desc, key),
+            "repeats": {"n": len(reps), "roofline_frac": fr, "roofline_frac_min": min(fr), "roofline_frac_max": max(fr)},
+            "telemetry": {"before": before, "after": after}}, tm
+
+
+def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out, tele):
     """Rank 0, N = 1 only: the CPU baseline and the informational legs (each bounded to a few seconds)."""
     out["cpu_baseline"] = cpu_baseline(w)
     # the same launches without the one-step affine map (general stage-by-stage RK4)
@@ -407,46 +616,84 @@ def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out):
     r0 = roofline_of(w, n_local, spl, t0.launch_ms, desc0, args.workload + "/nolinmap")
     out["headline_no_linmap"] = {"value": n_local * spl * min(args.steps, 10) / t0.wall, "unit": "env-steps/s", "launch_ms": t0.launch_ms,
                                  "achieved_GBps": r0["achieved"], "frac_of_peak": r0["frac"], "env": "GEMX_LINMAP=0"}
+    # does the 3-ms window hold for a second?  (clocks / power sampled every 20 ms while the launches run)
+    envs_ = make_env(ga, w, n_local, dev_index)
+    dt, lms, n, smp = measure_sustained(torch, envs_, n_local, spl, device, 11, args.sustain_s, tele, out["roofline"]["launch_ms"])
+    envs_.close()
+    rs = roofline_of(w, n_local, spl, lms, out["roofline"]["kernel"], args.workload)
+    out["sustained_1s"] = {"value": n_local * spl * n / dt, "unit": "env-steps/s", "launches": n, "seconds": dt, "launch_ms": lms,
+                           "roofline_frac": rs["frac"], "telemetry_during": smp,
+                           "note": f">= {args.sustain_s} s of back-to-back launches of the headline workload, no host synchronisation inside"}
     # closed-loop usage: one launch per control step, eager and from a HIP graph
     b1 = bytes_per_env_step_single(w)
     env1 = make_env(ga, w, n_local, dev_index)
     host_s, dev_ms, n1 = measure_single_step(torch, env1, n_local, 2000, 100, device, seed=99, settle_ms=args.settle_ms)
     out["single_step"] = {"value": n_local / host_s, "unit": "env-steps/s", "ms_per_step": host_s * 1e3, "device_ms_per_step": dev_ms,
                           "achieved_GBps": n_local * b1 / (dev_ms * 1e-3) / 1e9, "bytes_per_env_step": b1, "steps": n1,
-                          "note": "one gemx_step launch per control step, eager"}
+                          "note": "one gemx_step launch per control step, eager (PhysicalSystem.simulate on a device tensor)"}
     host_s, dev_ms, n1 = measure_single_step(torch, env1, n_local, 4096, 100, device, seed=99, graph_steps=64, settle_ms=args.settle_ms)
     out["single_step_graph"] = {"value": n_local / host_s, "unit": "env-steps/s", "ms_per_step": host_s * 1e3, "device_ms_per_step": dev_ms,
                                 "achieved_GBps": n_local * b1 / (dev_ms * 1e-3) / 1e9, "bytes_per_env_step": b1, "steps": n1,
                                 "note": "64 gemx_step launches captured into one HIP graph (torch.cuda.CUDAGraph) and replayed"}
     env1.close()
-    # BASELINE configs 2 and 4 through the same measurement
+    # BASELINE configs 2, 4 and 5's per-GPU shard through the same measurement (3 repeats each: median, min, max)
     out["configs"] = {}
     for key in ("permexdc", "scim", "scim_constspeed"):
         if key == args.workload:
             continue
-        wc = dict(WORKLOADS[key], key=key)
-        envc = make_env(ga, wc, wc["envs"], dev_index)
-        tc = measure(torch, dist, envc, wc["envs"], 10, 3, spl, device, 1, seed=5, settle_ms=args.settle_ms)
-        rc = roofline_of(wc, wc["envs"], spl, tc.launch_ms, envc.physical_system.last_launch(), key)
-        envc.close()
-        out["configs"][key] = {"workload": wc["desc"], "envs": wc["envs"], "steps_per_launch": spl, "value": wc["envs"] * spl * 10 / tc.wall,
-                               "unit": "env-steps/s", "roofline": rc}
+        out["configs"][key], tm = leg(torch, dist, ga, args, key, device, dev_index, spl, tele)
         if key == "scim":  # the same config with RK4Solver(split_kinks=True): steps cut at the PolynomialStaticLoad's kinks (accuracy option)
-            envk = make_env(ga, wc, wc["envs"], dev_index, split_kinks=True)
-            tk = measure(torch, dist, envk, wc["envs"], 10, 3, spl, device, 1, seed=5, settle_ms=args.settle_ms)
-            rk = roofline_of(wc, wc["envs"], spl, tk.launch_ms, envk.physical_system.last_launch(), key + "/split_kinks")
-            envk.close()
-            out["configs"]["scim_split_kinks"] = {"workload": wc["desc"] + ", RK4Solver(split_kinks=True)", "envs": wc["envs"], "steps_per_launch": spl,
-                                                  "value": wc["envs"] * spl * 10 / tk.wall, "unit": "env-steps/s", "roofline": rk}
+            out["configs"]["scim_split_kinks"], _ = leg(torch, dist, ga, args, key, device, dev_index, spl, tele, split_kinks=True)
+            wc = dict(WORKLOADS[key], key=key)
+            envs_ = make_env(ga, wc, wc["envs"], dev_index)
+            dt, lms, n, smp = measure_sustained(torch, envs_, wc["envs"], spl, device, 13, args.sustain_s, tele, tm.launch_ms)
+            envs_.close()
+            out["configs"]["scim"]["sustained_1s"] = {"value": wc["envs"] * spl * n / dt, "launches": n, "seconds": dt, "launch_ms": lms,
+                                                      "roofline_frac": roofline_of(wc, wc["envs"], spl, lms, "", key)["frac"], "telemetry_during": smp}
+        if key == "permexdc":
+            out["configs"][key]["launch_model"] = launch_model(torch, dist, ga, args, key, device, dev_index, out["configs"][key])
+    if args.workload == "pmsm":  # BASELINE config 5 = 8 x 32768 envs: its shard on this one GPU (the <4, 2> shape)
+        out["configs"]["pmsm_c5_shard"], _ = leg(torch, dist, ga, args, "pmsm", device, dev_index, spl, tele, envs=32768)
     # the headline kernel with the chip full
     n_big, c_big = 2 ** 20, 100
     envb = make_env(ga, w, n_big, dev_index)
-    tb = measure(torch, dist, envb, n_big, 4, 2, c_big, device, 1, seed=7, settle_ms=args.settle_ms)
+    tb = measure(torch, dist, envb, n_big, 4, 2, c_big, device, 1, seed=7, settle_ms=args.settle_ms, repeats=3)
     envb.close()
     bb = n_big * (c_big * bytes_per_env_step_fused(w) + 2 * 4 * w["s_ode"])
-    out["at_scale"] = {"envs": n_big, "steps_per_launch": c_big, "value": n_big * 4 * c_big / tb.wall, "unit": "env-steps/s",
-                       "launch_ms": tb.launch_ms, "achieved_GBps": bb / (tb.launch_ms * 1e-3) / 1e9,
-                       "frac_of_peak": bb / (tb.launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    tbm = median_of(tb)
+    fr = [bb / (r.launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS for r in tb]
+    out["at_scale"] = {"envs": n_big, "steps_per_launch": c_big, "value": n_big * 4 * c_big / tbm.wall, "unit": "env-steps/s",
+                       "launch_ms": tbm.launch_ms, "achieved_GBps": bb / (tbm.launch_ms * 1e-3) / 1e9,
+                       "frac_of_peak": bb / (tbm.launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "frac_of_peak_repeats": fr,
+                       "telemetry_after": tele.sample()}
+
+
+def launch_model(torch, dist, ga, args, key, device, dev_index, leg_out):
+    """BASELINE config 2 is not bandwidth bound: 4096 envs are 64 workgroups on 256 CUs, and a launch lasts K times what ONE wave needs
+    per control step plus a fixed part.  Fit t_launch(K) = t_fixed + K t_step over four launch lengths and put the
+    result beside two floors: the step-to-step dependency chain of the integrator wave (3 dependent VALU instructions, 14.1 cycles at
+    2.4 GHz: tools/microbench_chain.hip) and the time the algorithmic bytes take at the HBM peak."""
+    wc = dict(WORKLOADS[key], key=key)
+    pts = []
+    for k in (250, 500, 1000, 2000):
+        env = make_env(ga, wc, wc["envs"], dev_index)
+        r = measure(torch, dist, env, wc["envs"], 10, 3, k, device, 1, seed=5, settle_ms=args.settle_ms, repeats=3)
+        env.close()
+        pts.append((k, median_of(r).launch_ms * 1e3))
+    n = len(pts)
+    sx, sy = sum(p[0] for p in pts), sum(p[1] for p in pts)
+    sxx, sxy = sum(p[0] * p[0] for p in pts), sum(p[0] * p[1] for p in pts)
+    t_step = (n * sxy - sx * sy) / (n * sxx - sx * sx)
+    t_fixed = (sy - t_step * sx) / n
+    spl = leg_out["steps_per_launch"]
+    t_meas = leg_out["roofline"]["launch_ms"] * 1e3
+    chain_ns = 14.1 / 2.4
+    t_chain = spl * chain_ns * 1e-3 + t_fixed
+    t_hbm = leg_out["roofline"]["algorithmic_bytes_per_launch"] / (HBM_PEAK_GBPS * 1e3)
+    return {"fit_us": {"t_fixed": t_fixed, "t_step": t_step, "points": pts}, "unit": "microseconds (t_launch = t_fixed + K * t_step, least squares)",
+            "floor_dependency_chain_us": t_chain, "floor_hbm_peak_us": t_hbm, "measured_us": t_meas,
+            "frac_of_latency_bound": t_chain / t_meas,
+            "note": "frac_of_latency_bound = (K x 5.9 ns of the integrator's 3-instruction dependency chain + the fitted fixed part) / measured launch time"}
 
 
 def _spawned(local_rank, args, world, port, backend):
@@ -472,6 +719,10 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=60.0,
                     help="untimed launches of the same workload for this long before each leg's warm-up (clock governor; 0 = off)")
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / single_step / configs / at_scale legs")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps launches each; the median is reported, min / max beside it")
+    ap.add_argument("--sustain-s", type=float, default=1.0, help="length of the sustained legs (back-to-back launches, clocks / power sampled)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child runs (N = 1 only)")
+    ap.add_argument("--dist-timeout", type=float, default=300.0, help="torch.distributed timeout in seconds (rendezvous, barriers, collectives)")
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0 or args.steps_per_launch < 2 or args.settle_ms < 0:
         raise SystemExit("bench.py: --steps >= 1, --warmup >= 0, --steps-per-launch >= 2, --settle-ms >= 0")
@@ -493,10 +744,9 @@ def main():
         if args.gpus > ndev and not args.oversubscribe:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible; pass --oversubscribe to share GPUs between "
                              "ranks (gloo control plane; a functional check, not a measurement)")
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-        s.close()
+        from gym_electric_motor_amd.distributed import free_port
+
+        port = free_port()  # (not a fixed default: two jobs on one node would meet on it)
         mp.spawn(_spawned, args=(args, args.gpus, port, backend), nprocs=args.gpus, join=True)
 
 

@@ -49,7 +49,10 @@ template <int SYS, class R> struct Elec;
 template <class R> struct Elec<GEMX_SYS_DC_PERMEX, R> {
     static constexpr int NM = 1;
     struct Pre { R b; };
-    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[MAX_U]) { return Pre{P.m[0] * w + P.m[2] * u[0]}; }
+    static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[MAX_U]) {
+        const R bw = P.m[0] * w;  // (wave-uniform and loop invariant behind a ConstantSpeedLoad: the input term is ONE fma per step)
+        return Pre{fma(P.m[2], u[0], bw)};
+    }
     static __device__ __forceinline__ void f(const DevParams<R> &P, const Pre &p, const R (&x)[1], R (&dx)[1]) { dx[0] = p.b + P.m[1] * x[0]; }
     static __device__ __forceinline__ R torque(const DevParams<R> &P, const R (&x)[1]) { return P.tc0 * x[0]; }  // line 67-69
     static constexpr int NG = 1;  // affine part g of f(x) = A x + g: its first NG rows are non-zero
@@ -1086,14 +1089,16 @@ __device__ __forceinline__ void full_step(const DevParams<R> &P, R (&y)[ND], typ
     ST::template advance<false, LIN>(P, y, ang, sw, act, dact, ho, nullptr, linr);
     ST::observe(P, y, ang, ho, obs);
 }
-// instantiations whose electrical subsystem can be stepped by the precomputed one-step map (see integrate<..., LIN>)
-template <int LOAD, int SOLVER, bool IL, class R> constexpr bool linable() {
-    return LOAD == GEMX_LOAD_CONST_SPEED && !IL && SOLVER != GEMX_SOLVER_EULER && sizeof(R) == 4;
+// instantiations whose electrical subsystem can be stepped by the precomputed one-step map (see integrate<..., LIN>).  Euler: only the
+// ONE-state machines -- there the map is one multiply (the input term, off the recurrence) and one FMA against Euler's two dependent
+// FMAs; with two states it is 8 FMAs against 6
+template <int SYS, int LOAD, int SOLVER, bool IL, class R> constexpr bool linable() {
+    return LOAD == GEMX_LOAD_CONST_SPEED && !IL && (SOLVER != GEMX_SOLVER_EULER || Elec<SYS, R>::NM == 1) && sizeof(R) == 4;
 }
 // the map is valid for a wave if every lane's omega equals init[0] (then it stays so: a ConstantSpeedLoad never changes omega, and a
 // reset puts init[0] back); omega set to something else through gemx_set_state falls back to the stage-by-stage solver
-template <int LOAD, int SOLVER, bool IL, class R> __device__ __forceinline__ bool lin_usable(const DevParams<R> &P, R omega) {
-    if (!linable<LOAD, SOLVER, IL, R>()) return false;
+template <int SYS, int LOAD, int SOLVER, bool IL, class R> __device__ __forceinline__ bool lin_usable(const DevParams<R> &P, R omega) {
+    if (!linable<SYS, LOAD, SOLVER, IL, R>()) return false;
     return P.lin_on && __all(omega == P.init[0]);
 }
 // the map's NM * (NM + NG) coefficients into registers, once per kernel (see integrate<..., LIN>)
@@ -1503,7 +1508,7 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
             sup[1] = P.tau;
             PL.u_sup = sup[0];
         }
-        if (linable<LOAD, SOLVER, IL, R>() && lin_ok) full_step<ST, ND, NOUT, R, linable<LOAD, SOLVER, IL, R>()>(PL, y, ang, sw, act, dact, obs, linc);
+        if (linable<SYS, LOAD, SOLVER, IL, R>() && lin_ok) full_step<ST, ND, NOUT, R, linable<SYS, LOAD, SOLVER, IL, R>()>(PL, y, ang, sw, act, dact, obs, linc);
         else full_step<ST, ND, NOUT, R, false>(PL, y, ang, sw, act, dact, obs);
         if (!IL && conv_has_legs<CONV>() && P.rc_supply) sw = ST::legs_of(dact);  // (the IL code keeps `sw` itself)
         const bool done = constraint_done<ST, NOUT, R>(P, obs);
@@ -1595,9 +1600,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SYS == GE
         if (conv_sw_bytes<CONV>() == 2) sw |= (uint32_t)a.sw[N + e] << 8;
     }
     const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
-    const bool lin_ok = lin_usable<LOAD, SOLVER, IL, R>(P, y[0]);  // wave-uniform
+    const bool lin_ok = lin_usable<SYS, LOAD, SOLVER, IL, R>(P, y[0]);  // wave-uniform
     R linc[lin_count<SYS, R>()];  // the one-step map's coefficients, in registers for the whole launch (drained with the prologue loads)
-    lin_preload<SYS, R>(P, linable<LOAD, SOLVER, IL, R>() && lin_ok, linc);
+    lin_preload<SYS, R>(P, linable<SYS, LOAD, SOLVER, IL, R>() && lin_ok, linc);
     R sup[2] = {P.u_sup, R(0)};  // RCVoltageSupply: capacitor voltage, time since the supply's last update
     if (P.rc_supply) {
         sup[0] = a.state[(int64_t)ND * N + e];
@@ -1792,7 +1797,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs<R> a) {
         for (int i = 0; i < NACTC; ++i) popped[i] = DISCRETE ? (R)a.ring[slot0 + i] : reinterpret_cast<const R *>(a.ring)[slot0 + i];
     }
     const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
-    const bool lin_ok = lin_usable<LOAD, SOLVER, IL, R>(P, y[0]);  // wave-uniform
+    const bool lin_ok = lin_usable<SYS, LOAD, SOLVER, IL, R>(P, y[0]);  // wave-uniform
 
     // ---- the control step, exactly as compute_block() does it
     uint32_t bad_action = 0;
@@ -1819,7 +1824,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs<R> a) {
         PL.u_sup = sup[0];
     }
     R obs[NOUT];
-    if (linable<LOAD, SOLVER, IL, R>() && lin_ok) full_step<ST, ND, NOUT, R, linable<LOAD, SOLVER, IL, R>()>(PL, y, ang, sw, act, dact, obs);
+    if (linable<SYS, LOAD, SOLVER, IL, R>() && lin_ok) full_step<ST, ND, NOUT, R, linable<SYS, LOAD, SOLVER, IL, R>()>(PL, y, ang, sw, act, dact, obs);
     else full_step<ST, ND, NOUT, R, false>(PL, y, ang, sw, act, dact, obs);
     if (!IL && conv_has_legs<CONV>() && P.rc_supply) sw = ST::legs_of(dact);
     const bool done = constraint_done<ST, NOUT, R>(P, obs);
@@ -2007,8 +2012,8 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             }
             if (P.init_kind) rcount = a.rcnt[env];
         }
-        constexpr bool LINABLE = linable<LOAD, SOLVER, IL, R>();
-        const bool lin_ok = lin_usable<LOAD, SOLVER, IL, R>(P, y[0]);  // wave-uniform
+        constexpr bool LINABLE = linable<SYS, LOAD, SOLVER, IL, R>();
+        const bool lin_ok = lin_usable<SYS, LOAD, SOLVER, IL, R>(P, y[0]);  // wave-uniform
         // DeadTimeProcessor, two representations of the same queue (both leave the same [delay][N] ring in HBM):
         //   FIFO:    an LDS ring per lane, swapped every step (the rolled, run-time-checked copy of the step);
         //   DELAYED: no queue at all -- the converter sees the action row staged `delay` steps EARLIER (rows before the block: `carry`,
@@ -2651,27 +2656,47 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
 // SIMD and its issue slots: wave 4 stays resident but does nothing except meet the others at every barrier (a parked wave costs its
 // SIMD's other wave ~2 %; it used to END at once, relying on "an ended wave no longer counts at the barrier" -- true on this hardware,
 // but not something the programming model promises).  Integrator = wave 0, pre waves = 1, 2, output waves = 3, 5, 6, 7.
-constexpr int DCS_PRE = 2, DCS_OUT = 4, DCS_WAVES = 8, DCS_PREFETCH = 3;
+// Roles per system: the one-state machines (PermEx, Series) run <D = 32, 4 pre waves, 8 output waves> = 16 waves, the two-state ones
+// (Shunt, ExtEx: twice the LDS per step) <32, 2, 4> = 8 waves.  Same-box A/B at 4096 envs, PermExDc, Euler, us per 1000 steps
+// (profiles/r03e_dcs_ab.md): <64, 2, 4> 32.4, <64, 4, 4> 30.2, <32, 2, 8> 30.2, <32, 4, 8> 29.3 (round 2's kernel: 34.4).
+// GEMX_DCS_D1 / GEMX_DCS_PRE / GEMX_DCS_OUT override the one-state choice (A/B builds, tools/dev_build.py).
 #ifndef GEMX_DCS_D1
-#define GEMX_DCS_D1 64
+#define GEMX_DCS_D1 32
 #endif
+#ifndef GEMX_DCS_PRE
+#define GEMX_DCS_PRE 4
+#endif
+#ifndef GEMX_DCS_OUT
+#define GEMX_DCS_OUT 8
+#endif
+constexpr int DCS_PREFETCH = 3;
 template <int SYS> constexpr int dcs_depth() { return SysTraits<SYS>::ND == 2 ? GEMX_DCS_D1 : 32; }  // ND == 2: one motor state, one voltage
-constexpr int dcs_output_index(int wave) { return wave - 1 - DCS_PRE - (wave > 4 ? 1 : 0); }
-static_assert(dcs_output_index(3) == 0 && dcs_output_index(DCS_WAVES - 1) == DCS_OUT - 1, "wave roles");
+template <int SYS> constexpr int dcs_pre() { return SysTraits<SYS>::ND == 2 ? GEMX_DCS_PRE : 2; }
+template <int SYS> constexpr int dcs_out() { return SysTraits<SYS>::ND == 2 ? GEMX_DCS_OUT : 4; }
+// worker waves = every wave whose index is not a multiple of four: wave w is worker w - 1 - w / 4 (waves 1, 2, 3, 5, 6, 7, 9, ...); the
+// first dcs_pre() workers are pre waves, the next dcs_out() output waves
+constexpr int dcs_worker_index(int wave) { return wave - 1 - (wave >> 2); }
+template <int SYS> constexpr int dcs_waves() {  // smallest workgroup whose worker waves cover the roles
+    int w = 2;
+    while (dcs_worker_index(w - 1) + 1 < dcs_pre<SYS>() + dcs_out<SYS>() || ((w - 1) & 3) == 0) ++w;
+    return w;
+}
 template <int SYS, int CONV> constexpr size_t dcs_smem_bytes() {
     constexpr int NM = SysTraits<SYS>::ND - 1, NU = SYS == GEMX_SYS_DC_EXTEX ? 2 : 1;
     return (size_t)dcs_depth<SYS>() * BLOCK * sizeof(float) * (3 * NM + 3 * NU + 2 * NM) +
-           (size_t)DCS_OUT * 4 * BLOCK * SysTraits<SYS>::NOUT * sizeof(float);
+           (size_t)dcs_out<SYS>() * 4 * BLOCK * SysTraits<SYS>::NOUT * sizeof(float) + (size_t)dcs_out<SYS>() * 4 * BLOCK;
 }
 template <int SYS, int CONV, int SOLVER, class R>
-__global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArgs<R> a) {
+__global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(const KArgs<R> a) {
+    constexpr int DCS_PRE = dcs_pre<SYS>(), DCS_OUT = dcs_out<SYS>(), DCS_WAVES = dcs_waves<SYS>();
+    static_assert(DCS_WAVES <= 16 && dcs_worker_index(DCS_WAVES - 1) == DCS_PRE + DCS_OUT - 1, "wave roles");
     constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NM = ND - 1, NACT = ConvTraits<CONV>::NACT;
     constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
     constexpr int D = dcs_depth<SYS>(), NGR = D / 4;  // steps, groups of four steps per block
     using ST = Stepper<SYS, CONV, GEMX_LOAD_CONST_SPEED, SOLVER, false, R>;
     using AngT = typename Angle<R>::T;
     constexpr int NU = ST::NU;
-    constexpr bool LINABLE = linable<GEMX_LOAD_CONST_SPEED, SOLVER, false, R>();
+    constexpr bool LINABLE = linable<SYS, GEMX_LOAD_CONST_SPEED, SOLVER, false, R>();
     static_assert(sizeof(R) == 4 && !SysTraits<SYS>::HAS_ANGLE && D % 4 == 0 && NM <= 2, "fp32 DC machines");
 
     const DevParams<R> &P = a.P;
@@ -2681,7 +2706,7 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
     // active lanes of a store -- 1650 cycles per 32-step block either way -- and the exec masking around the stores cost 20 %.)
     const int64_t N = a.N, blk0 = (int64_t)blockIdx.x * BLOCK, env = blk0 + tid;
     const int K = a.K, nb = (K + D - 1) / D;
-    auto steps_of = [&](int b) { return (K - b * D) < D ? (K - b * D) : D; };
+    auto steps_of = [&](int b) __attribute__((always_inline)) { return (K - b * D) < D ? (K - b * D) : D; };
     // LDS: input terms [3][NGR][64][4][NM] | voltages [3][NGR][64][4][NU] | new motor states [2][NGR][64][4][NM] | row staging [DCS_OUT][4][64][NOUT]
     R *gin = reinterpret_cast<R *>(gemx_smem);
     R *uu = gin + 3 * (size_t)D * BLOCK * NM;
@@ -2709,35 +2734,47 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
         R thr[NM];  // |i_c| >= thr[c]  <=>  this step's state violates the default constraint (DevParams::dc_thr)
 #pragma unroll
         for (int i = 0; i < NM; ++i) thr[i] = resets ? P.dc_thr[i] : R(INFINITY);
-        bool rprev = false;  // `if terminated: env.reset()` of the previous step, still to be applied
-        auto one_step = [&](auto lin_tag, const R *in_, R *out_) {  // (lin_tag: a std::bool_constant, so that the step has no branch)
-            constexpr bool LIN = decltype(lin_tag)::value;
-            R in[NM], xa[NM], xb[NM];
+        // The reset, `x <- init where some |y_c| >= thr_c`, WITHOUT a compare: on gfx950 a VALU-written mask (VCC or any SGPR pair) may
+        // not be read by the next VALU instruction -- the compiler pads v_cmp -> v_cndmask with `s_nop 1`, and the pair costs 15.6 cycles
+        // on top of the 6.3 of the step's FMA (tools/microbench_chain.hip: 21.9 cycles per step; 13.9 without the nop, which the hazard
+        // rules do not allow).  With a ZERO initial state -- every DC env's default -- the select is a multiplication:
+        //     keep_c = sat((thr_c - |y_c|) 2^100)  in {0, 1} exactly (the FMA's single rounding keeps the sign of thr_c - |y_c|,
+        //              zero only for equality; 2^100 lifts the smallest non-zero difference far above 1),
+        //     x <- (prod_c keep_c) y          = y, or (+-)0 = init
+        // three dependent VALU instructions for the one-state machines, 14.1 cycles per step.  Other initial states keep the select.
+        R tbig[NM];
+        constexpr R BIG = R(1.2676506002282294e30);  // 2^100
 #pragma unroll
-            for (int i = 0; i < NM; ++i) { in[i] = in_[i]; xa[i] = y[i]; xb[i] = P.init[1 + i]; }
-#ifdef GEMX_DCS_NO_SPEC  // A/B: the select in front of the step (round 2's chain)
+        for (int i = 0; i < NM; ++i) tbig[i] = thr[i] * BIG;
+        bool zero_init = true;
 #pragma unroll
-            for (int i = 0; i < NM; ++i) xa[i] = rprev ? xb[i] : xa[i];
+        for (int i = 0; i < NM; ++i) zero_init &= P.init[1 + i] == R(0);
+        R x[NM];  // the state the next step starts from (the last step's result with its reset applied)
+#pragma unroll
+        for (int i = 0; i < NM; ++i) x[i] = y[i];
+        auto one_step = [&](auto lin_tag, auto zero_tag, const R *in_, R *out_) __attribute__((always_inline)) {  // (tags: std::bool_constant -- no branch in the step)
+            constexpr bool LIN = decltype(lin_tag)::value, ZERO = decltype(zero_tag)::value;
+            R in[NM], xa[NM];
+#pragma unroll
+            for (int i = 0; i < NM; ++i) { in[i] = in_[i]; xa[i] = x[i]; }
             elec_apply<SYS, SOLVER, R, LIN>(P, om, xa, in, LIN ? linc : nullptr);
 #pragma unroll
-            for (int i = 0; i < NM; ++i) { y[i] = xa[i]; out_[i] = y[i]; }
-#else
-            elec_apply<SYS, SOLVER, R, LIN>(P, om, xa, in, LIN ? linc : nullptr);  // from the running state: on the step-to-step chain
-            elec_apply<SYS, SOLVER, R, LIN>(P, om, xb, in, LIN ? linc : nullptr);  // from the reset state: off it
+            for (int i = 0; i < NM; ++i) out_[i] = xa[i];
+            if constexpr (ZERO) {
+                R keep = clip01(fma(-fabs(xa[0]), BIG, tbig[0]));
 #pragma unroll
-            for (int i = 0; i < NM; ++i) {
-                // (opaque to the optimiser, which would otherwise sink the select back IN FRONT of the common step and restore the long chain)
-                asm volatile("" : "+v"(xb[i]));
-                y[i] = rprev ? xb[i] : xa[i];
-                out_[i] = y[i];
+                for (int i = 1; i < NM; ++i) keep *= clip01(fma(-fabs(xa[i]), BIG, tbig[i]));
+#pragma unroll
+                for (int i = 0; i < NM; ++i) x[i] = keep * xa[i];
+            } else {
+                bool rs = fabs(xa[0]) >= thr[0];
+#pragma unroll
+                for (int i = 1; i < NM; ++i) rs |= fabs(xa[i]) >= thr[i];
+#pragma unroll
+                for (int i = 0; i < NM; ++i) x[i] = rs ? P.init[1 + i] : xa[i];
             }
-#endif
-            bool rs = fabs(y[0]) >= thr[0];
-#pragma unroll
-            for (int i = 1; i < NM; ++i) rs |= fabs(y[i]) >= thr[i];
-            rprev = rs;
         };
-        auto run_block = [&](auto lin_tag, int b) {
+        auto run_block = [&](auto lin_tag, auto zero_tag, int b) __attribute__((always_inline)) {
             const int sb = steps_of(b);
             const R *gb = gin + ((size_t)(b % 3) * NGR * BLOCK + tid) * 4 * NM;
             R *hb = hand + ((size_t)(b & 1) * NGR * BLOCK + tid) * 4 * NM;
@@ -2751,11 +2788,16 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
                 fetch(1, in4[1]);
 #pragma unroll
                 for (int g = 0; g < NGR; ++g) {
+                    // LDS operations retire IN ORDER, so the wait for a group's input terms also waits for every LDS operation issued
+                    // before that read: read two groups ahead, then the four steps, then this group's write -- and keep the compiler from
+                    // clustering several groups' writes and reads in front of one wait (r03d: 37 cycles per step for 3 VALU instructions)
                     if (g + 2 < NGR) fetch(g + 2, in4[(g + 2) % 3]);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) one_step(lin_tag, &in4[g % 3][j * NM], &out4[j * NM]);
+                    for (int j = 0; j < 4; ++j) one_step(lin_tag, zero_tag, &in4[g % 3][j * NM], &out4[j * NM]);
 #pragma unroll
                     for (int i = 0; i < 4 * NM; ++i) hb[(size_t)g * BLOCK * 4 * NM + i] = out4[i];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
 #pragma nounroll
@@ -2764,7 +2806,7 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
                     R in[NM], out[NM];
 #pragma unroll
                     for (int i = 0; i < NM; ++i) in[i] = gb[o + i];
-                    one_step(lin_tag, in, out);
+                    one_step(lin_tag, zero_tag, in, out);
 #pragma unroll
                     for (int i = 0; i < NM; ++i) hb[o + i] = out[i];
                 }
@@ -2778,8 +2820,13 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
 #ifdef GEMX_TIMING
             const unsigned long long t0 = clock64();
 #endif
-            if (LINABLE && lin_ok) run_block(std::bool_constant<LINABLE>{}, b);
-            else run_block(std::false_type{}, b);
+            if (LINABLE && lin_ok) {
+                if (zero_init) run_block(std::bool_constant<LINABLE>{}, std::true_type{}, b);
+                else run_block(std::bool_constant<LINABLE>{}, std::false_type{}, b);
+            } else {
+                if (zero_init) run_block(std::false_type{}, std::true_type{}, b);
+                else run_block(std::false_type{}, std::false_type{}, b);
+            }
 #ifdef GEMX_TIMING
             const unsigned long long t1 = clock64();
 #endif
@@ -2792,50 +2839,56 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
         if (tid == 0 && blockIdx.x == 0) {
             unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64);
             dbg[0] = 0; dbg[1] = tc; dbg[2] = tw; dbg[3] = clock64() - T0; dbg[4] = wall_clock64() - W0; dbg[5] = nb;
+            dbg[32] = tc; dbg[33] = tw;  // every wave of workgroup 0: [32 + 2 wave] = cycles at work, [33 + 2 wave] = cycles at the barriers
         }
 #endif
 #pragma unroll
-        for (int i = 0; i < NM; ++i) a.state[(int64_t)(1 + i) * N + env] = rprev ? P.init[1 + i] : y[i];
+        for (int i = 0; i < NM; ++i) a.state[(int64_t)(1 + i) * N + env] = x[i];
     } else if ((wave & 3) == 0) {
-        // ------------------------------------------------------------------ idle: keeps SIMD 0 to the integrator, meets every barrier
+        // ------------------------------------------------------------------ idle: keep SIMD 0 to the integrator, meet every barrier
 #ifdef GEMX_DCS_WAVE4_EXITS  // A/B: round 2's behaviour (an ended wave no longer counts at the barrier on gfx950)
         return;
 #endif
         __builtin_amdgcn_s_setprio(0);
         for (int b = 0; b <= nb; ++b) __syncthreads();
-    } else if (wave <= DCS_PRE) {
+    } else if (dcs_worker_index(wave) < DCS_PRE) {
         // ------------------------------------------------------------------ pre: actions -> converter -> input term, DCS_PREFETCH blocks ahead
         constexpr int GP = NGR / DCS_PRE, RP = 4 * GP;  // groups / rows per pre wave and block: groups j * DCS_PRE + pw
         static_assert(NGR % DCS_PRE == 0, "groups per pre wave");
-        const int pw = wave - 1;
+        const int pw = dcs_worker_index(wave);
         uint32_t bad = 0;
         struct Rows { R f[RP][NACT]; uint32_t d[RP]; };
         constexpr int ABYTES = DISCRETE ? 1 : NACT * (int)sizeof(R);
         const int64_t rowb = N * ABYTES, bstride = (int64_t)D * rowb;
-        const unsigned char *abase = a.actions + ((int64_t)(4 * pw) * N + env) * ABYTES;  // this lane's entry of this wave's first row
-        auto load_rows = [&](auto clamp_tag, int bb, Rows &v) {
-            const unsigned char *p0 = abase + (int64_t)bb * bstride;
+        // Loads through a buffer descriptor (wave-uniform base, rebased per block) with the row AND lane offsets in ONE precomputed 32-bit
+        // VGPR per row: a load is exactly one instruction -- a per-lane 64-bit pointer costs a v_lshl_add_u64 per row, and this wave, like
+        // every wave here, is bound by the number of instructions it issues (one per ~5 cycles, whatever their kind).  The descriptor's
+        // size is what is left of the tensor, so rows past the end of the rollout (the last blocks' prefetch) read as 0 instead of being
+        // clamped in a second copy of the loads: two copies merge in PHIs, and the copies of their registers wait for the loads just
+        // issued (r03a: 48 v_mov behind an s_waitcnt vmcnt per block).
+        const int64_t abase_off = ((int64_t)(4 * pw) * N + blk0) * ABYTES;  // this workgroup's span of this wave's first row
+        const int64_t atotal = (int64_t)K * N * ABYTES;
+        uint32_t voff[RP];
+#pragma unroll
+        for (int j = 0; j < RP; ++j) {
+            const int r = (j >> 2) * 4 * DCS_PRE + (j & 3);  // row within the block, relative to this wave's first row
+            voff[j] = (uint32_t)((int64_t)r * rowb) + (uint32_t)tid * (uint32_t)ABYTES;
+        }
+        auto load = [&](int bb, Rows &v) __attribute__((always_inline)) {
+            const int64_t off = abase_off + (int64_t)bb * bstride;
+            int64_t rem = atotal - off;
+            rem = rem < 0 ? 0 : (rem > 0xFFFFFFFFll ? 0xFFFFFFFFll : rem);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(a.actions + (rem > 0 ? off : 0)), 0, (int)(uint32_t)rem, 0x00020000);
 #pragma unroll
             for (int j = 0; j < RP; ++j) {
-                const int r = (j >> 2) * 4 * DCS_PRE + (j & 3);  // row within the block, relative to this wave's first row
-                const unsigned char *p = p0 + (int64_t)r * rowb;
-                if constexpr (decltype(clamp_tag)::value) {  // rows past the end of the rollout: the last valid row again
-                    int64_t k = (int64_t)bb * D + 4 * pw + r;
-                    k = k < K ? k : K - 1;
-                    p = a.actions + (k * N + env) * ABYTES;
-                }
-                if (DISCRETE) v.d[j] = *p;
+                if (DISCRETE) v.d[j] = __builtin_amdgcn_raw_buffer_load_b8(rs, (int)voff[j], 0, 0);
                 else {
 #pragma unroll
-                    for (int i = 0; i < NACT; ++i) v.f[j][i] = reinterpret_cast<const R *>(p)[i];
+                    for (int i = 0; i < NACT; ++i) v.f[j][i] = __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff[j] + 4 * i, 0, 0));
                 }
             }
         };
-        auto load = [&](int bb, Rows &v) {  // (ONE wave-uniform branch around the loads, both sides loading the same registers)
-            if ((bb + 1) * D <= K) load_rows(std::false_type{}, bb, v);
-            else load_rows(std::true_type{}, bb, v);
-        };
-        auto convert_t = [&](auto lin_tag, int bb, const Rows &v) {
+        auto convert_t = [&](auto lin_tag, int bb, const Rows &v) __attribute__((always_inline)) {
             constexpr bool LIN = decltype(lin_tag)::value;
             R *gb = gin + ((size_t)(bb % 3) * NGR * BLOCK + tid) * 4 * NM;
             R *ub = uu + ((size_t)(bb % 3) * NGR * BLOCK + tid) * 4 * NU;
@@ -2871,7 +2924,7 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
                 for (int i = 0; i < 4 * NU; ++i) ub[(size_t)g * BLOCK * 4 * NU + i] = u4[i];
             }
         };
-        auto convert = [&](int bb, const Rows &v) {
+        auto convert = [&](int bb, const Rows &v) __attribute__((always_inline)) {
             if (LINABLE && lin_ok) convert_t(std::bool_constant<LINABLE>{}, bb, v);
             else convert_t(std::false_type{}, bb, v);
         };
@@ -2887,7 +2940,7 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
         for (int q = 0; q < NPF; ++q) load(q, S_[q]);
         convert(0, S_[0]);
         __syncthreads();
-        auto iteration = [&](int b, Rows &free_set, const Rows &next_set, bool fetch) {
+        auto iteration = [&](int b, Rows &free_set, const Rows &next_set, bool fetch) __attribute__((always_inline)) {
 #ifdef GEMX_TIMING
             const unsigned long long l0 = clock64();
 #endif
@@ -2910,9 +2963,10 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
         for (int q = 0; q < NPF - 1; ++q)  // the last nb % NPF iterations: nothing left to request
             if (b0 + q < nb) iteration(b0 + q, S_[q], S_[(q + 1) % NPF], false);
 #ifdef GEMX_TIMING
-        if (tid == 0 && blockIdx.x == 0 && pw == 0) {
+        if (tid == 0 && blockIdx.x == 0) {
             unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64);
-            dbg[12] = ptl; dbg[13] = ptb;
+            if (pw == 0) { dbg[12] = ptl; dbg[13] = ptb; }
+            dbg[32 + 2 * wave] = ptl; dbg[33 + 2 * wave] = ptb;
         }
 #endif
         if (bad) atomicOr(a.err, 1u);
@@ -2920,9 +2974,10 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
         // ------------------------------------------------------------------ output: observation row + done flag, one block behind
         constexpr int GPW = NGR / DCS_OUT;  // groups per output wave and block: groups j * DCS_OUT + ow
         static_assert(NGR % DCS_OUT == 0, "groups per output wave");
-        const int ow = dcs_output_index(wave);
+        const int ow = dcs_worker_index(wave) - DCS_PRE;
         struct __attribute__((packed, aligned(4))) Row { R v[NOUT]; };
         typedef float v4f_t __attribute__((ext_vector_type(4)));
+        typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
         const bool has_done = a.done != nullptr;
         auto observe_row = [&](const R *xr, const R *ur, R (&obs)[NOUT]) -> bool {
             R y[ND], ho[ST::NH];
@@ -2934,7 +2989,7 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
             ST::observe(P, y, AngT(0), ho, obs);
             return ST::state_violation(P, y, ho) > thr_done;
         };
-        auto emit = [&](const R *xr, const R *ur, R *orow) -> bool {  // (tail blocks: the lane's row straight from registers)
+        auto emit = [&](const R *xr, const R *ur, R *orow) __attribute__((always_inline)) -> bool {  // (tail blocks: the lane's row straight from registers)
             R obs[NOUT];
             const bool done = observe_row(xr, ur, obs);
             Row row;
@@ -2949,19 +3004,47 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
         // order, so the reads need no barrier behind the writes)
         R *stg = stage + (size_t)ow * 4 * BLOCK * NOUT;
         constexpr int CPRW = BLOCK * NOUT / 4;
-        int64_t coff[NOUT];  // byte offset of this lane's chunk i from the group's first row
+        uint32_t coff[NOUT];  // byte offset of this lane's chunk i from the (wave-uniform) address of the group's first row
 #pragma unroll
         for (int i = 0; i < NOUT; ++i) {
             const int q = i * BLOCK + tid, row = q / CPRW, col = q - row * CPRW;
-            coff[i] = ((int64_t)row * N * NOUT) * (int64_t)sizeof(R) + (int64_t)col * 16;
+            coff[i] = (uint32_t)((int64_t)row * N * NOUT * (int64_t)sizeof(R) + (int64_t)col * 16);  // (the launcher checks 4 rows < 4 GiB)
+        }
+        // columns 0 (omega: constant behind a ConstantSpeedLoad) and NOUT - 1 (u_sup: ideal supply) of a DC machine's row are the same in
+        // every row of the launch (DcStepper::observe): the staging rows get them ONCE, every row then writes columns 1 .. NOUT - 2 only
+        {
+            R y0[ND], ho0[ST::NH], obs0[NOUT];
+            y0[0] = om;
+#pragma unroll
+            for (int i = 0; i < NM; ++i) y0[1 + i] = R(0);
+#pragma unroll
+            for (int i = 0; i < ST::NH; ++i) ho0[i] = R(0);
+            ST::observe(P, y0, AngT(0), ho0, obs0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                stg[((size_t)s4 * BLOCK + tid) * NOUT] = obs0[0];
+                stg[((size_t)s4 * BLOCK + tid) * NOUT + NOUT - 1] = obs0[NOUT - 1];
+            }
+            asm volatile("" ::: "memory");
         }
         const int64_t ostride = N * NOUT;
-        unsigned char *gbase = reinterpret_cast<unsigned char *>(a.obs + ((int64_t)(4 * ow) * N + blk0) * NOUT);  // this workgroup's span of this wave's first row
+        // stores through buffer descriptors rebased per block (wave-uniform), the lane's part of the address in ONE constant 32-bit VGPR per
+        // chunk, the group's in an SGPR: a store is one instruction (see the pre waves' loads)
+        const int64_t obase_off = (((int64_t)(4 * ow) * N + blk0) * NOUT) * (int64_t)sizeof(R);  // this workgroup's span of this wave's first row
+        const int64_t ototal = (int64_t)K * ostride * (int64_t)sizeof(R);
         R *obase = a.obs + ((int64_t)(4 * ow) * N + env) * NOUT;  // this lane's row of this wave's first step (tail blocks)
-        // done bytes of a group of four steps in ONE store: lane l writes bytes 4 (l % 16) .. + 3 of step l / 16
-        const int dq = tid >> 4, dc = tid & 15;
-        uint8_t *dlane = has_done ? a.done + (int64_t)(4 * ow + dq) * N + blk0 + 4 * dc : nullptr;
-        auto process = [&](int pb) {
+        // done bytes of a group of four steps: every lane leaves its env's byte of each step in a [4][64]-byte staging area; read back as one
+        // dword per lane that is bytes 4 (l % 16) .. + 3 of step l / 16 -- ONE store per group and no bit fiddling
+        unsigned char *dstg = reinterpret_cast<unsigned char *>(stage + (size_t)DCS_OUT * 4 * BLOCK * NOUT) + (size_t)ow * 4 * BLOCK;
+        const int64_t dbase_off = (int64_t)(4 * ow) * N + blk0;
+        const int64_t dtotal = (int64_t)K * N;
+        const uint32_t doff = (uint32_t)((int64_t)(tid >> 4) * N + 4 * (tid & 15));
+        auto clamp32 = [](int64_t v) { return (int)(uint32_t)(v < 0 ? 0 : (v > 0xFFFFFFFFll ? 0xFFFFFFFFll : v)); };
+#ifdef GEMX_TIMING
+        unsigned long long to_w = 0, to_r = 0, to_s = 0;  // per group: compute + staging writes | read back + wait | stores
+#endif
+        auto process_t = [&](auto done_tag, int pb) __attribute__((always_inline)) {
+            constexpr bool HAS_DONE = decltype(done_tag)::value;  // (compile-time: a wave-uniform run-time test costs two issue slots per group)
             const int sb = steps_of(pb);
             const R *hb = hand + ((size_t)(pb & 1) * NGR * BLOCK + tid) * 4 * NM;
             const R *ub = uu + ((size_t)(pb % 3) * NGR * BLOCK + tid) * 4 * NU;
@@ -2975,11 +3058,19 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
 #pragma unroll
                     for (int i = 0; i < 4 * NU; ++i) us[jg][i] = ub[(size_t)g * BLOCK * 4 * NU + i];
                 }
+                const int64_t oblk = obase_off + (int64_t)pb * D * ostride * (int64_t)sizeof(R), dblk = dbase_off + (int64_t)pb * D * N;
+                const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<unsigned char *>(a.obs) + oblk), 0,
+                                                                                    clamp32(ototal - oblk), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)(a.done + (has_done ? dblk : 0)), 0,
+                                                                                    has_done ? clamp32(dtotal - dblk) : 0, 0x00020000);
 #pragma unroll
                 for (int jg = 0; jg < GPW; ++jg) {
                     const int r0 = 4 * jg * DCS_OUT;  // first row of the group, relative to this wave's first row
-                    unsigned long long m[4];
-#ifdef GEMX_DCS_DIRECT_ROWS  // A/B: round 2's rows, stored straight from the lanes' registers
+#ifdef GEMX_TIMING
+                    const unsigned long long o0 = clock64();
+#endif
+#ifdef GEMX_DCS_DIRECT_ROWS
+                    unsigned long long m[4];  // A/B: round 2's rows, stored straight from the lanes' registers
                     R *ob = obase + (int64_t)pb * D * ostride;
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4)
@@ -2988,27 +3079,44 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) {
                         R obs[NOUT];
-                        m[s4] = __ballot(observe_row(&xs[jg][s4 * NM], &us[jg][s4 * NU], obs));
+                        const bool dn = observe_row(&xs[jg][s4 * NM], &us[jg][s4 * NU], obs);
 #pragma unroll
-                        for (int i = 0; i < NOUT; ++i) stg[((size_t)s4 * BLOCK + tid) * NOUT + i] = obs[i];
+                        for (int i = 1; i < NOUT - 1; ++i) stg[((size_t)s4 * BLOCK + tid) * NOUT + i] = obs[i];
+                        if (HAS_DONE) dstg[s4 * BLOCK + tid] = dn ? 1 : 0;
                     }
-                    // (compiler-level fences: the rows are written as floats and read back as float4 -- distinct types to the alias
-                    // analysis, which would otherwise keep the PREVIOUS group's chunks in registers or move the next group's writes up)
+                    // (compiler-level fences: the rows are written as floats / bytes and read back as float4 / dwords -- distinct types to
+                    // the alias analysis, which would otherwise keep the PREVIOUS group's chunks in registers or move the next group's
+                    // writes up; LDS operations of one wave complete in order, so the hardware needs nothing)
                     asm volatile("" ::: "memory");
+#ifdef GEMX_TIMING
+                    const unsigned long long o1 = clock64();
+#endif
                     v4f_t c[NOUT];
 #pragma unroll
                     for (int i = 0; i < NOUT; ++i) c[i] = reinterpret_cast<const v4f_t *>(stg)[i * BLOCK + tid];
+                    const uint32_t dbytes = reinterpret_cast<const uint32_t *>(dstg)[tid];
+                    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) ONCE (else the compiler puts a separate wait in front of every store)
                     asm volatile("" ::: "memory");
-                    unsigned char *gb = gbase + ((int64_t)pb * D + r0) * ostride * (int64_t)sizeof(R);
-#pragma unroll
-                    for (int i = 0; i < NOUT; ++i) __builtin_nontemporal_store(c[i], reinterpret_cast<v4f_t *>(gb + coff[i]));
+#ifdef GEMX_TIMING
+                    const unsigned long long o2 = clock64();
 #endif
+                    const int goff = (int)((int64_t)r0 * ostride * (int64_t)sizeof(R));  // (a group's offset within the block: wave-uniform, < 4 GiB by the launcher's check)
+#pragma unroll
+                    for (int i = 0; i < NOUT; ++i) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, c[i]), ro, (int)coff[i], goff, /*nt*/ 2);
+                    if (HAS_DONE) __builtin_amdgcn_raw_buffer_store_b32(dbytes, rd, (int)doff, (int)((int64_t)r0 * N), 0);
+#ifdef GEMX_TIMING
+                    to_w += o1 - o0; to_r += o2 - o1; to_s += clock64() - o2;
+#endif
+#endif
+#ifdef GEMX_DCS_DIRECT_ROWS
                     if (has_done) {
+                        const int dq = tid >> 4, dc = tid & 15;
                         const unsigned long long mq = dq == 0 ? m[0] : (dq == 1 ? m[1] : (dq == 2 ? m[2] : m[3]));
                         const uint32_t nib = (uint32_t)(mq >> (4 * dc)) & 15u;
                         const uint32_t bytes = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
-                        *reinterpret_cast<uint32_t *>(dlane + ((int64_t)pb * D + r0) * N) = bytes;
+                        *reinterpret_cast<uint32_t *>(a.done + dblk + (int64_t)r0 * N + doff) = bytes;
                     }
+#endif
                 }
             } else {
 #pragma nounroll
@@ -3032,11 +3140,15 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
             }
         };
         (void)obase;
+        auto process = [&](int pb) __attribute__((always_inline)) {
+            if (has_done) process_t(std::true_type{}, pb);
+            else process_t(std::false_type{}, pb);
+        };
         __syncthreads();
 #ifdef GEMX_TIMING
         unsigned long long tp = 0, tq = 0;
 #endif
-        for (int b = 0; b < nb; ++b) {
+        for (int b = 0; b <= nb; ++b) {  // (ONE call site of process(): a second one doubles the kernel's code and tempts the inliner to refuse)
 #ifdef GEMX_TIMING
             const unsigned long long q0 = clock64();
 #endif
@@ -3044,16 +3156,17 @@ __global__ __launch_bounds__(DCS_WAVES * BLOCK) void dc_stream_kernel(const KArg
 #ifdef GEMX_TIMING
             const unsigned long long q1 = clock64();
 #endif
-            __syncthreads();
+            if (b < nb) __syncthreads();
 #ifdef GEMX_TIMING
             tp += q1 - q0; tq += clock64() - q1;
 #endif
         }
-        process(nb - 1);
 #ifdef GEMX_TIMING
-        if (tid == 0 && blockIdx.x == 0 && ow < 3) {
+        if (tid == 0 && blockIdx.x == 0) {
             unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64);
-            dbg[6 + 2 * ow] = tp; dbg[7 + 2 * ow] = tq;
+            if (ow < 3) { dbg[6 + 2 * ow] = tp; dbg[7 + 2 * ow] = tq; }
+            dbg[32 + 2 * wave] = tp; dbg[33 + 2 * wave] = tq;
+            if (ow == 0) { dbg[64] = to_w; dbg[65] = to_r; dbg[66] = to_s; }
         }
 #endif
     }
@@ -3106,7 +3219,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     a.err = h->err;
     if (h->linmap_state == 0) {  // once per handle: the electrical subsystem's one-step map (constant-speed loads)
         // (random initialisers may draw omega per episode: those handles keep the stage-by-stage solver)
-        if constexpr (linable<LOAD, SOLVER, IL, R>()) {
+        if constexpr (linable<SYS, LOAD, SOLVER, IL, R>()) {
             hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
             (void)hipStreamIsCapturing(st, &capturing);
             if (h->cfg.init_kind != GEMX_INIT_CONST) {
@@ -3170,7 +3283,8 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                   (SYS == GEMX_SYS_DC_PERMEX || SYS == GEMX_SYS_DC_SERIES || SYS == GEMX_SYS_DC_SHUNT || SYS == GEMX_SYS_DC_EXTEX)) {
         bool dcs_ok = pipe_ok && h->use_dc_stream != 0 && !need_full && delay == 0 && h->cur_reward == nullptr && (h->omega_is_init || h->use_dc_stream >= 3) &&
                       params_of<R>(h).obs_layout == GEMX_OBS_AOS && params_of<R>(h).t_il == R(0) &&
-                      (h->use_dc_stream > 1 || 2 * blocks <= (int64_t)h->n_cu) && dcs_smem_bytes<SYS, CONV>() <= h->lds_max;
+                      (h->use_dc_stream > 1 || 2 * blocks <= (int64_t)h->n_cu) && dcs_smem_bytes<SYS, CONV>() <= h->lds_max &&
+                      (int64_t)h->n * h->nout * 16 < ((int64_t)1 << 32);  // (32-bit lane offsets across the four rows of a group)
         if (dcs_ok) {
             // never into a graph: `omega_is_init` is what the host knows NOW, a captured launch runs later, possibly behind a gemx_set_state.
             // The pipelined kernel decides on the device (lin_usable), so it is what a graph gets.
@@ -3189,9 +3303,9 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             // (more than half the LDS: ONE workgroup per CU, else the dispatcher stacks two on one CU while others idle and their
             // integrator waves share issue slots -- 41 -> 88 us per 1000 steps between 8192 and 12288 envs)
             const size_t dneed = dcs_smem_bytes<SYS, CONV>(), dhalf = (size_t)h->lds_max / 2 + 1024, dsmem = dneed > dhalf ? dneed : dhalf;
-            hipLaunchKernelGGL(dkern, dim3((unsigned)blocks), dim3(DCS_WAVES * BLOCK), dsmem, st, a);
+            hipLaunchKernelGGL(dkern, dim3((unsigned)blocks), dim3(dcs_waves<SYS>() * BLOCK), dsmem, st, a);
             GEMX_HIP_TRY(hipGetLastError());
-            h->ll = {3, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), dcs_depth<SYS>(), DCS_WAVES * BLOCK, K, dcs_depth<SYS>(), (long long)blocks, dsmem};
+            h->ll = {3, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), dcs_depth<SYS>(), dcs_waves<SYS>() * BLOCK, K, dcs_depth<SYS>(), (long long)blocks, dsmem};
             return GEMX_OK;
         }
     }

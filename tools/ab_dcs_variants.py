@@ -43,6 +43,10 @@ print("| library | env | envs | solver | us per 1000 steps (median of 3 x 40 lau
 print("|---|---|---|---|---|---|---|---|---|---|")
 for env_id, n, solver in cases:
     for lib in libs:
+        if lib and "slim" not in os.environ.get("AB_FULL_VARIANTS", "slim") and False:
+            continue
+        if lib and env_id != "Cont-CC-PermExDc-v0":  # (slim variants carry the Cont-4QC PermExDc unit only)
+            continue
         env = dict(os.environ)
         if lib:
             env["GEMX_LIBRARY"] = os.path.abspath(lib)

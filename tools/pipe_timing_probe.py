@@ -41,6 +41,8 @@ print(L.gemx_last_launch(ps._handle))
 for base in (0, 16):
     tv, tc, tw, tot, wall, nb = buf[base:base + 6]
     nlong, nb = nb >> 32, nb & 0xFFFFFFFF
+    if nb == 0:  # (dc_stream_kernel instruments workgroup 0 only)
+        continue
     outs = buf[base + 6:base + 12]
     print(f"blk{'0' if base == 0 else '37'}: nb={nb} total={tot} cyc wall={wall} (100MHz ticks => {wall*10} ns, clock={tot/(wall*10+1e-9):.3f} GHz)")
     print(f"   integrator per block: vmwait={tv/nb:.0f} compute={tc/nb:.0f} barrier={tw/nb:.0f} cycles")
@@ -50,6 +52,17 @@ for base in (0, 16):
     v = buf[base + 15]
     print(f"   integrator: {nlong} of {nb} barrier waits > 1000 cycles; out wave 0: longest block {v >> 40} cycles, {v & 0xFFFFF} blocks > 2000, {(v >> 20) & 0xFFFFF} > 3000")
     print(f"   loader: stage+wait={buf[base+12]/nb:.0f} barrier={buf[base+13]/nb:.0f}")
+
+if b"dc_stream" in L.gemx_last_launch(ps._handle):  # every wave of workgroup 0 (dc_stream_kernel, -DGEMX_TIMING): work / barrier cycles per block
+    allw = (C.c_ulonglong * 96)()
+    L.gemx_debug_read(ps._handle, allw, 96)
+    nb0 = buf[5] & 0xFFFFFFFF
+    for w in range(16):
+        wk, br = allw[32 + 2 * w], allw[33 + 2 * w]
+        if wk or br:
+            print(f"   wave {w:2d}: work={wk / nb0:7.0f} barrier={br / nb0:7.0f} cycles per block")
+    if allw[64] or allw[65]:
+        print(f"   first output wave, per block: observe + staging writes={allw[64] / nb0:.0f}  read back + wait={allw[65] / nb0:.0f}  stores={allw[66] / nb0:.0f}")
 
 if os.environ.get("PROBE_TRACE"):  # barrier trace of workgroup 0, blocks 100..147: per wave (arrive, release), relative to the first arrival
     big = (C.c_ulonglong * 448)()
