@@ -414,7 +414,7 @@ struct gemx_handle {
     void *angle = nullptr;   // [n] int32 | double
     uint8_t *sw = nullptr;   // [sw_rows][n]
     int sw_rows = 1;
-    void *linmap_dev = nullptr;  // one-step map of the electrical subsystem (constant-speed loads), R[64]
+    void *linmap_dev = nullptr;  // one-step maps of the electrical subsystem (constant-speed loads), R[3][lin_count]: tau, t_il, tau - t_il
     int linmap_state = 0;        // 0: not built yet, 1: built and enabled, -1: not applicable
     void *rinit_dev = nullptr;  // InitDev (random initial states)
     uint32_t *rcnt = nullptr;   // [n] resets so far per env

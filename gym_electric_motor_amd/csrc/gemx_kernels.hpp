@@ -30,9 +30,14 @@ namespace gemx {
 // ------------------------------------------------------------------------------------------------
 // load: d(omega)/dt (constant_speed_load.py:40-42; polynomial_static_load.py:62-66, 87-99)
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float med3_r(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+__device__ __forceinline__ double med3_r(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 template <class R> __device__ __forceinline__ R poly_load_ode(const DevParams<R> &P, R omega, R torque) {
-    // sign(w) * c * w^2 = c * w * |w|; sign(w) * a only matters where |w| > limit >= 0, i.e. w != 0: copysign(1, w) (one v_bfi) does
-    const R a = fabs(omega) > P.omega_lim ? copysign(R(1), omega) * P.la : P.lin_factor * omega;
+    // sign(w) * c * w^2 = c * w * |w|.  The constant term -- sign(w) a beyond |w| = a tau_decay / J, (J / tau_decay) w inside
+    // (polynomial_static_load.py:87-92) -- IS the saturation clamp((J / tau_decay) w, -a, a): one multiply and one v_med3_f32.  As a
+    // compare + select it was a VALU-written mask in every Runge-Kutta stage, which the next VALU instruction may not read on gfx950
+    // (`s_nop 1` + ~8 cycles each, tools/microbench_chain.hip).  At |w| within an ulp of the kink the two forms differ by an ulp of a.
+    const R a = med3_r(P.lin_factor * omega, -P.la, P.la);
     const R tl = P.lc * (omega * fabs(omega)) + P.lb * omega + a;
     return (torque - tl) * P.inv_j;
 }
@@ -246,8 +251,11 @@ __device__ __forceinline__ R rk_step(R (&z)[NZ], R h, F &&rhs) {
 // x1 = Phi x0 + S g with Phi = R(hA), S = h (R(hA) - I)(hA)^-1 (R = the scheme's stability polynomial).  P.lin holds Phi and S as
 // linmap_kernel obtained them by pushing unit vectors through rk_step itself; a step is then NM*(NM+NG) FMAs instead of 4 (RK4) or
 // 6 (DP5) right-hand sides plus stage combinations.  Same polynomial, so same result up to rounding.
-template <int SYS, int LOAD, int SOLVER, class R, bool NS1 = false, bool LIN = false>
-__device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<SYS>::ND], const R (&u)[MAX_U], R h, const R *linr = nullptr) {
+// SEG (LIN only): which of the handle's three maps steps this segment -- 0: the whole control step tau; with converter dead time a step
+// may be cut at the switching instant (converters.py:302-310): 1 = FIRST segment, of length t_il in the lanes with a switching leg (`two`)
+// and tau in the others (per-lane select of the coefficients), 2 = the rest, tau - t_il.  linmap_kernel builds all three.
+template <int SYS, int LOAD, int SOLVER, class R, bool NS1 = false, bool LIN = false, int SEG = 0>
+__device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<SYS>::ND], const R (&u)[MAX_U], R h, const R *linr = nullptr, bool two = false) {
     using E = Elec<SYS, R>;
     constexpr int NM = E::NM;
     const int ns = NS1 ? 1 : P.nsteps;     // NS1: the caller guarantees solver_nsteps == 1 (branch-free code)
@@ -258,7 +266,21 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
         // the map's coefficients: from the caller's registers when it preloaded them (lin_preload), else through the device pointer --
         // which, inside a rolled step loop, is TWO vector loads and a full trip to memory on every step (they cannot be hoisted out of the
         // `lin_ok` branch): the run-time-checked copies of the step spent 680 of their 1190 cycles per step there (s_memtime probe)
-        const R *L = linr != nullptr ? linr : P.lin;
+        const R *L0 = linr != nullptr ? linr : P.lin;
+        constexpr int NC = NM * (NM + NG);
+        R L[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            if constexpr (SEG == 1) {
+                // a per-lane select between two REGISTERS: made opaque, because the optimiser turns `two ? a[i] : b[i]` into ONE load at a
+                // selected address -- which demotes the preloaded coefficients to scratch memory and puts two scratch loads on every step
+                R c_tau = L0[i], c_til = L0[NC + i];
+                asm volatile("" : "+v"(c_tau), "+v"(c_til));
+                L[i] = two ? c_til : c_tau;
+            } else {
+                L[i] = L0[SEG == 2 ? 2 * NC + i : i];
+            }
+        }
         const R om = P.init[0];  // == y[0] in every lane (lin_usable); wave-uniform, so everything derived from it is loop-invariant
         E::get_b(E::prep(P, om, u), g);
 #pragma unroll
@@ -476,11 +498,14 @@ __device__ __forceinline__ void b6_voltages(const DevParams<R> &P, const R (&act
 __device__ __forceinline__ float rsqrt_r(float x) { return __frsqrt_rn(x); }  // V_RSQ_F32, 1 ulp (an IEEE division is ~12 instructions)
 __device__ __forceinline__ double rsqrt_r(double x) { return 1.0 / sqrt(x); }
 template <class R> __device__ __forceinline__ void flux_angle(R pa, R pb, R &s, R &c) {
-    R n2 = pa * pa + pb * pb;
-    if (n2 < R(1e-30)) { pa *= R(1e18); pb *= R(1e18); n2 = pa * pa + pb * pb; }
-    const R rn = n2 > R(0) ? rsqrt_r(n2) : R(0);
-    c = n2 > R(0) ? pa * rn : R(1);  // atan2(0, 0) = 0
-    s = pb * rn;
+    // Branch- and compare-free: both components scaled by 2^40 (exact; the squares of any flux from 1e-31 to 1e6 Wb stay normal
+    // numbers) and 2^-50 added to the alpha component -- invisible next to a flux above 1e-20 Wb, and a flux of exactly zero (every
+    // episode starts there) gives c = 1, s = 0, i.e. atan2(0, 0) = 0 as the reference's np.arctan2 does.  (Round 2: three compares and
+    // four selects per call, each compare a VALU-written mask with its `s_nop`.)
+    const R qa = fma(pa, R(1099511627776.0), R(8.8817841970012523e-16)), qb = pb * R(1099511627776.0);
+    const R rn = rsqrt_r(qa * qa + qb * qb);
+    c = qa * rn;
+    s = qb * rn;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -582,7 +607,7 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
                 if (P.t_il > R(0)) legs = b6_interlock<2 * NU>(sw, legs, two);
                 sw = legs;
             }
-            auto segment = [&](R h) {
+            auto segment = [&](R h, auto seg_tag) {
 #pragma unroll
                 for (int j = 0; j < NU; ++j) {
                     const uint32_t s0 = (legs >> (4 * j)) & 3u, s1 = (legs >> (4 * j + 2)) & 3u;
@@ -597,13 +622,13 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
                     }
                     u[j] = (v0 - v1) * P.u_sup;
                 }
-                integrate<SYS, LOAD, SOLVER, R, NS1, LIN>(P, y, u, h, linr);
+                integrate<SYS, LOAD, SOLVER, R, NS1, LIN, decltype(seg_tag)::value>(P, y, u, h, linr, two);
             };
             if (IL) {
-                segment(two ? P.t_il : P.tau);
-                if (two) segment(P.tau - P.t_il);
+                segment(two ? P.t_il : P.tau, std::integral_constant<int, 1>{});
+                if (two) segment(P.tau - P.t_il, std::integral_constant<int, 2>{});
             } else {
-                segment(P.tau);
+                segment(P.tau, std::integral_constant<int, 0>{});
             }
         }
 #pragma unroll
@@ -681,7 +706,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             sw = legs;
         }
         R ua, ub, uc, u[MAX_U] = {R(0), R(0), R(0), R(0)};
-        auto segment = [&](R h) {
+        auto segment = [&](R h, auto seg_tag) {
             R ia = R(0), ib = R(0), ic = R(0);
             if (IL) {  // i_in = T32(Q(i_dq, eps)) (line 493/505); only its sign matters (dead legs / cont. interlocking)
                 const R ial = c * y[1] - s * y[2], ibe = s * y[1] + c * y[2];
@@ -696,17 +721,17 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             }
             u[0] = c * ual + s * ube;  // Q^-1(., eps): u_dq frozen at the segment-start angle (line 501/511)
             u[1] = -s * ual + c * ube;
-            const R deps = integrate<GEMX_SYS_SYNC, LOAD, SOLVER, R, NS1, LIN>(P, y, u, h, linr);
+            const R deps = integrate<GEMX_SYS_SYNC, LOAD, SOLVER, R, NS1, LIN, decltype(seg_tag)::value>(P, y, u, h, linr, two);
             ang = Angle<R>::advance(ang, deps);
         };
         if (IL) {
-            segment(two ? P.t_il : P.tau);
+            segment(two ? P.t_il : P.tau, std::integral_constant<int, 1>{});
             if (two) {  // exec-masked; the whole wave skips it when no lane switches (s_cbranch_execz)
                 Angle<R>::sincos(ang, s, c);  // eps / i_in refreshed at the switching instant (lines 504-505)
-                segment(P.tau - P.t_il);
+                segment(P.tau - P.t_il, std::integral_constant<int, 2>{});
             }
         } else {
-            segment(P.tau);
+            segment(P.tau, std::integral_constant<int, 0>{});
         }
         ho[0] = s; ho[1] = c; ho[2] = ua; ho[3] = ub; ho[4] = uc; ho[5] = u[0]; ho[6] = u[1];
     }
@@ -848,7 +873,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             sw = legs;
         }
         R ua, ub, uc, u[MAX_U] = {R(0), R(0), R(0), R(0)};
-        auto segment = [&](R h) {
+        auto segment = [&](R h, auto seg_tag) {
             R ia = R(0), ib = R(0), ic = R(0);
             if (IL) t32(y[1], y[2], ia, ib, ic);  // i_in = T32(i_alphabeta) (line 780/792)
             if (TAB) {  // this action's table entry
@@ -857,17 +882,17 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
                 b6_voltages<CONV, IL, R>(P, act, dact, legs, ia, ib, ic, ua, ub, uc);
                 t23(ua, ub, uc, u[0], u[1]);  // u_alphabeta constant over the segment (line 788/799)
             }
-            const R deps = integrate<GEMX_SYS_SCIM, LOAD, SOLVER, R, NS1, LIN>(P, y, u, h, linr);
+            const R deps = integrate<GEMX_SYS_SCIM, LOAD, SOLVER, R, NS1, LIN, decltype(seg_tag)::value>(P, y, u, h, linr, two);
             ang = Angle<R>::advance(ang, deps);
         };
         if (IL) {
-            segment(two ? P.t_il : P.tau);
+            segment(two ? P.t_il : P.tau, std::integral_constant<int, 1>{});
             if (two) {
                 field_angle(y[3], y[4], s, c);  // line 791
-                segment(P.tau - P.t_il);
+                segment(P.tau - P.t_il, std::integral_constant<int, 2>{});
             }
         } else {
-            segment(P.tau);
+            segment(P.tau, std::integral_constant<int, 0>{});
         }
         ho[0] = s; ho[1] = c; ho[2] = ua; ho[3] = ub; ho[4] = uc; ho[5] = u[0]; ho[6] = u[1];
     }
@@ -929,7 +954,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             sw = legs;
         }
         R usa, usb, usc, urd, ure, urf, u[MAX_U];
-        auto segment = [&](R h) {
+        auto segment = [&](R h, auto seg_tag) {
             R isa = R(0), isb = R(0), isc = R(0), ird = R(0), ire = R(0), irf = R(0);
             if (IL) {  // i_sabc = T32(i_s alphabeta); i_rdef = T32(calculate_rotor_current(state)) (lines 960-963, 980-981)
                 t32(y[1], y[2], isa, isb, isc);
@@ -943,18 +968,18 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             t23(urd, ure, urf, urg, urh);
             u[2] = ce * urg - se * urh;
             u[3] = se * urg + ce * urh;
-            const R deps = integrate<GEMX_SYS_DFIM, LOAD, SOLVER, R, NS1, LIN>(P, y, u, h, linr);
+            const R deps = integrate<GEMX_SYS_DFIM, LOAD, SOLVER, R, NS1, LIN, decltype(seg_tag)::value>(P, y, u, h, linr, two);
             ang = Angle<R>::advance(ang, deps);
         };
         if (IL) {
-            segment(two ? P.t_il : P.tau);
+            segment(two ? P.t_il : P.tau, std::integral_constant<int, 1>{});
             if (two) {
                 SC::field_angle(y[3], y[4], sf, cf);  // lines 978-979
                 Angle<R>::sincos_precise(ang, se, ce);
-                segment(P.tau - P.t_il);
+                segment(P.tau - P.t_il, std::integral_constant<int, 2>{});
             }
         } else {
-            segment(P.tau);
+            segment(P.tau, std::integral_constant<int, 0>{});
         }
         ho[0] = sf; ho[1] = cf; ho[2] = se; ho[3] = ce; ho[4] = usa; ho[5] = usb; ho[6] = usc; ho[7] = urd; ho[8] = ure; ho[9] = urf;
     }
@@ -1093,7 +1118,7 @@ __device__ __forceinline__ void full_step(const DevParams<R> &P, R (&y)[ND], typ
 // ONE-state machines -- there the map is one multiply (the input term, off the recurrence) and one FMA against Euler's two dependent
 // FMAs; with two states it is 8 FMAs against 6
 template <int SYS, int LOAD, int SOLVER, bool IL, class R> constexpr bool linable() {
-    return LOAD == GEMX_LOAD_CONST_SPEED && !IL && (SOLVER != GEMX_SOLVER_EULER || Elec<SYS, R>::NM == 1) && sizeof(R) == 4;
+    return LOAD == GEMX_LOAD_CONST_SPEED && (SOLVER != GEMX_SOLVER_EULER || Elec<SYS, R>::NM == 1) && sizeof(R) == 4;
 }
 // the map is valid for a wave if every lane's omega equals init[0] (then it stays so: a ConstantSpeedLoad never changes omega, and a
 // reset puts init[0] back); omega set to something else through gemx_set_state falls back to the stage-by-stage solver
@@ -1103,35 +1128,42 @@ template <int SYS, int LOAD, int SOLVER, bool IL, class R> __device__ __forceinl
 }
 // the map's NM * (NM + NG) coefficients into registers, once per kernel (see integrate<..., LIN>)
 template <int SYS, class R> constexpr int lin_count() { return Elec<SYS, R>::NM * (Elec<SYS, R>::NM + Elec<SYS, R>::NG); }
-template <int SYS, class R> __device__ __forceinline__ void lin_preload(const DevParams<R> &P, bool lin_ok, R (&c)[lin_count<SYS, R>()]) {
+// registers of a kernel instantiation's preloaded coefficients: one map, or the three segment maps of the dead-time (IL) instantiations
+template <int SYS, class R, bool IL> constexpr int lin_regs() { return lin_count<SYS, R>() * (IL ? 3 : 1); }
+template <int SYS, class R, int NR> __device__ __forceinline__ void lin_preload(const DevParams<R> &P, bool lin_ok, R (&c)[NR]) {
 #pragma unroll
-    for (int i = 0; i < lin_count<SYS, R>(); ++i) c[i] = lin_ok ? P.lin[i] : R(0);
+    for (int i = 0; i < NR; ++i) c[i] = lin_ok ? P.lin[i] : R(0);
 }
 // builds the map for one handle: Phi's columns are rk_step(e_j) with g = 0, S's columns rk_step(0) with g = e_i
 template <int SYS, int SOLVER, class R> __global__ void linmap_kernel(DevParams<R> P, R *out) {
     using E = Elec<SYS, R>;
-    constexpr int NM = E::NM, NG = E::NG;
+    constexpr int NM = E::NM, NG = E::NG, NC = NM * (NM + NG);
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const R hs = P.tau * P.inv_ns;
     const R u0[MAX_U] = {R(0), R(0), R(0), R(0)};
     R zg[NG];
     for (int i = 0; i < NG; ++i) zg[i] = R(0);
     const typename E::Pre pre0 = E::set_b(E::prep(P, P.init[0], u0), zg);
-    for (int j = 0; j < NM; ++j) {
-        R x[NM];
-        for (int i = 0; i < NM; ++i) x[i] = i == j ? R(1) : R(0);
-        auto rhs = [&](const R (&xx)[NM], R (&dx)[NM]) { E::f(P, pre0, xx, dx); };
-        rk_step<SOLVER, NM, R>(x, hs, rhs);
-        for (int r = 0; r < NM; ++r) out[r * NM + j] = x[r];
-    }
-    for (int i = 0; i < NG; ++i) {
-        R gi[NG], x[NM];
-        for (int k = 0; k < NG; ++k) gi[k] = k == i ? R(1) : R(0);
-        for (int k = 0; k < NM; ++k) x[k] = R(0);
-        const typename E::Pre prei = E::set_b(pre0, gi);
-        auto rhs = [&](const R (&xx)[NM], R (&dx)[NM]) { E::f(P, prei, xx, dx); };
-        rk_step<SOLVER, NM, R>(x, hs, rhs);
-        for (int r = 0; r < NM; ++r) out[NM * NM + r * NG + i] = x[r];
+    // map 0: the whole control step; maps 1 / 2: the two segments of a step cut by converter dead time (integrate<..., SEG>)
+    const R hseg[3] = {P.tau, P.t_il, P.tau - P.t_il};
+    for (int k = 0; k < 3; ++k) {
+        const R hs = hseg[k] * P.inv_ns;
+        R *o = out + k * NC;
+        for (int j = 0; j < NM; ++j) {
+            R x[NM];
+            for (int i = 0; i < NM; ++i) x[i] = i == j ? R(1) : R(0);
+            auto rhs = [&](const R (&xx)[NM], R (&dx)[NM]) { E::f(P, pre0, xx, dx); };
+            rk_step<SOLVER, NM, R>(x, hs, rhs);
+            for (int r = 0; r < NM; ++r) o[r * NM + j] = x[r];
+        }
+        for (int i = 0; i < NG; ++i) {
+            R gi[NG], x[NM];
+            for (int q = 0; q < NG; ++q) gi[q] = q == i ? R(1) : R(0);
+            for (int q = 0; q < NM; ++q) x[q] = R(0);
+            const typename E::Pre prei = E::set_b(pre0, gi);
+            auto rhs = [&](const R (&xx)[NM], R (&dx)[NM]) { E::f(P, prei, xx, dx); };
+            rk_step<SOLVER, NM, R>(x, hs, rhs);
+            for (int r = 0; r < NM; ++r) o[NM * NM + r * NG + i] = x[r];
+        }
     }
 }
 
@@ -1432,7 +1464,7 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
                                               R (&obs)[SysTraits<SYS>::NOUT], uint32_t &done_or, uint32_t &bad_action, R *ring,
                                               const unsigned char *atile, unsigned char *donebuf, int k0, int sb, int tid,
                                               int64_t e, typename Angle<R>::T init_ang, R *fifo, int &slot, R (&sup)[2], bool lin_ok,
-                                              const R (&linc)[lin_count<SYS, R>()]) {
+                                              const R (&linc)[lin_regs<SYS, R, IL>()]) {
     constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
     constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
     constexpr int ABYTES = DISCRETE ? 1 : NACT * (int)sizeof(R);
@@ -1601,7 +1633,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SYS == GE
     }
     const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
     const bool lin_ok = lin_usable<SYS, LOAD, SOLVER, IL, R>(P, y[0]);  // wave-uniform
-    R linc[lin_count<SYS, R>()];  // the one-step map's coefficients, in registers for the whole launch (drained with the prologue loads)
+    R linc[lin_regs<SYS, R, IL>()];  // the one-step map's coefficients, in registers for the whole launch (drained with the prologue loads)
     lin_preload<SYS, R>(P, linable<SYS, LOAD, SOLVER, IL, R>() && lin_ok, linc);
     R sup[2] = {P.u_sup, R(0)};  // RCVoltageSupply: capacitor voltage, time since the supply's last update
     if (P.rc_supply) {
@@ -2020,7 +2052,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
         //            the last `delay` rows of the previous block / of the HBM ring), zeroed while fewer than `delay` steps have passed
         //            since the env's last reset (`since`).  It keeps the unrolled, table-driven blocks; deep shape only, and not
         //            behind a DqToAbcActionProcessor, whose transform (a function of the state at SUBMISSION time) precedes the queue.
-        R linc[lin_count<SYS, R>()];
+        R linc[lin_regs<SYS, R, IL>()];
         lin_preload<SYS, R>(P, LINABLE && lin_ok, linc);
         constexpr bool CAN_DELAY = D == PIPE_D && !FULL;
         const uint32_t delay_u = (uint32_t)P.delay;
@@ -2714,7 +2746,7 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
     R *stage = hand + 2 * (size_t)D * BLOCK * NM;
     const R om = P.init[0];  // == omega of every env (launcher); a ConstantSpeedLoad never changes it, a reset puts it back
     const bool lin_ok = LINABLE && P.lin_on != 0;  // wave-uniform
-    R linc[lin_count<SYS, R>()];
+    R linc[lin_regs<SYS, R, false>()];
     lin_preload<SYS, R>(P, lin_ok, linc);
     const bool check_default = P.constr_kind == 1;
     const R thr_done = check_default ? R(1) : R(INFINITY);

@@ -10,6 +10,7 @@ Tolerances (normalised states are O(1); angle compared on the circle):
   * "rel" = max |got - ref| of a column / max(|ref| range of that column, 1e-3)
 """
 import glob
+import sys
 import json
 import os
 
@@ -18,6 +19,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))  # (sibling test modules: shared transcript helpers)
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz")) if "converter_kats" not in f and "init_samples" not in f and "wiener_samples" not in f)
 
@@ -1734,3 +1736,46 @@ def test_rccl_gather_of_real_rollout_outputs_in_a_world_of_one():
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     r = subprocess.run([sys.executable, "-c", _RCCL_WORLD1 % repo], env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("name", ["Cont-CC-PermExDc-v0", "Finite-CC-PMSM-v0", "Cont-SC-SCIM-v0", "Finite-CC-PMSM-v0_DeadTime2"])
+def test_replay_of_the_reference_env_shell_transcript(name):
+    """The contract of the drop-in seam, replayed: tests/golden/shell_*.json is the ordered list of everything the UNMODIFIED reference
+    env shell (ElectricMotorEnvironment, core.py:197-371, with its reference generator, reward function, constraint monitor and
+    dashboards) read from and called on its physical system over a seeded 200-step run with resets -- recorded in the build container by
+    oracle/make_shell_transcript.py (the GPU box has no reference; the build container has no GPU).  `make(env_id, n_envs=1)`'s physical
+    system answers the same sequence: metadata reads identically, `k` exactly, `reset()` to 1e-12, `simulate(action)` within the 1e-4
+    contract of the reference's default solver (numpy in, 1-D numpy out, as core.py:328-371 consumes it)."""
+    import gym_electric_motor_amd as ga
+    from test_host_cpu import _decode, check_shell_get, shell_transcript
+
+    doc = shell_transcript(name)
+    wr = (ga.DeadTimeProcessor(steps=2),) if doc["wrappers"] else ()
+    env = ga.make(doc["env_id"], n_envs=1, physical_system_wrappers=wr)
+    ps = env.physical_system
+    got, ref, n_sim, n_reset = [], [], 0, 0
+    for e in doc["log"]:
+        if e["op"] == "get":
+            if e["name"] == "k":
+                assert ps.k == e["value"], (ps.k, e["value"])
+            else:
+                check_shell_get(ps, e)
+            continue
+        args, ret = _decode(e["args"]), _decode(e["ret"])
+        if e["name"] == "simulate":
+            out = ps.simulate(*args)
+            assert isinstance(out, np.ndarray) and out.ndim == 1 and out.dtype == np.float64 and out.shape == ret.shape
+            got.append(out)
+            ref.append(ret)
+            n_sim += 1
+        elif e["name"] == "reset":
+            out = ps.reset(*args)
+            assert isinstance(out, np.ndarray) and np.abs(out - ret).max() < 1e-12
+            n_reset += 1
+        elif e["name"] == "close":
+            ps.close()
+        else:
+            raise AssertionError(f"the shell called {e['name']}: not part of the surface this test knows")
+    assert n_sim == doc["steps"] and n_reset >= 1
+    rel, ab = _rel_err(np.asarray(got), np.asarray(ref), list(ps.state_names))
+    assert rel < 1e-4, (rel, ab)

@@ -479,3 +479,66 @@ def test_bench_cli_contract_without_a_gpu():
     if not torch.cuda.is_available():  # self-spawn without enough GPUs: a clear message
         r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=env)
         assert r.returncode != 0 and "GPU(s) visible" in r.stderr
+
+
+# ------------------------------------------------------------------------------------------------ the reference env shell's transcript
+def _decode(v):
+    """inverse of oracle/make_shell_transcript.py:encode"""
+    if isinstance(v, dict):
+        if "f" in v:
+            return float(v["f"])
+        if "nd" in v:
+            return np.array([float(x) for x in v["nd"]], dtype=np.float64).reshape(v["shape"])
+        if "seq" in v:
+            s = [_decode(x) for x in v["seq"]]
+            return tuple(s) if v["tuple"] else s
+        if "dict" in v:
+            return {k: _decode(x) for k, x in v["dict"].items()}
+        return v  # Box / Discrete / MultiDiscrete / object descriptors
+    return v
+
+
+def shell_transcript(name):
+    import json
+
+    with open(os.path.join(REPO, "tests", "golden", f"shell_{name}.json")) as fh:
+        return json.load(fh)
+
+
+def check_shell_get(ps, entry):
+    """One attribute READ of the reference env shell against the replacement physical system."""
+    name, want = entry["name"], _decode(entry["value"])
+    got = getattr(ps, name)
+    if isinstance(want, dict) and "Box" in want:
+        assert np.allclose(np.asarray(got.low, dtype=float), _decode(want["Box"]["low"]), rtol=1e-13, atol=0), name
+        assert np.allclose(np.asarray(got.high, dtype=float), _decode(want["Box"]["high"]), rtol=1e-13, atol=0), name
+        assert list(got.shape) == want["Box"]["shape"]
+    elif isinstance(want, dict) and "Discrete" in want:
+        assert int(got.n) == want["Discrete"]
+    elif isinstance(want, np.ndarray):
+        assert np.allclose(np.asarray(got, dtype=float), want, rtol=1e-13, atol=0), (name, got, want)
+    elif isinstance(want, float):
+        assert got == pytest.approx(want, rel=1e-15), name
+    else:
+        assert (list(got) if isinstance(want, list) else got) == want, (name, got, want)
+
+
+@pytest.mark.parametrize("name", ["Cont-CC-PermExDc-v0", "Finite-CC-PMSM-v0", "Cont-SC-SCIM-v0", "Finite-CC-PMSM-v0_DeadTime2"])
+def test_reference_env_shell_reads_are_answered_identically(name):
+    """tests/golden/shell_*.json: every attribute the UNMODIFIED reference env shell (ElectricMotorEnvironment + its reference generator,
+    reward function, constraint monitor, dashboards; core.py:197-371) read from its physical system, from construction over a 200-step
+    run -- recorded by oracle/make_shell_transcript.py through a proxy.  Host part: the replacement offers every name the shell touched and
+    answers every metadata read identically (the calls -- simulate / reset -- are replayed on the GPU: tests/test_gpu_parity.py)."""
+    doc = shell_transcript(name)
+    wr = (ga.DeadTimeProcessor(steps=2),) if doc["wrappers"] else ()
+    ps = ga.make(doc["env_id"], n_envs=1, physical_system_wrappers=wr, _defer_create=True).physical_system
+    assert set(doc["attribute_names"]) == {"action_space", "close", "k", "limits", "nominal_state", "reset", "simulate", "state_names",
+                                           "state_positions", "state_space", "tau"}  # the whole surface the shell uses
+    for n in doc["attribute_names"]:
+        assert hasattr(ps, n), n
+    n_get = 0
+    for e in doc["log"]:
+        if e["op"] == "get" and e["name"] != "k":  # (k counts simulate() calls: checked in the GPU replay)
+            check_shell_get(ps, e)
+            n_get += 1
+    assert n_get > 25 and not any(e["op"] == "set" for e in doc["log"])
