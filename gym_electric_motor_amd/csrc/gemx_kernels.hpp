@@ -2659,25 +2659,25 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
 // converter stage, the solver, the constraint, the reset and a 16-byte hand-off write: 150 cycles per step for a one-state motor.  Here the
 // step's recurrence is all the integrator wave keeps.  With omega constant and no dead time the electrical right-hand side is
 // f(x) = A x + g(u_k), and g(u_k) does not depend on the state, so
-//   * PRE waves (DCS_PRE of them, alternating groups of four steps) load the action rows DCS_PREFETCH blocks ahead straight into registers,
-//     run the converter stage and Elec::prep, and leave the step's input term (elec_input(): g, or S g of the one-step map) and the
-//     voltages in LDS;
-//   * the INTEGRATOR wave reads the input terms of four steps with one 16-byte LDS read, applies the solver (elec_apply(): a 1-state Euler
-//     step is two FMAs), decides the reset, and hands over NOTHING but the new motor states, four steps per 16-byte write.  The reset is
-//     SPECULATED: the step is taken from the running state AND from the (constant) initial state, and the previous step's reset decision
-//     selects between the two results -- the violation test then runs beside the next step's FMAs instead of in front of them.  The chain
-//     from step to step is solver -> select (3 dependent instructions for the one-state Euler step) instead of solver -> normalise ->
-//     compare -> select (5): a lone wave issues a DEPENDENT instruction only every ~9 cycles (r02j probe: 45 cycles for those 5), so the
-//     launch time follows the chain, not the instruction count.  The test itself is |i| >= dc_thr (DevParams), bit-equivalent to
-//     |i * inv_lim| > 1;
-//   * OUTPUT waves (DCS_OUT) one block behind rebuild the rest -- observation row, done flag: the same device functions on the same
-//     values as everywhere else.  The rows of a group of four steps go through a per-wave LDS staging buffer and leave as FULL, 16-byte
-//     ALIGNED `global_store_dwordx4` (4 rows x 64 envs x NOUT dwords = 64 NOUT chunks = NOUT instructions): stored straight from the
-//     lanes' registers a row is 64 pieces of 20-28 bytes that straddle 16-byte boundaries, and the CU's store path took ~50 cycles per
-//     row for them (r02j probe) against 20 for aligned 64-byte quads.  The done bytes of four steps leave in ONE store (ballots, lane l
-//     writes bytes 4 (l % 16) .. + 3 of step l / 16).
-// LDS rows are [group of 4 steps][lane][step in group][value]: 16 bytes per lane and value.  One s_barrier per block of D steps
-// (64 for the one-state machines, 32 for the two-state ones: what the LDS holds).
+//   * PRE waves (alternating groups of four steps) load the action rows DCS_PREFETCH blocks ahead straight into registers -- through a
+//     buffer descriptor, one instruction per row --, run the converter stage and Elec::prep, and leave the step's input term
+//     (elec_input(): g, or S g of the one-step map) and the voltages in LDS;
+//   * the INTEGRATOR wave (wave 0, raised priority, alone on its SIMD) reads the input terms of four steps with one 16-byte LDS read two
+//     groups ahead, applies the solver (elec_apply(): a 1-state Euler step is one FMA), applies the reset, and hands over NOTHING but the
+//     new motor states, four steps per 16-byte write.  The reset is a multiplication when the initial state is zero (one_step(), ZERO):
+//     a VALU-written mask may not be read by the next VALU instruction on gfx950, so compare -> select costs 15.6 cycles where
+//     FMA -> clamp -> multiply costs 7.8 (tools/microbench_chain.hip, profiles/r03d_microbench_chain.txt).  A lone wave issues one
+//     instruction per ~5 cycles whatever its kind, so the step costs what its instruction COUNT is: 3 VALU + 1/4 LDS read + 1/4 LDS write;
+//   * OUTPUT waves one block behind rebuild the rest -- observation row, done flag: the same device functions on the same values as
+//     everywhere else.  The rows of a group of four steps go through a per-wave LDS staging buffer and leave as FULL, 16-byte ALIGNED
+//     16-byte stores (4 rows x 64 envs x NOUT dwords = 64 NOUT chunks = NOUT instructions, through a buffer descriptor whose base is
+//     advanced per block): stored straight from the lanes' registers a row is 64 pieces of 20-28 bytes that straddle 16-byte boundaries,
+//     ~50 cycles per row in the CU's store path against 20 for aligned quads.  The constant columns of a DC machine's row (omega, u_sup)
+//     are put into the staging rows once per launch.  The done bytes of four steps go through a byte staging area and leave in ONE store.
+// LDS rows are [group of 4 steps][lane][step in group][value]: 16 bytes per lane and value.  One s_barrier per block of D = 32 steps.
+// What bounds it now (profiles/r03h_dcs_probe.txt): the output waves (1200-1600 cycles of a 1700-cycle block period), themselves
+// waiting on the LDS: a block moves ~130 KB through it (hand-offs 48 KB, row staging 24 KB in + 40 KB out, done bytes), ~1000 cycles
+// at 128 B/clk.
 // Every value is produced by the code the other kernels run (prep / rk_step / observe / state_violation), so the results are
 // bit-identical to theirs; the tests assert it.  Preconditions beyond the pipelined kernel's (checked by the launcher): DC machine,
 // ConstantSpeedLoad, no dead time of either kind, ideal supply, constant initial state, no fused reward, AoS observations, and
@@ -2685,12 +2685,14 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
 // stream is being captured into a graph, and the integrator wave CHECKS the omega row: a moved omega raises GEMX_ERRFLAG_OMEGA_MOVED).
 // ------------------------------------------------------------------------------------------------
 // Waves of a workgroup go to the CU's four SIMDs round robin, so the waves whose index is a multiple of four would share the integrator's
-// SIMD and its issue slots: wave 4 stays resident but does nothing except meet the others at every barrier (a parked wave costs its
-// SIMD's other wave ~2 %; it used to END at once, relying on "an ended wave no longer counts at the barrier" -- true on this hardware,
-// but not something the programming model promises).  Integrator = wave 0, pre waves = 1, 2, output waves = 3, 5, 6, 7.
+// SIMD and its issue slots: waves 4, 8, 12 stay resident but do nothing except meet the others at every barrier (a parked wave costs its
+// SIMD's other wave ~2 %; round 2's wave 4 ENDED at once, relying on "an ended wave no longer counts at the barrier" -- true on this
+// hardware, but not something the programming model promises; GEMX_DCS_WAVE4_EXITS keeps that as an A/B).
 // Roles per system: the one-state machines (PermEx, Series) run <D = 32, 4 pre waves, 8 output waves> = 16 waves, the two-state ones
 // (Shunt, ExtEx: twice the LDS per step) <32, 2, 4> = 8 waves.  Same-box A/B at 4096 envs, PermExDc, Euler, us per 1000 steps
-// (profiles/r03e_dcs_ab.md): <64, 2, 4> 32.4, <64, 4, 4> 30.2, <32, 2, 8> 30.2, <32, 4, 8> 29.3 (round 2's kernel: 34.4).
+// (profiles/r03e_dcs_ab.md, r03h_dcs_ab.md): <64, 2, 4> 32.4, <64, 4, 4> 30.2, <32, 2, 8> 30.2, <32, 4, 8> 29.3 -> 28.45 with the running
+// descriptor bases, <64, 4, 8> 27.7 (but 33.5 against 31.2 at 8192 envs: twice the unrolled code, and two CUs share an instruction
+// cache once more than half of them are busy); round 2's kernel: 34.4.
 // GEMX_DCS_D1 / GEMX_DCS_PRE / GEMX_DCS_OUT override the one-state choice (A/B builds, tools/dev_build.py).
 #ifndef GEMX_DCS_D1
 #define GEMX_DCS_D1 32
@@ -2715,7 +2717,7 @@ template <int SYS> constexpr int dcs_waves() {  // smallest workgroup whose work
 }
 template <int SYS, int CONV> constexpr size_t dcs_smem_bytes() {
     constexpr int NM = SysTraits<SYS>::ND - 1, NU = SYS == GEMX_SYS_DC_EXTEX ? 2 : 1;
-    return (size_t)dcs_depth<SYS>() * BLOCK * sizeof(float) * (3 * NM + 3 * NU + 2 * NM) +
+    return (size_t)dcs_depth<SYS>() * BLOCK * sizeof(float) * (2 * NM + 3 * NU + 2 * NM) +
            (size_t)dcs_out<SYS>() * 4 * BLOCK * SysTraits<SYS>::NOUT * sizeof(float) + (size_t)dcs_out<SYS>() * 4 * BLOCK;
 }
 template <int SYS, int CONV, int SOLVER, class R>
@@ -2739,9 +2741,11 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
     const int64_t N = a.N, blk0 = (int64_t)blockIdx.x * BLOCK, env = blk0 + tid;
     const int K = a.K, nb = (K + D - 1) / D;
     auto steps_of = [&](int b) __attribute__((always_inline)) { return (K - b * D) < D ? (K - b * D) : D; };
-    // LDS: input terms [3][NGR][64][4][NM] | voltages [3][NGR][64][4][NU] | new motor states [2][NGR][64][4][NM] | row staging [DCS_OUT][4][64][NOUT]
+    // LDS: input terms [2][NGR][64][4][NM] | voltages [3][NGR][64][4][NU] | new motor states [2][NGR][64][4][NM] | row staging [DCS_OUT][4][64][NOUT]
+    // (in iteration b the integrator reads the input terms of block b while the pre waves write block b + 1's: two buffers; the voltages of
+    // block b - 1 are still being read by the output waves then: three)
     R *gin = reinterpret_cast<R *>(gemx_smem);
-    R *uu = gin + 3 * (size_t)D * BLOCK * NM;
+    R *uu = gin + 2 * (size_t)D * BLOCK * NM;
     R *hand = uu + 3 * (size_t)D * BLOCK * NU;
     R *stage = hand + 2 * (size_t)D * BLOCK * NM;
     const R om = P.init[0];  // == omega of every env (launcher); a ConstantSpeedLoad never changes it, a reset puts it back
@@ -2808,7 +2812,7 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
         };
         auto run_block = [&](auto lin_tag, auto zero_tag, int b) __attribute__((always_inline)) {
             const int sb = steps_of(b);
-            const R *gb = gin + ((size_t)(b % 3) * NGR * BLOCK + tid) * 4 * NM;
+            const R *gb = gin + ((size_t)(b & 1) * NGR * BLOCK + tid) * 4 * NM;
             R *hb = hand + ((size_t)(b & 1) * NGR * BLOCK + tid) * 4 * NM;
             if (sb == D) {  // whole block: a group's input terms are read two groups ahead (a step is far shorter than an LDS round trip)
                 R in4[3][4 * NM], out4[4 * NM];
@@ -2922,7 +2926,7 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
         };
         auto convert_t = [&](auto lin_tag, int bb, const Rows &v) __attribute__((always_inline)) {
             constexpr bool LIN = decltype(lin_tag)::value;
-            R *gb = gin + ((size_t)(bb % 3) * NGR * BLOCK + tid) * 4 * NM;
+            R *gb = gin + ((size_t)(bb & 1) * NGR * BLOCK + tid) * 4 * NM;
             R *ub = uu + ((size_t)(bb % 3) * NGR * BLOCK + tid) * 4 * NU;
 #pragma unroll
             for (int jg = 0; jg < GP; ++jg) {
@@ -3063,15 +3067,15 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
         // stores through buffer descriptors rebased per block (wave-uniform), the lane's part of the address in ONE constant 32-bit VGPR per
         // chunk, the group's in an SGPR: a store is one instruction (see the pre waves' loads)
         const int64_t obase_off = (((int64_t)(4 * ow) * N + blk0) * NOUT) * (int64_t)sizeof(R);  // this workgroup's span of this wave's first row
-        const int64_t ototal = (int64_t)K * ostride * (int64_t)sizeof(R);
         R *obase = a.obs + ((int64_t)(4 * ow) * N + env) * NOUT;  // this lane's row of this wave's first step (tail blocks)
         // done bytes of a group of four steps: every lane leaves its env's byte of each step in a [4][64]-byte staging area; read back as one
         // dword per lane that is bytes 4 (l % 16) .. + 3 of step l / 16 -- ONE store per group and no bit fiddling
         unsigned char *dstg = reinterpret_cast<unsigned char *>(stage + (size_t)DCS_OUT * 4 * BLOCK * NOUT) + (size_t)ow * 4 * BLOCK;
         const int64_t dbase_off = (int64_t)(4 * ow) * N + blk0;
-        const int64_t dtotal = (int64_t)K * N;
         const uint32_t doff = (uint32_t)((int64_t)(tid >> 4) * N + 4 * (tid & 15));
-        auto clamp32 = [](int64_t v) { return (int)(uint32_t)(v < 0 ? 0 : (v > 0xFFFFFFFFll ? 0xFFFFFFFFll : v)); };
+        unsigned char *optr = reinterpret_cast<unsigned char *>(a.obs) + obase_off;  // block pb's rows of this wave / workgroup (wave-uniform, advanced per block)
+        unsigned char *dptr = a.done + (has_done ? dbase_off : 0);
+        const int64_t ostep = (int64_t)D * ostride * (int64_t)sizeof(R), dstep = has_done ? (int64_t)D * N : 0;
 #ifdef GEMX_TIMING
         unsigned long long to_w = 0, to_r = 0, to_s = 0;  // per group: compute + staging writes | read back + wait | stores
 #endif
@@ -3090,11 +3094,10 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
 #pragma unroll
                     for (int i = 0; i < 4 * NU; ++i) us[jg][i] = ub[(size_t)g * BLOCK * 4 * NU + i];
                 }
-                const int64_t oblk = obase_off + (int64_t)pb * D * ostride * (int64_t)sizeof(R), dblk = dbase_off + (int64_t)pb * D * N;
-                const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<unsigned char *>(a.obs) + oblk), 0,
-                                                                                    clamp32(ototal - oblk), 0x00020000);
-                const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)(a.done + (has_done ? dblk : 0)), 0,
-                                                                                    has_done ? clamp32(dtotal - dblk) : 0, 0x00020000);
+                // (whole blocks lie inside the tensors: no clipping needed, and the block's base is a running 64-bit value -- rebuilding
+                // offset and remaining size from pb cost ~40 scalar instructions per block, every one an issue slot of this wave)
+                const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)optr, 0, -1, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)dptr, 0, HAS_DONE ? -1 : 0, 0x00020000);
 #pragma unroll
                 for (int jg = 0; jg < GPW; ++jg) {
                     const int r0 = 4 * jg * DCS_OUT;  // first row of the group, relative to this wave's first row
@@ -3103,7 +3106,7 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
 #endif
 #ifdef GEMX_DCS_DIRECT_ROWS
                     unsigned long long m[4];  // A/B: round 2's rows, stored straight from the lanes' registers
-                    R *ob = obase + (int64_t)pb * D * ostride;
+                    R *ob = obase + (int64_t)pb * D * ostride;  // (A/B only)
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4)
                         m[s4] = __ballot(emit(&xs[jg][s4 * NM], &us[jg][s4 * NU], ob + (int64_t)(r0 + s4) * ostride));
@@ -3146,7 +3149,7 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
                         const unsigned long long mq = dq == 0 ? m[0] : (dq == 1 ? m[1] : (dq == 2 ? m[2] : m[3]));
                         const uint32_t nib = (uint32_t)(mq >> (4 * dc)) & 15u;
                         const uint32_t bytes = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
-                        *reinterpret_cast<uint32_t *>(a.done + dblk + (int64_t)r0 * N + doff) = bytes;
+                        *reinterpret_cast<uint32_t *>(dptr + (int64_t)r0 * N + doff) = bytes;
                     }
 #endif
                 }
@@ -3184,7 +3187,7 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
 #ifdef GEMX_TIMING
             const unsigned long long q0 = clock64();
 #endif
-            if (b >= 1) process(b - 1);
+            if (b >= 1) { process(b - 1); optr += ostep; dptr += dstep; }
 #ifdef GEMX_TIMING
             const unsigned long long q1 = clock64();
 #endif

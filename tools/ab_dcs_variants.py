@@ -33,7 +33,7 @@ for rep in range(3):
 res.sort()
 us = res[1]
 b = (1 if ps._discrete else 4 * ps._n_act) + 4 * ps._n_out + 1
-print(f"{us:.2f} {res[0]:.2f} {res[2]:.2f} {n * K * b / us / 1e6 / 8000:.3f} {ps.last_launch().split('<')[0].replace('gemx::', '')} {float(obs.double().sum()):.9e}")
+print(f"{us:.2f} {res[0]:.2f} {res[2]:.2f} {n * K * b / us / 8e6:.3f} {ps.last_launch().split('<')[0].replace('gemx::', '')} {float(obs.double().sum()):.9e}")
 ''' % REPO
 
 libs = [None] + sys.argv[1:]
