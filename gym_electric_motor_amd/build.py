@@ -34,12 +34,19 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: cannot build gym_electric_motor_amd/libgemx.so")
 
 
-def _digest():
+def _digest(sources=None):
     h = hashlib.sha256()
-    for p in SOURCES + [HEADER]:
+    for p in (SOURCES if sources is None else sources) + [HEADER]:
         h.update(open(p, "rb").read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
+
+
+# what each kind of object is compiled from (an edit to the C ABI alone does not recompile the 38 kernel units)
+_DEPS = {"inst": ["gemx_common.hpp", "gemx_kernels.hpp", "gemx_inst.hip"], "capi": ["gemx_common.hpp", "gemx_capi.hip"],
+         "refgen": ["gemx_common.hpp", "gemx_refgen.hip"]}
+# compile cost of an fp32 unit by system kind (object size, MB: induction > synchronous > DC); fp64 units take the single-wave kernel only
+_COST = {7: 6.0, 2: 5.3, 6: 4.9, 1: 4.5, 5: 4.0, 4: 3.9, 3: 3.5, 0: 3.5}
 
 
 def is_stale():
@@ -55,26 +62,36 @@ def build_library(force=False, verbose=False, jobs=None):
     hipcc = hipcc_path()
     os.makedirs(OBJ_DIR, exist_ok=True)
     inc = ["-I" + os.path.join(REPO, "include"), "-I" + CSRC]
-    cmds = []
+    cmds = []  # (object, command, kind, cost)
     for s, c in UNITS:
         for f64 in (0, 1):
             obj = os.path.join(OBJ_DIR, f"gemx_inst_{s}_{c}_{f64}.o")
             cmds.append((obj, [hipcc] + FLAGS + inc + [f"-DGEMX_INST_SYS={s}", f"-DGEMX_INST_CONV={c}", f"-DGEMX_INST_F64={f64}",
-                                                      "-c", os.path.join(CSRC, "gemx_inst.hip"), "-o", obj]))
+                                                      "-c", os.path.join(CSRC, "gemx_inst.hip"), "-o", obj], "inst", _COST[s] * (0.15 if f64 else 1.0)))
     capi_obj = os.path.join(OBJ_DIR, "gemx_capi.o")
-    cmds.append((capi_obj, [hipcc] + FLAGS + inc + ["-c", os.path.join(CSRC, "gemx_capi.hip"), "-o", capi_obj]))
+    cmds.append((capi_obj, [hipcc] + FLAGS + inc + ["-c", os.path.join(CSRC, "gemx_capi.hip"), "-o", capi_obj], "capi", 0.3))
     refgen_obj = os.path.join(OBJ_DIR, "gemx_refgen.o")
-    cmds.append((refgen_obj, [hipcc] + FLAGS + inc + ["-c", os.path.join(CSRC, "gemx_refgen.hip"), "-o", refgen_obj]))
+    cmds.append((refgen_obj, [hipcc] + FLAGS + inc + ["-c", os.path.join(CSRC, "gemx_refgen.hip"), "-o", refgen_obj], "refgen", 0.2))
+    digests = {k: _digest([os.path.join(CSRC, f) for f in v]) for k, v in _DEPS.items()}
 
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
 
+    def compile_one(job):  # skipped when the object was built from the same sources with the same flags
+        obj, cmd, kind, _ = job
+        stamp = obj + ".sha256"
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == digests[kind]:
+            return
+        run(cmd)
+        with open(stamp, "w") as fh:
+            fh.write(digests[kind])
+
     jobs = jobs or min(len(cmds), os.cpu_count() or 4)
-    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
-        list(ex.map(lambda oc: run(oc[1]), cmds))
-    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [o for o, _ in cmds])
+    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:  # longest first: the big induction-machine units do not end up as the tail
+        list(ex.map(compile_one, sorted(cmds, key=lambda j: -j[3])))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [j[0] for j in cmds])
     with open(STAMP, "w") as fh:
         fh.write(_digest())
     return LIB

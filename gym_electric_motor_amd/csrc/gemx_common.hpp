@@ -123,12 +123,14 @@ template <> struct Angle<float> {
     // (the float -> int conversion SATURATES at +-2^31 counts = half a turn, so an increment beyond pi -- the DqToAbcActionProcessor's
     // (0.5 + dead time) * tau * p * omega at 8 dead-time steps near the speed limit, or a large tau -- is first reduced modulo one turn:
     // x - 2^32 rint(x 2^-32) is exact, both terms being multiples of x's ulp)
-    static __device__ __forceinline__ T advance(T a, float d_rad) {
+    using Inc = int32_t;  // an increment in counts
+    static __device__ __forceinline__ Inc increment(float d_rad) {
         const float x = d_rad * kCountsPerRad;
         const float y = fmaf(-4294967296.0f, rintf(x * 2.3283064365386963e-10f), x);  // in [-2^31, 2^31]
-        int32_t inc = __float2int_rn(y);
-        return (T)((uint32_t)a + (uint32_t)inc);
+        return __float2int_rn(y);
     }
+    static __device__ __forceinline__ T add(T a, Inc inc) { return (T)((uint32_t)a + (uint32_t)inc); }
+    static __device__ __forceinline__ T advance(T a, float d_rad) { return add(a, increment(d_rad)); }
     static __device__ __forceinline__ float wrapped(T a) { return (float)a * kRadPerCount; }  // [-pi, pi]
     static __device__ __forceinline__ float to_rad(T a) { return wrapped(a); }
     // sin/cos of a fixed-point angle with the hardware's V_SIN_F32 / V_COS_F32, whose argument is in REVOLUTIONS: the count times
@@ -164,6 +166,9 @@ template <> struct Angle<double> {
     static __host__ __device__ T from_rad(double a) { return a; }
     static __host__ __device__ T from_bits(int64_t b) { T r; memcpy(&r, &b, 8); return r; }
     static __host__ int64_t to_bits(T a) { int64_t b; memcpy(&b, &a, 8); return b; }
+    using Inc = double;
+    static __device__ __forceinline__ Inc increment(double d) { return d; }
+    static __device__ __forceinline__ T add(T a, Inc inc) { return a + inc; }
     static __device__ __forceinline__ T advance(T a, double d) { return a + d; }
     static __device__ __forceinline__ double wrapped(T a) {  // physical_systems.py:520-522
         double e = fmod(a, kTwoPi);

@@ -269,14 +269,23 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
         const R *L0 = linr != nullptr ? linr : P.lin;
         constexpr int NC = NM * (NM + NG);
         R L[NC];
+        [[maybe_unused]] uint32_t two_mask = (SEG == 1 && two) ? 0xFFFFFFFFu : 0u;
+        if constexpr (SEG == 1 && sizeof(R) == 4) asm volatile("" : "+v"(two_mask));
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
-            if constexpr (SEG == 1) {
-                // a per-lane select between two REGISTERS: made opaque, because the optimiser turns `two ? a[i] : b[i]` into ONE load at a
-                // selected address -- which demotes the preloaded coefficients to scratch memory and puts two scratch loads on every step
-                R c_tau = L0[i], c_til = L0[NC + i];
-                asm volatile("" : "+v"(c_tau), "+v"(c_til));
-                L[i] = two ? c_til : c_tau;
+            if constexpr (SEG == 1 && sizeof(R) == 4) {
+                // a per-lane select between two REGISTERS as a bit-field insert under an all-ones / all-zeros lane mask (one v_bfi_b32 per
+                // coefficient, VGPR operands only).  Written as `two ? a[i] : b[i]` the optimiser makes ONE load at a selected address of
+                // it -- which demotes the preloaded coefficients to scratch memory and puts two scratch loads on every step -- and an
+                // opaque copy of both operands in front of the select (round 3a) cost two v_mov per coefficient and step; the mask is
+                // opaque instead, so that the and / or form is not folded back into that select
+                uint32_t ca, cb;
+                memcpy(&ca, &L0[i], 4);
+                memcpy(&cb, &L0[NC + i], 4);
+                const uint32_t cs = (two_mask & cb) | (~two_mask & ca);
+                memcpy(&L[i], &cs, 4);
+            } else if constexpr (SEG == 1) {
+                L[i] = two ? L0[NC + i] : L0[i];
             } else {
                 L[i] = L0[SEG == 2 ? 2 * NC + i : i];
             }
@@ -450,25 +459,32 @@ template <class R> __device__ __forceinline__ R fin_leg_u(uint32_t st, R i, R ha
     const bool upper = (st == 1u) | ((st == 0u) & (i < R(0)));
     return upper ? half_us : -half_us;
 }
-// Finite-B6C action -> per-leg sub-action (1 = upper, 2 = lower), converters.py:788-797, packed 2 bits per leg.
-__device__ __forceinline__ uint32_t b6_subactions(uint32_t a) {
+// Finite-B6C action -> per-leg sub-action (1 = upper, 2 = lower), converters.py:788-797, packed 2 bits per leg: a look-up in a 48-bit
+// constant (8 actions x 6 bits), three instructions instead of three test-and-select pairs and their merges.
+constexpr uint32_t b6_subactions_of(uint32_t a) {
     return ((a & 4u) ? 1u : 2u) | (((a & 2u) ? 1u : 2u) << 2) | (((a & 1u) ? 1u : 2u) << 4);
+}
+constexpr uint64_t b6_subaction_table() {
+    uint64_t t = 0;
+    for (uint32_t a = 0; a < 8; ++a) t |= (uint64_t)b6_subactions_of(a) << (6 * a);
+    return t;
+}
+__device__ __forceinline__ uint32_t b6_subactions(uint32_t a) {
+    constexpr uint64_t T = b6_subaction_table();
+    return (uint32_t)(T >> (6u * (a & 7u))) & 63u;
 }
 // Interlocking (FiniteTwoQuadrantConverter._set_switching_pattern 300-310 + convert 270-276 as driven by
 // *.simulate(), which passes the segment START time): a leg that changes between upper and lower goes to the
 // dead state 0 for the WHOLE step (two segments [t, t+t_il], [t+t_il, t+tau]) and takes the new state on the
 // next step.  Returns the leg states used during this step; `two` = this env integrates two segments.
+// All legs at once: a leg's states are 1 (upper), 2 (lower), 0 (dead) and its sub-action is 1 or 2, so "changes between upper and lower"
+// is exactly prev ^ want == 3 in that leg's two bits -- a dead leg (0 ^ want = want) never does, an unchanged one gives 0.
 template <int NLEG = 3> __device__ __forceinline__ uint32_t b6_interlock(uint32_t prev, uint32_t want, bool &two) {
-    uint32_t used = 0;
-    two = false;
-#pragma unroll
-    for (int l = 0; l < NLEG; ++l) {
-        uint32_t s = (prev >> (2 * l)) & 3u, a = (want >> (2 * l)) & 3u;
-        bool trans = (s != 0u) && (a != s);
-        two |= trans;
-        used |= (trans ? 0u : a) << (2 * l);
-    }
-    return used;
+    constexpr uint32_t LOW = ((1u << (2 * NLEG)) - 1u) / 3u;  // bit 0 of every leg: 0b0101...
+    const uint32_t x = prev ^ want;
+    const uint32_t t = x & (x >> 1) & LOW;  // bit 0 of every switching leg
+    two = t != 0u;
+    return want & ~(t * 3u);                // switching legs are dead for this step
 }
 
 // B6 bridges: phase voltages u_a, u_b, u_c [V].  `legs` only matters for Finite-B6C with IL; A0 = index of this bridge's
@@ -536,6 +552,21 @@ __device__ __forceinline__ void dq_action_stage(const DevParams<R> &P, const R (
 //     default_done() applies to the row
 // step() = advance() + observe() (single-wave kernel).
 // ------------------------------------------------------------------------------------------------
+// the angle after a segment whose integrate<> returned `deps`.  First dead-time segment of the one-step-map instantiations (LIN, SEG == 1):
+// omega is the wave-uniform init[0] there and the segment is t_il or tau long, so BOTH possible increments are launch constants (hoisted
+// out of the step loop) and the lane picks one -- a select and an add instead of the float -> fixed-point conversion of a per-lane product
+// (8 instructions).  Same expressions as integrate<>'s `pole * omega * h`, so the same bits.
+template <class R, bool LIN, int SEG>
+__device__ __forceinline__ typename Angle<R>::T advance_angle(const DevParams<R> &P, typename Angle<R>::T ang, R deps, bool two) {
+    if constexpr (LIN && SEG == 1) {
+        const R w = P.pole * P.init[0];
+        const typename Angle<R>::Inc i_il = Angle<R>::increment(w * P.t_il), i_tau = Angle<R>::increment(w * P.tau);
+        return Angle<R>::add(ang, two ? i_il : i_tau);
+    } else {
+        return Angle<R>::advance(ang, deps);
+    }
+}
+
 template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper;
 
 // ---- DcMotorSystem (physical_systems.py:171-203, 290-318): permanently excited, series, shunt motors behind ONE
@@ -722,7 +753,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             u[0] = c * ual + s * ube;  // Q^-1(., eps): u_dq frozen at the segment-start angle (line 501/511)
             u[1] = -s * ual + c * ube;
             const R deps = integrate<GEMX_SYS_SYNC, LOAD, SOLVER, R, NS1, LIN, decltype(seg_tag)::value>(P, y, u, h, linr, two);
-            ang = Angle<R>::advance(ang, deps);
+            ang = advance_angle<R, LIN, decltype(seg_tag)::value>(P, ang, deps, two);
         };
         if (IL) {
             segment(two ? P.t_il : P.tau, std::integral_constant<int, 1>{});
@@ -883,7 +914,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
                 t23(ua, ub, uc, u[0], u[1]);  // u_alphabeta constant over the segment (line 788/799)
             }
             const R deps = integrate<GEMX_SYS_SCIM, LOAD, SOLVER, R, NS1, LIN, decltype(seg_tag)::value>(P, y, u, h, linr, two);
-            ang = Angle<R>::advance(ang, deps);
+            ang = advance_angle<R, LIN, decltype(seg_tag)::value>(P, ang, deps, two);
         };
         if (IL) {
             segment(two ? P.t_il : P.tau, std::integral_constant<int, 1>{});
@@ -969,7 +1000,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             u[2] = ce * urg - se * urh;
             u[3] = se * urg + ce * urh;
             const R deps = integrate<GEMX_SYS_DFIM, LOAD, SOLVER, R, NS1, LIN, decltype(seg_tag)::value>(P, y, u, h, linr, two);
-            ang = Angle<R>::advance(ang, deps);
+            ang = advance_angle<R, LIN, decltype(seg_tag)::value>(P, ang, deps, two);
         };
         if (IL) {
             segment(two ? P.t_il : P.tau, std::integral_constant<int, 1>{});
