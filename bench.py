@@ -28,17 +28,32 @@ the environment `--gpus N` (N > 1) spawns its own N ranks (torch.multiprocessing
 `--gather chunk|step` additionally times the batched-return path: one RCCL all-gather of each launch's [K, n_local, S_out]
 observation chunk (+ done bytes) / of every step's [n_local, S_out] rows; reported under "gather" beside the gather-off `value`.
 
+Robustness to the box (round 3): the timed region is run `--repeats` (3) times back to back and the MEDIAN region is what `value`,
+`ms_per_step` and `roofline` report (min / max under `repeats`); core clock, memory clock, socket power and temperature are read from
+the GPU's hwmon files before and after every leg (`telemetry`); `sustained_1s` legs run >= `--sustain-s` seconds of back-to-back
+launches with those sensors sampled every 20 ms -- a slower line can be told from a slower or power-limited box.
+Multi-process robustness: `init_process_group` gets `--dist-timeout` (a dead rank is an exception, not a hung barrier), a world > 1
+without MASTER_PORT is refused, and the self-spawner picks a free port.
+
 Extra objects in the JSON line (rank 0):
   roofline            HBM roofline of the dominant kernel: algorithmic bytes per launch / mean launch duration measured HERE with HIP
-                      events on the launch stream around the K timed launches; peak = 8000 GB/s (MI355X spec); traffic = PMC-measured
-                      HBM bytes per launch of this exact (workload, envs, steps_per_launch) from profiles/hbm_traffic.json.
+                      events on the launch stream around the K timed launches; peak = 8000 GB/s (MI355X spec); traffic = HBM bytes
+                      per launch MEASURED IN THIS RUN: two child runs of this script under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE`
+                      (separate passes; FETCH_SIZE doubled per the guide's gfx950 note) -- `traffic_source` says so, or names
+                      profiles/hbm_traffic.json (an earlier collection's passes) when rocprofv3 is not available / `--no-pmc`.
+  repeats, telemetry  see above.
   cpu_baseline        oracle/gemx_oracle.c (scalar fp64 restatement, "port") timed on ONE host core on a bounded sample of the same
                       workload (`all_cores`: the same port on up to 32 host cores), plus the REFERENCE's own Python path as
                       recorded by oracle/cpu_reference_bench.py (fields, not prose).
   headline_no_linmap  the same launches with GEMX_LINMAP=0 (RK4 evaluated stage by stage instead of through the one-step affine map).
-  single_step / single_step_graph   one launch per control step (closed-loop RL usage), eager and replayed from a HIP graph.
-  configs             BASELINE configs 2 and 4 (PermExDc 4096 envs Euler; SCIM 65536 envs RK4 with the env's PolynomialStaticLoad -- also
-                      with split_kinks -- and with the ConstantSpeedLoad BASELINE.json names) through the same measurement.
+  sustained_1s        >= 1 s of back-to-back launches of the headline workload with clocks / power sampled (also under configs.scim).
+  single_step / single_step_graph   one launch per control step (closed-loop RL usage): eager `PhysicalSystem.simulate()` on a device
+                      tensor, and 64 steps replayed from a HIP graph.
+  configs             BASELINE config 2 (PermExDc 4096 envs Euler, with `launch_model`: t = t_fixed + K t_step fitted over launches of
+                      250 ... 2000 steps, and `frac_of_latency_bound` = (K x the integrator's dependency chain + t_fixed) / measured),
+                      config 4 (SCIM 65536 envs RK4 with the env's PolynomialStaticLoad -- also with split_kinks, the solver
+                      `make(env_id)` hands out -- and with the ConstantSpeedLoad BASELINE.json names) and config 5's per-GPU shard
+                      (PMSM 32768 envs), each through the same measurement with 3 repeats.
   at_scale            the headline kernel with the chip full (1M envs).
 """
 import argparse
@@ -493,7 +508,9 @@ def worker(args, rank, world, local_rank, backend):
         dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.dist_timeout))
 
     w = dict(WORKLOADS[args.workload], key=args.workload)
-    n_local = args.envs_per_gpu or (32768 if (args.workload == "pmsm" and world == 8) else w["envs"])  # BASELINE config 5: 8 x 32768
+    # the same shard on every GPU at every N (weak scaling: per-GPU work fixed); BASELINE config 5 (8 x 32768 envs) is measured beside it
+    # at --gpus 8 as `config5` (rounds 1-2 made it the N = 8 default, which mixed a change of shard size into the driver's scaling curve)
+    n_local = args.envs_per_gpu or w["envs"]
     n_total = n_local * world
     K, W, spl = args.steps, args.warmup, args.steps_per_launch
 
@@ -507,13 +524,14 @@ def worker(args, rank, world, local_rank, backend):
     tele_after = tele.sample()
     t = median_of(reps)
     kernel_desc = env.physical_system.last_launch()
-    same_shard = None
-    if n_local != w["envs"] and args.envs_per_gpu is None:  # --gpus 8 default = BASELINE config 5 (8 x 32768): also the N=1 shard size
-        env_s = make_env(ga, w, w["envs"], dev_index)
-        ts = measure(torch, dist, env_s, w["envs"], K, W, spl, device, world, seed=1234 + rank, settle_ms=S)
+    config5 = None
+    if args.workload == "pmsm" and world == 8 and args.envs_per_gpu is None:
+        env_s = make_env(ga, w, 32768, dev_index)
+        ts = measure(torch, dist, env_s, 32768, K, W, spl, device, world, seed=1234 + rank, settle_ms=S)
         env_s.close()
-        same_shard = {"envs_per_gpu": w["envs"], "value": w["envs"] * world * spl * K / ts.wall, "unit": "env-steps/s",
-                      "ms_per_step": ts.wall / K * 1e3, "note": "same per-GPU shard as the --gpus 1/2/4 lines (strict weak scaling)"}
+        config5 = {"envs_per_gpu": 32768, "value": 32768 * world * spl * K / ts.wall, "unit": "env-steps/s", "ms_per_step": ts.wall / K * 1e3,
+                   "note": "BASELINE.json configs[4]: 8 x 32768 envs (twice the per-GPU shard of the scaling lines; the single-GPU figure "
+                           "for that shard is configs.pmsm_c5_shard of the --gpus 1 line)"}
     gathered = None
     if args.gather != "off":  # (gloo, i.e. --oversubscribe: the same collectives staged through host memory -- functional, not a measurement)
         modes = ["chunk", "step"] if args.gather == "both" else [args.gather]
@@ -568,8 +586,8 @@ def worker(args, rank, world, local_rank, backend):
                                  "note": f"the same {W} + {K} launches straight from an idle GPU, no clock settling (module docstring)"}
         if gathered is not None:
             out["gather"] = gathered
-        if same_shard is not None:
-            out["same_shard_as_n1"] = same_shard
+        if config5 is not None:
+            out["config5"] = config5
         if not args.no_extras and world == 1:
             extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out, tele)
         elif not args.no_extras:

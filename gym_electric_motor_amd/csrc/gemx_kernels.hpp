@@ -459,17 +459,21 @@ template <class R> __device__ __forceinline__ R fin_leg_u(uint32_t st, R i, R ha
     const bool upper = (st == 1u) | ((st == 0u) & (i < R(0)));
     return upper ? half_us : -half_us;
 }
-// Finite-B6C action -> per-leg sub-action (1 = upper, 2 = lower), converters.py:788-797, packed 2 bits per leg: a look-up in a 48-bit
-// constant (8 actions x 6 bits), three instructions instead of three test-and-select pairs and their merges.
+// Finite-B6C action -> per-leg sub-action (1 = upper, 2 = lower), converters.py:788-797, packed 2 bits per leg.
+// b6_subactions(): test-and-select per leg -- transparent to the optimiser, which folds a later `leg state == 1` back into the action
+// bit (the RC supply's i_sup of a dead-time-free bridge, Stepper::legs_of: the opaque look-up below cost that path 12 %).
+// b6_subactions_packed(): a look-up in a 48-bit constant (8 actions x 6 bits), three instructions: for the dead-time code, which works
+// on the packed value (b6_interlock).
 constexpr uint32_t b6_subactions_of(uint32_t a) {
     return ((a & 4u) ? 1u : 2u) | (((a & 2u) ? 1u : 2u) << 2) | (((a & 1u) ? 1u : 2u) << 4);
 }
+__device__ __forceinline__ uint32_t b6_subactions(uint32_t a) { return b6_subactions_of(a); }
 constexpr uint64_t b6_subaction_table() {
     uint64_t t = 0;
     for (uint32_t a = 0; a < 8; ++a) t |= (uint64_t)b6_subactions_of(a) << (6 * a);
     return t;
 }
-__device__ __forceinline__ uint32_t b6_subactions(uint32_t a) {
+__device__ __forceinline__ uint32_t b6_subactions_packed(uint32_t a) {
     constexpr uint64_t T = b6_subaction_table();
     return (uint32_t)(T >> (6u * (a & 7u))) & 63u;
 }
@@ -732,7 +736,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
         uint32_t legs = 0;
         bool two = false;
         if (IL && CONV == GEMX_CONV_FINITE_B6) {
-            legs = b6_subactions(dact);
+            legs = b6_subactions_packed(dact);
             if (P.t_il > R(0)) legs = b6_interlock(sw, legs, two);  // converters.py:302: no dead time -> pattern [action]
             sw = legs;
         }
@@ -899,7 +903,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
         uint32_t legs = 0;
         bool two = false;
         if (IL && CONV == GEMX_CONV_FINITE_B6) {
-            legs = b6_subactions(dact);
+            legs = b6_subactions_packed(dact);
             if (P.t_il > R(0)) legs = b6_interlock(sw, legs, two);
             sw = legs;
         }
@@ -980,7 +984,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
         uint32_t legs = 0;
         bool two = false;
         if (IL && CONV == GEMX_CONV_FINITE_2XB6) {  // flat action = a_stator + 8 * a_rotor; 6 half-bridges, 2 bits each
-            legs = b6_subactions(dact & 7u) | (b6_subactions((dact >> 3) & 7u) << 6);
+            legs = b6_subactions_packed(dact & 7u) | (b6_subactions_packed((dact >> 3) & 7u) << 6);
             if (P.t_il > R(0)) legs = b6_interlock<6>(sw, legs, two);
             sw = legs;
         }
@@ -2462,6 +2466,13 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64) + (blockIdx.x ? 16 : 0);
             dbg[0] = tv; dbg[1] = tc; dbg[2] = tw; dbg[3] = clock64() - T0; dbg[4] = wall_clock64() - W0; dbg[5] = (unsigned long long)nb | (tlong << 32);
         }
+        if (tid == 0 && blockIdx.x < 1024) {  // where the integrator wave of every workgroup ran: HW_ID[15:0] (wave, SIMD, pipe, CU, SH, SE) | XCC_ID << 16
+            uint32_t hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(a.err) + 64 + 1024)[blockIdx.x] =
+                (uint16_t)(((hw >> 4) & 3u) | (((hw >> 8) & 15u) << 2) | (((hw >> 12) & 1u) << 6) | (((hw >> 13) & 7u) << 7) | ((xcc & 15u) << 10));
+        }
 #endif
 #pragma unroll
         for (int j = 0; j < ND; ++j) a.state[(int64_t)j * N + env] = y[j];
@@ -3400,9 +3411,10 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             D = PIPE_D; OW = PIPE_OUT_WAVES; shape = 0;
             if (h->cur_reward != nullptr) { OW = PIPE_OUT_WAVES_RW; shape = 3; }  // (eight waves: still one workgroup per CU)
         }
-        else if (SysTraits<SYS>::NOUT >= 14 && smem_of(PIPE_D3) <= h->lds_max && blocks <= resident(PIPE_D3, PIPE_OUT_WAVES3) &&
+        else if ((SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM) && smem_of(PIPE_D3) <= h->lds_max && blocks <= resident(PIPE_D3, PIPE_OUT_WAVES3) &&
                  blocks > resident(PIPE_D2, PIPE_OUT_WAVES2) && 2 * blocks <= 3 * resident(PIPE_D2, PIPE_OUT_WAVES2)) {
-            // (three-phase machines only: the DC machines' light steppers lose with the shallow shape -- ExtExDc 131072 envs 133 -> 104 G)
+            // (induction machines only: lighter steppers lose with the shallow shape -- ExtExDc 131072 envs 133 -> 104 G; PMSM finite at
+            // 98304 envs, where this rule used to apply: 75.8 G against 84.2 G through <4, 2>, profiles/r03k_shapes_pmsm.md)
             // one resident round with the shallow shape where <4, 2> would run one round plus a tail of at most half a round: SCIM,
             // 65536 envs (BASELINE config 4) 49 -> 67 G env-steps/s.  Everywhere else <4, 2> is 5-20 % ahead of <2, 2> (fewer barriers,
             // fewer waves per SIMD): PMSM finite at 131072 envs = two FULL rounds of <4, 2>: 89-92 G against 79 G in one round of <2, 2>

@@ -1738,6 +1738,52 @@ def test_rccl_gather_of_real_rollout_outputs_in_a_world_of_one():
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
+_DCS_WATCHDOG = r'''
+import sys
+sys.path.insert(0, %r)
+import torch
+import gym_electric_motor_amd as ga
+launches = 0
+for env_id in ("Cont-CC-PermExDc-v0", "Finite-CC-PermExDc-v0", "Cont-CC-SeriesDc-v0", "Finite-CC-ShuntDc-v0", "Cont-CC-ExtExDc-v0"):
+    for n in (64, 4096):
+        kw = {} if "PermExDc" in env_id else {"load": ga.ConstantSpeedLoad(omega_fixed=30.0)}
+        env = ga.make(env_id, n_envs=n, ode_solver=ga.EulerSolver(), tau=1e-4, **kw)
+        ps = env.physical_system
+        g = torch.Generator(device="cuda").manual_seed(n)
+        for K in (2, 3, 31, 32, 33, 64, 65, 96, 127, 1000, 1023):
+            env.reset()
+            if ps._discrete:
+                a = torch.randint(0, int(ps.action_space.n) if hasattr(ps.action_space, "n") else 4, (K, n), device="cuda", generator=g, dtype=torch.uint8)
+            else:
+                a = torch.rand((K, n, ps._n_act), device="cuda", generator=g) * 2 - 1
+            for _ in range(3):  # back to back: a workgroup of the next launch starts while one of the last still drains
+                obs, done = ps.rollout(a)
+            torch.cuda.synchronize()
+            assert "dc_stream_kernel" in ps.last_launch(), ps.last_launch()
+            assert bool(torch.isfinite(obs).all())
+            launches += 3
+        env.close()
+print("DCS_WATCHDOG_OK", launches)
+'''
+
+
+@pytest.mark.timeout(200)
+def test_dc_stream_kernel_finishes_under_a_watchdog():
+    """dc_stream_kernel synchronises sixteen (eight) waves with different jobs through one s_barrier per block, and three (one) of
+    them only exist to keep a SIMD free: every wave has to reach every barrier exactly as often as the others, for every block count
+    -- whole blocks, tail blocks, fewer steps than one block -- or the workgroup hangs.  All of those shapes, every DC machine, in a
+    child process that a watchdog kills: a hang fails this test after 150 s instead of stalling the suite (and the box)."""
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        r = subprocess.run([sys.executable, "-c", _DCS_WATCHDOG % repo], capture_output=True, text=True, timeout=150)
+    except subprocess.TimeoutExpired as e:  # (subprocess.run has killed the child)
+        pytest.fail(f"dc_stream_kernel did not finish within the watchdog's 150 s: {(e.stdout or b'')[-500:]!r}")
+    assert r.returncode == 0 and "DCS_WATCHDOG_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 @pytest.mark.parametrize("name", ["Cont-CC-PermExDc-v0", "Finite-CC-PMSM-v0", "Cont-SC-SCIM-v0", "Finite-CC-PMSM-v0_DeadTime2"])
 def test_replay_of_the_reference_env_shell_transcript(name):
     """The contract of the drop-in seam, replayed: tests/golden/shell_*.json is the ordered list of everything the UNMODIFIED reference
