@@ -52,7 +52,7 @@ Extra objects in the JSON line (rank 0):
   configs             BASELINE config 2 (PermExDc 4096 envs Euler, with `launch_model`: t = t_fixed + K t_step fitted over launches of
                       250 ... 2000 steps, and `frac_of_latency_bound` = (K x the integrator's dependency chain + t_fixed) / measured),
                       config 4 (SCIM 65536 envs RK4 with the env's PolynomialStaticLoad -- also with split_kinks, the solver
-                      `make(env_id)` hands out -- and with the ConstantSpeedLoad BASELINE.json names) and config 5's per-GPU shard
+                      `make(env_id)` hands out, and with ScipyOdeSolver(), the device's error-controlled Dormand-Prince -- and with the ConstantSpeedLoad BASELINE.json names) and config 5's per-GPU shard
                       (PMSM 32768 envs), each through the same measurement with 3 repeats.
   at_scale            the headline kernel with the chip full (1M envs).
 """
@@ -190,8 +190,8 @@ def bytes_per_env_step_single(w):
     return bytes_per_env_step_fused(w) + 2 * 4 * w["s_ode"]
 
 
-def make_env(ga, w, n_envs, device, split_kinks=False):
-    sol = ga.EulerSolver() if w["solver"] == "euler" else ga.RK4Solver(split_kinks=split_kinks)
+def make_env(ga, w, n_envs, device, split_kinks=False, error_controlled=False):
+    sol = ga.ScipyOdeSolver() if error_controlled else (ga.EulerSolver() if w["solver"] == "euler" else ga.RK4Solver(split_kinks=split_kinks))
     kw = {}
     if w.get("const_speed") is not None:
         kw["load"] = ga.ConstantSpeedLoad(omega_fixed=w["const_speed"])
@@ -599,12 +599,12 @@ def worker(args, rank, world, local_rank, backend):
         dist.destroy_process_group()
 
 
-def leg(torch, dist, ga, args, key, device, dev_index, spl, tele, envs=None, split_kinks=False, steps=10, repeats=3, seed=5):
+def leg(torch, dist, ga, args, key, device, dev_index, spl, tele, envs=None, split_kinks=False, error_controlled=False, steps=10, repeats=3, seed=5):
     """One informational leg through the same measurement as the headline: `repeats` timed regions of `steps` launches, MEDIAN reported,
     min / max beside it, clocks / power before and after."""
     wc = dict(WORKLOADS[key], key=key)
     n = envs or wc["envs"]
-    env = make_env(ga, wc, n, dev_index, split_kinks=split_kinks)
+    env = make_env(ga, wc, n, dev_index, split_kinks=split_kinks, error_controlled=error_controlled)
     before = tele.sample()
     reps = measure(torch, dist, env, n, steps, 3, spl, device, 1, seed=seed, settle_ms=args.settle_ms, repeats=repeats)
     reps = reps if isinstance(reps, list) else [reps]
@@ -613,7 +613,8 @@ def leg(torch, dist, ga, args, key, device, dev_index, spl, tele, envs=None, spl
     env.close()
     tm = median_of(reps)
     fr = [roofline_of(wc, n, spl, r.launch_ms, desc, key)["frac"] for r in reps]
-    return {"workload": wc["desc"] + (", RK4Solver(split_kinks=True)" if split_kinks else ""), "envs": n, "steps_per_launch": spl,
+    how = ", RK4Solver(split_kinks=True)" if split_kinks else (", ScipyOdeSolver() = error-controlled Dormand-Prince 5(4), rtol 1e-6" if error_controlled else "")
+    return {"workload": wc["desc"] + how, "envs": n, "steps_per_launch": spl,
             "value": n * spl * steps / tm.wall, "unit": "env-steps/s", "roofline": roofline_of(wc, n, spl, tm.launch_ms, desc, key),
             "repeats": {"n": len(reps), "roofline_frac": fr, "roofline_frac_min": min(fr), "roofline_frac_max": max(fr)},
             "telemetry": {"before": before, "after": after}}, tm
@@ -662,6 +663,8 @@ def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out, tele)
         out["configs"][key], tm = leg(torch, dist, ga, args, key, device, dev_index, spl, tele)
         if key == "scim":  # the same config with RK4Solver(split_kinks=True): steps cut at the PolynomialStaticLoad's kinks (accuracy option)
             out["configs"]["scim_split_kinks"], _ = leg(torch, dist, ga, args, key, device, dev_index, spl, tele, split_kinks=True)
+            # ... and with the reference default's semantics on the device (GEMX_SOLVER_ADAPTIVE: every lane cuts its own steps)
+            out["configs"]["scim_error_controlled"], _ = leg(torch, dist, ga, args, key, device, dev_index, spl, tele, error_controlled=True, steps=5)
             wc = dict(WORKLOADS[key], key=key)
             envs_ = make_env(ga, wc, wc["envs"], dev_index)
             dt, lms, n, smp = measure_sustained(torch, envs_, wc["envs"], spl, device, 13, args.sustain_s, tele, tm.launch_ms)

@@ -15,6 +15,7 @@ from .components import (  # noqa: F401
     DcShuntMotor,
     DoublyFedInductionMotor,
     DormandPrince5Solver,
+    ScipyOdeSolver,
     EulerSolver,
     ExternallyExcitedSynchronousMotor,
     FiniteB6BridgeConverter,

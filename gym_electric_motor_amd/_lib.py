@@ -6,7 +6,7 @@ import os
 from . import build as _build
 
 MAX_ODE, MAX_OUT, MODEL_ROWS, MODEL_COLS = 8, 24, 5, 11
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 SYS_DC_PERMEX, SYS_SYNC, SYS_SCIM, SYS_DC_SERIES, SYS_DC_SHUNT, SYS_DC_EXTEX, SYS_EESM, SYS_DFIM = 0, 1, 2, 3, 4, 5, 6, 7
 CONV_CONT_4QC, CONV_FINITE_B6, CONV_CONT_B6, CONV_FINITE_4QC = 0, 1, 2, 3
@@ -17,10 +17,10 @@ MAX_DELAY = 8
 CONV_CONT_2X4QC, CONV_FINITE_2X4QC, CONV_CONT_B6_4QC, CONV_FINITE_B6_4QC, CONV_CONT_2XB6, CONV_FINITE_2XB6 = 4, 5, 6, 7, 8, 9
 LOAD_CONST_SPEED, LOAD_POLY_STATIC = 0, 1
 SOLVER_EULER, SOLVER_RK4, SOLVER_DP5 = 0, 1, 2
-SOLVER_SPLIT_KINKS = 1
+SOLVER_SPLIT_KINKS, SOLVER_ADAPTIVE = 1, 2
 F32, F64 = 0, 1
 OBS_AOS, OBS_SOA = 0, 1
-ERRFLAG_ACTION, ERRFLAG_OMEGA_MOVED = 1, 2  # gemx_error_flags bits (GEMX_ERRFLAG_*)
+ERRFLAG_ACTION, ERRFLAG_OMEGA_MOVED, ERRFLAG_TOLERANCE = 1, 2, 4  # gemx_error_flags bits (GEMX_ERRFLAG_*)
 
 
 class GemxConfig(C.Structure):
@@ -36,7 +36,7 @@ class GemxConfig(C.Structure):
         ("supply_kind", C.c_int32), ("init_kind", C.c_int32), ("seed", C.c_uint64),
         ("init_lo", C.c_double * MAX_ODE), ("init_hi", C.c_double * MAX_ODE), ("init_mu", C.c_double * MAX_ODE),
         ("init_sigma", C.c_double * MAX_ODE),
-        ("supply_r", C.c_double), ("supply_c", C.c_double),
+        ("supply_r", C.c_double), ("supply_c", C.c_double), ("solver_rtol", C.c_double), ("solver_atol", C.c_double),
         ("tau", C.c_double), ("interlocking_time", C.c_double), ("u_nominal", C.c_double),
         ("model", C.c_double * (MODEL_ROWS * MODEL_COLS)),
         ("torque_coef", C.c_double * 4),

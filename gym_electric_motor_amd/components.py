@@ -200,6 +200,24 @@ class DormandPrince5Solver:
         self._split_kinks = bool(split_kinks)
 
 
+class ScipyOdeSolver(DormandPrince5Solver):
+    """The device's counterpart of the reference's DEFAULT solver, ScipyOdeSolver('dopri5') (solvers.py:139-184: scipy's adaptive DOPRI5,
+    rtol 1e-6, atol 1e-12): error-controlled Dormand-Prince 5(4) -- every integration segment is tried as one step and cut, lane by
+    lane, where the embedded error estimate exceeds the tolerance in scipy's norm (include/gemx.h: GEMX_SOLVER_ADAPTIVE).  Same
+    tolerance semantics, not scipy's step sequence.  Keyword arguments as `scipy.integrate.ode.set_integrator('dopri5', ...)` takes
+    them: `rtol`, `atol` (absolute, in state units; default 1e-9 -- scipy's 1e-12 is below fp32 resolution and changes nothing); others
+    (`nsteps`, `first_step`, `safety`, ...) are accepted and ignored.  A step at the floor of 1/1024 of a segment that still misses the
+    tolerance raises a warning through `check_errors()`."""
+
+    def __init__(self, integrator="dopri5", rtol=1e-6, atol=1e-9, **kwargs):
+        if integrator != "dopri5":
+            raise ValueError(f"integrator {integrator!r}: the accelerated path restates 'dopri5' (the reference's default) only")
+        super().__init__(nsteps=1, split_kinks=False)
+        self._adaptive = True
+        self._rtol, self._atol = float(rtol), float(atol)
+        self._ignored = dict(kwargs)
+
+
 # ------------------------------------------------------------------------------------------------- motors
 class _ElectricMotor:
     """electric_motors/electric_motor.py:9-325 (parameter / limit / nominal bookkeeping only)."""

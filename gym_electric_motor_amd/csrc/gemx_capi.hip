@@ -225,6 +225,11 @@ template <class R> static void fill_params(const gemx_handle &h, const double *m
     P.delay = c.action_delay;
     P.dq_adv = (R)((0.5 + c.action_delay) * c.tau * pole);  // dq_to_abc_action_processor.py:83-86, 98-100
     P.kink_split = (c.solver_flags & GEMX_SOLVER_SPLIT_KINKS) && c.load_kind == GEMX_LOAD_POLY_STATIC && P.omega_lim > R(0);
+    P.adaptive = (c.solver_flags & GEMX_SOLVER_ADAPTIVE) ? 1 : 0;
+    P.rtol = (R)(c.solver_rtol > 0 ? c.solver_rtol : 1e-6);
+    P.atol = (R)(c.solver_atol > 0 ? c.solver_atol : 1e-9);
+    P.errw = nullptr;  // (set per launch: launch_advance_t)
+    if (P.adaptive) P.kink_split = 0;
     P.auto_reset = c.auto_reset;
     P.obs_layout = c.obs_layout;
     P.dc_thr[0] = P.dc_thr[1] = (R)INFINITY;
@@ -423,7 +428,11 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         return fail(GEMX_ERR_ARG, "interlocking_time must be in [0, tau)");
     if (cfg->solver_kind < GEMX_SOLVER_EULER || cfg->solver_kind > GEMX_SOLVER_DP5) return fail(GEMX_ERR_ARG, "unknown solver_kind");
     if (cfg->solver_nsteps < 1 || cfg->solver_nsteps > 1024) return fail(GEMX_ERR_ARG, "solver_nsteps must be in [1, 1024]");
-    if (cfg->solver_flags & ~GEMX_SOLVER_SPLIT_KINKS) return fail(GEMX_ERR_ARG, "unknown solver_flags 0x%x", cfg->solver_flags);
+    if (cfg->solver_flags & ~(GEMX_SOLVER_SPLIT_KINKS | GEMX_SOLVER_ADAPTIVE)) return fail(GEMX_ERR_ARG, "unknown solver_flags 0x%x", cfg->solver_flags);
+    if ((cfg->solver_flags & GEMX_SOLVER_ADAPTIVE) && cfg->solver_kind != GEMX_SOLVER_DP5)
+        return fail(GEMX_ERR_ARG, "GEMX_SOLVER_ADAPTIVE needs solver_kind GEMX_SOLVER_DP5 (the embedded error estimate is Dormand-Prince's)");
+    if ((cfg->solver_flags & GEMX_SOLVER_ADAPTIVE) && (cfg->solver_rtol < 0 || cfg->solver_atol < 0 || cfg->solver_rtol > 0.1))
+        return fail(GEMX_ERR_ARG, "solver_rtol must be in [0, 0.1] and solver_atol >= 0 (0 = default)");
     if (cfg->dtype != GEMX_F32 && cfg->dtype != GEMX_F64) return fail(GEMX_ERR_ARG, "unknown dtype");
     if (cfg->obs_layout != GEMX_OBS_AOS && cfg->obs_layout != GEMX_OBS_SOA) return fail(GEMX_ERR_ARG, "unknown obs_layout");
     if (cfg->load_kind != GEMX_LOAD_CONST_SPEED && cfg->load_kind != GEMX_LOAD_POLY_STATIC) return fail(GEMX_ERR_ARG, "unknown load_kind");

@@ -90,6 +90,9 @@ template <class R> struct DevParams {
     int32_t delay;          // DeadTimeProcessor steps
     R dq_adv;               // (0.5 + delay) * tau * pole: angle advance per rad/s of omega
     int32_t kink_split;     // GEMX_SOLVER_SPLIT_KINKS: steps are cut at the PolynomialStaticLoad's kinks (integrate<>)
+    int32_t adaptive;       // GEMX_SOLVER_ADAPTIVE (DP5 only): error-controlled sub-stepping, dp5_adaptive()
+    R rtol, atol;           //   its tolerances (gemx_config.solver_rtol / solver_atol)
+    uint32_t *errw;         //   the handle's device error word (GEMX_ERRFLAG_TOLERANCE)
     // DC machines: the default LimitConstraint on current c as a threshold in AMPERES, dc_thr[c] = the smallest R with
     // fl(dc_thr[c] * inv_lim[2 + c]) > 1 (viol_threshold(), host): |i| >= dc_thr[c]  <=>  |i * inv_lim| > 1 for EVERY i, because
     // rounding is monotonic -- the same done / reset decisions bit for bit, without the multiply on the step-to-step chain
@@ -419,7 +422,7 @@ struct gemx_handle {
     void *angle = nullptr;   // [n] int32 | double
     uint8_t *sw = nullptr;   // [sw_rows][n]
     int sw_rows = 1;
-    void *linmap_dev = nullptr;  // one-step maps of the electrical subsystem (constant-speed loads), R[3][lin_count]: tau, t_il, tau - t_il
+    void *linmap_dev = nullptr;  // one-step maps of the electrical subsystem (constant-speed loads), R[4][lin_count]: Phi(tau) | D(t_il), D(tau - t_il), D(tau) (linmap_kernel)
     int linmap_state = 0;        // 0: not built yet, 1: built and enabled, -1: not applicable
     void *rinit_dev = nullptr;  // InitDev (random initial states)
     uint32_t *rcnt = nullptr;   // [n] resets so far per env

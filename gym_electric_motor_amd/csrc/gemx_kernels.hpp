@@ -243,6 +243,92 @@ __device__ __forceinline__ R rk_step(R (&z)[NZ], R h, F &&rhs) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// GEMX_SOLVER_ADAPTIVE: error-controlled Dormand-Prince 5(4) over one integration segment of length hs -- the semantics of the
+// reference's default solver (scipy's dopri5 behind ScipyOdeSolver, solvers.py:139-184: local error estimate from the embedded
+// 4th-order solution, norm sqrt(mean((err_i / (atol + rtol max(|y_i|, |y_i new|)))^2)), step accepted iff <= 1, next step
+// h * clamp(0.9 err^-1/5, 0.2, 10)), restated for a lock-stepped wave: every lane tries the whole segment first and cuts it where ITS
+// estimate demands; the wave iterates until its last lane is through, lanes that are done ride along with h = 0 (z + 0 k = z).  The
+// first stage of a sub-step is the last of the one before (FSAL), so an accepted sub-step costs six right-hand sides.  Differences to
+// scipy's code, none of which the tolerance depends on: the step size is not carried from one control step to the next (a control step
+// is tried whole), no PI term in the step-size rule, and a floor of hs / 1024 under which a step is taken as it is and bit
+// GEMX_ERRFLAG_TOLERANCE of the handle's error word is raised.  Returns the integral of z[0] over the segment (for the angle).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pow_m01(float x) { return __builtin_amdgcn_exp2f(-0.1f * __builtin_amdgcn_logf(x)); }  // x^-0.1, x > 0
+__device__ __forceinline__ double pow_m01(double x) { return pow(x, -0.1); }
+__device__ __forceinline__ float rcp_r(float x) { return __builtin_amdgcn_rcpf(x); }  // V_RCP_F32, 1 ulp: the error norm is compared with 1
+__device__ __forceinline__ double rcp_r(double x) { return 1.0 / x; }
+template <int NZ, class R, class F>
+__device__ __forceinline__ R dp5_adaptive(const DevParams<R> &P, R (&z)[NZ], R hs, F &&rhs) {
+    R k1[NZ];
+    rhs(z, k1);
+    R t = R(0), h = hs, integral = R(0);
+    const R hmin = hs * R(1.0 / 1024.0);
+    bool gave_up = false;
+#pragma nounroll
+    for (int guard = 0; guard < 4096; ++guard) {
+        const bool active = t < hs;
+        if (!__any(active)) break;
+        const bool fin = !(h < hs - t);  // this attempt reaches the end of the segment
+        const R hh = active ? (fin ? hs - t : h) : R(0);
+        R k2[NZ], k3[NZ], k4[NZ], k5[NZ], k6[NZ], k7[NZ], zt[NZ], zn[NZ];
+        R q = R(35.0 / 384.0) * z[0];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) zt[i] = z[i] + hh * (R(1.0 / 5.0) * k1[i]);
+        rhs(zt, k2);
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) zt[i] = z[i] + hh * (R(3.0 / 40.0) * k1[i] + R(9.0 / 40.0) * k2[i]);
+        rhs(zt, k3);
+        q += R(500.0 / 1113.0) * zt[0];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) zt[i] = z[i] + hh * (R(44.0 / 45.0) * k1[i] - R(56.0 / 15.0) * k2[i] + R(32.0 / 9.0) * k3[i]);
+        rhs(zt, k4);
+        q += R(125.0 / 192.0) * zt[0];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i)
+            zt[i] = z[i] + hh * (R(19372.0 / 6561.0) * k1[i] - R(25360.0 / 2187.0) * k2[i] + R(64448.0 / 6561.0) * k3[i] -
+                                 R(212.0 / 729.0) * k4[i]);
+        rhs(zt, k5);
+        q -= R(2187.0 / 6784.0) * zt[0];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i)
+            zt[i] = z[i] + hh * (R(9017.0 / 3168.0) * k1[i] - R(355.0 / 33.0) * k2[i] + R(46732.0 / 5247.0) * k3[i] +
+                                 R(49.0 / 176.0) * k4[i] - R(5103.0 / 18656.0) * k5[i]);
+        rhs(zt, k6);
+        q += R(11.0 / 84.0) * zt[0];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i)
+            zn[i] = z[i] + hh * (R(35.0 / 384.0) * k1[i] + R(500.0 / 1113.0) * k3[i] + R(125.0 / 192.0) * k4[i] -
+                                 R(2187.0 / 6784.0) * k5[i] + R(11.0 / 84.0) * k6[i]);
+        rhs(zn, k7);
+        R e2 = R(0);
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) {
+            const R err = hh * (R(71.0 / 57600.0) * k1[i] - R(71.0 / 16695.0) * k3[i] + R(71.0 / 1920.0) * k4[i] -
+                                R(17253.0 / 339200.0) * k5[i] + R(22.0 / 525.0) * k6[i] - R(1.0 / 40.0) * k7[i]);
+            const R sk = P.atol + P.rtol * fmax(fabs(z[i]), fabs(zn[i]));
+            const R r = err * rcp_r(sk);
+            e2 += r * r;
+        }
+        const R en2 = e2 * R(1.0 / NZ);  // the norm squared: err <= 1 <=> en2 <= 1, err^-1/5 = en2^-1/10
+        const bool floor_hit = !(hh > hmin);
+        const bool accept = active && (!(en2 > R(1)) || floor_hit);
+        gave_up |= active && floor_hit && en2 > R(1);
+        R fac = en2 > R(1e-20) ? R(0.9) * pow_m01(en2) : R(10);
+        fac = fmin(fmax(fac, R(0.2)), accept ? R(10) : R(1));
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) {
+            z[i] = accept ? zn[i] : z[i];
+            k1[i] = accept ? k7[i] : k1[i];
+        }
+        integral += accept ? hh * q : R(0);
+        t = accept ? (fin ? hs : t + hh) : t;
+        h = active ? fmax(hh * fac, hmin) : h;
+    }
+    if (gave_up && P.errw != nullptr) atomicOr(P.errw, (uint32_t)GEMX_ERRFLAG_TOLERANCE);
+    return integral;
+}
+
+// ------------------------------------------------------------------------------------------------
 // integrate one segment of length h with `nsteps` sub-steps (EulerSolver(nsteps), solvers.py:103-122).
 // y = [omega, motor states].  Returns the angle increment  pole * int(omega dt)  of the scheme.
 // ------------------------------------------------------------------------------------------------
@@ -266,8 +352,9 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
         // the map's coefficients: from the caller's registers when it preloaded them (lin_preload), else through the device pointer --
         // which, inside a rolled step loop, is TWO vector loads and a full trip to memory on every step (they cannot be hoisted out of the
         // `lin_ok` branch): the run-time-checked copies of the step spent 680 of their 1190 cycles per step there (s_memtime probe)
-        const R *L0 = linr != nullptr ? linr : P.lin;
         constexpr int NC = NM * (NM + NG);
+        // (SEG != 0: the caller's registers / the array start at map 1 -- [t_il | tau - t_il | tau], see linmap_kernel)
+        const R *L0 = linr != nullptr ? linr : P.lin + (SEG != 0 ? NC : 0);
         R L[NC];
         [[maybe_unused]] uint32_t two_mask = (SEG == 1 && two) ? 0xFFFFFFFFu : 0u;
         if constexpr (SEG == 1 && sizeof(R) == 4) asm volatile("" : "+v"(two_mask));
@@ -280,14 +367,14 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
                 // opaque copy of both operands in front of the select (round 3a) cost two v_mov per coefficient and step; the mask is
                 // opaque instead, so that the and / or form is not folded back into that select
                 uint32_t ca, cb;
-                memcpy(&ca, &L0[i], 4);
-                memcpy(&cb, &L0[NC + i], 4);
+                memcpy(&ca, &L0[2 * NC + i], 4);  // tau
+                memcpy(&cb, &L0[i], 4);           // t_il
                 const uint32_t cs = (two_mask & cb) | (~two_mask & ca);
                 memcpy(&L[i], &cs, 4);
             } else if constexpr (SEG == 1) {
-                L[i] = two ? L0[NC + i] : L0[i];
+                L[i] = two ? L0[i] : L0[2 * NC + i];
             } else {
-                L[i] = L0[SEG == 2 ? 2 * NC + i : i];
+                L[i] = L0[SEG == 2 ? NC + i : i];
             }
         }
         const R om = P.init[0];  // == y[0] in every lane (lin_usable); wave-uniform, so everything derived from it is loop-invariant
@@ -303,7 +390,7 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
                 for (int i = 1; i < NG; ++i) acc += L[NM * NM + r * NG + i] * g[i];
 #pragma unroll
                 for (int c = 0; c < NM; ++c) acc += L[r * NM + c] * x[c];
-                xn[r] = acc;
+                xn[r] = SEG != 0 ? x[r] + acc : acc;  // (dead-time maps hold D = Phi - I)
             }
 #pragma unroll
             for (int r = 0; r < NM; ++r) x[r] = xn[r];
@@ -320,7 +407,9 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
 #pragma unroll
         for (int i = 0; i < NM; ++i) x[i] = y[1 + i];
         auto rhs = [&](const R (&xx)[NM], R (&dx)[NM]) { E::f(P, pre, xx, dx); };
-        if (NS1 || ns == 1) {
+        if (SOLVER == GEMX_SOLVER_DP5 && P.adaptive) {
+            dp5_adaptive<NM, R>(P, x, h, rhs);
+        } else if (NS1 || ns == 1) {
             rk_step<SOLVER, NM, R>(x, hs, rhs);
         } else {
             for (int s = 0; s < ns; ++s) rk_step<SOLVER, NM, R>(x, hs, rhs);
@@ -340,6 +429,7 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
 #pragma unroll
             for (int i = 0; i < NM; ++i) dz[1 + i] = dx[i];
         };
+        if (SOLVER == GEMX_SOLVER_DP5 && P.adaptive) return P.pole * dp5_adaptive<NM + 1, R>(P, y, h, rhs);
         if (!P.kink_split) {
             R wsum = R(0);
             if (NS1 || ns == 1) {
@@ -629,7 +719,9 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
                 const R i = i_in(y, j);
                 u[j] = (cont_leg<IL, R>(P, d0, i) - cont_leg<IL, R>(P, d1, i)) * P.u_sup;  // both sub-converters see the same i (line 483)
             }
-            integrate<SYS, LOAD, SOLVER, R, NS1, LIN>(P, y, u, P.tau, linr);
+            // (one segment; the dead-time instantiations' registers hold maps 1..3, so they name the whole step as `first segment, no
+            // switching leg`: integrate<..., SEG = 1>(two = false) takes the tau map among them)
+            integrate<SYS, LOAD, SOLVER, R, NS1, LIN, IL ? 1 : 0>(P, y, u, P.tau, linr, false);
         } else {  // Finite-4QC: action -> (leg0, leg1) sub-actions [1,1,2,2] / [1,2,1,2] (converters.py:360-361)
             uint32_t legs = 0;
 #pragma unroll
@@ -843,7 +935,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
         u[0] = c * ual + s * ube;  // Q^-1(., eps) at the step-start angle (line 643)
         u[1] = -s * ual + c * ube;
         u[2] = ue;
-        const R deps = integrate<GEMX_SYS_EESM, LOAD, SOLVER, R, NS1, LIN>(P, y, u, P.tau, linr);
+        const R deps = integrate<GEMX_SYS_EESM, LOAD, SOLVER, R, NS1, LIN, IL ? 1 : 0>(P, y, u, P.tau, linr, false);  // (see DcStepper: one segment, the tau map)
         ang = Angle<R>::advance(ang, deps);
         ho[0] = s; ho[1] = c; ho[2] = ua; ho[3] = ub; ho[4] = uc; ho[5] = u[0]; ho[6] = u[1]; ho[7] = ue;
     }
@@ -1166,38 +1258,44 @@ template <int SYS, class R> constexpr int lin_count() { return Elec<SYS, R>::NM 
 // registers of a kernel instantiation's preloaded coefficients: one map, or the three segment maps of the dead-time (IL) instantiations
 template <int SYS, class R, bool IL> constexpr int lin_regs() { return lin_count<SYS, R>() * (IL ? 3 : 1); }
 template <int SYS, class R, int NR> __device__ __forceinline__ void lin_preload(const DevParams<R> &P, bool lin_ok, R (&c)[NR]) {
+    constexpr int OFF = NR > lin_count<SYS, R>() ? lin_count<SYS, R>() : 0;  // the dead-time instantiations take maps 1..3 (linmap_kernel)
 #pragma unroll
-    for (int i = 0; i < NR; ++i) c[i] = lin_ok ? P.lin[i] : R(0);
+    for (int i = 0; i < NR; ++i) c[i] = lin_ok ? P.lin[OFF + i] : R(0);
 }
 // builds the map for one handle: Phi's columns are rk_step(e_j) with g = 0, S's columns rk_step(0) with g = e_i
-template <int SYS, int SOLVER, class R> __global__ void linmap_kernel(DevParams<R> P, R *out) {
-    using E = Elec<SYS, R>;
+template <int SYS, int SOLVER, class R> __global__ void linmap_kernel(DevParams<double> P, R *out) {
+    // Evaluated in DOUBLE whatever R is: the maps are Phi = I + D with D = O(h A), and what a step needs of them is D.  Formed in fp32,
+    // 1 + D carries D to an absolute 6e-8 only -- a relative 6e-8 / (h A) error of every decay rate, SYSTEMATIC (the same coefficient
+    // every step): 1e-3 for the 1 us dead-time segment of a PMSM, which turned currents near zero to the wrong sign and with them a
+    // freewheeling leg's voltage (r03m: u_a off by 2.0 normalised with nsteps = 8).  So: rk_step in double, and
+    //   map 0 (whole step tau, the instantiations without dead time): Phi and S, rounded once (h A ~ 5e-3 ... 0.1 there: 1e-5 at worst);
+    //   maps 1, 2, 3 (t_il, tau - t_il, tau: the dead-time instantiations): D = Phi - I and S -- the step is x + (D x + S g).
+    using E = Elec<SYS, double>;
     constexpr int NM = E::NM, NG = E::NG, NC = NM * (NM + NG);
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const R u0[MAX_U] = {R(0), R(0), R(0), R(0)};
-    R zg[NG];
-    for (int i = 0; i < NG; ++i) zg[i] = R(0);
+    const double u0[MAX_U] = {0.0, 0.0, 0.0, 0.0};
+    double zg[NG];
+    for (int i = 0; i < NG; ++i) zg[i] = 0.0;
     const typename E::Pre pre0 = E::set_b(E::prep(P, P.init[0], u0), zg);
-    // map 0: the whole control step; maps 1 / 2: the two segments of a step cut by converter dead time (integrate<..., SEG>)
-    const R hseg[3] = {P.tau, P.t_il, P.tau - P.t_il};
-    for (int k = 0; k < 3; ++k) {
-        const R hs = hseg[k] * P.inv_ns;
+    const double hseg[4] = {P.tau, P.t_il, P.tau - P.t_il, P.tau};
+    for (int k = 0; k < 4; ++k) {
+        const double hs = hseg[k] * P.inv_ns;
         R *o = out + k * NC;
         for (int j = 0; j < NM; ++j) {
-            R x[NM];
-            for (int i = 0; i < NM; ++i) x[i] = i == j ? R(1) : R(0);
-            auto rhs = [&](const R (&xx)[NM], R (&dx)[NM]) { E::f(P, pre0, xx, dx); };
-            rk_step<SOLVER, NM, R>(x, hs, rhs);
-            for (int r = 0; r < NM; ++r) o[r * NM + j] = x[r];
+            double x[NM];
+            for (int i = 0; i < NM; ++i) x[i] = i == j ? 1.0 : 0.0;
+            auto rhs = [&](const double (&xx)[NM], double (&dx)[NM]) { E::f(P, pre0, xx, dx); };
+            rk_step<SOLVER, NM, double>(x, hs, rhs);
+            for (int r = 0; r < NM; ++r) o[r * NM + j] = (R)(k == 0 ? x[r] : x[r] - (r == j ? 1.0 : 0.0));
         }
         for (int i = 0; i < NG; ++i) {
-            R gi[NG], x[NM];
-            for (int q = 0; q < NG; ++q) gi[q] = q == i ? R(1) : R(0);
-            for (int q = 0; q < NM; ++q) x[q] = R(0);
+            double gi[NG], x[NM];
+            for (int q = 0; q < NG; ++q) gi[q] = q == i ? 1.0 : 0.0;
+            for (int q = 0; q < NM; ++q) x[q] = 0.0;
             const typename E::Pre prei = E::set_b(pre0, gi);
-            auto rhs = [&](const R (&xx)[NM], R (&dx)[NM]) { E::f(P, prei, xx, dx); };
-            rk_step<SOLVER, NM, R>(x, hs, rhs);
-            for (int r = 0; r < NM; ++r) o[NM * NM + r * NG + i] = x[r];
+            auto rhs = [&](const double (&xx)[NM], double (&dx)[NM]) { E::f(P, prei, xx, dx); };
+            rk_step<SOLVER, NM, double>(x, hs, rhs);
+            for (int r = 0; r < NM; ++r) o[NM * NM + r * NG + i] = (R)x[r];
         }
     }
 }
@@ -3299,12 +3397,12 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         if constexpr (linable<SYS, LOAD, SOLVER, IL, R>()) {
             hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
             (void)hipStreamIsCapturing(st, &capturing);
-            if (h->cfg.init_kind != GEMX_INIT_CONST) {
+            if (h->cfg.init_kind != GEMX_INIT_CONST || (h->cfg.solver_flags & GEMX_SOLVER_ADAPTIVE) || h->cfg.solver_nsteps != 1) {  // (error control, sub-steps: stage by stage)
                 h->linmap_state = -1;
             } else if (capturing == hipStreamCaptureStatusNone) {
                 // built and COMPLETED here, so that later launches on any stream (or from a captured graph) find it; a first launch
                 // that is itself being captured into a graph goes without the map and leaves the attempt to the next eager launch
-                hipLaunchKernelGGL((linmap_kernel<SYS, SOLVER, R>), dim3(1), dim3(64), 0, st, params_of<R>(h), (R *)h->linmap_dev);
+                hipLaunchKernelGGL((linmap_kernel<SYS, SOLVER, R>), dim3(1), dim3(64), 0, st, params_of<double>(h), (R *)h->linmap_dev);
                 GEMX_HIP_TRY(hipGetLastError());
                 GEMX_HIP_TRY(hipStreamSynchronize(st));
                 h->linmap_state = 1;
@@ -3315,6 +3413,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         }
     }
     a.P = params_of<R>(h);
+    a.P.errw = h->err;
     a.rinit = (const InitDev *)h->rinit_dev;
     a.rcnt = h->rcnt;
     a.rw = h->cur_reward != nullptr ? (const RewardDev<R> *)h->rw_dev : nullptr;
@@ -3358,7 +3457,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     // PermExDc, us per 1000 steps at 4096 / 8192 / 12288 / 16384 envs: 39 / 41 / 88 / 94 against 71 / 72 / 72 / 72; tools/ab_dc_stream.py)
     if constexpr (sizeof(R) == 4 && LOAD == GEMX_LOAD_CONST_SPEED && !IL &&
                   (SYS == GEMX_SYS_DC_PERMEX || SYS == GEMX_SYS_DC_SERIES || SYS == GEMX_SYS_DC_SHUNT || SYS == GEMX_SYS_DC_EXTEX)) {
-        bool dcs_ok = pipe_ok && h->use_dc_stream != 0 && !need_full && delay == 0 && h->cur_reward == nullptr && (h->omega_is_init || h->use_dc_stream >= 3) &&
+        bool dcs_ok = pipe_ok && h->use_dc_stream != 0 && !need_full && delay == 0 && !(h->cfg.solver_flags & GEMX_SOLVER_ADAPTIVE) && h->cur_reward == nullptr && (h->omega_is_init || h->use_dc_stream >= 3) &&
                       params_of<R>(h).obs_layout == GEMX_OBS_AOS && params_of<R>(h).t_il == R(0) &&
                       (h->use_dc_stream > 1 || 2 * blocks <= (int64_t)h->n_cu) && dcs_smem_bytes<SYS, CONV>() <= h->lds_max &&
                       (int64_t)h->n * h->nout * 16 < ((int64_t)1 << 32);  // (32-bit lane offsets across the four rows of a group)

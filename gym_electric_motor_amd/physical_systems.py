@@ -282,8 +282,21 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             raise ValueError(f"the sub-converters of a multi converter must share one interlocking_time on the accelerated path, got {sorted(tils)}")
         return tils.pop()
 
+    def _adaptive_tolerances(self):
+        """(rtol, atol) if the solver is the error-controlled one: this package's ScipyOdeSolver, or the REFERENCE's own
+        ScipyOdeSolver('dopri5', **kwargs) instance (solvers.py:139-184; scipy's defaults rtol 1e-6, atol 1e-12 -> device floor 1e-9)."""
+        s = self._ode_solver
+        if getattr(s, "_adaptive", False):
+            return float(s._rtol), float(s._atol)
+        if _is_a(s, "ScipyOdeSolver") and getattr(s, "_integrator", None) == "dopri5":
+            kw = dict(getattr(s, "_solver_args", {}) or {})
+            return float(kw.get("rtol", 1e-6)), max(float(kw.get("atol", 1e-12)), 1e-9)
+        return None
+
     def _solver_kind(self):
         s = self._ode_solver
+        if self._adaptive_tolerances() is not None:
+            return _lib.SOLVER_DP5, 1
         nsteps = int(getattr(s, "_nsteps", 1))
         if _is_a(s, "EulerSolver"):
             return _lib.SOLVER_EULER, nsteps
@@ -291,8 +304,8 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             return _lib.SOLVER_RK4, nsteps
         if _is_a(s, "DormandPrince5Solver"):
             return _lib.SOLVER_DP5, nsteps
-        raise ValueError(f"ode_solver {type(s).__name__} is a CPU (scipy) solver; the GPU path takes EulerSolver, "
-                         "RK4Solver or DormandPrince5Solver")
+        raise ValueError(f"ode_solver {type(s).__name__} is a CPU (scipy) solver; the GPU path takes EulerSolver, RK4Solver, "
+                         "DormandPrince5Solver or ScipyOdeSolver('dopri5') (error-controlled Dormand-Prince on the device)")
 
     def _load_params(self):
         ld = self._mechanical_load
@@ -352,6 +365,10 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
                              f"{type(self._electrical_motor).__name__}: it is not on the accelerated path")
         cfg.solver_kind, cfg.solver_nsteps = self._solver_kind()
         cfg.solver_flags = _lib.SOLVER_SPLIT_KINKS if getattr(self._ode_solver, "_split_kinks", False) else 0
+        tol = self._adaptive_tolerances()
+        if tol is not None:  # ScipyOdeSolver: error-controlled DP5
+            cfg.solver_flags = _lib.SOLVER_ADAPTIVE
+            cfg.solver_rtol, cfg.solver_atol = tol
         cfg.dtype = _lib.F64 if self._dtype_name == "float64" else _lib.F32
         cfg.obs_layout = {"aos": _lib.OBS_AOS, "soa": _lib.OBS_SOA}[self._obs_layout]
         cfg.auto_reset = int(self._auto_reset)
@@ -728,6 +745,11 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             raise _lib.GemxError("a launch specialised for envs at their initial speed (dc_stream_kernel) found another omega in device memory: "
                                  "set_state() and the rollout were enqueued on different streams without synchronisation; the observations "
                                  "of that launch are invalid")
+        if flags.value & _lib.ERRFLAG_TOLERANCE:
+            import warnings
+
+            warnings.warn("the error-controlled solver (ScipyOdeSolver) took a step at its floor of 1/1024 of a segment whose error estimate "
+                          "exceeded the tolerance: some trajectory since the last check is less accurate than asked for", RuntimeWarning)
 
     # ------------------------------------------------------------------ checkpoint / parity access
     def get_state(self):

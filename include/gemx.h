@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GEMX_ABI_VERSION 3 /* 2: GEMX_MAX_OUT 16 -> 24 (DFIM system, 24 states); 3: gemx_config.solver_flags */
+#define GEMX_ABI_VERSION 4 /* 2: GEMX_MAX_OUT 16 -> 24 (DFIM system, 24 states); 3: gemx_config.solver_flags; 4: solver_rtol / solver_atol */
 #define GEMX_MAX_ODE 8  /* ODE state length incl. omega and the angle      */
 #define GEMX_MAX_OUT 24 /* system-state (observation) length               */
 #define GEMX_MODEL_ROWS 5
@@ -78,6 +78,15 @@ typedef enum { GEMX_SOLVER_EULER = 0, GEMX_SOLVER_RK4 = 1, GEMX_SOLVER_DP5 = 2 }
  * solvers.py:139-184), which rejects and splits exactly these steps: a fixed step loses its order at a kink.  Worst observed error against
  * the reference's dopri5 trajectories (fp64, SCIM + PolynomialStaticLoad): 7.5e-5 without, 1.3e-5 with.  Ignored for a ConstantSpeedLoad. */
 #define GEMX_SOLVER_SPLIT_KINKS 1
+/* GEMX_SOLVER_ADAPTIVE (with GEMX_SOLVER_DP5 only): error-controlled sub-stepping -- what the reference's default solver does
+ * (ScipyOdeSolver('dopri5'), solvers.py:139-184: scipy's DOPRI5 with rtol 1e-6, atol 1e-12).  Every integration segment is tried as one
+ * Dormand-Prince 5(4) step; where the embedded error estimate, in scipy's norm sqrt(mean((err_i / (solver_atol + solver_rtol
+ * max(|y_i|, |y_i new|)))^2)), exceeds 1 the lane cuts its step (h <- h clamp(0.9 err^-1/5, 0.2, 1)) and goes on with steps chosen the same
+ * way until the segment is through; the other lanes of its wave wait.  Not scipy's step sequence (no step size carried between control
+ * steps, no PI term), so not its bits -- the same tolerance.  Floor: a step of 1/1024 of the segment is taken whatever its estimate and
+ * raises GEMX_ERRFLAG_TOLERANCE.  Takes precedence over GEMX_SOLVER_SPLIT_KINKS and over solver_nsteps; the one-step map and the
+ * small-batch DC kernel are not used. */
+#define GEMX_SOLVER_ADAPTIVE 2
 typedef enum { GEMX_F32 = 0, GEMX_F64 = 1 } gemx_dtype;
 /* observation layout: [N, S_out] rows per env (the reference contract) or [S_out, N] */
 typedef enum { GEMX_OBS_AOS = 0, GEMX_OBS_SOA = 1 } gemx_obs_layout;
@@ -129,6 +138,7 @@ typedef struct gemx_config {
     uint64_t seed;
     double init_lo[GEMX_MAX_ODE], init_hi[GEMX_MAX_ODE], init_mu[GEMX_MAX_ODE], init_sigma[GEMX_MAX_ODE];
     double supply_r, supply_c;
+    double solver_rtol, solver_atol; /* GEMX_SOLVER_ADAPTIVE: relative / absolute (state units) tolerance; 0 = 1e-6 / 1e-9 */
     double tau;               /* control step, PhysicalSystem.tau */
     double interlocking_time; /* converter dead time, converters.py:35-41; must be < tau */
     double u_nominal;         /* IdealVoltageSupply.u_nominal, voltage_supplies.py:60-72 */
@@ -266,9 +276,11 @@ const char *gemx_last_launch(const gemx_handle *h);
  *                converters.py:204-206; the kernel masks it into range);
  *   OMEGA_MOVED  a launch specialised for "omega of every env == its initial value" (dc_stream_kernel, constant-speed loads) found
  *                another omega in device memory -- e.g. enqueued on a different stream than a preceding gemx_set_state: the
- *                observations of that launch are invalid. */
+ *                observations of that launch are invalid;
+ *   TOLERANCE    GEMX_SOLVER_ADAPTIVE took a step at its floor (1/1024 of a segment) whose error estimate exceeded the tolerance. */
 #define GEMX_ERRFLAG_ACTION 1u
 #define GEMX_ERRFLAG_OMEGA_MOVED 2u
+#define GEMX_ERRFLAG_TOLERANCE 4u
 int gemx_error_flags(gemx_handle *h, uint32_t *flags_host, void *stream);
 
 #ifdef __cplusplus

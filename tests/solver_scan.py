@@ -17,7 +17,7 @@ sys.path.insert(0, HERE)
 
 import test_gpu_parity as T  # noqa: E402
 
-OPTIONS = ["rk4", "rk4x2", "rk4x4", "rk4x8", "rk4k", "rk4kx2", "dp5", "dp5x2", "dp5k"]
+OPTIONS = ["rk4", "rk4x2", "rk4x4", "rk4x8", "rk4k", "rk4kx2", "dp5", "dp5x2", "dp5k", "ode"]  # ode: ScipyOdeSolver() (error-controlled DP5)
 
 
 def main():
@@ -35,6 +35,8 @@ def main():
             try:
                 if o == "default":
                     s = ga.default_ode_solver(meta["env_id"], tau=meta["tau"], load=meta["load"])
+                elif o == "ode":
+                    s = ga.ScipyOdeSolver()
                 else:
                     kind = o[:3]
                     rest = o[3:]

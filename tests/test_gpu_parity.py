@@ -270,6 +270,110 @@ def test_fp32_plain_rk4_on_constant_speed_loads_matches_reference_default_dopri5
     assert rel < 1e-4, (rel, col, dmsg)
 
 
+@pytest.mark.parametrize("name", ["pmsm_free_held_til_dopri5", "pmsm_free_uniform_til_dopri5", "dfim_fin_free_held_til_dopri5"])
+@pytest.mark.parametrize("nsteps", [1, 8])
+def test_dead_time_maps_keep_the_stage_by_stage_accuracy(name, nsteps):
+    """Converter dead time through the per-segment one-step maps must be as accurate as the stage-by-stage solver: a map formed in fp32
+    as I + D loses D to an absolute 6e-8, i.e. 1e-3 of the decay over a 1 us segment -- the first version of these maps took the PMSM
+    fixtures from 7.7e-7 to 7.5e-6 and, sub-stepped, flipped a freewheeling leg (u_a off by 2.0).  Maps evaluated in double, D-form for the
+    dead-time segments, none for sub-stepped solvers: within 1.5x + 1e-6 of the run with GEMX_LINMAP=0, and far inside the contract."""
+    import gym_electric_motor_amd as ga
+
+    errs = {}
+    for lm in ("1", "0"):
+        os.environ["GEMX_LINMAP"] = lm
+        try:
+            d, meta, obs, done = _run_golden(name, "float32", solver=ga.RK4Solver(nsteps=nsteps))
+        finally:
+            os.environ.pop("GEMX_LINMAP", None)
+        errs[lm] = compare_trajectory(meta, d, obs, done)[0]
+    assert errs["1"] < 1.5 * errs["0"] + 1e-6 and errs["1"] < 2e-5, errs
+
+
+ADAPTIVE_CASES = DOPRI + [c for c in DEFAULTS if "_sc_" in c or "_tc_" in c][::3]
+
+
+@pytest.mark.parametrize("name", ADAPTIVE_CASES)
+def test_error_controlled_solver_tracks_the_reference_default_solver(name):
+    """GEMX_SOLVER_ADAPTIVE (ga.ScipyOdeSolver(): Dormand-Prince 5(4) with the embedded error estimate, rtol 1e-6 in scipy's norm, each
+    lane cutting its own steps) against the runs the reference's default solver -- scipy's adaptive dopri5 at the same tolerance --
+    recorded: every dopri5 fixture of every machine and a third of the speed- and torque-control default fixtures, fp32, within the
+    north star's 1e-4 (observed: the fp32 noise floor of the machine, a few 1e-6), done masks exact, and the tolerance flag down."""
+    import gym_electric_motor_amd as ga
+
+    d, meta, obs, done = _run_golden(name, "float32", solver=ga.ScipyOdeSolver())
+    rel, _, col, dmsg = compare_trajectory(meta, d, obs, done)
+    assert rel < 1e-4, (rel, col, dmsg)
+
+
+@pytest.mark.parametrize("name", ["scim_free_held_dopri5", "pmsm_sc_free_held_dopri5", "permexdc_epi_held_dopri5", "synrm_cont_sc_epi_held_dopri5",
+                                  "pmsm_epi_uniform_tau1e-4_dopri5"])
+def test_error_controlled_solver_fp64_against_the_reference_default_solver(name):
+    """The fp64 build of the same code against the reference's dopri5 runs: two error-controlled integrations at rtol 1e-6 with different
+    step sequences stay within a few 1e-6 of each other (bound 2e-5), where the device's fixed steps are at 1e-5 ... 7e-5."""
+    import gym_electric_motor_amd as ga
+
+    d, meta, obs, done = _run_golden(name, "float64", solver=ga.ScipyOdeSolver())
+    rel, _, col, dmsg = compare_trajectory(meta, d, obs, done)
+    assert rel < 2e-5, (rel, col, dmsg)
+
+
+def test_error_controlled_solver_is_the_same_in_every_kernel_and_chunking():
+    """One fused rollout == the same steps in uneven chunks == step by step (gemx_step), and the pipelined kernel == the single-wave
+    kernel: the step-size decisions are per control step and per lane, so nothing may depend on how the steps are batched."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    n, K = 256, 60
+    outs = {}
+    for tag, pipe in (("pipe", "1"), ("wave", "0")):
+        os.environ["GEMX_PIPE"] = pipe
+        try:
+            env = ga.make("Cont-SC-SCIM-v0", n_envs=n, ode_solver=ga.ScipyOdeSolver(), tau=1e-4)
+            g = torch.Generator(device="cuda").manual_seed(11)
+            acts = torch.rand((K, n, 3), device="cuda", generator=g) * 2 - 1
+            env.reset()
+            obs, done = env.rollout(acts)
+            outs[tag] = (obs.clone(), done.clone(), env.physical_system.last_launch())
+            if tag == "pipe":
+                env.reset()
+                parts = [env.rollout(acts[a:b]) for a, b in ((0, 7), (7, 8), (8, 41), (41, K))]
+                assert torch.equal(torch.cat([p[0] for p in parts]), obs) and torch.equal(torch.cat([p[1] for p in parts]), done)
+                env.reset()
+                ps = env.physical_system
+                for k in range(K):
+                    o = ps.simulate(acts[k])
+                    assert torch.equal(o, obs[k]), k
+            env.physical_system.check_errors()
+            env.close()
+        finally:
+            os.environ.pop("GEMX_PIPE", None)
+    assert "advance_pipe_kernel" in outs["pipe"][2] and "advance_kernel" in outs["wave"][2]
+    assert torch.equal(outs["pipe"][0], outs["wave"][0]) and torch.equal(outs["pipe"][1], outs["wave"][1])
+
+
+def test_error_controlled_solver_raises_its_flag_at_the_floor():
+    """A tolerance below the arithmetic's resolution (rtol 1e-12 in fp32) cannot be met: the steps end at the floor of 1/1024 of the
+    control step and bit GEMX_ERRFLAG_TOLERANCE goes up -- check_errors() warns.  At the default tolerance the flag stays down."""
+    import warnings
+
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    for rtol, expect in ((1e-6, False), (1e-12, True)):
+        env = ga.make("Cont-SC-PMSM-v0", n_envs=128, ode_solver=ga.ScipyOdeSolver(rtol=rtol, atol=1e-30 if expect else 1e-9), tau=1e-4)
+        env.reset()
+        g = torch.Generator(device="cuda").manual_seed(3)
+        env.rollout(torch.rand((50, 128, 3), device="cuda", generator=g) * 2 - 1)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            env.physical_system.check_errors()
+        assert any("error-controlled" in str(x.message) for x in w) == expect, (rtol, [str(x.message) for x in w])
+        env.close()
+
+
 SCIM_POLY_DOPRI = [c for c in DOPRI if c.startswith("scim_") and "constspeed" not in c]
 
 

@@ -165,6 +165,10 @@ def test_unsupported_pieces_raise():
 
     with pytest.raises(ValueError):
         ga.make("Cont-CC-PermExDc-v0", n_envs=2, ode_solver=ScipyOdeSolver(), _defer_create=True)
+    lsoda = ScipyOdeSolver()
+    lsoda._integrator, lsoda._solver_args = "lsoda", {}
+    with pytest.raises(ValueError):
+        ga.make("Cont-CC-PermExDc-v0", n_envs=2, ode_solver=lsoda, _defer_create=True)
     with pytest.raises(KeyError):  # update_parameter_dict semantics, utils.py:73-94
         ga.DcPermanentlyExcitedMotor(motor_parameter=dict(r_x=1.0))
     with pytest.raises(AssertionError, match="only available for Continuous"):  # physical_systems.py:431-434
@@ -176,6 +180,48 @@ def test_unsupported_pieces_raise():
     with pytest.raises(ValueError, match="INSIDE"):
         ga.make("Cont-CC-PMSM-v0", n_envs=2, _defer_create=True,
                 physical_system_wrappers=(ga.DqToAbcActionProcessor.make("PMSM"), ga.DeadTimeProcessor(1)))
+
+
+def test_error_controlled_solver_config():
+    """ga.ScipyOdeSolver() and the REFERENCE's own ScipyOdeSolver('dopri5', **kwargs) instance (solvers.py:139-184: its default solver)
+    both select the device's error-controlled Dormand-Prince: GEMX_SOLVER_DP5 + GEMX_SOLVER_ADAPTIVE with the caller's tolerances (scipy's
+    atol 1e-12 is raised to the device's floor 1e-9); the flag is refused with another scheme."""
+    cfg = ga.make("Cont-SC-SCIM-v0", n_envs=2, ode_solver=ga.ScipyOdeSolver(), _defer_create=True).physical_system._cfg
+    assert (cfg.solver_kind, cfg.solver_nsteps, cfg.solver_flags) == (_lib.SOLVER_DP5, 1, _lib.SOLVER_ADAPTIVE)
+    assert (cfg.solver_rtol, cfg.solver_atol) == (1e-6, 1e-9)
+    cfg = ga.make("Cont-SC-SCIM-v0", n_envs=2, ode_solver=ga.ScipyOdeSolver(rtol=1e-5, atol=1e-7, nsteps=500), _defer_create=True).physical_system._cfg
+    assert (cfg.solver_flags, cfg.solver_rtol, cfg.solver_atol) == (_lib.SOLVER_ADAPTIVE, 1e-5, 1e-7)
+    with pytest.raises(ValueError):
+        ga.ScipyOdeSolver("lsoda")
+
+    class ScipyOdeSolver:  # the shape of the reference's class (duck-typed by name, like every reference component)
+        def __init__(self, integrator="dopri5", **kwargs):
+            self._integrator, self._solver_args = integrator, kwargs
+
+    cfg = ga.make("Cont-SC-SCIM-v0", n_envs=2, ode_solver=ScipyOdeSolver(), _defer_create=True).physical_system._cfg
+    assert (cfg.solver_kind, cfg.solver_flags, cfg.solver_rtol, cfg.solver_atol) == (_lib.SOLVER_DP5, _lib.SOLVER_ADAPTIVE, 1e-6, 1e-9)
+    cfg = ga.make("Cont-SC-SCIM-v0", n_envs=2, ode_solver=ScipyOdeSolver(rtol=1e-4, atol=1e-5), _defer_create=True).physical_system._cfg
+    assert (cfg.solver_rtol, cfg.solver_atol) == (1e-4, 1e-5)
+    if os.path.isdir("/root/reference/src"):  # the live class, in a child process (its imports stay out of this session)
+        import subprocess
+        import sys
+
+        code = ("import os, sys; os.environ['MPLBACKEND'] = 'Agg'; sys.path[:0] = [%r, %r, %r]\n"
+                "from gym_electric_motor.physical_systems.solvers import ScipyOdeSolver\n"
+                "import gym_electric_motor_amd as ga\nfrom gym_electric_motor_amd import _lib\n"
+                "c = ga.make('Cont-SC-SCIM-v0', n_envs=2, ode_solver=ScipyOdeSolver(), _defer_create=True).physical_system._cfg\n"
+                "assert (c.solver_kind, c.solver_flags, c.solver_rtol) == (_lib.SOLVER_DP5, _lib.SOLVER_ADAPTIVE, 1e-6)\nprint('OK')\n"
+                % (os.path.join(REPO, "oracle", "gymnasium_standin"), "/root/reference/src", REPO))
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-3000:]
+    L = _lib.load()
+    h = C.c_void_p()
+    bad = _lib.GemxConfig.from_buffer_copy(cfg)
+    bad.solver_kind = _lib.SOLVER_RK4
+    assert L.gemx_create(C.byref(bad), 4, 0, C.byref(h)) == -1 and b"GEMX_SOLVER_ADAPTIVE" in L.gemx_last_error()
+    bad = _lib.GemxConfig.from_buffer_copy(cfg)
+    bad.solver_rtol = 0.5
+    assert L.gemx_create(C.byref(bad), 4, 0, C.byref(h)) == -1 and b"solver_rtol" in L.gemx_last_error()
 
 
 def test_c_abi_argument_validation_without_gpu():
