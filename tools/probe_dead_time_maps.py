@@ -1,3 +1,5 @@
+"""GPU box: converter dead time through the per-segment one-step maps (GEMX_LINMAP=1) against the stage-by-stage solver (=0), plain and
+sub-stepped RK4, on the recorded dopri5 runs with interlocking (what found the fp32 map-precision bug of round 3)."""
 import os, sys
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import test_gpu_parity as T
