@@ -47,8 +47,8 @@ Extra objects in the JSON line (rank 0):
                       recorded by oracle/cpu_reference_bench.py (fields, not prose).
   headline_no_linmap  the same launches with GEMX_LINMAP=0 (RK4 evaluated stage by stage instead of through the one-step affine map).
   sustained_1s        >= 1 s of back-to-back launches of the headline workload with clocks / power sampled (also under configs.scim).
-  single_step / single_step_graph   one launch per control step (closed-loop RL usage): eager `PhysicalSystem.simulate()` on a device
-                      tensor, and 64 steps replayed from a HIP graph.
+  single_step / single_step_bound / single_step_graph   one launch per control step (closed-loop RL usage): eager
+                      `PhysicalSystem.simulate()` on a device tensor, the pre-bound `bind_step()` call, and 64 steps replayed from a HIP graph.
   configs             BASELINE config 2 (PermExDc 4096 envs Euler, with `launch_model`: t = t_fixed + K t_step fitted over launches of
                       250 ... 2000 steps, and `frac_of_latency_bound` = (K x the integrator's dependency chain + t_fixed) / measured),
                       config 4 (SCIM 65536 envs RK4 with the env's PolynomialStaticLoad -- also with split_kinks, the solver
@@ -345,8 +345,9 @@ def measure_traffic_pmc(args, workload, timeout_s=150):
             "passes, 4 launches each), (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch")
 
 
-def measure_single_step(torch, env, n_local, K, W, device, seed, graph_steps=0, settle_ms=0.0):
-    """One gemx_step launch per control step.  graph_steps > 0: `graph_steps` launches captured into ONE HIP graph and replayed."""
+def measure_single_step(torch, env, n_local, K, W, device, seed, graph_steps=0, settle_ms=0.0, bound=False):
+    """One gemx_step launch per control step.  graph_steps > 0: `graph_steps` launches captured into ONE HIP graph and replayed.
+    bound: through PhysicalSystem.bind_step() -- one action buffer the 'policy' writes into (here: not at all), a pre-bound FFI call."""
     ps = env.physical_system
     Ka = 256
     acts_all = make_actions(torch, ps, Ka, n_local, device, seed)
@@ -391,6 +392,19 @@ def measure_single_step(torch, env, n_local, K, W, device, seed, graph_steps=0, 
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         n = reps * S
+    elif bound:
+        step, _, _ = ps.bind_step(acts_all[0])
+        for _ in range(64):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(K):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n = K
     else:
         t0 = time.perf_counter()
         e0.record()
@@ -650,6 +664,10 @@ def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out, tele)
     out["single_step"] = {"value": n_local / host_s, "unit": "env-steps/s", "ms_per_step": host_s * 1e3, "device_ms_per_step": dev_ms,
                           "achieved_GBps": n_local * b1 / (dev_ms * 1e-3) / 1e9, "bytes_per_env_step": b1, "steps": n1,
                           "note": "one gemx_step launch per control step, eager (PhysicalSystem.simulate on a device tensor)"}
+    host_s, dev_ms, n1 = measure_single_step(torch, env1, n_local, 2000, 100, device, seed=99, settle_ms=args.settle_ms, bound=True)
+    out["single_step_bound"] = {"value": n_local / host_s, "unit": "env-steps/s", "ms_per_step": host_s * 1e3, "device_ms_per_step": dev_ms, "steps": n1,
+                                "note": "one gemx_step launch per control step through PhysicalSystem.bind_step(): the policy writes into one "
+                                        "action buffer, a call is the pre-bound FFI call and nothing else"}
     host_s, dev_ms, n1 = measure_single_step(torch, env1, n_local, 4096, 100, device, seed=99, graph_steps=64, settle_ms=args.settle_ms)
     out["single_step_graph"] = {"value": n_local / host_s, "unit": "env-steps/s", "ms_per_step": host_s * 1e3, "device_ms_per_step": dev_ms,
                                 "achieved_GBps": n_local * b1 / (dev_ms * 1e-3) / 1e9, "bytes_per_env_step": b1, "steps": n1,

@@ -422,6 +422,8 @@ struct gemx_handle {
     void *angle = nullptr;   // [n] int32 | double
     uint8_t *sw = nullptr;   // [sw_rows][n]
     int sw_rows = 1;
+    void *step_fn = nullptr;      // hipFunction_t of this handle's step_kernel instantiation (resolved at the first gemx_step)
+    bool step_fn_failed = false;
     void *linmap_dev = nullptr;  // one-step maps of the electrical subsystem (constant-speed loads), R[4][lin_count]: Phi(tau) | D(t_il), D(tau - t_il), D(tau) (linmap_kernel)
     int linmap_state = 0;        // 0: not built yet, 1: built and enabled, -1: not applicable
     void *rinit_dev = nullptr;  // InitDev (random initial states)

@@ -1842,6 +1842,38 @@ def test_rccl_gather_of_real_rollout_outputs_in_a_world_of_one():
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
+def test_bind_step_is_simulate_without_the_argument_handling():
+    """PhysicalSystem.bind_step(action_buffer): the closed loop's pre-bound FFI call.  Same launches as simulate() -- bit-identical
+    observations and done flags, step counter advanced, the internal observation tensor returned -- and it refuses a buffer the kernel
+    could not read as it is."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    n, K = 192, 40
+    g = torch.Generator(device="cuda").manual_seed(2)
+    acts = torch.randint(0, 8, (K, n), device="cuda", generator=g, dtype=torch.uint8)
+    e1 = ga.make("Finite-CC-PMSM-v0", n_envs=n, ode_solver=ga.RK4Solver(), tau=1e-4)
+    e2 = ga.make("Finite-CC-PMSM-v0", n_envs=n, ode_solver=ga.RK4Solver(), tau=1e-4)
+    e1.reset()
+    e2.reset()
+    p1, p2 = e1.physical_system, e2.physical_system
+    buf = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    step, obs, done = p2.bind_step(buf)
+    for k in range(K):
+        o1 = p1.simulate(acts[k])
+        buf.copy_(acts[k])
+        o2 = step()
+        assert o2 is obs and torch.equal(o1, o2) and torch.equal(p1._done, done), k
+    assert p2.k == p1.k == K
+    with pytest.raises(ValueError):
+        p2.bind_step(torch.zeros(n, dtype=torch.float32, device="cuda"))
+    with pytest.raises(ValueError):
+        p2.bind_step(torch.zeros(2 * n, dtype=torch.uint8, device="cuda")[::2])
+    e1.close()
+    e2.close()
+
+
 _DCS_WATCHDOG = r'''
 import sys
 sys.path.insert(0, %r)
