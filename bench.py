@@ -539,7 +539,7 @@ def worker(args, rank, world, local_rank, backend):
     t = median_of(reps)
     kernel_desc = env.physical_system.last_launch()
     config5 = None
-    if args.workload == "pmsm" and world == 8 and args.envs_per_gpu is None:
+    if args.workload == "pmsm" and args.envs_per_gpu is None and (args.config5 == "on" or (args.config5 == "auto" and world == 8)):
         env_s = make_env(ga, w, 32768, dev_index)
         ts = measure(torch, dist, env_s, 32768, K, W, spl, device, world, seed=1234 + rank, settle_ms=S)
         env_s.close()
@@ -761,6 +761,8 @@ def main():
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps launches each; the median is reported, min / max beside it")
     ap.add_argument("--sustain-s", type=float, default=1.0, help="length of the sustained legs (back-to-back launches, clocks / power sampled)")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child runs (N = 1 only)")
+    ap.add_argument("--config5", choices=["auto", "on", "off"], default="auto",
+                    help="also measure BASELINE config 5's shard (32768 envs per GPU) on every rank and report it as `config5` (auto: at --gpus 8)")
     ap.add_argument("--dist-timeout", type=float, default=300.0, help="torch.distributed timeout in seconds (rendezvous, barriers, collectives)")
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0 or args.steps_per_launch < 2 or args.settle_ms < 0:
