@@ -578,7 +578,7 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         if (hipMemcpy(h->rinit_dev, &I, sizeof(I), hipMemcpyHostToDevice) != hipSuccess || hipMemset(h->rcnt, 0, sizeof(uint32_t) * (size_t)h->n) != hipSuccess)
             return cleanup(fail(GEMX_ERR_DEVICE, "hipMemcpy failed"));
     }
-    // three maps (whole step, the two dead-time segments) of <= 32 coefficients each
+    // four maps (whole step; the two dead-time segments and the whole step again in the D form: linmap_kernel) of <= 32 coefficients each
     if (hipMalloc(&h->linmap_dev, sizeof(double) * 3 * 64) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(linmap) failed"));
     if (hipMalloc((void **)&h->err, 4096) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(err) failed"));
     if (hipMalloc((void **)&h->fifo_phase, 64) != hipSuccess || hipMemset(h->fifo_phase, 0, 64) != hipSuccess)

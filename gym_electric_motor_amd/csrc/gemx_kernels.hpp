@@ -328,6 +328,8 @@ __device__ __forceinline__ R dp5_adaptive(const DevParams<R> &P, R (&z)[NZ], R h
     return integral;
 }
 
+// form of a one-step map (linmap_kernel): Phi (x1 = Phi x0 + S g) for the DC machines' whole-step map, D = Phi - I elsewhere
+template <int SYS, int SEG> constexpr bool lin_phi_form() { return SEG == 0 && !SysTraits<SYS>::HAS_ANGLE; }
 // ------------------------------------------------------------------------------------------------
 // integrate one segment of length h with `nsteps` sub-steps (EulerSolver(nsteps), solvers.py:103-122).
 // y = [omega, motor states].  Returns the angle increment  pole * int(omega dt)  of the scheme.
@@ -337,9 +339,9 @@ __device__ __forceinline__ R dp5_adaptive(const DevParams<R> &P, R (&z)[NZ], R h
 // x1 = Phi x0 + S g with Phi = R(hA), S = h (R(hA) - I)(hA)^-1 (R = the scheme's stability polynomial).  P.lin holds Phi and S as
 // linmap_kernel obtained them by pushing unit vectors through rk_step itself; a step is then NM*(NM+NG) FMAs instead of 4 (RK4) or
 // 6 (DP5) right-hand sides plus stage combinations.  Same polynomial, so same result up to rounding.
-// SEG (LIN only): which of the handle's three maps steps this segment -- 0: the whole control step tau; with converter dead time a step
-// may be cut at the switching instant (converters.py:302-310): 1 = FIRST segment, of length t_il in the lanes with a switching leg (`two`)
-// and tau in the others (per-lane select of the coefficients), 2 = the rest, tau - t_il.  linmap_kernel builds all three.
+// SEG (LIN only): which of the handle's maps steps this segment (linmap_kernel builds four) -- 0: the whole control step tau; with
+// converter dead time a step may be cut at the switching instant (converters.py:302-310): 1 = FIRST segment, of length t_il in the lanes
+// with a switching leg (`two`) and tau in the others (per-lane select of the coefficients), 2 = the rest, tau - t_il.
 template <int SYS, int LOAD, int SOLVER, class R, bool NS1 = false, bool LIN = false, int SEG = 0>
 __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<SYS>::ND], const R (&u)[MAX_U], R h, const R *linr = nullptr, bool two = false) {
     using E = Elec<SYS, R>;
@@ -385,12 +387,20 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
             R xn[NM];
 #pragma unroll
             for (int r = 0; r < NM; ++r) {
-                R acc = L[NM * NM + r * NG] * g[0];
+                // Phi form: S g + Phi x.  D form, whole step (the three-phase machines, the headline): x + S g + D x with x as the FIRST
+                // addend -- the same instruction count as the Phi form (the leading multiply becomes a fused multiply-add), every
+                // partial sum rounded at |x|'s scale, unbiased.  D form, dead-time segments: the small terms first, then x.
+                // (x first for the synchronous and squirrel-cage machines: 3.2e-6 / 4.4e-6 against their recorded runs; the EESM and the
+                // DFIM, whose five- and four-state maps have more partial sums to round and whose steps are 150+ instructions anyway, add x
+                // LAST like the dead-time segments: one rounding at |x|'s scale)
+                constexpr bool X_FIRST = SEG == 0 && (SYS == GEMX_SYS_SYNC || SYS == GEMX_SYS_SCIM);
+                constexpr bool X_LAST = !lin_phi_form<SYS, SEG>() && !X_FIRST;
+                R acc = X_FIRST ? fma(L[NM * NM + r * NG], g[0], x[r]) : L[NM * NM + r * NG] * g[0];
 #pragma unroll
                 for (int i = 1; i < NG; ++i) acc += L[NM * NM + r * NG + i] * g[i];
 #pragma unroll
                 for (int c = 0; c < NM; ++c) acc += L[r * NM + c] * x[c];
-                xn[r] = SEG != 0 ? x[r] + acc : acc;  // (dead-time maps hold D = Phi - I)
+                xn[r] = X_LAST ? x[r] + acc : acc;
             }
 #pragma unroll
             for (int r = 0; r < NM; ++r) x[r] = xn[r];
@@ -1255,7 +1265,8 @@ template <int SYS, int LOAD, int SOLVER, bool IL, class R> __device__ __forceinl
 }
 // the map's NM * (NM + NG) coefficients into registers, once per kernel (see integrate<..., LIN>)
 template <int SYS, class R> constexpr int lin_count() { return Elec<SYS, R>::NM * (Elec<SYS, R>::NM + Elec<SYS, R>::NG); }
-// registers of a kernel instantiation's preloaded coefficients: one map, or the three segment maps of the dead-time (IL) instantiations
+// registers of a kernel instantiation's preloaded coefficients: one map (tau), or the three maps of the dead-time (IL) instantiations
+// (t_il, tau - t_il, tau: maps 1..3 of linmap_kernel)
 template <int SYS, class R, bool IL> constexpr int lin_regs() { return lin_count<SYS, R>() * (IL ? 3 : 1); }
 template <int SYS, class R, int NR> __device__ __forceinline__ void lin_preload(const DevParams<R> &P, bool lin_ok, R (&c)[NR]) {
     constexpr int OFF = NR > lin_count<SYS, R>() ? lin_count<SYS, R>() : 0;  // the dead-time instantiations take maps 1..3 (linmap_kernel)
@@ -1268,10 +1279,15 @@ template <int SYS, int SOLVER, class R> __global__ void linmap_kernel(DevParams<
     // 1 + D carries D to an absolute 6e-8 only -- a relative 6e-8 / (h A) error of every decay rate, SYSTEMATIC (the same coefficient
     // every step): 1e-3 for the 1 us dead-time segment of a PMSM, which turned currents near zero to the wrong sign and with them a
     // freewheeling leg's voltage (r03m: u_a off by 2.0 normalised with nsteps = 8).  So: rk_step in double, and
-    //   map 0 (whole step tau, the instantiations without dead time): Phi and S, rounded once (h A ~ 5e-3 ... 0.1 there: 1e-5 at worst);
-    //   maps 1, 2, 3 (t_il, tau - t_il, tau: the dead-time instantiations): D = Phi - I and S -- the step is x + (D x + S g).
+    //   every map holds D = Phi - I and S, and the step is x + D x + S g -- except map 0 (whole step tau, no dead time) of the DC machines,
+    //   which keeps Phi: their h A is 0.01 ... 0.1 (relative error of the decay <= 6e-6) and dc_stream_kernel's split of the step into a
+    //   state-independent input term and ONE fused multiply-add on the recurrence needs that form.  The three-phase machines' whole-step
+    //   map in the Phi form cost a factor 5-10 of accuracy against the stage-by-stage solver on every recorded run (DFIM 9.8e-5 against
+    //   9.6e-6, EESM 6.4e-5 / 5.3e-6, PMSM at tau = 1e-5 8.1e-6 / 1.1e-6: tools/probe_map_bias.py, profiles/r03p_map_bias.md).
+    //   maps: 0 tau | 1 t_il | 2 tau - t_il | 3 tau (1..3: the dead-time instantiations' registers)
     using E = Elec<SYS, double>;
     constexpr int NM = E::NM, NG = E::NG, NC = NM * (NM + NG);
+    constexpr bool PHI_FORM0 = lin_phi_form<SYS, 0>();
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double u0[MAX_U] = {0.0, 0.0, 0.0, 0.0};
     double zg[NG];
@@ -1286,7 +1302,7 @@ template <int SYS, int SOLVER, class R> __global__ void linmap_kernel(DevParams<
             for (int i = 0; i < NM; ++i) x[i] = i == j ? 1.0 : 0.0;
             auto rhs = [&](const double (&xx)[NM], double (&dx)[NM]) { E::f(P, pre0, xx, dx); };
             rk_step<SOLVER, NM, double>(x, hs, rhs);
-            for (int r = 0; r < NM; ++r) o[r * NM + j] = (R)(k == 0 ? x[r] : x[r] - (r == j ? 1.0 : 0.0));
+            for (int r = 0; r < NM; ++r) o[r * NM + j] = (R)((k == 0 && PHI_FORM0) ? x[r] : x[r] - (r == j ? 1.0 : 0.0));
         }
         for (int i = 0; i < NG; ++i) {
             double gi[NG], x[NM];
