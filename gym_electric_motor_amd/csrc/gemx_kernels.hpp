@@ -120,7 +120,10 @@ template <class R> struct Elec<GEMX_SYS_SYNC, R> {  // permanent_magnet_synchron
     static constexpr int NM = 2;
     struct Pre { R bd, bq, wdq, wqd; };
     static __device__ __forceinline__ Pre prep(const DevParams<R> &P, R w, const R (&u)[MAX_U]) {
-        return Pre{P.m[1] * u[0], P.m[3] * w + P.m[5] * u[1], P.m[2] * w, P.m[6] * w};
+        // (the back-EMF term as a product of its own: behind a constant-speed load it is loop-invariant and leaves the step -- written
+        // m3 w + m5 u_q the compiler fuses it the other way round, a multiply, a fused multiply-add and a register copy of omega per step)
+        const R bw = P.m[3] * w;
+        return Pre{P.m[1] * u[0], fma(P.m[5], u[1], bw), P.m[2] * w, P.m[6] * w};
     }
     static __device__ __forceinline__ void f(const DevParams<R> &P, const Pre &p, const R (&x)[2], R (&dx)[2]) {
         dx[0] = p.bd + P.m[0] * x[0] + p.wdq * x[1];
@@ -826,8 +829,10 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     }
     static __device__ __forceinline__ void action_entry(const DevParams<R> &P, uint32_t dact, R (&e)[8]) {
         const R zero[MAX_ACT] = {R(0), R(0), R(0), R(0), R(0), R(0)};
-        b6_voltages<CONV, false, R>(P, zero, dact, 0u, R(0), R(0), R(0), e[0], e[1], e[2]);
-        t23(e[0], e[1], e[2], e[3], e[4]);
+        // entry = [u_alpha, u_beta | u_a, u_b, u_c]: the pair the integrator needs first, 8-byte aligned (ONE LDS read per step where the
+        // hand-off row is compact and u_abc is looked up by the output waves: advance_pipe_kernel, COMPACT_K)
+        b6_voltages<CONV, false, R>(P, zero, dact, 0u, R(0), R(0), R(0), e[2], e[3], e[4]);
+        t23(e[2], e[3], e[4], e[0], e[1]);
         e[5] = e[6] = e[7] = R(0);
     }
     template <bool NS1 = false, bool LIN = false, bool TAB = false>
@@ -851,7 +856,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             }
             R ual, ube;
             if (TAB) {  // this action's table entry (action_entry)
-                ua = tab[0]; ub = tab[1]; uc = tab[2]; ual = tab[3]; ube = tab[4];
+                ual = tab[0]; ube = tab[1]; ua = tab[2]; ub = tab[3]; uc = tab[4];
             } else {
                 b6_voltages<CONV, IL, R>(P, act, dact, legs, ia, ib, ic, ua, ub, uc);
                 t23(ua, ub, uc, ual, ube);
@@ -2125,9 +2130,18 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
     constexpr int ACTB_BYTES = PIPE_ACT_BUFS * ((D + 3) / 4 * 4) * BLOCK * (DISCRETE ? 1 : NACT * (int)sizeof(R));
     R *refb = reinterpret_cast<R *>(actb + ACTB_BYTES);
     const int n_ref = a.rw != nullptr ? a.rh.n_ref : 0;
-    // per-action voltage table [NACTIONS][8] R of steppers that have one (ST::NVT > 0), read by the integrator wave only
+    // per-action voltage table [NACTIONS][8] R of steppers that have one (ST::NVT > 0): written by the integrator wave before its first block, read by it and
+    // (COMPACT rows, below) by the output waves
     constexpr bool USE_TAB = ST::NVT > 0 && DISCRETE && !FULL;  // (FULL: the supply voltage may differ per lane; the table is built from the uniform one)
     R *vtab = refb + 3 * (size_t)D * BLOCK * n_ref;
+    // COMPACT hand-off rows (synchronous machines behind a finite converter and a constant-speed load: the headline): the integrator's
+    // time per step is dominated by its LDS instructions (~25 cycles of issue apiece against ~5 for a VALU instruction: six of them were
+    // 150 of the step's 320 cycles), so the blocks that run on the voltage table and the one-step map hand over EIGHT values instead of
+    // twelve -- [i_sd, i_sq, done << 8 | action, eps | sin, cos, u_sd, u_sq], two 16-byte writes instead of three -- and read only
+    // u_alpha, u_beta of the action's table entry: omega is the launch constant init[0] in those blocks, and u_a, u_b, u_c are the
+    // table entry of the action, which the output waves look up themselves.  The format of block b is published in the padding of table
+    // entry 0 (vtab[6 + (b & 1)]) before the block's barrier; every other copy of the step keeps the full row.
+    constexpr bool COMPACT_K = USE_TAB && SYS == GEMX_SYS_SYNC && linable<SYS, LOAD, SOLVER, IL, R>() && ST::NVT <= 5;
     auto steps_of = [&](int b) { return (K - b * D) < D ? (K - b * D) : D; };
 
     // Action staging: global memory -> LDS DIRECTLY (`global_load_lds_dword`: each lane's dword lands at M0 + 4 * lane, no VGPR
@@ -2184,6 +2198,13 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             if (conv_sw_bytes<CONV>() == 2) sw |= (uint32_t)a.sw[N + env] << 8;
         }
         const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
+        // the reset values in VGPRs of their own, opaque to the optimiser: as kernel arguments (SGPRs) they cannot be the VGPR operand
+        // v_cndmask wants, and the compiler re-creates them with a v_mov per select and step (three of the headline step's 44 instructions)
+        R init_v[ND];
+#pragma unroll
+        for (int j = 0; j < ND; ++j) { init_v[j] = P.init[j]; asm volatile("" : "+v"(init_v[j])); }
+        AngT init_ang_v = init_ang;
+        asm volatile("" : "+v"(init_ang_v));
         R sup[2] = {P.u_sup, R(0)};  // RCVoltageSupply: capacitor voltage, time since the supply's last update (FULL)
         uint32_t rcount = 0;         // random initialisers: resets of this env so far (FULL)
         if constexpr (FULL) {
@@ -2339,24 +2360,35 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             // compare mask: VALU compare -> SALU and -> VALU select sat twice on every step's dependency chain; probe: -3 % integrator cycles)
             const R viol = ST::state_violation(P, y, ho);
             const bool done = viol > thr_done;
-#pragma unroll
-            for (int j = 0; j < ND; ++j) row[ST::row_slot(j)] = y[j];
-            if (HAS_ANGLE) {
-                R bits;
+            constexpr bool COMPACT_ROW = COMPACT_K && TAB;  // (the table-driven copies: modes 0 and 2)
+            if constexpr (COMPACT_ROW) {
+                // Stepper<SYNC>::row_slot: i_sd -> 0, i_sq -> 1, (omega -> 2), eps -> 3 | sin, cos -> 4, 5, u_sd, u_sq -> 6, 7
+                const uint32_t pk = (done ? 0x100u : 0u) | dact;
+                R pkf, bits;
+                memcpy(&pkf, &pk, sizeof(R));
                 memcpy(&bits, &ang, sizeof(R));
-                row[ST::row_slot(ND)] = bits;
-            }
+                row[0] = y[1]; row[1] = y[2]; row[2] = pkf; row[3] = bits;
+                row[4] = ho[0]; row[5] = ho[1]; row[6] = ho[5]; row[7] = ho[6];
+            } else {
 #pragma unroll
-            for (int j = 0; j < NH; ++j) row[ST::row_slot(ND + (HAS_ANGLE ? 1 : 0) + j)] = ho[j];
-            row[ST::row_slot(NDONE)] = done ? R(1) : R(0);
-            if constexpr (FULL) row[ST::row_slot(NDONE + 1)] = usup_lane;
+                for (int j = 0; j < ND; ++j) row[ST::row_slot(j)] = y[j];
+                if (HAS_ANGLE) {
+                    R bits;
+                    memcpy(&bits, &ang, sizeof(R));
+                    row[ST::row_slot(ND)] = bits;
+                }
+#pragma unroll
+                for (int j = 0; j < NH; ++j) row[ST::row_slot(ND + (HAS_ANGLE ? 1 : 0) + j)] = ho[j];
+                row[ST::row_slot(NDONE)] = done ? R(1) : R(0);
+                if constexpr (FULL) row[ST::row_slot(NDONE + 1)] = usup_lane;
+            }
             const bool rs = viol > thr_reset;  // `if terminated: env.reset()`; switching state survives
             // every copy of the step but the FIFO one runs only while the one-step map is valid for this wave (`lin_ok`), i.e. while every
             // lane's omega IS init[0] and stays so: putting it back is a no-op there
             constexpr bool OMEGA_FIXED = LINABLE && MODE != 1;
 #pragma unroll
-            for (int j = OMEGA_FIXED ? 1 : 0; j < ND; ++j) y[j] = rs ? P.init[j] : y[j];
-            ang = rs ? init_ang : ang;
+            for (int j = OMEGA_FIXED ? 1 : 0; j < ND; ++j) y[j] = rs ? init_v[j] : y[j];
+            ang = rs ? init_ang_v : ang;
             if constexpr (FULL) {
                 if (rs && P.init_kind) draw_initial_state_cnt<SYS, R>(a.rinit, env, rcount, y, ang);  // (rare: exec-masked, skipped wave-wide)
                 sup[0] = rs ? P.u_sup : sup[0];  // RCVoltageSupply.reset: the capacitor is loaded again, the supply's clock restarts
@@ -2452,6 +2484,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                             const bool queued = since >= delay_u;  // else: the refilled (zero) reset action
 #pragma unroll
                             for (int j = 0; j < ST::NVT; ++j) ec[j] = queued ? ec[j] : e0[j];
+                            if constexpr (COMPACT_K) dc = queued ? dc : 0u;  // (compact rows carry the action the converter saw)
                         }
                         one_step(Mode{}, ac, dc, hb + (size_t)s * BLOCK * NHT, ec);
                     }
@@ -2472,9 +2505,12 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                     }
                 }
             };
+            bool compact_blk = false;  // this block's rows are COMPACT (see COMPACT_K)
             if (sb == D && P.delay == 0 && (!LINABLE || lin_ok)) {
                 run_block(std::false_type{});
+                compact_blk = COMPACT_K;
             } else if (CAN_DELAY && delayed) {
+                compact_blk = COMPACT_K;
                 if constexpr (CAN_DELAY) {
                     if (sb == D) {
                         run_block(std::true_type{});
@@ -2560,6 +2596,9 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                     read_action(b, s + 1 < sb ? s + 1 : s, an, dn);
                     one_step(std::integral_constant<int, 1>{}, ac, dc, hb + (size_t)s * BLOCK * NHT, nullptr);
                 }
+            }
+            if constexpr (COMPACT_K) {
+                if (tid == 0) vtab[6 + (b & 1)] = compact_blk ? R(1) : R(0);
             }
 #ifdef GEMX_TIMING
             t1 = clock64();
@@ -2676,18 +2715,30 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
     } else {
         // ------------------------------------------------------------------ output + stores
         const bool aos = P.obs_layout == GEMX_OBS_AOS;
-        auto one_row = [&](const R (&row)[NHT], int rs) {
+        auto one_row = [&](auto compact_tag, const R (&row)[NHT], int rs) {
+            constexpr bool COMPACT = decltype(compact_tag)::value;
             R y[ND], ho[NH], obs[NOUT];
-#pragma unroll
-            for (int j = 0; j < ND; ++j) y[j] = row[ST::row_slot(j)];
             AngT ang = AngT(0);
-            if (HAS_ANGLE) {
-                const R bits = row[ST::row_slot(ND)];
-                memcpy(&ang, &bits, sizeof(R));
-            }
+            R dn;
+            if constexpr (COMPACT) {  // (see COMPACT_K: eight values; omega is the launch constant, u_abc the action's table entry)
+                uint32_t pk;
+                memcpy(&pk, &row[2], sizeof(R));
+                memcpy(&ang, &row[3], sizeof(R));
+                const R *e = vtab + (size_t)(pk & 0xFFu) * 8;
+                y[0] = P.init[0]; y[1] = row[0]; y[2] = row[1];
+                ho[0] = row[4]; ho[1] = row[5]; ho[2] = e[2]; ho[3] = e[3]; ho[4] = e[4]; ho[5] = row[6]; ho[6] = row[7];  // (entry: Stepper<SYNC>::action_entry)
+                dn = (pk & 0x100u) ? R(1) : R(0);
+            } else {
 #pragma unroll
-            for (int j = 0; j < NH; ++j) ho[j] = row[ST::row_slot(ND + (HAS_ANGLE ? 1 : 0) + j)];
-            const R dn = row[ST::row_slot(NDONE)];
+                for (int j = 0; j < ND; ++j) y[j] = row[ST::row_slot(j)];
+                if (HAS_ANGLE) {
+                    const R bits = row[ST::row_slot(ND)];
+                    memcpy(&ang, &bits, sizeof(R));
+                }
+#pragma unroll
+                for (int j = 0; j < NH; ++j) ho[j] = row[ST::row_slot(ND + (HAS_ANGLE ? 1 : 0) + j)];
+                dn = row[ST::row_slot(NDONE)];
+            }
             ST::observe(P, y, ang, ho, obs);
             if constexpr (FULL) obs[NOUT - 1] = row[ST::row_slot(NDONE + 1)] * P.inv_lim[NOUT - 1];  // u_sup column: this lane's supply voltage
             if (aos) {
@@ -2699,9 +2750,9 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             }
             donebuf[rs * BLOCK + tid] = dn != R(0) ? 1 : 0;
         };
-        auto load_row = [&](const R *src, R (&row)[NHT]) {
+        auto load_row = [&](auto compact_tag, const R *src, R (&row)[NHT]) {
 #pragma unroll
-            for (int j = 0; j < NHT; ++j) row[j] = src[j];
+            for (int j = 0; j < (decltype(compact_tag)::value ? 8 : NHT); ++j) row[j] = src[j];
         };
         // output wave `ow` of OW owns rows [ow*RPW, (ow+1)*RPW) of every hand-off block: it turns them into
         // observation rows in ITS part of the ring and flushes them itself -- the output waves never synchronise with
@@ -2723,21 +2774,30 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             if (nr <= 0) return;
             const R *hb = hand + (size_t)(pb & 1) * D * BLOCK * NHT + (size_t)r0 * BLOCK * NHT + (size_t)tid * NHT;
             R rows[2][NHT];
-            load_row(hb, rows[0]);
-            if (nr == RPW) {
+            auto convert_rows = [&](auto compact_tag) {
+                load_row(compact_tag, hb, rows[0]);
+                if (nr == RPW) {
 #pragma unroll
-                for (int s = 0; s < RPW; ++s) {  // the next row's LDS reads are issued BEFORE this row's ring writes
-                    if (s + 1 < RPW) load_row(hb + (size_t)(s + 1) * BLOCK * NHT, rows[(s + 1) & 1]);
-                    one_row(rows[s & 1], r0 + s);
-                }
-            } else {
+                    for (int s = 0; s < RPW; ++s) {  // the next row's LDS reads are issued BEFORE this row's ring writes
+                        if (s + 1 < RPW) load_row(compact_tag, hb + (size_t)(s + 1) * BLOCK * NHT, rows[(s + 1) & 1]);
+                        one_row(compact_tag, rows[s & 1], r0 + s);
+                    }
+                } else {
 #pragma unroll
-                for (int s = 0; s < RPW; ++s) {
-                    if (s < nr) {
-                        if (s + 1 < nr) load_row(hb + (size_t)(s + 1) * BLOCK * NHT, rows[(s + 1) & 1]);
-                        one_row(rows[s & 1], r0 + s);
+                    for (int s = 0; s < RPW; ++s) {
+                        if (s < nr) {
+                            if (s + 1 < nr) load_row(compact_tag, hb + (size_t)(s + 1) * BLOCK * NHT, rows[(s + 1) & 1]);
+                            one_row(compact_tag, rows[s & 1], r0 + s);
+                        }
                     }
                 }
+            };
+            if constexpr (COMPACT_K) {
+                // (the block's format, published by the integrator before the barrier that handed the block over)
+                if (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, vtab[6 + (pb & 1)])) != 0) convert_rows(std::true_type{});
+                else convert_rows(std::false_type{});
+            } else {
+                convert_rows(std::false_type{});
             }
 #ifdef GEMX_TIMING
             const unsigned long long f0 = clock64();
@@ -3524,7 +3584,12 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         int D = 0, OW = 0, shape = 0;
         if (smem_of(PIPE_D) <= h->lds_max && blocks <= resident(PIPE_D, PIPE_OUT_WAVES)) {
             D = PIPE_D; OW = PIPE_OUT_WAVES; shape = 0;
-            if (h->cur_reward != nullptr) { OW = PIPE_OUT_WAVES_RW; shape = 3; }  // (eight waves: still one workgroup per CU)
+            // six output waves (eight waves in all: still one workgroup per CU) where the output side carries more than three waves keep up
+            // with: the fused reward, and the COMPACT hand-off rows of the synchronous machines behind a finite converter (advance_pipe_kernel,
+            // COMPACT_K: the integrator is 8 % faster per block there, 3555 against 3875 cycles, and the output waves look the phase voltages
+            // up themselves -- three of them need 4100 cycles per block, six 2500; PMSM headline 147.6 -> 140 us per launch)
+            constexpr bool COMPACT_L = SYS == GEMX_SYS_SYNC && ST::NVT > 0 && ConvTraits<CONV>::DISCRETE && linable<SYS, LOAD, SOLVER, IL, R>();
+            if (h->cur_reward != nullptr || (COMPACT_L && h->pf.lin_on != 0)) { OW = PIPE_OUT_WAVES_RW; shape = 3; }
         }
         else if ((SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM) && smem_of(PIPE_D3) <= h->lds_max && blocks <= resident(PIPE_D3, PIPE_OUT_WAVES3) &&
                  blocks > resident(PIPE_D2, PIPE_OUT_WAVES2) && 2 * blocks <= 3 * resident(PIPE_D2, PIPE_OUT_WAVES2)) {
