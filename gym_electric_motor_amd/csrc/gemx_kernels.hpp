@@ -3582,14 +3582,25 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         // envs over all motor families (profiles/r01d_matrix.md) it is on par with or ahead of the single-wave kernel (PMSM
         // 1M envs: 100 vs 86 G env-steps/s) -- the split keeps stores fire-and-forget and the integrator free of vmcnt waits
         int D = 0, OW = 0, shape = 0;
-        if (smem_of(PIPE_D) <= h->lds_max && blocks <= resident(PIPE_D, PIPE_OUT_WAVES)) {
+        // six output waves (eight waves in all: still one workgroup per CU) where the output side carries more than three waves keep up
+        // with: the fused reward, and the COMPACT hand-off rows of the synchronous machines behind a finite converter (advance_pipe_kernel,
+        // COMPACT_K: the integrator is 8 % faster per block there, 3555 against 3875 cycles, and the output waves look the phase voltages
+        // up themselves -- three of them need 4100 cycles per block, six 2500; PMSM headline 147.6 -> 140 us per launch)
+        constexpr bool COMPACT_L = SYS == GEMX_SYS_SYNC && ST::NVT > 0 && ConvTraits<CONV>::DISCRETE && linable<SYS, LOAD, SOLVER, IL, R>();
+        const bool compact_l = COMPACT_L && h->pf.lin_on != 0 && !need_full;
+        // ... and with those rows the deep shape is ahead of <4, 2> at ANY N whose workgroups fill its rounds of one workgroup per CU: same box,
+        // PMSM finite, of the roofline at 28672 / 32768 / 49152 / 65536 / 131072 envs: 0.71 / 0.72 / 0.70 / 0.77 / 0.79 against 0.68 / 0.68 / 0.67 /
+        // 0.65 / 0.70 (profiles/r03s_shapes_compact.md); a last round less than ~85 % full loses instead (24576 envs: 0.59 against 0.65)
+        // -- and a launch too short to amortise a workgroup's ~10 us outside its block loop, which <4, 2>'s four co-resident workgroups overlap
+        // (1M envs x 100 steps: 0.53 against 0.68): K >= 400
+        bool deep_rounds = false;
+        if (compact_l && K >= 400 && smem_of(PIPE_D) <= h->lds_max) {
+            const int64_t res0 = resident(PIPE_D, PIPE_OUT_WAVES_RW), rounds = (blocks + res0 - 1) / res0;
+            deep_rounds = blocks > res0 && 100 * blocks >= 85 * rounds * res0;
+        }
+        if (smem_of(PIPE_D) <= h->lds_max && (blocks <= resident(PIPE_D, PIPE_OUT_WAVES) || deep_rounds)) {
             D = PIPE_D; OW = PIPE_OUT_WAVES; shape = 0;
-            // six output waves (eight waves in all: still one workgroup per CU) where the output side carries more than three waves keep up
-            // with: the fused reward, and the COMPACT hand-off rows of the synchronous machines behind a finite converter (advance_pipe_kernel,
-            // COMPACT_K: the integrator is 8 % faster per block there, 3555 against 3875 cycles, and the output waves look the phase voltages
-            // up themselves -- three of them need 4100 cycles per block, six 2500; PMSM headline 147.6 -> 140 us per launch)
-            constexpr bool COMPACT_L = SYS == GEMX_SYS_SYNC && ST::NVT > 0 && ConvTraits<CONV>::DISCRETE && linable<SYS, LOAD, SOLVER, IL, R>();
-            if (h->cur_reward != nullptr || (COMPACT_L && h->pf.lin_on != 0)) { OW = PIPE_OUT_WAVES_RW; shape = 3; }
+            if (h->cur_reward != nullptr || compact_l) { OW = PIPE_OUT_WAVES_RW; shape = 3; }
         }
         else if ((SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM) && smem_of(PIPE_D3) <= h->lds_max && blocks <= resident(PIPE_D3, PIPE_OUT_WAVES3) &&
                  blocks > resident(PIPE_D2, PIPE_OUT_WAVES2) && 2 * blocks <= 3 * resident(PIPE_D2, PIPE_OUT_WAVES2)) {
