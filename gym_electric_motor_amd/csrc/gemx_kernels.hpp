@@ -3594,7 +3594,9 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         // -- and a launch too short to amortise a workgroup's ~10 us outside its block loop, which <4, 2>'s four co-resident workgroups overlap
         // (1M envs x 100 steps: 0.53 against 0.68): K >= 400
         bool deep_rounds = false;
-        if (compact_l && K >= 400 && smem_of(PIPE_D) <= h->lds_max) {
+        // (not behind a DeadTimeProcessor: its delayed-read blocks are slower in the deep shape than <4, 2>'s queue: 131072 envs 0.57 against 0.69)
+        // (nor with the fused reward, whose output waves are the bound at large N either way: 131072 envs 0.56 against 0.60)
+        if (compact_l && K >= 400 && delay == 0 && h->cur_reward == nullptr && smem_of(PIPE_D) <= h->lds_max) {
             const int64_t res0 = resident(PIPE_D, PIPE_OUT_WAVES_RW), rounds = (blocks + res0 - 1) / res0;
             deep_rounds = blocks > res0 && 100 * blocks >= 85 * rounds * res0;
         }
