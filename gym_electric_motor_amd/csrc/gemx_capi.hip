@@ -541,6 +541,8 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         ev = getenv("GEMX_DC_STREAM");  // 0: never take dc_stream_kernel; 2: at any N (A/B runs and bit-identity tests); 3: also without the
                                         // host-side "omega is at its initial value" knowledge (test of the kernel's own check of that premise)
         if (ev) h->use_dc_stream = atoi(ev);
+        ev = getenv("GEMX_DCS_EPW");  // 64: dc_stream_kernel with one env per lane at every size (A/B runs; default: 32 envs per workgroup where they find a CU each)
+        if (ev) h->dcs_epw = atoi(ev);
         ev = getenv("GEMX_LINMAP");  // 0: never use the one-step map of the electrical subsystem (A/B runs)
         if (ev && atoi(ev) == 0) h->linmap_state = -1;
 

@@ -456,8 +456,9 @@ struct gemx_handle {
     int pipe_shape = -1;      // GEMX_PIPE_SHAPE=0/1/2 forces <12,3> / <4,2> / <2,2> whenever it fits (tests: every shape on small N)
     int use_step_kernel = 1;  // K = 1 launches take step_kernel (GEMX_STEP_KERNEL=0: advance_kernel, for A/B runs and bit-identity tests)
     int use_pipe = -1;        // pipelined kernel: -1 / 1 whenever eligible (default), 0 never (GEMX_PIPE=0: A/B and bit-identity tests)
+    int dcs_epw = 32;         // dc_stream_kernel: envs per workgroup where twice the workgroups still find a CU each (GEMX_DCS_EPW=64: always 64)
     int use_dc_stream = 1;    // dc_stream_kernel: 1 when eligible and N <= 64 * CUs (default), 2 at any N, 0 never (GEMX_DC_STREAM)
-    bool dcs_attr_set = false;
+    int dcs_attr_set = 0;     // bit 0 / 1: the 64- / 32-env instantiation's dynamic-LDS attribute is set
     bool omega_is_init = true;  // every env's omega equals init[0] (constant-speed loads): false between gemx_set_state and the next full reset
     bool omega_unknown = false; // a state-changing call was CAPTURED into a graph: the host cannot know when it runs -> omega_is_init stays false
 };

@@ -2936,13 +2936,22 @@ template <int SYS, int CONV> constexpr size_t dcs_smem_bytes() {
     return (size_t)dcs_depth<SYS>() * BLOCK * sizeof(float) * (2 * NM + 3 * NU + 2 * NM) +
            (size_t)dcs_out<SYS>() * 4 * BLOCK * SysTraits<SYS>::NOUT * sizeof(float) + (size_t)dcs_out<SYS>() * 4 * BLOCK;
 }
-template <int SYS, int CONV, int SOLVER, class R>
+// EPW = envs per workgroup.  64: a lane is an env.  32 (what the launcher takes: twice the workgroups, i.e. twice the CUs, for the same
+// batch): the integrator's lanes 32..63 mirror lanes 0..31, while the pre and output waves -- whose work is not a recurrence -- give their
+// upper half lanes the NEXT group of four steps of the same envs.  What bounds the 64-env form at 4096 envs is a CU's store path: ~33 cycles
+// per 1-KiB wave store, 48 of them per 32 steps = the 1600 of its 1700-cycle block period (r03h probe); with 32 envs per workgroup a
+// store instruction is still full (8 rows x 32 envs x NOUT dwords) but every CU has half of them to issue.  LDS rows stay [group][lane]: lane
+// l of double group G holds steps 4 (2 G + l / 32) .. + 3 of env l % 32, so every index below is the 64-env one with "group" read as
+// "double group" -- except the integrator's, which walks the groups in step order.
+template <int SYS, int CONV, int SOLVER, class R, int EPW = BLOCK>
 __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(const KArgs<R> a) {
+    static_assert(EPW == BLOCK || EPW == BLOCK / 2, "envs per workgroup");
+    constexpr int HALVES = BLOCK / EPW;
     constexpr int DCS_PRE = dcs_pre<SYS>(), DCS_OUT = dcs_out<SYS>(), DCS_WAVES = dcs_waves<SYS>();
     static_assert(DCS_WAVES <= 16 && dcs_worker_index(DCS_WAVES - 1) == DCS_PRE + DCS_OUT - 1, "wave roles");
     constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NM = ND - 1, NACT = ConvTraits<CONV>::NACT;
     constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
-    constexpr int D = dcs_depth<SYS>(), NGR = D / 4;  // steps, groups of four steps per block
+    constexpr int D = dcs_depth<SYS>() * HALVES, NGR = D / 4, NG2 = NGR / HALVES;  // steps, groups of four steps, (double) groups = LDS rows per block
     using ST = Stepper<SYS, CONV, GEMX_LOAD_CONST_SPEED, SOLVER, false, R>;
     using AngT = typename Angle<R>::T;
     constexpr int NU = ST::NU;
@@ -2954,16 +2963,17 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
     const int tid = threadIdx.x & (BLOCK - 1);
     // (32 envs per workgroup on twice as many CUs was tried for the output waves' sake: their time per row does not go down with the
     // active lanes of a store -- 1650 cycles per 32-step block either way -- and the exec masking around the stores cost 20 %.)
-    const int64_t N = a.N, blk0 = (int64_t)blockIdx.x * BLOCK, env = blk0 + tid;
+    const int le = tid & (EPW - 1), hf = HALVES == 2 ? tid >> 5 : 0;  // env lane, half (which group of a double group)
+    const int64_t N = a.N, blk0 = (int64_t)blockIdx.x * EPW, env = blk0 + le;
     const int K = a.K, nb = (K + D - 1) / D;
     auto steps_of = [&](int b) __attribute__((always_inline)) { return (K - b * D) < D ? (K - b * D) : D; };
     // LDS: input terms [2][NGR][64][4][NM] | voltages [3][NGR][64][4][NU] | new motor states [2][NGR][64][4][NM] | row staging [DCS_OUT][4][64][NOUT]
     // (in iteration b the integrator reads the input terms of block b while the pre waves write block b + 1's: two buffers; the voltages of
     // block b - 1 are still being read by the output waves then: three)
     R *gin = reinterpret_cast<R *>(gemx_smem);
-    R *uu = gin + 2 * (size_t)D * BLOCK * NM;
-    R *hand = uu + 3 * (size_t)D * BLOCK * NU;
-    R *stage = hand + 2 * (size_t)D * BLOCK * NM;
+    R *uu = gin + 2 * (size_t)D * EPW * NM;
+    R *hand = uu + 3 * (size_t)D * EPW * NU;
+    R *stage = hand + 2 * (size_t)D * EPW * NM;
     const R om = P.init[0];  // == omega of every env (launcher); a ConstantSpeedLoad never changes it, a reset puts it back
     const bool lin_ok = LINABLE && P.lin_on != 0;  // wave-uniform
     R linc[lin_regs<SYS, R, false>()];
@@ -3028,13 +3038,15 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
         };
         auto run_block = [&](auto lin_tag, auto zero_tag, int b) __attribute__((always_inline)) {
             const int sb = steps_of(b);
-            const R *gb = gin + ((size_t)(b & 1) * NGR * BLOCK + tid) * 4 * NM;
-            R *hb = hand + ((size_t)(b & 1) * NGR * BLOCK + tid) * 4 * NM;
+            // (group g of the block = half g % HALVES of double group g / HALVES)
+            const R *gb = gin + ((size_t)(b & 1) * NG2 * BLOCK + le) * 4 * NM;
+            R *hb = hand + ((size_t)(b & 1) * NG2 * BLOCK + le) * 4 * NM;
+            auto goff = [](int g) __attribute__((always_inline)) { return ((size_t)(g / HALVES) * BLOCK + (size_t)(g % HALVES) * EPW) * 4 * NM; };
             if (sb == D) {  // whole block: a group's input terms are read two groups ahead (a step is far shorter than an LDS round trip)
                 R in4[3][4 * NM], out4[4 * NM];
                 auto fetch = [&](int g, R (&dst)[4 * NM]) {
 #pragma unroll
-                    for (int i = 0; i < 4 * NM; ++i) dst[i] = gb[(size_t)g * BLOCK * 4 * NM + i];
+                    for (int i = 0; i < 4 * NM; ++i) dst[i] = gb[goff(g) + i];
                 };
                 fetch(0, in4[0]);
                 fetch(1, in4[1]);
@@ -3048,13 +3060,13 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
 #pragma unroll
                     for (int j = 0; j < 4; ++j) one_step(lin_tag, zero_tag, &in4[g % 3][j * NM], &out4[j * NM]);
 #pragma unroll
-                    for (int i = 0; i < 4 * NM; ++i) hb[(size_t)g * BLOCK * 4 * NM + i] = out4[i];
+                    for (int i = 0; i < 4 * NM; ++i) hb[goff(g) + i] = out4[i];
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
 #pragma nounroll
                 for (int s = 0; s < sb; ++s) {
-                    const size_t o = ((size_t)(s >> 2) * BLOCK * 4 + (s & 3)) * NM;
+                    const size_t o = goff(s >> 2) + (size_t)(s & 3) * NM;
                     R in[NM], out[NM];
 #pragma unroll
                     for (int i = 0; i < NM; ++i) in[i] = gb[o + i];
@@ -3105,8 +3117,8 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
         for (int b = 0; b <= nb; ++b) __syncthreads();
     } else if (dcs_worker_index(wave) < DCS_PRE) {
         // ------------------------------------------------------------------ pre: actions -> converter -> input term, DCS_PREFETCH blocks ahead
-        constexpr int GP = NGR / DCS_PRE, RP = 4 * GP;  // groups / rows per pre wave and block: groups j * DCS_PRE + pw
-        static_assert(NGR % DCS_PRE == 0, "groups per pre wave");
+        constexpr int GP = NG2 / DCS_PRE, RP = 4 * GP;  // (double) groups / rows per lane, pre wave and block: (double) groups j * DCS_PRE + pw
+        static_assert(NG2 % DCS_PRE == 0, "groups per pre wave");
         const int pw = dcs_worker_index(wave);
         uint32_t bad = 0;
         struct Rows { R f[RP][NACT]; uint32_t d[RP]; };
@@ -3118,13 +3130,13 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
         // size is what is left of the tensor, so rows past the end of the rollout (the last blocks' prefetch) read as 0 instead of being
         // clamped in a second copy of the loads: two copies merge in PHIs, and the copies of their registers wait for the loads just
         // issued (r03a: 48 v_mov behind an s_waitcnt vmcnt per block).
-        const int64_t abase_off = ((int64_t)(4 * pw) * N + blk0) * ABYTES;  // this workgroup's span of this wave's first row
+        const int64_t abase_off = ((int64_t)(4 * HALVES * pw) * N + blk0) * ABYTES;  // this workgroup's span of this wave's first row
         const int64_t atotal = (int64_t)K * N * ABYTES;
         uint32_t voff[RP];
 #pragma unroll
         for (int j = 0; j < RP; ++j) {
-            const int r = (j >> 2) * 4 * DCS_PRE + (j & 3);  // row within the block, relative to this wave's first row
-            voff[j] = (uint32_t)((int64_t)r * rowb) + (uint32_t)tid * (uint32_t)ABYTES;
+            const int r = ((j >> 2) * DCS_PRE * HALVES + hf) * 4 + (j & 3);  // this lane's row within the block, relative to this wave's first row
+            voff[j] = (uint32_t)((int64_t)r * rowb) + (uint32_t)le * (uint32_t)ABYTES;
         }
         auto load = [&](int bb, Rows &v) __attribute__((always_inline)) {
             const int64_t off = abase_off + (int64_t)bb * bstride;
@@ -3142,8 +3154,8 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
         };
         auto convert_t = [&](auto lin_tag, int bb, const Rows &v) __attribute__((always_inline)) {
             constexpr bool LIN = decltype(lin_tag)::value;
-            R *gb = gin + ((size_t)(bb & 1) * NGR * BLOCK + tid) * 4 * NM;
-            R *ub = uu + ((size_t)(bb % 3) * NGR * BLOCK + tid) * 4 * NU;
+            R *gb = gin + ((size_t)(bb & 1) * NG2 * BLOCK + tid) * 4 * NM;
+            R *ub = uu + ((size_t)(bb % 3) * NG2 * BLOCK + tid) * 4 * NU;
 #pragma unroll
             for (int jg = 0; jg < GP; ++jg) {
                 const int g = jg * DCS_PRE + pw;
@@ -3155,7 +3167,7 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
                     uint32_t dact = 0;
                     if (DISCRETE) {
                         dact = v.d[j];
-                        bad |= ((int64_t)bb * D + 4 * g + s4 < K) & (dact >= (uint32_t)ConvTraits<CONV>::NACTIONS);
+                        bad |= ((int64_t)bb * D + 4 * (g * HALVES + hf) + s4 < K) & (dact >= (uint32_t)ConvTraits<CONV>::NACTIONS);
                         dact &= (uint32_t)(ConvTraits<CONV>::NACTIONS - 1);
                     } else {
 #pragma unroll
@@ -3224,8 +3236,9 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
         if (bad) atomicOr(a.err, 1u);
     } else {
         // ------------------------------------------------------------------ output: observation row + done flag, one block behind
-        constexpr int GPW = NGR / DCS_OUT;  // groups per output wave and block: groups j * DCS_OUT + ow
-        static_assert(NGR % DCS_OUT == 0, "groups per output wave");
+        constexpr int GPW = NG2 / DCS_OUT;  // (double) groups per output wave and block: (double) groups j * DCS_OUT + ow
+        static_assert(NG2 % DCS_OUT == 0, "groups per output wave");
+        constexpr int RG = 4 * HALVES;     // rows of a (double) group
         const int ow = dcs_worker_index(wave) - DCS_PRE;
         struct __attribute__((packed, aligned(4))) Row { R v[NOUT]; };
         typedef float v4f_t __attribute__((ext_vector_type(4)));
@@ -3255,7 +3268,7 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
         // is bytes 16 (q % CPRW) .. + 15 of row q / CPRW (CPRW = 16 NOUT chunks per 64-env row; LDS operations of one wave complete in
         // order, so the reads need no barrier behind the writes)
         R *stg = stage + (size_t)ow * 4 * BLOCK * NOUT;
-        constexpr int CPRW = BLOCK * NOUT / 4;
+        constexpr int CPRW = EPW * NOUT / 4;
         uint32_t coff[NOUT];  // byte offset of this lane's chunk i from the (wave-uniform) address of the group's first row
 #pragma unroll
         for (int i = 0; i < NOUT; ++i) {
@@ -3274,21 +3287,21 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
             ST::observe(P, y0, AngT(0), ho0, obs0);
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                stg[((size_t)s4 * BLOCK + tid) * NOUT] = obs0[0];
-                stg[((size_t)s4 * BLOCK + tid) * NOUT + NOUT - 1] = obs0[NOUT - 1];
+                stg[((size_t)(hf * 4 + s4) * EPW + le) * NOUT] = obs0[0];
+                stg[((size_t)(hf * 4 + s4) * EPW + le) * NOUT + NOUT - 1] = obs0[NOUT - 1];
             }
             asm volatile("" ::: "memory");
         }
         const int64_t ostride = N * NOUT;
         // stores through buffer descriptors rebased per block (wave-uniform), the lane's part of the address in ONE constant 32-bit VGPR per
         // chunk, the group's in an SGPR: a store is one instruction (see the pre waves' loads)
-        const int64_t obase_off = (((int64_t)(4 * ow) * N + blk0) * NOUT) * (int64_t)sizeof(R);  // this workgroup's span of this wave's first row
-        R *obase = a.obs + ((int64_t)(4 * ow) * N + env) * NOUT;  // this lane's row of this wave's first step (tail blocks)
+        const int64_t obase_off = (((int64_t)(RG * ow) * N + blk0) * NOUT) * (int64_t)sizeof(R);  // this workgroup's span of this wave's first row
+        R *obase = a.obs + ((int64_t)(RG * ow) * N + env) * NOUT;  // this lane's row of this wave's first step (tail blocks)
         // done bytes of a group of four steps: every lane leaves its env's byte of each step in a [4][64]-byte staging area; read back as one
         // dword per lane that is bytes 4 (l % 16) .. + 3 of step l / 16 -- ONE store per group and no bit fiddling
         unsigned char *dstg = reinterpret_cast<unsigned char *>(stage + (size_t)DCS_OUT * 4 * BLOCK * NOUT) + (size_t)ow * 4 * BLOCK;
-        const int64_t dbase_off = (int64_t)(4 * ow) * N + blk0;
-        const uint32_t doff = (uint32_t)((int64_t)(tid >> 4) * N + 4 * (tid & 15));
+        const int64_t dbase_off = (int64_t)(RG * ow) * N + blk0;
+        const uint32_t doff = (uint32_t)((int64_t)((4 * tid) / EPW) * N + (4 * tid) % EPW);  // (dword `tid` of the [RG][EPW] byte staging area)
         unsigned char *optr = reinterpret_cast<unsigned char *>(a.obs) + obase_off;  // block pb's rows of this wave / workgroup (wave-uniform, advanced per block)
         unsigned char *dptr = a.done + (has_done ? dbase_off : 0);
         const int64_t ostep = (int64_t)D * ostride * (int64_t)sizeof(R), dstep = has_done ? (int64_t)D * N : 0;
@@ -3298,8 +3311,8 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
         auto process_t = [&](auto done_tag, int pb) __attribute__((always_inline)) {
             constexpr bool HAS_DONE = decltype(done_tag)::value;  // (compile-time: a wave-uniform run-time test costs two issue slots per group)
             const int sb = steps_of(pb);
-            const R *hb = hand + ((size_t)(pb & 1) * NGR * BLOCK + tid) * 4 * NM;
-            const R *ub = uu + ((size_t)(pb % 3) * NGR * BLOCK + tid) * 4 * NU;
+            const R *hb = hand + ((size_t)(pb & 1) * NG2 * BLOCK + tid) * 4 * NM;
+            const R *ub = uu + ((size_t)(pb % 3) * NG2 * BLOCK + tid) * 4 * NU;
             if (sb == D) {  // whole block: all LDS reads of this wave's groups first, then group after group without a branch
                 R xs[GPW][4 * NM], us[GPW][4 * NU];
 #pragma unroll
@@ -3316,11 +3329,12 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
                 const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)dptr, 0, HAS_DONE ? -1 : 0, 0x00020000);
 #pragma unroll
                 for (int jg = 0; jg < GPW; ++jg) {
-                    const int r0 = 4 * jg * DCS_OUT;  // first row of the group, relative to this wave's first row
+                    const int r0 = RG * jg * DCS_OUT;  // first row of the (double) group, relative to this wave's first row
 #ifdef GEMX_TIMING
                     const unsigned long long o0 = clock64();
 #endif
 #ifdef GEMX_DCS_DIRECT_ROWS
+                    static_assert(EPW == BLOCK, "A/B path of the 64-env form");
                     unsigned long long m[4];  // A/B: round 2's rows, stored straight from the lanes' registers
                     R *ob = obase + (int64_t)pb * D * ostride;  // (A/B only)
 #pragma unroll
@@ -3332,8 +3346,8 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
                         R obs[NOUT];
                         const bool dn = observe_row(&xs[jg][s4 * NM], &us[jg][s4 * NU], obs);
 #pragma unroll
-                        for (int i = 1; i < NOUT - 1; ++i) stg[((size_t)s4 * BLOCK + tid) * NOUT + i] = obs[i];
-                        if (HAS_DONE) dstg[s4 * BLOCK + tid] = dn ? 1 : 0;
+                        for (int i = 1; i < NOUT - 1; ++i) stg[((size_t)(hf * 4 + s4) * EPW + le) * NOUT + i] = obs[i];
+                        if (HAS_DONE) dstg[(hf * 4 + s4) * EPW + le] = dn ? 1 : 0;
                     }
                     // (compiler-level fences: the rows are written as floats / bytes and read back as float4 / dwords -- distinct types to
                     // the alias analysis, which would otherwise keep the PREVIOUS group's chunks in registers or move the next group's
@@ -3375,7 +3389,7 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
                     const int g = jg * DCS_OUT + ow;
 #pragma nounroll
                     for (int s4 = 0; s4 < 4; ++s4) {
-                        const int r = 4 * g + s4;  // row within the block
+                        const int r = 4 * (g * HALVES + hf) + s4;  // this lane's row within the block
                         if (r < sb) {
                             R xr[NM], ur[NU];
 #pragma unroll
@@ -3536,7 +3550,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         bool dcs_ok = pipe_ok && h->use_dc_stream != 0 && !need_full && delay == 0 && !(h->cfg.solver_flags & GEMX_SOLVER_ADAPTIVE) && h->cur_reward == nullptr && (h->omega_is_init || h->use_dc_stream >= 3) &&
                       params_of<R>(h).obs_layout == GEMX_OBS_AOS && params_of<R>(h).t_il == R(0) &&
                       (h->use_dc_stream > 1 || 2 * blocks <= (int64_t)h->n_cu) && dcs_smem_bytes<SYS, CONV>() <= h->lds_max &&
-                      (int64_t)h->n * h->nout * 16 < ((int64_t)1 << 32);  // (32-bit lane offsets across the four rows of a group)
+                      (int64_t)h->n * h->nout * 32 < ((int64_t)1 << 32);  // (32-bit lane offsets across the four / eight rows of a (double) group)
         if (dcs_ok) {
             // never into a graph: `omega_is_init` is what the host knows NOW, a captured launch runs later, possibly behind a gemx_set_state.
             // The pipelined kernel decides on the device (lin_usable), so it is what a graph gets.
@@ -3545,19 +3559,26 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             dcs_ok = capturing == hipStreamCaptureStatusNone;
         }
         if (dcs_ok) {
-            auto dkern = dc_stream_kernel<SYS, CONV, SOLVER, R>;
-            if (!h->dcs_attr_set) {
+            // 32 envs per workgroup -- twice the workgroups and CUs for the same batch, half the store instructions per CU -- whenever they
+            // are few enough (GEMX_DCS_EPW=64: the 64-env form at every size)
+            // (same box, PermExDc, Euler, us per 1000 steps: 4096 envs 28.6 -> 19.7, 1024 envs 28.9 -> 19.0; at 8192 envs -- 256 workgroups of 32, every
+            // CU busy -- 33.0 against 31.2: so up to one workgroup per TWO CUs)
+            const bool epw32 = h->dcs_epw != 64 && 4 * blocks <= (int64_t)h->n_cu;
+            auto dkern = epw32 ? dc_stream_kernel<SYS, CONV, SOLVER, R, BLOCK / 2> : dc_stream_kernel<SYS, CONV, SOLVER, R, BLOCK>;
+            if (!(h->dcs_attr_set & (epw32 ? 2 : 1))) {
                 GEMX_HIP_TRY(hipFuncSetAttribute((const void *)dkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max));
-                h->dcs_attr_set = true;
+                h->dcs_attr_set |= epw32 ? 2 : 1;
             }
-            a.S = dcs_depth<SYS>();
-            a.D = dcs_depth<SYS>();
+            const int dd = dcs_depth<SYS>() * (epw32 ? 2 : 1);
+            a.S = dd;
+            a.D = dd;
             // (more than half the LDS: ONE workgroup per CU, else the dispatcher stacks two on one CU while others idle and their
             // integrator waves share issue slots -- 41 -> 88 us per 1000 steps between 8192 and 12288 envs)
             const size_t dneed = dcs_smem_bytes<SYS, CONV>(), dhalf = (size_t)h->lds_max / 2 + 1024, dsmem = dneed > dhalf ? dneed : dhalf;
-            hipLaunchKernelGGL(dkern, dim3((unsigned)blocks), dim3(dcs_waves<SYS>() * BLOCK), dsmem, st, a);
+            const long long dblocks = epw32 ? 2 * blocks : blocks;
+            hipLaunchKernelGGL(dkern, dim3((unsigned)dblocks), dim3(dcs_waves<SYS>() * BLOCK), dsmem, st, a);
             GEMX_HIP_TRY(hipGetLastError());
-            h->ll = {3, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), dcs_depth<SYS>(), dcs_waves<SYS>() * BLOCK, K, dcs_depth<SYS>(), (long long)blocks, dsmem};
+            h->ll = {3, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), dd, dcs_waves<SYS>() * BLOCK, K, dd, dblocks, dsmem};
             return GEMX_OK;
         }
     }
