@@ -2890,10 +2890,12 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
 //     advanced per block): stored straight from the lanes' registers a row is 64 pieces of 20-28 bytes that straddle 16-byte boundaries,
 //     ~50 cycles per row in the CU's store path against 20 for aligned quads.  The constant columns of a DC machine's row (omega, u_sup)
 //     are put into the staging rows once per launch.  The done bytes of four steps go through a byte staging area and leave in ONE store.
-// LDS rows are [group of 4 steps][lane][step in group][value]: 16 bytes per lane and value.  One s_barrier per block of D = 32 steps.
-// What bounds it now (profiles/r03h_dcs_probe.txt): the output waves (1200-1600 cycles of a 1700-cycle block period), themselves
-// waiting on the LDS: a block moves ~130 KB through it (hand-offs 48 KB, row staging 24 KB in + 40 KB out, done bytes), ~1000 cycles
-// at 128 B/clk.
+// LDS rows are [group of 4 steps][lane][step in group][value]: 16 bytes per lane and value.  One s_barrier per block of D = 32 steps
+// (64 with 32 envs per workgroup -- the form the launcher takes up to 4096 envs, see the note at the kernel: the bound named next is
+// what that form removes).
+// What bounds the 64-env form (profiles/r03h_dcs_probe.txt): the output waves (1200-1600 cycles of a 1700-cycle block period) -- a block
+// moves ~130 KB through the LDS (~1000 cycles at 128 B/clk), and, decisively, the CU issues one 1-KiB wave store per ~33 cycles: 48 of them
+// per 32 steps.  With 32 envs per workgroup every CU has half of them and the integrator (34 cycles per step) is the bound again.
 // Every value is produced by the code the other kernels run (prep / rk_step / observe / state_violation), so the results are
 // bit-identical to theirs; the tests assert it.  Preconditions beyond the pipelined kernel's (checked by the launcher): DC machine,
 // ConstantSpeedLoad, no dead time of either kind, ideal supply, constant initial state, no fused reward, AoS observations, and
