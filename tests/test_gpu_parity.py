@@ -1554,7 +1554,7 @@ def test_single_step_launches_replay_from_a_hip_graph_bit_identically():
 
 @pytest.mark.parametrize("env_id", ["Cont-CC-PermExDc-v0", "Finite-CC-PermExDc-v0", "Cont-CC-SeriesDc-v0", "Finite-SC-SeriesDc-v0", "Cont-CC-ShuntDc-v0",
                                     "Finite-CC-ShuntDc-v0", "Cont-CC-ExtExDc-v0", "Finite-CC-ExtExDc-v0"])
-@pytest.mark.parametrize("solver", ["euler", "rk4", "rk4_nolinmap", "dp5"])
+@pytest.mark.parametrize("solver", ["euler", "rk4", "rk4_nolinmap", "dp5", "euler_epw64", "rk4_epw64"])
 def test_dc_stream_kernel_is_bit_identical_to_the_pipelined_kernel(env_id, solver, monkeypatch):
     """Small batches of the DC machines behind a ConstantSpeedLoad take dc_stream_kernel (pre waves: converter + input term; integrator:
     the recurrence alone; output waves: observation row + done flag, stored from registers).  It calls the device functions the other
@@ -1567,6 +1567,12 @@ def test_dc_stream_kernel_is_bit_identical_to_the_pipelined_kernel(env_id, solve
     import gym_electric_motor_amd as ga
 
     n = 192
+    # (`_epw64`: the form with one env per lane, which the launcher takes from 4097 to 8192 envs; default here: 32 envs per workgroup)
+    if solver.endswith("_epw64"):
+        monkeypatch.setenv("GEMX_DCS_EPW", "64")
+        solver = solver[:-6]
+    else:
+        monkeypatch.delenv("GEMX_DCS_EPW", raising=False)
     sol = dict(euler=ga.EulerSolver, rk4=ga.RK4Solver, rk4_nolinmap=ga.RK4Solver, dp5=ga.DormandPrince5Solver)[solver]
 
     def run(stream):
@@ -1608,6 +1614,7 @@ def test_dc_stream_kernel_is_bit_identical_to_the_pipelined_kernel(env_id, solve
     a, ka = run("1")
     b, kb = run("0")
     assert all("dc_stream_kernel" in k for k in ka[:6]) and "dc_stream_kernel" not in ka[6] and "dc_stream_kernel" in ka[7], ka
+    assert all(("grid=3 x" in k) == (os.environ.get("GEMX_DCS_EPW") == "64") for k in ka[:6]), ka  # 192 envs: 3 workgroups of 64 or 6 of 32
     assert not any("dc_stream_kernel" in k for k in kb), kb
     if "PermExDc" in env_id:
         assert a[1].any(), "the rollout should contain terminations"
