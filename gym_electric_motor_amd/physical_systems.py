@@ -604,11 +604,11 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             raise ValueError(f"bind_step needs a contiguous {self._want_dtype} tensor of {self._act_numel} elements on {self._tdev}")
         st = (stream if stream is not None else torch.cuda.current_stream(self._tdev)).cuda_stream
         call, check, obs = self._gemx_step, _lib.check, self._obs
-        args = (self._handle, C.c_void_p(a.data_ptr()), C.c_void_p(self._obs_ptr), C.c_void_p(self._done_ptr), C.c_void_p(st))
+        args = (C.c_void_p(a.data_ptr()), C.c_void_p(self._obs_ptr), C.c_void_p(self._done_ptr), C.c_void_p(st))
         keep = (a, stream)  # the buffers behind the raw pointers stay alive as long as the stepper does
 
         def step(_args=args, _call=call, _keep=keep):
-            rc = _call(*_args)
+            rc = _call(self._handle, *_args)  # (the handle is read per call: None after close() -> the C ABI's "null handle" error, not a stale pointer)
             if rc:
                 check(rc)
             self._k += 1

@@ -1879,6 +1879,8 @@ def test_bind_step_is_simulate_without_the_argument_handling():
         p2.bind_step(torch.zeros(2 * n, dtype=torch.uint8, device="cuda")[::2])
     e1.close()
     e2.close()
+    with pytest.raises(ValueError):  # a stepper outliving its system: the C ABI's "null handle", not a stale pointer
+        step()
 
 
 _DCS_WATCHDOG = r'''
