@@ -190,12 +190,20 @@ def bytes_per_env_step_single(w):
     return bytes_per_env_step_fused(w) + 2 * 4 * w["s_ode"]
 
 
-def make_env(ga, w, n_envs, device, split_kinks=False, error_controlled=False):
-    sol = ga.ScipyOdeSolver() if error_controlled else (ga.EulerSolver() if w["solver"] == "euler" else ga.RK4Solver(split_kinks=split_kinks))
+def make_env(ga, w, n_envs, device, split_kinks=None, error_controlled=False):
+    """split_kinks None: the solver `make(env_id)` hands out when the caller names none (envs.default_ode_solver: RK4, with the
+    PolynomialStaticLoad's kinks corrected for wherever the env id's own load has them) -- except Euler for BASELINE config 2, which
+    names it; True / False: RK4Solver(split_kinks=...) by name."""
     kw = {}
     if w.get("const_speed") is not None:
         kw["load"] = ga.ConstantSpeedLoad(omega_fixed=w["const_speed"])
-    return ga.make(w["env_id"], n_envs=n_envs, device=device, ode_solver=sol, tau=w["tau"], **kw)
+    if error_controlled:
+        kw["ode_solver"] = ga.ScipyOdeSolver()
+    elif w["solver"] == "euler":
+        kw["ode_solver"] = ga.EulerSolver()
+    elif split_kinks is not None:
+        kw["ode_solver"] = ga.RK4Solver(split_kinks=split_kinks)
+    return ga.make(w["env_id"], n_envs=n_envs, device=device, tau=w["tau"], **kw)
 
 
 def make_actions(torch, ps, K, n, device, seed):
@@ -226,6 +234,10 @@ def measure(torch, dist, env, n_local, steps, warmup, spl, device, world, seed, 
     acts = make_actions(torch, ps, spl * n_act_bufs, n_local, device, seed)
     obs = torch.empty((spl, n_local, ps._n_out), dtype=torch.float32, device=device)
     done = torch.empty((spl, n_local), dtype=torch.uint8, device=device)
+    gbuf = None
+    if gather == "chunk":  # the gathered chunk [W, K, n_local, S_out] (+ done bytes), allocated once
+        wg = dist.get_world_size()
+        gbuf = (torch.empty((wg,) + tuple(obs.shape), dtype=obs.dtype, device=device), torch.empty((wg,) + tuple(done.shape), dtype=done.dtype, device=device))
     env.reset()
 
     def launch(i):
@@ -233,11 +245,11 @@ def measure(torch, dist, env, n_local, steps, warmup, spl, device, world, seed, 
         if gather == "step":  # batched return after EVERY control step: one launch + one all-gather per step
             for k in range(spl):
                 o = ps.simulate(acts[a0 + k])
-                gd.gather_observations(o, ps.done)
+                gd.gather_observations(o, ps.done, force=True)
         else:
             env.rollout(acts[a0 : a0 + spl], obs_out=obs, done_out=done)
             if gather == "chunk":
-                gd.gather_rollout(obs, done)
+                gd.gather_rollout(obs, done, force=True, out=gbuf)
 
     if settle_ms > 0:
         t_end, i = time.perf_counter() + settle_ms * 1e-3, 0
@@ -250,9 +262,10 @@ def measure(torch, dist, env, n_local, steps, warmup, spl, device, world, seed, 
     for i in range(warmup):
         launch(i)
     out = []
+    pg = dist.is_available() and dist.is_initialized()  # (also a world of ONE under torchrun: the same barriers / all-reduce as any N)
     for _ in range(max(1, repeats)):
         torch.cuda.synchronize()
-        if world > 1:
+        if pg:
             dist.barrier()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -262,11 +275,11 @@ def measure(torch, dist, env, n_local, steps, warmup, spl, device, world, seed, 
             launch(i)
         e1.record()
         torch.cuda.synchronize()
-        if world > 1:
+        if pg:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if pg:
             if dist.get_backend() == "gloo":
                 t = torch.tensor([dt], dtype=torch.float64)
             else:
@@ -303,7 +316,7 @@ def measure_sustained(torch, env, n_local, spl, device, seed, seconds, tele, lau
     return dt, e0.elapsed_time(e1) / n, n, smp.summary()
 
 
-def measure_traffic_pmc(args, workload, timeout_s=150):
+def measure_traffic_pmc(args, workload, n_local, timeout_s=150):
     """HBM bytes per launch of the dominant kernel, MEASURED IN THIS RUN: two child runs of this script under `rocprofv3 --pmc`
     (FETCH_SIZE and WRITE_SIZE in separate passes -- they do not fit one: 3 + 2 TCC slots), per the guide's HBM section:
     counters in KiB, FETCH_SIZE doubled on gfx950 (it tallies 128-byte requests at 64 bytes), WRITE_SIZE as reported.
@@ -322,9 +335,10 @@ def measure_traffic_pmc(args, workload, timeout_s=150):
         d = tempfile.mkdtemp(prefix="gemx_pmc_", dir="/tmp")
         cmd = [rp, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                "--no-extras", "--no-pmc", "--workload", workload, "--steps", "3", "--warmup", "1", "--settle-ms", "0", "--repeats", "1",
-               "--steps-per-launch", str(args.steps_per_launch)]
+               "--steps-per-launch", str(args.steps_per_launch), "--envs-per-gpu", str(n_local), "--gather", "off"]
         try:
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            cenv = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+            subprocess.run(cmd, cwd="/tmp", env=dict(cenv, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
             acc = {}
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 for r in csv.DictReader(open(f)):
@@ -480,7 +494,11 @@ def cpu_baseline(w, budget_s=12.0):
     return out
 
 
-def roofline_of(w, n_local, spl, launch_ms, kernel_desc, workload_key, traffic=None, traffic_source=None):
+def roofline_of(w, n_local, spl, launch_ms, kernel_desc, workload_key, traffic=None, traffic_source=None, events_ms=None):
+    """launch_ms: the time per launch the roofline fraction is priced with.  Since round 4 that is the SAME clock `value` uses -- wall time
+    of the timed region / launches (max over ranks) -- so that value x bytes_per_env_step == roofline.achieved; the mean from the HIP
+    events on the launch stream is reported beside it (`launch_ms_hip_events`; it excludes the host's barrier / synchronise tail, and
+    the two differ by ~1 % on a 3-ms region)."""
     b_step = bytes_per_env_step_fused(w)
     launch_bytes = n_local * (spl * b_step + 2 * 4 * w["s_ode"])
     achieved = launch_bytes / (launch_ms * 1e-3) / 1e9
@@ -494,6 +512,7 @@ def roofline_of(w, n_local, spl, launch_ms, kernel_desc, workload_key, traffic=N
                 traffic = None
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_desc, "launch_ms": launch_ms,
+            "launch_ms_hip_events": events_ms, "clock": "wall time of the timed region / launches (the clock `value` uses)",
             "algorithmic_bytes_per_launch": launch_bytes, "bytes_per_env_step": b_step}
 
 
@@ -512,25 +531,30 @@ def worker(args, rank, world, local_rank, backend):
                          "--oversubscribe to put several ranks on one GPU (gloo control plane; a functional check, not a measurement)")
     device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    dist_on = world > 1 or args.force_dist
+    if dist_on and not dist.is_initialized():
         import datetime
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
-            raise SystemExit("bench.py: WORLD_SIZE > 1 without MASTER_PORT (torchrun sets it; --gpus N without torchrun picks a free port)")
+            if world > 1:
+                raise SystemExit("bench.py: WORLD_SIZE > 1 without MASTER_PORT (torchrun sets it; --gpus N without torchrun picks a free port)")
+            from gym_electric_motor_amd.distributed import free_port
+
+            os.environ["MASTER_PORT"] = str(free_port())  # a world of one talks to itself
         # a rank that dies leaves the others with an exception after --dist-timeout seconds instead of a hang in a barrier
         dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.dist_timeout))
 
     w = dict(WORKLOADS[args.workload], key=args.workload)
     # the same shard on every GPU at every N (weak scaling: per-GPU work fixed); BASELINE config 5 (8 x 32768 envs) is measured beside it
-    # at --gpus 8 as `config5` (rounds 1-2 made it the N = 8 default, which mixed a change of shard size into the driver's scaling curve)
+    # at every N > 1 as `config5` (rounds 1-2 made it the N = 8 default, which mixed a change of shard size into the driver's scaling curve)
     n_local = args.envs_per_gpu or w["envs"]
     n_total = n_local * world
     K, W, spl = args.steps, args.warmup, args.steps_per_launch
 
     S = args.settle_ms
     tele = Telemetry(dev_index)
-    env = make_env(ga, w, n_local, dev_index)
+    env = make_env(ga, w, n_local, dev_index, split_kinks=False)  # (Finite-CC-PMSM-v0: constant-speed load, RK4 is what make() picks too)
     t_cold = measure(torch, dist, env, n_local, K, W, spl, device, world, seed=1234 + rank) if S > 0 else None  # straight from idle
     tele_before = tele.sample()
     reps = measure(torch, dist, env, n_local, K, W, spl, device, world, seed=1234 + rank, settle_ms=S, repeats=max(1, args.repeats))
@@ -538,29 +562,12 @@ def worker(args, rank, world, local_rank, backend):
     tele_after = tele.sample()
     t = median_of(reps)
     kernel_desc = env.physical_system.last_launch()
-    config5 = None
-    if args.workload == "pmsm" and args.envs_per_gpu is None and (args.config5 == "on" or (args.config5 == "auto" and world == 8)):
-        env_s = make_env(ga, w, 32768, dev_index)
-        ts = measure(torch, dist, env_s, 32768, K, W, spl, device, world, seed=1234 + rank, settle_ms=S)
-        env_s.close()
-        config5 = {"envs_per_gpu": 32768, "value": 32768 * world * spl * K / ts.wall, "unit": "env-steps/s", "ms_per_step": ts.wall / K * 1e3,
-                   "note": "BASELINE.json configs[4]: 8 x 32768 envs (twice the per-GPU shard of the scaling lines; the single-GPU figure "
-                           "for that shard is configs.pmsm_c5_shard of the --gpus 1 line)"}
-    gathered = None
-    if args.gather != "off":  # (gloo, i.e. --oversubscribe: the same collectives staged through host memory -- functional, not a measurement)
-        modes = ["chunk", "step"] if args.gather == "both" else [args.gather]
-        gathered = {}
-        for mode in modes:
-            Kg = K if mode == "chunk" else max(1, min(K, 2))
-            spl_g = spl if mode == "chunk" else min(spl, 200)
-            tg = measure(torch, dist, env, n_local, Kg, min(W, 2), spl_g, device, world, seed=4321 + rank, gather=mode, gd=gd, settle_ms=S)
-            per_call = n_local * (spl_g if mode == "chunk" else 1) * (4 * w["s_out"] + 1)
-            gathered[mode] = {"value": n_total * spl_g * Kg / tg.wall, "unit": "env-steps/s", "steps": Kg, "steps_per_launch": spl_g,
-                              "ms_per_step": tg.wall / Kg * 1e3, "bytes_gathered_per_rank_per_call": per_call * world,
-                              "collective": f"{backend} all_gather_into_tensor, world {world}"}
-    env.close()
 
-    if rank == 0:
+    def rl(tm, traffic=None, source=None):
+        return roofline_of(w, n_local, spl, tm.wall / K * 1e3, kernel_desc, args.workload, traffic=traffic, traffic_source=source, events_ms=tm.launch_ms)
+
+    out = None
+    if rank == 0:  # the headline is complete BEFORE any optional leg runs: nothing below can lose `value`
         out = {
             "metric": "env-steps/sec (batched PMSM, tau=1e-4)" if args.workload == "pmsm" else f"env-steps/sec ({args.workload})",
             "value": n_total * spl * K / t.wall,
@@ -579,59 +586,187 @@ def worker(args, rank, world, local_rank, backend):
                        "env_id": w["env_id"], "envs_per_gpu": n_local, "solver": w["solver"], "tau": w["tau"],
                        "steps_per_launch": spl, "control_steps_timed": spl * K, "clock_settle_ms": S,
                        "parallelism": f"env-sharded x{world}, no data-path collective", "world_size": world,
-                       "backend": (backend if world > 1 else None), "oversubscribed": bool(args.oversubscribe and world > ndev)},
-            "roofline": roofline_of(w, n_local, spl, t.launch_ms, kernel_desc, args.workload),
+                       "backend": (backend if dist_on else None), "oversubscribed": bool(args.oversubscribe and world > ndev)},
+            "roofline": rl(t),
             "repeats": {"n": len(reps), "note": f"the timed region ({K} launches) run {len(reps)} times back to back; value / ms_per_step / roofline = the MEDIAN region",
-                        "values": [n_total * spl * K / r.wall for r in reps], "launch_ms": [r.launch_ms for r in reps],
-                        "roofline_frac_min": min(roofline_of(w, n_local, spl, r.launch_ms, kernel_desc, args.workload)["frac"] for r in reps),
-                        "roofline_frac_max": max(roofline_of(w, n_local, spl, r.launch_ms, kernel_desc, args.workload)["frac"] for r in reps)},
+                        "values": [n_total * spl * K / r.wall for r in reps], "launch_ms": [r.wall / K * 1e3 for r in reps],
+                        "launch_ms_hip_events": [r.launch_ms for r in reps],
+                        "roofline_frac_min": min(rl(r)["frac"] for r in reps), "roofline_frac_max": max(rl(r)["frac"] for r in reps)},
             "telemetry": dict(tele.describe(), before=tele_before, after=tele_after),
         }
+        if t_cold is not None:
+            out["cold_start"] = {"value": n_total * spl * K / t_cold.wall, "unit": "env-steps/s", "ms_per_step": t_cold.wall / K * 1e3,
+                                 "roofline_frac": rl(t_cold)["frac"],
+                                 "note": f"the same {W} + {K} launches straight from an idle GPU, no clock settling (module docstring)"}
+
+    # ---- optional legs.  Every one is wrapped: a failure becomes an "error" field of the line, never a lost line.
+    def guarded(name, fn):
+        try:
+            return fn()
+        except BaseException as e:  # (incl. SystemExit / KeyboardInterrupt from a library: the line must still be printed)
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            import traceback
+
+            return {"error": repr(e), "leg": name, "trace": traceback.format_exc(limit=4)}
+
+    if args.workload == "pmsm" and args.envs_per_gpu is None and (args.config5 == "on" or (args.config5 == "auto" and world > 1)):
+        def c5():
+            env_s = make_env(ga, w, 32768, dev_index, split_kinks=False)
+            try:
+                ts = measure(torch, dist, env_s, 32768, K, W, spl, device, world, seed=1234 + rank, settle_ms=S)
+            finally:
+                env_s.close()
+            r5 = roofline_of(w, 32768, spl, ts.wall / K * 1e3, "", args.workload, events_ms=ts.launch_ms)
+            return {"envs_per_gpu": 32768, "envs_total": 32768 * world, "value": 32768 * world * spl * K / ts.wall, "unit": "env-steps/s",
+                    "ms_per_step": ts.wall / K * 1e3, "roofline_frac_per_gpu": r5["frac"],
+                    "note": "BASELINE.json configs[4] is 8 x 32768 envs: this is world x 32768 (twice the per-GPU shard of the scaling lines; "
+                            "the single-GPU figure for that shard is configs.pmsm_c5_shard of the --gpus 1 line)"}
+        c5r = guarded("config5", c5)
+        if out is not None:
+            out["config5"] = c5r
+
+    gmode = args.gather
+    if gmode == "auto":  # the batched-return path is part of every multi-GPU line (bounded: a few launches), off on a lone GPU
+        gmode = "chunk" if world > 1 else "off"
+    if gmode != "off":
+        if not dist_on:
+            raise SystemExit("bench.py: --gather needs a process group: run under torchrun, with --gpus N > 1, or add --force-dist")
+        modes = ["chunk", "step"] if gmode == "both" else [gmode]
+        gathered = {}
+        for mode in modes:
+            def gleg(mode=mode):
+                Kg = max(1, min(K, 5)) if mode == "chunk" else max(1, min(K, 2))
+                spl_g = spl if mode == "chunk" else min(spl, 200)
+                tg = measure(torch, dist, env, n_local, Kg, min(W, 2), spl_g, device, world, seed=4321 + rank, gather=mode, gd=gd, settle_ms=S)
+                per_call = n_local * (spl_g if mode == "chunk" else 1) * (4 * w["s_out"] + 1)
+                res = {"value": n_total * spl_g * Kg / tg.wall, "unit": "env-steps/s", "steps": Kg, "steps_per_launch": spl_g,
+                       "ms_per_step": tg.wall / Kg * 1e3, "bytes_gathered_per_rank_per_call": per_call * world,
+                       "collective": f"{backend} all_gather_into_tensor, world {world}"}
+                if mode == "chunk":  # the collective alone, on this launch's real outputs
+                    res["rccl"] = collective_alone(torch, dist, gd, env, n_local, spl_g, device, world, backend, per_call)
+                return res
+            gathered[mode] = guarded("gather:" + mode, gleg)
+        if out is not None:
+            out["gather"] = gathered
+            ch = gathered.get("chunk")
+            out["rccl"] = ch.get("rccl") if isinstance(ch, dict) and "rccl" in ch else {"error": (ch or {}).get("error", "chunk gather leg did not run")}
+    env.close()
+
+    if rank == 0:
         if not args.no_pmc and world == 1:
-            tr, note = measure_traffic_pmc(args, args.workload)
+            tr, note = guarded_pair(lambda: measure_traffic_pmc(args, args.workload, n_local))
             if tr is not None:
-                out["roofline"] = roofline_of(w, n_local, spl, t.launch_ms, kernel_desc, args.workload, traffic=tr, traffic_source=note)
+                out["roofline"] = rl(t, traffic=tr, source=note)
             else:
                 out["roofline"]["traffic_source"] = f"{out['roofline'].get('traffic_source')}; in-run PMC pass unavailable: {note}"
-        if t_cold is not None:
-            rcold = roofline_of(w, n_local, spl, t_cold.launch_ms, kernel_desc, args.workload)
-            out["cold_start"] = {"value": n_total * spl * K / t_cold.wall, "unit": "env-steps/s", "ms_per_step": t_cold.wall / K * 1e3,
-                                 "roofline_frac": rcold["frac"],
-                                 "note": f"the same {W} + {K} launches straight from an idle GPU, no clock settling (module docstring)"}
-        if gathered is not None:
-            out["gather"] = gathered
-        if config5 is not None:
-            out["config5"] = config5
         if not args.no_extras and world == 1:
-            extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out, tele)
+            try:
+                extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out, tele)
+            except Exception as e:  # an informational leg must not cost the headline
+                import traceback
+
+                out["extras_error"] = {"error": repr(e), "trace": traceback.format_exc(limit=6)}
         elif not args.no_extras:
             out["cpu_baseline"] = None
+        out["overrides"] = {k: v for k, v in os.environ.items() if k.startswith("GEMX_")}  # A/B switches active in THIS run (normally none)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if dist_on:
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:  # (the line is out already)
+            print(f"bench.py: rank {rank}: shutdown barrier failed: {e!r}", file=sys.stderr)
 
 
-def leg(torch, dist, ga, args, key, device, dev_index, spl, tele, envs=None, split_kinks=False, error_controlled=False, steps=10, repeats=3, seed=5):
+def guarded_pair(fn):
+    try:
+        return fn()
+    except Exception as e:
+        return None, repr(e)
+
+
+def collective_alone(torch, dist, gd, env, n_local, spl, device, world, backend, per_call):
+    """The batched-return collective by itself: all-gather of ONE launch's real outputs ([K, n_local, S_out] rows + done bytes) into
+    preallocated buffers, timed over a few calls between barriers.  bytes_per_rank = what each rank contributes per call;
+    GB_per_s = bus bandwidth per rank, (W - 1) x bytes_per_rank / time (what each rank receives over its xGMI links; a world of one
+    moves bytes_per_rank through a device-local copy and reports that instead)."""
+    ps = env.physical_system
+    obs = torch.empty((spl, n_local, ps._n_out), dtype=torch.float32, device=device)
+    done = torch.empty((spl, n_local), dtype=torch.uint8, device=device)
+    acts = make_actions(torch, ps, spl, n_local, device, 99)
+    env.reset()
+    env.rollout(acts, obs_out=obs, done_out=done)
+    wg = dist.get_world_size()
+    gbuf = (torch.empty((wg,) + tuple(obs.shape), dtype=obs.dtype, device=device), torch.empty((wg,) + tuple(done.shape), dtype=done.dtype, device=device))
+    for _ in range(2):
+        gd.gather_rollout(obs, done, force=True, out=gbuf)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    n = 5
+    t0 = time.perf_counter()
+    for _ in range(n):
+        gd.gather_rollout(obs, done, force=True, out=gbuf)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    rank = dist.get_rank()
+    ok = bool(torch.equal(gbuf[0][rank], obs)) and bool(torch.equal(gbuf[1][rank], done))  # this rank's own slot, bit for bit
+    try:
+        ver = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
+    except Exception:
+        ver = None
+    moved = (wg - 1) * per_call if wg > 1 else per_call
+    return {"world_seen": wg, "backend": backend, "version": ver, "bytes_per_rank": per_call, "ms": dt * 1e3, "GB_per_s": moved / dt / 1e9,
+            "own_slot_bit_identical": ok, "calls": n,
+            "note": "all_gather_into_tensor of one launch's observation chunk + done bytes; GB_per_s = (W - 1) x bytes_per_rank / time"
+                    + (" (world of one: bytes_per_rank / time, a device-local copy)" if wg == 1 else "")}
+
+
+def leg(torch, dist, ga, args, key, device, dev_index, spl, tele, envs=None, split_kinks=None, error_controlled=False, steps=10, repeats=3, seed=5,
+        sustained=True):
     """One informational leg through the same measurement as the headline: `repeats` timed regions of `steps` launches, MEDIAN reported,
-    min / max beside it, clocks / power before and after."""
+    min / max beside it, clocks / power before and after; then (round 4, every leg) >= --sustain-s seconds of back-to-back launches with
+    the sensors sampled -- `frac` = min(window, sustained) is the figure to quote: a 16-ms window can sit above what the chip holds once
+    it reaches its power limit.  split_kinks: see make_env (None = the solver make(env_id) hands out)."""
     wc = dict(WORKLOADS[key], key=key)
     n = envs or wc["envs"]
     env = make_env(ga, wc, n, dev_index, split_kinks=split_kinks, error_controlled=error_controlled)
-    before = tele.sample()
-    reps = measure(torch, dist, env, n, steps, 3, spl, device, 1, seed=seed, settle_ms=args.settle_ms, repeats=repeats)
-    reps = reps if isinstance(reps, list) else [reps]
-    after = tele.sample()
-    desc = env.physical_system.last_launch()
-    env.close()
-    tm = median_of(reps)
-    fr = [roofline_of(wc, n, spl, r.launch_ms, desc, key)["frac"] for r in reps]
-    how = ", RK4Solver(split_kinks=True)" if split_kinks else (", ScipyOdeSolver() = error-controlled Dormand-Prince 5(4), rtol 1e-6" if error_controlled else "")
-    return {"workload": wc["desc"] + how, "envs": n, "steps_per_launch": spl,
-            "value": n * spl * steps / tm.wall, "unit": "env-steps/s", "roofline": roofline_of(wc, n, spl, tm.launch_ms, desc, key),
-            "repeats": {"n": len(reps), "roofline_frac": fr, "roofline_frac_min": min(fr), "roofline_frac_max": max(fr)},
-            "telemetry": {"before": before, "after": after}}, tm
+    try:
+        # the timed region is priced by the wall clock (barrier / synchronise tail included): make it >= 3 ms of launches, as the headline's
+        # 20 x 0.15 ms is -- ten 20-us launches of BASELINE config 2 would be a 0.2-ms region, a tenth of it host synchronisation
+        probe = measure(torch, dist, env, n, 10, 3, spl, device, 1, seed=seed, settle_ms=args.settle_ms, repeats=1)
+        steps = max(steps, int(math.ceil(3.0 / max(probe.launch_ms, 1e-3))))
+        before = tele.sample()
+        reps = measure(torch, dist, env, n, steps, 3, spl, device, 1, seed=seed, settle_ms=args.settle_ms, repeats=repeats)
+        reps = reps if isinstance(reps, list) else [reps]
+        after = tele.sample()
+        desc = env.physical_system.last_launch()
+        solver_name = type(env.physical_system._ode_solver).__name__ + ("(split_kinks=True)" if getattr(env.physical_system._ode_solver, "_split_kinks", False) else "")
+        tm = median_of(reps)
+        ro = lambda r: roofline_of(wc, n, spl, r.wall / steps * 1e3, desc, key, events_ms=r.launch_ms)  # noqa: E731
+        fr = [ro(r)["frac"] for r in reps]
+        how = (", the solver make(env_id) hands out: " if split_kinks is None and not error_controlled and wc["solver"] != "euler" else ", ") + solver_name
+        if error_controlled:
+            how += " = error-controlled Dormand-Prince 5(4), rtol 1e-6"
+        res = {"workload": wc["desc"] + how, "envs": n, "steps_per_launch": spl, "launches_per_region": steps, "solver": solver_name,
+               "value": n * spl * steps / tm.wall, "unit": "env-steps/s", "roofline": ro(tm),
+               "repeats": {"n": len(reps), "roofline_frac": fr, "roofline_frac_min": min(fr), "roofline_frac_max": max(fr)},
+               "telemetry": {"before": before, "after": after}}
+        res["frac"] = min(fr)
+        if sustained and args.sustain_s > 0:
+            dt, lms, nl, smp = measure_sustained(torch, env, n, spl, device, seed + 8, args.sustain_s, tele, tm.launch_ms)
+            fs = roofline_of(wc, n, spl, dt / nl * 1e3, "", key)["frac"]
+            res["sustained_1s"] = {"value": n * spl * nl / dt, "launches": nl, "seconds": dt, "launch_ms": dt / nl * 1e3, "launch_ms_hip_events": lms,
+                                   "roofline_frac": fs, "telemetry_during": smp}
+            res["frac"] = min(res["frac"], fs)
+        res["frac_note"] = "min(minimum of the repeated windows, sustained second)"
+    finally:
+        env.close()
+    return res, tm
 
 
 def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out, tele):
@@ -640,26 +775,26 @@ def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out, tele)
     # the same launches without the one-step affine map (general stage-by-stage RK4)
     os.environ["GEMX_LINMAP"] = "0"
     try:
-        env0 = make_env(ga, w, n_local, dev_index)
+        env0 = make_env(ga, w, n_local, dev_index, split_kinks=False)
         t0 = measure(torch, dist, env0, n_local, min(args.steps, 10), 2, spl, device, 1, seed=77, settle_ms=args.settle_ms)
         desc0 = env0.physical_system.last_launch()
         env0.close()
     finally:
         del os.environ["GEMX_LINMAP"]
-    r0 = roofline_of(w, n_local, spl, t0.launch_ms, desc0, args.workload + "/nolinmap")
+    r0 = roofline_of(w, n_local, spl, t0.wall / min(args.steps, 10) * 1e3, desc0, args.workload + "/nolinmap", events_ms=t0.launch_ms)
     out["headline_no_linmap"] = {"value": n_local * spl * min(args.steps, 10) / t0.wall, "unit": "env-steps/s", "launch_ms": t0.launch_ms,
                                  "achieved_GBps": r0["achieved"], "frac_of_peak": r0["frac"], "env": "GEMX_LINMAP=0"}
     # does the 3-ms window hold for a second?  (clocks / power sampled every 20 ms while the launches run)
-    envs_ = make_env(ga, w, n_local, dev_index)
+    envs_ = make_env(ga, w, n_local, dev_index, split_kinks=False)
     dt, lms, n, smp = measure_sustained(torch, envs_, n_local, spl, device, 11, args.sustain_s, tele, out["roofline"]["launch_ms"])
     envs_.close()
-    rs = roofline_of(w, n_local, spl, lms, out["roofline"]["kernel"], args.workload)
-    out["sustained_1s"] = {"value": n_local * spl * n / dt, "unit": "env-steps/s", "launches": n, "seconds": dt, "launch_ms": lms,
-                           "roofline_frac": rs["frac"], "telemetry_during": smp,
+    rs = roofline_of(w, n_local, spl, dt / n * 1e3, out["roofline"]["kernel"], args.workload)
+    out["sustained_1s"] = {"value": n_local * spl * n / dt, "unit": "env-steps/s", "launches": n, "seconds": dt, "launch_ms": dt / n * 1e3,
+                           "launch_ms_hip_events": lms, "roofline_frac": rs["frac"], "telemetry_during": smp,
                            "note": f">= {args.sustain_s} s of back-to-back launches of the headline workload, no host synchronisation inside"}
     # closed-loop usage: one launch per control step, eager and from a HIP graph
     b1 = bytes_per_env_step_single(w)
-    env1 = make_env(ga, w, n_local, dev_index)
+    env1 = make_env(ga, w, n_local, dev_index, split_kinks=False)
     host_s, dev_ms, n1 = measure_single_step(torch, env1, n_local, 2000, 100, device, seed=99, settle_ms=args.settle_ms)
     out["single_step"] = {"value": n_local / host_s, "unit": "env-steps/s", "ms_per_step": host_s * 1e3, "device_ms_per_step": dev_ms,
                           "achieved_GBps": n_local * b1 / (dev_ms * 1e-3) / 1e9, "bytes_per_env_step": b1, "steps": n1,
@@ -673,37 +808,36 @@ def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out, tele)
                                 "achieved_GBps": n_local * b1 / (dev_ms * 1e-3) / 1e9, "bytes_per_env_step": b1, "steps": n1,
                                 "note": "64 gemx_step launches captured into one HIP graph (torch.cuda.CUDAGraph) and replayed"}
     env1.close()
-    # BASELINE configs 2, 4 and 5's per-GPU shard through the same measurement (3 repeats each: median, min, max)
+    # BASELINE configs 2, 4 and 5's per-GPU shard through the same measurement (3 repeats each: median, min, max; then a sustained second)
     out["configs"] = {}
     for key in ("permexdc", "scim", "scim_constspeed"):
         if key == args.workload:
             continue
-        out["configs"][key], tm = leg(torch, dist, ga, args, key, device, dev_index, spl, tele)
-        if key == "scim":  # the same config with RK4Solver(split_kinks=True): steps cut at the PolynomialStaticLoad's kinks (accuracy option)
-            out["configs"]["scim_split_kinks"], _ = leg(torch, dist, ga, args, key, device, dev_index, spl, tele, split_kinks=True)
+        # `scim` = BASELINE config 4 with the solver make("Cont-SC-SCIM-v0") hands out (RK4 + kink correction); plain RK4 beside it
+        out["configs"][key], tm = leg(torch, dist, ga, args, key, device, dev_index, spl, tele, split_kinks=None if key == "scim" else False)
+        if key == "scim":
+            out["configs"]["scim_plain_rk4"], _ = leg(torch, dist, ga, args, key, device, dev_index, spl, tele, split_kinks=False)
+            out["configs"]["scim_split_kinks"] = {"same_as": "configs.scim", "frac": out["configs"]["scim"]["frac"],
+                                                  "roofline": out["configs"]["scim"]["roofline"],
+                                                  "note": "rounds 2-3 reported make()'s solver under this key and plain RK4 as `scim`; since round 4 "
+                                                          "`scim` IS make()'s solver and plain RK4 is `scim_plain_rk4`"}
             # ... and with the reference default's semantics on the device (GEMX_SOLVER_ADAPTIVE: every lane cuts its own steps)
-            out["configs"]["scim_error_controlled"], _ = leg(torch, dist, ga, args, key, device, dev_index, spl, tele, error_controlled=True, steps=5)
-            wc = dict(WORKLOADS[key], key=key)
-            envs_ = make_env(ga, wc, wc["envs"], dev_index)
-            dt, lms, n, smp = measure_sustained(torch, envs_, wc["envs"], spl, device, 13, args.sustain_s, tele, tm.launch_ms)
-            envs_.close()
-            out["configs"]["scim"]["sustained_1s"] = {"value": wc["envs"] * spl * n / dt, "launches": n, "seconds": dt, "launch_ms": lms,
-                                                      "roofline_frac": roofline_of(wc, wc["envs"], spl, lms, "", key)["frac"], "telemetry_during": smp}
+            out["configs"]["scim_error_controlled"], _ = leg(torch, dist, ga, args, key, device, dev_index, spl, tele, error_controlled=True, steps=5, sustained=False)
         if key == "permexdc":
             out["configs"][key]["launch_model"] = launch_model(torch, dist, ga, args, key, device, dev_index, out["configs"][key])
-    if args.workload == "pmsm":  # BASELINE config 5 = 8 x 32768 envs: its shard on this one GPU (the <4, 2> shape)
-        out["configs"]["pmsm_c5_shard"], _ = leg(torch, dist, ga, args, "pmsm", device, dev_index, spl, tele, envs=32768)
+    if args.workload == "pmsm":  # BASELINE config 5 = 8 x 32768 envs: its shard on this one GPU
+        out["configs"]["pmsm_c5_shard"], _ = leg(torch, dist, ga, args, "pmsm", device, dev_index, spl, tele, envs=32768, split_kinks=False)
     # the headline kernel with the chip full
     n_big, c_big = 2 ** 20, 100
-    envb = make_env(ga, w, n_big, dev_index)
+    envb = make_env(ga, w, n_big, dev_index, split_kinks=False)
     tb = measure(torch, dist, envb, n_big, 4, 2, c_big, device, 1, seed=7, settle_ms=args.settle_ms, repeats=3)
     envb.close()
     bb = n_big * (c_big * bytes_per_env_step_fused(w) + 2 * 4 * w["s_ode"])
     tbm = median_of(tb)
-    fr = [bb / (r.launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS for r in tb]
+    fr = [bb / (r.wall / 4) / 1e9 / HBM_PEAK_GBPS for r in tb]
     out["at_scale"] = {"envs": n_big, "steps_per_launch": c_big, "value": n_big * 4 * c_big / tbm.wall, "unit": "env-steps/s",
-                       "launch_ms": tbm.launch_ms, "achieved_GBps": bb / (tbm.launch_ms * 1e-3) / 1e9,
-                       "frac_of_peak": bb / (tbm.launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "frac_of_peak_repeats": fr,
+                       "launch_ms": tbm.wall / 4 * 1e3, "launch_ms_hip_events": tbm.launch_ms, "achieved_GBps": bb / (tbm.wall / 4) / 1e9,
+                       "frac_of_peak": bb / (tbm.wall / 4) / 1e9 / HBM_PEAK_GBPS, "frac_of_peak_repeats": fr,
                        "telemetry_after": tele.sample()}
 
 
@@ -715,7 +849,7 @@ def launch_model(torch, dist, ga, args, key, device, dev_index, leg_out):
     wc = dict(WORKLOADS[key], key=key)
     pts = []
     for k in (250, 500, 1000, 2000):
-        env = make_env(ga, wc, wc["envs"], dev_index)
+        env = make_env(ga, wc, wc["envs"], dev_index, split_kinks=False)
         r = measure(torch, dist, env, wc["envs"], 10, 3, k, device, 1, seed=5, settle_ms=args.settle_ms, repeats=3)
         env.close()
         pts.append((k, median_of(r).launch_ms * 1e3))
@@ -725,7 +859,7 @@ def launch_model(torch, dist, ga, args, key, device, dev_index, leg_out):
     t_step = (n * sxy - sx * sy) / (n * sxx - sx * sx)
     t_fixed = (sy - t_step * sx) / n
     spl = leg_out["steps_per_launch"]
-    t_meas = leg_out["roofline"]["launch_ms"] * 1e3
+    t_meas = (leg_out["roofline"]["launch_ms_hip_events"] or leg_out["roofline"]["launch_ms"]) * 1e3  # (HIP events, like the fit's points)
     chain_ns = 14.1 / 2.4
     t_chain = spl * chain_ns * 1e-3 + t_fixed
     t_hbm = leg_out["roofline"]["algorithmic_bytes_per_launch"] / (HBM_PEAK_GBPS * 1e3)
@@ -751,8 +885,12 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--steps-per-launch", "--chunk", dest="steps_per_launch", type=int, default=1000,
                     help="control steps fused into one launch")
-    ap.add_argument("--gather", choices=["off", "chunk", "step", "both"], default="off",
-                    help="also time the batched-return path: all-gather of each launch's observation chunk / of every step's rows")
+    ap.add_argument("--gather", choices=["auto", "off", "chunk", "step", "both"], default="auto",
+                    help="also time the batched-return path: all-gather of each launch's observation chunk / of every step's rows; "
+                         "auto (default) = a bounded `chunk` leg whenever the world is larger than one rank, off on a lone GPU")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even for ONE rank (implied when WORLD_SIZE is in the environment): the barriers, the "
+                         "max-over-ranks all-reduce and --gather then run through RCCL exactly as in a multi-GPU run")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="allow more ranks than visible GPUs (ranks share GPUs, gloo control plane): functional check only")
     ap.add_argument("--settle-ms", type=float, default=60.0,
@@ -774,6 +912,7 @@ def main():
         world = int(world_env)
         if world != args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+        args.force_dist = True  # a launcher-made world, even of one rank, gets its process group
         worker(args, int(os.environ.get("RANK", "0")), world, int(os.environ.get("LOCAL_RANK", "0")), backend)
     elif args.gpus == 1:
         worker(args, 0, 1, 0, backend)

@@ -203,6 +203,7 @@ template <class R> static void fill_params(const gemx_handle &h, const double *m
     // PolynomialStaticLoad.set_j_rotor, polynomial_static_load.py:62-66
     P.omega_lim = (R)(c.j_total > 0 ? c.load_a / c.j_total * c.tau_decay : 0.0);
     P.lin_factor = (R)(c.tau_decay > 0 ? c.j_total / c.tau_decay : 0.0);
+    P.inv_tau_decay = (R)(c.tau_decay > 0 ? 1.0 / c.tau_decay : 0.0);
     P.u_sup = (R)c.u_nominal;
     P.il_ratio = (R)(c.interlocking_time / c.tau);
     P.tau = (R)c.tau;

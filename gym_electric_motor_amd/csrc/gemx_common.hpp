@@ -71,6 +71,7 @@ template <class R> struct DevParams {
     R tc2, tc3;   // DFIM rotor current reconstruction: i_r = tc2 * psi_r - tc3 * i_s
     R pole;       // d(eps)/dt = pole * omega
     R inv_j, la, lb, lc, omega_lim, lin_factor;  // PolynomialStaticLoad
+    R inv_tau_decay;                             //   lin_factor / J
     R u_sup;      // IdealVoltageSupply
     R il_ratio;   // interlocking_time / tau (continuous converters)
     R tau, t_il;  // control step, dead time
@@ -89,7 +90,7 @@ template <class R> struct DevParams {
     int32_t dq_processor;   // dq action frames: 0 control_space='dq' (step-start angle), 1 DqToAbcActionProcessor (advanced angle)
     int32_t delay;          // DeadTimeProcessor steps
     R dq_adv;               // (0.5 + delay) * tau * pole: angle advance per rad/s of omega
-    int32_t kink_split;     // GEMX_SOLVER_SPLIT_KINKS: steps are cut at the PolynomialStaticLoad's kinks (integrate<>)
+    int32_t kink_split;     // GEMX_SOLVER_SPLIT_KINKS: the PolynomialStaticLoad's kinks are corrected for in closed form (integrate<>)
     int32_t adaptive;       // GEMX_SOLVER_ADAPTIVE (DP5 only): error-controlled sub-stepping, dp5_adaptive()
     R rtol, atol;           //   its tolerances (gemx_config.solver_rtol / solver_atol)
     uint32_t *errw;         //   the handle's device error word (GEMX_ERRFLAG_TOLERANCE)

@@ -331,6 +331,26 @@ __device__ __forceinline__ R dp5_adaptive(const DevParams<R> &P, R (&z)[NZ], R h
     return integral;
 }
 
+// GEMX_SOLVER_SPLIT_KINKS (integrate<>): the model system's omega path over one step as the cubic Hermite interpolant in th = t / h,
+// s(th) = w + V0 th + c2 th^2 + c3 th^3 (V0, V1 = h x the end slopes), and its ramp integrals U(c) = int_0^1 (s - c)_+ dth.
+__device__ __forceinline__ float sqrt_r(float x) { return __builtin_amdgcn_sqrtf(x); }  // V_SQRT_F32, 1 ulp
+__device__ __forceinline__ double sqrt_r(double x) { return sqrt(x); }
+template <class R> struct KinkPath {
+    R w, w1, V0, V0sq, q4, c2t, c3q, hV0, M;  // q4 = 4 (w1 - w - V0); c2t = c2 / 3, c3q = c3 / 4, hV0 = V0 / 2; M = int_0^1 s
+    bool up;                                   // w1 > w
+    __device__ __forceinline__ R ramp(R c) const {
+        // crossing instant: the root (towards the end of travel) of the quadratic through both ends with the start slope,
+        // th = 2 (c - w) / (V0 +- sqrt(V0^2 + 4 (w1 - w - V0)(c - w))); NaN-safe clamp to [0, 1] (fmax / fmin drop a NaN operand)
+        const R cs = c - w;
+        const R sq = sqrt_r(fmax(fma(q4, cs, V0sq), R(0)));
+        const R th = fmin(fmax((cs + cs) * rcp_r(V0 + (up ? sq : -sq)), R(0)), R(1));
+        const R Q = fma(fma(fma(c3q, th, c2t), th, hV0), th, -cs) * th;  // int_0^th (s - c)
+        const R Mc = M - c;
+        const bool a0 = w >= c, a1 = w1 >= c;
+        return (a0 & a1) ? Mc : ((a0 | a1) ? (up ? Mc - Q : Q) : R(0));
+    }
+};
+
 // form of a one-step map (linmap_kernel): Phi (x1 = Phi x0 + S g) for the DC machines' whole-step map, D = Phi - I elsewhere
 template <int SYS, int SEG> constexpr bool lin_phi_form() { return SEG == 0 && !SysTraits<SYS>::HAS_ANGLE; }
 // ------------------------------------------------------------------------------------------------
@@ -453,49 +473,69 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
             return P.pole * hs * wsum;
         }
         // GEMX_SOLVER_SPLIT_KINKS (PolynomialStaticLoad only).  The load torque's constant term is the saturation
-        // clamp(J / tau_decay * omega, -a, a) (polynomial_static_load.py:87-92): the right-hand side has kinks at |omega| = omega_lim, where
-        // a fixed step loses its order -- the reference's adaptive default solver rejects and splits exactly those steps.  Each (sub-)step
-        // is cut at the instants omega is PREDICTED to reach the next kink in its direction of travel (second order: d omega/dt from the
-        // first stage, the torque's slope from an Euler look-ahead of the motor states, the load's own slope in the current region);
-        // each piece is one step of the scheme, at most three pieces.  Lanes that are done ride along with h = 0 (z + 0 k = z).
-        // (The test suite's fp64 CPU restatement follows the same steps: 1e-9 agreement with the fp64 build of this code.)
+        // sigma(omega) = clamp(J / tau_decay * omega, -a, a) (polynomial_static_load.py:87-92): the right-hand side has kinks at
+        // |omega| = omega_lim, where a fixed step loses its order -- the reference's adaptive default solver rejects and splits exactly
+        // those steps.  Rounds 2-3 cut the step at the predicted crossings, up to three passes of the scheme for the whole wave whenever ANY
+        // lane crossed (BASELINE config 4: 0.70 -> 0.37 of the roofline).  Now ONE pass, for every lane:
+        //   * the pass integrates a SMOOTH system: sigma replaced by the affine piece sigma_m(omega) = c0 + c1 omega of the region the
+        //     Euler-predicted mid-step omega lies in (-a | J / tau_decay omega | +a), so the scheme keeps its order whatever the lanes do;
+        //   * the defect D = omega_true - omega_model obeys D' = -(1 / tau_decay) [clamp(omega, -lim, lim) - phi_m(omega)] (phi_m: region m's
+        //     piece of the clamp, extended), integrated to first order along the model's own omega path -- the cubic through both ends
+        //     of the step with both end slopes (the end slope costs one torque evaluation, no right-hand side) -- in closed form:
+        //     int clamp = -lim + U(-lim) - U(lim) with the ramp integrals U(c) = int (omega - c)_+ dt; U needs the instant the path
+        //     crosses c, but is stationary in it (the integrand vanishes there), so the root of the quadratic through both ends with the
+        //     start slope is accurate enough; D is added to omega at the end of the step.
+        // Lanes whose path stays inside region m have D = 0 exactly; the closed forms run behind a wave ballot.  Against the recorded runs
+        // of the reference's default solver this is MORE accurate than the cuts were (fp64, worst over every PolynomialStaticLoad fixture:
+        // 6.3e-6 against 2.0e-5; tools/oracle_solver_scan.py), because the crossing is located a posteriori from a third-order path instead of
+        // predicted from the first stage.  (The test suite's fp64 CPU restatement follows the same steps: 1e-9 agreement with the fp64 build.)
         R deps = R(0);
-        const R lim = P.omega_lim, margin = R(1e-6) * lim;
+        const R lim = P.omega_lim;
+        const R h_td = hs * P.inv_tau_decay;
         for (int s = 0; s < ns; ++s) {
-            R rem = hs;
-#pragma nounroll
-            for (int piece = 0; piece < 3; ++piece) {
-                R k1[NM + 1];
-                rhs(y, k1);
-                R h = rem;
-                if (piece < 2) {
-                    const R w = y[0], dw = k1[0];
-                    R b = R(0);
-                    bool have = false;
-                    if (dw > R(0)) {
-                        if (w < -lim - margin) { b = -lim; have = true; }
-                        else if (w < lim - margin) { b = lim; have = true; }
-                    } else if (dw < R(0)) {
-                        if (w > lim + margin) { b = lim; have = true; }
-                        else if (w > -lim + margin) { b = -lim; have = true; }
-                    }
-                    if (have & (rem > R(0))) {
-                        R x0[NM], x1[NM];
+            R k1[NM + 1];
+            rhs(y, k1);
+            const R w = y[0];
+            const R wmid = fma(R(0.5) * hs, k1[0], w);
+            const bool band = fabs(wmid) < lim;
+            const R c1 = band ? P.lin_factor : R(0), c0 = band ? R(0) : copysign(P.la, wmid);
+            k1[0] = fma(med3_r(P.lin_factor * w, -P.la, P.la) - fma(c1, w, c0), P.inv_j, k1[0]);  // first stage of the model system
+            auto load_m = [&](R om, R torque) { return (torque - (P.lc * (om * fabs(om)) + P.lb * om + fma(c1, om, c0))) * P.inv_j; };
+            auto rhs_m = [&](const R (&z)[NM + 1], R (&dz)[NM + 1]) {
+                R x[NM], dx[NM];
 #pragma unroll
-                        for (int i = 0; i < NM; ++i) { x0[i] = y[1 + i]; x1[i] = y[1 + i] + rem * k1[1 + i]; }
-                        const R dT = (E::torque(P, x1) - E::torque(P, x0)) / rem;
-                        const R slope = P.lb + (fabs(w) <= lim ? P.lin_factor : R(0)) + R(2) * P.lc * fabs(w);
-                        const R ddw = (dT - slope * dw) * P.inv_j;
-                        const R disc = dw * dw + R(2) * ddw * (b - w);
-                        R tc = R(2) * rem;
-                        if (disc >= R(0)) tc = R(2) * (b - w) / (dw + copysign(sqrt(disc), dw));
-                        if (tc < rem * R(0.999)) h = fmax(tc, hs * R(1.0 / 64.0));
-                        if (h > rem) h = rem;
-                    }
+                for (int i = 0; i < NM; ++i) x[i] = z[1 + i];
+                const typename E::Pre pre = E::prep(P, z[0], u);
+                E::f(P, pre, x, dx);
+                dz[0] = load_m(z[0], E::torque(P, x));
+#pragma unroll
+                for (int i = 0; i < NM; ++i) dz[1 + i] = dx[i];
+            };
+            deps += (P.pole * hs) * rk_step_k1<SOLVER, NM + 1, R>(y, k1, hs, rhs_m);
+            const R w1 = y[0];
+            const R phi_lim = copysign(lim, wmid);
+            const bool needs = (med3_r(w, -lim, lim) != (band ? w : phi_lim)) | (med3_r(w1, -lim, lim) != (band ? w1 : phi_lim));
+            if (__any(needs)) {  // wave-uniform
+                R x1[NM];
+#pragma unroll
+                for (int i = 0; i < NM; ++i) x1[i] = y[1 + i];
+                const R V0 = hs * k1[0], V1 = hs * load_m(w1, E::torque(P, x1)), dl = w1 - w;
+                const R c2 = R(3) * dl - R(2) * V0 - V1, c3 = V0 + V1 - R(2) * dl;
+                const KinkPath<R> kp{w, w1, V0, V0 * V0, R(4) * (dl - V0), c2 * R(1.0 / 3.0), c3 * R(0.25), R(0.5) * V0,
+                                     w + R(0.5) * V0 + c2 * R(1.0 / 3.0) + c3 * R(0.25), w1 > w};
+                // the first kink ahead of the start in the direction of travel; the other one is crossed in the same step only by a lane
+                // that passes the whole band (rare: second ballot)
+                const R lev = (kp.up ? (w < -lim) : !(w > lim)) ? -lim : lim, oth = -lev;
+                const R U1 = kp.ramp(lev);
+                const bool o0 = w >= oth, o1 = w1 >= oth, full = o0 != o1;
+                R U2 = (o0 & o1) ? kp.M - oth : R(0);
+                if (__any(full)) {
+                    const R uf = kp.ramp(oth);
+                    U2 = full ? uf : U2;
                 }
-                deps += (P.pole * h) * rk_step_k1<SOLVER, NM + 1, R>(y, k1, h, rhs);
-                rem -= h;
-                if (!__any(rem > R(0))) break;  // wave-uniform
+                const R Up = lev > R(0) ? U1 : U2, Um = lev > R(0) ? U2 : U1;
+                const R D = -h_td * ((Um - Up - lim) - (band ? kp.M : phi_lim));
+                y[0] = w1 + (needs ? D : R(0));
             }
         }
         return deps;

@@ -116,12 +116,14 @@ def gather_observations(obs_local, done_local=None, n_total=None, group=None, fo
     return obs_all, done_all
 
 
-def gather_rollout(obs_chunk, done_chunk=None, group=None, force=False):
+def gather_rollout(obs_chunk, done_chunk=None, group=None, force=False, out=None):
     """All-gather one fused launch's outputs: `[K, n_local, S_out]` observation chunks (+ `[K, n_local]` done bytes) of every rank
     -> `[W, K, n_local, S_out]` (+ `[W, K, n_local]`) on every rank, RANK-MAJOR and zero-copy: row `[r, k, i]` is env
     `shard_range(n_total, r, W)[0] + i` at control step k.  (Interleaving the shards into `[K, n_total, S_out]` would cost a second
     pass over W times the chunk; a consumer that needs that view indexes `[:, k]` instead.)  All ranks must hold equally sized shards
-    (bench.py / make_sharded with n_total % W == 0); unequal shards go through gather_observations per step."""
+    (bench.py / make_sharded with n_total % W == 0); unequal shards go through gather_observations per step.
+    out: optional pair of preallocated result tensors `([W, K, n_local, S_out], [W, K, n_local])` (a training loop gathers every
+    launch's chunk into the same buffers: W x 0.9 GB per launch of the headline config is not something to allocate per call)."""
     import torch
     import torch.distributed as dist
 
@@ -129,13 +131,17 @@ def gather_rollout(obs_chunk, done_chunk=None, group=None, force=False):
         return obs_chunk.unsqueeze(0), (done_chunk.unsqueeze(0) if done_chunk is not None else None)
     world = dist.get_world_size(group)
 
-    def _gather(x):
+    def _gather(x, res):
         x = x.contiguous()
-        out = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
-        _all_gather_rows(out.view((world * x.shape[0],) + tuple(x.shape[1:])), x, group)
-        return out
+        if res is None:
+            res = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        elif tuple(res.shape) != (world,) + tuple(x.shape) or res.dtype != x.dtype or res.device != x.device or not res.is_contiguous():
+            raise ValueError(f"gather_rollout: out buffer {tuple(res.shape)} {res.dtype} does not match world {world} x chunk {tuple(x.shape)} {x.dtype}")
+        _all_gather_rows(res.view((world * x.shape[0],) + tuple(x.shape[1:])), x, group)
+        return res
 
-    return _gather(obs_chunk), (_gather(done_chunk) if done_chunk is not None else None)
+    o_obs, o_done = out if out is not None else (None, None)
+    return _gather(obs_chunk, o_obs), (_gather(done_chunk, o_done) if done_chunk is not None else None)
 
 
 def make_sharded(env_id, n_envs_total, rank, world, device, **kwargs):

@@ -33,8 +33,8 @@
  * RungeKutta._step_impl + common.py select_initial_step (Hairer II.4 starting step, error_estimator_order 4, SAFETY 0.9,
  * MIN_FACTOR 0.2, MAX_FACTOR 10, rms norm, scale = atol + max(|y|, |y_new|) rtol), defaults rtol 1e-3 / atol 1e-6.
  * ORC_SOLVER_RK4_KINK / ORC_SOLVER_DP5_KINK restate what the HIP kernels do for a PolynomialStaticLoad (they have no
- * counterpart in the reference): one fixed step per control step, split where omega is predicted to reach a kink of the
- * load torque (|omega| = omega_lim), see integrate_kink().
+ * counterpart in the reference): one fixed step per control step on a smooth extension of the load torque, corrected in closed
+ * form for the time omega spends beyond a kink of the load torque (|omega| = omega_lim), see integrate_kink().
  */
 #include <math.h>
 #include <stdint.h>
@@ -432,85 +432,98 @@ static void ivp_rk45(const orc_params *p, orc_env *e, double t_end) {
     e->t = t_end;
 }
 
-/* What the HIP kernels do for a PolynomialStaticLoad (gemx_kernels.hpp integrate<>): the load torque's constant term is the
- * saturation clamp(J / tau_decay * omega, -a, a) (polynomial_static_load.py:87-92), i.e. the right-hand side has kinks at
- * |omega| = omega_lim, where a fixed step loses its order (scipy's adaptive solvers split their steps there).  A control step is
- * therefore cut at the instants omega is PREDICTED (first order, from d omega / dt at the start of the piece) to reach the next
- * kink in its direction of travel; each piece is one step of the scheme.  At most 3 pieces. */
-static void fixed_step(const orc_params *p, orc_env *e, int dp5, double h) {
+/* What the HIP kernels do for a PolynomialStaticLoad under GEMX_SOLVER_SPLIT_KINKS (gemx_kernels.hpp integrate<>, KinkPath): the load
+ * torque's constant term is the saturation sigma(omega) = clamp(J / tau_decay * omega, -a, a) (polynomial_static_load.py:87-92), i.e. the
+ * right-hand side has kinks at |omega| = omega_lim, where a fixed step loses its order (scipy's adaptive solvers split their steps
+ * there).  ONE step of the scheme per (sub-)step, on a smooth system: sigma replaced by the affine piece c0 + c1 omega of the region the
+ * Euler-predicted mid-step omega lies in; then the defect D = omega_true - omega_model, D' = -(1 / tau_decay) [clamp(omega) - phi_m(omega)],
+ * integrated to first order along the model's omega path (cubic Hermite through both ends with both end slopes) in closed form and
+ * added to omega.  Same operations in the same order as the kernels (their fp64 build agrees to 1e-9: tests). */
+static void system_equation_m(const orc_params *p, const orc_env *e, const double *y, double *dy, int model, double c0, double c1) {
+    if (!model) { system_equation(p, e, y, dy); return; }
+    const double w = y[0];
+    const double tl = p->load_c * (w * fabs(w)) + p->load_b * w + (c1 * w + c0);
+    dy[0] = (motor_torque(p, y + 1) - tl) * (1.0 / p->j_total);
+    electrical_ode(p, e, y + 1, e->u, w, dy + 1);
+}
+/* one step of the scheme for the model system, first stage k1 given */
+static void fixed_step_m(const orc_params *p, orc_env *e, int dp5, double h, const double *k1, int model, double c0, double c1) {
     int n = n_ode(p);
-    double k1[ORC_MAX_ODE], k2[ORC_MAX_ODE], k3[ORC_MAX_ODE], k4[ORC_MAX_ODE], k5[ORC_MAX_ODE], k6[ORC_MAX_ODE], yt[ORC_MAX_ODE];
-    system_equation(p, e, e->y, k1);
+    double k2[ORC_MAX_ODE], k3[ORC_MAX_ODE], k4[ORC_MAX_ODE], k5[ORC_MAX_ODE], k6[ORC_MAX_ODE], yt[ORC_MAX_ODE];
     if (!dp5) {
         for (int i = 0; i < n; ++i) yt[i] = e->y[i] + 0.5 * h * k1[i];
-        system_equation(p, e, yt, k2);
+        system_equation_m(p, e, yt, k2, model, c0, c1);
         for (int i = 0; i < n; ++i) yt[i] = e->y[i] + 0.5 * h * k2[i];
-        system_equation(p, e, yt, k3);
+        system_equation_m(p, e, yt, k3, model, c0, c1);
         for (int i = 0; i < n; ++i) yt[i] = e->y[i] + h * k3[i];
-        system_equation(p, e, yt, k4);
-        for (int i = 0; i < n; ++i) e->y[i] = e->y[i] + h / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+        system_equation_m(p, e, yt, k4, model, c0, c1);
+        for (int i = 0; i < n; ++i) e->y[i] = e->y[i] + h / 6.0 * (k1[i] + 2.0 * (k2[i] + k3[i]) + k4[i]);
         return;
     }
     for (int i = 0; i < n; ++i) yt[i] = e->y[i] + h * (1.0 / 5.0) * k1[i];
-    system_equation(p, e, yt, k2);
+    system_equation_m(p, e, yt, k2, model, c0, c1);
     for (int i = 0; i < n; ++i) yt[i] = e->y[i] + h * (3.0 / 40.0 * k1[i] + 9.0 / 40.0 * k2[i]);
-    system_equation(p, e, yt, k3);
+    system_equation_m(p, e, yt, k3, model, c0, c1);
     for (int i = 0; i < n; ++i) yt[i] = e->y[i] + h * (44.0 / 45.0 * k1[i] - 56.0 / 15.0 * k2[i] + 32.0 / 9.0 * k3[i]);
-    system_equation(p, e, yt, k4);
+    system_equation_m(p, e, yt, k4, model, c0, c1);
     for (int i = 0; i < n; ++i)
         yt[i] = e->y[i] + h * (19372.0 / 6561.0 * k1[i] - 25360.0 / 2187.0 * k2[i] + 64448.0 / 6561.0 * k3[i] - 212.0 / 729.0 * k4[i]);
-    system_equation(p, e, yt, k5);
+    system_equation_m(p, e, yt, k5, model, c0, c1);
     for (int i = 0; i < n; ++i)
         yt[i] = e->y[i] + h * (9017.0 / 3168.0 * k1[i] - 355.0 / 33.0 * k2[i] + 46732.0 / 5247.0 * k3[i] + 49.0 / 176.0 * k4[i] -
                                5103.0 / 18656.0 * k5[i]);
-    system_equation(p, e, yt, k6);
+    system_equation_m(p, e, yt, k6, model, c0, c1);
     for (int i = 0; i < n; ++i)
         e->y[i] = e->y[i] + h * (35.0 / 384.0 * k1[i] + 500.0 / 1113.0 * k3[i] + 125.0 / 192.0 * k4[i] - 2187.0 / 6784.0 * k5[i] +
                                  11.0 / 84.0 * k6[i]);
 }
-static void integrate_kink_substep(const orc_params *p, orc_env *e, int dp5, double h_total) {
-    const int MAX_PIECES = 3;
-    double rem = h_total;
-    const double lim = p->load == ORC_LOAD_POLY_STATIC ? p->load_a / p->j_total * p->tau_decay : 0.0;
-    for (int piece = 0; piece < MAX_PIECES && rem > 0.0; ++piece) {
-        double h = rem;
-        if (p->load == ORC_LOAD_POLY_STATIC && lim > 0.0 && piece + 1 < MAX_PIECES) {
-            double k1[ORC_MAX_ODE];
-            system_equation(p, e, e->y, k1);
-            const double w = e->y[0], dw = k1[0];
-            /* next kink in the direction of travel, strictly ahead of omega */
-            const double margin = 1e-6 * lim;
-            double b = 0.0;
-            int have = 0;
-            if (dw > 0.0) {
-                if (w < -lim - margin) { b = -lim; have = 1; }
-                else if (w < lim - margin) { b = lim; have = 1; }
-            } else if (dw < 0.0) {
-                if (w > lim + margin) { b = lim; have = 1; }
-                else if (w > -lim + margin) { b = -lim; have = 1; }
-            }
-            if (have) {
-                /* second-order prediction of the crossing time: omega(t) ~ w + dw t + 0.5 ddw t^2, with the torque's slope taken from an
-                 * Euler look-ahead of the motor states over the rest of the step and the load's own slope in the current region */
-                double yt[ORC_MAX_ODE];
-                const int n = n_ode(p);
-                for (int i = 0; i < n; ++i) yt[i] = e->y[i] + rem * k1[i];
-                const double dT = (motor_torque(p, yt + 1) - motor_torque(p, e->y + 1)) / rem;
-                const double slope = p->load_b + (fabs(w) <= lim ? p->j_total / p->tau_decay : 0.0) + 2.0 * p->load_c * fabs(w);
-                const double ddw = (dT - slope * dw) / p->j_total;
-                const double disc = dw * dw + 2.0 * ddw * (b - w);
-                double tc = 2.0 * rem;
-                if (disc >= 0.0) tc = 2.0 * (b - w) / (dw + copysign(sqrt(disc), dw));
-                if (tc < rem * 0.999) h = fmax(tc, h_total * (1.0 / 64.0));
-                if (h > rem) h = rem;
-            }
-        }
-        fixed_step(p, e, dp5, h);
-        rem -= h;
-    }
-    if (rem > 0.0) fixed_step(p, e, dp5, rem);
+static double clamp3(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
+/* KinkPath::ramp: U(c) = int_0^1 (s(th) - c)_+ dth along s = w + V0 th + c2 th^2 + c3 th^3; the crossing instant from the quadratic
+ * through both ends with the start slope (U is stationary in it) */
+typedef struct { double w, w1, V0, V0sq, q4, c2t, c3q, hV0, M; int up; } kink_path;
+static double kink_ramp(const kink_path *k, double c) {
+    const double cs = c - k->w;
+    const double sq = sqrt(fmax(k->q4 * cs + k->V0sq, 0.0));
+    const double th = fmin(fmax((cs + cs) * (1.0 / (k->V0 + (k->up ? sq : -sq))), 0.0), 1.0);
+    const double Q = (((k->c3q * th + k->c2t) * th + k->hV0) * th + -cs) * th;
+    const double Mc = k->M - c;
+    const int a0 = k->w >= c, a1 = k->w1 >= c;
+    return (a0 & a1) ? Mc : ((a0 | a1) ? (k->up ? Mc - Q : Q) : 0.0);
 }
-/* `nsteps` equal sub-steps per segment, each cut at the kinks on its own (gemx_kernels.hpp integrate<>: `for s < ns`); the env's clock
+static void integrate_kink_substep(const orc_params *p, orc_env *e, int dp5, double h) {
+    const double lim = p->load == ORC_LOAD_POLY_STATIC ? p->load_a / p->j_total * p->tau_decay : 0.0;
+    double k1[ORC_MAX_ODE];
+    system_equation(p, e, e->y, k1);
+    if (!(lim > 0.0)) { /* no kink at all (gemx_create leaves the flag off): the plain scheme on the true system */
+        fixed_step_m(p, e, dp5, h, k1, 0, 0.0, 0.0);
+        return;
+    }
+    const double kap = p->j_total / p->tau_decay, inv_j = 1.0 / p->j_total, a = p->load_a;
+    const double w = e->y[0];
+    const double wmid = 0.5 * h * k1[0] + w;
+    const int band = fabs(wmid) < lim;
+    const double c1 = band ? kap : 0.0, c0 = band ? 0.0 : copysign(a, wmid);
+    k1[0] = (clamp3(kap * w, -a, a) - (c1 * w + c0)) * inv_j + k1[0]; /* first stage of the model system */
+    fixed_step_m(p, e, dp5, h, k1, 1, c0, c1);
+    const double w1 = e->y[0], phi_lim = copysign(lim, wmid);
+    const int needs = (clamp3(w, -lim, lim) != (band ? w : phi_lim)) | (clamp3(w1, -lim, lim) != (band ? w1 : phi_lim));
+    if (!needs) return;
+    double ke[ORC_MAX_ODE];
+    system_equation_m(p, e, e->y, ke, 1, c0, c1); /* (only its load derivative is used: the end slope of omega) */
+    const double V0 = h * k1[0], V1 = h * ke[0], dl = w1 - w;
+    const double c2 = 3.0 * dl - 2.0 * V0 - V1, c3 = V0 + V1 - 2.0 * dl;
+    const kink_path kp = {w, w1, V0, V0 * V0, 4.0 * (dl - V0), c2 * (1.0 / 3.0), c3 * 0.25, 0.5 * V0,
+                          w + 0.5 * V0 + c2 * (1.0 / 3.0) + c3 * 0.25, w1 > w};
+    const double lev = (kp.up ? (w < -lim) : !(w > lim)) ? -lim : lim, oth = -lev;
+    const double U1 = kink_ramp(&kp, lev);
+    const int o0 = w >= oth, o1 = w1 >= oth;
+    double U2 = (o0 & o1) ? kp.M - oth : 0.0;
+    if (o0 != o1) U2 = kink_ramp(&kp, oth);
+    const double Up = lev > 0.0 ? U1 : U2, Um = lev > 0.0 ? U2 : U1;
+    const double D = -(h * (1.0 / p->tau_decay)) * ((Um - Up - lim) - (band ? kp.M : phi_lim));
+    e->y[0] = w1 + D;
+}
+/* `nsteps` equal sub-steps per segment, each corrected on its own (gemx_kernels.hpp integrate<>: `for s < ns`); the env's clock
  * advances to the segment end like in every other solver (the converter's dead-time bookkeeping and the RC supply read it) */
 static void integrate_kink(const orc_params *p, orc_env *e, int dp5, double t_end) {
     const int ns = p->nsteps > 1 ? p->nsteps : 1;

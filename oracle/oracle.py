@@ -80,7 +80,7 @@ _SOLVER = {"euler": (SOLVER_EULER, 1), "euler4": (SOLVER_EULER, 4), "rk4": (SOLV
            "dopri5": (SOLVER_DOPRI5, 1), "dp5_fixed": (SOLVER_DP5_FIXED, 1),
            # scipy.integrate.solve_ivp(method="RK45") as ScipySolveIvpSolver drives it (solvers.py:187-219); tolerances below
            "ivp": (SOLVER_IVP_RK45, 1), "ivp_tight": (SOLVER_IVP_RK45, 1),
-           # what the HIP kernels do for a PolynomialStaticLoad: a fixed step split at the load's kinks (no reference counterpart)
+           # what the HIP kernels do for a PolynomialStaticLoad: a fixed step corrected for the load's kinks in closed form (no reference counterpart)
            "rk4_kink": (SOLVER_RK4_KINK, 1), "dp5_kink": (SOLVER_DP5_KINK, 1)}
 _IVP_TOL = {"ivp": (1e-3, 1e-6), "ivp_tight": (1e-10, 1e-12)}  # solve_ivp defaults | oracle/make_golden.py:make_solver("ivp_tight")
 _MP_KEYS = {SYS_DC: ("r_a", "l_a", "psi_e"), SYS_PMSM: ("p", "l_d", "l_q", "r_s", "psi_p"),

@@ -1849,6 +1849,40 @@ def test_rccl_gather_of_real_rollout_outputs_in_a_world_of_one():
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
+@pytest.mark.timeout(600)
+def test_bench_multi_gpu_code_path_through_rccl_in_a_world_of_one():
+    """The exact code path of the driver's scaling run (`torchrun ... bench.py --gpus N`: process group on `nccl`, barriers, the
+    max-over-ranks all-reduce, the bounded `chunk` gather leg with its `rccl` record, `config5`) executed on ONE GPU: WORLD_SIZE=1 in the
+    environment makes bench.py initialise torch.distributed exactly as for N > 1.  The line must carry value, roofline (one clock:
+    value x bytes per env-step == roofline.achieved), rccl.world_seen / bytes_per_rank / GB_per_s, and the gathered chunk's own slot
+    must be this rank's outputs bit for bit."""
+    import json
+    import subprocess
+    import sys
+
+    from gym_electric_motor_amd.distributed import free_port
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--gather", "chunk", "--config5", "on",
+           "--no-extras", "--no-pmc", "--settle-ms", "5", "--repeats", "1", "--steps-per-launch", "200"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["backend"] == "nccl"
+    rf = line["roofline"]
+    # one clock: value (env-steps/s) x algorithmic bytes per env-step of a launch == roofline.achieved
+    per_env_step = rf["algorithmic_bytes_per_launch"] / (16384 * 200)
+    assert abs(line["value"] * per_env_step / 1e9 / rf["achieved"] - 1) < 1e-9
+    rc = line["rccl"]
+    assert "error" not in rc, rc
+    assert rc["world_seen"] == 1 and rc["backend"] == "nccl" and rc["own_slot_bit_identical"] is True
+    assert rc["bytes_per_rank"] == 16384 * 200 * 57 and rc["GB_per_s"] > 0 and rc["ms"] > 0
+    assert line["gather"]["chunk"]["value"] > 0 and "error" not in line["config5"] and line["config5"]["envs_per_gpu"] == 32768
+    assert line["overrides"] == {k: v for k, v in os.environ.items() if k.startswith("GEMX_")}
+
+
 def test_bind_step_is_simulate_without_the_argument_handling():
     """PhysicalSystem.bind_step(action_buffer): the closed loop's pre-bound FFI call.  Same launches as simulate() -- bit-identical
     observations and done flags, step counter advanced, the internal observation tensor returned -- and it refuses a buffer the kernel
