@@ -82,10 +82,11 @@ __global__ void reset_kernel(R *state, typename Angle<R>::T *angle, const uint8_
     if (P.init_kind) {
         const uint32_t count = rcnt[env] + 1u;
         rcnt[env] = count;
-        double u[GEMX_MAX_ODE];
-        init_uniforms(rinit, env, count, u);
-        for (int j = 0; j < nd; ++j) y0[j] = init_state_from_uniform(rinit, j, u[j]);
-        if (has_angle) eps0 = init_state_from_uniform(rinit, nd, u[nd]);
+        double v[GEMX_MAX_ODE];
+        if (sys == GEMX_SYS_SCIM || sys == GEMX_SYS_DFIM) init_draw_all<true>(rinit, env, count, v);
+        else init_draw_all<false>(rinit, env, count, v);
+        for (int j = 0; j < nd; ++j) y0[j] = v[j];
+        if (has_angle) eps0 = v[nd];
     }
     for (int j = 0; j < nd; ++j) state[(int64_t)j * N + env] = (R)y0[j];
     if (P.rc_supply) {  // RCVoltageSupply.reset (voltage_supplies.py:108-114): capacitor loaded, the supply's clock at 0
@@ -459,6 +460,10 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
                         cfg->action_frame);
     }
     if (cfg->init_kind < GEMX_INIT_CONST || cfg->init_kind > GEMX_INIT_GAUSSIAN) return fail(GEMX_ERR_ARG, "unknown init_kind");
+    if (cfg->init_flux_mode != 0 && !(cfg->init_flux_mode == 1 && (s == GEMX_SYS_SCIM || s == GEMX_SYS_DFIM) && cfg->init_kind != GEMX_INIT_CONST))
+        return fail(GEMX_ERR_ARG, "init_flux_mode is 0, or 1 for a SCIM / DFIM system with a random init_kind");
+    if (cfg->init_flux_mode == 1 && !(cfg->init_flux[1] > 0 && cfg->init_flux[5] > 0))
+        return fail(GEMX_ERR_ARG, "init_flux_mode = 1 needs init_flux[1] (pole pairs) and init_flux[5] (l_m / l_r) positive");
     if (cfg->init_kind != GEMX_INIT_CONST) {
         const int n_ode = (s == GEMX_SYS_DC_PERMEX || s == GEMX_SYS_DC_SERIES) ? 2 : ((s == GEMX_SYS_DC_SHUNT || s == GEMX_SYS_DC_EXTEX) ? 3 :
                           (s == GEMX_SYS_SYNC ? 4 : (s == GEMX_SYS_EESM ? 5 : 6)));
@@ -466,9 +471,9 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
             if (cfg->init_lo[j] > cfg->init_hi[j]) return fail(GEMX_ERR_ARG, "init_lo[%d] > init_hi[%d]", j, j);
             if (cfg->init_lo[j] < cfg->init_hi[j]) {
                 if (cfg->init_kind == GEMX_INIT_GAUSSIAN && !(cfg->init_sigma[j] > 0)) return fail(GEMX_ERR_ARG, "init_sigma[%d] must be positive", j);
-                if (j > 0 && (s == GEMX_SYS_SCIM || s == GEMX_SYS_DFIM))
-                    return fail(GEMX_ERR_ARG, "random MOTOR initial states are not available for the induction-motor systems (flux limits, "
-                                              "induction_motor.py:314-364, are not on the accelerated path); the load's omega is");
+                if (j > 0 && (s == GEMX_SYS_SCIM || s == GEMX_SYS_DFIM) && cfg->init_flux_mode != 1)
+                    return fail(GEMX_ERR_ARG, "random MOTOR initial states of an induction-motor system need init_flux_mode = 1 (the flux "
+                                              "bounds are re-derived at every reset: induction_motor.py:250-285)");
                 if (j == 0 && cfg->load_kind == GEMX_LOAD_CONST_SPEED)
                     return fail(GEMX_ERR_ARG, "a ConstantSpeedLoad has no random initial omega (constant_speed_load.py:30-38)");
             }
@@ -576,6 +581,9 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
                 I.cdf_hi[j] = 0.5 * erfc(-(I.hi[j] - I.mu[j]) / I.sigma[j] / sqrt(2.0));
             }
         }
+        I.flux_mode = cfg->init_flux_mode;
+        I.flux_slot = 3;  // [omega, i_s alpha, i_s beta, psi_r alpha, psi_r beta, epsilon]
+        for (int j = 0; j < 8; ++j) I.flux[j] = cfg->init_flux[j];
         if (hipMalloc(&h->rinit_dev, sizeof(InitDev)) != hipSuccess || hipMalloc((void **)&h->rcnt, sizeof(uint32_t) * (size_t)h->n) != hipSuccess)
             return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(random initialiser) failed"));
         if (hipMemcpy(h->rinit_dev, &I, sizeof(I), hipMemcpyHostToDevice) != hipSuccess || hipMemset(h->rcnt, 0, sizeof(uint32_t) * (size_t)h->n) != hipSuccess)

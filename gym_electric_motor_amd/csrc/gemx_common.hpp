@@ -244,6 +244,10 @@ struct InitDev {
     uint64_t seed;
     double lo[GEMX_MAX_ODE], hi[GEMX_MAX_ODE], mu[GEMX_MAX_ODE], sigma[GEMX_MAX_ODE], constant[GEMX_MAX_ODE];
     double cdf_lo[GEMX_MAX_ODE], cdf_hi[GEMX_MAX_ODE];  // gaussian: Phi((lo - mu) / sigma), Phi((hi - mu) / sigma), computed on the host
+    // induction machines (gemx_config.init_flux_mode): the two flux states' bounds are re-derived at every reset from a random field
+    // angle; lo / hi of their slots then hold the user's `interval` (+-HUGE_VAL = none), flux[] = gemx_config.init_flux
+    int32_t flux_mode, flux_slot;  // first flux slot (ODE index of psi_r alpha)
+    double flux[8];
 };
 // inverse of the standard normal CDF: Wichura's algorithm AS 241 (PPND16, |rel err| < 1e-16) -- a few rational polynomials instead
 // of the library's normcdfinv expansion, because this code is inlined into every advance kernel's (rare) auto-reset path
@@ -291,6 +295,48 @@ __device__ __forceinline__ void init_uniforms(const InitDev *I, int64_t env, uin
     Philox::block(I->seed, (uint64_t)env, count, 1u, r1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { u[i] = Philox::u01(r0[i]); u[4 + i] = Philox::u01(r1[i]); }
+}
+// one state from its uniform with explicit bounds (the induction machines' per-reset flux bounds)
+__device__ __forceinline__ double init_draw_bounded(const InitDev *I, int j, double lo, double hi, double u) {
+    if (!(lo < hi)) return lo;  // (upper - lower) * u + lower of a degenerate interval
+    if (I->kind == GEMX_INIT_UNIFORM) return lo + (hi - lo) * u;
+    // electric_motor.py:236-249: mue = random_params[0] or the middle of the interval, sigma = random_params[1] or 1 (mu[j] = NaN: middle)
+    const double mu = I->mu[j] == I->mu[j] ? I->mu[j] : 0.5 * (hi - lo) + lo, sg = I->sigma[j];
+    const double cl = 0.5 * erfc(-(lo - mu) / sg * 0.70710678118654752440), ch = 0.5 * erfc(-(hi - mu) / sg * 0.70710678118654752440);
+    return fmin(fmax(mu + sg * inv_norm_cdf(cl + (ch - cl) * u), lo), hi);
+}
+// THE draw of one reset: out[0 .. n-1] = the ODE states (+ the angle in slot n - 1 when the system has one) of (env, reset count).
+// Induction machines (flux_mode; induction_motor.py:174-185, 250-285, squirrel_cage_induction_motor.py:146-157): a field angle
+// eps_mag ~ U(-pi, pi) from uniform 7, psi_d_max from this reset's omega -- and, for omega != 0, from the stator currents of the
+// PREVIOUS reset's draw (the reference reads the motor's stale _initial_states; the counter-based stream lets the kernel recompute
+// them instead of storing them) --, flux bounds +-psi_d_max (|cos|, |sin|) clipped to the user's interval.
+// FLUX: compiled in for the induction-machine systems only (the code sits in every kernel's auto-reset path).
+template <bool FLUX>
+__device__ __forceinline__ void init_draw_all(const InitDev *I, int64_t env, uint32_t count, double (&out)[GEMX_MAX_ODE]) {
+    double u[GEMX_MAX_ODE];
+    init_uniforms(I, env, count, u);
+    for (int j = 0; j < I->n && j < GEMX_MAX_ODE; ++j) out[j] = init_state_from_uniform(I, j, u[j]);
+    if (FLUX && I->flux_mode) {
+        const int fs = I->flux_slot;  // slots fs - 2, fs - 1: i_s alpha, i_s beta
+        const double eps = 6.283185307179586476925286766559 * u[7] - 3.141592653589793238462643383279;
+        const double ce = cos(eps), se = sin(eps), om = out[0];
+        double psi = I->flux[0];
+        if (om != 0.0) {
+            double ia = I->constant[fs - 2], ib = I->constant[fs - 1];
+            if (count > 1u) {
+                double up[GEMX_MAX_ODE];
+                init_uniforms(I, env, count - 1u, up);
+                ia = init_state_from_uniform(I, fs - 2, up[fs - 2]);
+                ib = init_state_from_uniform(I, fs - 1, up[fs - 1]);
+            }
+            const double id = ce * ia + se * ib, iq = -se * ia + ce * ib;  // q_inv(i_alphabeta, eps_mag)
+            psi = (I->flux[1] * om * I->flux[2] * id + I->flux[3] * iq + I->flux[4]) / (-I->flux[1] * om * I->flux[5]);
+            psi = 0.9 * fmin(fmax(psi, 0.0), fabs(I->flux[6] * id));
+        }
+        const double ha = fabs(psi * ce), hb = fabs(psi * se);
+        out[fs] = init_draw_bounded(I, fs, fmax(-ha, I->lo[fs]), fmin(ha, I->hi[fs]), u[fs]);
+        out[fs + 1] = init_draw_bounded(I, fs + 1, fmax(-hb, I->lo[fs + 1]), fmin(hb, I->hi[fs + 1]), u[fs + 1]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

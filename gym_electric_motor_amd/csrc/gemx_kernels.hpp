@@ -1268,11 +1268,11 @@ __device__ __forceinline__ void draw_initial_state(const KArgs<R> &a, int64_t en
     constexpr int ND = SysTraits<SYS>::ND;
     const uint32_t count = a.rcnt[env] + 1u;
     a.rcnt[env] = count;
-    double u[GEMX_MAX_ODE];
-    init_uniforms(a.rinit, env, count, u);
+    double v[GEMX_MAX_ODE];
+    init_draw_all<SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM>(a.rinit, env, count, v);
 #pragma unroll
-    for (int j = 0; j < ND; ++j) y[j] = (R)init_state_from_uniform(a.rinit, j, u[j]);
-    if (SysTraits<SYS>::HAS_ANGLE) ang = Angle<R>::from_rad(init_state_from_uniform(a.rinit, ND, u[ND]));
+    for (int j = 0; j < ND; ++j) y[j] = (R)v[j];
+    if (SysTraits<SYS>::HAS_ANGLE) ang = Angle<R>::from_rad(v[ND]);
 }
 
 // the same draw with the env's reset counter held in a register (pipelined kernel: no global memory traffic besides the description)
@@ -1281,11 +1281,11 @@ __device__ __forceinline__ void draw_initial_state_cnt(const InitDev *rinit, int
                                                        typename Angle<R>::T &ang) {
     constexpr int ND = SysTraits<SYS>::ND;
     count += 1u;
-    double u[GEMX_MAX_ODE];
-    init_uniforms(rinit, env, count, u);
+    double v[GEMX_MAX_ODE];
+    init_draw_all<SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM>(rinit, env, count, v);
 #pragma unroll
-    for (int j = 0; j < ND; ++j) y[j] = (R)init_state_from_uniform(rinit, j, u[j]);
-    if (SysTraits<SYS>::HAS_ANGLE) ang = Angle<R>::from_rad(init_state_from_uniform(rinit, ND, u[ND]));
+    for (int j = 0; j < ND; ++j) y[j] = (R)v[j];
+    if (SysTraits<SYS>::HAS_ANGLE) ang = Angle<R>::from_rad(v[ND]);
 }
 
 // step() for the single-wave kernel

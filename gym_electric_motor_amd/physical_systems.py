@@ -415,11 +415,17 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         """Random initialisers (`motor_initializer` / `load_initializer` with random_init='uniform' | 'gaussian'): per-ODE-state
         sampling bounds exactly as electric_motor.py:199-227 / mechanical_load.py:117-130 derive them -- upper = nominal value of the
         state, lower = upper * state_space.low, both clipped to `interval` -- in the ODE slot order the reference fills (the VALUES of
-        the `states` dict in dict order, electric_motor.py:270-285)."""
+        the `states` dict in dict order, electric_motor.py:270-285).
+        Induction machines (electric_motor.py:197-211: bounds from `_initial_limits` = the nominal values, lower = -upper for every
+        state): the stator currents and the angle are static bounds like everyone else's; the two FLUX bounds are re-derived at every
+        reset from a random field angle (induction_motor.py:174-185, 250-285) -- gemx_config.init_flux_mode / init_flux carry what
+        that needs, and the flux slots' init_lo / init_hi hold the user's `interval` only."""
         pos, low = self._state_positions, np.asarray(self._state_space.low, dtype=float)
         kinds = set()
+        mot = self._electrical_motor
+        induction = _is_a(mot, "SquirrelCageInductionMotor") or _is_a(mot, "DoublyFedInductionMotor") or _is_a(mot, "InductionMotor")
 
-        def bounds(component, nominal_of, slot0):
+        def bounds(component, nominal_of, slot0, symmetric=False):
             ini = getattr(component, "initializer", None) or {}
             dist = ini.get("random_init")
             if dist is None:
@@ -429,24 +435,41 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             interval = ini.get("interval")
             mue, sigma = (ini.get("random_params") or (None, None))
             for k_, name in enumerate(names):
-                up = float(nominal_of(name))
-                lo = up * low[pos[name]] if name in pos else -up  # epsilon etc. are system states too
+                flux = symmetric and name.startswith("psi_")
+                if flux:
+                    lo, up = -math.inf, math.inf  # this reset's +-psi_d_max (|cos|, |sin|) on the device, clipped to the interval below
+                else:
+                    up = abs(float(nominal_of(name))) if symmetric else float(nominal_of(name))
+                    lo = -up if symmetric else (up * low[pos[name]] if name in pos else -up)  # epsilon etc. are system states too
                 if interval is not None:
                     iv = np.asarray(interval, dtype=float).reshape(-1, 2)
                     lo, up = max(lo, iv[k_][0]), min(up, iv[k_][1])
                 j = slot0 + k_
                 cfg.init_lo[j], cfg.init_hi[j] = lo, up
-                cfg.init_mu[j] = float(mue) if mue else (up - lo) / 2 + lo
+                cfg.init_mu[j] = float(mue) if mue else (math.nan if flux else (up - lo) / 2 + lo)  # (NaN: the middle of this reset's bounds)
                 cfg.init_sigma[j] = float(sigma) if sigma else 1.0
 
         ld = self._mechanical_load
         bounds(ld, lambda n: self._nominal_state[pos[n]], 0)
-        mot = self._electrical_motor
-        bounds(mot, lambda n: mot.nominal_values[n], 1)
+        bounds(mot, lambda n: mot.nominal_values[n], 1, symmetric=induction)
         if len(kinds) > 1:
             raise ValueError("motor and load initialisers must use the same distribution on the accelerated path")
         cfg.init_kind = {"uniform": _lib.INIT_UNIFORM, "gaussian": _lib.INIT_GAUSSIAN}[kinds.pop()] if kinds else _lib.INIT_CONST
         cfg.seed = self._seed
+        if induction and (getattr(mot, "initializer", None) or {}).get("random_init") is not None:
+            names = list(((mot.initializer or {}).get("states") or {}).keys())
+            if names[:4] != ["i_salpha", "i_sbeta", "psi_ralpha", "psi_rbeta"]:
+                raise ValueError(f"induction-motor initialiser states {names}: the accelerated path expects the reference's order "
+                                 "i_salpha, i_sbeta, psi_ralpha, psi_rbeta, epsilon (induction_motor.py:107-118)")
+            mp, nv = mot.motor_parameter, mot.nominal_values
+            l_s, l_r = mp["l_m"] + mp["l_sigs"], mp["l_m"] + mp["l_sigr"]
+            l_mr = mp["l_m"] / l_r
+            sigma_l = (l_s * l_r - mp["l_m"] ** 2) / (l_s * l_r)
+            u_rq = float(nv.get("u_rq", 0.0)) if _is_a(mot, "DoublyFedInductionMotor") else 0.0  # doubly_fed_induction_motor.py:158-163
+            vals = [mp["l_m"] * nv["i_sd"], mp["p"], sigma_l * l_s, mp["r_s"] + mp["r_r"] * l_mr ** 2, nv["u_sq"] + l_mr * u_rq, l_mr, mp["l_m"], 0.0]
+            cfg.init_flux_mode = 1
+            for i, v in enumerate(vals):
+                cfg.init_flux[i] = float(v)
 
     # ------------------------------------------------------------------ device plumbing (torch = memory + streams)
     def _create(self):

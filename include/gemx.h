@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GEMX_ABI_VERSION 4 /* 2: GEMX_MAX_OUT 16 -> 24 (DFIM system, 24 states); 3: gemx_config.solver_flags; 4: solver_rtol / solver_atol */
+#define GEMX_ABI_VERSION 5 /* 2: GEMX_MAX_OUT 16 -> 24 (DFIM system, 24 states); 3: gemx_config.solver_flags; 4: solver_rtol / solver_atol; 5: init_flux_mode / init_flux */
 #define GEMX_MAX_ODE 8  /* ODE state length incl. omega and the angle      */
 #define GEMX_MAX_OUT 24 /* system-state (observation) length               */
 #define GEMX_MODEL_ROWS 5
@@ -132,9 +132,18 @@ typedef struct gemx_config {
      * (scipy.stats.truncnorm in the reference) -- from a counter-based Philox4x32-10 stream keyed by `seed` and indexed by
      * (env, number of resets of that env, j); states with lo == hi keep init_state[j].  numpy's PCG64 streams of the reference
      * cannot be reproduced on a device: parity is distributional (tests/test_gpu_parity.py), and exact for the state -> reset
-     * observation map.  DC, synchronous and EESM systems (the induction motors' flux limits, induction_motor.py:314-364, are
-     * not on the accelerated path); the load's omega for any system with a PolynomialStaticLoad. */
+     * observation map.  Every system; the load's omega for any system with a PolynomialStaticLoad.
+     * Induction machines (SCIM, DFIM; ABI 5): init_flux_mode = 1 re-derives the bounds of the two flux states at EVERY reset as the
+     * reference does (induction_motor.py:174-185, 250-285; squirrel_cage_induction_motor.py:146-157; doubly_fed_induction_motor.py:
+     * 154-165): a field angle eps_mag ~ U(-pi, pi) is drawn, psi_d_max = init_flux[0] (= l_m * nominal i_sd) if this reset's omega
+     * is 0, else 0.9 * clip((p omega sigma l_s i_d + (r_s + r_r l_mr^2) i_q + u_q_max + l_mr u_rq_max) / (-p omega l_mr), 0,
+     * |l_m i_d|) with (i_d, i_q) = Q^-1(i_s alpha/beta OF THE PREVIOUS RESET'S DRAW -- the configured constants at the first reset --,
+     * eps_mag) (the reference reads the motor's stale `_initial_states` there), and the flux states are drawn from
+     * +-psi_d_max * (|cos eps_mag|, |sin eps_mag|) clipped to [init_lo, init_hi] of their slots (the user's `interval`;
+     * +-HUGE_VAL = none).  init_flux = [l_m * i_sd_nominal, p, sigma * l_s, r_s + r_r * l_mr^2, u_q_max + l_mr * u_rq_max, l_mr, l_m, 0]. */
     int32_t init_kind;
+    int32_t init_flux_mode;
+    double init_flux[8];
     uint64_t seed;
     double init_lo[GEMX_MAX_ODE], init_hi[GEMX_MAX_ODE], init_mu[GEMX_MAX_ODE], init_sigma[GEMX_MAX_ODE];
     double supply_r, supply_c;

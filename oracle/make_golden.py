@@ -374,6 +374,8 @@ def main(only=None):
         main_supply()
     if not only or "init" in only:
         init_samples()
+    if only and "init_r04" in only:
+        init_samples(only=INIT_CASES_R04)
     if not only or "wiener" in only:
         wiener_samples()
     if not only or "r02" in only:
@@ -578,17 +580,37 @@ INIT_CASES = {
                           dict(random_init="gaussian", random_params=(100.0, 60.0))),
     "extex_cc_uniform_interval": ("Cont-CC-ExtExDc-v0", dict(random_init="uniform", interval=[[-20.0, 60.0], [0.0, 10.0]]), None),
     "eesm_sc_uniform": ("Cont-SC-EESM-v0", dict(random_init="uniform"), dict(random_init="uniform", interval=[[-100.0, 300.0]])),
+    # round 4: induction machines -- the flux bounds are re-derived at every reset from a random field angle (induction_motor.py:174-185,
+    # 250-285).  omega == 0 (the SC envs): psi_d_max = l_m i_sd_nominal; omega != 0: from the PREVIOUS reset's stator currents, clipped
+    # (at the CC envs' +100 rad/s the clip leaves 0 -- every flux draw is 0 --, so the live branch is recorded at -100 rad/s)
+    "scim_sc_uniform": ("Cont-SC-SCIM-v0", dict(random_init="uniform"), None),
+    "scim_cc_uniform": ("Cont-CC-SCIM-v0", dict(random_init="uniform"), None),
+    "scim_cc_negspeed_uniform": ("Cont-CC-SCIM-v0", dict(random_init="uniform"), None, dict(omega_fixed=-100.0)),
+    "dfim_cc_negspeed_interval_uniform": ("Cont-CC-DFIM-v0", dict(random_init="uniform", interval=[[-5.0, 6.0], [-7.5, 7.5], [-0.8, 1.5], [-2.0, 0.4], [-1.0, 2.0]]),
+                                          None, dict(omega_fixed=-60.0)),
 }
+INIT_CASES_R04 = ("scim_sc_uniform", "scim_cc_uniform", "scim_cc_negspeed_uniform", "dfim_cc_negspeed_interval_uniform")
 
 
-def init_samples(n=4000):
+def init_samples(n=4000, only=None):
     """random initialisers.  The reference's numpy streams cannot be reproduced on a device, so the fixture holds
-    SAMPLES of the initial ODE state the reference draws (physical_system.reset() n times) for distributional tests."""
+    SAMPLES of the initial ODE state the reference draws (physical_system.reset() n times) for distributional tests.
+    only: regenerate just these cases and keep the file's other entries (round 4 added the induction machines this way)."""
+    path = os.path.join(OUT, "init_samples.npz")
     out = {}
-    for name, (env_id, mi, li) in INIT_CASES.items():
+    if only is not None and os.path.exists(path):
+        old = np.load(path)
+        out = {k: old[k] for k in old.files}
+    for name, case in INIT_CASES.items():
+        if only is not None and name not in only:
+            continue
+        env_id, mi, li = case[:3]
         kw = dict(motor=dict(motor_initializer=mi))
         if li is not None:
             kw["load"] = dict(load_initializer=li)
+        if len(case) > 3:
+            kw["load"] = dict(kw.get("load", {}), **case[3])
+        np.random.seed(4021)  # InductionMotor._update_initial_limits draws its field angle from the GLOBAL numpy stream
         env = gem.make(env_id, **kw)
         env.reset(seed=123)
         psys = env.physical_system.unwrapped
@@ -601,7 +623,7 @@ def init_samples(n=4000):
         out[name + "_obs"] = np.asarray(obs)
         out[name + "_meta"] = np.array(json.dumps(dict(describe(env), env_id=env_id, motor_initializer=mi, load_initializer=li)))
         print(f"init samples {name}: y mean {np.asarray(ys).mean(axis=0).round(3)} min {np.asarray(ys).min(axis=0).round(3)} max {np.asarray(ys).max(axis=0).round(3)}")
-    np.savez_compressed(os.path.join(OUT, "init_samples.npz"), **out)
+    np.savez_compressed(path, **out)
 
 
 def wiener_samples(T=400000, n_reset=3000):

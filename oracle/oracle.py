@@ -202,24 +202,28 @@ class OracleEnv:
         return Cm
 
 
-def undefined_field_angle_steps(params, actions, auto_reset=True, flux_floor=1e-9):
+def undefined_field_angle_steps(params, actions, auto_reset=True, flux_floor=1e-9, exact=False):
     """Induction-motor systems report dq quantities in the rotor-flux frame, eps_field = arctan2(psi_rbeta, psi_ralpha)
     (physical_systems.py:765-769 / 918-929).  While the rotor flux is still (numerically) zero -- the first steps after a
     reset -- the reference's angle is the arctan2 of matmul rounding noise (~1e-17 Wb), which no restatement can reproduce.
     Returns a bool mask [K]: True where the flux magnitude at the START of step k is below `flux_floor` [Wb], i.e. where the
-    dq columns of step k are not comparable (everything else, including |i_dq| and the done mask, is)."""
+    dq columns of step k are not comparable (everything else, including |i_dq| and the done mask, is).
+    exact=True: returns (mask, zero) with zero[k] True where that flux is EXACTLY zero -- there arctan2(0, 0) = 0 is this build's
+    (documented) field angle, so its dq columns must equal the alpha-beta quantities."""
     a = np.asarray(actions, dtype=np.float64).reshape(len(actions), -1)
     env = OracleEnv(params)
     env.reset()
     mask = np.zeros(len(a), dtype=bool)
+    zero = np.zeros(len(a), dtype=bool)
     if params.system not in (SYS_SCIM, SYS_DFIM):
-        return mask
+        return (mask, zero) if exact else mask
     for k in range(len(a)):
         mask[k] = np.hypot(env.y[3], env.y[4]) < flux_floor
+        zero[k] = env.y[3] == 0.0 and env.y[4] == 0.0
         obs = env.step(a[k])
         if auto_reset and env.done(obs):
             env.reset()
-    return mask
+    return (mask, zero) if exact else mask
 
 
 DQ_COLUMNS = ("i_sd", "i_sq", "i_rd", "i_rq", "u_sd", "u_sq", "u_rd", "u_rq")

@@ -346,7 +346,42 @@ def test_random_initialiser_bounds_match_reference_support():
                 assert np.ptp(y[:, j]) == 0 and y[0, j] == c.init_state[j]
             else:
                 assert lo <= y[:, j].min() < lo + 0.01 * (hi - lo) and hi - 0.01 * (hi - lo) < y[:, j].max() <= hi
-    # validation in gemx_create: induction-motor states and a constant-speed omega cannot be random
+    # induction machines (round 4): static bounds for currents / angle, the flux slots carry the interval only, and init_flux what the
+    # per-reset flux bounds need (induction_motor.py:250-285); the draw RULE, restated in numpy, passes KS tests against the reference
+    from scipy import stats
+
+    for case in ("scim_sc_uniform", "scim_cc_negspeed_uniform", "dfim_cc_negspeed_interval_uniform"):
+        meta, y = json.loads(str(d[case + "_meta"])), d[case + "_y"]
+        mcls = ga.SquirrelCageInductionMotor if "scim" in case else ga.DoublyFedInductionMotor
+        kw = dict(motor=mcls(motor_initializer=meta["motor_initializer"]), n_envs=2, seed=5, _defer_create=True)
+        if meta["load"] == "ConstantSpeedLoad":
+            kw["load"] = ga.ConstantSpeedLoad(omega_fixed=float(y[0, 0]))
+        c = ga.make(meta["env_id"], **kw).physical_system._cfg
+        mp = meta["motor_parameter"]
+        l_r = mp["l_m"] + mp["l_sigr"]
+        assert c.init_flux_mode == 1 and c.init_flux[1] == mp["p"] and abs(c.init_flux[5] - mp["l_m"] / l_r) < 1e-15 and c.init_flux[6] == mp["l_m"]
+        lo, hi, const, fl = (np.array(x[:8]) for x in (c.init_lo, c.init_hi, c.init_state, c.init_flux))
+        rng, prev, got = np.random.default_rng(3), None, np.zeros((4000, 6))
+        for k in range(4000):  # gemx_common.hpp:init_draw_all, operation by operation
+            u = rng.uniform(size=8)
+            v = np.array([lo[j] + (hi[j] - lo[j]) * u[j] if lo[j] < hi[j] and np.isfinite(lo[j]) else const[j] for j in range(8)])
+            eps = 2 * np.pi * u[7] - np.pi
+            ce, se, psi = np.cos(eps), np.sin(eps), fl[0]
+            if v[0] != 0:
+                ia, ib = (const[1], const[2]) if prev is None else (prev[1], prev[2])
+                i_d, i_q = ce * ia + se * ib, -se * ia + ce * ib
+                psi = 0.9 * min(max((fl[1] * v[0] * fl[2] * i_d + fl[3] * i_q + fl[4]) / (-fl[1] * v[0] * fl[5]), 0.0), abs(fl[6] * i_d))
+            for j, h in ((3, abs(psi * ce)), (4, abs(psi * se))):
+                a, b = max(-h, lo[j]), min(h, hi[j])
+                v[j] = a + (b - a) * u[j] if a < b else a
+            got[k], prev = v[:6], v
+        for j in range(6):
+            if np.ptp(y[:, j]) == 0:
+                assert np.ptp(got[:, j]) == 0 and got[0, j] == y[0, j]
+            else:
+                assert stats.ks_2samp(got[:, j], y[:, j]).pvalue > 1e-3, (case, j)
+        assert stats.ks_2samp(np.hypot(got[:, 3], got[:, 4]), np.hypot(y[:, 3], y[:, 4])).pvalue > 1e-3, case
+    # validation in gemx_create: induction-motor states need the flux mode, and a constant-speed omega cannot be random
     L = _lib.load()
     h = C.c_void_p()
     scim = ga.make("Cont-CC-SCIM-v0", n_envs=2, _defer_create=True).physical_system._cfg
