@@ -101,6 +101,7 @@ template <class R> struct DevParams {
 };
 // smallest t >= 0 with fl(t * c) > 1 (c > 0): see DevParams::dc_thr
 template <class R> inline R viol_threshold(R c) {
+    if (!(c > R(0)) || !std::isfinite(c)) return (R)INFINITY;  // (no finite current violates such a limit; gemx_create rejects it anyway)
     volatile R t = R(1) / c, p = t * c;
     while (p > R(1)) { t = std::nextafter((R)t, R(0)); p = t * c; }
     while (!(p > R(1))) { t = std::nextafter((R)t, (R)INFINITY); p = t * c; }
@@ -496,7 +497,8 @@ struct gemx_handle {
     int steps_per_block = 0;  // 0 = heuristic
     struct LastLaunch { int pipe, sys, conv, load, solver, il, real_size, d, threads, k, s; long long blocks; size_t lds; };
     LastLaunch ll = {};            // most recent advance launch (formatted lazily by gemx_last_launch)
-    mutable char last_launch[256] = "";
+    mutable char last_launch[512] = "";
+    char overrides[192] = "";  // the GEMX_* environment switches that were set when the handle was created ("NAME=value ..."): gemx_last_launch() names them
     unsigned pipe_attr_set = 0;  // bit k: hipFuncSetAttribute(max dynamic LDS) done for pipelined shape k (per handle = per device:
     bool attr_set = false;       //   the attribute is per device, and a handle is bound to one device and one kernel instantiation)
     int wg_per_cu = 0;           // single-wave kernel: resident workgroups per CU from its VGPR count (0: not queried yet)

@@ -1262,7 +1262,10 @@ __device__ __forceinline__ R supply_current(const DevParams<R> &P, const R (&y)[
     return tot;
 }
 
-// in-kernel auto-reset with random initialisers: a fresh initial state for this env, its reset counter advanced (rare path)
+// in-kernel auto-reset with random initialisers: a fresh initial state for this env, its reset counter advanced (rare path).
+// (Round 4 tried this as a real call, `noinline`: advance_kernel's spills went from 41-55 to 2-27 registers -- not to zero, the 256-VGPR
+// cap is the blocked I/O's prefetch and flush registers, not this path -- while step_kernel, which calls it too, went from no scratch
+// at all to 247 VGPRs and 112 bytes of stack for the callee.  Kept inline.)
 template <int SYS, class R>
 __device__ __forceinline__ void draw_initial_state(const KArgs<R> &a, int64_t env, R (&y)[SysTraits<SYS>::ND], typename Angle<R>::T &ang) {
     constexpr int ND = SysTraits<SYS>::ND;
@@ -3670,8 +3673,14 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             D = PIPE_D; OW = PIPE_OUT_WAVES; shape = 0;
             if (h->cur_reward != nullptr || compact_l) { OW = PIPE_OUT_WAVES_RW; shape = 3; }
         }
-        else if ((SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM) && smem_of(PIPE_D3) <= h->lds_max && blocks <= resident(PIPE_D3, PIPE_OUT_WAVES3) &&
+        else if (smem_of(PIPE_D3) <= h->lds_max && blocks <= resident(PIPE_D3, PIPE_OUT_WAVES3) &&
                  blocks > resident(PIPE_D2, PIPE_OUT_WAVES2) && 2 * blocks <= 3 * resident(PIPE_D2, PIPE_OUT_WAVES2)) {
+            // (round 4: EVERY system.  Rounds 2-3 kept this to the induction machines on one sample -- ExtExDc at 131072 envs, which is not
+            // this case at all (two full rounds of <4, 2>) -- but where <4, 2> runs a round plus a tail of at most half a round and <2, 2>
+            // fits everything into one, the interleaved same-box A/B (tools/ab_matrix_shapes.py, profiles/r04c_shapes_ab.md, 65536 envs,
+            // of the roofline) has it ahead almost everywhere: PMSM cont 0.57 -> 0.71, PMSM cont SC 0.50 -> 0.69, ShuntDc 0.61 -> 0.73,
+            // EESM 0.57 -> 0.64 / 0.56 -> 0.61, DqToAbc + DeadTime 0.59 -> 0.75, PermExDc 0.78 -> 0.85, fused reward 0.56 -> 0.62;
+            // level: SeriesDc SC, ExtExDc.)
             // (induction machines only: lighter steppers lose with the shallow shape -- ExtExDc 131072 envs 133 -> 104 G; PMSM finite at
             // 98304 envs, where this rule used to apply: 75.8 G against 84.2 G through <4, 2>, profiles/r03k_shapes_pmsm.md)
             // one resident round with the shallow shape where <4, 2> would run one round plus a tail of at most half a round: SCIM,

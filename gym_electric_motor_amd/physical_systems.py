@@ -495,7 +495,11 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         _lib.check(L.gemx_reset_observation(h, ro))
         self._reset_obs = np.array(ro[: self._n_out], dtype=float)
         # the internal observation buffer starts out as the reset observation of every env (reset(mask) returns it for rows outside the mask)
+        # (random initialisers: gemx_create left the counters at 0 with draw #1 in place, so this is draw #1 AGAIN -- the same states, now with
+        # their observation rows -- and the user's first reset() is draw #2, as before the prefill existed.  Launched on the stream that is
+        # current at construction and waited for, so that a caller stepping on another stream later needs no event.)
         _lib.check(L.gemx_reset(h, None, C.c_void_p(self._obs.data_ptr()), self._stream()))
+        torch.cuda.current_stream(self._tdev).synchronize()
         # closed-loop hot path (simulate() on a device tensor): everything a call needs, bound once
         self._Tensor = torch.Tensor
         self._want_dtype = torch.uint8 if self._discrete else self._tdtype

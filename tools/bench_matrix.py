@@ -4,10 +4,13 @@
     python tools/bench_matrix.py [--envs 16384 131072] [--steps 500] > profiles/<round>_matrix.md
 
 For each case: fused rollouts of `--steps` control steps (observation rows + done bytes written every step, default
-constraints + auto-reset, RK4, fp32, uniformly random actions resident in HBM), mean launch time over 5 launches after
-2 warm-up launches (HIP events on the launch stream), preceded by 60 ms of the same launches so that the clock governor has
-settled (bench.py docstring).  Algorithmic bytes per env-step = action + 4 * S_out + 1
-(+ 4 * n_ref + 4 with the fused reward)."""
+constraints + auto-reset, RK4, fp32, uniformly random actions resident in HBM) timed the way bench.py times its legs (round 4: the
+rows used to be 5 launches behind a 60-ms settle and were not comparable with the bench legs quoted beside them): 60 ms of the same
+launches untimed (clock governor), 2 warm-up launches, then THREE timed regions of >= 4 ms of launches each, bracketed by
+synchronize on both sides and priced by the WALL clock; the MEDIAN region is the row, `min..max` of the three beside it.
+Algorithmic bytes per env-step = action + 4 * S_out + 1 (+ 4 * n_ref + 4 with the fused reward).
+`--solver default` takes the solver make(env_id) hands out (RK4, kink-corrected where the id's load has kinks) instead of plain RK4;
+`--shape S` forces GEMX_PIPE_SHAPE (A/B of the pipelined kernel's shapes over every family); `--only SUBSTR` selects rows."""
 import argparse
 import time
 import os
@@ -48,16 +51,23 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, nargs="+", default=[16384, 131072])
     ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--solver", choices=["rk4", "default"], default="rk4")
+    ap.add_argument("--shape", default=None, help="GEMX_PIPE_SHAPE for every row (0: <12,3>, 1: <4,2>, 2: <2,2>, 3: <12,6>)")
+    ap.add_argument("--only", nargs="*", default=None, help="substrings: run the rows whose label contains one of them")
     args = ap.parse_args()
+    if args.shape is not None:
+        os.environ["GEMX_PIPE_SHAPE"] = args.shape
     import numpy as np
     import torch
 
     import gym_electric_motor_amd as ga
 
     K = args.steps
-    print(f"| case | envs | G env-steps/s | B/env-step | GB/s (algorithmic) | frac of 8 TB/s | kernel |")
-    print("|---|---|---|---|---|---|---|")
+    print(f"| case | envs | G env-steps/s | B/env-step | GB/s (algorithmic) | frac of 8 TB/s | min..max of 3 regions | kernel |")
+    print("|---|---|---|---|---|---|---|---|")
     for label, env_id, kw, with_reward in CASES:
+        if args.only and not any(o in label for o in args.only):
+            continue
         for n in args.envs:
             kw2 = dict(kw)
             if kw2.pop("rc", False):
@@ -65,7 +75,9 @@ def main():
             ws = []
             for wname in kw2.pop("wrappers", ()):
                 ws.append(ga.DeadTimeProcessor(int(wname[4:])) if wname.startswith("dead") else ga.DqToAbcActionProcessor.make("PMSM"))
-            env = ga.make(env_id, n_envs=n, ode_solver=ga.RK4Solver(), physical_system_wrappers=tuple(ws), **kw2)
+            if args.solver == "rk4":
+                kw2["ode_solver"] = ga.RK4Solver()
+            env = ga.make(env_id, n_envs=n, physical_system_wrappers=tuple(ws), **kw2)
             ps = env.physical_system
             g = torch.Generator(device="cuda").manual_seed(1)
             if ps._discrete:
@@ -101,15 +113,25 @@ def main():
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(5):
+            for _ in range(3):
                 launch()
             e1.record()
             torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 5
-            rate = n * K / (ms * 1e-3)
+            nl = max(5, int(4.0 / max(e0.elapsed_time(e1) / 3, 1e-3)) + 1)  # launches per timed region: >= 4 ms
+            walls = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(nl):
+                    launch()
+                torch.cuda.synchronize()
+                walls.append((time.perf_counter() - t0) / nl)
+            ws_ = sorted(walls)
+            rate = n * K / ws_[1]
             gbs = rate * b / 1e9
+            lohi = f"{n * K / ws_[2] * b / 8e12:.3f}..{n * K / ws_[0] * b / 8e12:.3f}"
             kern = ps.last_launch().split(" grid")[0].replace("gemx::", "")
-            print(f"| {label} | {n} | {rate / 1e9:.1f} | {b} | {gbs:.0f} | {gbs / 8000:.3f} | `{kern}` |", flush=True)
+            print(f"| {label} | {n} | {rate / 1e9:.1f} | {b} | {gbs:.0f} | {gbs / 8000:.3f} | {lohi} | `{kern}` |", flush=True)
             assert torch.isfinite(obs).all()
             env.close()
 
