@@ -25,8 +25,18 @@ sustained rate a training run sees; the figure for the same W / K straight from 
 (`--settle-ms 0` makes it the headline again).
 Multi-GPU: envs are independent -> each rank steps its own shard, no data-path collective ("scaling": "weak").  Without WORLD_SIZE in
 the environment `--gpus N` (N > 1) spawns its own N ranks (torch.multiprocessing, one per GPU, RCCL on 127.0.0.1).
-`--gather chunk|step` additionally times the batched-return path: one RCCL all-gather of each launch's [K, n_local, S_out]
-observation chunk (+ done bytes) / of every step's [n_local, S_out] rows; reported under "gather" beside the gather-off `value`.
+`--gather` times the batched-return path beside the gather-off `value`: `chunk` = one RCCL all-gather of each launch's [K, n_local,
+S_out] observation chunk (+ done bytes) into preallocated buffers, `step` = of every step's [n_local, S_out] rows.  Default `auto`
+(round 4) = a bounded `chunk` leg (<= 5 launches) whenever the world has more than one rank, so that every multi-GPU line carries the
+only collective the north star names: `gather.chunk` (rollout + gather rate) and `rccl` = the collective by itself on a launch's real
+outputs {world_seen, backend, version, bytes_per_rank, ms, GB_per_s = (W - 1) x bytes_per_rank / time, own_slot_bit_identical}; `config5`
+(W x 32768 envs, BASELINE config 5's shard size) rides every N > 1 line too.  The headline is assembled BEFORE any optional leg runs and
+every optional leg is wrapped: a failing gather / config5 / extras leg becomes an "error" field of the line, never a lost line.
+WORLD_SIZE in the environment -- also WORLD_SIZE=1 -- or --force-dist initialises the process group, so one rank on one GPU runs the
+exact code path of the scaling run (tests/test_gpu_parity.py::test_bench_multi_gpu_code_path_through_rccl_in_a_world_of_one).
+One clock (round 4): `roofline.achieved / frac / launch_ms` are priced with the WALL time of the timed region / launches -- the clock
+`value` and `ms_per_step` use -- so value x bytes per env-step == roofline.achieved; the HIP-event mean is `launch_ms_hip_events`.
+Legs whose launches are short (BASELINE config 2: 20 us) time >= 3 ms of launches per region for the same reason.
 
 Robustness to the box (round 3): the timed region is run `--repeats` (3) times back to back and the MEDIAN region is what `value`,
 `ms_per_step` and `roofline` report (min / max under `repeats`); core clock, memory clock, socket power and temperature are read from
@@ -46,13 +56,16 @@ Extra objects in the JSON line (rank 0):
                       workload (`all_cores`: the same port on up to 32 host cores), plus the REFERENCE's own Python path as
                       recorded by oracle/cpu_reference_bench.py (fields, not prose).
   headline_no_linmap  the same launches with GEMX_LINMAP=0 (RK4 evaluated stage by stage instead of through the one-step affine map).
-  sustained_1s        >= 1 s of back-to-back launches of the headline workload with clocks / power sampled (also under configs.scim).
+  sustained_1s        >= 1 s of back-to-back launches of the headline workload with clocks / power sampled; since round 4 EVERY leg under
+                      `configs` has one, and its `frac` = min(minimum of the repeated windows, sustained second) is the figure to quote.
+  overrides           the GEMX_* environment switches active in this run (normally none); gemx_last_launch() names them too.
   single_step / single_step_bound / single_step_graph   one launch per control step (closed-loop RL usage): eager
                       `PhysicalSystem.simulate()` on a device tensor, the pre-bound `bind_step()` call, and 64 steps replayed from a HIP graph.
   configs             BASELINE config 2 (PermExDc 4096 envs Euler, with `launch_model`: t = t_fixed + K t_step fitted over launches of
                       250 ... 2000 steps, and `frac_of_latency_bound` = (K x the integrator's dependency chain + t_fixed) / measured),
-                      config 4 (SCIM 65536 envs RK4 with the env's PolynomialStaticLoad -- also with split_kinks, the solver
-                      `make(env_id)` hands out, and with ScipyOdeSolver(), the device's error-controlled Dormand-Prince -- and with the ConstantSpeedLoad BASELINE.json names) and config 5's per-GPU shard
+                      config 4 (`scim`: SCIM 65536 envs with the env's PolynomialStaticLoad and the solver `make(env_id)` hands out = RK4 + kink
+                      correction; `scim_plain_rk4` beside it; `scim_error_controlled` = ScipyOdeSolver(), the device's error-controlled
+                      Dormand-Prince; `scim_constspeed` = with the ConstantSpeedLoad BASELINE.json names) and config 5's per-GPU shard
                       (PMSM 32768 envs), each through the same measurement with 3 repeats.
   at_scale            the headline kernel with the chip full (1M envs).
 """
@@ -554,7 +567,7 @@ def worker(args, rank, world, local_rank, backend):
 
     S = args.settle_ms
     tele = Telemetry(dev_index)
-    env = make_env(ga, w, n_local, dev_index, split_kinks=False)  # (Finite-CC-PMSM-v0: constant-speed load, RK4 is what make() picks too)
+    env = make_env(ga, w, n_local, dev_index)  # the solver make(env_id) hands out (Finite-CC-PMSM-v0: plain RK4; --workload scim: RK4 + kink correction)
     t_cold = measure(torch, dist, env, n_local, K, W, spl, device, world, seed=1234 + rank) if S > 0 else None  # straight from idle
     tele_before = tele.sample()
     reps = measure(torch, dist, env, n_local, K, W, spl, device, world, seed=1234 + rank, settle_ms=S, repeats=max(1, args.repeats))
@@ -612,7 +625,7 @@ def worker(args, rank, world, local_rank, backend):
 
     if args.workload == "pmsm" and args.envs_per_gpu is None and (args.config5 == "on" or (args.config5 == "auto" and world > 1)):
         def c5():
-            env_s = make_env(ga, w, 32768, dev_index, split_kinks=False)
+            env_s = make_env(ga, w, 32768, dev_index)
             try:
                 ts = measure(torch, dist, env_s, 32768, K, W, spl, device, world, seed=1234 + rank, settle_ms=S)
             finally:
@@ -775,7 +788,7 @@ def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out, tele)
     # the same launches without the one-step affine map (general stage-by-stage RK4)
     os.environ["GEMX_LINMAP"] = "0"
     try:
-        env0 = make_env(ga, w, n_local, dev_index, split_kinks=False)
+        env0 = make_env(ga, w, n_local, dev_index)
         t0 = measure(torch, dist, env0, n_local, min(args.steps, 10), 2, spl, device, 1, seed=77, settle_ms=args.settle_ms)
         desc0 = env0.physical_system.last_launch()
         env0.close()
@@ -785,7 +798,7 @@ def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out, tele)
     out["headline_no_linmap"] = {"value": n_local * spl * min(args.steps, 10) / t0.wall, "unit": "env-steps/s", "launch_ms": t0.launch_ms,
                                  "achieved_GBps": r0["achieved"], "frac_of_peak": r0["frac"], "env": "GEMX_LINMAP=0"}
     # does the 3-ms window hold for a second?  (clocks / power sampled every 20 ms while the launches run)
-    envs_ = make_env(ga, w, n_local, dev_index, split_kinks=False)
+    envs_ = make_env(ga, w, n_local, dev_index)
     dt, lms, n, smp = measure_sustained(torch, envs_, n_local, spl, device, 11, args.sustain_s, tele, out["roofline"]["launch_ms"])
     envs_.close()
     rs = roofline_of(w, n_local, spl, dt / n * 1e3, out["roofline"]["kernel"], args.workload)
@@ -794,7 +807,7 @@ def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out, tele)
                            "note": f">= {args.sustain_s} s of back-to-back launches of the headline workload, no host synchronisation inside"}
     # closed-loop usage: one launch per control step, eager and from a HIP graph
     b1 = bytes_per_env_step_single(w)
-    env1 = make_env(ga, w, n_local, dev_index, split_kinks=False)
+    env1 = make_env(ga, w, n_local, dev_index)
     host_s, dev_ms, n1 = measure_single_step(torch, env1, n_local, 2000, 100, device, seed=99, settle_ms=args.settle_ms)
     out["single_step"] = {"value": n_local / host_s, "unit": "env-steps/s", "ms_per_step": host_s * 1e3, "device_ms_per_step": dev_ms,
                           "achieved_GBps": n_local * b1 / (dev_ms * 1e-3) / 1e9, "bytes_per_env_step": b1, "steps": n1,
@@ -814,7 +827,7 @@ def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out, tele)
         if key == args.workload:
             continue
         # `scim` = BASELINE config 4 with the solver make("Cont-SC-SCIM-v0") hands out (RK4 + kink correction); plain RK4 beside it
-        out["configs"][key], tm = leg(torch, dist, ga, args, key, device, dev_index, spl, tele, split_kinks=None if key == "scim" else False)
+        out["configs"][key], tm = leg(torch, dist, ga, args, key, device, dev_index, spl, tele)
         if key == "scim":
             out["configs"]["scim_plain_rk4"], _ = leg(torch, dist, ga, args, key, device, dev_index, spl, tele, split_kinks=False)
             out["configs"]["scim_split_kinks"] = {"same_as": "configs.scim", "frac": out["configs"]["scim"]["frac"],
@@ -826,10 +839,10 @@ def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out, tele)
         if key == "permexdc":
             out["configs"][key]["launch_model"] = launch_model(torch, dist, ga, args, key, device, dev_index, out["configs"][key])
     if args.workload == "pmsm":  # BASELINE config 5 = 8 x 32768 envs: its shard on this one GPU
-        out["configs"]["pmsm_c5_shard"], _ = leg(torch, dist, ga, args, "pmsm", device, dev_index, spl, tele, envs=32768, split_kinks=False)
+        out["configs"]["pmsm_c5_shard"], _ = leg(torch, dist, ga, args, "pmsm", device, dev_index, spl, tele, envs=32768)
     # the headline kernel with the chip full
     n_big, c_big = 2 ** 20, 100
-    envb = make_env(ga, w, n_big, dev_index, split_kinks=False)
+    envb = make_env(ga, w, n_big, dev_index)
     tb = measure(torch, dist, envb, n_big, 4, 2, c_big, device, 1, seed=7, settle_ms=args.settle_ms, repeats=3)
     envb.close()
     bb = n_big * (c_big * bytes_per_env_step_fused(w) + 2 * 4 * w["s_ode"])
@@ -849,7 +862,7 @@ def launch_model(torch, dist, ga, args, key, device, dev_index, leg_out):
     wc = dict(WORKLOADS[key], key=key)
     pts = []
     for k in (250, 500, 1000, 2000):
-        env = make_env(ga, wc, wc["envs"], dev_index, split_kinks=False)
+        env = make_env(ga, wc, wc["envs"], dev_index)
         r = measure(torch, dist, env, wc["envs"], 10, 3, k, device, 1, seed=5, settle_ms=args.settle_ms, repeats=3)
         env.close()
         pts.append((k, median_of(r).launch_ms * 1e3))

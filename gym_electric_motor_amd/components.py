@@ -183,8 +183,10 @@ class EulerSolver:
 class RK4Solver:
     """Classical 4th-order Runge-Kutta with `nsteps` sub-steps per integration segment.  The reference has no
     RK4; its like-for-like CPU counterpart is the default scipy dopri5 path.
-    split_kinks: cut every step where omega is predicted to reach a kink of a PolynomialStaticLoad's torque (|omega| = a tau_decay / J),
-    as the reference's adaptive default solver does by rejecting such steps (include/gemx.h: GEMX_SOLVER_SPLIT_KINKS)."""
+    split_kinks: correct every step for the kinks of a PolynomialStaticLoad's torque (|omega| = a tau_decay / J), where the reference's
+    adaptive default solver rejects and splits its steps (include/gemx.h: GEMX_SOLVER_SPLIT_KINKS).  Since round 4 that is ONE pass of the
+    scheme on a smooth extension of the load torque plus the defect integrated in closed form along the step's own omega path (rounds
+    2-3 cut the step at the predicted crossings: up to three passes); the name of the option is kept."""
 
     def __init__(self, nsteps=1, split_kinks=False):
         self._nsteps = int(nsteps)

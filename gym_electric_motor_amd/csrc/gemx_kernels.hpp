@@ -177,11 +177,14 @@ template <class R> struct Elec<GEMX_SYS_DFIM, R> {  // the SCIM matrix with live
 // Dormand-Prince 5th-order solution without error control.
 // ------------------------------------------------------------------------------------------------
 // rk_step_k1: the same step with the first stage k1 = F(z) already evaluated by the caller (who may need it to choose h).
+// last0 (optional): receives d z[0] / dt of the scheme's LAST stage, which sits at t + h in all three schemes -- the end slope of
+// omega's path to the order the kink correction of integrate<> needs, for free.
 template <int SOLVER, int NZ, class R, class F>
-__device__ __forceinline__ R rk_step_k1(R (&z)[NZ], const R (&k1)[NZ], R h, F &&rhs) {
+__device__ __forceinline__ R rk_step_k1(R (&z)[NZ], const R (&k1)[NZ], R h, F &&rhs, R *last0 = nullptr) {
     R zt[NZ];
     if (SOLVER == GEMX_SOLVER_EULER) {
         const R q = z[0];
+        if (last0 != nullptr) *last0 = k1[0];
 #pragma unroll
         for (int i = 0; i < NZ; ++i) z[i] = z[i] + k1[i] * h;
         return q;
@@ -200,6 +203,7 @@ __device__ __forceinline__ R rk_step_k1(R (&z)[NZ], const R (&k1)[NZ], R h, F &&
 #pragma unroll
         for (int i = 0; i < NZ; ++i) zt[i] = z[i] + h * k3[i];
         rhs(zt, k4);
+        if (last0 != nullptr) *last0 = k4[0];
         q += zt[0];
         const R h6 = h * R(1.0 / 6.0);
 #pragma unroll
@@ -230,6 +234,7 @@ __device__ __forceinline__ R rk_step_k1(R (&z)[NZ], const R (&k1)[NZ], R h, F &&
             zt[i] = z[i] + h * (R(9017.0 / 3168.0) * k1[i] - R(355.0 / 33.0) * k2[i] + R(46732.0 / 5247.0) * k3[i] +
                                 R(49.0 / 176.0) * k4[i] - R(5103.0 / 18656.0) * k5[i]);
         rhs(zt, k6);
+        if (last0 != nullptr) *last0 = k6[0];
         q += R(11.0 / 84.0) * zt[0];
 #pragma unroll
         for (int i = 0; i < NZ; ++i)
@@ -481,7 +486,7 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
         //     Euler-predicted mid-step omega lies in (-a | J / tau_decay omega | +a), so the scheme keeps its order whatever the lanes do;
         //   * the defect D = omega_true - omega_model obeys D' = -(1 / tau_decay) [clamp(omega, -lim, lim) - phi_m(omega)] (phi_m: region m's
         //     piece of the clamp, extended), integrated to first order along the model's own omega path -- the cubic through both ends
-        //     of the step with both end slopes (the end slope costs one torque evaluation, no right-hand side) -- in closed form:
+        //     of the step with the slopes of the scheme's first and last stage (the last stage sits at t + h) -- in closed form:
         //     int clamp = -lim + U(-lim) - U(lim) with the ramp integrals U(c) = int (omega - c)_+ dt; U needs the instant the path
         //     crosses c, but is stationary in it (the integrand vanishes there), so the root of the quadratic through both ends with the
         //     start slope is accurate enough; D is added to omega at the end of the step.
@@ -511,15 +516,13 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
 #pragma unroll
                 for (int i = 0; i < NM; ++i) dz[1 + i] = dx[i];
             };
-            deps += (P.pole * hs) * rk_step_k1<SOLVER, NM + 1, R>(y, k1, hs, rhs_m);
+            R dw_end;  // d omega / dt of the last stage (at t + hs)
+            deps += (P.pole * hs) * rk_step_k1<SOLVER, NM + 1, R>(y, k1, hs, rhs_m, &dw_end);
             const R w1 = y[0];
             const R phi_lim = copysign(lim, wmid);
             const bool needs = (med3_r(w, -lim, lim) != (band ? w : phi_lim)) | (med3_r(w1, -lim, lim) != (band ? w1 : phi_lim));
             if (__any(needs)) {  // wave-uniform
-                R x1[NM];
-#pragma unroll
-                for (int i = 0; i < NM; ++i) x1[i] = y[1 + i];
-                const R V0 = hs * k1[0], V1 = hs * load_m(w1, E::torque(P, x1)), dl = w1 - w;
+                const R V0 = hs * k1[0], V1 = hs * dw_end, dl = w1 - w;
                 const R c2 = R(3) * dl - R(2) * V0 - V1, c3 = V0 + V1 - R(2) * dl;
                 const KinkPath<R> kp{w, w1, V0, V0 * V0, R(4) * (dl - V0), c2 * R(1.0 / 3.0), c3 * R(0.25), R(0.5) * V0,
                                      w + R(0.5) * V0 + c2 * R(1.0 / 3.0) + c3 * R(0.25), w1 > w};

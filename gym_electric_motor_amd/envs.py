@@ -116,15 +116,15 @@ def default_ode_solver(env_id, tau=None, load=None):
     """The solver `make(env_id)` uses when the caller names none.  The reference's default is scipy's ADAPTIVE dopri5 (rtol 1e-6,
     solvers.py:139-184); the device integrates with fixed steps, so the default is chosen per env such that the fp32 trajectories stay
     within the 1e-4 contract of the reference's default-solver runs.  Measured on the GPU over every one of the reference's 54 env ids
-    exactly as `gem.make(env_id)` builds them plus 46 further recorded dopri5 runs (tests/solver_scan.py -> profiles/r03_solver_scan.md):
+    exactly as `gem.make(env_id)` builds them plus ~100 further recorded dopri5 runs (tests/solver_scan.py -> profiles/r04a_solver_scan.md):
 
     * ConstantSpeedLoad (the CC / TC envs): one classical RK4 step per control step -- the electrical subsystem is linear there and the
       step is the exact one-step map of the scheme: <= 1.8e-5 on the envs as shipped (free runs far beyond the limits: < 1e-4).
       More sub-steps make fp32 WORSE here (rounding accumulates: 8 sub-steps reach 2.7e-3 on a free-running EESM), so none;
     * PolynomialStaticLoad (the SC envs: omega is a state, the load torque has kinks at |omega| = a tau_decay / J): RK4 with every step
-      cut at those kinks (split_kinks: what the adaptive reference solver does by rejecting such steps): <= 2.0e-5 on every recorded
-      run (plain RK4: up to 7.9e-5 -- Cont-SC-ShuntDc-v0 --, 6.8e-5 on the SCIM), still one right-hand-side pass per stage, so these
-      envs keep the pipelined kernel.
+      corrected for those kinks in closed form (split_kinks; the adaptive reference solver rejects and splits such steps): <= 6.3e-6 on
+      every recorded run with such a load (plain RK4: up to 7.9e-5 -- Cont-SC-ShuntDc-v0 --, 6.8e-5 on the SCIM), ONE pass of the
+      scheme (rounds 2-3: up to three), at plain RK4's rate wherever the launch is bandwidth bound (BASELINE config 4).
 
     `tau` / `load` (instance, class or class name): what the env is actually built with, when it differs from the env id's defaults."""
     d = default_components(env_id)

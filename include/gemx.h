@@ -72,11 +72,14 @@ typedef enum { GEMX_LOAD_CONST_SPEED = 0, GEMX_LOAD_POLY_STATIC = 1 } gemx_load_
 /* EulerSolver(nsteps) (solvers.py:79-136); classical RK4 (not in the reference); one fixed Dormand-Prince-5
  * step per segment (what the reference's default scipy dopri5 does whenever its trial step is accepted) */
 typedef enum { GEMX_SOLVER_EULER = 0, GEMX_SOLVER_RK4 = 1, GEMX_SOLVER_DP5 = 2 } gemx_solver_kind;
-/* gemx_config.solver_flags.  GEMX_SOLVER_SPLIT_KINKS: with a PolynomialStaticLoad every (sub-)step is cut where omega is predicted to
- * reach a kink of the load torque, |omega| = a * tau_decay / J (polynomial_static_load.py:87-92), and each piece is one step of the
- * scheme (at most 3 pieces).  This is the device's stand-in for the step-size control of the reference's default solver (scipy dopri5,
- * solvers.py:139-184), which rejects and splits exactly these steps: a fixed step loses its order at a kink.  Worst observed error against
- * the reference's dopri5 trajectories (fp64, SCIM + PolynomialStaticLoad): 7.5e-5 without, 1.3e-5 with.  Ignored for a ConstantSpeedLoad. */
+/* gemx_config.solver_flags.  GEMX_SOLVER_SPLIT_KINKS: with a PolynomialStaticLoad every (sub-)step is corrected for the kinks of the
+ * load torque at |omega| = a * tau_decay / J (polynomial_static_load.py:87-92), where a fixed step loses its order and the reference's
+ * default solver (scipy dopri5, solvers.py:139-184) rejects and splits its steps.  ABI >= 5 libraries do it in ONE pass of the scheme: the
+ * saturation term is replaced by the affine piece of the region the mid-step omega is predicted in (a smooth system: the scheme keeps
+ * its order), and the defect -- the time integral of (true - modelled) saturation along the step's own omega path, a cubic through both
+ * ends with the first and last stage's slopes -- is added to omega in closed form.  (Earlier libraries cut the step at the predicted
+ * crossings, up to three passes; the flag kept its name.)  Worst observed error against the reference's dopri5 trajectories over every
+ * recorded PolynomialStaticLoad run (fp32): 7.9e-5 without, 6.3e-6 with.  Ignored for a ConstantSpeedLoad. */
 #define GEMX_SOLVER_SPLIT_KINKS 1
 /* GEMX_SOLVER_ADAPTIVE (with GEMX_SOLVER_DP5 only): error-controlled sub-stepping -- what the reference's default solver does
  * (ScipyOdeSolver('dopri5'), solvers.py:139-184: scipy's DOPRI5 with rtol 1e-6, atol 1e-12).  Every integration segment is tried as one

@@ -437,7 +437,8 @@ static void ivp_rk45(const orc_params *p, orc_env *e, double t_end) {
  * right-hand side has kinks at |omega| = omega_lim, where a fixed step loses its order (scipy's adaptive solvers split their steps
  * there).  ONE step of the scheme per (sub-)step, on a smooth system: sigma replaced by the affine piece c0 + c1 omega of the region the
  * Euler-predicted mid-step omega lies in; then the defect D = omega_true - omega_model, D' = -(1 / tau_decay) [clamp(omega) - phi_m(omega)],
- * integrated to first order along the model's omega path (cubic Hermite through both ends with both end slopes) in closed form and
+ * integrated to first order along the model's omega path (cubic Hermite through both ends with the slopes of the scheme's first and
+ * last stage) in closed form and
  * added to omega.  Same operations in the same order as the kernels (their fp64 build agrees to 1e-9: tests). */
 static void system_equation_m(const orc_params *p, const orc_env *e, const double *y, double *dy, int model, double c0, double c1) {
     if (!model) { system_equation(p, e, y, dy); return; }
@@ -447,6 +448,7 @@ static void system_equation_m(const orc_params *p, const orc_env *e, const doubl
     electrical_ode(p, e, y + 1, e->u, w, dy + 1);
 }
 /* one step of the scheme for the model system, first stage k1 given */
+static __thread double g_last0; /* d omega / dt of the scheme's last stage (at t + h): the end slope of omega's path */
 static void fixed_step_m(const orc_params *p, orc_env *e, int dp5, double h, const double *k1, int model, double c0, double c1) {
     int n = n_ode(p);
     double k2[ORC_MAX_ODE], k3[ORC_MAX_ODE], k4[ORC_MAX_ODE], k5[ORC_MAX_ODE], k6[ORC_MAX_ODE], yt[ORC_MAX_ODE];
@@ -458,6 +460,7 @@ static void fixed_step_m(const orc_params *p, orc_env *e, int dp5, double h, con
         for (int i = 0; i < n; ++i) yt[i] = e->y[i] + h * k3[i];
         system_equation_m(p, e, yt, k4, model, c0, c1);
         for (int i = 0; i < n; ++i) e->y[i] = e->y[i] + h / 6.0 * (k1[i] + 2.0 * (k2[i] + k3[i]) + k4[i]);
+        g_last0 = k4[0];
         return;
     }
     for (int i = 0; i < n; ++i) yt[i] = e->y[i] + h * (1.0 / 5.0) * k1[i];
@@ -473,6 +476,7 @@ static void fixed_step_m(const orc_params *p, orc_env *e, int dp5, double h, con
         yt[i] = e->y[i] + h * (9017.0 / 3168.0 * k1[i] - 355.0 / 33.0 * k2[i] + 46732.0 / 5247.0 * k3[i] + 49.0 / 176.0 * k4[i] -
                                5103.0 / 18656.0 * k5[i]);
     system_equation_m(p, e, yt, k6, model, c0, c1);
+    g_last0 = k6[0];
     for (int i = 0; i < n; ++i)
         e->y[i] = e->y[i] + h * (35.0 / 384.0 * k1[i] + 500.0 / 1113.0 * k3[i] + 125.0 / 192.0 * k4[i] - 2187.0 / 6784.0 * k5[i] +
                                  11.0 / 84.0 * k6[i]);
@@ -508,9 +512,7 @@ static void integrate_kink_substep(const orc_params *p, orc_env *e, int dp5, dou
     const double w1 = e->y[0], phi_lim = copysign(lim, wmid);
     const int needs = (clamp3(w, -lim, lim) != (band ? w : phi_lim)) | (clamp3(w1, -lim, lim) != (band ? w1 : phi_lim));
     if (!needs) return;
-    double ke[ORC_MAX_ODE];
-    system_equation_m(p, e, e->y, ke, 1, c0, c1); /* (only its load derivative is used: the end slope of omega) */
-    const double V0 = h * k1[0], V1 = h * ke[0], dl = w1 - w;
+    const double V0 = h * k1[0], V1 = h * g_last0, dl = w1 - w;
     const double c2 = 3.0 * dl - 2.0 * V0 - V1, c3 = V0 + V1 - 2.0 * dl;
     const kink_path kp = {w, w1, V0, V0 * V0, 4.0 * (dl - V0), c2 * (1.0 / 3.0), c3 * 0.25, 0.5 * V0,
                           w + 0.5 * V0 + c2 * (1.0 / 3.0) + c3 * 0.25, w1 > w};

@@ -39,9 +39,11 @@ for WL in pmsm scim permexdc; do
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d /tmp/pmc_sq -- python $R/bench.py --no-extras --no-pmc --repeats 1 --workload $WL --steps 5 --warmup 2 --settle-ms 0 > /tmp/pmc_sq.log 2>&1
   python $R/tools/pmc_sum.py /tmp/pmc_sq $(ksub $WL) | sed "s/^/$WL SQ /" >> $OUT/${TAG}_pmc_raw.txt
 done
-python $R/tools/bench_matrix.py > $OUT/${TAG}_matrix.md 2>/dev/null
+python $R/tools/bench_matrix.py > $OUT/${TAG}_matrix.md 2>/dev/null                          # plain RK4 on every row (rounds 1-3's matrix)
+python $R/tools/bench_matrix.py --solver default > $OUT/${TAG}_matrix_default_solver.md 2>/dev/null  # what make(env_id) hands out (kink correction on the SC rows)
 # the records that go with them: the GPU suite, the parity report, two ranks on this one GPU (gloo control plane) with the chunk gather
 cd $R
 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/${TAG}_gpu_tests.txt
 python tests/parity_report.py > $OUT/${TAG}_parity.md 2>&1
+python tests/solver_scan.py > $OUT/${TAG}_solver_scan.md 2>/dev/null
 python bench.py --gpus 2 --oversubscribe --gather chunk --steps 5 --warmup 2 --no-extras --no-pmc 2>&1 | tail -1 > $OUT/${TAG}_bench_gpus2_oversubscribe.json
