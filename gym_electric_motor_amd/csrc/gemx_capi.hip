@@ -93,9 +93,14 @@ __global__ void reset_kernel(R *state, typename Angle<R>::T *angle, const uint8_
         state[(int64_t)nd * N + env] = P.u_sup;
         state[(int64_t)(nd + 1) * N + env] = R(0);
     }
-    // DeadTimeProcessor.reset (dead_time_processor.py:63-72): the deque is refilled with the (zero) reset action
-    for (int d = 0; d < P.delay; ++d)
-        for (int b = 0; b < ring_row_bytes; ++b) ring[((int64_t)d * N + env) * ring_row_bytes + b] = 0;
+    // DeadTimeProcessor.reset (dead_time_processor.py:63-72): the deque is refilled with the reset action (zeros unless the handle
+    // carries a custom one: one byte = a discrete index, else ring_row_bytes / sizeof(R) continuous entries)
+    for (int d = 0; d < P.delay; ++d) {
+        unsigned char *row = ring + ((int64_t)d * N + env) * ring_row_bytes;
+        if (ring_row_bytes == 1) row[0] = (unsigned char)P.dreset_d;
+        else
+            for (int i = 0; i < ring_row_bytes / (int)sizeof(R); ++i) reinterpret_cast<R *>(row)[i] = P.dreset[i];
+    }
     if (has_angle) angle[env] = P.init_kind ? Angle<R>::from_rad(eps0) : Angle<R>::from_bits(P.init_angle_rep);
     if (obs != nullptr) {
         double row[GEMX_MAX_OUT];
@@ -225,6 +230,13 @@ template <class R> static void fill_params(const gemx_handle &h, const double *m
     P.sup_inv_rc = (R)(P.rc_supply ? 1.0 / (c.supply_r * c.supply_c) : 0.0);
     P.dq_processor = c.action_frame == GEMX_ACT_DQ_PROCESSOR;
     P.delay = c.action_delay;
+    {
+        const int ck = c.converter_kind;
+        const bool disc = ck == GEMX_CONV_FINITE_B6 || ck == GEMX_CONV_FINITE_4QC || ck == GEMX_CONV_FINITE_2X4QC || ck == GEMX_CONV_FINITE_B6_4QC ||
+                          ck == GEMX_CONV_FINITE_2XB6;
+        for (int i = 0; i < MAX_ACT; ++i) P.dreset[i] = (R)(c.action_delay > 0 ? c.action_delay_reset[i] : 0.0);
+        P.dreset_d = disc && c.action_delay > 0 ? (uint32_t)c.action_delay_reset[0] : 0u;
+    }
     P.dq_adv = (R)((0.5 + c.action_delay) * c.tau * pole);  // dq_to_abc_action_processor.py:83-86, 98-100
     P.kink_split = (c.solver_flags & GEMX_SOLVER_SPLIT_KINKS) && c.load_kind == GEMX_LOAD_POLY_STATIC && P.omega_lim > R(0);
     P.adaptive = (c.solver_flags & GEMX_SOLVER_ADAPTIVE) ? 1 : 0;
@@ -460,6 +472,17 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
                         cfg->action_frame);
     }
     if (cfg->init_kind < GEMX_INIT_CONST || cfg->init_kind > GEMX_INIT_GAUSSIAN) return fail(GEMX_ERR_ARG, "unknown init_kind");
+    if (cfg->action_delay > 0) {
+        const bool disc = c == GEMX_CONV_FINITE_B6 || c == GEMX_CONV_FINITE_4QC || c == GEMX_CONV_FINITE_2X4QC || c == GEMX_CONV_FINITE_B6_4QC ||
+                          c == GEMX_CONV_FINITE_2XB6;
+        const int nflat = c == GEMX_CONV_FINITE_B6 ? 8 : (c == GEMX_CONV_FINITE_4QC ? 4 : (c == GEMX_CONV_FINITE_2X4QC ? 16 : (c == GEMX_CONV_FINITE_B6_4QC ? 32 : 64)));
+        for (int i = 0; i < 6; ++i) {
+            const double v = cfg->action_delay_reset[i];
+            if (!std::isfinite(v)) return fail(GEMX_ERR_ARG, "action_delay_reset[%d] is not finite", i);
+            if (disc && (i > 0 ? v != 0.0 : (v < 0.0 || v >= (double)nflat || v != std::floor(v))))
+                return fail(GEMX_ERR_ARG, "action_delay_reset: a discrete converter takes ONE flat action index in [0, %d) in entry 0 (got [%d] = %g)", nflat, i, v);
+        }
+    }
     if (cfg->init_flux_mode != 0 && !(cfg->init_flux_mode == 1 && (s == GEMX_SYS_SCIM || s == GEMX_SYS_DFIM) && cfg->init_kind != GEMX_INIT_CONST))
         return fail(GEMX_ERR_ARG, "init_flux_mode is 0, or 1 for a SCIM / DFIM system with a random init_kind");
     if (cfg->init_flux_mode == 1 && !(cfg->init_flux[1] > 0 && cfg->init_flux[5] > 0))

@@ -89,6 +89,8 @@ template <class R> struct DevParams {
     R sup_r, sup_inv_rc;    // R, 1 / (R C)
     int32_t dq_processor;   // dq action frames: 0 control_space='dq' (step-start angle), 1 DqToAbcActionProcessor (advanced angle)
     int32_t delay;          // DeadTimeProcessor steps
+    R dreset[MAX_ACT];      //   the action every reset refills its queue with (gemx_config.action_delay_reset; a discrete index as R) ...
+    uint32_t dreset_d;      //   ... and that index as an integer (0 for continuous actions)
     R dq_adv;               // (0.5 + delay) * tau * pole: angle advance per rad/s of omega
     int32_t kink_split;     // GEMX_SOLVER_SPLIT_KINKS: the PolynomialStaticLoad's kinks are corrected for in closed form (integrate<>)
     int32_t adaptive;       // GEMX_SOLVER_ADAPTIVE (DP5 only): error-controlled sub-stepping, dp5_adaptive()

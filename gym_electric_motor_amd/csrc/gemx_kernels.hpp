@@ -1755,7 +1755,7 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
             sup[1] = R(0);
             for (int d = 0; d < P.delay; ++d) {  // DeadTimeProcessor.reset: the deque is refilled with the reset action
 #pragma unroll
-                for (int i = 0; i < NACTC; ++i) fifo[((size_t)d * BLOCK + tid) * NACTC + i] = R(0);
+                for (int i = 0; i < NACTC; ++i) fifo[((size_t)d * BLOCK + tid) * NACTC + i] = P.dreset[i];
             }
         }
         if (!COOP && s + 1 < sb) read_action(s + 1, nact, ndact);
@@ -2072,8 +2072,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs<R> a) {
 #pragma unroll
                 for (int i = 0; i < NACTC; ++i) {
                     const int64_t gi = ((int64_t)d * N + e) * NACTC + i;
-                    if (DISCRETE) a.ring[gi] = 0;
-                    else reinterpret_cast<R *>(a.ring)[gi] = R(0);
+                    if (DISCRETE) a.ring[gi] = (unsigned char)P.dreset_d;
+                    else reinterpret_cast<R *>(a.ring)[gi] = P.dreset[i];
                 }
             }
         }
@@ -2254,6 +2254,12 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
         for (int j = 0; j < ND; ++j) { init_v[j] = P.init[j]; asm volatile("" : "+v"(init_v[j])); }
         AngT init_ang_v = init_ang;
         asm volatile("" : "+v"(init_ang_v));
+        // DeadTimeProcessor reset action (zeros unless the handle carries a custom one), in VGPRs for the same reason
+        R dreset_v[NACTC];
+#pragma unroll
+        for (int i = 0; i < NACTC; ++i) { dreset_v[i] = P.dreset[i]; asm volatile("" : "+v"(dreset_v[i])); }
+        uint32_t dreset_dv = P.dreset_d;
+        asm volatile("" : "+v"(dreset_dv));
         R sup[2] = {P.u_sup, R(0)};  // RCVoltageSupply: capacitor voltage, time since the supply's last update (FULL)
         uint32_t rcount = 0;         // random initialisers: resets of this env so far (FULL)
         if constexpr (FULL) {
@@ -2352,7 +2358,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                     qw[i] = t;                                   // row s + delay
                     const R q = one_deep ? tprev[i] : qpre[i];   // row s
                     tprev[i] = t;
-                    act[i] = queued ? q : R(0);                  // (the refilled zero action right after a reset)
+                    act[i] = queued ? q : dreset_v[i];           // (the refilled reset action right after a reset)
                     qpre[i] = qnext[i];
                 }
             }
@@ -2444,15 +2450,15 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                 sup[1] = rs ? R(0) : sup[1];
             }
             if constexpr (MODE == 2 || MODE == 3) since = rs ? 0u : (since < delay_u ? since + 1u : delay_u);
-            if (FIFO && P.delay > 0) {  // DeadTimeProcessor.reset: the deque is refilled with the (zero) reset action
+            if (FIFO && P.delay > 0) {  // DeadTimeProcessor.reset: the deque is refilled with the reset action
                 if (rs) {
                     for (int d = 0; d < P.delay; ++d) {
 #pragma unroll
-                        for (int i = 0; i < NACTC; ++i) fifo[((size_t)d * BLOCK + tid) * NACTC + i] = R(0);
+                        for (int i = 0; i < NACTC; ++i) fifo[((size_t)d * BLOCK + tid) * NACTC + i] = dreset_v[i];
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < NACTC; ++i) pop[i] = rs ? R(0) : pop[i];
+                for (int i = 0; i < NACTC; ++i) pop[i] = rs ? dreset_v[i] : pop[i];
             }
         };
         stage_actions(0);
@@ -2518,7 +2524,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                     // in flight (each LDS read has a whole step to land)
                     R en[8], ec[8], e0[8];
                     uint32_t dnn = 0;
-                    if constexpr (DEL) fetch_entry(0u, e0);  // the zero action's entry, for the steps right after a reset
+                    if constexpr (DEL) fetch_entry(P.dreset_d, e0);  // the reset action's entry, for the steps right after a reset
                     fetch_entry(dn, en);
                     rd(1, an, dnn);
 #pragma unroll 4
@@ -2530,10 +2536,10 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                         fetch_entry(dn, en);
                         rd(s + 2 < D ? s + 2 : D - 1, an, dnn);
                         if constexpr (DEL) {
-                            const bool queued = since >= delay_u;  // else: the refilled (zero) reset action
+                            const bool queued = since >= delay_u;  // else: the refilled reset action
 #pragma unroll
                             for (int j = 0; j < ST::NVT; ++j) ec[j] = queued ? ec[j] : e0[j];
-                            if constexpr (COMPACT_K) dc = queued ? dc : 0u;  // (compact rows carry the action the converter saw)
+                            if constexpr (COMPACT_K) dc = queued ? dc : dreset_dv;  // (compact rows carry the action the converter saw)
                         }
                         one_step(Mode{}, ac, dc, hb + (size_t)s * BLOCK * NHT, ec);
                     }
@@ -2546,9 +2552,9 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                         rd(s + 1 < D ? s + 1 : s, an, dn);  // one step ahead: its LDS latency hides behind this step
                         if constexpr (DEL) {
                             const bool queued = since >= delay_u;
-                            dc = queued ? dc : 0u;
+                            dc = queued ? dc : dreset_dv;
 #pragma unroll
-                            for (int i = 0; i < NACT; ++i) ac[i] = queued ? ac[i] : R(0);
+                            for (int i = 0; i < NACT; ++i) ac[i] = queued ? ac[i] : (i < NACTC ? dreset_v[i < NACTC ? i : 0] : R(0));
                         }
                         one_step(Mode{}, ac, dc, hb + (size_t)s * BLOCK * NHT, nullptr);
                     }
@@ -2569,9 +2575,9 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                         for (int s = 0; s < sb; ++s) {
                             read_delayed(s, ac, dc);
                             const bool queued = since >= delay_u;
-                            dc = queued ? dc : 0u;
+                            dc = queued ? dc : dreset_dv;
 #pragma unroll
-                            for (int i = 0; i < NACT; ++i) ac[i] = queued ? ac[i] : R(0);
+                            for (int i = 0; i < NACT; ++i) ac[i] = queued ? ac[i] : (i < NACTC ? dreset_v[i < NACTC ? i : 0] : R(0));
                             if constexpr (USE_TAB) fetch_entry(dc, ect);
                             one_step(std::integral_constant<int, 2>{}, ac, dc, hb + (size_t)s * BLOCK * NHT, ect);
                         }
@@ -2694,7 +2700,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
         if (P.delay > 0) phase_end = (ring_phase + K) % P.delay;
         for (int d = 0; d < P.delay; ++d) {
             // FIFO: slot d as it stands.  DELAYED: carry row d is the entry popped d steps after this launch -> ring slot (phase_end + d)
-            // mod delay; entries submitted before the env's last reset are the refilled zero action
+            // mod delay; entries submitted before the env's last reset are the refilled reset action
             int dst = d;
             bool keep = true;
             if (delayed_any) {
@@ -2705,7 +2711,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
 #pragma unroll
             for (int i = 0; i < NACTC; ++i) {
                 const int64_t gi = ((int64_t)dst * N + env) * NACTC + i;
-                const R v = keep ? fifo[((size_t)d * BLOCK + tid) * NACTC + i] : R(0);
+                const R v = keep ? fifo[((size_t)d * BLOCK + tid) * NACTC + i] : dreset_v[i];
                 if (DISCRETE) a.ring[gi] = (unsigned char)(uint32_t)v;
                 else reinterpret_cast<R *>(a.ring)[gi] = v;
             }

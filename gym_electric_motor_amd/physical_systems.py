@@ -100,7 +100,7 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
 
     def __init__(self, converter, motor, load, supply, ode_solver, tau=1e-4, calc_jacobian=None, n_envs=1, device=0,
                  dtype="float32", constraints=(), auto_reset=None, obs_layout="aos", control_space="abc", action_frame=None,
-                 action_delay=0, seed=0, _defer_create=False):
+                 action_delay=0, action_delay_reset=None, seed=0, _defer_create=False):
         """
         Args (first six as in SCMLSystem.__init__, physical_systems.py:54-65):
             converter, motor, load, supply: component instances (this package's or the reference's).
@@ -121,7 +121,9 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             action_frame: None (from control_space) | 'abc' | 'dq' | 'dq_processor' -- the latter is the reference's
                 DqToAbcActionProcessor wrapper folded into the kernel (angle advanced by 0.5 + action_delay steps).
             action_delay(int): DeadTimeProcessor(steps) folded into the kernel: the converter sees the action submitted
-                `action_delay` steps earlier (zero action right after a reset).
+                `action_delay` steps earlier (the reset action right after a reset).
+            action_delay_reset: the ONE action every reset refills that queue with (DeadTimeProcessor(reset_action=...)), in the
+                action space of the system the processor wraps; None = zeros, the reference's default.
         """
         if control_space not in ("abc", "dq"):
             raise ValueError(f"control_space must be 'abc' or 'dq', got {control_space!r}")
@@ -134,6 +136,7 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         self._action_delay = int(action_delay)
         if not 0 <= self._action_delay <= _lib.MAX_DELAY:
             raise ValueError(f"action_delay must be in [0, {_lib.MAX_DELAY}]")
+        self._action_delay_reset = None if action_delay_reset is None else [float(x) for x in np.atleast_1d(action_delay_reset).ravel()]
         self._converter = converter
         self._electrical_motor = motor
         self._mechanical_load = load
@@ -375,6 +378,15 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         cfg.limit_mask, cfg.squared_mask = limit_mask, squared_mask
         cfg.action_frame = {"abc": _lib.ACT_ABC, "dq": _lib.ACT_DQ_SPACE, "dq_processor": _lib.ACT_DQ_PROCESSOR}[self._action_frame]
         cfg.action_delay = self._action_delay
+        if self._action_delay_reset is not None:
+            row = list(self._action_delay_reset)
+            nvec = getattr(self.action_space, "nvec", None)
+            if nvec is not None and len(row) == 2:  # MultiDiscrete([n0, n1]) -> the flat index the kernel reads (include/gemx.h)
+                row = [row[0] + int(nvec[0]) * row[1]]
+            if len(row) > 6:
+                raise ValueError(f"action_delay_reset has {len(row)} entries")
+            for i, v in enumerate(row):
+                cfg.action_delay_reset[i] = float(v)
         if self._action_frame != "abc":
             sysk, convk = self._SYSTEM_KIND, self._converter_kind()
             ok = (self._action_frame == "dq" and sysk in (_lib.SYS_SYNC, _lib.SYS_SCIM) and convk == _lib.CONV_CONT_B6) or \

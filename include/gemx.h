@@ -118,8 +118,10 @@ typedef struct gemx_config {
      *                         dq_to_abc_action_processor.py:100-114; EESM 158-175): A = 2 (SYNC) | 3 (EESM: u_d, u_q, u_e),
      *                         abc = T32(Q(a_dq, eps + (0.5 + action_delay) * tau * omega * p)).
      * action_delay = DeadTimeProcessor(steps) INSIDE the dq processor (dead_time_processor.py:63-85): the converter
-     * receives the action submitted action_delay steps earlier; the per-env FIFO is refilled with the zero action
-     * by every reset (default reset_actions).  Any system / converter; 0 = none, max GEMX_MAX_DELAY. */
+     * receives the action submitted action_delay steps earlier; the per-env FIFO is refilled by every reset with
+     * action_delay_reset below -- zeros, the reference's default reset_actions, or the ONE action a custom
+     * `reset_action` callable returns action_delay copies of (dead_time_processor.py:27-50).  Any system / converter;
+     * 0 = none, max GEMX_MAX_DELAY. */
     int32_t action_frame;
     int32_t action_delay;
     /* Supply: GEMX_SUPPLY_IDEAL (IdealVoltageSupply, voltage_supplies.py:60-72: u_sup = u_nominal) or GEMX_SUPPLY_RC
@@ -150,6 +152,9 @@ typedef struct gemx_config {
     uint64_t seed;
     double init_lo[GEMX_MAX_ODE], init_hi[GEMX_MAX_ODE], init_mu[GEMX_MAX_ODE], init_sigma[GEMX_MAX_ODE];
     double supply_r, supply_c;
+    /* DeadTimeProcessor reset action, in the action space of the system the processor wraps: continuous converter actions
+     * [0 .. A_conv - 1] (A_conv = 2 for control_space='dq'), or [0] = the flat index of a discrete action */
+    double action_delay_reset[6];
     double solver_rtol, solver_atol; /* GEMX_SOLVER_ADAPTIVE: relative / absolute (state units) tolerance; 0 = 1e-6 / 1e-9 */
     double tau;               /* control step, PhysicalSystem.tau */
     double interlocking_time; /* converter dead time, converters.py:35-41; must be < tau */

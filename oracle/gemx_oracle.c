@@ -75,6 +75,8 @@ typedef struct orc_params {
     double init[ORC_MAX_ODE]; /* initial ODE state [omega, motor states...] */
     double sup_r, sup_c;      /* RCVoltageSupply supply_parameter R, C */
     double rtol, atol;        /* ORC_SOLVER_IVP_RK45: solve_ivp tolerances (0 -> scipy's defaults 1e-3 / 1e-6) */
+    double act_delay_reset[6]; /* DeadTimeProcessor(reset_action=...) returning `steps` copies of ONE action (dead_time_processor.py:27-50): that
+                               * action in the inner system's action space (a discrete index as a double); zeros = the reference's default */
 } orc_params;
 
 typedef struct orc_env {
@@ -1033,7 +1035,8 @@ void orc_reset(const orc_params *p, orc_env *e, double *obs) {
         obs[5] = i_dq[0]; obs[6] = i_dq[1]; obs[7] = u_abc[0]; obs[8] = u_abc[1]; obs[9] = u_abc[2];
         obs[10] = u_dq[0]; obs[11] = u_dq[1]; obs[12] = eps; obs[13] = u_sup;
     }
-    memset(e->fifo, 0, sizeof(e->fifo)); /* DeadTimeProcessor.reset: deque refilled with the reset action (zeros) */
+    for (int d = 0; d < 8; ++d) /* DeadTimeProcessor.reset (dead_time_processor.py:63-72): the deque is refilled with the reset actions */
+        for (int i = 0; i < 6; ++i) e->fifo[d][i] = p->act_delay_reset[i];
     normalise(p, obs);
     for (int i = 0; i < n_out(p); ++i) e->last_state[i] = obs[i] * p->limits[i]; /* dq processor reset(), line 96 */
 }

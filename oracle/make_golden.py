@@ -154,7 +154,7 @@ class _StepRecorder:
 
 
 def run_case(name, env_id, solver, K, seed, mode, episodic, space_kind, every=1, action_frame="abc", dead_time_steps=0,
-             record_reward=False, **make_kwargs):
+             record_reward=False, dead_time_reset_action=None, **make_kwargs):
     """action_frame: 'abc' | 'dq' (system.control_space = 'dq') | 'dq_processor' (DqToAbcActionProcessor wrapper);
     dead_time_steps > 0: DeadTimeProcessor(steps) wrapped INSIDE the dq processor, as the reference's processors expect."""
     from gym_electric_motor.physical_system_wrappers import DeadTimeProcessor, DqToAbcActionProcessor
@@ -162,7 +162,12 @@ def run_case(name, env_id, solver, K, seed, mode, episodic, space_kind, every=1,
     kw = dict(make_kwargs)
     wrappers = []
     if dead_time_steps:
-        wrappers.append(DeadTimeProcessor(steps=dead_time_steps))
+        if dead_time_reset_action is None:
+            wrappers.append(DeadTimeProcessor(steps=dead_time_steps))
+        else:  # a custom reset action (dead_time_processor.py:27-50): `steps` copies of one action of the inner system's action space
+            ra = dead_time_reset_action
+            one = int(ra[0]) if space_kind.startswith("disc") else (np.array(ra, dtype=np.int64) if space_kind.startswith("mdisc") else np.array(ra, dtype=np.float64))
+            wrappers.append(DeadTimeProcessor(steps=dead_time_steps, reset_action=lambda: [one] * dead_time_steps))
     if action_frame == "dq_processor":
         wrappers.append(DqToAbcActionProcessor.make("EESM" if "EESM" in env_id else "PMSM"))
     if wrappers:
@@ -201,6 +206,8 @@ def run_case(name, env_id, solver, K, seed, mode, episodic, space_kind, every=1,
     meta.update(name=name, env_id=env_id, solver=solver, K=K, seed=seed, mode=mode, episodic=bool(episodic),
                 every=every, constraints=("default" if episodic else "none"), action_frame=action_frame,
                 dead_time_steps=int(dead_time_steps))
+    if dead_time_reset_action is not None:
+        meta["dead_time_reset_action"] = [float(x) for x in dead_time_reset_action]
     idx = np.arange(K)
     keep = idx[(idx % every == every - 1)] if every > 1 else idx
     extra = {}
@@ -374,6 +381,8 @@ def main(only=None):
         main_supply()
     if not only or "init" in only:
         init_samples()
+    if only and "reset_action" in only:
+        main_reset_action()
     if only and "init_r04" in only:
         init_samples(only=INIT_CASES_R04)
     if not only or "wiener" in only:
@@ -408,6 +417,23 @@ def main_defaults():
     for i, env_id in enumerate(ALL_ENV_IDS):
         slug = env_id[:-3].replace("-", "_").lower()
         run_case(f"default_{slug}_dopri5", env_id, "dopri5", 800, 3000 + i, "held", True, default_space_kind(env_id))
+
+
+def main_reset_action():
+    """Round 4 (SURVEY 8f rank 2 leftover): DeadTimeProcessor(steps, reset_action=...) -- the deque refilled with a NON-zero action at every
+    reset (dead_time_processor.py:27-50, 63-72): continuous and discrete actions, episodic (refills inside the run), alone and inside the
+    dq processor."""
+    K = 1200
+    run_case("pmsm_cont_dead2_reset_epi_held_euler", "Cont-CC-PMSM-v0", "euler", K, 1320, "held", True, "box3", dead_time_steps=2,
+             dead_time_reset_action=[0.4, -0.3, 0.1])
+    run_case("pmsm_fin_dead3_reset_epi_uniform_tau1e-4_euler", "Finite-CC-PMSM-v0", "euler", K, 1321, "uniform", True, "disc8", tau=1e-4,
+             dead_time_steps=3, dead_time_reset_action=[5])
+    run_case("permexdc_cont_dead1_reset_epi_held_euler", "Cont-CC-PermExDc-v0", "euler", K, 1322, "held", True, "box1", dead_time_steps=1,
+             dead_time_reset_action=[-0.03])
+    run_case("pmsm_cont_dqproc_dead2_reset_epi_held_euler", "Cont-CC-PMSM-v0", "euler", K, 1323, "held", True, "box2",
+             action_frame="dq_processor", dead_time_steps=2, dead_time_reset_action=[0.2, 0.5, -0.4])
+    run_case("extex_fin_dead2_reset_epi_uniform_euler", "Finite-CC-ExtExDc-v0", "euler", K, 1324, "uniform", True, "mdisc44", dead_time_steps=2,
+             dead_time_reset_action=[2, 1])
 
 
 def main_r02():

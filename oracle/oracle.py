@@ -35,6 +35,7 @@ class OrcParams(C.Structure):
         ("init", C.c_double * MAX_ODE),
         ("sup_r", C.c_double), ("sup_c", C.c_double),
         ("rtol", C.c_double), ("atol", C.c_double),
+        ("act_delay_reset", C.c_double * 6),
     ]
 
 
@@ -132,6 +133,8 @@ def params_from_meta(meta, solver=None, episodic=None):
     # action-side wrappers / control space recorded by make_golden.run_case
     p.dq_mode = {"abc": 0, "dq": 1, "dq_processor": 2}[meta.get("action_frame", "abc")]
     p.act_delay = int(meta.get("dead_time_steps", 0))
+    for i, v in enumerate(meta.get("dead_time_reset_action") or []):  # DeadTimeProcessor(reset_action=lambda: [a] * steps): the one action a
+        p.act_delay_reset[i] = float(v)
     if meta["supply"] == "RCVoltageSupply":
         p.rc_supply, p.sup_r, p.sup_c = 1, meta["supply_parameter"]["R"], meta["supply_parameter"]["C"]
     return p

@@ -64,7 +64,13 @@ def _make_from_meta(meta, n_envs, solver=None, dtype="float32", episodic=None, o
     frame = meta.get("action_frame", "abc")
     wrappers = []
     if meta.get("dead_time_steps", 0):
-        wrappers.append(ga.DeadTimeProcessor(steps=meta["dead_time_steps"]))
+        ra = meta.get("dead_time_reset_action")
+        if ra is None:
+            wrappers.append(ga.DeadTimeProcessor(steps=meta["dead_time_steps"]))
+        else:  # a custom reset action recorded with the fixture (oracle/make_golden.py:main_reset_action): `steps` copies of one action
+            one = [int(x) for x in ra] if "Finite" in meta["env_id"] else [float(x) for x in ra]
+            one = one[0] if len(one) == 1 and "Finite" in meta["env_id"] else one
+            wrappers.append(ga.DeadTimeProcessor(steps=meta["dead_time_steps"], reset_action=lambda one=one, n=meta["dead_time_steps"]: [one] * n))
     if frame == "dq_processor":
         wrappers.append(ga.DqToAbcActionProcessor.make("EESM" if "EESM" in meta["env_id"] else "PMSM"))
     if wrappers:
@@ -1314,6 +1320,68 @@ def test_delayed_read_deadtime_queue_matches_the_fifo_representation(env_id, del
     if "PMSM" in env_id or "EESM" in env_id or "ShuntDc" in env_id or "PermExDc" in env_id:
         assert done.any()  # resets happened: the zero-action window after a reset was exercised
     for e in (env, ref, e2):
+        e.close()
+
+
+RESET_ACTION_CASES = ["pmsm_cont_dead2_reset_epi_held_euler", "pmsm_fin_dead3_reset_epi_uniform_tau1e-4_euler", "permexdc_cont_dead1_reset_epi_held_euler",
+                      "pmsm_cont_dqproc_dead2_reset_epi_held_euler", "extex_fin_dead2_reset_epi_uniform_euler"]
+
+
+@pytest.mark.parametrize("name", RESET_ACTION_CASES)
+def test_custom_dead_time_reset_action_in_every_kernel(name, monkeypatch):
+    """DeadTimeProcessor(steps, reset_action=...) (dead_time_processor.py:27-50; round 4): every reset -- gemx_reset and
+    the in-kernel auto-reset -- refills the queue with a NON-zero action.  The five fixtures recorded from the reference with such a
+    processor (continuous / discrete / MultiDiscrete actions, alone and inside the dq processor; episodic, so the refill happens inside
+    the run) are compared by the Euler golden tests like every other fixture; here every representation of the queue must agree bit for
+    bit: the pipelined kernel's deep shape (delayed reads / the row buffer of transformed actions), its <4, 2> shape (LDS FIFO), the
+    single-wave kernel, uneven chunks (the ring in HBM between launches) and step-by-step simulate() (step_kernel) -- with per-env
+    random actions and resets at different steps in different lanes."""
+    import torch
+
+    d, meta = _load(name)
+    n, K = 192, 150
+
+    def mk(pipe, shape=None):
+        monkeypatch.setenv("GEMX_PIPE", pipe)
+        if shape is None:
+            monkeypatch.delenv("GEMX_PIPE_SHAPE", raising=False)
+        else:
+            monkeypatch.setenv("GEMX_PIPE_SHAPE", shape)
+        return _make_from_meta(meta, n, solver="rk4", auto_reset=True)
+
+    env = mk("1", "0")
+    ps = env.physical_system
+    assert any(ps._cfg.action_delay_reset[i] != 0.0 for i in range(6)) and ps._cfg.action_delay == meta["dead_time_steps"]
+    g = torch.Generator(device="cuda").manual_seed(8)
+    if ps._discrete:
+        nflat = int(np.prod(ps.action_space.nvec)) if hasattr(ps.action_space, "nvec") else int(ps.action_space.n)
+        acts = torch.randint(0, nflat, (K, n), device="cuda", generator=g, dtype=torch.uint8)
+    else:
+        acts = torch.rand((K, n, ps._n_act), device="cuda", generator=g) * 2 - 1
+    obs, done = env.rollout(acts)
+    assert done.any() and not done.all()
+    for pipe, shape in (("1", "1"), ("0", None)):
+        e = mk(pipe, shape)
+        o, dn = e.rollout(acts)
+        assert torch.equal(o, obs) and torch.equal(dn, done), (pipe, shape, e.physical_system.last_launch())
+        e.close()
+    e2 = mk("1", "0")
+    parts, k0 = [], 0
+    for kk in (1, 2, 9, 24, 50, 64):
+        parts.append(e2.rollout(acts[k0:k0 + kk]))
+        k0 += kk
+    assert k0 == K and torch.equal(torch.cat([p_[0] for p_ in parts]), obs) and torch.equal(torch.cat([p_[1] for p_ in parts]), done)
+    e3 = mk("1")
+    for k in range(40):
+        assert torch.equal(e3.physical_system.simulate(acts[k]), obs[k]) and torch.equal(e3.physical_system.done, done[k]), k
+    # the reset action is what the converter sees right after a reset: a handle with the DEFAULT (zero) reset action differs
+    m0 = dict(meta)
+    m0.pop("dead_time_reset_action")
+    monkeypatch.setenv("GEMX_PIPE", "1")
+    e0 = _make_from_meta(m0, n, solver="rk4", auto_reset=True)
+    o0, _ = e0.rollout(acts)
+    assert not torch.equal(o0[0], obs[0])
+    for e in (env, e2, e3, e0):
         e.close()
 
 

@@ -429,6 +429,31 @@ def test_multi_converter_holders():
                 converter=ga.FiniteMultiConverter(subconverters=[ga.FiniteB6BridgeConverter, ga.FiniteB6BridgeConverter]))
 
 
+def test_dead_time_processor_reset_action_is_folded_into_the_config():
+    """DeadTimeProcessor(steps, reset_action=callable) (dead_time_processor.py:27-50): `steps` copies of ONE action travel as
+    gemx_config.action_delay_reset (a MultiDiscrete action as its flat index); different actions per slot are refused with a message;
+    the reference's default (None / zeros) leaves the row at zero; gemx_create validates a discrete index."""
+    ps = ga.make("Cont-CC-PMSM-v0", n_envs=2, _defer_create=True,
+                 physical_system_wrappers=(ga.DeadTimeProcessor(2, reset_action=lambda: [np.array([0.4, -0.3, 0.1])] * 2),)).physical_system
+    assert list(ps._cfg.action_delay_reset)[:4] == [0.4, -0.3, 0.1, 0.0] and ps._cfg.action_delay == 2
+    ps = ga.make("Finite-CC-ExtExDc-v0", n_envs=2, _defer_create=True,
+                 physical_system_wrappers=(ga.DeadTimeProcessor(3, reset_action=lambda: [[2, 1]] * 3),)).physical_system
+    assert ps._cfg.action_delay_reset[0] == 2 + 4 * 1 and ps._cfg.action_delay_reset[1] == 0.0
+    ps = ga.make("Finite-CC-PMSM-v0", n_envs=2, _defer_create=True, physical_system_wrappers=(ga.DeadTimeProcessor(2, reset_action=lambda: [5, 5]),)).physical_system
+    assert ps._cfg.action_delay_reset[0] == 5.0
+    ps = ga.make("Finite-CC-PMSM-v0", n_envs=2, _defer_create=True, physical_system_wrappers=(ga.DeadTimeProcessor(2),)).physical_system
+    assert not any(ps._cfg.action_delay_reset)
+    with pytest.raises(NotImplementedError, match="ONE action"):
+        ga.make("Finite-CC-PMSM-v0", n_envs=2, _defer_create=True, physical_system_wrappers=(ga.DeadTimeProcessor(2, reset_action=lambda: [5, 3]),))
+    with pytest.raises(ValueError, match="for a dead time of 2 steps"):
+        ga.make("Finite-CC-PMSM-v0", n_envs=2, _defer_create=True, physical_system_wrappers=(ga.DeadTimeProcessor(2, reset_action=lambda: [5]),))
+    L = _lib.load()
+    h = C.c_void_p()
+    bad = _lib.GemxConfig.from_buffer_copy(ps._cfg)
+    bad.action_delay_reset[0] = 8.0  # Finite-B6C has 8 switching states: 0 .. 7
+    assert L.gemx_create(C.byref(bad), 4, 0, C.byref(h)) == -1 and b"action_delay_reset" in L.gemx_last_error()
+
+
 def test_no_gpu_means_loud_failure_not_cpu_fallback():
     import torch
 
