@@ -501,6 +501,7 @@ struct gemx_handle {
     LastLaunch ll = {};            // most recent advance launch (formatted lazily by gemx_last_launch)
     mutable char last_launch[512] = "";
     char overrides[192] = "";  // the GEMX_* environment switches that were set when the handle was created ("NAME=value ..."): gemx_last_launch() names them
+    int pipe_regs[4] = {0, 0, 0, 0};  // VGPRs of the pipelined kernel's shape k (hipFuncGetAttributes, once): the launcher's residency arithmetic
     unsigned pipe_attr_set = 0;  // bit k: hipFuncSetAttribute(max dynamic LDS) done for pipelined shape k (per handle = per device:
     bool attr_set = false;       //   the attribute is per device, and a handle is bound to one device and one kernel instantiation)
     int wg_per_cu = 0;           // single-wave kernel: resident workgroups per CU from its VGPR count (0: not queried yet)

@@ -2138,8 +2138,18 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs<R> a) {
 // and one more hand-off value, from which the output waves take the u_sup column) and random initialisers (the rare auto-reset path
 // draws the new state in the integrator wave, reset counter in a register).  One extra instantiation (shape <4, 2>) instead of
 // burdening the common ones with the registers of that code (the fp64 Philox / inverse-CDF draw alone costs ~50 VGPRs).
+// The shallow shapes (<4, 2>, <2, 2>: four waves per workgroup) exist to put FOUR workgroups on a CU -- four waves per SIMD, i.e. at most 128
+// VGPRs -- and the launcher's residency arithmetic (LDS, wave slots) takes that for granted.  Several instantiations land a handful of
+// registers above the line on their own (SCIM RK4 <4, 2>: 129; SCIM error-controlled <2, 2>: 134, which ran BASELINE config 4 under
+// ScipyOdeSolver() in two rounds instead of one: tools/vgpr_report.py, profiles/r04j_vgpr_report.md), and which side of it a kernel falls
+// on moves with every unrelated edit.  So the line is REQUESTED where the natural count is close to it (everything but the DFIM's rows and
+// the dead-time variants of the fixed DP5 step, which need 160-170: forcing those would spill into the step loop).
+template <int SYS, int SOLVER, bool IL, int D, bool FULL> constexpr int pipe_waves_per_eu() {
+    return (D <= 4 && !FULL && SYS != GEMX_SYS_DFIM && !(SOLVER == GEMX_SOLVER_DP5 && IL)) ? 4 : 1;
+}
 template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R, int D, int OW, bool FULL = false>
-__global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advance_pipe_kernel(const KArgs<R> a) {
+__global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) __attribute__((amdgpu_waves_per_eu(pipe_waves_per_eu<SYS, SOLVER, IL, D, FULL>())))
+void advance_pipe_kernel(const KArgs<R> a) {
     constexpr int LW = pipe_loader_waves(D);  // 1: a loader wave stages actions / references instead of the integrator
     constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
     constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
@@ -2254,12 +2264,11 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
         for (int j = 0; j < ND; ++j) { init_v[j] = P.init[j]; asm volatile("" : "+v"(init_v[j])); }
         AngT init_ang_v = init_ang;
         asm volatile("" : "+v"(init_ang_v));
-        // DeadTimeProcessor reset action (zeros unless the handle carries a custom one), in VGPRs for the same reason
-        R dreset_v[NACTC];
-#pragma unroll
-        for (int i = 0; i < NACTC; ++i) { dreset_v[i] = P.dreset[i]; asm volatile("" : "+v"(dreset_v[i])); }
-        uint32_t dreset_dv = P.dreset_d;
-        asm volatile("" : "+v"(dreset_dv));
+        // (The DeadTimeProcessor's reset action, P.dreset / P.dreset_d, is NOT given VGPRs of its own like the reset values above: four
+        // registers that are live through every instantiation pushed the <4, 2> SCIM kernel from 125 to 129 VGPRs and the error-controlled
+        // <2, 2> one from 130 to 134 -- across the 128-register line, three resident workgroups per CU instead of four, BASELINE config 4
+        // with ScipyOdeSolver() at half its rate (profiles/r04i_bench.json against r04g).  The selects that read it sit in the
+        // DeadTimeProcessor copies of the step only and pay a v_mov each there.)
         R sup[2] = {P.u_sup, R(0)};  // RCVoltageSupply: capacitor voltage, time since the supply's last update (FULL)
         uint32_t rcount = 0;         // random initialisers: resets of this env so far (FULL)
         if constexpr (FULL) {
@@ -2358,7 +2367,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                     qw[i] = t;                                   // row s + delay
                     const R q = one_deep ? tprev[i] : qpre[i];   // row s
                     tprev[i] = t;
-                    act[i] = queued ? q : dreset_v[i];           // (the refilled reset action right after a reset)
+                    act[i] = queued ? q : P.dreset[i];           // (the refilled reset action right after a reset)
                     qpre[i] = qnext[i];
                 }
             }
@@ -2451,14 +2460,15 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
             }
             if constexpr (MODE == 2 || MODE == 3) since = rs ? 0u : (since < delay_u ? since + 1u : delay_u);
             if (FIFO && P.delay > 0) {  // DeadTimeProcessor.reset: the deque is refilled with the reset action
-                if (rs) {
+                if (rs) {  // (rare, exec-masked: the reset action is an SGPR operand of plain moves here -- as the VGPR operand of a select in
+                           // every step it held NACTC registers live through the loop and took the shallow kernels across the 128-VGPR line)
                     for (int d = 0; d < P.delay; ++d) {
 #pragma unroll
-                        for (int i = 0; i < NACTC; ++i) fifo[((size_t)d * BLOCK + tid) * NACTC + i] = dreset_v[i];
+                        for (int i = 0; i < NACTC; ++i) fifo[((size_t)d * BLOCK + tid) * NACTC + i] = P.dreset[i];
                     }
-                }
 #pragma unroll
-                for (int i = 0; i < NACTC; ++i) pop[i] = rs ? dreset_v[i] : pop[i];
+                    for (int i = 0; i < NACTC; ++i) pop[i] = P.dreset[i];
+                }
             }
         };
         stage_actions(0);
@@ -2539,7 +2549,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                             const bool queued = since >= delay_u;  // else: the refilled reset action
 #pragma unroll
                             for (int j = 0; j < ST::NVT; ++j) ec[j] = queued ? ec[j] : e0[j];
-                            if constexpr (COMPACT_K) dc = queued ? dc : dreset_dv;  // (compact rows carry the action the converter saw)
+                            if constexpr (COMPACT_K) dc = queued ? dc : P.dreset_d;  // (compact rows carry the action the converter saw)
                         }
                         one_step(Mode{}, ac, dc, hb + (size_t)s * BLOCK * NHT, ec);
                     }
@@ -2552,9 +2562,9 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                         rd(s + 1 < D ? s + 1 : s, an, dn);  // one step ahead: its LDS latency hides behind this step
                         if constexpr (DEL) {
                             const bool queued = since >= delay_u;
-                            dc = queued ? dc : dreset_dv;
+                            dc = queued ? dc : P.dreset_d;
 #pragma unroll
-                            for (int i = 0; i < NACT; ++i) ac[i] = queued ? ac[i] : (i < NACTC ? dreset_v[i < NACTC ? i : 0] : R(0));
+                            for (int i = 0; i < NACT; ++i) ac[i] = queued ? ac[i] : (i < NACTC ? P.dreset[i < NACTC ? i : 0] : R(0));
                         }
                         one_step(Mode{}, ac, dc, hb + (size_t)s * BLOCK * NHT, nullptr);
                     }
@@ -2575,9 +2585,9 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
                         for (int s = 0; s < sb; ++s) {
                             read_delayed(s, ac, dc);
                             const bool queued = since >= delay_u;
-                            dc = queued ? dc : dreset_dv;
+                            dc = queued ? dc : P.dreset_d;
 #pragma unroll
-                            for (int i = 0; i < NACT; ++i) ac[i] = queued ? ac[i] : (i < NACTC ? dreset_v[i < NACTC ? i : 0] : R(0));
+                            for (int i = 0; i < NACT; ++i) ac[i] = queued ? ac[i] : (i < NACTC ? P.dreset[i < NACTC ? i : 0] : R(0));
                             if constexpr (USE_TAB) fetch_entry(dc, ect);
                             one_step(std::integral_constant<int, 2>{}, ac, dc, hb + (size_t)s * BLOCK * NHT, ect);
                         }
@@ -2711,7 +2721,7 @@ __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) void advan
 #pragma unroll
             for (int i = 0; i < NACTC; ++i) {
                 const int64_t gi = ((int64_t)dst * N + env) * NACTC + i;
-                const R v = keep ? fifo[((size_t)d * BLOCK + tid) * NACTC + i] : dreset_v[i];
+                const R v = keep ? fifo[((size_t)d * BLOCK + tid) * NACTC + i] : P.dreset[i];
                 if (DISCRETE) a.ring[gi] = (unsigned char)(uint32_t)v;
                 else reinterpret_cast<R *>(a.ring)[gi] = v;
             }
@@ -3607,7 +3617,10 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         bool dcs_ok = pipe_ok && h->use_dc_stream != 0 && !need_full && delay == 0 && !(h->cfg.solver_flags & GEMX_SOLVER_ADAPTIVE) && h->cur_reward == nullptr && (h->omega_is_init || h->use_dc_stream >= 3) &&
                       params_of<R>(h).obs_layout == GEMX_OBS_AOS && params_of<R>(h).t_il == R(0) &&
                       (h->use_dc_stream > 1 || 2 * blocks <= (int64_t)h->n_cu) && dcs_smem_bytes<SYS, CONV>() <= h->lds_max &&
-                      (int64_t)h->n * h->nout * 32 < ((int64_t)1 << 32);  // (32-bit lane offsets across the four / eight rows of a (double) group)
+                      (int64_t)h->n * h->nout * 64 < ((int64_t)1 << 31);  // (SIGNED 32-bit store offsets: lane offsets across the rows of a (double)
+                                                                          // group plus the per-group offset of up to 16 rows x N x NOUT x 4 bytes
+                                                                          // of the two-state form -- advisor finding, round 3; only reachable with
+                                                                          // GEMX_DC_STREAM >= 2 forcing the kernel beyond its 8192 envs)
         if (dcs_ok) {
             // never into a graph: `omega_is_init` is what the host knows NOW, a captured launch runs later, possibly behind a gemx_set_state.
             // The pipelined kernel decides on the device (lin_usable), so it is what a graph gets.
@@ -3651,10 +3664,31 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             if (ST::NVT > 0 && ConvTraits<CONV>::DISCRETE) b += (size_t)ConvTraits<CONV>::NACTIONS * 8 * sizeof(R);  // per-action voltage table
             return (b + 15) & ~(size_t)15;
         };
+        // workgroups of a shape one CU holds: LDS, wave slots -- and REGISTERS (round 4: the arithmetic used to stop at the first two and
+        // took four resident workgroups of a shallow shape for granted; a kernel at 129-136 VGPRs holds three, and a "one round" rule that
+        // does not know runs a round plus a tail.  hipFuncGetAttributes once per handle and shape.)
+        auto regs_limit = [&](int shape_, int waves_per_wg) -> int64_t {
+            if (h->pipe_regs[shape_] == 0) {
+                const void *kp = shape_ == 0   ? (const void *)advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES>
+                                 : shape_ == 1 ? (const void *)advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2>
+                                 : shape_ == 2 ? (const void *)advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D3, PIPE_OUT_WAVES3>
+                                               : (const void *)advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES_RW>;
+                hipFuncAttributes fa;
+                h->pipe_regs[shape_] = (hipFuncGetAttributes(&fa, kp) == hipSuccess && fa.numRegs > 0) ? fa.numRegs : 128;
+            }
+            int waves_per_simd = 512 / ((h->pipe_regs[shape_] + 7) & ~7);  // gfx950: 512 VGPRs per SIMD lane, allocation granule 8
+            if (waves_per_simd < 1) waves_per_simd = 1;
+            if (waves_per_simd > 8) waves_per_simd = 8;
+            return (int64_t)(4 * waves_per_simd) / waves_per_wg;
+        };
         auto resident = [&](int D, int OW) {
             int64_t w = (int64_t)(h->lds_max / smem_of(D));
-            const int64_t wmax = 32 / (1 + OW + pipe_loader_waves(D));
-            return (w > wmax ? wmax : w) * (int64_t)h->n_cu;
+            const int waves_per_wg = 1 + OW + pipe_loader_waves(D);
+            const int64_t wmax = 32 / waves_per_wg;
+            const int64_t wreg = regs_limit(D == PIPE_D ? (OW == PIPE_OUT_WAVES ? 0 : 3) : (D == PIPE_D2 ? 1 : 2), waves_per_wg);
+            w = w > wmax ? wmax : w;
+            w = w > wreg ? wreg : w;
+            return (w < 1 ? 1 : w) * (int64_t)h->n_cu;
         };
         // one resident round of the 4-wave shape if N is that small, else the 3-wave shape at ANY N: measured at 131072 and 1048576
         // envs over all motor families (profiles/r01d_matrix.md) it is on par with or ahead of the single-wave kernel (PMSM

@@ -76,12 +76,37 @@ def main():
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", args.out] + objs)
     if args.inplace:
+        # (advisor finding, round 3) the library-wide stamp may only say "current" if EVERY object linked above was built from the current
+        # sources: after an edit to a shared header (gemx_kernels.hpp, gemx_common.hpp) the objects that were not named here are stale, and a
+        # mixed-layout library (KArgs / DevParams) would otherwise be loaded in silence
+        stale = []
+        for s_, c_ in b.UNITS:
+            for f64 in (0, 1):
+                name = f"gemx_inst_{s_}_{c_}_{f64}.o"
+                if name in replaced:
+                    continue
+                st = os.path.join(b.OBJ_DIR, name + ".sha256")
+                want = b._digest([os.path.join(b.CSRC, f) for f in b._DEPS["inst"]])
+                if not os.path.exists(st) or open(st).read().strip() != want:
+                    stale.append(name)
+        for name, kind in (("gemx_capi.o", "capi"), ("gemx_refgen.o", "refgen")):
+            if name in replaced:
+                continue
+            st = os.path.join(b.OBJ_DIR, name + ".sha256")
+            if not os.path.exists(st) or open(st).read().strip() != b._digest([os.path.join(b.CSRC, f) for f in b._DEPS[kind]]):
+                stale.append(name)
         for name, obj in replaced.items():  # the per-object stamps build_library() goes by
             kind = "capi" if name == "gemx_capi.o" else "inst"
             with open(obj + ".sha256", "w") as fh:
                 fh.write(b._digest([os.path.join(b.CSRC, f) for f in b._DEPS[kind]]))
-        with open(b.STAMP, "w") as fh:
-            fh.write(b._digest())
+        if stale:
+            print(f"dev_build --inplace: {len(stale)} other object(s) were built from OLDER sources ({', '.join(stale[:4])}{' ...' if len(stale) > 4 else ''}): "
+                  "the library-wide stamp is NOT updated -- build.is_stale() stays True until build_library() has recompiled them", file=sys.stderr)
+            if os.path.exists(b.STAMP):
+                os.remove(b.STAMP)
+        else:
+            with open(b.STAMP, "w") as fh:
+                fh.write(b._digest())
     print(args.out)
 
 
