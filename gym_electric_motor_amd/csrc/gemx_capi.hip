@@ -561,7 +561,7 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         }
         // every switch below changes which kernel a PRODUCT call runs: whatever is set is recorded and shows up in gemx_last_launch(), so that
         // a stray variable cannot silently change a benchmark (round 3 verdict)
-        for (const char *name : {"GEMX_STEPS_PER_BLOCK", "GEMX_PIPE", "GEMX_PIPE_SHAPE", "GEMX_STEP_KERNEL", "GEMX_DC_STREAM", "GEMX_DCS_EPW", "GEMX_LINMAP"}) {
+        for (const char *name : {"GEMX_STEPS_PER_BLOCK", "GEMX_PIPE", "GEMX_PIPE_SHAPE", "GEMX_STEP_KERNEL", "GEMX_DC_STREAM", "GEMX_DCS_EPW", "GEMX_LINMAP", "GEMX_PACE_GBPS"}) {
             const char *v = getenv(name);
             if (v == nullptr) continue;
             const size_t used = strlen(h->overrides);
@@ -580,6 +580,8 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         if (ev) h->use_dc_stream = atoi(ev);
         ev = getenv("GEMX_DCS_EPW");  // 64: dc_stream_kernel with one env per lane at every size (A/B runs; default: 32 envs per workgroup where they find a CU each)
         if (ev) h->dcs_epw = atoi(ev);
+        ev = getenv("GEMX_PACE_GBPS");  // target rate of the large-batch rate limiter in GB/s (A/B runs); 0: off
+        if (ev) h->pace_gbps = atof(ev);
         ev = getenv("GEMX_LINMAP");  // 0: never use the one-step map of the electrical subsystem (A/B runs)
         if (ev && atoi(ev) == 0) h->linmap_state = -1;
 
@@ -831,11 +833,16 @@ const char *gemx_last_launch(const gemx_handle *h) {
     else if (l.pipe == 2)
         snprintf(h->last_launch, sizeof(h->last_launch), "gemx::step_kernel<sys=%d,conv=%d,load=%d,solver=%d,il=%d,%s> grid=%lld x %d threads, K=1", l.sys, l.conv,
                  l.load, l.solver, l.il, l.real_size == 4 ? "f32" : "f64", l.blocks, l.threads);
-    else if (l.pipe)
+    else if (l.pipe) {
         snprintf(h->last_launch, sizeof(h->last_launch),
                  "gemx::advance_pipe_kernel<sys=%d,conv=%d,load=%d,solver=%d,il=%d,%s,D=%d> grid=%lld x %d threads, lds=%zu B, K=%d", l.sys,
                  l.conv, l.load, l.solver, l.il, l.real_size == 4 ? "f32" : "f64", l.d, l.blocks, l.threads, l.lds, l.k);
-    else
+        if (l.pace != 0) {  // the large-batch rate limiter was set for this launch: interval per hand-off block, and what it was priced for
+            const size_t used = strlen(h->last_launch);
+            snprintf(h->last_launch + used, sizeof(h->last_launch) - used, ", rate limit %u0 ns per block (%lld resident workgroups%s)", l.pace,
+                     l.pace_res < l.blocks ? l.pace_res : l.blocks, l.pace_tail != 0 ? "; shorter in the last round" : "");
+        }
+    } else
         snprintf(h->last_launch, sizeof(h->last_launch),
                  "gemx::advance_kernel<sys=%d,conv=%d,load=%d,solver=%d,il=%d,%s> grid=%lld x %d threads, lds=%zu B, K=%d, S=%d", l.sys, l.conv,
                  l.load, l.solver, l.il, l.real_size == 4 ? "f32" : "f64", l.blocks, l.threads, l.lds, l.k, l.s);

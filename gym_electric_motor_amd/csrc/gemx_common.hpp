@@ -414,6 +414,11 @@ template <class R> struct KArgs {
     int32_t D;                      // pipelined kernel: control steps per hand-off block (one barrier per D steps)
     int32_t coop;                   // 1: action rows / done rows of full blocks are 16-byte aligned -> cooperative staging
     int32_t obs_vec;                // 1: observation rows of full blocks are 16-byte aligned -> 16-byte stores
+    // pipelined kernel, large batches: a RATE LIMIT on every workgroup -- hand-off block b starts no earlier than b * pace_block_ticks
+    // ticks of the constant 100 MHz clock (s_memrealtime) after the workgroup's start; 0 = none.  See launch_advance_t.
+    uint32_t pace_block_ticks;
+    uint32_t pace_tail_ticks;       // ... of the workgroups from index pace_tail_from on: the LAST round, which has the chip to itself with fewer
+    uint32_t pace_tail_from;        //     workgroups than a full one and may run that much faster each
 };
 
 // FIFO slot of this launch's first step (0 without a DeadTimeProcessor) / its advance by the last workgroup to finish: every workgroup
@@ -445,7 +450,12 @@ constexpr int PIPE_D3 = 2, PIPE_OUT_WAVES3 = 2;
 // both shapes carry a LOADER wave that stages actions / references global -> LDS (0: the integrator wave stages them itself).  Measured
 // at 131072 envs over all motor families (same box A/B): -5 .. +22 %, the heavier steppers and the continuous-action ones gain most
 constexpr int pipe_loader_waves(int) { return 1; }
-constexpr int PIPE_ACT_BUFS = 2;  // action staging buffers of the pipelined kernel: the loader wave runs one block ahead
+// action staging buffers of the pipelined kernel: the loader wave runs one block ahead.  (Two ahead through a third buffer: round 2 saw no
+// change; round 4 tried again for the launches whose action tensor no longer fits the 256 MB Infinity Cache -- PMSM cont from 22 M
+// env-steps per launch, where the rate falls from 0.89 to 0.68 of the roofline -- and again nothing moved (16384 envs x 2000 steps 0.687 ->
+// 0.683, PermExDc cont 131072 x 1000 0.573 -> 0.570) while the extra LDS cost EESM cont its deep shape: profiles/r04r_probe4.txt.  The
+// loss there is the HBM serving reads between the writes, not the latency of this wave's loads.)
+constexpr int PIPE_ACT_BUFS = 2;
 // rows of the pipelined kernel's per-lane action queue in LDS: `delay` (FIFO / carry rows), or D + delay where the queue of TRANSFORMED
 // actions behind a DqToAbcActionProcessor is kept as a row buffer indexed by the step of the block (deep shape only)
 __host__ __device__ constexpr int pipe_queue_rows(int D, int delay, bool dq_processor, bool full) {
@@ -497,10 +507,13 @@ struct gemx_handle {
     int n_cu = 256;
     size_t lds_max = 160 * 1024;
     int steps_per_block = 0;  // 0 = heuristic
-    struct LastLaunch { int pipe, sys, conv, load, solver, il, real_size, d, threads, k, s; long long blocks; size_t lds; };
+    struct LastLaunch { int pipe, sys, conv, load, solver, il, real_size, d, threads, k, s; long long blocks; size_t lds; unsigned pace, pace_tail; long long pace_res; };
     LastLaunch ll = {};            // most recent advance launch (formatted lazily by gemx_last_launch)
     mutable char last_launch[512] = "";
     char overrides[192] = "";  // the GEMX_* environment switches that were set when the handle was created ("NAME=value ..."): gemx_last_launch() names them
+    double pace_gbps = -1.0;  // target chip-wide algorithmic rate of the rate limiter [GB/s]; < 0: the built-in default, 0: off (GEMX_PACE_GBPS)
+    size_t pipe_occ_smem[4] = {0, 0, 0, 0};
+    int pipe_occ[4] = {0, 0, 0, 0};   // ... and the workgroups per CU the runtime reports for it with this handle's LDS bytes (occupancy API, once)
     int pipe_regs[4] = {0, 0, 0, 0};  // VGPRs of the pipelined kernel's shape k (hipFuncGetAttributes, once): the launcher's residency arithmetic
     unsigned pipe_attr_set = 0;  // bit k: hipFuncSetAttribute(max dynamic LDS) done for pipelined shape k (per handle = per device:
     bool attr_set = false;       //   the attribute is per device, and a handle is bound to one device and one kernel instantiation)

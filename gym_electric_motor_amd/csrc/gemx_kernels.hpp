@@ -2144,6 +2144,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs<R> a) {
 // ScipyOdeSolver() in two rounds instead of one: tools/vgpr_report.py, profiles/r04j_vgpr_report.md), and which side of it a kernel falls
 // on moves with every unrelated edit.  So the line is REQUESTED where the natural count is close to it (everything but the DFIM's rows and
 // the dead-time variants of the fixed DP5 step, which need 160-170: forcing those would spill into the step loop).
+// target of the large-batch rate limiter: chip-wide algorithmic GB/s (tools/microbench_rowpitch.hip, profiles/r04k_*; GEMX_PACE_GBPS overrides)
+#ifndef GEMX_PACE_DEFAULT_ON
+#define GEMX_PACE_DEFAULT_ON 1
+#endif
 template <int SYS, int SOLVER, bool IL, int D, bool FULL> constexpr int pipe_waves_per_eu() {
     return (D <= 4 && !FULL && SYS != GEMX_SYS_DFIM && !(SOLVER == GEMX_SOLVER_DP5 && IL)) ? 4 : 1;
 }
@@ -2480,7 +2484,31 @@ void advance_pipe_kernel(const KArgs<R> a) {
 #ifdef GEMX_TIMING
         unsigned long long tv = 0, tc = 0, tw = 0, tlong = 0, T0 = clock64(), W0 = wall_clock64(), t0, t0b, t1, t2;
 #endif
+        // Rate limit (round 4; a.pace_block_ticks, set by the launcher for large batches only): the write path of this chip delivers MORE when
+        // it is offered slightly less than it can take -- the rollout's store pattern as a pure store kernel (tools/microbench_rowpitch.hip)
+        // moves 5.2-5.4 TB/s at every batch size when the stores are issued as fast as they go, and 6.0-6.9 TB/s when every workgroup is
+        // held to one row per interval (16384 envs 0.675 -> 0.869 of the 8 TB/s; 65536 envs, four workgroups per CU, 0.655 -> 0.795).  At 16384
+        // envs the integrator's own instruction stream is that pacing (one workgroup per CU, a row per ~330 cycles); in the large batches
+        // nothing paces the output waves, they run into the congested path and the whole launch sits at 0.60-0.70.  So the wave that drives
+        // the block loop waits for the block's slot on the constant 100 MHz clock; one s_memrealtime per block.
+        // Not in the deep shape with six output waves (PIPE_PACED; the launcher uses it for one workgroup per CU only while the limiter is on):
+        // there the mere presence of the clock read and the wait loop in the block loop cost the UNPACED headline launch 5 % (same box, 16384
+        // envs: 145 -> 153 us per 1000 steps, profiles/r04p_ab_old.txt).  <12, 3> keeps it: the DC machines run it at two workgroups per CU
+        // (32768 envs, ShuntDc / ExtExDc finite 0.62 unpaced -> 0.83 paced; <4, 2> paced 0.73-0.76: profiles/r04p_shape_32768.txt).
+        constexpr bool PIPE_PACED = !(D == PIPE_D && OW == PIPE_OUT_WAVES_RW);
+        uint32_t pace = 0u;
+        unsigned long long pace_t0 = 0ull;
+        if constexpr (PIPE_PACED) {
+            pace = blockIdx.x >= a.pace_tail_from ? a.pace_tail_ticks : a.pace_block_ticks;
+            pace_t0 = pace != 0u ? wall_clock64() : 0ull;
+        }
         for (int b = 0; b < nb; ++b) {
+            if constexpr (PIPE_PACED) {
+                if (pace != 0u) {
+                    const unsigned long long due = pace_t0 + (unsigned long long)b * pace;
+                    while (wall_clock64() < due) __builtin_amdgcn_s_sleep(4);
+                }
+            }
 #ifdef GEMX_TIMING
             t0 = clock64();
 #endif
@@ -2743,7 +2771,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
         if (DISCRETE) __syncthreads();
         // (Staging TWO blocks ahead through a third buffer was tried in round 2 -- the s_memtime probe shows this wave's loads taking longer
         // than the integrator's block in the shallow shapes -- and changed nothing, same box, over all motor families:
-        // profiles/r02h_loader_depth.md.)
+        // profiles/r02h_loader_depth.md; and again in round 4 for action tensors too large for the Infinity Cache: PIPE_ACT_BUFS.)
         for (int b = 0; b < nb; ++b) {
 #ifdef GEMX_TIMING
             const unsigned long long l0 = clock64();
@@ -3681,13 +3709,39 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             if (waves_per_simd > 8) waves_per_simd = 8;
             return (int64_t)(4 * waves_per_simd) / waves_per_wg;
         };
+        // ... and what the runtime itself says a CU holds (hipOccupancyMaxActiveBlocksPerMultiprocessor with this launch's LDS bytes, once
+        // per handle and shape): the rate limiter below prices every workgroup's interval with the number of workgroups that are
+        // RUNNING, and the PermExDc <4, 2> kernel, eight per CU by LDS, wave slots and registers, runs five (r04m: 98304 envs paced for
+        // 1536 concurrent workgroups with ~1280 resident ran 0.54 of the roofline against 0.90 at 65536)
+        auto occ_limit = [&](int shape_, int threads, size_t smem_b) -> int64_t {
+            if (h->pipe_occ[shape_] == 0 || h->pipe_occ_smem[shape_] != smem_b) {  // (the LDS bytes move with the fused reward / the queue depth)
+                const void *kp = shape_ == 0   ? (const void *)advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES>
+                                 : shape_ == 1 ? (const void *)advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2>
+                                 : shape_ == 2 ? (const void *)advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D3, PIPE_OUT_WAVES3>
+                                               : (const void *)advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES_RW>;
+                int nb_ = 0;
+                h->pipe_occ_smem[shape_] = smem_b;
+                if (!(h->pipe_attr_set & (1u << shape_))) {
+                    (void)hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max);
+                    h->pipe_attr_set |= 1u << shape_;
+                }
+                h->pipe_occ[shape_] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, kp, threads, smem_b) == hipSuccess && nb_ > 0) ? nb_ : 64;
+                (void)hipGetLastError();
+            }
+            return (int64_t)h->pipe_occ[shape_];
+        };
         auto resident = [&](int D, int OW) {
             int64_t w = (int64_t)(h->lds_max / smem_of(D));
             const int waves_per_wg = 1 + OW + pipe_loader_waves(D);
             const int64_t wmax = 32 / waves_per_wg;
-            const int64_t wreg = regs_limit(D == PIPE_D ? (OW == PIPE_OUT_WAVES ? 0 : 3) : (D == PIPE_D2 ? 1 : 2), waves_per_wg);
+            const int shape_ = D == PIPE_D ? (OW == PIPE_OUT_WAVES ? 0 : 3) : (D == PIPE_D2 ? 1 : 2);
+            const int64_t wreg = regs_limit(shape_, waves_per_wg);
             w = w > wmax ? wmax : w;
             w = w > wreg ? wreg : w;
+            if (smem_of(D) <= h->lds_max) {
+                const int64_t wocc = occ_limit(shape_, waves_per_wg * BLOCK, smem_of(D));
+                w = w > wocc ? wocc : w;
+            }
             return (w < 1 ? 1 : w) * (int64_t)h->n_cu;
         };
         // one resident round of the 4-wave shape if N is that small, else the 3-wave shape at ANY N: measured at 131072 and 1048576
@@ -3708,13 +3762,28 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         bool deep_rounds = false;
         // (not behind a DeadTimeProcessor: its delayed-read blocks are slower in the deep shape than <4, 2>'s queue: 131072 envs 0.57 against 0.69)
         // (nor with the fused reward, whose output waves are the bound at large N either way: 131072 envs 0.56 against 0.60)
-        if (compact_l && K >= 400 && delay == 0 && h->cur_reward == nullptr && smem_of(PIPE_D) <= h->lds_max) {
+        // (round 4: only while the rate limiter is OFF.  With it the shallow shapes hold 0.79 at every size from 32768 envs on, the deep shape in
+        // rounds 0.64-0.77: profiles/r04m_pace_shapes.txt)
+        const bool pacing_on = (h->pace_gbps < 0.0 ? GEMX_PACE_DEFAULT_ON != 0 : h->pace_gbps > 0.0) && K >= 64;
+        if (compact_l && !pacing_on && K >= 400 && delay == 0 && h->cur_reward == nullptr && smem_of(PIPE_D) <= h->lds_max) {
             const int64_t res0 = resident(PIPE_D, PIPE_OUT_WAVES_RW), rounds = (blocks + res0 - 1) / res0;
             deep_rounds = blocks > res0 && 100 * blocks >= 85 * rounds * res0;
         }
-        if (smem_of(PIPE_D) <= h->lds_max && (blocks <= resident(PIPE_D, PIPE_OUT_WAVES) || deep_rounds)) {
+        // (limiter on: the deep shape up to TWO workgroups per CU -- at three, 49152 envs, the DC machines it fits run 0.76 / 0.59 / 0.33 (PermExDc /
+        // ShuntDc / SeriesDc SC) against 0.86 / 0.85 / 0.60 through <4, 2> under the limiter: profiles/r04p_shape_32768.txt)
+        // LONG launches at one workgroup per CU lose their rate as well: the headline holds 0.80-0.83 of the roofline up to 1000 steps per launch,
+        // 0.75 at 2000, 0.70 at 3000, 0.68 at 6000 -- workgroups that start in the same phase drift apart, and the stores of a CU's neighbours
+        // stop landing in the same DRAM rows.  The limiter is also a clock that keeps them together: the same launches through <12, 3> at
+        // the 32768-env target run 0.83 / 0.84 at 3000 / 6000 steps (PMSM cont 0.69 / 0.70 -> 0.77 / 0.79; profiles/r04r_probe5.txt).  Only the
+        // rows whose integrator is faster than the target gain (the synchronous machines on the one-step map); an integrator-bound
+        // row pays 3-6 % for the clock reads (SCIM finite 0.66 -> 0.62, ShuntDc 0.54 -> 0.52) and keeps its unpaced launch.
+        const bool long_one = pacing_on && h->pace_gbps < 0.0 && K >= 1500 && SYS == GEMX_SYS_SYNC && h->pf.lin_on != 0 && !need_full && h->cur_reward == nullptr &&
+                              blocks <= (int64_t)h->n_cu;
+        const int64_t deep_max = pacing_on && resident(PIPE_D, PIPE_OUT_WAVES) > 2 * (int64_t)h->n_cu ? 2 * (int64_t)h->n_cu : resident(PIPE_D, PIPE_OUT_WAVES);
+        if (smem_of(PIPE_D) <= h->lds_max && (blocks <= deep_max || deep_rounds)) {
             D = PIPE_D; OW = PIPE_OUT_WAVES; shape = 0;
-            if (h->cur_reward != nullptr || compact_l) { OW = PIPE_OUT_WAVES_RW; shape = 3; }
+            // (long launches of the synchronous machines' one-step-map rows: <12, 3>, which carries the rate limiter -- see `long_one` below)
+            if (h->cur_reward != nullptr || (compact_l && !long_one)) { OW = PIPE_OUT_WAVES_RW; shape = 3; }
         }
         else if (smem_of(PIPE_D3) <= h->lds_max && blocks <= resident(PIPE_D3, PIPE_OUT_WAVES3) &&
                  blocks > resident(PIPE_D2, PIPE_OUT_WAVES2) && 2 * blocks <= 3 * resident(PIPE_D2, PIPE_OUT_WAVES2)) {
@@ -3747,6 +3816,47 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         if (D != 0) {
             a.S = D;
             a.D = D;
+            // the rate limiter (advance_pipe_kernel): only where the batch oversubscribes the write path -- more workgroups than CUs; at one
+            // workgroup per CU in one round the integrator's instruction stream is the pacing, and an s_memrealtime per block would only cost
+            // it time.  interval per row and workgroup = algorithmic bytes of a 64-env step x workgroups resident on the chip / target rate.
+            int64_t pace_res = 0;
+            a.pace_block_ticks = 0;
+            a.pace_tail_ticks = 0;
+            a.pace_tail_from = 0xFFFFFFFFu;
+            {
+                // Target: a few per cent under the knee the sweeps over the real kernels found (profiles/r04l_pace_sweep.txt, r04n_pace_sweep2.txt;
+                // same box, of the 8 TB/s).  Under the limiter a launch runs at ~0.98 x target / 8000 up to the knee and collapses beyond it:
+                // rows of 14-24 values (3.5-6 KB per workgroup and step) at 32768 / 65536 / 131072 envs peak at 7000-7200 / 6800-7000 / 6400-6600
+                // GB/s (PMSM finite 0.65 / 0.66 / 0.65 unpaced -> 0.85 / 0.84 / 0.80 at the knee, 0.66 / 0.79 / 0.76 one step beyond it; SCIM,
+                // EESM, DFIM finite alike), the DC machines' 5-7 values (1.3-1.8 KB) at 7200-7600 / 7200 / 7000 (ShuntDc 0.62 / 0.61 / 0.65 ->
+                // 0.85 / 0.87 / 0.80).  The knee moves down with the number of workgroups in flight.  Kernels whose integrators offer less
+                // than the target (the speed-control rows, 16384 envs) never wait and are unchanged.
+                const bool few = blocks <= 2 * (int64_t)h->n_cu, some = blocks <= 4 * (int64_t)h->n_cu;
+                // Launches that also READ eight bytes or more per env-step (continuous duty cycles through the loader wave) have the knee lower and
+                // a softer landing beyond it (back to the unpaced level, not below): 65536 / 131072 envs PMSM cont 0.66 / 0.63 unpaced -> 0.68 / 0.63
+                // at 6000 / 5600, EESM cont 0.62 / 0.59 -> 0.73 / 0.66, DFIM cont 0.60 / 0.70 -> 0.72 / 0.69, control_space='dq' 0.62 / 0.62 -> 0.68 /
+                // 0.65, ExtExDc cont 0.72 / 0.64 -> 0.77 / 0.64 at 6400 (profiles/r04p_pace_sweep3.txt).
+                const bool reads = ABYTES >= 8;
+                const double dflt = h->nout <= 8 ? (reads ? (few ? 7000.0 : 6400.0) : (some ? 7000.0 : 6600.0))
+                                    : reads      ? (few ? 6400.0 : (some ? 6000.0 : 5800.0))
+                                                 : (few ? 6800.0 : (some ? 6600.0 : 6400.0));
+                const double target = h->pace_gbps < 0.0 ? (GEMX_PACE_DEFAULT_ON ? dflt : 0.0) : h->pace_gbps;
+                const int64_t res = shape == 4 ? 2 * (int64_t)h->n_cu : resident(D, OW);
+                pace_res = res;
+                if (target > 0.0 && (blocks > (int64_t)h->n_cu || h->pace_gbps > 0.0 || long_one) && K >= 64 && shape != 3) {  // (<12, 6> carries no limiter: see the kernel)
+                    const double wg_step_bytes = (double)BLOCK * (ABYTES + h->nout * sizeof(R) + 1 + (h->cur_reward != nullptr ? (h->rw_n_ref + 1) * sizeof(R) : 0));
+                    auto ticks_for = [&](double active) {
+                        const double t = wg_step_bytes * active / target * D / 10.0;  // bytes / (GB/s) = ns; 10 ns per tick; D rows per block
+                        return t < 1.0 ? 1u : (t > 4.0e9 ? 0u : (uint32_t)(t + 0.5));
+                    };
+                    const int64_t full = blocks / res, tail = blocks - full * res;
+                    a.pace_block_ticks = ticks_for((double)(blocks < res ? blocks : res));
+                    if (full >= 1 && tail > 0) {  // the last round: `tail` workgroups on the chip
+                        a.pace_tail_from = (uint32_t)(full * res);
+                        a.pace_tail_ticks = ticks_for((double)(tail < (int64_t)h->n_cu ? (int64_t)h->n_cu : tail));
+                    }
+                }
+            }
             const size_t psmem = smem_of(D);
             auto pkern = shape == 0   ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES>
                          : shape == 1 ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2>
@@ -3760,7 +3870,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             const int threads = (1 + OW + pipe_loader_waves(D)) * BLOCK;
             hipLaunchKernelGGL(pkern, dim3((unsigned)blocks), dim3(threads), psmem, st, a);
             GEMX_HIP_TRY(hipGetLastError());
-            h->ll = {1, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), D, threads, K, D, (long long)blocks, psmem};
+            h->ll = {1, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), D, threads, K, D, (long long)blocks, psmem, a.pace_block_ticks, a.pace_tail_ticks, (long long)pace_res};
             return GEMX_OK;
         }
     }

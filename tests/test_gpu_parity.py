@@ -2168,6 +2168,46 @@ def test_last_launch_names_every_active_override(monkeypatch):
     assert forced.endswith("overrides[GEMX_PIPE_SHAPE=1 GEMX_LINMAP=0]") and "D=4" in forced
 
 
+@pytest.mark.parametrize("env_id,n_envs,K", [("Finite-CC-PMSM-v0", 51968, 96), ("Cont-CC-PMSM-v0", 32768, 96), ("Finite-CC-ShuntDc-v0", 33216, 96),
+                                             ("Cont-SC-SCIM-v0", 65536, 96), ("Finite-CC-PMSM-v0", 16384, 1600), ("Cont-CC-PMSM-v0", 8192, 1536)])
+def test_rate_limiter_changes_launch_time_only(monkeypatch, env_id, n_envs, K):
+    """The large-batch rate limiter (advance_pipe_kernel: the integrator waits for its block's slot on the 100 MHz clock) holds
+    workgroups back and does nothing else: limiter off (GEMX_PACE_GBPS=0), the built-in default and a target far too low give the same
+    bits -- full rounds and a ragged last round (the pipelined kernel takes whole 64-env workgroups only) -- and gemx_last_launch() names the interval
+    of a launch that was paced.  The last two cases: LONG launches at one workgroup per CU, which the launcher moves from <12, 6> to the paced
+    <12, 3> on its own (`long_one`)."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    for k in [k for k in os.environ if k.startswith("GEMX_")]:
+        monkeypatch.delenv(k)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    outs = {}
+    for tag, val in (("off", "0"), ("default", None), ("slow", "900" if K < 1000 else "5000")):
+        if val is None:
+            monkeypatch.delenv("GEMX_PACE_GBPS", raising=False)
+        else:
+            monkeypatch.setenv("GEMX_PACE_GBPS", val)
+        e = ga.make(env_id, n_envs=n_envs)
+        ps = e.physical_system
+        if tag == "off":
+            acts = (torch.randint(0, int(ps.action_space.n), (K, n_envs), device="cuda", generator=g, dtype=torch.uint8) if ps._discrete
+                    else torch.rand((K, n_envs, ps._n_act), device="cuda", generator=g) * 2 - 1)
+        e.reset()
+        obs, done = ps.rollout(acts)
+        outs[tag] = (obs.clone(), done.clone(), ps.last_launch())
+        e.close()
+    assert "rate limit" not in outs["off"][2] and "GEMX_PACE_GBPS=0" in outs["off"][2]
+    assert "rate limit" in outs["default"][2] and "overrides" not in outs["default"][2], outs["default"][2]
+    if K < 1000:
+        assert "rate limit" in outs["slow"][2]
+    else:  # the long launches: five output waves' worth of threads = <12, 3>, against <12, 6> with the limiter off (finite-set converter)
+        assert "D=12" in outs["default"][2] and "x 320 threads" in outs["default"][2], outs["default"][2]
+    for tag in ("default", "slow"):
+        assert torch.equal(outs[tag][0], outs["off"][0]) and torch.equal(outs[tag][1], outs["off"][1]), (tag, outs[tag][2])
+
+
 def test_bind_step_is_simulate_without_the_argument_handling():
     """PhysicalSystem.bind_step(action_buffer): the closed loop's pre-bound FFI call.  Same launches as simulate() -- bit-identical
     observations and done flags, step counter advanced, the internal observation tensor returned -- and it refuses a buffer the kernel

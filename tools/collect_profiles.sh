@@ -41,6 +41,12 @@ for WL in pmsm scim permexdc; do
 done
 python $R/tools/bench_matrix.py > $OUT/${TAG}_matrix.md 2>/dev/null                          # plain RK4 on every row (rounds 1-3's matrix)
 python $R/tools/bench_matrix.py --solver default > $OUT/${TAG}_matrix_default_solver.md 2>/dev/null  # what make(env_id) hands out (kink correction on the SC rows)
+# round 4: the large batches limiter off -> on (same box, interleaved), and LONG launches at one workgroup per CU (paced <12, 3> from 1500 steps on)
+bash $R/tools/ab_rate_limiter.sh > $OUT/${TAG}_pace_ab.txt 2>&1
+python $R/tools/ab_rate_limiter_table.py $OUT/${TAG}_pace_ab.txt > $OUT/${TAG}_pace_ab.md 2>&1
+for K in 1000 3000 6000; do
+  python $R/tools/bench_matrix.py --envs 16384 --steps $K --only "PMSM finite (headline)" "SynRM" "PMSM cont" 2>/dev/null | grep -v "^| case\|^|---" | sed "s/^| /| $K steps per launch: /" >> $OUT/${TAG}_matrix_long.md
+done
 # the records that go with them: the GPU suite, the parity report, two ranks on this one GPU (gloo control plane) with the chunk gather
 cd $R
 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/${TAG}_gpu_tests.txt
