@@ -45,6 +45,10 @@ launches with those sensors sampled every 20 ms -- a slower line can be told fro
 Multi-process robustness: `init_process_group` gets `--dist-timeout` (a dead rank is an exception, not a hung barrier), a world > 1
 without MASTER_PORT is refused, and the self-spawner picks a free port.
 
+Every fused launch of every leg goes through `PhysicalSystem.bind_rollout()` (round 4): the action / observation / done tensors of a leg
+are fixed, so they are checked and their pointers taken once and a bench step is the `gemx_rollout` FFI call -- `rollout()`'s per-call
+argument handling, 8-12 us of Python, is more than half of what a launch of BASELINE config 2 takes on the device.
+
 Extra objects in the JSON line (rank 0):
   roofline            HBM roofline of the dominant kernel: algorithmic bytes per launch / mean launch duration measured HERE with HIP
                       events on the launch stream around the K timed launches; peak = 8000 GB/s (MI355X spec); traffic = HBM bytes
@@ -252,15 +256,20 @@ def measure(torch, dist, env, n_local, steps, warmup, spl, device, world, seed, 
         wg = dist.get_world_size()
         gbuf = (torch.empty((wg,) + tuple(obs.shape), dtype=obs.dtype, device=device), torch.empty((wg,) + tuple(done.shape), dtype=done.dtype, device=device))
     env.reset()
+    # one pre-bound launcher per action chunk (PhysicalSystem.bind_rollout: the tensors are checked and their pointers taken ONCE; a
+    # call is the gemx_rollout FFI call).  rollout()'s per-call argument handling is 8-12 us of Python -- more than half of what a
+    # 20-us launch of BASELINE config 2 takes on the device, and the host set that leg's pace (round 4: a kernel 1.7 us shorter did not
+    # move it, profiles/r04t_tail_pipe2.txt)
+    bound = [env.bind_rollout(acts[j * spl : (j + 1) * spl], obs, done) for j in range(n_act_bufs)]
 
     def launch(i):
-        a0 = (i % n_act_bufs) * spl
         if gather == "step":  # batched return after EVERY control step: one launch + one all-gather per step
+            a0 = (i % n_act_bufs) * spl
             for k in range(spl):
                 o = ps.simulate(acts[a0 + k])
                 gd.gather_observations(o, ps.done, force=True)
         else:
-            env.rollout(acts[a0 : a0 + spl], obs_out=obs, done_out=done)
+            bound[i % n_act_bufs]()
             if gather == "chunk":
                 gd.gather_rollout(obs, done, force=True, out=gbuf)
 
@@ -268,8 +277,7 @@ def measure(torch, dist, env, n_local, steps, warmup, spl, device, world, seed, 
         t_end, i = time.perf_counter() + settle_ms * 1e-3, 0
         while time.perf_counter() < t_end:
             for _ in range(4):  # (plain launches: a wall-clock-bounded loop must not contain collectives)
-                a0 = (i % n_act_bufs) * spl
-                env.rollout(acts[a0 : a0 + spl], obs_out=obs, done_out=done)
+                bound[i % n_act_bufs]()
                 i += 1
             torch.cuda.synchronize()
     for i in range(warmup):
@@ -314,15 +322,16 @@ def measure_sustained(torch, env, n_local, spl, device, seed, seconds, tele, lau
     done = torch.empty((spl, n_local), dtype=torch.uint8, device=device)
     env.reset()
     n = max(8, int(math.ceil(seconds / (launch_ms_hint * 1e-3))))
+    bound = [env.bind_rollout(acts[j * spl : (j + 1) * spl], obs, done) for j in range(2)]  # (see measure())
     for i in range(8):
-        env.rollout(acts[(i % 2) * spl : (i % 2 + 1) * spl], obs_out=obs, done_out=done)
+        bound[i % 2]()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with Sampler(tele) as smp:
         t0 = time.perf_counter()
         e0.record()
         for i in range(n):
-            env.rollout(acts[(i % 2) * spl : (i % 2 + 1) * spl], obs_out=obs, done_out=done)
+            bound[i % 2]()
         e1.record()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -750,9 +759,12 @@ def leg(torch, dist, ga, args, key, device, dev_index, spl, tele, envs=None, spl
     env = make_env(ga, wc, n, dev_index, split_kinks=split_kinks, error_controlled=error_controlled)
     try:
         # the timed region is priced by the wall clock (barrier / synchronise tail included): make it >= 3 ms of launches, as the headline's
-        # 20 x 0.15 ms is -- ten 20-us launches of BASELINE config 2 would be a 0.2-ms region, a tenth of it host synchronisation
+        # 20 x 0.15 ms is -- ten 20-us launches of BASELINE config 2 would be a 0.2-ms region, a tenth of it host synchronisation.  Launches
+        # shorter than 50 us: >= 10 ms.  With the pre-bound launcher the host queues such launches five times faster than the device runs
+        # them, and the region's start and end (first submission, the wake-up of the final synchronise with ~150 launches queued) came
+        # to 185 us of a 2.9-ms region of config 2: 19.6 us per launch on the wall clock, 18.3 between the HIP events (r04t_bench2.txt)
         probe = measure(torch, dist, env, n, 10, 3, spl, device, 1, seed=seed, settle_ms=args.settle_ms, repeats=1)
-        steps = max(steps, int(math.ceil(3.0 / max(probe.launch_ms, 1e-3))))
+        steps = max(steps, int(math.ceil((10.0 if probe.launch_ms < 0.05 else 3.0) / max(probe.launch_ms, 1e-3))))
         before = tele.sample()
         reps = measure(torch, dist, env, n, steps, 3, spl, device, 1, seed=seed, settle_ms=args.settle_ms, repeats=repeats)
         reps = reps if isinstance(reps, list) else [reps]

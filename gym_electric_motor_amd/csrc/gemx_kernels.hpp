@@ -2549,8 +2549,12 @@ void advance_pipe_kernel(const KArgs<R> a) {
             };
             // full block, unrolled into branch-free basic blocks of FOUR steps (unrolling all twelve makes basic blocks of up to ~8000
             // instructions for the heavier systems, on which the instruction scheduler's compile time explodes; the run time is the same)
-            auto run_block = [&](auto delayed_tag) {
+            // (`ns_tag`: the steps of the block -- D, or, deep shape, a tail block of 4 or 8 steps: 1000 steps = 83 blocks of 12 + 4, and through the
+            // rolled run-time-checked step below those four cost 2.9 us of the headline's 143.6 where four steps of a whole block cost 0.56:
+            // profiles/r04t_tail_pipe.txt)
+            auto run_block = [&](auto delayed_tag, auto ns_tag) {
                 constexpr bool DEL = decltype(delayed_tag)::value;
+                constexpr int NS = decltype(ns_tag)::value;
                 using Mode = std::integral_constant<int, DEL ? 2 : 0>;
                 auto rd = [&](int s, R (&dst)[NACT], uint32_t &ddst) {
                     if constexpr (DEL) read_delayed(s, dst, ddst);
@@ -2566,13 +2570,13 @@ void advance_pipe_kernel(const KArgs<R> a) {
                     fetch_entry(dn, en);
                     rd(1, an, dnn);
 #pragma unroll 4
-                    for (int s = 0; s < D; ++s) {
+                    for (int s = 0; s < NS; ++s) {
                         dc = dn;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) ec[j] = en[j];
                         dn = dnn;
                         fetch_entry(dn, en);
-                        rd(s + 2 < D ? s + 2 : D - 1, an, dnn);
+                        rd(s + 2 < NS ? s + 2 : NS - 1, an, dnn);
                         if constexpr (DEL) {
                             const bool queued = since >= delay_u;  // else: the refilled reset action
 #pragma unroll
@@ -2583,11 +2587,11 @@ void advance_pipe_kernel(const KArgs<R> a) {
                     }
                 } else {
 #pragma unroll 4
-                    for (int s = 0; s < D; ++s) {
+                    for (int s = 0; s < NS; ++s) {
                         dc = dn;
 #pragma unroll
                         for (int i = 0; i < NACT; ++i) ac[i] = an[i];
-                        rd(s + 1 < D ? s + 1 : s, an, dn);  // one step ahead: its LDS latency hides behind this step
+                        rd(s + 1 < NS ? s + 1 : s, an, dn);  // one step ahead: its LDS latency hides behind this step
                         if constexpr (DEL) {
                             const bool queued = since >= delay_u;
                             dc = queued ? dc : P.dreset_d;
@@ -2599,14 +2603,20 @@ void advance_pipe_kernel(const KArgs<R> a) {
                 }
             };
             bool compact_blk = false;  // this block's rows are COMPACT (see COMPACT_K)
-            if (sb == D && P.delay == 0 && (!LINABLE || lin_ok)) {
-                run_block(std::false_type{});
+            using WholeBlock = std::integral_constant<int, D>;
+            constexpr bool TAIL48 = D == PIPE_D && PIPE_D == 12;  // tail blocks of 4 / 8 steps through the unrolled code (deep shape)
+            if ((sb == D || (TAIL48 && (sb == 4 || sb == 8))) && P.delay == 0 && (!LINABLE || lin_ok)) {
+                if (sb == D) run_block(std::false_type{}, WholeBlock{});
+                else if constexpr (TAIL48) {
+                    if (sb == 8) run_block(std::false_type{}, std::integral_constant<int, 8>{});
+                    else run_block(std::false_type{}, std::integral_constant<int, 4>{});
+                }
                 compact_blk = COMPACT_K;
             } else if (CAN_DELAY && delayed) {
                 compact_blk = COMPACT_K;
                 if constexpr (CAN_DELAY) {
                     if (sb == D) {
-                        run_block(std::true_type{});
+                        run_block(std::true_type{}, WholeBlock{});
                     } else {  // tail block: the same steps, rolled
                         R ect[8] = {};
 #pragma nounroll
@@ -3054,6 +3064,9 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
     static_assert(sizeof(R) == 4 && !SysTraits<SYS>::HAS_ANGLE && D % 4 == 0 && NM <= 2, "fp32 DC machines");
 
     const DevParams<R> &P = a.P;
+#ifdef GEMX_TIMING
+    const unsigned long long WE = wall_clock64();  // kernel entry of this wave, 100 MHz ticks: where the launch's FIXED part goes (dbg[70..77])
+#endif
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int tid = threadIdx.x & (BLOCK - 1);
     // (32 envs per workgroup on twice as many CUs was tried for the output waves' sake: their time per row does not go down with the
@@ -3137,30 +3150,47 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
             const R *gb = gin + ((size_t)(b & 1) * NG2 * BLOCK + le) * 4 * NM;
             R *hb = hand + ((size_t)(b & 1) * NG2 * BLOCK + le) * 4 * NM;
             auto goff = [](int g) __attribute__((always_inline)) { return ((size_t)(g / HALVES) * BLOCK + (size_t)(g % HALVES) * EPW) * 4 * NM; };
-            if (sb == D) {  // whole block: a group's input terms are read two groups ahead (a step is far shorter than an LDS round trip)
+            // groups of four steps: a group's input terms are read two groups ahead (a step is far shorter than an LDS round trip).
+            // run_groups<NG>(g0): NG consecutive groups from group g0 (even, so that with 32 envs per workgroup g0 is a whole number of
+            // double groups and the offsets inside stay compile-time constants), unrolled, no branch.
+            auto run_groups = [&](auto ng_tag, int g0) __attribute__((always_inline)) {
+                constexpr int NG = decltype(ng_tag)::value;
+                const size_t base = goff(g0);
                 R in4[3][4 * NM], out4[4 * NM];
-                auto fetch = [&](int g, R (&dst)[4 * NM]) {
+                auto fetch = [&](int g, R (&dst)[4 * NM]) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int i = 0; i < 4 * NM; ++i) dst[i] = gb[goff(g) + i];
+                    for (int i = 0; i < 4 * NM; ++i) dst[i] = gb[base + goff(g) + i];
                 };
                 fetch(0, in4[0]);
-                fetch(1, in4[1]);
+                if (NG > 1) fetch(1, in4[1]);
 #pragma unroll
-                for (int g = 0; g < NGR; ++g) {
+                for (int g = 0; g < NG; ++g) {
                     // LDS operations retire IN ORDER, so the wait for a group's input terms also waits for every LDS operation issued
                     // before that read: read two groups ahead, then the four steps, then this group's write -- and keep the compiler from
                     // clustering several groups' writes and reads in front of one wait (r03d: 37 cycles per step for 3 VALU instructions)
-                    if (g + 2 < NGR) fetch(g + 2, in4[(g + 2) % 3]);
+                    if (g + 2 < NG) fetch(g + 2, in4[(g + 2) % 3]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) one_step(lin_tag, zero_tag, &in4[g % 3][j * NM], &out4[j * NM]);
 #pragma unroll
-                    for (int i = 0; i < 4 * NM; ++i) hb[goff(g) + i] = out4[i];
+                    for (int i = 0; i < 4 * NM; ++i) hb[base + goff(g) + i] = out4[i];
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            };
+            if (sb == D) {  // whole block
+                run_groups(std::integral_constant<int, NGR>{}, 0);
             } else {
+                // The LAST block of a launch whose length is not a multiple of D: chunks of four groups (16 steps) through the same unrolled
+                // code, then pairs of groups, then single steps.  It used to take the per-step loop alone, one LDS round trip per step:
+                // 150 cycles a step against 27 -- the 40-step tail of BASELINE config 2's 1000-step launch (15 blocks of 64 + 40) was 6100
+                // cycles, 2.6 us of 19.8 (profiles/r04t_dcs_fixed.txt: K = 250, tail of 58 steps: 8916 cycles against 1750 for a whole block).
+                const int ng = sb >> 2;  // whole groups
+                int g0 = 0;
 #pragma nounroll
-                for (int s = 0; s < sb; ++s) {
+                for (; g0 + 4 <= ng; g0 += 4) run_groups(std::integral_constant<int, 4>{}, g0);
+                if (g0 + 2 <= ng) { run_groups(std::integral_constant<int, 2>{}, g0); g0 += 2; }
+#pragma nounroll
+                for (int s = 4 * g0; s < sb; ++s) {
                     const size_t o = goff(s >> 2) + (size_t)(s & 3) * NM;
                     R in[NM], out[NM];
 #pragma unroll
@@ -3192,6 +3222,10 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
             __syncthreads();  // publishes the states of block b; the pre waves have block b + 1 ready
 #ifdef GEMX_TIMING
             tc += t1 - t0; tw += clock64() - t1;
+            if (tid == 0 && blockIdx.x == 0 && b < 8) {  // the first blocks: [80 + b] = barrier b released (ticks since entry), [88 + b] = this wave's cycles in block b
+                unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64);
+                dbg[80 + b] = wall_clock64() - WE; dbg[88 + b] = t1 - t0;
+            }
 #endif
         }
 #ifdef GEMX_TIMING
@@ -3199,6 +3233,8 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
             unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64);
             dbg[0] = 0; dbg[1] = tc; dbg[2] = tw; dbg[3] = clock64() - T0; dbg[4] = wall_clock64() - W0; dbg[5] = nb;
             dbg[32] = tc; dbg[33] = tw;  // every wave of workgroup 0: [32 + 2 wave] = cycles at work, [33 + 2 wave] = cycles at the barriers
+            dbg[70] = W0 - WE;                // entry -> the integrator is at its first barrier (state loaded)
+            dbg[71] = wall_clock64() - WE;    // entry -> the integrator's last barrier passed
         }
 #endif
 #pragma unroll
@@ -3297,7 +3333,13 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
         Rows S_[NPF];
 #pragma unroll
         for (int q = 0; q < NPF; ++q) load(q, S_[q]);
+#ifdef GEMX_TIMING
+        const unsigned long long WP0 = wall_clock64();
+#endif
         convert(0, S_[0]);
+#ifdef GEMX_TIMING
+        const unsigned long long WP1 = wall_clock64();
+#endif
         __syncthreads();
         auto iteration = [&](int b, Rows &free_set, const Rows &next_set, bool fetch) __attribute__((always_inline)) {
 #ifdef GEMX_TIMING
@@ -3324,7 +3366,7 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
 #ifdef GEMX_TIMING
         if (tid == 0 && blockIdx.x == 0) {
             unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64);
-            if (pw == 0) { dbg[12] = ptl; dbg[13] = ptb; }
+            if (pw == 0) { dbg[12] = ptl; dbg[13] = ptb; dbg[75] = WP0 - WE; dbg[76] = WP1 - WE; dbg[77] = wall_clock64() - WE; }  // loads issued | block 0 converted | done
             dbg[32 + 2 * wave] = ptl; dbg[33 + 2 * wave] = ptb;
         }
 #endif
@@ -3507,6 +3549,7 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
         __syncthreads();
 #ifdef GEMX_TIMING
         unsigned long long tp = 0, tq = 0;
+        const unsigned long long WO1 = wall_clock64();  // the first barrier released: block 0's input terms are in LDS
 #endif
         for (int b = 0; b <= nb; ++b) {  // (ONE call site of process(): a second one doubles the kernel's code and tempts the inliner to refuse)
 #ifdef GEMX_TIMING
@@ -3526,7 +3569,7 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
             unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64);
             if (ow < 3) { dbg[6 + 2 * ow] = tp; dbg[7 + 2 * ow] = tq; }
             dbg[32 + 2 * wave] = tp; dbg[33 + 2 * wave] = tq;
-            if (ow == 0) { dbg[64] = to_w; dbg[65] = to_r; dbg[66] = to_s; }
+            if (ow == 0) { dbg[64] = to_w; dbg[65] = to_r; dbg[66] = to_s; dbg[73] = WO1 - WE; dbg[74] = wall_clock64() - WE; }
         }
 #endif
     }

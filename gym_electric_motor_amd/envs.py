@@ -165,6 +165,10 @@ class BatchedElectricMotorEnv:
     def rollout(self, actions, **kw):
         return self.physical_system.rollout(actions, **kw)
 
+    def bind_rollout(self, actions, obs_out, done_out, stream=None):
+        """-> zero-argument launch(): the pre-bound `gemx_rollout` call for fixed tensors (PhysicalSystem.bind_rollout)."""
+        return self.physical_system.bind_rollout(actions, obs_out, done_out, stream=stream)
+
     def close(self):
         self.physical_system.close()
 

@@ -655,6 +655,40 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
 
         return step, obs, self._done
 
+    def bind_rollout(self, actions, obs_out, done_out, stream=None):
+        """A zero-argument `launch()` for a loop that reuses its tensors (a fixed action chunk -- or one the policy overwrites -- and fixed
+        output buffers): what `rollout(actions, obs_out=..., done_out=...)` checks and converts on every call -- dtype, device, shape,
+        contiguity, pointers, the stream -- is resolved here, once, and a call is the FFI call `gemx_rollout` and nothing else.  Python's
+        share of a `rollout()` call is 8-12 us, which is what a short launch costs on the device as well (BASELINE config 2: 4096 envs x
+        1000 steps = 18.5 us of kernel): without this the host sets the pace there.  Returns `launch`; `launch()` returns
+        `(obs_out, done_out)`.  `stream`: a torch.cuda.Stream to launch on (default: the stream current NOW)."""
+        torch = _torch()
+        if not torch.is_tensor(actions) or actions.dim() < 1:
+            raise ValueError("bind_rollout needs a device tensor of actions [K, N, A] / [K, N]")
+        K = int(actions.shape[0])
+        a = actions
+        if not (a.device == self._tdev and a.is_contiguous() and a.dtype is self._want_dtype and a.numel() == K * self._act_numel):
+            raise ValueError(f"bind_rollout needs a contiguous {self._want_dtype} tensor of {K} x {self._act_numel} elements on {self._tdev}")
+        oshape, dshape = (K,) + tuple(self._obs.shape), (K, self._n_envs)
+        if not (torch.is_tensor(obs_out) and tuple(obs_out.shape) == oshape and obs_out.is_contiguous() and obs_out.dtype == self._tdtype and obs_out.device == self._tdev):
+            raise ValueError(f"bind_rollout: obs_out must be a contiguous {self._tdtype} tensor of shape {oshape} on {self._tdev}")
+        if not (torch.is_tensor(done_out) and tuple(done_out.shape) == dshape and done_out.is_contiguous() and done_out.dtype == torch.uint8 and done_out.device == self._tdev):
+            raise ValueError(f"bind_rollout: done_out must be a contiguous uint8 tensor of shape {dshape} on {self._tdev}")
+        st = (stream if stream is not None else torch.cuda.current_stream(self._tdev)).cuda_stream
+        call, check = self._L.gemx_rollout, _lib.check
+        args = (C.c_void_p(a.data_ptr()), K, C.c_void_p(obs_out.data_ptr()), C.c_void_p(done_out.data_ptr()), 1, C.c_void_p(st))
+        keep = (a, obs_out, done_out, stream)  # the buffers behind the raw pointers stay alive as long as the launcher does
+        out = (obs_out, done_out)
+
+        def launch(_args=args, _call=call, _keep=keep):
+            rc = _call(self._handle, *_args)  # (the handle is read per call: None after close() -> the C ABI's "null handle" error)
+            if rc:
+                check(rc)
+            self._k += K
+            return out
+
+        return launch
+
     def rollout(self, actions, obs_out=None, done_out=None, last_only=False, references=None, reward_out=None):
         """K fused control steps in one launch.  actions: [K, N, A] / [K, N]; returns (obs [K, N, S_out], done [K, N])
         device tensors (or the last step's [N, S_out], [N] with last_only=True).

@@ -2242,6 +2242,47 @@ def test_bind_step_is_simulate_without_the_argument_handling():
         step()
 
 
+@pytest.mark.parametrize("env_id", ["Finite-CC-PMSM-v0", "Cont-CC-PermExDc-v0"])
+def test_bind_rollout_is_rollout_without_the_argument_handling(env_id):
+    """PhysicalSystem.bind_rollout(actions, obs_out, done_out): the pre-bound fused launch (what bench.py's loops call).  Same launches as
+    rollout() -- bit-identical observations and done flags over consecutive chunks, the step counter advanced, the caller's buffers
+    returned -- it follows what the caller writes into the bound action tensor, and it refuses tensors the kernel could not use as they are."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    n, K = 4096, 200
+    e1, e2 = ga.make(env_id, n_envs=n), ga.make(env_id, n_envs=n)
+    e1.reset()
+    e2.reset()
+    p1, p2 = e1.physical_system, e2.physical_system
+    g = torch.Generator(device="cuda").manual_seed(3)
+    mk = (lambda: torch.randint(0, int(p1.action_space.n), (K, n), device="cuda", generator=g, dtype=torch.uint8)) if p1._discrete else \
+         (lambda: torch.rand((K, n, p1._n_act), device="cuda", generator=g) * 2 - 1)
+    chunks = [mk() for _ in range(3)]
+    buf = torch.empty_like(chunks[0])
+    obs, done = torch.empty((K, n, p2._n_out), device="cuda"), torch.empty((K, n), dtype=torch.uint8, device="cuda")
+    launch = e2.bind_rollout(buf, obs, done)
+    for c in chunks:
+        o1, d1 = p1.rollout(c)
+        buf.copy_(c)
+        o2, d2 = launch()
+        assert o2 is obs and d2 is done and torch.equal(o1, o2) and torch.equal(d1, d2)
+    assert p1.k == p2.k == 3 * K and p1.last_launch() == p2.last_launch()
+    with pytest.raises(ValueError):
+        p2.bind_rollout(buf.to(torch.float64) if not p1._discrete else buf.to(torch.float32), obs, done)
+    with pytest.raises(ValueError):
+        p2.bind_rollout(buf, obs[:-1], done)
+    with pytest.raises(ValueError):
+        p2.bind_rollout(buf, obs, done.to(torch.int32))
+    with pytest.raises(ValueError):
+        p2.bind_rollout(buf.cpu(), obs, done)
+    e1.close()
+    e2.close()
+    with pytest.raises(ValueError):  # a launcher outliving its system: the C ABI's "null handle", not a stale pointer
+        launch()
+
+
 _DCS_WATCHDOG = r'''
 import sys
 sys.path.insert(0, %r)
