@@ -521,7 +521,11 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
             const R w1 = y[0];
             const R phi_lim = copysign(lim, wmid);
             const bool needs = (med3_r(w, -lim, lim) != (band ? w : phi_lim)) | (med3_r(w1, -lim, lim) != (band ? w1 : phi_lim));
+#ifdef GEMX_KINK_NO_DEFECT  // timing-only A/B build: what the closed forms behind the ballot cost (results are WRONG in steps that cross a kink)
+            if (false) {
+#else
             if (__any(needs)) {  // wave-uniform
+#endif
                 const R V0 = hs * k1[0], V1 = hs * dw_end, dl = w1 - w;
                 const R c2 = R(3) * dl - R(2) * V0 - V1, c3 = V0 + V1 - R(2) * dl;
                 const KinkPath<R> kp{w, w1, V0, V0 * V0, R(4) * (dl - V0), c2 * R(1.0 / 3.0), c3 * R(0.25), R(0.5) * V0,

@@ -13,8 +13,11 @@ sys.path.insert(0, %r)
 import torch
 import gym_electric_motor_amd as ga
 env_id, n, solver, K = sys.argv[1], int(sys.argv[2]), sys.argv[3], 1000
-sol = dict(euler=ga.EulerSolver, rk4=ga.RK4Solver, dp5=ga.DormandPrince5Solver)[solver]()
-env = ga.make(env_id, n_envs=n, device="cuda:0", ode_solver=sol, tau=1e-4)
+if solver == "default":  # what make(env_id) hands out (RK4 + kink correction behind a PolynomialStaticLoad)
+    env = ga.make(env_id, n_envs=n, device="cuda:0")
+else:
+    sol = dict(euler=ga.EulerSolver, rk4=ga.RK4Solver, dp5=ga.DormandPrince5Solver)[solver]()
+    env = ga.make(env_id, n_envs=n, device="cuda:0", ode_solver=sol, tau=1e-4)
 ps = env.physical_system
 env.reset()
 g = torch.Generator(device="cuda").manual_seed(1)

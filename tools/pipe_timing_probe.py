@@ -9,7 +9,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 env_id = sys.argv[3] if len(sys.argv) > 3 else "Finite-CC-PMSM-v0"
 solver = ga.EulerSolver() if os.environ.get("PROBE_SOLVER", "rk4") == "euler" else ga.RK4Solver()
-env = ga.make(env_id, n_envs=n, device="cuda:0", ode_solver=solver, tau=1e-4)
+env = ga.make(env_id, n_envs=n, device="cuda:0") if os.environ.get("PROBE_SOLVER") == "default" else ga.make(env_id, n_envs=n, device="cuda:0", ode_solver=solver, tau=1e-4)
 ps = env.physical_system
 env.reset()
 if "Finite" in env_id:
