@@ -2608,7 +2608,9 @@ void advance_pipe_kernel(const KArgs<R> a) {
             };
             bool compact_blk = false;  // this block's rows are COMPACT (see COMPACT_K)
             using WholeBlock = std::integral_constant<int, D>;
-            constexpr bool TAIL48 = D == PIPE_D && PIPE_D == 12;  // tail blocks of 4 / 8 steps through the unrolled code (deep shape)
+            // tail blocks of 4 / 8 steps through the unrolled code: deep shape, synchronous machines (the headline's family, where the rolled
+            // tail was 1.6 % of a 1000-step launch; every system would gain its 1-1.5 %, at +24 % compile time for the library -- not taken)
+            constexpr bool TAIL48 = D == PIPE_D && PIPE_D == 12 && SYS == GEMX_SYS_SYNC;
             if ((sb == D || (TAIL48 && (sb == 4 || sb == 8))) && P.delay == 0 && (!LINABLE || lin_ok)) {
                 if (sb == D) run_block(std::false_type{}, WholeBlock{});
                 else if constexpr (TAIL48) {
@@ -3579,6 +3581,23 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
     }
 }
 
+// Which shapes of the pipelined kernel exist for a solver: the two DEEP shapes (<12, 3>, <12, 6>) are not built for the Dormand-Prince
+// kernels (fixed-step DP5 and the error-controlled ScipyOdeSolver()).  Those launches are bound by the integrator at 0.1-0.3 of the
+// roofline whatever the hand-off depth, their twelve-step unrolled blocks were the most expensive code of the library to compile (a fifth
+// of its build time for 8 of each unit's 60 pipelined instantiations), and <4, 2> / <2, 2> / the FULL form serve every batch size.
+template <int SOLVER> constexpr bool pipe_deep_built() { return SOLVER != GEMX_SOLVER_DP5; }
+// shape index -> kernel (0: <12, 3>, 1: <4, 2>, 2: <2, 2>, 3: <12, 6>, 4: <4, 2> FULL); nullptr for a shape that is not built
+template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> inline void (*pipe_kernel_of(int shape))(const KArgs<R>) {
+    if constexpr (pipe_deep_built<SOLVER>()) {
+        if (shape == 0) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES>;
+        if (shape == 3) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES_RW>;
+    }
+    if (shape == 1) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2>;
+    if (shape == 2) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D3, PIPE_OUT_WAVES3>;
+    if (shape == 4) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2, true>;
+    return nullptr;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host launcher
 // ------------------------------------------------------------------------------------------------
@@ -3744,10 +3763,8 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         // does not know runs a round plus a tail.  hipFuncGetAttributes once per handle and shape.)
         auto regs_limit = [&](int shape_, int waves_per_wg) -> int64_t {
             if (h->pipe_regs[shape_] == 0) {
-                const void *kp = shape_ == 0   ? (const void *)advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES>
-                                 : shape_ == 1 ? (const void *)advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2>
-                                 : shape_ == 2 ? (const void *)advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D3, PIPE_OUT_WAVES3>
-                                               : (const void *)advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES_RW>;
+                const void *kp = (const void *)pipe_kernel_of<SYS, CONV, LOAD, SOLVER, IL, R>(shape_);
+                if (kp == nullptr) return 0;  // (a shape that is not built holds no workgroup)
                 hipFuncAttributes fa;
                 h->pipe_regs[shape_] = (hipFuncGetAttributes(&fa, kp) == hipSuccess && fa.numRegs > 0) ? fa.numRegs : 128;
             }
@@ -3762,10 +3779,8 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         // 1536 concurrent workgroups with ~1280 resident ran 0.54 of the roofline against 0.90 at 65536)
         auto occ_limit = [&](int shape_, int threads, size_t smem_b) -> int64_t {
             if (h->pipe_occ[shape_] == 0 || h->pipe_occ_smem[shape_] != smem_b) {  // (the LDS bytes move with the fused reward / the queue depth)
-                const void *kp = shape_ == 0   ? (const void *)advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES>
-                                 : shape_ == 1 ? (const void *)advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2>
-                                 : shape_ == 2 ? (const void *)advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D3, PIPE_OUT_WAVES3>
-                                               : (const void *)advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES_RW>;
+                const void *kp = (const void *)pipe_kernel_of<SYS, CONV, LOAD, SOLVER, IL, R>(shape_);
+                if (kp == nullptr) return 0;  // (a shape that is not built holds no workgroup)
                 int nb_ = 0;
                 h->pipe_occ_smem[shape_] = smem_b;
                 if (!(h->pipe_attr_set & (1u << shape_))) {
@@ -3789,6 +3804,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                 const int64_t wocc = occ_limit(shape_, waves_per_wg * BLOCK, smem_of(D));
                 w = w > wocc ? wocc : w;
             }
+            if (wreg == 0) return (int64_t)0;  // not built (pipe_deep_built)
             return (w < 1 ? 1 : w) * (int64_t)h->n_cu;
         };
         // one resident round of the 4-wave shape if N is that small, else the 3-wave shape at ANY N: measured at 131072 and 1048576
@@ -3812,7 +3828,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         // (round 4: only while the rate limiter is OFF.  With it the shallow shapes hold 0.79 at every size from 32768 envs on, the deep shape in
         // rounds 0.64-0.77: profiles/r04m_pace_shapes.txt)
         const bool pacing_on = (h->pace_gbps < 0.0 ? GEMX_PACE_DEFAULT_ON != 0 : h->pace_gbps > 0.0) && K >= 64;
-        if (compact_l && !pacing_on && K >= 400 && delay == 0 && h->cur_reward == nullptr && smem_of(PIPE_D) <= h->lds_max) {
+        if (pipe_deep_built<SOLVER>() && compact_l && !pacing_on && K >= 400 && delay == 0 && h->cur_reward == nullptr && smem_of(PIPE_D) <= h->lds_max) {
             const int64_t res0 = resident(PIPE_D, PIPE_OUT_WAVES_RW), rounds = (blocks + res0 - 1) / res0;
             deep_rounds = blocks > res0 && 100 * blocks >= 85 * rounds * res0;
         }
@@ -3827,7 +3843,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         const bool long_one = pacing_on && h->pace_gbps < 0.0 && K >= 1500 && SYS == GEMX_SYS_SYNC && h->pf.lin_on != 0 && !need_full && h->cur_reward == nullptr &&
                               blocks <= (int64_t)h->n_cu;
         const int64_t deep_max = pacing_on && resident(PIPE_D, PIPE_OUT_WAVES) > 2 * (int64_t)h->n_cu ? 2 * (int64_t)h->n_cu : resident(PIPE_D, PIPE_OUT_WAVES);
-        if (smem_of(PIPE_D) <= h->lds_max && (blocks <= deep_max || deep_rounds)) {
+        if (pipe_deep_built<SOLVER>() && smem_of(PIPE_D) <= h->lds_max && (blocks <= deep_max || deep_rounds)) {
             D = PIPE_D; OW = PIPE_OUT_WAVES; shape = 0;
             // (long launches of the synchronous machines' one-step-map rows: <12, 3>, which carries the rate limiter -- see `long_one` below)
             if (h->cur_reward != nullptr || (compact_l && !long_one)) { OW = PIPE_OUT_WAVES_RW; shape = 3; }
@@ -3849,7 +3865,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         } else if (smem_of(PIPE_D2) <= h->lds_max) { D = PIPE_D2; OW = PIPE_OUT_WAVES2; shape = 1; }
         if (h->pipe_shape >= 0 && h->pipe_shape <= 3) {  // forced shape (tests)
             const int fd[4] = {PIPE_D, PIPE_D2, PIPE_D3, PIPE_D}, fo[4] = {PIPE_OUT_WAVES, PIPE_OUT_WAVES2, PIPE_OUT_WAVES3, PIPE_OUT_WAVES_RW};
-            if (smem_of(fd[h->pipe_shape]) <= h->lds_max) { shape = h->pipe_shape; D = fd[shape]; OW = fo[shape]; }
+            if (smem_of(fd[h->pipe_shape]) <= h->lds_max && (pipe_deep_built<SOLVER>() || fd[h->pipe_shape] != PIPE_D)) { shape = h->pipe_shape; D = fd[shape]; OW = fo[shape]; }
         }
         if (need_full) {  // one instantiation serves these handles
             // ~180 VGPRs = two resident workgroups per CU.  RC supply: ahead of the single-wave kernel at every size (PMSM finite, same box:
@@ -3905,11 +3921,8 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                 }
             }
             const size_t psmem = smem_of(D);
-            auto pkern = shape == 0   ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES>
-                         : shape == 1 ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2>
-                         : shape == 2 ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D3, PIPE_OUT_WAVES3>
-                         : shape == 3 ? advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES_RW>
-                                      : advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2, true>;
+            auto pkern = pipe_kernel_of<SYS, CONV, LOAD, SOLVER, IL, R>(shape);
+            if (pkern == nullptr) return fail(GEMX_ERR_ARG, "internal: pipelined shape %d is not built for this solver", shape);
             if (!(h->pipe_attr_set & (1u << shape))) {
                 GEMX_HIP_TRY(hipFuncSetAttribute((const void *)pkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max));
                 h->pipe_attr_set |= 1u << shape;
