@@ -661,7 +661,8 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         contiguity, pointers, the stream -- is resolved here, once, and a call is the FFI call `gemx_rollout` and nothing else.  Python's
         share of a `rollout()` call is 8-12 us, which is what a short launch costs on the device as well (BASELINE config 2: 4096 envs x
         1000 steps = 18.5 us of kernel): without this the host sets the pace there.  Returns `launch`; `launch()` returns
-        `(obs_out, done_out)`.  `stream`: a torch.cuda.Stream to launch on (default: the stream current NOW)."""
+        `(obs_out, done_out)`.  `stream`: a torch.cuda.Stream to launch on (default: the stream current NOW).  (Observations of every step,
+        no fused reward: those launches take `rollout(..., references=...)`.)"""
         torch = _torch()
         if not torch.is_tensor(actions) or actions.dim() < 1:
             raise ValueError("bind_rollout needs a device tensor of actions [K, N, A] / [K, N]")
