@@ -2618,6 +2618,23 @@ void advance_pipe_kernel(const KArgs<R> a) {
                     else run_block(std::false_type{}, std::integral_constant<int, 4>{});
                 }
                 compact_blk = COMPACT_K;
+            } else if (P.delay == 0 && (!LINABLE || lin_ok)) {
+                // any other tail block without a DeadTimeProcessor: the SAME step as the whole blocks (table entry, one-step map, compact rows),
+                // rolled -- one LDS round trip per step exposed, but not the run-time-checked copy below, which is four times the step
+                // (500 steps = 41 blocks of 12 + 8: that tail was 4.6 us of a 75-us launch for every system but the synchronous machines)
+                using Mode0 = std::integral_constant<int, 0>;
+                read_action(b, 0, an, dn);
+#pragma nounroll
+                for (int s = 0; s < sb; ++s) {
+                    dc = dn;
+#pragma unroll
+                    for (int i = 0; i < NACT; ++i) ac[i] = an[i];
+                    R ect[8] = {};
+                    if constexpr (USE_TAB) fetch_entry(dc, ect);
+                    read_action(b, s + 1 < sb ? s + 1 : s, an, dn);
+                    one_step(Mode0{}, ac, dc, hb + (size_t)s * BLOCK * NHT, USE_TAB ? ect : nullptr);
+                }
+                compact_blk = COMPACT_K;
             } else if (CAN_DELAY && delayed) {
                 compact_blk = COMPACT_K;
                 if constexpr (CAN_DELAY) {
@@ -3839,8 +3856,9 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         // stop landing in the same DRAM rows.  The limiter is also a clock that keeps them together: the same launches through <12, 3> at
         // the 32768-env target run 0.83 / 0.84 at 3000 / 6000 steps (PMSM cont 0.69 / 0.70 -> 0.77 / 0.79; profiles/r04r_probe5.txt).  Only the
         // rows whose integrator is faster than the target gain (the synchronous machines on the one-step map); an integrator-bound
-        // row pays 3-6 % for the clock reads (SCIM finite 0.66 -> 0.62, ShuntDc 0.54 -> 0.52) and keeps its unpaced launch.
-        const bool long_one = pacing_on && h->pace_gbps < 0.0 && K >= 1500 && SYS == GEMX_SYS_SYNC && h->pf.lin_on != 0 && !need_full && h->cur_reward == nullptr &&
+        // row pays 3-6 % for the clock reads (SCIM finite 0.66 -> 0.62, ShuntDc 0.54 -> 0.52) and keeps its unpaced launch.  From 1200 steps on: at
+        // 1000 the unpaced <12, 6> is ahead (0.84 against 0.81), at 1400 behind (0.77 against 0.81-0.83: profiles/r04q_probe3.txt A, r04r_probe5.txt).
+        const bool long_one = pacing_on && h->pace_gbps < 0.0 && K >= 1200 && SYS == GEMX_SYS_SYNC && h->pf.lin_on != 0 && !need_full && h->cur_reward == nullptr &&
                               blocks <= (int64_t)h->n_cu;
         const int64_t deep_max = pacing_on && resident(PIPE_D, PIPE_OUT_WAVES) > 2 * (int64_t)h->n_cu ? 2 * (int64_t)h->n_cu : resident(PIPE_D, PIPE_OUT_WAVES);
         if (pipe_deep_built<SOLVER>() && smem_of(PIPE_D) <= h->lds_max && (blocks <= deep_max || deep_rounds)) {
