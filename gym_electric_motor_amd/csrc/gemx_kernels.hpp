@@ -2618,23 +2618,6 @@ void advance_pipe_kernel(const KArgs<R> a) {
                     else run_block(std::false_type{}, std::integral_constant<int, 4>{});
                 }
                 compact_blk = COMPACT_K;
-            } else if (P.delay == 0 && (!LINABLE || lin_ok)) {
-                // any other tail block without a DeadTimeProcessor: the SAME step as the whole blocks (table entry, one-step map, compact rows),
-                // rolled -- one LDS round trip per step exposed, but not the run-time-checked copy below, which is four times the step
-                // (500 steps = 41 blocks of 12 + 8: that tail was 4.6 us of a 75-us launch for every system but the synchronous machines)
-                using Mode0 = std::integral_constant<int, 0>;
-                read_action(b, 0, an, dn);
-#pragma nounroll
-                for (int s = 0; s < sb; ++s) {
-                    dc = dn;
-#pragma unroll
-                    for (int i = 0; i < NACT; ++i) ac[i] = an[i];
-                    R ect[8] = {};
-                    if constexpr (USE_TAB) fetch_entry(dc, ect);
-                    read_action(b, s + 1 < sb ? s + 1 : s, an, dn);
-                    one_step(Mode0{}, ac, dc, hb + (size_t)s * BLOCK * NHT, USE_TAB ? ect : nullptr);
-                }
-                compact_blk = COMPACT_K;
             } else if (CAN_DELAY && delayed) {
                 compact_blk = COMPACT_K;
                 if constexpr (CAN_DELAY) {
