@@ -1037,7 +1037,10 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
 // ---- SquirrelCageInductionMotorSystem (physical_systems.py:771-814), control_space 'abc' -----------------------
 template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_SCIM, CONV, LOAD, SOLVER, IL, R> {
     using AngT = typename Angle<R>::T;
-    static constexpr int NH = 7;  // ho: sin, cos of the last segment-start field angle, u_a, u_b, u_c, u_alpha, u_beta
+    // ho: sin, cos of the last segment-start field angle, u_a, u_b, u_c.  (u_alpha, u_beta = T23(u_abc) are NOT handed over: observe() computes
+    // them again -- the same function of the same three values -- and the pipelined kernel's hand-off row is 12 values at a 48-byte stride,
+    // 16-byte aligned like the synchronous machines', instead of 14 at 56 bytes that left as eight LDS instructions per step.)
+    static constexpr int NH = 5;
     static __device__ __forceinline__ uint32_t legs_of(uint32_t dact) { return CONV == GEMX_CONV_FINITE_B6 ? b6_subactions(dact) : 0u; }
     // per-action voltage table of the pipelined kernel, as for the synchronous machines (Stepper<GEMX_SYS_SYNC>::action_entry)
     static constexpr int NVT = (CONV == GEMX_CONV_FINITE_B6 && !IL) ? 5 : 0;
@@ -1083,7 +1086,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
         } else {
             segment(P.tau, std::integral_constant<int, 0>{});
         }
-        ho[0] = s; ho[1] = c; ho[2] = ua; ho[3] = ub; ho[4] = uc; ho[5] = u[0]; ho[6] = u[1];
+        ho[0] = s; ho[1] = c; ho[2] = ua; ho[3] = ub; ho[4] = uc;
     }
     static __device__ __forceinline__ void observe(const DevParams<R> &P, const R (&y)[5], AngT ang, const R (&ho)[NH], R (&obs)[14]) {
         // i_dq = Q^-1(i_alphabeta_new, eps_fs of the last segment start) (line 806, reference quirk);
@@ -1102,8 +1105,10 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
         obs[7] = ho[2] * P.inv_lim[7];
         obs[8] = ho[3] * P.inv_lim[8];
         obs[9] = ho[4] * P.inv_lim[9];
-        obs[10] = (c * ho[5] + s * ho[6]) * P.inv_lim[10];
-        obs[11] = (-s * ho[5] + c * ho[6]) * P.inv_lim[11];
+        R ual, ube;
+        t23(ho[2], ho[3], ho[4], ual, ube);  // (what advance() integrated with: T23 of the same u_abc)
+        obs[10] = (c * ual + s * ube) * P.inv_lim[10];
+        obs[11] = (-s * ual + c * ube) * P.inv_lim[11];
         obs[12] = Angle<R>::wrapped(ang) * P.inv_lim[12];
         obs[13] = P.u_sup * P.inv_lim[13];
     }
