@@ -959,7 +959,9 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
 // dead time for this system (the reference's interlocking loop, lines 628-638, cannot execute). -------------------
 template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_SYS_EESM, CONV, LOAD, SOLVER, IL, R> {
     using AngT = typename Angle<R>::T;
-    static constexpr int NH = 8;  // ho: sin, cos of the step-start angle, u_a, u_b, u_c, u_sd, u_sq, u_e
+    // ho: sin, cos of the step-start angle, u_a, u_b, u_c, u_e.  (u_sd, u_sq = Q^-1(T23(u_abc), eps) are NOT handed over: observe() computes them
+    // again from the same values, and the pipelined kernel's hand-off row is 12 values at a 16-byte aligned stride: see Stepper<SCIM>.)
+    static constexpr int NH = 6;
     static __device__ __forceinline__ uint32_t legs_of(uint32_t) { return 0u; }  // (no RC supply behind the finite EESM converter: gemx_create)
     static constexpr int B6 = CONV == GEMX_CONV_CONT_B6_4QC ? GEMX_CONV_CONT_B6 : GEMX_CONV_FINITE_B6;
     // converter output of a flat action index: u_a, u_b, u_c, u_e (the multi-converter has no dead time here)
@@ -999,7 +1001,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
         u[2] = ue;
         const R deps = integrate<GEMX_SYS_EESM, LOAD, SOLVER, R, NS1, LIN, IL ? 1 : 0>(P, y, u, P.tau, linr, false);  // (see DcStepper: one segment, the tau map)
         ang = Angle<R>::advance(ang, deps);
-        ho[0] = s; ho[1] = c; ho[2] = ua; ho[3] = ub; ho[4] = uc; ho[5] = u[0]; ho[6] = u[1]; ho[7] = ue;
+        ho[0] = s; ho[1] = c; ho[2] = ua; ho[3] = ub; ho[4] = uc; ho[5] = ue;
     }
     static __device__ __forceinline__ void observe(const DevParams<R> &P, const R (&y)[4], AngT ang, const R (&ho)[NH], R (&obs)[16]) {
         const R s = ho[0], c = ho[1];  // i_abc from the NEW i_dq with the step-start angle (line 646)
@@ -1018,9 +1020,11 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
         obs[8] = ho[2] * P.inv_lim[8];
         obs[9] = ho[3] * P.inv_lim[9];
         obs[10] = ho[4] * P.inv_lim[10];
-        obs[11] = ho[5] * P.inv_lim[11];
-        obs[12] = ho[6] * P.inv_lim[12];
-        obs[13] = ho[7] * P.inv_lim[13];
+        R ual, ube;
+        t23(ho[2], ho[3], ho[4], ual, ube);  // (what advance() integrated with: the same expressions on the same values)
+        obs[11] = (c * ual + s * ube) * P.inv_lim[11];
+        obs[12] = (-s * ual + c * ube) * P.inv_lim[12];
+        obs[13] = ho[5] * P.inv_lim[13];
         obs[14] = Angle<R>::wrapped(ang) * P.inv_lim[14];
         obs[15] = P.u_sup * P.inv_lim[15];
     }
