@@ -3914,7 +3914,14 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                                     : reads      ? (few ? 6400.0 : (some ? 6000.0 : 5800.0))
                                                  : (few ? 6800.0 : (some ? 6600.0 : 6400.0));
                 const double target = h->pace_gbps < 0.0 ? (GEMX_PACE_DEFAULT_ON ? dflt : 0.0) : h->pace_gbps;
-                const int64_t res = shape == 4 ? 2 * (int64_t)h->n_cu : resident(D, OW);
+                int64_t res = shape == 4 ? 2 * (int64_t)h->n_cu : resident(D, OW);
+                // More than four workgroups per CU (the DC machines' small rows) and a launch that needs the LAST slot of every CU to be one round:
+                // count one slot less.  Registers, LDS, wave slots and the occupancy API said seven of the ShuntDc <4, 2> kernel; 114688 envs = 1792
+                // workgroups were priced as one round of 1792 -- and ran 0.41 of the roofline against 0.63 unpaced: whichever workgroups do not
+                // find their slot at once run alone afterwards at an interval meant for 1792.  Priced for six per CU they are a tail round,
+                // 0.64.  (Only in that band: at 131072 envs, one round of 1792 and a tail of 256, the seven slots price right -- 0.79 against 0.65
+                // with six; profiles/r04final_odd_sizes.txt, r04final_dc_residency.txt.)
+                if (res > 4 * (int64_t)h->n_cu && blocks <= res && blocks > res - (int64_t)h->n_cu) res -= (int64_t)h->n_cu;
                 pace_res = res;
                 if (target > 0.0 && (blocks > (int64_t)h->n_cu || h->pace_gbps > 0.0 || long_one) && K >= 64 && shape != 3) {  // (<12, 6> carries no limiter: see the kernel)
                     const double wg_step_bytes = (double)BLOCK * (ABYTES + h->nout * sizeof(R) + 1 + (h->cur_reward != nullptr ? (h->rw_n_ref + 1) * sizeof(R) : 0));
