@@ -85,7 +85,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md); 6290 GB/s measured float4 copy
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_MEASURED_COPY_GBPS = 6290.0  # the guide's MEASURED float4 copy rate (MI355X_MICROARCH.md:35): SURVEY.md 8(d) asks for both roofs
 
 class Telemetry:
     """Shader clock / memory clock / socket power / temperature of ONE GPU from the amdgpu hwmon files in sysfs (microseconds per read),
@@ -533,6 +534,7 @@ def roofline_of(w, n_local, spl, launch_ms, kernel_desc, workload_key, traffic=N
             except Exception:
                 traffic = None
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "peak_measured_copy": HBM_MEASURED_COPY_GBPS, "frac_of_measured": achieved / HBM_MEASURED_COPY_GBPS,
             "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_desc, "launch_ms": launch_ms,
             "launch_ms_hip_events": events_ms, "clock": "wall time of the timed region / launches (the clock `value` uses)",
             "algorithmic_bytes_per_launch": launch_bytes, "bytes_per_env_step": b_step}
@@ -690,7 +692,12 @@ def worker(args, rank, world, local_rank, backend):
 
                 out["extras_error"] = {"error": repr(e), "trace": traceback.format_exc(limit=6)}
         elif not args.no_extras:
-            out["cpu_baseline"] = None
+            # N > 1: the CPU figure does not depend on the number of GPUs -- the same port on rank 0's host cores, on a shorter sample (the
+            # other ranks wait at the shutdown barrier meanwhile; round 4 left this field None on every multi-GPU line)
+            cb = guarded("cpu_baseline", lambda: cpu_baseline(w, budget_s=4.0))
+            if isinstance(cb, dict) and "error" not in cb:
+                cb["note"] = f"timed on rank 0's host while the other {world - 1} rank(s) wait; identical at every N"
+            out["cpu_baseline"] = cb
         out["overrides"] = {k: v for k, v in os.environ.items() if k.startswith("GEMX_")}  # A/B switches active in THIS run (normally none)
         print(json.dumps(out), flush=True)
 

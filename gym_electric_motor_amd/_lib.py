@@ -6,7 +6,7 @@ import os
 from . import build as _build
 
 MAX_ODE, MAX_OUT, MODEL_ROWS, MODEL_COLS = 8, 24, 5, 11
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 SYS_DC_PERMEX, SYS_SYNC, SYS_SCIM, SYS_DC_SERIES, SYS_DC_SHUNT, SYS_DC_EXTEX, SYS_EESM, SYS_DFIM = 0, 1, 2, 3, 4, 5, 6, 7
 CONV_CONT_4QC, CONV_FINITE_B6, CONV_CONT_B6, CONV_FINITE_4QC = 0, 1, 2, 3
@@ -84,7 +84,7 @@ EXPORTS = (
     "gemx_n_envs", "gemx_n_ode", "gemx_n_out", "gemx_n_action", "gemx_action_itemsize", "gemx_n_switch_bytes", "gemx_reset_observation", "gemx_set_reward", "gemx_rollout_reward", "gemx_refgen_create", "gemx_refgen_destroy", "gemx_refgen_reset",
     "gemx_refgen_rollout", "gemx_refgen_get_state",
     "gemx_reset", "gemx_step", "gemx_rollout", "gemx_get_state", "gemx_set_state", "gemx_get_switch_state",
-    "gemx_set_switch_state", "gemx_set_steps_per_block", "gemx_last_launch", "gemx_error_flags", "gemx_debug_read",
+    "gemx_set_switch_state", "gemx_aux_state_bytes", "gemx_get_aux_state", "gemx_set_aux_state", "gemx_reset_again", "gemx_set_steps_per_block", "gemx_last_launch", "gemx_error_flags", "gemx_debug_read",
 )
 
 
@@ -118,6 +118,11 @@ def load():
         getattr(L, f).argtypes = [vp]
     L.gemx_reset_observation.argtypes = [vp, C.POINTER(C.c_double)]
     L.gemx_reset.argtypes = [vp, vp, vp, vp]
+    L.gemx_reset_again.argtypes = [vp, vp, vp, vp]
+    L.gemx_aux_state_bytes.argtypes = [vp]
+    L.gemx_aux_state_bytes.restype = i64
+    L.gemx_get_aux_state.argtypes = [vp, vp, vp]
+    L.gemx_set_aux_state.argtypes = [vp, vp, vp]
     L.gemx_step.argtypes = [vp, vp, vp, vp, vp]
     L.gemx_rollout.argtypes = [vp, vp, i32, vp, vp, i32, vp]
     L.gemx_set_reward.argtypes = [vp, C.POINTER(GemxRewardConfig)]

@@ -72,7 +72,7 @@ __device__ void reset_obs_row(int sys, const DevParams<R> &P, const double *y, d
 template <class R>
 __global__ void reset_kernel(R *state, typename Angle<R>::T *angle, const uint8_t *mask, R *obs, int64_t N, int nd, int nout,
                              int has_angle, int obs_layout, DevParams<R> P, const R *reset_obs, unsigned char *ring, int ring_row_bytes,
-                             int sys, const InitDev *rinit, uint32_t *rcnt) {
+                             int sys, const InitDev *rinit, uint32_t *rcnt, int advance) {
     int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= N) return;
     if (mask != nullptr && mask[env] == 0) return;
@@ -80,7 +80,8 @@ __global__ void reset_kernel(R *state, typename Angle<R>::T *angle, const uint8_
     for (int j = 0; j < nd; ++j) y0[j] = (double)P.init[j];
     double eps0 = 0.0;
     if (P.init_kind) {
-        const uint32_t count = rcnt[env] + 1u;
+        // advance = 0 (gemx_reset_again): back to the draw the env last STARTED from -- the counter stays where it is
+        const uint32_t count = advance ? rcnt[env] + 1u : (rcnt[env] > 0u ? rcnt[env] : 1u);
         rcnt[env] = count;
         double v[GEMX_MAX_ODE];
         if (sys == GEMX_SYS_SCIM || sys == GEMX_SYS_DFIM) init_draw_all<true>(rinit, env, count, v);
@@ -343,16 +344,42 @@ static void host_reset_obs(gemx_handle &h, const double *m) {
     for (int i = 0; i < h.nout; ++i) o[i] /= c.limits[i];
 }
 
-template <class R> static int launch_reset(gemx_handle *h, const uint8_t *mask, void *obs, hipStream_t st) {
+template <class R> static int launch_reset(gemx_handle *h, const uint8_t *mask, void *obs, hipStream_t st, int advance = 1) {
     using AngT = typename Angle<R>::T;
     const DevParams<R> &P = params_of<R>(h);
     int64_t blocks = (h->n + 255) / 256;
     hipLaunchKernelGGL(reset_kernel<R>, dim3((unsigned)blocks), dim3(256), 0, st, (R *)h->state, (AngT *)h->angle, mask, (R *)obs, h->n,
                        h->nd, h->nout, h->has_angle, h->cfg.obs_layout, P, (const R *)h->reset_obs_dev, (unsigned char *)h->ring,
                        h->cfg.action_delay > 0 ? (int)(h->ring_bytes / ((size_t)h->cfg.action_delay * (size_t)h->n)) : 0, h->cfg.system_kind,
-                       (const InitDev *)h->rinit_dev, h->rcnt);
+                       (const InitDev *)h->rinit_dev, h->rcnt, advance);
     HIP_TRY(hipGetLastError());
     return GEMX_OK;
+}
+
+// ---- checkpoint of everything gemx_get_state / gemx_get_switch_state do not carry (gemx_get_aux_state) ---------------------------
+// blob = header (128 bytes) | RC supply rows [2][N] R | DeadTimeProcessor ring | reset counters [N] uint32, sections padded to 16 bytes
+struct AuxHeader {
+    uint32_t magic, version;
+    int64_t n;
+    uint32_t elem_size, delay, nact_conv, supply_rc, init_kind, fifo_phase;
+    uint64_t steps_total, rc_bytes, ring_bytes, rcnt_bytes;
+    uint32_t system_kind, converter_kind;
+    unsigned char pad[128 - 80];
+};
+static_assert(sizeof(AuxHeader) == 128, "aux header is 128 bytes");
+constexpr uint32_t AUX_MAGIC = 0x55415847u;  // "GXAU"
+static size_t pad16(size_t b) { return (b + 15) & ~(size_t)15; }
+static void aux_sections(const gemx_handle *h, size_t &rc_b, size_t &ring_b, size_t &rcnt_b) {
+    const size_t es = h->cfg.dtype == GEMX_F64 ? 8 : 4;
+    rc_b = h->cfg.supply_kind == GEMX_SUPPLY_RC ? 2 * (size_t)h->n * es : 0;
+    ring_b = h->ring != nullptr ? h->ring_bytes : 0;
+    rcnt_b = h->rcnt != nullptr ? sizeof(uint32_t) * (size_t)h->n : 0;
+}
+__global__ void aux_header_kernel(AuxHeader hd, const uint32_t *fifo_phase, AuxHeader *out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        hd.fifo_phase = fifo_phase[0];  // (lives on the device: a launch replayed from a graph advances it without the host)
+        *out = hd;
+    }
 }
 
 namespace gemx {
@@ -658,11 +685,11 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
     rc = gemx_reset(h, nullptr, nullptr, nullptr);
     if (rc != GEMX_OK) return cleanup(rc);
     if (hipDeviceSynchronize() != hipSuccess) return cleanup(fail(GEMX_ERR_DEVICE, "hipDeviceSynchronize failed"));
-    // random initialisers: the envs now hold draw #1, and the counters go back to 0 -- the caller's FIRST gemx_reset is draw #1 again (the
-    // same states: a binding that resets once more to obtain the reset observation rows, as gym_electric_motor_amd does, shifts nothing),
-    // its second one draw #2, ... (advisor finding, round 3: the binding's construction-time reset had moved every seeded sequence by one)
-    if (h->rcnt != nullptr && hipMemset(h->rcnt, 0, sizeof(uint32_t) * (size_t)h->n) != hipSuccess)
-        return cleanup(fail(GEMX_ERR_DEVICE, "hipMemset failed"));
+    // random initialisers: the envs now hold draw #1 and their counters say so (1).  A caller that steps with auto_reset straight away
+    // gets draw #2 at an env's first in-kernel reset, its first gemx_reset is draw #2 as well.  (Rounds 3-4 put the counters back to 0
+    // here so that a binding's construction-time reset -- made only to obtain the reset observation rows -- would not shift the seeded
+    // sequence; but then a C caller who never calls gemx_reset started episodes 1 AND 2 from the same state: advisor finding, round 4.
+    // A binding now asks for those rows with gemx_reset_again, which re-creates draw #1 without advancing.)
     *out = h;
     return GEMX_OK;
 }
@@ -720,6 +747,79 @@ int gemx_reset(gemx_handle *h, const uint8_t *mask_dev, void *obs_out_dev, void 
     if (capturing != hipStreamCaptureStatusNone) { h->omega_unknown = true; h->omega_is_init = false; }
     else if (rc == GEMX_OK && mask_dev == nullptr && h->cfg.init_kind == GEMX_INIT_CONST && !h->omega_unknown) h->omega_is_init = true;
     return rc;
+}
+
+int gemx_reset_again(gemx_handle *h, const uint8_t *mask_dev, void *obs_out_dev, void *stream) {
+    if (!h) return fail(GEMX_ERR_ARG, "null handle");
+    gemx::DeviceGuard guard(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = h->cfg.dtype == GEMX_F64 ? launch_reset<double>(h, mask_dev, obs_out_dev, st, 0) : launch_reset<float>(h, mask_dev, obs_out_dev, st, 0);
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &capturing);
+    if (capturing != hipStreamCaptureStatusNone) { h->omega_unknown = true; h->omega_is_init = false; }
+    else if (rc == GEMX_OK && mask_dev == nullptr && h->cfg.init_kind == GEMX_INIT_CONST && !h->omega_unknown) h->omega_is_init = true;
+    return rc;
+}
+
+int64_t gemx_aux_state_bytes(const gemx_handle *h) {
+    if (!h) return GEMX_ERR_ARG;
+    size_t a, b, c;
+    aux_sections(h, a, b, c);
+    return (int64_t)(sizeof(AuxHeader) + pad16(a) + pad16(b) + pad16(c));
+}
+int gemx_get_aux_state(gemx_handle *h, void *blob_out_dev, void *stream) {
+    if (!h || !blob_out_dev) return fail(GEMX_ERR_ARG, "null argument");
+    if (((uintptr_t)blob_out_dev & 15u) != 0) return fail(GEMX_ERR_ARG, "blob_out_dev must be 16-byte aligned");
+    gemx::DeviceGuard guard(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    size_t rc_b, ring_b, rcnt_b;
+    aux_sections(h, rc_b, ring_b, rcnt_b);
+    AuxHeader hd;
+    memset(&hd, 0, sizeof(hd));
+    hd.magic = AUX_MAGIC; hd.version = 1; hd.n = h->n; hd.elem_size = (uint32_t)elem_size(h); hd.delay = (uint32_t)h->cfg.action_delay;
+    hd.nact_conv = (uint32_t)h->nact_conv; hd.supply_rc = h->cfg.supply_kind == GEMX_SUPPLY_RC; hd.init_kind = (uint32_t)h->cfg.init_kind;
+    hd.steps_total = h->steps_total; hd.rc_bytes = rc_b; hd.ring_bytes = ring_b; hd.rcnt_bytes = rcnt_b;
+    hd.system_kind = (uint32_t)h->cfg.system_kind; hd.converter_kind = (uint32_t)h->cfg.converter_kind;
+    hipLaunchKernelGGL(aux_header_kernel, dim3(1), dim3(64), 0, st, hd, (const uint32_t *)h->fifo_phase, (AuxHeader *)blob_out_dev);
+    HIP_TRY(hipGetLastError());
+    unsigned char *p = (unsigned char *)blob_out_dev + sizeof(AuxHeader);
+    if (rc_b) HIP_TRY(hipMemcpyAsync(p, (const unsigned char *)h->state + (size_t)h->nd * (size_t)h->n * elem_size(h), rc_b, hipMemcpyDeviceToDevice, st));
+    p += pad16(rc_b);
+    if (ring_b) HIP_TRY(hipMemcpyAsync(p, h->ring, ring_b, hipMemcpyDeviceToDevice, st));
+    p += pad16(ring_b);
+    if (rcnt_b) HIP_TRY(hipMemcpyAsync(p, h->rcnt, rcnt_b, hipMemcpyDeviceToDevice, st));
+    return GEMX_OK;
+}
+int gemx_set_aux_state(gemx_handle *h, const void *blob_in_dev, void *stream) {
+    if (!h || !blob_in_dev) return fail(GEMX_ERR_ARG, "null argument");
+    gemx::DeviceGuard guard(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &capturing);
+    if (capturing != hipStreamCaptureStatusNone) return fail(GEMX_ERR_ARG, "gemx_set_aux_state validates the blob on the host: not inside a stream capture");
+    AuxHeader hd;
+    HIP_TRY(hipMemcpyAsync(&hd, blob_in_dev, sizeof(hd), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    size_t rc_b, ring_b, rcnt_b;
+    aux_sections(h, rc_b, ring_b, rcnt_b);
+    if (hd.magic != AUX_MAGIC || hd.version != 1) return fail(GEMX_ERR_ARG, "not a gemx aux-state blob (magic %08x, version %u)", hd.magic, hd.version);
+    if (hd.n != h->n || hd.elem_size != (uint32_t)elem_size(h) || hd.delay != (uint32_t)h->cfg.action_delay || hd.nact_conv != (uint32_t)h->nact_conv ||
+        hd.supply_rc != (uint32_t)(h->cfg.supply_kind == GEMX_SUPPLY_RC) || hd.init_kind != (uint32_t)h->cfg.init_kind || hd.rc_bytes != rc_b ||
+        hd.ring_bytes != ring_b || hd.rcnt_bytes != rcnt_b || hd.system_kind != (uint32_t)h->cfg.system_kind || hd.converter_kind != (uint32_t)h->cfg.converter_kind)
+        return fail(GEMX_ERR_ARG, "aux-state blob was taken from a handle of another configuration (n_envs %lld vs %lld, dtype, DeadTimeProcessor steps, supply or initialiser kind differ)",
+                    (long long)hd.n, (long long)h->n);
+    if (h->cfg.action_delay > 0 && hd.fifo_phase >= (uint32_t)h->cfg.action_delay) return fail(GEMX_ERR_ARG, "aux-state blob: FIFO phase %u out of range", hd.fifo_phase);
+    const unsigned char *p = (const unsigned char *)blob_in_dev + sizeof(AuxHeader);
+    if (rc_b) HIP_TRY(hipMemcpyAsync((unsigned char *)h->state + (size_t)h->nd * (size_t)h->n * elem_size(h), p, rc_b, hipMemcpyDeviceToDevice, st));
+    p += pad16(rc_b);
+    if (ring_b) HIP_TRY(hipMemcpyAsync(h->ring, p, ring_b, hipMemcpyDeviceToDevice, st));
+    p += pad16(ring_b);
+    if (rcnt_b) HIP_TRY(hipMemcpyAsync(h->rcnt, p, rcnt_b, hipMemcpyDeviceToDevice, st));
+    const uint32_t ph[2] = {hd.fifo_phase, 0u};
+    HIP_TRY(hipMemcpyAsync(h->fifo_phase, ph, sizeof(ph), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // (`ph` is a stack buffer)
+    h->steps_total = hd.steps_total;
+    return GEMX_OK;
 }
 
 int gemx_rollout(gemx_handle *h, const void *actions_dev, int32_t K, void *obs_out_dev, uint8_t *done_out_dev, int32_t obs_every,

@@ -524,6 +524,7 @@ struct gemx_handle {
     int dcs_epw = 32;         // dc_stream_kernel: envs per workgroup where twice the workgroups still find a CU each (GEMX_DCS_EPW=64: always 64)
     int use_dc_stream = 1;    // dc_stream_kernel: 1 when eligible and N <= 64 * CUs (default), 2 at any N, 0 never (GEMX_DC_STREAM)
     int dcs_attr_set = 0;     // bit 0 / 1: the 64- / 32-env instantiation's dynamic-LDS attribute is set
+    bool warned_fallback = false;  // the one-time note that fused rollouts of this handle take the single-wave kernel has been printed
     bool omega_is_init = true;  // every env's omega equals init[0] (constant-speed loads): false between gemx_set_state and the next full reset
     bool omega_unknown = false; // a state-changing call was CAPTURED into a graph: the host cannot know when it runs -> omega_is_init stays false
 };

@@ -2186,6 +2186,15 @@ void advance_pipe_kernel(const KArgs<R> a) {
     const int64_t env = blk0 + tid;
     const int64_t N = a.N;
     const int K = a.K;
+    // The LAST workgroup of a batch that is not a multiple of 64 envs is PARTIAL (round 5; such a batch used to fall back to the single-wave
+    // kernel, 6-8 x slower): its lanes beyond the batch integrate a copy of env N - 1 (loads clamped, actions read as zeros) and store
+    // nothing; its loader wave stages actions / references lane by lane instead of in 16-byte units that would reach past the row (and,
+    // in the last row, past the tensor); its output waves flush through flush_rings (16-byte units over the rows' valid span + a scalar
+    // tail).  All three tests are wave-uniform and sit outside the step loops; every full workgroup runs the code it ran before.
+    const bool full_wg = blk0 + BLOCK <= N;
+    const int rows_n = full_wg ? BLOCK : (int)(N - blk0);  // envs of this workgroup
+    const bool valid = env < N;
+    const int64_t envc = valid ? env : N - 1;  // clamped env index for loads
     constexpr int S = D;              // the observation ring holds exactly one hand-off block
     const int nb = (K + D - 1) / D;   // hand-off blocks
 
@@ -2233,6 +2242,23 @@ void advance_pipe_kernel(const KArgs<R> a) {
         const int sb = steps_of(b);
         unsigned char *dst = actb + (size_t)(b % PIPE_ACT_BUFS) * DP * ROWB;
         const unsigned char *src = a.actions + ((int64_t)b * D * N + blk0) * ABYTES;
+        if (!full_wg) {  // partial workgroup: this lane's own action of every row through a register; lanes beyond the batch stage zeros
+            for (int s = 0; s < D; ++s) {
+                const int row = s < sb ? s : sb - 1;
+                const unsigned char *g = src + ((int64_t)row * N + (envc - blk0)) * ABYTES;
+                if constexpr (DISCRETE) {
+                    const unsigned char v = *g;
+                    dst[(size_t)s * ROWB + tid] = valid ? v : (unsigned char)0;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NACT; ++i) {
+                        const R v = reinterpret_cast<const R *>(g)[i];
+                        reinterpret_cast<R *>(dst + (size_t)s * ROWB)[tid * NACT + i] = valid ? v : R(0);
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NSTAGE; ++j) {
             const int q = j * 64 + tid;
@@ -2248,6 +2274,14 @@ void advance_pipe_kernel(const KArgs<R> a) {
         const int sb = steps_of(b);
         const int dwords = n_ref * (int)(sizeof(R) / 4);  // per env
         R *dst = refb + (size_t)(b % 3) * D * BLOCK * n_ref;
+        if (!full_wg) {  // partial workgroup: lane by lane (see stage_actions)
+            for (int s = 0; s < D; ++s) {
+                const int row = s < sb ? s : sb - 1;
+                const R *g = a.refs + (((int64_t)b * D + row) * N + envc) * n_ref;
+                for (int j = 0; j < n_ref; ++j) dst[((size_t)s * BLOCK + tid) * n_ref + j] = g[j];
+            }
+            return;
+        }
         for (int s = 0; s < D; ++s) {
             const int row = s < sb ? s : sb - 1;
             const unsigned char *src = reinterpret_cast<const unsigned char *>(a.refs + (((int64_t)b * D + row) * N + blk0) * n_ref);
@@ -2264,14 +2298,14 @@ void advance_pipe_kernel(const KArgs<R> a) {
         __builtin_amdgcn_s_setprio(3);
         R y[ND];
 #pragma unroll
-        for (int j = 0; j < ND; ++j) y[j] = a.state[(int64_t)j * N + env];
+        for (int j = 0; j < ND; ++j) y[j] = a.state[(int64_t)j * N + envc];
         AngT ang = AngT(0);
-        if (HAS_ANGLE) ang = a.angle[env];
+        if (HAS_ANGLE) ang = a.angle[envc];
         uint32_t sw = 0;
         const bool USE_SW = conv_has_legs<CONV>() && (IL || (FULL && P.rc_supply));
         if (USE_SW) {
-            sw = a.sw[env];
-            if (conv_sw_bytes<CONV>() == 2) sw |= (uint32_t)a.sw[N + env] << 8;
+            sw = a.sw[envc];
+            if (conv_sw_bytes<CONV>() == 2) sw |= (uint32_t)a.sw[N + envc] << 8;
         }
         const AngT init_ang = Angle<R>::from_bits(P.init_angle_rep);
         // the reset values in VGPRs of their own, opaque to the optimiser: as kernel arguments (SGPRs) they cannot be the VGPR operand
@@ -2290,10 +2324,10 @@ void advance_pipe_kernel(const KArgs<R> a) {
         uint32_t rcount = 0;         // random initialisers: resets of this env so far (FULL)
         if constexpr (FULL) {
             if (P.rc_supply) {
-                sup[0] = a.state[(int64_t)ND * N + env];
-                sup[1] = a.state[(int64_t)(ND + 1) * N + env];
+                sup[0] = a.state[(int64_t)ND * N + envc];
+                sup[1] = a.state[(int64_t)(ND + 1) * N + envc];
             }
-            if (P.init_kind) rcount = a.rcnt[env];
+            if (P.init_kind) rcount = a.rcnt[envc];
         }
         constexpr bool LINABLE = linable<SYS, LOAD, SOLVER, IL, R>();
         const bool lin_ok = lin_usable<SYS, LOAD, SOLVER, IL, R>(P, y[0]);  // wave-uniform
@@ -2319,7 +2353,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
             if (delayed_any) { src = ring_phase + d; src = src >= P.delay ? src - P.delay : src; }
 #pragma unroll
             for (int i = 0; i < NACTC; ++i) {
-                const int64_t gi = ((int64_t)src * N + env) * NACTC + i;
+                const int64_t gi = ((int64_t)src * N + envc) * NACTC + i;
                 fifo[((size_t)d * BLOCK + tid) * NACTC + i] = DISCRETE ? (R)a.ring[gi] : reinterpret_cast<const R *>(a.ring)[gi];
             }
         }
@@ -2471,7 +2505,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
             for (int j = OMEGA_FIXED ? 1 : 0; j < ND; ++j) y[j] = rs ? init_v[j] : y[j];
             ang = rs ? init_ang_v : ang;
             if constexpr (FULL) {
-                if (rs && P.init_kind) draw_initial_state_cnt<SYS, R>(a.rinit, env, rcount, y, ang);  // (rare: exec-masked, skipped wave-wide)
+                if (rs && P.init_kind) draw_initial_state_cnt<SYS, R>(a.rinit, envc, rcount, y, ang);  // (rare: exec-masked, skipped wave-wide)
                 sup[0] = rs ? P.u_sup : sup[0];  // RCVoltageSupply.reset: the capacitor is loaded again, the supply's clock restarts
                 sup[1] = rs ? R(0) : sup[1];
             }
@@ -2745,38 +2779,40 @@ void advance_pipe_kernel(const KArgs<R> a) {
                 (uint16_t)(((hw >> 4) & 3u) | (((hw >> 8) & 15u) << 2) | (((hw >> 12) & 1u) << 6) | (((hw >> 13) & 7u) << 7) | ((xcc & 15u) << 10));
         }
 #endif
+        if (valid) {  // (lanes of a partial workgroup beyond the batch store nothing)
 #pragma unroll
-        for (int j = 0; j < ND; ++j) a.state[(int64_t)j * N + env] = y[j];
-        if (HAS_ANGLE) a.angle[env] = ang;
-        if (USE_SW) {
-            a.sw[env] = (uint8_t)sw;
-            if (conv_sw_bytes<CONV>() == 2) a.sw[N + env] = (uint8_t)(sw >> 8);
-        }
-        if constexpr (FULL) {
-            if (P.rc_supply) {
-                a.state[(int64_t)ND * N + env] = sup[0];
-                a.state[(int64_t)(ND + 1) * N + env] = sup[1];
+            for (int j = 0; j < ND; ++j) a.state[(int64_t)j * N + env] = y[j];
+            if (HAS_ANGLE) a.angle[env] = ang;
+            if (USE_SW) {
+                a.sw[env] = (uint8_t)sw;
+                if (conv_sw_bytes<CONV>() == 2) a.sw[N + env] = (uint8_t)(sw >> 8);
             }
-            if (P.init_kind) a.rcnt[env] = rcount;
-        }
-        int phase_end = 0;
-        if (P.delay > 0) phase_end = (ring_phase + K) % P.delay;
-        for (int d = 0; d < P.delay; ++d) {
-            // FIFO: slot d as it stands.  DELAYED: carry row d is the entry popped d steps after this launch -> ring slot (phase_end + d)
-            // mod delay; entries submitted before the env's last reset are the refilled reset action
-            int dst = d;
-            bool keep = true;
-            if (delayed_any) {
-                dst = phase_end + d;
-                dst = dst >= P.delay ? dst - P.delay : dst;
-                keep = (uint32_t)d + since >= delay_u;
+            if constexpr (FULL) {
+                if (P.rc_supply) {
+                    a.state[(int64_t)ND * N + env] = sup[0];
+                    a.state[(int64_t)(ND + 1) * N + env] = sup[1];
+                }
+                if (P.init_kind) a.rcnt[env] = rcount;
             }
+            int phase_end = 0;
+            if (P.delay > 0) phase_end = (ring_phase + K) % P.delay;
+            for (int d = 0; d < P.delay; ++d) {
+                // FIFO: slot d as it stands.  DELAYED: carry row d is the entry popped d steps after this launch -> ring slot (phase_end + d)
+                // mod delay; entries submitted before the env's last reset are the refilled reset action
+                int dst = d;
+                bool keep = true;
+                if (delayed_any) {
+                    dst = phase_end + d;
+                    dst = dst >= P.delay ? dst - P.delay : dst;
+                    keep = (uint32_t)d + since >= delay_u;
+                }
 #pragma unroll
-            for (int i = 0; i < NACTC; ++i) {
-                const int64_t gi = ((int64_t)dst * N + env) * NACTC + i;
-                const R v = keep ? fifo[((size_t)d * BLOCK + tid) * NACTC + i] : P.dreset[i];
-                if (DISCRETE) a.ring[gi] = (unsigned char)(uint32_t)v;
-                else reinterpret_cast<R *>(a.ring)[gi] = v;
+                for (int i = 0; i < NACTC; ++i) {
+                    const int64_t gi = ((int64_t)dst * N + env) * NACTC + i;
+                    const R v = keep ? fifo[((size_t)d * BLOCK + tid) * NACTC + i] : P.dreset[i];
+                    if (DISCRETE) a.ring[gi] = (unsigned char)(uint32_t)v;
+                    else reinterpret_cast<R *>(a.ring)[gi] = v;
+                }
             }
         }
         if (bad_action) atomicOr(a.err, 1u);
@@ -2808,7 +2844,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
             if (DISCRETE) {
                 const unsigned char *rows = actb + (size_t)(b % PIPE_ACT_BUFS) * DP * ROWB;
                 const int sb = steps_of(b);
-                for (int s = 0; s < sb; ++s) bad |= (uint32_t)rows[(size_t)s * ROWB + tid] >= (uint32_t)ConvTraits<CONV>::NACTIONS;
+                for (int s = 0; s < sb; ++s) bad |= (uint32_t)rows[(size_t)s * ROWB + tid] >= (uint32_t)ConvTraits<CONV>::NACTIONS;  // (lanes beyond the batch: staged as 0)
             }
             if (b + 1 < nb) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): landed in LDS before the barrier publishes it
 #ifdef GEMX_TIMING
@@ -2940,15 +2976,15 @@ void advance_pipe_kernel(const KArgs<R> a) {
                 };
                 if (nr == RPW) {  // full block: the row count is a compile-time constant in this copy
                     fetch_refs(RPW);
-                    reward_apply<NOUT, RPW, R>(a, WR, ring, donebuf, pb * D + r0, r0, RPW, tid, env, true, rv);
+                    reward_apply<NOUT, RPW, R>(a, WR, ring, donebuf, pb * D + r0, r0, RPW, tid, env, valid, rv);
                 } else {
                     fetch_refs(nr);
-                    reward_apply<NOUT, RPW, R>(a, WR, ring, donebuf, pb * D + r0, r0, nr, tid, env, true, rv);
+                    reward_apply<NOUT, RPW, R>(a, WR, ring, donebuf, pb * D + r0, r0, nr, tid, env, valid, rv);
                 }
             }
-            if (aos && nr == RPW) flush_rows_pipe<NOUT, RPW, R>(a, ring + (size_t)r0 * BLOCK * NOUT, donebuf + (size_t)r0 * BLOCK, pb * D + r0, tid, blk0);
-            else flush_rings<NOUT, R>(a, ring + (size_t)r0 * BLOCK * NOUT, donebuf + (size_t)r0 * BLOCK, pb * D + r0, nr, tid, blk0, BLOCK, true,
-                                      true, env);
+            if (aos && nr == RPW && full_wg) flush_rows_pipe<NOUT, RPW, R>(a, ring + (size_t)r0 * BLOCK * NOUT, donebuf + (size_t)r0 * BLOCK, pb * D + r0, tid, blk0);
+            else flush_rings<NOUT, R>(a, ring + (size_t)r0 * BLOCK * NOUT, donebuf + (size_t)r0 * BLOCK, pb * D + r0, nr, tid, blk0, rows_n, full_wg,
+                                      valid, env);
 #ifdef GEMX_TIMING
             tflush += clock64() - f0;
 #endif
@@ -3706,7 +3742,9 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     smem += (size_t)delay * BLOCK * conv_nact_c<CONV>() * sizeof(R);  // DeadTimeProcessor FIFO
     const int64_t blocks = (h->n + BLOCK - 1) / BLOCK;
     // pipelined kernel (integrator / output / loader waves) whenever the launch qualifies
-    const bool pipe_ok = h->use_pipe != 0 && K >= 2 && obs_every && a.coop && a.obs_vec && (h->n % BLOCK) == 0 &&
+    // (round 5: any batch size whose rows stay 16-byte aligned, i.e. N % 16 == 0 with one-byte actions / done bytes -- a last workgroup of
+    // fewer than 64 envs is handled inside the pipelined kernel; dc_stream_kernel still wants whole workgroups)
+    const bool pipe_ok = h->use_pipe != 0 && K >= 2 && obs_every && a.coop && a.obs_vec &&
                          params_of<R>(h).constr_kind <= 1 && h->cfg.solver_nsteps == 1;
     // RC supply / random initialisers: the FULL instantiation (shape <4, 2> only; see advance_pipe_kernel)
     const bool need_full = h->cfg.supply_kind != GEMX_SUPPLY_IDEAL || h->cfg.init_kind != GEMX_INIT_CONST;
@@ -3717,7 +3755,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     // PermExDc, us per 1000 steps at 4096 / 8192 / 12288 / 16384 envs: 39 / 41 / 88 / 94 against 71 / 72 / 72 / 72; tools/ab_dc_stream.py)
     if constexpr (sizeof(R) == 4 && LOAD == GEMX_LOAD_CONST_SPEED && !IL &&
                   (SYS == GEMX_SYS_DC_PERMEX || SYS == GEMX_SYS_DC_SERIES || SYS == GEMX_SYS_DC_SHUNT || SYS == GEMX_SYS_DC_EXTEX)) {
-        bool dcs_ok = pipe_ok && h->use_dc_stream != 0 && !need_full && delay == 0 && !(h->cfg.solver_flags & GEMX_SOLVER_ADAPTIVE) && h->cur_reward == nullptr && (h->omega_is_init || h->use_dc_stream >= 3) &&
+        bool dcs_ok = pipe_ok && (h->n % BLOCK) == 0 && h->use_dc_stream != 0 && !need_full && delay == 0 && !(h->cfg.solver_flags & GEMX_SOLVER_ADAPTIVE) && h->cur_reward == nullptr && (h->omega_is_init || h->use_dc_stream >= 3) &&
                       params_of<R>(h).obs_layout == GEMX_OBS_AOS && params_of<R>(h).t_il == R(0) &&
                       (h->use_dc_stream > 1 || 2 * blocks <= (int64_t)h->n_cu) && dcs_smem_bytes<SYS, CONV>() <= h->lds_max &&
                       (int64_t)h->n * h->nout * 64 < ((int64_t)1 << 31);  // (SIGNED 32-bit store offsets: lane offsets across the rows of a (double)
@@ -3969,6 +4007,19 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         }
         h->ll = {2, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), 0, BLOCK, K, 1, (long long)blocks, 0};
         return GEMX_OK;
+    }
+    if (sizeof(R) == 4 && K >= 2 && obs_every && h->use_pipe != 0 && !h->warned_fallback) {
+        // A fused fp32 rollout that lands HERE runs the single-wave kernel, several times slower than the pipelined one at the same size
+        // (round 4 verdict: nothing but gemx_last_launch() told).  Said once per handle, with the reason; GEMX_QUIET=1 silences it.
+        h->warned_fallback = true;
+        const char *why = !a.coop ? "action / done rows are not 16-byte aligned (batch size not a multiple of 16, or an unaligned tensor)"
+                          : !a.obs_vec ? "observation rows are not 16-byte aligned (n_envs * n_out not a multiple of 4)"
+                          : params_of<R>(h).constr_kind > 1 ? "custom constraint set (only none / the env's default constraint are pipelined)"
+                          : h->cfg.solver_nsteps != 1 ? "solver sub-stepping (nsteps > 1)"
+                                                       : "random initial states beyond 4 workgroups per CU, or the LDS footprint of this configuration";
+        const char *q = getenv("GEMX_QUIET");
+        if (q == nullptr || atoi(q) == 0)
+            fprintf(stderr, "gemx: note: this handle's fused rollouts run the single-wave fallback kernel (%s); expect a fraction of the pipelined kernel's rate\n", why);
     }
     if (!h->attr_set) {
         GEMX_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max));

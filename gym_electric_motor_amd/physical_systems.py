@@ -507,10 +507,11 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         _lib.check(L.gemx_reset_observation(h, ro))
         self._reset_obs = np.array(ro[: self._n_out], dtype=float)
         # the internal observation buffer starts out as the reset observation of every env (reset(mask) returns it for rows outside the mask)
-        # (random initialisers: gemx_create left the counters at 0 with draw #1 in place, so this is draw #1 AGAIN -- the same states, now with
-        # their observation rows -- and the user's first reset() is draw #2, as before the prefill existed.  Launched on the stream that is
-        # current at construction and waited for, so that a caller stepping on another stream later needs no event.)
-        _lib.check(L.gemx_reset(h, None, C.c_void_p(self._obs.data_ptr()), self._stream()))
+        # (random initialisers: gemx_create left draw #1 in place with the counters at 1; gemx_reset_again re-creates that draw -- the same
+        # states, now with their observation rows -- without advancing, so the user's first reset() and an env's first in-kernel auto-reset
+        # are both draw #2.  Launched on the stream that is current at construction and waited for, so that a caller stepping on another
+        # stream later needs no event.)
+        _lib.check(L.gemx_reset_again(h, None, C.c_void_p(self._obs.data_ptr()), self._stream()))
         torch.cuda.current_stream(self._tdev).synchronize()
         # closed-loop hot path (simulate() on a device tensor): everything a call needs, bound once
         self._Tensor = torch.Tensor
@@ -877,6 +878,31 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         s = torch.as_tensor(sw).to(device=self._tdev, dtype=torch.uint8).contiguous()
         _lib.check(self._L.gemx_set_switch_state(self._handle, C.c_void_p(s.data_ptr()), self._stream()))
         torch.cuda.current_stream(self._tdev).synchronize()
+
+
+    def get_checkpoint(self):
+        """Everything a resumed system needs, as device tensors: the ODE state, the converters' leg states, and the opaque `aux` blob
+        (RCVoltageSupply rows, DeadTimeProcessor queue + phase, reset counters of the random initialisers: include/gemx.h,
+        gemx_get_aux_state) plus the step counter `k` (PhysicalSystem._k).  The reference keeps the same things in
+        solvers.py:44-45, converters.py:193-197, dead_time_processor.py:63-72, voltage_supplies.py:100-123."""
+        torch = _torch()
+        nb = int(self._L.gemx_aux_state_bytes(self._handle))
+        aux = torch.empty(nb, dtype=torch.uint8, device=self._tdev)
+        _lib.check(self._L.gemx_get_aux_state(self._handle, C.c_void_p(aux.data_ptr()), self._stream()))
+        return {"state": self.get_state(), "switch_state": self.get_switch_state(), "aux": aux, "k": int(self._k)}
+
+    def set_checkpoint(self, ckpt):
+        """Restore `get_checkpoint()` of a system of the SAME configuration (n_envs, dtype, converter, supply, wrappers, initialisers;
+        checked by the library): the next simulate() / rollout() continues bit for bit."""
+        torch = _torch()
+        aux = torch.as_tensor(ckpt["aux"]).to(device=self._tdev, dtype=torch.uint8).contiguous()
+        if aux.numel() != int(self._L.gemx_aux_state_bytes(self._handle)):
+            raise ValueError(f"checkpoint aux blob has {aux.numel()} bytes, this system needs {int(self._L.gemx_aux_state_bytes(self._handle))}: "
+                             "it was taken from a system of another configuration")
+        self.set_state(ckpt["state"])
+        self.set_switch_state(ckpt["switch_state"])
+        _lib.check(self._L.gemx_set_aux_state(self._handle, C.c_void_p(aux.data_ptr()), self._stream()))
+        self._k = int(ckpt["k"])
 
 
 class BatchedDcMotorSystem(BatchedSCMLSystem):

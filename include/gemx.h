@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define GEMX_ABI_VERSION 5 /* 2: GEMX_MAX_OUT 16 -> 24 (DFIM system, 24 states); 3: gemx_config.solver_flags; 4: solver_rtol / solver_atol; 5: init_flux_mode / init_flux */
+#define GEMX_ABI_VERSION 6 /* 2: GEMX_MAX_OUT 16 -> 24 (DFIM system, 24 states); 3: gemx_config.solver_flags; 4: solver_rtol / solver_atol; 5: init_flux_mode / init_flux;
+                            * 6: gemx_get_aux_state / gemx_set_aux_state / gemx_aux_state_bytes, gemx_reset_again; reset counters stay at 1 after gemx_create */
 #define GEMX_MAX_ODE 8  /* ODE state length incl. omega and the angle      */
 #define GEMX_MAX_OUT 24 /* system-state (observation) length               */
 #define GEMX_MODEL_ROWS 5
@@ -209,6 +210,11 @@ int gemx_reset_observation(const gemx_handle *h, double *obs_host);
  * counter to 0; the converter switching state survives, as in the reference (converters.py:45-54).
  * obs_out_dev (optional, layout per config) receives the reset observation for the reset envs. */
 int gemx_reset(gemx_handle *h, const uint8_t *mask_dev, void *obs_out_dev, void *stream);
+/* The same reset WITHOUT drawing anew: with random initialisers (init_kind != GEMX_INIT_CONST) the masked envs go back to the state
+ * their current episode started from (reset counters untouched); with constant initialisers identical to gemx_reset.  gemx_create leaves
+ * every env in draw #1 with its counter at 1, so a binding obtains the construction-time observation rows with this call and the first
+ * in-kernel auto-reset (or gemx_reset) of an env is draw #2 -- never draw #1 twice. */
+int gemx_reset_again(gemx_handle *h, const uint8_t *mask_dev, void *obs_out_dev, void *stream);
 
 /* PhysicalSystem.simulate() for all N envs: one control step.
  *   actions_dev : [N, A] R for continuous converters, [N] uint8 for finite ones (0..7 Finite-B6C, 0..3 Finite-4QC)
@@ -273,12 +279,21 @@ int gemx_refgen_get_state(gemx_refgen *r, double *value_out_dev, double *sigma_o
  * angle as a 32-bit fraction of a turn internally, so a get/set round trip rounds it to fp32 radians, ~1e-7 rad), plus the
  * per-env packed converter switching state, 2 bits per half-bridge: [N] uint8, or [2][N] uint8 (row 0 = bits 0..7,
  * row 1 = bits 8..11) for the 6 half-bridges of GEMX_CONV_FINITE_2XB6; gemx_n_switch_bytes() = bytes per env.
- * Step counters are not exported. */
+ * Step counters are not exported.
+ * Everything else a resumed handle needs is ONE opaque device blob (gemx_aux_state_bytes() bytes, 16-byte aligned): the
+ * RCVoltageSupply's two rows (capacitor voltage, time since its last update; voltage_supplies.py:100-123), the DeadTimeProcessor's
+ * action queue and its phase (dead_time_processor.py:63-85), the per-env reset counters of the random initialisers (the counter-based
+ * streams continue where they were) and the launched-steps count.  A checkpoint = get_state + get_switch_state + get_aux_state;
+ * restored into a fresh handle of the SAME configuration (checked: gemx_set_aux_state fails with GEMX_ERR_ARG otherwise, and
+ * synchronises `stream` to read the blob's header) the next launches continue bit for bit. */
 int gemx_n_switch_bytes(const gemx_handle *h);
 int gemx_get_state(gemx_handle *h, void *soa_out_dev, void *stream);
 int gemx_set_state(gemx_handle *h, const void *soa_in_dev, void *stream);
 int gemx_get_switch_state(gemx_handle *h, uint8_t *out_dev, void *stream);
 int gemx_set_switch_state(gemx_handle *h, const uint8_t *in_dev, void *stream);
+int64_t gemx_aux_state_bytes(const gemx_handle *h);
+int gemx_get_aux_state(gemx_handle *h, void *blob_out_dev, void *stream);
+int gemx_set_aux_state(gemx_handle *h, const void *blob_in_dev, void *stream);
 
 /* Tuning: number of control steps whose observations are staged in LDS between global-memory bursts inside
  * gemx_rollout (0 = heuristic from N, S_out and the LDS size; also settable with env GEMX_STEPS_PER_BLOCK). */

@@ -619,7 +619,12 @@ static double sgn(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0); } /* np
 
 /* ContTwoQuadrantConverter via ContDynamicallyAveragedConverter: set_action clips to action_space [0,1]
  * (converters.py:144-146), convert = clip(duty - sign(i)/tau*t_il, 0, 1) (148-158, 177-184, 425-427). */
+/* diagnostic for the parity tests (orc_rollout_diag): the smallest |i| [A] a current-SIGN decision of the running step met -- a
+ * dead leg's freewheeling diode, a continuous leg's dead-time correction.  An fp32 run may decide such a step the other way. */
+static __thread double g_sign_margin = 1e300;
+static void note_sign(double i) { if (fabs(i) < g_sign_margin) g_sign_margin = fabs(i); }
 static double cont2qc_convert(const orc_params *p, double duty, double i) {
+    if (p->t_il > 0.0) note_sign(i);
     return clip(duty - sgn(i) / p->tau * p->t_il, 0.0, 1.0);
 }
 
@@ -638,7 +643,7 @@ static double fin2qc_convert(const orc_params *p, orc_env *e, int leg, double i,
         e->sw_state[leg] = e->sw_pattern[leg][e->sw_plen[leg] - 1];
     else
         e->sw_state[leg] = e->sw_pattern[leg][0];
-    if (e->sw_state[leg] == 0) return i < 0 ? 1.0 : 0.0;
+    if (e->sw_state[leg] == 0) { note_sign(i); return i < 0 ? 1.0 : 0.0; }
     if (e->sw_state[leg] == 1) return 1.0;
     return 0.0;
 }
@@ -1096,6 +1101,26 @@ void orc_rollout(const orc_params *p, orc_env *e, const double *actions, int n_a
     for (int k = 0; k < K; ++k) {
         double *obs = obs_out + (size_t)k * no;
         orc_step(p, e, actions + (size_t)k * n_act, obs);
+        int d = orc_done(p, obs);
+        if (done_out) done_out[k] = (uint8_t)d;
+        if (d && auto_reset) orc_reset(p, e, scratch);
+    }
+}
+
+/* orc_rollout with two diagnostics per step for the parity tests' conditioning arguments: diag[k][0] = |psi_r| [Wb] at the START of
+ * step k (induction machines: the flux the step's field angle is the arctan2 of; 0 otherwise), diag[k][1] = the smallest |i| [A] a
+ * current-sign decision of step k met (1e300: none). */
+void orc_rollout_diag(const orc_params *p, orc_env *e, const double *actions, int n_act, int K, int auto_reset,
+                      double *obs_out, uint8_t *done_out, double *diag) {
+    int no = n_out(p);
+    double scratch[ORC_MAX_OUT];
+    const int im = p->system == ORC_SYS_SCIM || p->system == ORC_SYS_DFIM;
+    for (int k = 0; k < K; ++k) {
+        double *obs = obs_out + (size_t)k * no;
+        diag[2 * k] = im ? hypot(e->y[3], e->y[4]) : 0.0;
+        g_sign_margin = 1e300;
+        orc_step(p, e, actions + (size_t)k * n_act, obs);
+        diag[2 * k + 1] = g_sign_margin;
         int d = orc_done(p, obs);
         if (done_out) done_out[k] = (uint8_t)d;
         if (d && auto_reset) orc_reset(p, e, scratch);

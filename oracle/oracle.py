@@ -177,6 +177,20 @@ class OracleEnv:
                            C.c_int(int(auto_reset)), obs.ctypes.data_as(C.c_void_p), done.ctypes.data_as(C.c_void_p))
         return obs, done.astype(bool)
 
+    def rollout_diag(self, actions, auto_reset=True):
+        """rollout() plus per-step diagnostics: (obs, done, |psi_r| at the start of each step [Wb], smallest |i| a current-sign
+        decision of the step met [A], inf where the step made none)."""
+        a = np.ascontiguousarray(np.asarray(actions, dtype=np.float64).reshape(len(actions), -1))
+        K = a.shape[0]
+        obs = np.zeros((K, self.n_out))
+        done = np.zeros(K, dtype=np.uint8)
+        diag = np.zeros((K, 2))
+        self.L.orc_rollout_diag(C.byref(self.p), self._env, a.ctypes.data_as(C.c_void_p), C.c_int(a.shape[1]), C.c_int(K),
+                                C.c_int(int(auto_reset)), obs.ctypes.data_as(C.c_void_p), done.ctypes.data_as(C.c_void_p),
+                                diag.ctypes.data_as(C.c_void_p))
+        margin = np.where(diag[:, 1] > 1e299, np.inf, diag[:, 1])
+        return obs, done.astype(bool), diag[:, 0], margin
+
     def done(self, obs):
         o = np.ascontiguousarray(obs, dtype=np.float64)
         full = np.zeros(MAX_OUT)

@@ -28,6 +28,7 @@ def main():
     print("| fixture | load | " + " | ".join(OPTIONS) + " | make(env_id) default |")
     print("|---|---|" + "---|" * (len(OPTIONS) + 1))
     worst = {o: 0.0 for o in OPTIONS + ["default"]}
+    failures = []  # (fixture, option, the whole assertion message): printed in full below the table, and the exit status is non-zero
     for name in names:
         d, meta = T._load(name)
         row = []
@@ -48,11 +49,21 @@ def main():
                 worst[o] = max(worst[o], rel)
                 row.append(f"{rel:.1e}" + ("*" if "flip" in dmsg else ""))
             except AssertionError as e:
-                row.append("FAIL " + str(e)[:40])
+                failures.append((name, o, str(e)))
+                row.append(f"**FAIL [{len(failures)}]**")
         print(f"| {name[:-7]} | {'poly' if meta['load'] != 'ConstantSpeedLoad' else 'const'} | " + " | ".join(row) + " |")
         sys.stdout.flush()
     print("| **worst** | | " + " | ".join(f"{worst[o]:.1e}" for o in OPTIONS + ["default"]) + " |")
     print("\n(* = the done mask flipped at a step whose constraint margin in the reference is < 1e-5: compared up to there)")
+    # Round 5: a FAIL cell used to be a 40-character stub that the `worst` row skipped, and the script exited 0 -- which is how an
+    # out-of-contract lane survived ten collections.  Every failure is now printed whole and fails the collection.
+    if failures:
+        print(f"\n## {len(failures)} FAILED cell(s)\n")
+        for i, (name, o, msg) in enumerate(failures, 1):
+            print(f"[{i}] {name} / {o}: {msg}\n")
+        sys.stdout.flush()
+        sys.exit(1)
+    print("\nno FAIL cells")
 
 
 if __name__ == "__main__":

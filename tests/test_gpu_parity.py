@@ -160,19 +160,27 @@ def _oracle_solver_for(meta, sol):
 LANE_SAMPLE = (1, 31, 33, 63, 65, 68)  # lanes checked against the oracle: both halves of a wave, the wave boundary, the tail workgroup
 
 
-def _run_golden(name, dtype, solver=None, n_envs=70):
+def _run_golden(name, dtype, solver=None, n_envs=70, plain_make=False):
     """One recorded reference run through the device with n_envs envs.  Lanes 0, 64 and n_envs - 1 carry the RECORDED action sequence
     (compared with the golden by the caller; they must agree bit for bit among themselves); every other lane carries its OWN seeded
     random action stream (round 4: rounds 1-3 fed all lanes the same sequence, so a lane-dependent fault in a feature path -- RC
     supply, DeadTimeProcessor queue, dq action stage -- could not fail), and the lanes of LANE_SAMPLE are compared with the fp64
-    oracle run on exactly their streams (episode by episode, done masks included)."""
+    oracle run on exactly their streams (episode by episode, done masks included).
+    plain_make: the env is `make(env_id, n_envs=N)` and NOTHING else (the `default_*` fixtures: what a user of the 54 ids gets)."""
     import torch
 
-    from oracle import oracle as orc
+    import gym_electric_motor_amd as ga
 
     d, meta = _load(name)
-    env = _make_from_meta(meta, n_envs, solver=solver, dtype=dtype, auto_reset=True)
+    if plain_make:
+        assert solver is None and dtype == "float32"
+        env = ga.make(meta["env_id"], n_envs=n_envs)
+    else:
+        env = _make_from_meta(meta, n_envs, solver=solver, dtype=dtype, auto_reset=True)
     ps = env.physical_system
+    if plain_make:
+        assert ps.tau == meta["tau"] and list(ps.state_names) == meta["state_names"]
+        assert np.allclose(ps.limits, meta["limits"], rtol=1e-13, atol=0)
     assert np.abs(ps.reset_observation - d["reset_state"]).max() < 1e-12
     acts = d["actions"]
     K = acts.shape[0]
@@ -201,29 +209,7 @@ def _run_golden(name, dtype, solver=None, n_envs=70):
     # lockstep determinism: the lanes that saw the same actions
     for j in recorded[1:]:
         assert np.array_equal(obs[:, 0], obs[:, j]) and np.array_equal(done[:, 0], done[:, j]), j
-    osol = _oracle_solver_for(meta, sol_obj)
-    if meta["interlocking_time"] > 0:
-        # converter dead time: a dead leg's voltage follows the SIGN of its phase current (converters.py:277-285, 144-158), so an fp32 run
-        # and the fp64 oracle part ways for good the first time a random stream catches a current within rounding of zero -- the recorded
-        # sequences avoid that by luck, random lanes do not.  Lane dependence of the dead-time code is covered by the bit-identity tests
-        # across kernels (all of them with per-lane distinct actions).
-        osol = None
-    if osol is not None:
-        p = orc.params_from_meta(meta, solver=osol[0])
-        p.nsteps = osol[1]
-        meta1 = dict(meta, every=1)
-        for j in [j for j in LANE_SAMPLE if j < n_envs and j not in recorded]:
-            e = orc.OracleEnv(p)
-            e.reset()
-            aj = a_np[:, j, :] if acts.ndim > 1 else a_np[:, j, 0]
-            ro, rd = e.rollout(aj.astype(np.float64), auto_reset=True)
-            dj = {"states": ro, "terminated": rd, "state_index": np.arange(K)}
-            rel, ab, col, dmsg = compare_trajectory(meta1, dj, obs[:, j], done[:, j], min_fraction=0.3)
-            same = osol[0] != "dopri5"
-            # (error-controlled on both sides: two step sequences at the same tolerance; the DFIM's field-oriented columns amplify their
-            # ~1e-5 difference -- 1.6e-4 observed on u_sd of a random lane against 4e-5 on the recorded sequence)
-            tol = (1e-4 if same else 3e-4) if dtype == "float32" or not same else 1e-7
-            assert rel < tol, (name, "lane", j, rel, col, dmsg)
+    _lanes_against_oracle(name, meta, a_np, obs, done, [j for j in LANE_SAMPLE if j < n_envs and j not in recorded], sol_obj, dtype, acts.ndim)
     obs0 = obs[:, 0].copy()
     if meta["system"] in ("DoublyFedInductionMotorSystem", "SquirrelCageInductionMotorSystem") and (
             meta["system"].startswith("Doubly") or name.startswith("default_")):
@@ -256,12 +242,26 @@ def _check_done(meta, d, got_done, ref_states_full=None):
     assert margin[first] < 1e-5, f"done mask differs at step {first} with margin {margin[first]:.3e}"
 
 
-def compare_trajectory(meta, d, obs, done, min_fraction=0.0):
+FLUX_FLOOR = 0.05  # field-oriented columns: the 1e-4 contract holds as it stands while |psi_r| >= 5 % of its range over the run
+
+
+def compare_trajectory(meta, d, obs, done, min_fraction=0.0, psi=None, stop=None, per_step=False):
     """Whole-trajectory comparison of one env's device rollout with a recorded reference run, EPISODE BY EPISODE: both sides restart
     from the reset state on the step after a termination, so as long as the done masks agree every episode is compared, not just the
     first.  A done flip is accepted only where the reference's constraint margin is < 1e-5 (fp32 vs fp64 at the boundary); from there
     on the two runs are out of phase for good (same action sequence, different episode starts), so the comparison ends at the flip.
-    Returns (worst rel err, max abs err, worst column, description of the done-mask comparison)."""
+    stop: compare steps < stop only (dead-time lanes: up to the first current-sign decision within rounding of zero).
+    psi [K] (induction machines; the oracle's |psi_r| at the START of each step): the CONDITIONING of the field-oriented columns.  Their
+    frame is eps_field = arctan2(psi_rbeta, psi_ralpha) (physical_systems.py:765-769), so a flux error d_psi turns every dq pair by
+    d_psi / |psi_r|: an fp32 flux that is right to 1e-6 of its range -- what this function measures on the flux-driven abc columns --
+    gives 1e-4 on u_sd once |psi_r| falls to 1 % of the range (random switching walks the flux through zero; round 4 recorded 1.6e-4
+    on u_sd of Finite-TC-DFIM at |psi_r| = 1.2e-4 Wb of 0.35).  No arithmetic in the observation can undo that; the contract for those
+    columns is therefore stated on what is well-posed:
+      * the dq columns' error WEIGHTED by min(1, |psi_r| / (FLUX_FLOOR max|psi_r|)) within the tolerance -- i.e. 1e-4 as it stands
+        wherever the flux is above 5 % of its range, and the flux itself within 5e-6 of its range below;
+      * the rotation-invariant content, |i_sdq|, |u_sdq|, |i_rdq|, |u_rdq|, within the tolerance at EVERY step, unweighted.
+    Returns (worst rel err, max abs err, worst column, description of the done-mask comparison); per_step: the worst relative error
+    of every compared step instead (an array)."""
     names = meta["state_names"]
     idx, ref, ref_done = d["state_index"], d["states"], d["terminated"]
     K = len(ref_done)
@@ -271,10 +271,14 @@ def compare_trajectory(meta, d, obs, done, min_fraction=0.0):
             dmsg = f"identical, {int(ref_done.sum())} terminations"
         else:
             first = int(np.argmax(done != ref_done))
-            margin = _constraint_margin(meta, d)[first]
-            assert margin < 1e-5, f"done mask differs at step {first} with margin {margin:.3e}"
-            n_cmp = first + 1  # the state returned by step `first` is still the same episode on both sides
-            dmsg = f"flip at step {first} (reference margin {margin:.1e}): {n_cmp}/{K} steps, {int(ref_done[:first].sum())} terminations compared"
+            if stop is None or first < stop:
+                margin = _constraint_margin(meta, d)[first]
+                assert margin < 1e-5, f"done mask differs at step {first} with margin {margin:.3e}"
+                n_cmp = first + 1  # the state returned by step `first` is still the same episode on both sides
+                dmsg = f"flip at step {first} (reference margin {margin:.1e}): {n_cmp}/{K} steps, {int(ref_done[:first].sum())} terminations compared"
+    if stop is not None and stop < n_cmp:
+        n_cmp = stop
+        dmsg += f"; compared up to step {stop} (first current-sign decision within rounding of zero)"
     assert n_cmp >= min_fraction * K, dmsg
     sel = idx < n_cmp
     diff = np.abs(obs[idx[sel]] - ref[sel])
@@ -282,9 +286,78 @@ def compare_trajectory(meta, d, obs, done, min_fraction=0.0):
         i = names.index("epsilon")
         diff[:, i] = np.minimum(diff[:, i], 2.0 - diff[:, i])
     scale = np.maximum(np.abs(ref).max(axis=0), 1e-3)
+    if psi is not None and "InductionMotorSystem" in meta["system"]:
+        from oracle import oracle as orc
+
+        w = np.minimum(1.0, psi[idx[sel]] / (FLUX_FLOOR * max(float(psi.max()), 1e-30)))
+        lim = np.asarray(meta["limits"], dtype=np.float64)
+        for a, b in (("i_sd", "i_sq"), ("u_sd", "u_sq"), ("i_rd", "i_rq"), ("u_rd", "u_rq")):
+            if a not in names:
+                continue
+            ia, ib = names.index(a), names.index(b)
+            got = np.hypot(obs[idx[sel], ia] * lim[ia], obs[idx[sel], ib] * lim[ib])
+            want = np.hypot(ref[sel, ia] * lim[ia], ref[sel, ib] * lim[ib])
+            mag = np.abs(got - want) / max(lim[ia] * scale[ia], lim[ib] * scale[ib])  # |pair|: rotation invariant, unweighted
+            diff[:, ia] = np.maximum(diff[:, ia] * w, mag * scale[ia])
+            diff[:, ib] = np.maximum(diff[:, ib] * w, mag * scale[ib])
+        assert set(n for n in names if n.endswith(("d", "q")) and n[0] in "iu") <= set(orc.DQ_COLUMNS)
+    if per_step:
+        return (diff / scale).max(axis=1)
     per_col = diff.max(axis=0) / scale
     j = int(np.argmax(per_col))
     return float(per_col[j]), float(diff.max()), names[j], dmsg
+
+
+SIGN_MARGIN = 2e-5  # dead-time lanes: a current-sign decision is "within rounding of zero" below this fraction of the current limit
+
+
+def _lanes_against_oracle(name, meta, a_np, obs, done, lanes, sol_obj, dtype, acts_ndim):
+    """Sampled lanes of a device rollout, each on its OWN action stream, against the fp64 oracle with the same integrator (episode by
+    episode, done masks included).  Induction machines: field-oriented columns by their conditioning (compare_trajectory, psi).
+    Converter dead time: a dead leg's voltage follows the SIGN of its phase current (converters.py:277-285, 144-158), so an fp32 run
+    and the fp64 oracle part ways for good when a stream catches a current within rounding of zero at such a decision and the two
+    decide it differently.  Rounds 1-4 skipped these lanes altogether; now a lane is compared over the whole run, and a divergence
+    is accepted only if it BEGINS at a step where the oracle's decision margin is below SIGN_MARGIN of the current limit (then the
+    lane is compared up to that step) -- a lane that leaves the oracle anywhere else fails."""
+    from oracle import oracle as orc
+
+    osol = _oracle_solver_for(meta, sol_obj)
+    if osol is None:
+        return None
+    p = orc.params_from_meta(meta, solver=osol[0])
+    p.nsteps = osol[1]
+    K = a_np.shape[0]
+    meta1 = dict(meta, every=1)
+    names = meta["state_names"]
+    i_lim = max(meta["limits"][names.index(c)] for c in names if c.startswith("i"))
+    worst, covered = 0.0, []
+    for j in lanes:
+        e = orc.OracleEnv(p)
+        e.reset()
+        aj = a_np[:, j, :] if acts_ndim > 1 else a_np[:, j, 0]
+        ro, rd, psi, margin = e.rollout_diag(aj.astype(np.float64), auto_reset=True)
+        dj = {"states": ro, "terminated": rd, "state_index": np.arange(K)}
+        same = osol[0] != "dopri5"
+        # fp32: the north star's 1e-4, whatever the solver pair (round 4 allowed the error-controlled pair 3e-4 to cover the DFIM's
+        # ill-conditioned steps; those are now weighted by their conditioning instead).  fp64, same integrator: 1e-7.
+        tol = 1e-4 if dtype == "float32" or not same else 1e-7
+        psi_j = psi if "InductionMotorSystem" in meta["system"] else None
+        stop = None
+        if meta["interlocking_time"] > 0:
+            free = dict(meta1, episodic=False)  # (step by step, done masks aside: they are compared below, up to `stop`)
+            over = np.nonzero(compare_trajectory(free, dj, obs[:, j], done[:, j], psi=psi_j, per_step=True) >= tol)[0]
+            flips = np.nonzero(done[:, j] != rd)[0]  # (a done flip at the constraint boundary comes first: compare_trajectory's business)
+            if len(over) and (len(flips) == 0 or over[0] <= flips[0]):
+                stop = int(over[0])
+                assert margin[stop] < SIGN_MARGIN * i_lim, (name, "lane", j, "leaves the oracle at step", stop, "where no current-sign decision is near zero",
+                                                            float(margin[stop]), i_lim)
+        rel, ab, col, dmsg = compare_trajectory(meta1, dj, obs[:, j], done[:, j], min_fraction=0.0 if stop is not None else 0.3, psi=psi_j, stop=stop)
+        covered.append(K if stop is None else stop)
+        assert rel < tol, (name, "lane", j, rel, col, dmsg)
+        worst = max(worst, rel)
+    if meta["interlocking_time"] > 0:  # the dead-time lanes together must still cover a fair share of the run
+        assert sum(covered) >= 0.5 * K * len(lanes), (name, covered)
+    return worst
 
 
 SAME_SOLVER = [c for c in CASES if c.endswith("euler") or c.endswith("euler4")]
@@ -314,33 +387,13 @@ def test_fp64_euler_matches_reference_euler(name):
 def test_make_env_id_as_the_user_gets_it_matches_the_reference_default_solver(name):
     """`gym_electric_motor_amd.make(env_id, n_envs=N)` and NOTHING else -- the env's own supply, converter, motor, load, tau, constraints
     and the solver make() picks (envs.default_ode_solver) -- against `gem.make(env_id)` with the reference's default solver (scipy
-    dopri5), for every one of the reference's 54 env ids: fp32 within 1e-4, episode by episode, done masks exact (margin-guarded)."""
-    import torch
-
-    import gym_electric_motor_amd as ga
-
-    d, meta = _load(name)
-    n_envs = 70
-    env = ga.make(meta["env_id"], n_envs=n_envs)
-    ps = env.physical_system
-    assert ps.tau == meta["tau"] and list(ps.state_names) == meta["state_names"]
-    assert np.allclose(ps.limits, meta["limits"], rtol=1e-13, atol=0)
-    assert np.abs(ps.reset_observation - d["reset_state"]).max() < 1e-12
-    acts = d["actions"]
-    K = acts.shape[0]
-    a = torch.as_tensor(np.repeat(acts.reshape(K, 1, -1), n_envs, axis=1))
-    if ps._discrete and acts.ndim == 1:
-        a = a.reshape(K, n_envs)
-    obs, done = env.rollout(a.cuda())
-    torch.cuda.synchronize()
-    obs = obs.double().cpu().numpy()
-    done = done.cpu().numpy().astype(bool)
-    env.close()
-    assert np.array_equal(obs[:, 0], obs[:, n_envs - 1]) and np.array_equal(done[:, 0], done[:, 64])
-    obs0 = obs[:, 0].copy()
-    if "InductionMotorSystem" in meta["system"]:  # zero-flux steps: the reference's dq frame is arctan2(rounding noise), see _run_golden
-        obs0 = _undefined_dq_steps_checked(meta, d, obs0)
-    rel, _, col, dmsg = compare_trajectory(meta, d, obs0, done[:, 0], min_fraction=0.5)
+    dopri5), for every one of the reference's 54 env ids: fp32 within 1e-4, episode by episode, done masks exact (margin-guarded).
+    Lanes 0 / 64 / 69 replay the recorded sequence (against the recording); the sampled other lanes run their own random streams and
+    are held to the same 1e-4 against the fp64 oracle with the integrator make() picked (round 5: the per-lane check used to leave
+    this test out -- and Finite-TC-DFIM's u_sd on a random lane sat at 1.6e-4 unasserted; see compare_trajectory on the conditioning
+    of the field-oriented columns)."""
+    d, meta, obs0, done0 = _run_golden(name, "float32", plain_make=True)
+    rel, _, col, dmsg = compare_trajectory(meta, d, obs0, done0, min_fraction=0.5)
     assert rel < 1e-4, (rel, col, dmsg)
 
 
@@ -568,7 +621,10 @@ def test_bench_configuration_episodic_rk4_against_reference_default_solver(mode,
     ("Cont-CC-PermExDc-v0", 4096, "euler"),   # BASELINE config 2
     ("Finite-CC-PMSM-v0", 16384, "rk4"),      # BASELINE config 3 (the bench headline: one-step map + voltage table + <12, 3> shape)
     ("Finite-CC-PMSM-v0", 32768, "rk4"),      # BASELINE config 5's per-GPU shard (8 x 32768): the <4, 2> shape
-    ("Cont-SC-SCIM-v0", 65536, "rk4"),        # BASELINE config 4 with the env's own PolynomialStaticLoad
+    ("Finite-CC-PMSM-v0", 32768, "default"),  # ... as bench.py's `configs.pmsm_32768` builds it: make() with no solver named, rate limiter on
+    ("Cont-SC-SCIM-v0", 65536, "rk4"),        # BASELINE config 4 with the env's own PolynomialStaticLoad, plain RK4 (`scim_plain_rk4`)
+    ("Cont-SC-SCIM-v0", 65536, "default"),    # ... as bench.py's `configs.scim` measures it: the solver make() hands out = RK4 + kink correction,
+                                              #     <2, 2> shape under the rate limiter, against the oracle's restatement of that scheme (rk4_kink)
     ("Cont-SC-SCIM-v0:constspeed", 65536, "rk4"),  # BASELINE config 4 as BASELINE.json words it: + ConstantSpeedLoad (one-step map)
 ])
 def test_full_size_configs_against_oracle(env_id, n_envs, solver):
@@ -576,14 +632,24 @@ def test_full_size_configs_against_oracle(env_id, n_envs, solver):
     actions, K = 1000 control steps in ONE fused launch.  64 sampled envs (first / last lanes of workgroups, both halves of the
     grid) are checked step by step against the fp64 oracle with the SAME integrator -- trajectories episode by episode, done masks
     exactly (flips only within 1e-5 of the constraint boundary) -- all envs for finiteness and a plausible termination count, and
-    step-by-step simulate() == the fused rollout bit for bit."""
+    step-by-step simulate() == the fused rollout bit for bit.  The kernel instantiation and shape the launcher picked are asserted
+    from gemx_last_launch(): what is compared here IS what bench.py times."""
+    _full_size_check(env_id, n_envs, solver, 1000)
+
+
+def test_headline_ten_thousand_step_fused_launch_against_oracle():
+    """The north star's horizon in ONE launch: BASELINE config 3 (Finite-CC-PMSM-v0, 16384 envs, RK4, tau 1e-4), 10 000 control steps
+    fused (9.2 GB of observation rows), 64 sampled envs against the fp64 oracle over all 10 000 steps and ~180 episodes each."""
+    _full_size_check("Finite-CC-PMSM-v0", 16384, "rk4", 10000, single_step_check=False)
+
+
+def _full_size_check(env_id, n_envs, solver, K, single_step_check=True):
     import torch
 
     import gym_electric_motor_amd as ga
     from oracle import oracle as orc
 
-    K = 1000
-    sol = ga.EulerSolver() if solver == "euler" else ga.RK4Solver()
+    sol = {"euler": ga.EulerSolver(), "rk4": ga.RK4Solver(), "default": None}[solver]  # default: whatever make() hands out (bench.py: make_env)
     env_id, _, variant = env_id.partition(":")
     golden = {"Cont-CC-PermExDc-v0": "permexdc_epi_held_euler", "Finite-CC-PMSM-v0": "pmsm_epi_held_tau1e-4_euler",
               "Cont-SC-SCIM-v0": "scim_epi_uniform_euler"}[env_id]
@@ -601,16 +667,28 @@ def test_full_size_configs_against_oracle(env_id, n_envs, solver):
     obs, done = env.rollout(acts)
     torch.cuda.synchronize()
     # the kernel the bench measures (BASELINE config 2, a small batch of a DC machine behind a constant-speed load: dc_stream_kernel)
-    assert ("dc_stream_kernel" if "PermExDc" in env_id else "advance_pipe_kernel") in ps.last_launch()
+    ll = ps.last_launch()
+    assert ("dc_stream_kernel" if "PermExDc" in env_id else "advance_pipe_kernel") in ll, ll
+    assert "overrides" not in ll, ll  # no GEMX_* switch changed what ran
+    if n_envs > 64 * 256:  # more workgroups than CUs: the large-batch rate limiter is part of the measured launch
+        assert "rate limit" in ll, ll
+    want_shape = {("Finite-CC-PMSM-v0", 16384): "D=12", ("Finite-CC-PMSM-v0", 32768): "D=4", ("Cont-SC-SCIM-v0", 65536): "D=2"}.get((env_id, n_envs))
+    if want_shape is not None and not variant:
+        assert want_shape + ">" in ll, ll
+    osol = _oracle_solver_for(dict(meta, env_id=env_id, tau=1e-4), ps._ode_solver)
+    assert osol is not None and osol[1] == 1
+    if solver == "default" and "SCIM" in env_id:
+        assert osol[0] == "rk4_kink"
     assert torch.isfinite(obs).all()
     # single-step path must give the same bits as the fused path (incl. the auto-reset)
-    env2 = ga.make(env_id, n_envs=n_envs, ode_solver=sol, tau=1e-4, **mkw)
-    for k in range(40):
-        o = env2.physical_system.simulate(acts[k])
-        assert torch.equal(o, obs[k]) and torch.equal(env2.physical_system.done, done[k])
-    env2.close()
+    if single_step_check:
+        env2 = ga.make(env_id, n_envs=n_envs, ode_solver=sol, tau=1e-4, **mkw)
+        for k in range(40):
+            o = env2.physical_system.simulate(acts[k])
+            assert torch.equal(o, obs[k]) and torch.equal(env2.physical_system.done, done[k])
+        env2.close()
     meta = dict(meta, tau=1e-4)
-    p = orc.params_from_meta(meta, solver=solver, episodic=True)
+    p = orc.params_from_meta(meta, solver=osol[0], episodic=True)
     names = meta["state_names"]
     rng = np.random.default_rng(7)
     sample = sorted(set([0, 1, 63, 64, 127, n_envs // 2 - 1, n_envs // 2, n_envs // 2 + 17, n_envs - 64, n_envs - 1]) |
@@ -636,7 +714,7 @@ def test_full_size_configs_against_oracle(env_id, n_envs, solver):
     assert n_term > len(sample)            # every sampled env terminated (and restarted) more than once on average
     assert n_flip <= len(sample) // 8      # boundary flips are the exception
     assert abs(total_done / n_envs - n_term / len(sample)) < 0.25 * n_term / len(sample)  # all envs: same termination rate as the sample
-    print(f"{env_id} N={n_envs} {solver}: worst rel err {worst:.2e} over {len(sample)} envs x {K} steps, {n_term} terminations, {n_flip} flips")
+    print(f"{env_id} N={n_envs} {solver} (oracle {osol[0]}): worst rel err {worst:.2e} over {len(sample)} envs x {K} steps, {n_term} terminations, {n_flip} flips; {ll}")
 
 
 @pytest.mark.parametrize("env_id, golden, til", [
@@ -1260,6 +1338,112 @@ def test_full_pipelined_variant_matches_single_wave_kernel(name, monkeypatch):
         assert torch.equal(x, y)
     if name.startswith("init:") or "epi" in name:
         assert a[1].any()
+
+
+def _varied_actions(d, ps, n):
+    """A fixture's recorded action sequence for n envs, varied per env so that lanes differ (continuous: scaled by 0.3 .. 1; discrete:
+    rotated by the env index)."""
+    import torch
+
+    acts = d["actions"]
+    K = acts.shape[0]
+    a = torch.as_tensor(np.repeat(acts.reshape(K, 1, -1), n, axis=1))
+    if ps._discrete and acts.ndim == 1:
+        a = a.reshape(K, n).cuda()
+        return ((a.long() + torch.arange(n, device="cuda").reshape(1, n)) % int(ps.action_space.n)).to(torch.uint8)
+    a = a.cuda()
+    if not ps._discrete:
+        a = a * torch.linspace(0.3, 1.0, n, device="cuda", dtype=a.dtype).reshape(1, n, 1)
+    return a
+
+
+PARTIAL_CASES = ["pmsm_epi_held_tau1e-4_euler",            # finite B6: voltage table, compact hand-off rows, one-step map
+                 "scim_epi_uniform_euler",                 # continuous duty cycles (12 bytes per env-step through the loader), PolynomialStaticLoad
+                 "permexdc_epi_held_euler",                # one-state DC machine (dc_stream_kernel wants whole workgroups: the pipelined kernel serves these)
+                 "pmsm_free_uniform_til_euler",            # converter dead time: leg states loaded / stored per lane
+                 "dfim_fin_epi_held_tau1e-4_euler",        # two bytes of leg state per env, 24-column rows
+                 "pmsm_fin_dead1_til_free_uniform_euler",  # DeadTimeProcessor queue in HBM
+                 "rc_pmsm_fin_til_epi_uniform_tau1e-4_euler",  # RCVoltageSupply: the FULL instantiation
+                 "init:pmsm_sc_uniform"]                   # random initialisers: reset counters per lane (FULL)
+
+
+@pytest.mark.parametrize("name", PARTIAL_CASES)
+@pytest.mark.parametrize("n", [16, 80, 208])
+def test_partial_last_workgroup_of_the_pipelined_kernel(name, n, monkeypatch):
+    """A batch that is not a multiple of 64 envs no longer falls back to the single-wave kernel (round 4: 6-8 x slower, silently): the
+    pipelined kernel's last workgroup takes the remaining envs (clamped loads, masked stores, lane-by-lane staging, row stores over
+    the valid span).  Every shape, bit for bit against the single-wave kernel: all observation rows and done bytes of all envs, a
+    second launch from the stored state, and the final ODE / leg / supply state -- and the memory right behind every output tensor
+    untouched (the partial workgroup's lanes beyond the batch store nothing)."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    def run(pipe, shape):
+        monkeypatch.setenv("GEMX_PIPE", pipe)
+        if shape is None:
+            monkeypatch.delenv("GEMX_PIPE_SHAPE", raising=False)
+        else:
+            monkeypatch.setenv("GEMX_PIPE_SHAPE", shape)
+        if name.startswith("init:"):
+            env = _init_env(name[5:], n, seed=9, ode_solver=ga.RK4Solver())[0]
+            ps = env.physical_system
+            g = torch.Generator(device="cuda").manual_seed(3)
+            if ps._discrete:
+                acts = torch.randint(0, 8, (150, n), device="cuda", generator=g, dtype=torch.uint8)
+            else:
+                acts = torch.rand((150, n, ps._n_act), device="cuda", generator=g) * 2 - 1
+        else:
+            d, meta = _load(name)
+            env = _make_from_meta(meta, n, auto_reset=True)
+            ps = env.physical_system
+            acts = _varied_actions(d, ps, n)[:150]
+        K = acts.shape[0]
+        # outputs inside larger guarded buffers: [K * n * n_out] rows followed by a canary
+        obuf = torch.full((K * n * ps._n_out + 64,), -7.0, device="cuda")
+        dbuf = torch.full((K * n + 64,), 9, device="cuda", dtype=torch.uint8)
+        obs = obuf[: K * n * ps._n_out].view(K, n, ps._n_out)
+        done = dbuf[: K * n].view(K, n)
+        env.rollout(acts, obs_out=obs, done_out=done)
+        kern = ps.last_launch()
+        assert (obuf[K * n * ps._n_out:] == -7.0).all() and (dbuf[K * n:] == 9).all()
+        obs2, done2 = env.rollout(acts[:37])
+        res = (obs.clone(), done.clone(), obs2, done2, ps.get_state(), ps.get_switch_state())
+        env.close()
+        return res, kern
+
+    ref, kref = run("0", None)
+    assert "advance_kernel" in kref
+    shapes = (None,) if name.startswith(("rc_", "init:")) else (None, "0", "1", "2", "3")  # (FULL: one instantiation, shape <4, 2>)
+    for shape in shapes:
+        got, k = run("1", shape)
+        assert "advance_pipe_kernel" in k, (shape, k)
+        for x, y in zip(got, ref):
+            assert torch.equal(x, y), (name, n, shape)
+    if "epi" in name or name.startswith("init:"):
+        assert ref[1].any()
+
+
+def test_unaligned_batch_sizes_say_that_they_take_the_fallback(capfd):
+    """Batch sizes whose rows are not 16-byte aligned (n_envs not a multiple of 16) still run the single-wave kernel -- and now SAY so,
+    once per handle, on stderr (GEMX_QUIET=1 silences it)."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    env = ga.make("Finite-CC-PMSM-v0", n_envs=70)
+    acts = torch.zeros((8, 70), dtype=torch.uint8, device="cuda")
+    env.rollout(acts)
+    env.rollout(acts)
+    assert "advance_kernel" in env.physical_system.last_launch()
+    env.close()
+    err = capfd.readouterr().err
+    assert err.count("single-wave fallback kernel") == 1 and "multiple of 16" in err
+    env = ga.make("Finite-CC-PMSM-v0", n_envs=80)
+    env.rollout(torch.zeros((8, 80), dtype=torch.uint8, device="cuda"))
+    assert "advance_pipe_kernel" in env.physical_system.last_launch()
+    env.close()
+    assert "fallback" not in capfd.readouterr().err
 
 
 @pytest.mark.parametrize("env_id, delay, kw", [
@@ -2141,6 +2325,39 @@ def test_bench_multi_gpu_code_path_through_rccl_in_a_world_of_one():
     assert rc["bytes_per_rank"] == 16384 * 200 * 57 and rc["GB_per_s"] > 0 and rc["ms"] > 0
     assert line["gather"]["chunk"]["value"] > 0 and "error" not in line["config5"] and line["config5"]["envs_per_gpu"] == 32768
     assert line["overrides"] == {k: v for k, v in os.environ.items() if k.startswith("GEMX_")}
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_on_two_gpus_through_rccl():
+    """The first box with >= 2 GPUs runs the collective under pytest too (round 4 verdict: no RCCL collective had ever run between two
+    ranks): `bench.py --gpus 2` spawns its own two ranks (one per GPU, `nccl` = RCCL over xGMI on 127.0.0.1), each steps its shard,
+    and the bounded chunk-gather leg all-gathers one launch's observation rows.  Asserted: both ranks were seen by the collective,
+    every rank's own slot of the gathered tensor is its own output bit for bit, the line carries the whole-job value (2 x the shard),
+    and config 5's leg.  Skipped on a box with one GPU (the driver's GPU test tier)."""
+    import json
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the two-rank RCCL path needs two (world-of-one code path: the test above; gloo world of 2: tests/test_distributed_cpu.py)")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-extras", "--no-pmc",
+           "--settle-ms", "5", "--repeats", "1", "--steps-per-launch", "200"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=840)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["backend"] == "nccl" and line["scaling"] == "weak"
+    assert line["config"]["envs_per_gpu"] == 16384 and not line["config"]["oversubscribed"]
+    rc = line["rccl"]
+    assert "error" not in rc, rc
+    assert rc["world_seen"] == 2 and rc["backend"] == "nccl" and rc["own_slot_bit_identical"] is True
+    assert rc["bytes_per_rank"] == 16384 * 200 * 57 and rc["GB_per_s"] > 0
+    assert line["gather"]["chunk"]["value"] > 0
+    assert "error" not in line["config5"] and line["config5"]["envs_total"] == 65536
 
 
 def test_last_launch_names_every_active_override(monkeypatch):

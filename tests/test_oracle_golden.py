@@ -262,3 +262,27 @@ def test_kink_splitting_restatement_tracks_reference_default_solver(name):
         diff[:, i] = np.minimum(diff[:, i], 2.0 - diff[:, i])
         rel = (diff.max(axis=0) / np.maximum(np.abs(d["states"]).max(axis=0), 1e-3)).max()
         assert n > 0.5 * len(done) and rel < 2e-5, (solver, rel, n)
+
+
+def test_rollout_diag_is_the_rollout_plus_its_conditioning_diagnostics():
+    """orc_rollout_diag (what the GPU lane checks weigh the field-oriented columns and cut the dead-time lanes with): the same rows and
+    done bytes as orc_rollout, |psi_r| at the start of every step for the induction machines (0 at a reset, 0 for other machines), and
+    a finite current-sign margin exactly on the steps of a dead-time fixture that have a dead leg."""
+    for name, solver in (("default_finite_tc_dfim_dopri5", "rk4"), ("pmsm_free_uniform_til_dopri5", "rk4"), ("scim_epi_uniform_euler", "euler")):
+        d, meta = orc.load_golden(name)
+        p = orc.params_from_meta(meta, solver=solver)
+        e1, e2 = orc.OracleEnv(p), orc.OracleEnv(p)
+        e1.reset(), e2.reset()
+        o1, d1 = e1.rollout(d["actions"])
+        o2, d2, psi, margin = e2.rollout_diag(d["actions"])
+        assert np.array_equal(o1, o2) and np.array_equal(d1, d2)
+        if "InductionMotorSystem" in meta["system"]:
+            assert psi[0] == 0.0 and psi.max() > 1e-3 and (psi >= 0).all()
+            if d1.any():  # the step after a termination starts from the reset state: zero flux again
+                assert psi[int(np.argmax(d1)) + 1] == 0.0
+        else:
+            assert not psi.any()
+        if meta["interlocking_time"] > 0:
+            assert np.isfinite(margin).any() and (margin >= 0).all()
+        else:
+            assert np.isinf(margin).all()
