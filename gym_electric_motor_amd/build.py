@@ -34,9 +34,9 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: cannot build gym_electric_motor_amd/libgemx.so")
 
 
-def _digest(sources=None):
+def _digest(sources=None, header=None):
     h = hashlib.sha256()
-    for p in (SOURCES if sources is None else sources) + [HEADER]:
+    for p in (SOURCES if sources is None else sources) + [header or HEADER]:
         h.update(open(p, "rb").read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
@@ -61,18 +61,28 @@ def build_library(force=False, verbose=False, jobs=None):
         return LIB
     hipcc = hipcc_path()
     os.makedirs(OBJ_DIR, exist_ok=True)
-    inc = ["-I" + os.path.join(REPO, "include"), "-I" + CSRC]
+    # compile from a SNAPSHOT of the sources taken now: a full build runs for minutes with the units starting at different times, and an
+    # edit of a header in between would otherwise give objects of two different versions of it (and a stamp that matches neither)
+    snap = os.path.join(OBJ_DIR, "src_snapshot")
+    shutil.rmtree(snap, ignore_errors=True)
+    os.makedirs(snap)
+    for f in SOURCES + [HEADER]:
+        shutil.copy2(f, snap)
+    snap_sources = [os.path.join(snap, os.path.basename(f)) for f in SOURCES]
+    snap_header = os.path.join(snap, os.path.basename(HEADER))
+    csrc = snap
+    inc = ["-I" + snap]
     cmds = []  # (object, command, kind, cost)
     for s, c in UNITS:
         for f64 in (0, 1):
             obj = os.path.join(OBJ_DIR, f"gemx_inst_{s}_{c}_{f64}.o")
             cmds.append((obj, [hipcc] + FLAGS + inc + [f"-DGEMX_INST_SYS={s}", f"-DGEMX_INST_CONV={c}", f"-DGEMX_INST_F64={f64}",
-                                                      "-c", os.path.join(CSRC, "gemx_inst.hip"), "-o", obj], "inst", _COST[s] * (0.15 if f64 else 1.0)))
+                                                      "-c", os.path.join(csrc, "gemx_inst.hip"), "-o", obj], "inst", _COST[s] * (0.15 if f64 else 1.0)))
     capi_obj = os.path.join(OBJ_DIR, "gemx_capi.o")
-    cmds.append((capi_obj, [hipcc] + FLAGS + inc + ["-c", os.path.join(CSRC, "gemx_capi.hip"), "-o", capi_obj], "capi", 0.3))
+    cmds.append((capi_obj, [hipcc] + FLAGS + inc + ["-c", os.path.join(csrc, "gemx_capi.hip"), "-o", capi_obj], "capi", 0.3))
     refgen_obj = os.path.join(OBJ_DIR, "gemx_refgen.o")
-    cmds.append((refgen_obj, [hipcc] + FLAGS + inc + ["-c", os.path.join(CSRC, "gemx_refgen.hip"), "-o", refgen_obj], "refgen", 0.2))
-    digests = {k: _digest([os.path.join(CSRC, f) for f in v]) for k, v in _DEPS.items()}
+    cmds.append((refgen_obj, [hipcc] + FLAGS + inc + ["-c", os.path.join(csrc, "gemx_refgen.hip"), "-o", refgen_obj], "refgen", 0.2))
+    digests = {k: _digest([os.path.join(csrc, f) for f in v], snap_header) for k, v in _DEPS.items()}
 
     def run(cmd):
         if verbose:
@@ -93,5 +103,5 @@ def build_library(force=False, verbose=False, jobs=None):
         list(ex.map(compile_one, sorted(cmds, key=lambda j: -j[3])))
     run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [j[0] for j in cmds])
     with open(STAMP, "w") as fh:
-        fh.write(_digest())
+        fh.write(_digest(snap_sources, snap_header))  # (of what was compiled: an edit made meanwhile leaves the library stale, as it should)
     return LIB

@@ -357,23 +357,27 @@ template <class R> static int launch_reset(gemx_handle *h, const uint8_t *mask, 
 }
 
 // ---- checkpoint of everything gemx_get_state / gemx_get_switch_state do not carry (gemx_get_aux_state) ---------------------------
-// blob = header (128 bytes) | RC supply rows [2][N] R | DeadTimeProcessor ring | reset counters [N] uint32, sections padded to 16 bytes
+// blob = header (128 bytes) | RC supply rows [2][N] R | DeadTimeProcessor ring | reset counters [N] uint32 | angle words [N] (the fp32
+// build's 32-bit fixed-point angle, which gemx_get_state rounds to fp32 radians: the exact words make the restore bit for bit), sections
+// padded to 16 bytes
 struct AuxHeader {
     uint32_t magic, version;
     int64_t n;
     uint32_t elem_size, delay, nact_conv, supply_rc, init_kind, fifo_phase;
     uint64_t steps_total, rc_bytes, ring_bytes, rcnt_bytes;
     uint32_t system_kind, converter_kind;
-    unsigned char pad[128 - 80];
+    uint64_t angle_bytes;
+    unsigned char pad[128 - 88];
 };
 static_assert(sizeof(AuxHeader) == 128, "aux header is 128 bytes");
 constexpr uint32_t AUX_MAGIC = 0x55415847u;  // "GXAU"
 static size_t pad16(size_t b) { return (b + 15) & ~(size_t)15; }
-static void aux_sections(const gemx_handle *h, size_t &rc_b, size_t &ring_b, size_t &rcnt_b) {
+static void aux_sections(const gemx_handle *h, size_t &rc_b, size_t &ring_b, size_t &rcnt_b, size_t &ang_b) {
     const size_t es = h->cfg.dtype == GEMX_F64 ? 8 : 4;
     rc_b = h->cfg.supply_kind == GEMX_SUPPLY_RC ? 2 * (size_t)h->n * es : 0;
     ring_b = h->ring != nullptr ? h->ring_bytes : 0;
     rcnt_b = h->rcnt != nullptr ? sizeof(uint32_t) * (size_t)h->n : 0;
+    ang_b = h->has_angle && h->angle != nullptr ? es * (size_t)h->n : 0;
 }
 __global__ void aux_header_kernel(AuxHeader hd, const uint32_t *fifo_phase, AuxHeader *out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -763,19 +767,20 @@ int gemx_reset_again(gemx_handle *h, const uint8_t *mask_dev, void *obs_out_dev,
 
 int64_t gemx_aux_state_bytes(const gemx_handle *h) {
     if (!h) return GEMX_ERR_ARG;
-    size_t a, b, c;
-    aux_sections(h, a, b, c);
-    return (int64_t)(sizeof(AuxHeader) + pad16(a) + pad16(b) + pad16(c));
+    size_t a, b, c, d;
+    aux_sections(h, a, b, c, d);
+    return (int64_t)(sizeof(AuxHeader) + pad16(a) + pad16(b) + pad16(c) + pad16(d));
 }
 int gemx_get_aux_state(gemx_handle *h, void *blob_out_dev, void *stream) {
     if (!h || !blob_out_dev) return fail(GEMX_ERR_ARG, "null argument");
     if (((uintptr_t)blob_out_dev & 15u) != 0) return fail(GEMX_ERR_ARG, "blob_out_dev must be 16-byte aligned");
     gemx::DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
-    size_t rc_b, ring_b, rcnt_b;
-    aux_sections(h, rc_b, ring_b, rcnt_b);
+    size_t rc_b, ring_b, rcnt_b, ang_b;
+    aux_sections(h, rc_b, ring_b, rcnt_b, ang_b);
     AuxHeader hd;
     memset(&hd, 0, sizeof(hd));
+    hd.angle_bytes = ang_b;
     hd.magic = AUX_MAGIC; hd.version = 1; hd.n = h->n; hd.elem_size = (uint32_t)elem_size(h); hd.delay = (uint32_t)h->cfg.action_delay;
     hd.nact_conv = (uint32_t)h->nact_conv; hd.supply_rc = h->cfg.supply_kind == GEMX_SUPPLY_RC; hd.init_kind = (uint32_t)h->cfg.init_kind;
     hd.steps_total = h->steps_total; hd.rc_bytes = rc_b; hd.ring_bytes = ring_b; hd.rcnt_bytes = rcnt_b;
@@ -788,6 +793,8 @@ int gemx_get_aux_state(gemx_handle *h, void *blob_out_dev, void *stream) {
     if (ring_b) HIP_TRY(hipMemcpyAsync(p, h->ring, ring_b, hipMemcpyDeviceToDevice, st));
     p += pad16(ring_b);
     if (rcnt_b) HIP_TRY(hipMemcpyAsync(p, h->rcnt, rcnt_b, hipMemcpyDeviceToDevice, st));
+    p += pad16(rcnt_b);
+    if (ang_b) HIP_TRY(hipMemcpyAsync(p, h->angle, ang_b, hipMemcpyDeviceToDevice, st));
     return GEMX_OK;
 }
 int gemx_set_aux_state(gemx_handle *h, const void *blob_in_dev, void *stream) {
@@ -800,12 +807,12 @@ int gemx_set_aux_state(gemx_handle *h, const void *blob_in_dev, void *stream) {
     AuxHeader hd;
     HIP_TRY(hipMemcpyAsync(&hd, blob_in_dev, sizeof(hd), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    size_t rc_b, ring_b, rcnt_b;
-    aux_sections(h, rc_b, ring_b, rcnt_b);
+    size_t rc_b, ring_b, rcnt_b, ang_b;
+    aux_sections(h, rc_b, ring_b, rcnt_b, ang_b);
     if (hd.magic != AUX_MAGIC || hd.version != 1) return fail(GEMX_ERR_ARG, "not a gemx aux-state blob (magic %08x, version %u)", hd.magic, hd.version);
     if (hd.n != h->n || hd.elem_size != (uint32_t)elem_size(h) || hd.delay != (uint32_t)h->cfg.action_delay || hd.nact_conv != (uint32_t)h->nact_conv ||
         hd.supply_rc != (uint32_t)(h->cfg.supply_kind == GEMX_SUPPLY_RC) || hd.init_kind != (uint32_t)h->cfg.init_kind || hd.rc_bytes != rc_b ||
-        hd.ring_bytes != ring_b || hd.rcnt_bytes != rcnt_b || hd.system_kind != (uint32_t)h->cfg.system_kind || hd.converter_kind != (uint32_t)h->cfg.converter_kind)
+        hd.ring_bytes != ring_b || hd.rcnt_bytes != rcnt_b || hd.angle_bytes != ang_b || hd.system_kind != (uint32_t)h->cfg.system_kind || hd.converter_kind != (uint32_t)h->cfg.converter_kind)
         return fail(GEMX_ERR_ARG, "aux-state blob was taken from a handle of another configuration (n_envs %lld vs %lld, dtype, DeadTimeProcessor steps, supply or initialiser kind differ)",
                     (long long)hd.n, (long long)h->n);
     if (h->cfg.action_delay > 0 && hd.fifo_phase >= (uint32_t)h->cfg.action_delay) return fail(GEMX_ERR_ARG, "aux-state blob: FIFO phase %u out of range", hd.fifo_phase);
@@ -815,6 +822,8 @@ int gemx_set_aux_state(gemx_handle *h, const void *blob_in_dev, void *stream) {
     if (ring_b) HIP_TRY(hipMemcpyAsync(h->ring, p, ring_b, hipMemcpyDeviceToDevice, st));
     p += pad16(ring_b);
     if (rcnt_b) HIP_TRY(hipMemcpyAsync(h->rcnt, p, rcnt_b, hipMemcpyDeviceToDevice, st));
+    p += pad16(rcnt_b);
+    if (ang_b) HIP_TRY(hipMemcpyAsync(h->angle, p, ang_b, hipMemcpyDeviceToDevice, st));
     const uint32_t ph[2] = {hd.fifo_phase, 0u};
     HIP_TRY(hipMemcpyAsync(h->fifo_phase, ph, sizeof(ph), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));  // (`ph` is a stack buffer)

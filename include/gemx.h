@@ -283,7 +283,8 @@ int gemx_refgen_get_state(gemx_refgen *r, double *value_out_dev, double *sigma_o
  * Everything else a resumed handle needs is ONE opaque device blob (gemx_aux_state_bytes() bytes, 16-byte aligned): the
  * RCVoltageSupply's two rows (capacitor voltage, time since its last update; voltage_supplies.py:100-123), the DeadTimeProcessor's
  * action queue and its phase (dead_time_processor.py:63-85), the per-env reset counters of the random initialisers (the counter-based
- * streams continue where they were) and the launched-steps count.  A checkpoint = get_state + get_switch_state + get_aux_state;
+ * streams continue where they were), the exact angle words (see above: gemx_get_state rounds them) and the launched-steps count.
+ * A checkpoint = get_state + get_switch_state + get_aux_state, restored in that order (the blob's angle words overwrite the rounded ones);
  * restored into a fresh handle of the SAME configuration (checked: gemx_set_aux_state fails with GEMX_ERR_ARG otherwise, and
  * synchronises `stream` to read the blob's header) the next launches continue bit for bit. */
 int gemx_n_switch_bytes(const gemx_handle *h);

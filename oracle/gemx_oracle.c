@@ -275,6 +275,8 @@ static void dp5_stages(const orc_params *p, const orc_env *e, int n, const doubl
 }
 
 /* scipy.integrate.ode('dopri5').integrate(t_end) as used by ScipyOdeSolver (solvers.py:139-184). */
+static __thread long g_dp5_attempts = 0; /* diagnostic: Dormand-Prince steps attempted (accepted + rejected), orc_dp5_attempts() */
+long orc_dp5_attempts(void) { return g_dp5_attempts; }
 static void dopri5_adaptive(const orc_params *p, orc_env *e, double t_end) {
     const double RTOL = 1e-6, ATOL = 1e-12, SAFE = 0.9, FAC1 = 0.2, FAC2 = 10.0, BETA = 0.04, UROUND = 2.3e-16;
     const int NMAX = 500;
@@ -315,6 +317,7 @@ static void dopri5_adaptive(const orc_params *p, orc_env *e, double t_end) {
         if (0.1 * fabs(h) <= fabs(x) * UROUND) break;  /* step size too small */
         if ((x + 1.01 * h - xend) * posneg > 0.0) { h = xend - x; last = 1; }
         nstep++;
+        g_dp5_attempts++;
         dp5_stages(p, e, n, e->y, h, k1, k2, k3, k4, k5, k6, y1);
         double err = 0.0;
         for (int i = 0; i < n; ++i) {

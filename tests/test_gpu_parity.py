@@ -1424,6 +1424,96 @@ def test_partial_last_workgroup_of_the_pipelined_kernel(name, n, monkeypatch):
         assert ref[1].any()
 
 
+CHECKPOINT_CASES = ["rc_pmsm_fin_til_epi_uniform_tau1e-4_euler",   # RCVoltageSupply rows + leg states (dead time)
+                    "rc_permexdc_cont_free_held_euler",            # RC supply behind a continuous converter
+                    "pmsm_fin_dead1_til_free_uniform_euler",       # DeadTimeProcessor queue + phase
+                    "init:pmsm_sc_uniform",                        # random initialisers: per-env reset counters
+                    "pmsm_epi_held_tau1e-4_euler"]                 # nothing but ODE state (the aux blob is its header)
+
+
+@pytest.mark.parametrize("name", CHECKPOINT_CASES)
+@pytest.mark.parametrize("n", [128, 70])
+def test_checkpoint_resumes_bit_for_bit(name, n):
+    """A COMPLETE checkpoint (round 4 verdict: gemx_get_state moved the ODE rows and the angle only, so a handle with an RC supply, a
+    DeadTimeProcessor or random initialisers could not be resumed): rollout K, save (state + leg states + aux blob + k), rollout K more
+    == restore into a FRESH system, rollout K more -- observations, done bytes and the final state bit for bit; with K not a multiple
+    of the DeadTimeProcessor's depth (the queue phase matters), through the pipelined kernel (n = 128) and the single-wave one (70).
+    A blob from another configuration is refused."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    def mk(nn=n):
+        if name.startswith("init:"):
+            env = _init_env(name[5:], nn, seed=11, ode_solver=ga.RK4Solver())[0]
+            return env, None
+        d, meta = _load(name)
+        return _make_from_meta(meta, nn, auto_reset=True), d
+
+    env, d = mk()
+    ps = env.physical_system
+    K = 75
+    if d is None:
+        g = torch.Generator(device="cuda").manual_seed(5)
+        acts = (torch.randint(0, 8, (2 * K, n), device="cuda", generator=g, dtype=torch.uint8) if ps._discrete
+                else torch.rand((2 * K, n, ps._n_act), device="cuda", generator=g) * 2 - 1)
+    else:
+        acts = _varied_actions(d, ps, n)[: 2 * K]
+    o1, d1 = env.rollout(acts[:K])
+    ck = ps.get_checkpoint()
+    assert ck["k"] == K and ck["aux"].numel() % 16 == 0
+    ck = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in ck.items()}
+    o2, d2 = env.rollout(acts[K:])
+    s2, sw2 = ps.get_state(), ps.get_switch_state()
+    env.close()
+    env_b, _ = mk()
+    pb = env_b.physical_system
+    pb.rollout(acts[:13])  # (a handle that has already moved: everything is overwritten)
+    pb.set_checkpoint(ck)
+    assert pb.k == K
+    o3, d3 = env_b.rollout(acts[K:])
+    assert torch.equal(o3, o2) and torch.equal(d3, d2)
+    assert torch.equal(pb.get_state(), s2) and torch.equal(pb.get_switch_state(), sw2)
+    if name.startswith("init:") or name == "pmsm_epi_held_tau1e-4_euler":
+        assert d2.any()  # (episodes end -- and, with random initialisers, restart from the next draw -- after the restore too)
+    env_b.close()
+    other, _ = mk(n + 16)
+    with pytest.raises(ValueError):
+        other.physical_system.set_checkpoint(ck)
+    bad = dict(ck, aux=torch.zeros(int(other.physical_system._L.gemx_aux_state_bytes(other.physical_system._handle)), dtype=torch.uint8, device="cuda"))
+    bad["state"], bad["switch_state"] = other.physical_system.get_state(), other.physical_system.get_switch_state()
+    with pytest.raises(ValueError):  # right size, not a blob
+        other.physical_system.set_checkpoint(bad)
+    other.close()
+
+
+def test_random_initialiser_counters_after_create():
+    """gemx_create leaves draw #1 in place with the counters at 1 (ABI 6): an env's first in-kernel auto-reset is draw #2 -- not draw #1
+    again (advisor finding, round 4: a caller stepping with auto_reset and never calling reset started episodes 1 and 2 from the same
+    state) -- and so is the user's first reset(); the construction-time observation rows ARE draw #1."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    n = 128
+    env = _init_env("pmsm_sc_uniform", n, seed=21, ode_solver=ga.RK4Solver())[0]
+    ps = env.physical_system
+    obs0 = ps._obs.clone()           # rows of draw #1 (gemx_reset_again at construction)
+    s1 = ps.get_state()
+    counters = lambda: ps.get_checkpoint()["aux"][128 : 128 + 4 * n].view(torch.int32)  # noqa: E731  (header | no RC rows | no queue | counters | angle words)
+    assert (counters() == 1).all()
+    r2 = env.reset()[0].clone()      # draw #2
+    s2 = ps.get_state()
+    assert not torch.equal(s1, s2) and not torch.equal(obs0, r2)
+    assert (counters() == 2).all()
+    env.close()
+    env = _init_env("pmsm_sc_uniform", n, seed=21, ode_solver=ga.RK4Solver())[0]  # same seed: same draws
+    assert torch.equal(env.physical_system.get_state(), s1) and torch.equal(env.physical_system._obs, obs0)
+    env.reset()
+    assert torch.equal(env.physical_system.get_state(), s2)
+    env.close()
+
+
 def test_unaligned_batch_sizes_say_that_they_take_the_fallback(capfd):
     """Batch sizes whose rows are not 16-byte aligned (n_envs not a multiple of 16) still run the single-wave kernel -- and now SAY so,
     once per handle, on stderr (GEMX_QUIET=1 silences it)."""
