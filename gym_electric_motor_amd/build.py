@@ -61,6 +61,22 @@ def build_library(force=False, verbose=False, jobs=None):
         return LIB
     hipcc = hipcc_path()
     os.makedirs(OBJ_DIR, exist_ok=True)
+    # ONE build at a time (a CPU test calls build() too: two builds racing for the snapshot directory and the objects produce garbage);
+    # a second caller waits here and then finds the objects the first one made
+    import fcntl
+
+    lock = open(os.path.join(OBJ_DIR, ".build.lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and not is_stale():
+            return LIB
+        return _build_locked(hipcc, force, verbose, jobs)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(hipcc, force, verbose, jobs):
     # compile from a SNAPSHOT of the sources taken now: a full build runs for minutes with the units starting at different times, and an
     # edit of a header in between would otherwise give objects of two different versions of it (and a stamp that matches neither)
     snap = os.path.join(OBJ_DIR, "src_snapshot")

@@ -592,7 +592,7 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         }
         // every switch below changes which kernel a PRODUCT call runs: whatever is set is recorded and shows up in gemx_last_launch(), so that
         // a stray variable cannot silently change a benchmark (round 3 verdict)
-        for (const char *name : {"GEMX_STEPS_PER_BLOCK", "GEMX_PIPE", "GEMX_PIPE_SHAPE", "GEMX_STEP_KERNEL", "GEMX_DC_STREAM", "GEMX_DCS_EPW", "GEMX_LINMAP", "GEMX_PACE_GBPS"}) {
+        for (const char *name : {"GEMX_STEPS_PER_BLOCK", "GEMX_PIPE", "GEMX_PIPE_SHAPE", "GEMX_STEP_KERNEL", "GEMX_DC_STREAM", "GEMX_DCS_EPW", "GEMX_LINMAP", "GEMX_PACE_GBPS", "GEMX_PACE_CAL"}) {
             const char *v = getenv(name);
             if (v == nullptr) continue;
             const size_t used = strlen(h->overrides);
@@ -613,6 +613,8 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         if (ev) h->dcs_epw = atoi(ev);
         ev = getenv("GEMX_PACE_GBPS");  // target rate of the large-batch rate limiter in GB/s (A/B runs); 0: off
         if (ev) h->pace_gbps = atof(ev);
+        ev = getenv("GEMX_PACE_CAL");  // 0: the rate limiter keeps its built-in target (no closed-loop calibration)
+        if (ev) h->pace_cal_on = atoi(ev);
         ev = getenv("GEMX_LINMAP");  // 0: never use the one-step map of the electrical subsystem (A/B runs)
         if (ev && atoi(ev) == 0) h->linmap_state = -1;
 
@@ -713,6 +715,11 @@ int gemx_destroy(gemx_handle *h) {
     if (h->fifo_phase) (void)hipFree(h->fifo_phase);
     if (h->reset_obs_dev) (void)hipFree(h->reset_obs_dev);
     if (h->cw_dev) (void)hipFree(h->cw_dev);
+    if (h->pcal.ev_init)
+        for (int i = 0; i < gemx_handle::PaceCal::RING; ++i) {
+            if (h->pcal.ev0[i]) (void)hipEventDestroy((hipEvent_t)h->pcal.ev0[i]);
+            if (h->pcal.ev1[i]) (void)hipEventDestroy((hipEvent_t)h->pcal.ev1[i]);
+        }
     delete h;
     return GEMX_OK;
 }
@@ -950,6 +957,11 @@ const char *gemx_last_launch(const gemx_handle *h) {
             const size_t used = strlen(h->last_launch);
             snprintf(h->last_launch + used, sizeof(h->last_launch) - used, ", rate limit %u0 ns per block (%lld resident workgroups%s)", l.pace,
                      l.pace_res < l.blocks ? l.pace_res : l.blocks, l.pace_tail != 0 ? "; shorter in the last round" : "");
+        }
+        if (h->pace_cal_state != 0) {  // the closed loop: what this launch ran at
+            const size_t used = strlen(h->last_launch);
+            snprintf(h->last_launch + used, sizeof(h->last_launch) - used, ", limiter %s at %.2f x the built-in target%s", h->pace_cal_state == 2 ? "calibrated" : "calibrating",
+                     h->pace_scale_last, h->pace_scale_last == 0.0 ? " (unpaced)" : "");
         }
     } else
         snprintf(h->last_launch, sizeof(h->last_launch),

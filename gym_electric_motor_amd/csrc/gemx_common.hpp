@@ -512,6 +512,26 @@ struct gemx_handle {
     mutable char last_launch[512] = "";
     char overrides[192] = "";  // the GEMX_* environment switches that were set when the handle was created ("NAME=value ..."): gemx_last_launch() names them
     double pace_gbps = -1.0;  // target chip-wide algorithmic rate of the rate limiter [GB/s]; < 0: the built-in default, 0: off (GEMX_PACE_GBPS)
+    // CLOSED LOOP (round 5): the built-in target is only where the calibration starts.  The first paced launches of a handle (per launch
+    // signature: steps, workgroups, shape) take turns at target x {1, 0.93, 1.07, 0.86} and unpaced, each timed with a pair of HIP events on
+    // the launch stream (harvested without ever blocking: hipEventQuery at later launches); when every candidate has PACE_CAL_SAMPLES
+    // completed launches the fastest (by its best time) is kept for the rest of the handle's life.  GEMX_PACE_CAL=0 / an explicit
+    // GEMX_PACE_GBPS: no calibration.  Results are unaffected either way (the limiter only delays block starts).
+    struct PaceCal {
+        static constexpr int NC = 5, SAMPLES = 3, RING = 16;
+        long long sig = -1;        // launch signature the state belongs to
+        int next = 0;              // launches handed out so far (candidate = next % NC)
+        int chosen = -1;           // >= 0: calibration done, candidate index kept
+        float best[NC] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
+        int count[NC] = {0, 0, 0, 0, 0};   // completed, timed launches per candidate
+        int issued[NC] = {0, 0, 0, 0, 0};  // launches handed out per candidate
+        void *ev0[RING] = {}, *ev1[RING] = {};  // hipEvent_t pairs
+        int ev_cand[RING];         // candidate of the launch a pair brackets, -1: free
+        bool ev_init = false;
+    } pcal;
+    int pace_cal_on = 1;  // GEMX_PACE_CAL
+    double pace_scale_last = 1.0;  // factor on the built-in target the last paced launch ran at (0: unpaced)
+    int pace_cal_state = 0;        // of the last launch: 0 no calibration, 1 a calibration launch, 2 calibrated
     size_t pipe_occ_smem[4] = {0, 0, 0, 0};
     int pipe_occ[4] = {0, 0, 0, 0};   // ... and the workgroups per CU the runtime reports for it with this handle's LDS bytes (occupancy API, once)
     int pipe_regs[4] = {0, 0, 0, 0};  // VGPRs of the pipelined kernel's shape k (hipFuncGetAttributes, once): the launcher's residency arithmetic

@@ -379,12 +379,30 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         cfg.action_frame = {"abc": _lib.ACT_ABC, "dq": _lib.ACT_DQ_SPACE, "dq_processor": _lib.ACT_DQ_PROCESSOR}[self._action_frame]
         cfg.action_delay = self._action_delay
         if self._action_delay_reset is not None:
-            row = list(self._action_delay_reset)
-            nvec = getattr(self.action_space, "nvec", None)
-            if nvec is not None and len(row) == 2:  # MultiDiscrete([n0, n1]) -> the flat index the kernel reads (include/gemx.h)
-                row = [row[0] + int(nvec[0]) * row[1]]
-            if len(row) > 6:
-                raise ValueError(f"action_delay_reset has {len(row)} entries")
+            # validated against the WRAPPED system's action space, entry by entry (advisor finding, round 4: a short continuous row was
+            # zero-padded in silence, values beyond the bounds and MultiDiscrete components beyond theirs -- [n0, 0] aliases the flat
+            # index of [0, 1] -- were accepted)
+            row = list(np.atleast_1d(np.asarray(self._action_delay_reset, dtype=float)).ravel())
+            space = self.action_space
+            nvec = getattr(space, "nvec", None)
+            if nvec is not None:  # MultiDiscrete([n0, n1]): the pair, or the flat index the kernel reads (include/gemx.h)
+                nv = [int(v) for v in nvec]
+                if len(row) == len(nv):
+                    if any(not (float(v).is_integer() and 0 <= v < n) for v, n in zip(row, nv)):
+                        raise ValueError(f"action_delay_reset {row} is not an element of {space}")
+                    row = [row[0] + nv[0] * row[1]]
+                elif not (len(row) == 1 and float(row[0]).is_integer() and 0 <= row[0] < int(np.prod(nv))):
+                    raise ValueError(f"action_delay_reset {row} is neither an element of {space} nor a flat index below {int(np.prod(nv))}")
+            elif hasattr(space, "n"):  # Discrete(n)
+                if not (len(row) == 1 and float(row[0]).is_integer() and 0 <= row[0] < int(space.n)):
+                    raise ValueError(f"action_delay_reset {row} is not an element of {space}")
+            else:  # Box: exact length, inside the bounds
+                lo, hi = np.asarray(space.low, dtype=float).ravel(), np.asarray(space.high, dtype=float).ravel()
+                if self._action_frame == "dq_processor":  # the DeadTimeProcessor sits INSIDE the dq processor: it wraps the abc system
+                    n_abc = 4 if self._SYSTEM_KIND == _lib.SYS_EESM else 3  # duty cycles (u_a, u_b, u_c[, u_e]) in [-1, 1]
+                    lo, hi = -np.ones(n_abc), np.ones(n_abc)
+                if len(row) != len(lo) or any(not (l <= v <= h_) for v, l, h_ in zip(row, lo, hi)):
+                    raise ValueError(f"action_delay_reset {row} is not an element of {space} (length {len(lo)}, bounds [{lo.min()}, {hi.max()}])")
             for i, v in enumerate(row):
                 cfg.action_delay_reset[i] = float(v)
         if self._action_frame != "abc":
@@ -642,7 +660,8 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         a = action_buffer
         if not (torch.is_tensor(a) and a.device == self._tdev and a.is_contiguous() and a.dtype is self._want_dtype and a.numel() == self._act_numel):
             raise ValueError(f"bind_step needs a contiguous {self._want_dtype} tensor of {self._act_numel} elements on {self._tdev}")
-        st = (stream if stream is not None else torch.cuda.current_stream(self._tdev)).cuda_stream
+        stream = stream if stream is not None else torch.cuda.current_stream(self._tdev)  # (the Stream OBJECT is kept: its raw handle must not dangle)
+        st = stream.cuda_stream
         call, check, obs = self._gemx_step, _lib.check, self._obs
         args = (C.c_void_p(a.data_ptr()), C.c_void_p(self._obs_ptr), C.c_void_p(self._done_ptr), C.c_void_p(st))
         keep = (a, stream)  # the buffers behind the raw pointers stay alive as long as the stepper does
@@ -676,10 +695,11 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             raise ValueError(f"bind_rollout: obs_out must be a contiguous {self._tdtype} tensor of shape {oshape} on {self._tdev}")
         if not (torch.is_tensor(done_out) and tuple(done_out.shape) == dshape and done_out.is_contiguous() and done_out.dtype == torch.uint8 and done_out.device == self._tdev):
             raise ValueError(f"bind_rollout: done_out must be a contiguous uint8 tensor of shape {dshape} on {self._tdev}")
-        st = (stream if stream is not None else torch.cuda.current_stream(self._tdev)).cuda_stream
+        stream = stream if stream is not None else torch.cuda.current_stream(self._tdev)  # (the Stream OBJECT is kept: its raw handle must not dangle)
+        st = stream.cuda_stream
         call, check = self._L.gemx_rollout, _lib.check
         args = (C.c_void_p(a.data_ptr()), K, C.c_void_p(obs_out.data_ptr()), C.c_void_p(done_out.data_ptr()), 1, C.c_void_p(st))
-        keep = (a, obs_out, done_out, stream)  # the buffers behind the raw pointers stay alive as long as the launcher does
+        keep = (a, obs_out, done_out, stream)  # the buffers and the stream behind the raw pointers stay alive as long as the launcher does
         out = (obs_out, done_out)
 
         def launch(_args=args, _call=call, _keep=keep):
