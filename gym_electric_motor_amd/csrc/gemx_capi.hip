@@ -94,6 +94,7 @@ __global__ void reset_kernel(R *state, typename Angle<R>::T *angle, const uint8_
         state[(int64_t)nd * N + env] = P.u_sup;
         state[(int64_t)(nd + 1) * N + env] = R(0);
     }
+    if (P.adaptive) state[(int64_t)(nd + 2) * N + env] = R(0);  // error-controlled solver: no step-size prediction at the start of an episode
     // DeadTimeProcessor.reset (dead_time_processor.py:63-72): the deque is refilled with the reset action (zeros unless the handle
     // carries a custom one: one byte = a discrete index, else ring_row_bytes / sizeof(R) continuous entries)
     for (int d = 0; d < P.delay; ++d) {
@@ -374,7 +375,7 @@ constexpr uint32_t AUX_MAGIC = 0x55415847u;  // "GXAU"
 static size_t pad16(size_t b) { return (b + 15) & ~(size_t)15; }
 static void aux_sections(const gemx_handle *h, size_t &rc_b, size_t &ring_b, size_t &rcnt_b, size_t &ang_b) {
     const size_t es = h->cfg.dtype == GEMX_F64 ? 8 : 4;
-    rc_b = h->cfg.supply_kind == GEMX_SUPPLY_RC ? 2 * (size_t)h->n * es : 0;
+    rc_b = (size_t)h->extra_rows * (size_t)h->n * es;  // RC supply rows and / or the error-controlled solver's carried step size
     ring_b = h->ring != nullptr ? h->ring_bytes : 0;
     rcnt_b = h->rcnt != nullptr ? sizeof(uint32_t) * (size_t)h->n : 0;
     ang_b = h->has_angle && h->angle != nullptr ? es * (size_t)h->n : 0;
@@ -623,7 +624,12 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
 
     const size_t es = (size_t)elem_size(h);
     auto cleanup = [&](int code) { gemx_destroy(h); return code; };
-    if (hipMalloc(&h->state, es * (h->nd + (cfg->supply_kind == GEMX_SUPPLY_RC ? 2 : 0)) * (size_t)h->n) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(state) failed"));
+    // rows: the ODE states | RCVoltageSupply: capacitor voltage, time since its last update (rows nd, nd + 1) | error-controlled solver: the carried
+    // step size (row nd + 2, whether or not the two before it are in use)
+    h->extra_rows = (cfg->solver_flags & GEMX_SOLVER_ADAPTIVE) ? 3 : (cfg->supply_kind == GEMX_SUPPLY_RC ? 2 : 0);
+    if (hipMalloc(&h->state, es * (h->nd + h->extra_rows) * (size_t)h->n) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(state) failed"));
+    if (h->extra_rows && hipMemset((char *)h->state + es * (size_t)h->nd * (size_t)h->n, 0, es * (size_t)h->extra_rows * (size_t)h->n) != hipSuccess)
+        return cleanup(fail(GEMX_ERR_DEVICE, "hipMemset failed"));
     if (h->has_angle && hipMalloc(&h->angle, (cfg->dtype == GEMX_F64 ? 8 : 4) * (size_t)h->n) != hipSuccess)
         return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(angle) failed"));
     if (hipMalloc((void **)&h->sw, (size_t)h->n * h->sw_rows) != hipSuccess) return cleanup(fail(GEMX_ERR_ALLOC, "hipMalloc(sw) failed"));

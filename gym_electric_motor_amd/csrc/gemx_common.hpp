@@ -478,7 +478,8 @@ struct gemx_handle {
     int nd, nout, nact, has_angle;
     gemx::DevParams<float> pf;
     gemx::DevParams<double> pd;
-    void *state = nullptr;   // [nd][n] R
+    void *state = nullptr;   // [nd + extra_rows][n] R
+    int extra_rows = 0;      // rows behind the ODE states: RC supply (2) / + the error-controlled solver's carried step size (3)
     void *angle = nullptr;   // [n] int32 | double
     uint8_t *sw = nullptr;   // [sw_rows][n]
     int sw_rows = 1;

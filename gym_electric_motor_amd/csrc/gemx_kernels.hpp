@@ -256,20 +256,32 @@ __device__ __forceinline__ R rk_step(R (&z)[NZ], R h, F &&rhs) {
 // 4th-order solution, norm sqrt(mean((err_i / (atol + rtol max(|y_i|, |y_i new|)))^2)), step accepted iff <= 1, next step
 // h * clamp(0.9 err^-1/5, 0.2, 10)), restated for a lock-stepped wave: every lane tries the whole segment first and cuts it where ITS
 // estimate demands; the wave iterates until its last lane is through, lanes that are done ride along with h = 0 (z + 0 k = z).  The
-// first stage of a sub-step is the last of the one before (FSAL), so an accepted sub-step costs six right-hand sides.  Differences to
-// scipy's code, none of which the tolerance depends on: the step size is not carried from one control step to the next (a control step
-// is tried whole), no PI term in the step-size rule, and a floor of hs / 1024 under which a step is taken as it is and bit
-// GEMX_ERRFLAG_TOLERANCE of the handle's error word is raised.  Returns the integral of z[0] over the segment (for the angle).
+// first stage of a sub-step is the last of the one before (FSAL), so an accepted sub-step costs six right-hand sides.  The step size IS
+// carried from one control step to the next, per env, as DOPRI5 does (it stores the controller's proposal back into WORK(7);
+// solvers.py:139-184 never clears it except through set_initial_value() = reset) -- round 5: a wave used to try every control step whole,
+// and since some lane of 64 rejects that almost every time under random actions, every step cost the wave one wasted attempt (three attempts
+// where two do).  *hc = the largest step the controller proposed after an accepted sub-step of the previous segment (0: none yet -- a fresh
+// episode tries the segment whole); the segment is cut into ceil(hs / *hc) equal first tries.  Differences to scipy's code, none of which
+// the tolerance depends on: equal first tries instead of proposal-sized ones with a sliver at the end, no PI term in the step-size rule,
+// and a floor of hs / 1024 under which a step is taken as it is and bit GEMX_ERRFLAG_TOLERANCE of the handle's error word is raised.
+// Returns the integral of z[0] over the segment (for the angle).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float pow_m01(float x) { return __builtin_amdgcn_exp2f(-0.1f * __builtin_amdgcn_logf(x)); }  // x^-0.1, x > 0
 __device__ __forceinline__ double pow_m01(double x) { return pow(x, -0.1); }
 __device__ __forceinline__ float rcp_r(float x) { return __builtin_amdgcn_rcpf(x); }  // V_RCP_F32, 1 ulp: the error norm is compared with 1
 __device__ __forceinline__ double rcp_r(double x) { return 1.0 / x; }
+// first try of a segment of length hs with the carried proposal hc: hs / ceil(hs / hc), the whole segment without a proposal
+template <class R> __device__ __forceinline__ R dp5_first_try(R hs, const R *hc) {
+    // (the proposal carries the controller's safety factor 0.9: a sub-step of proposal / 0.9 is the largest the last estimate would have let pass)
+    if (hc == nullptr || !(*hc > R(0)) || !(*hc < R(0.9) * hs)) return hs;
+    const R n = fmin(ceil(R(0.9) * hs / *hc), R(1024));
+    return hs / n;
+}
 template <int NZ, class R, class F>
-__device__ __forceinline__ R dp5_adaptive(const DevParams<R> &P, R (&z)[NZ], R hs, F &&rhs) {
+__device__ __forceinline__ R dp5_adaptive(const DevParams<R> &P, R (&z)[NZ], R hs, F &&rhs, R *hc = nullptr) {
     R k1[NZ];
     rhs(z, k1);
-    R t = R(0), h = hs, integral = R(0);
+    R t = R(0), h = dp5_first_try<R>(hs, hc), integral = R(0), hprop = R(0);
     const R hmin = hs * R(1.0 / 1024.0);
     bool gave_up = false;
 #pragma nounroll
@@ -331,8 +343,10 @@ __device__ __forceinline__ R dp5_adaptive(const DevParams<R> &P, R (&z)[NZ], R h
         integral += accept ? hh * q : R(0);
         t = accept ? (fin ? hs : t + hh) : t;
         h = active ? fmax(hh * fac, hmin) : h;
+        hprop = accept ? fmax(hprop, h) : hprop;  // (the controller's proposal after an accepted sub-step)
     }
     if (gave_up && P.errw != nullptr) atomicOr(P.errw, (uint32_t)GEMX_ERRFLAG_TOLERANCE);
+    if (hc != nullptr) *hc = hprop;
     return integral;
 }
 
@@ -576,6 +590,81 @@ __device__ __forceinline__ float integrate_pk(const DevParams<float> &P, float (
     return deps;
 }
 
+// dp5_adaptive on PkVec (three-phase machines, fp32, dynamic omega): the same controller, the stages and the error estimate on pairs
+template <int SYS>
+__device__ __forceinline__ float dp5_adaptive_pk(const DevParams<float> &P, float (&y)[SysTraits<SYS>::ND], const float (&u)[MAX_U], float hs, float *hc) {
+    constexpr int NP = pk_pairs<SYS>(), NZ = 1 + 2 * NP;
+    using V = PkVec<NP>;
+    const PkElec<SYS> E(P, u);
+    V z, k1;
+    z.w = y[0];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) z.p[j] = f2_t{y[1 + 2 * j], y[2 + 2 * j]};
+    auto rhs = [&](const V &zz, V &dz) { dz.w = poly_load_ode<float>(P, zz.w, E.rhs(P, zz, dz)); };
+    rhs(z, k1);
+    float t = 0.0f, h = dp5_first_try<float>(hs, hc), integral = 0.0f, hprop = 0.0f;
+    const float hmin = hs * (1.0f / 1024.0f);
+    bool gave_up = false;
+#pragma nounroll
+    for (int guard = 0; guard < 4096; ++guard) {
+        const bool active = t < hs;
+        if (!__any(active)) break;
+        const bool fin = !(h < hs - t);
+        const float hh = active ? (fin ? hs - t : h) : 0.0f;
+        V k2, k3, k4, k5, k6, k7, zt, zn;
+        float q = (float)(35.0 / 384.0) * z.w;
+        zt = pk_axpy(z, hh, pk_scale((float)(1.0 / 5.0), k1));
+        rhs(zt, k2);
+        zt = pk_axpy(z, hh, pk_acc(pk_scale((float)(3.0 / 40.0), k1), (float)(9.0 / 40.0), k2));
+        rhs(zt, k3);
+        q += (float)(500.0 / 1113.0) * zt.w;
+        zt = pk_axpy(z, hh, pk_acc(pk_acc(pk_scale((float)(44.0 / 45.0), k1), -(float)(56.0 / 15.0), k2), (float)(32.0 / 9.0), k3));
+        rhs(zt, k4);
+        q += (float)(125.0 / 192.0) * zt.w;
+        zt = pk_axpy(z, hh, pk_acc(pk_acc(pk_acc(pk_scale((float)(19372.0 / 6561.0), k1), -(float)(25360.0 / 2187.0), k2), (float)(64448.0 / 6561.0), k3),
+                                   -(float)(212.0 / 729.0), k4));
+        rhs(zt, k5);
+        q -= (float)(2187.0 / 6784.0) * zt.w;
+        zt = pk_axpy(z, hh, pk_acc(pk_acc(pk_acc(pk_acc(pk_scale((float)(9017.0 / 3168.0), k1), -(float)(355.0 / 33.0), k2), (float)(46732.0 / 5247.0), k3),
+                                          (float)(49.0 / 176.0), k4), -(float)(5103.0 / 18656.0), k5));
+        rhs(zt, k6);
+        q += (float)(11.0 / 84.0) * zt.w;
+        zn = pk_axpy(z, hh, pk_acc(pk_acc(pk_acc(pk_acc(pk_scale((float)(35.0 / 384.0), k1), (float)(500.0 / 1113.0), k3), (float)(125.0 / 192.0), k4),
+                                          -(float)(2187.0 / 6784.0), k5), (float)(11.0 / 84.0), k6));
+        rhs(zn, k7);
+        // error estimate hh (e1 k1 + e3 k3 + e4 k4 + e5 k5 + e6 k6 + e7 k7), scaled per component by atol + rtol max(|z|, |z new|)
+        const V er = pk_scale(hh, pk_acc(pk_acc(pk_acc(pk_acc(pk_acc(pk_scale((float)(71.0 / 57600.0), k1), -(float)(71.0 / 16695.0), k3), (float)(71.0 / 1920.0), k4),
+                                                        -(float)(17253.0 / 339200.0), k5), (float)(22.0 / 525.0), k6), -(float)(1.0 / 40.0), k7));
+        auto sq = [&](float e, float a0, float a1) { const float r = e * rcp_r(P.atol + P.rtol * fmaxf(fabsf(a0), fabsf(a1))); return r * r; };
+        float e2 = sq(er.w, z.w, zn.w);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) e2 += sq(er.p[j].x, z.p[j].x, zn.p[j].x) + sq(er.p[j].y, z.p[j].y, zn.p[j].y);
+        const float en2 = e2 * (1.0f / NZ);
+        const bool floor_hit = !(hh > hmin);
+        const bool accept = active && (!(en2 > 1.0f) || floor_hit);
+        gave_up |= active && floor_hit && en2 > 1.0f;
+        float fac = en2 > 1e-20f ? 0.9f * pow_m01(en2) : 10.0f;
+        fac = fminf(fmaxf(fac, 0.2f), accept ? 10.0f : 1.0f);
+        z.w = accept ? zn.w : z.w;
+        k1.w = accept ? k7.w : k1.w;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            z.p[j] = accept ? zn.p[j] : z.p[j];
+            k1.p[j] = accept ? k7.p[j] : k1.p[j];
+        }
+        integral += accept ? hh * q : 0.0f;
+        t = accept ? (fin ? hs : t + hh) : t;
+        h = active ? fmaxf(hh * fac, hmin) : h;
+        hprop = accept ? fmaxf(hprop, h) : hprop;
+    }
+    if (gave_up && P.errw != nullptr) atomicOr(P.errw, (uint32_t)GEMX_ERRFLAG_TOLERANCE);
+    if (hc != nullptr) *hc = hprop;
+    y[0] = z.w;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) { y[1 + 2 * j] = z.p[j].x; y[2 + 2 * j] = z.p[j].y; }
+    return integral;
+}
+
 // ------------------------------------------------------------------------------------------------
 // integrate one segment of length h with `nsteps` sub-steps (EulerSolver(nsteps), solvers.py:103-122).
 // y = [omega, motor states].  Returns the angle increment  pole * int(omega dt)  of the scheme.
@@ -589,7 +678,8 @@ __device__ __forceinline__ float integrate_pk(const DevParams<float> &P, float (
 // converter dead time a step may be cut at the switching instant (converters.py:302-310): 1 = FIRST segment, of length t_il in the lanes
 // with a switching leg (`two`) and tau in the others (per-lane select of the coefficients), 2 = the rest, tau - t_il.
 template <int SYS, int LOAD, int SOLVER, class R, bool NS1 = false, bool LIN = false, int SEG = 0>
-__device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<SYS>::ND], const R (&u)[MAX_U], R h, const R *linr = nullptr, bool two = false) {
+__device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<SYS>::ND], const R (&u)[MAX_U], R h, const R *linr = nullptr, bool two = false,
+                                       R *hc = nullptr) {  // hc: the error-controlled solver's step size carried between control steps (dp5_adaptive)
     using E = Elec<SYS, R>;
     constexpr int NM = E::NM;
     const int ns = NS1 ? 1 : P.nsteps;     // NS1: the caller guarantees solver_nsteps == 1 (branch-free code)
@@ -664,7 +754,7 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
         for (int i = 0; i < NM; ++i) x[i] = y[1 + i];
         auto rhs = [&](const R (&xx)[NM], R (&dx)[NM]) { E::f(P, pre, xx, dx); };
         if (SOLVER == GEMX_SOLVER_DP5 && P.adaptive) {
-            dp5_adaptive<NM, R>(P, x, h, rhs);
+            dp5_adaptive<NM, R>(P, x, h, rhs, hc);
         } else if (NS1 || ns == 1) {
             rk_step<SOLVER, NM, R>(x, hs, rhs);
         } else {
@@ -677,6 +767,7 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
         if constexpr (sizeof(R) == 4 && pk_pairs<SYS>() > 0 && GEMX_PACKED_RHS) {
             // fp32, three-phase machine: the packed form of the same schemes (see PkElec); error control keeps the array code
             if (!(SOLVER == GEMX_SOLVER_DP5 && P.adaptive)) return integrate_pk<SYS, SOLVER, NS1>(P, y, u, hs, ns);
+            if constexpr (SOLVER == GEMX_SOLVER_DP5) return P.pole * dp5_adaptive_pk<SYS>(P, y, u, h, hc);
         }
         // SCMLSystem._system_equation (physical_systems.py:205-236): [load derivative, motor derivative]
         auto rhs = [&](const R (&z)[NM + 1], R (&dz)[NM + 1]) {
@@ -689,7 +780,7 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
 #pragma unroll
             for (int i = 0; i < NM; ++i) dz[1 + i] = dx[i];
         };
-        if (SOLVER == GEMX_SOLVER_DP5 && P.adaptive) return P.pole * dp5_adaptive<NM + 1, R>(P, y, h, rhs);
+        if (SOLVER == GEMX_SOLVER_DP5 && P.adaptive) return P.pole * dp5_adaptive<NM + 1, R>(P, y, h, rhs, hc);
         if (!P.kink_split) {
             R wsum = R(0);
             if (NS1 || ns == 1) {
@@ -991,7 +1082,7 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
     }
     template <bool NS1 = false, bool LIN = false, bool TAB = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[ND], AngT &, uint32_t &sw, const R (&act)[MAX_ACT], uint32_t dact,
-                                                   R (&ho)[NH], const R * = nullptr, const R *linr = nullptr) {
+                                                   R (&ho)[NH], const R * = nullptr, const R *linr = nullptr, R *hc = nullptr) {
         R u[MAX_U] = {R(0), R(0), R(0), R(0)};
         if (CONT) {
 #pragma unroll
@@ -1003,7 +1094,7 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
             }
             // (one segment; the dead-time instantiations' registers hold maps 1..3, so they name the whole step as `first segment, no
             // switching leg`: integrate<..., SEG = 1>(two = false) takes the tau map among them)
-            integrate<SYS, LOAD, SOLVER, R, NS1, LIN, IL ? 1 : 0>(P, y, u, P.tau, linr, false);
+            integrate<SYS, LOAD, SOLVER, R, NS1, LIN, IL ? 1 : 0>(P, y, u, P.tau, linr, false, hc);
         } else {  // Finite-4QC: action -> (leg0, leg1) sub-actions [1,1,2,2] / [1,2,1,2] (converters.py:360-361)
             uint32_t legs = 0;
 #pragma unroll
@@ -1031,7 +1122,7 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> struct DcSt
                     }
                     u[j] = (v0 - v1) * P.u_sup;
                 }
-                integrate<SYS, LOAD, SOLVER, R, NS1, LIN, decltype(seg_tag)::value>(P, y, u, h, linr, two);
+                integrate<SYS, LOAD, SOLVER, R, NS1, LIN, decltype(seg_tag)::value>(P, y, u, h, linr, two, hc);
             };
             if (IL) {
                 segment(two ? P.t_il : P.tau, std::integral_constant<int, 1>{});
@@ -1106,7 +1197,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     }
     template <bool NS1 = false, bool LIN = false, bool TAB = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[3], AngT &ang, uint32_t &sw, const R (&act)[MAX_ACT],
-                                                   uint32_t dact, R (&ho)[NH], const R *tab = nullptr, const R *linr = nullptr) {
+                                                   uint32_t dact, R (&ho)[NH], const R *tab = nullptr, const R *linr = nullptr, R *hc = nullptr) {
         R s, c;
         Angle<R>::sincos(ang, s, c);
         uint32_t legs = 0;
@@ -1132,7 +1223,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             }
             u[0] = c * ual + s * ube;  // Q^-1(., eps): u_dq frozen at the segment-start angle (line 501/511)
             u[1] = -s * ual + c * ube;
-            const R deps = integrate<GEMX_SYS_SYNC, LOAD, SOLVER, R, NS1, LIN, decltype(seg_tag)::value>(P, y, u, h, linr, two);
+            const R deps = integrate<GEMX_SYS_SYNC, LOAD, SOLVER, R, NS1, LIN, decltype(seg_tag)::value>(P, y, u, h, linr, two, hc);
             ang = advance_angle<R, LIN, decltype(seg_tag)::value>(P, ang, deps, two);
         };
         if (IL) {
@@ -1207,7 +1298,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     }
     template <bool NS1 = false, bool LIN = false, bool TAB = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[4], AngT &ang, uint32_t &, const R (&act)[MAX_ACT],
-                                                   uint32_t dact, R (&ho)[NH], const R *tab = nullptr, const R *linr = nullptr) {
+                                                   uint32_t dact, R (&ho)[NH], const R *tab = nullptr, const R *linr = nullptr, R *hc = nullptr) {
         R s, c;
         Angle<R>::sincos(ang, s, c);
         R ua, ub, uc, ue, u[MAX_U] = {R(0), R(0), R(0), R(0)};
@@ -1221,7 +1312,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
         u[0] = c * ual + s * ube;  // Q^-1(., eps) at the step-start angle (line 643)
         u[1] = -s * ual + c * ube;
         u[2] = ue;
-        const R deps = integrate<GEMX_SYS_EESM, LOAD, SOLVER, R, NS1, LIN, IL ? 1 : 0>(P, y, u, P.tau, linr, false);  // (see DcStepper: one segment, the tau map)
+        const R deps = integrate<GEMX_SYS_EESM, LOAD, SOLVER, R, NS1, LIN, IL ? 1 : 0>(P, y, u, P.tau, linr, false, hc);  // (see DcStepper: one segment, the tau map)
         ang = Angle<R>::advance(ang, deps);
         ho[0] = s; ho[1] = c; ho[2] = ua; ho[3] = ub; ho[4] = uc; ho[5] = ue;
     }
@@ -1280,7 +1371,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     static __device__ __forceinline__ void field_angle(R pa, R pb, R &s, R &c) { flux_angle<R>(pa, pb, s, c); }
     template <bool NS1 = false, bool LIN = false, bool TAB = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[5], AngT &ang, uint32_t &sw, const R (&act)[MAX_ACT],
-                                                   uint32_t dact, R (&ho)[NH], const R *tab = nullptr, const R *linr = nullptr) {
+                                                   uint32_t dact, R (&ho)[NH], const R *tab = nullptr, const R *linr = nullptr, R *hc = nullptr) {
         R s, c;
         field_angle(y[3], y[4], s, c);
         uint32_t legs = 0;
@@ -1300,7 +1391,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
                 b6_voltages<CONV, IL, R>(P, act, dact, legs, ia, ib, ic, ua, ub, uc);
                 t23(ua, ub, uc, u[0], u[1]);  // u_alphabeta constant over the segment (line 788/799)
             }
-            const R deps = integrate<GEMX_SYS_SCIM, LOAD, SOLVER, R, NS1, LIN, decltype(seg_tag)::value>(P, y, u, h, linr, two);
+            const R deps = integrate<GEMX_SYS_SCIM, LOAD, SOLVER, R, NS1, LIN, decltype(seg_tag)::value>(P, y, u, h, linr, two, hc);
             ang = advance_angle<R, LIN, decltype(seg_tag)::value>(P, ang, deps, two);
         };
         if (IL) {
@@ -1362,7 +1453,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
     static constexpr int B6 = CONV == GEMX_CONV_CONT_2XB6 ? GEMX_CONV_CONT_B6 : GEMX_CONV_FINITE_B6;
     template <bool NS1 = false, bool LIN = false, bool TAB = false>
     static __device__ __forceinline__ void advance(const DevParams<R> &P, R (&y)[5], AngT &ang, uint32_t &sw, const R (&act)[MAX_ACT],
-                                                   uint32_t dact, R (&ho)[NH], const R * = nullptr, const R *linr = nullptr) {
+                                                   uint32_t dact, R (&ho)[NH], const R * = nullptr, const R *linr = nullptr, R *hc = nullptr) {
         R sf, cf, se, ce;
         SC::field_angle(y[3], y[4], sf, cf);
         Angle<R>::sincos_precise(ang, se, ce);
@@ -1388,7 +1479,7 @@ template <int CONV, int LOAD, int SOLVER, bool IL, class R> struct Stepper<GEMX_
             t23(urd, ure, urf, urg, urh);
             u[2] = ce * urg - se * urh;
             u[3] = se * urg + ce * urh;
-            const R deps = integrate<GEMX_SYS_DFIM, LOAD, SOLVER, R, NS1, LIN, decltype(seg_tag)::value>(P, y, u, h, linr, two);
+            const R deps = integrate<GEMX_SYS_DFIM, LOAD, SOLVER, R, NS1, LIN, decltype(seg_tag)::value>(P, y, u, h, linr, two, hc);
             ang = advance_angle<R, LIN, decltype(seg_tag)::value>(P, ang, deps, two);
         };
         if (IL) {
@@ -1532,9 +1623,9 @@ __device__ __forceinline__ void draw_initial_state_cnt(const InitDev *rinit, int
 // step() for the single-wave kernel
 template <class ST, int ND, int NOUT, class R, bool LIN = false>
 __device__ __forceinline__ void full_step(const DevParams<R> &P, R (&y)[ND], typename Angle<R>::T &ang, uint32_t &sw, const R (&act)[MAX_ACT],
-                                          uint32_t dact, R (&obs)[NOUT], const R *linr = nullptr) {
+                                          uint32_t dact, R (&obs)[NOUT], const R *linr = nullptr, R *hc = nullptr) {
     R ho[ST::NH];
-    ST::template advance<false, LIN>(P, y, ang, sw, act, dact, ho, nullptr, linr);
+    ST::template advance<false, LIN>(P, y, ang, sw, act, dact, ho, nullptr, linr, hc);
     ST::observe(P, y, ang, ho, obs);
 }
 // instantiations whose electrical subsystem can be stepped by the precomputed one-step map (see integrate<..., LIN>).  Euler: only the
@@ -1899,7 +1990,7 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
                                               R (&obs)[SysTraits<SYS>::NOUT], uint32_t &done_or, uint32_t &bad_action, R *ring,
                                               const unsigned char *atile, unsigned char *donebuf, int k0, int sb, int tid,
                                               int64_t e, typename Angle<R>::T init_ang, R *fifo, int &slot, R (&sup)[2], bool lin_ok,
-                                              const R (&linc)[lin_regs<SYS, R, IL>()]) {
+                                              const R (&linc)[lin_regs<SYS, R, IL>()], R &hcar) {
     constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
     constexpr bool DISCRETE = ConvTraits<CONV>::DISCRETE;
     constexpr int ABYTES = DISCRETE ? 1 : NACT * (int)sizeof(R);
@@ -1976,7 +2067,7 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
             PL.u_sup = sup[0];
         }
         if (linable<SYS, LOAD, SOLVER, IL, R>() && lin_ok) full_step<ST, ND, NOUT, R, linable<SYS, LOAD, SOLVER, IL, R>()>(PL, y, ang, sw, act, dact, obs, linc);
-        else full_step<ST, ND, NOUT, R, false>(PL, y, ang, sw, act, dact, obs);
+        else full_step<ST, ND, NOUT, R, false>(PL, y, ang, sw, act, dact, obs, nullptr, &hcar);
         if (!IL && conv_has_legs<CONV>() && P.rc_supply) sw = ST::legs_of(dact);  // (the IL code keeps `sw` itself)
         const bool done = constraint_done<ST, NOUT, R>(P, obs);
         done_or |= done ? 1u : 0u;
@@ -1985,6 +2076,7 @@ __device__ __forceinline__ void compute_block(const KArgs<R> &a, R (&y)[SysTrait
 #pragma unroll
             for (int j = 0; j < ND; ++j) y[j] = P.init[j];
             ang = init_ang;
+            hcar = R(0);  // (the error-controlled solver starts an episode without a step-size prediction, like set_initial_value())
             if (P.init_kind && (int64_t)blockIdx.x * BLOCK + tid < a.N) draw_initial_state<SYS, R>(a, e, y, ang);  // (not the clamped tail lanes)
             sup[0] = P.u_sup;  // RCVoltageSupply.reset: the capacitor is loaded again, the supply's clock restarts
             sup[1] = R(0);
@@ -2075,6 +2167,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SYS == GE
         sup[0] = a.state[(int64_t)ND * N + e];
         sup[1] = a.state[(int64_t)(ND + 1) * N + e];
     }
+    // error-controlled solver: the step size its controller proposed last (state row ND + 2; 0 = none yet), see dp5_adaptive
+    R hcar = R(0);
+    if (SOLVER == GEMX_SOLVER_DP5 && P.adaptive) hcar = a.state[(int64_t)(ND + 2) * N + e];
     for (int d = 0; d < P.delay; ++d) {  // this lane's FIFO entries (only this lane ever touches them)
 #pragma unroll
         for (int i = 0; i < NACTC; ++i) {
@@ -2138,8 +2233,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SYS == GE
 
         // 2. compute: no global memory traffic in here when coop
         const unsigned char *atile = actbuf + (size_t)half * S * ROWB;
-        if (coop) compute_block<true, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot, sup, lin_ok, linc);
-        else compute_block<false, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot, sup, lin_ok, linc);
+        if (coop) compute_block<true, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot, sup, lin_ok, linc, hcar);
+        else compute_block<false, SYS, CONV, LOAD, SOLVER, IL, R>(a, y, ang, sw, obs, done_or, bad_action, ring, atile, donebuf, k0, sb, tid, e, init_ang, fifo, slot, sup, lin_ok, linc, hcar);
         __syncthreads();
 #ifdef GEMX_TIMING
         if (k0 == 0) pT2 = clock64();
@@ -2180,6 +2275,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SYS == GE
             a.state[(int64_t)ND * N + env] = sup[0];
             a.state[(int64_t)(ND + 1) * N + env] = sup[1];
         }
+        if (SOLVER == GEMX_SOLVER_DP5 && P.adaptive) a.state[(int64_t)(ND + 2) * N + env] = hcar;
         for (int d = 0; d < P.delay; ++d) {
 #pragma unroll
             for (int i = 0; i < NACTC; ++i) {
@@ -2244,6 +2340,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs<R> a) {
         sup[0] = a.state[(int64_t)ND * N + e];
         sup[1] = a.state[(int64_t)(ND + 1) * N + e];
     }
+    R hcar = R(0);  // error-controlled solver: carried step size (state row ND + 2)
+    if (SOLVER == GEMX_SOLVER_DP5 && P.adaptive) hcar = a.state[(int64_t)(ND + 2) * N + e];
     R act[MAX_ACT];
 #pragma unroll
     for (int i = 0; i < MAX_ACT; ++i) act[i] = R(0);
@@ -2292,13 +2390,14 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs<R> a) {
     }
     R obs[NOUT];
     if (linable<SYS, LOAD, SOLVER, IL, R>() && lin_ok) full_step<ST, ND, NOUT, R, linable<SYS, LOAD, SOLVER, IL, R>()>(PL, y, ang, sw, act, dact, obs);
-    else full_step<ST, ND, NOUT, R, false>(PL, y, ang, sw, act, dact, obs);
+    else full_step<ST, ND, NOUT, R, false>(PL, y, ang, sw, act, dact, obs, nullptr, &hcar);
     if (!IL && conv_has_legs<CONV>() && P.rc_supply) sw = ST::legs_of(dact);
     const bool done = constraint_done<ST, NOUT, R>(P, obs);
     if (done && P.auto_reset) {  // `if terminated: env.reset()`; switching state survives (converters.py:45-54)
 #pragma unroll
         for (int j = 0; j < ND; ++j) y[j] = P.init[j];
         ang = init_ang;
+        hcar = R(0);
         if (P.init_kind && valid) draw_initial_state<SYS, R>(a, e, y, ang);
         sup[0] = P.u_sup;
         sup[1] = R(0);
@@ -2348,6 +2447,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs<R> a) {
             a.state[(int64_t)ND * N + env] = sup[0];
             a.state[(int64_t)(ND + 1) * N + env] = sup[1];
         }
+        if (SOLVER == GEMX_SOLVER_DP5 && P.adaptive) a.state[(int64_t)(ND + 2) * N + env] = hcar;
         if (bad_action) atomicOr(a.err, 1u);
     }
     fifo_phase_advance(a, ring_phase, threadIdx.x == 0);
@@ -2551,6 +2651,8 @@ void advance_pipe_kernel(const KArgs<R> a) {
             }
             if (P.init_kind) rcount = a.rcnt[envc];
         }
+        R hcar = R(0);  // error-controlled solver: the step size its controller proposed last (state row ND + 2), see dp5_adaptive
+        if (SOLVER == GEMX_SOLVER_DP5 && P.adaptive) hcar = a.state[(int64_t)(ND + 2) * N + envc];
         constexpr bool LINABLE = linable<SYS, LOAD, SOLVER, IL, R>();
         const bool lin_ok = lin_usable<SYS, LOAD, SOLVER, IL, R>(P, y[0]);  // wave-uniform
         // DeadTimeProcessor, two representations of the same queue (both leave the same [delay][N] ring in HBM):
@@ -2671,10 +2773,10 @@ void advance_pipe_kernel(const KArgs<R> a) {
             // launcher guarantees solver_nsteps == 1; LINABLE instantiations take the one-step map whenever it is valid for this wave
             auto run_advance = [&](const DevParams<R> &Q) {
                 if constexpr (TAB) {
-                    ST::template advance<true, LINABLE, true>(Q, y, ang, sw, act, dact, ho, tab, linc);
+                    ST::template advance<true, LINABLE, true>(Q, y, ang, sw, act, dact, ho, tab, linc, &hcar);
                 } else {
                     if (LINABLE && (!FIFO || lin_ok)) ST::template advance<true, LINABLE>(Q, y, ang, sw, act, dact, ho, nullptr, linc);
-                    else ST::template advance<true, false>(Q, y, ang, sw, act, dact, ho);
+                    else ST::template advance<true, false>(Q, y, ang, sw, act, dact, ho, nullptr, nullptr, &hcar);
                 }
             };
             R usup_lane = P.u_sup;
@@ -2726,6 +2828,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
 #pragma unroll
             for (int j = OMEGA_FIXED ? 1 : 0; j < ND; ++j) y[j] = rs ? init_v[j] : y[j];
             ang = rs ? init_ang_v : ang;
+            if constexpr (SOLVER == GEMX_SOLVER_DP5) hcar = rs ? R(0) : hcar;
             if constexpr (FULL) {
                 if (rs && P.init_kind) draw_initial_state_cnt<SYS, R>(a.rinit, envc, rcount, y, ang);  // (rare: exec-masked, skipped wave-wide)
                 sup[0] = rs ? P.u_sup : sup[0];  // RCVoltageSupply.reset: the capacitor is loaded again, the supply's clock restarts
@@ -3016,6 +3119,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
                 }
                 if (P.init_kind) a.rcnt[env] = rcount;
             }
+            if (SOLVER == GEMX_SOLVER_DP5 && P.adaptive) a.state[(int64_t)(ND + 2) * N + env] = hcar;
             int phase_end = 0;
             if (P.delay > 0) phase_end = (ring_phase + K) % P.delay;
             for (int d = 0; d < P.delay; ++d) {
@@ -4052,9 +4156,9 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                 if (kp == nullptr) return 0;  // (a shape that is not built holds no workgroup)
                 int nb_ = 0;
                 h->pipe_occ_smem[shape_] = smem_b;
-                if (!(h->pipe_attr_set & (1u << shape_))) {
-                    (void)hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max);
-                    h->pipe_attr_set |= 1u << shape_;
+                if (!(h->pipe_attr_set & (1u << shape_))) {  // (the bit only on success: the launch path then repeats the call, checked, and reports the error)
+                    if (hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max) == hipSuccess) h->pipe_attr_set |= 1u << shape_;
+                    else (void)hipGetLastError();
                 }
                 h->pipe_occ[shape_] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, kp, threads, smem_b) == hipSuccess && nb_ > 0) ? nb_ : 64;
                 (void)hipGetLastError();

@@ -1428,7 +1428,8 @@ CHECKPOINT_CASES = ["rc_pmsm_fin_til_epi_uniform_tau1e-4_euler",   # RCVoltageSu
                     "rc_permexdc_cont_free_held_euler",            # RC supply behind a continuous converter
                     "pmsm_fin_dead1_til_free_uniform_euler",       # DeadTimeProcessor queue + phase
                     "init:pmsm_sc_uniform",                        # random initialisers: per-env reset counters
-                    "pmsm_epi_held_tau1e-4_euler"]                 # nothing but ODE state (the aux blob is its header)
+                    "pmsm_epi_held_tau1e-4_euler",                 # nothing but ODE state (the aux blob is its header + the angle words)
+                    "adaptive:scim_epi_uniform_euler"]             # error-controlled solver: the carried step size of every env
 
 
 @pytest.mark.parametrize("name", CHECKPOINT_CASES)
@@ -1447,6 +1448,9 @@ def test_checkpoint_resumes_bit_for_bit(name, n):
         if name.startswith("init:"):
             env = _init_env(name[5:], nn, seed=11, ode_solver=ga.RK4Solver())[0]
             return env, None
+        if name.startswith("adaptive:"):
+            d, meta = _load(name[9:])
+            return _make_from_meta(meta, nn, solver=ga.ScipyOdeSolver(), auto_reset=True), d
         d, meta = _load(name)
         return _make_from_meta(meta, nn, auto_reset=True), d
 
