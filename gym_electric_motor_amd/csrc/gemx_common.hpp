@@ -456,6 +456,20 @@ constexpr int pipe_loader_waves(int) { return 1; }
 // 0.683, PermExDc cont 131072 x 1000 0.573 -> 0.570) while the extra LDS cost EESM cont its deep shape: profiles/r04r_probe4.txt.  The
 // loss there is the HBM serving reads between the writes, not the latency of this wave's loads.)
 constexpr int PIPE_ACT_BUFS = 2;
+// Round 5 tried once more, with a reason: a timing build at 65536 envs (<2, 2>, four workgroups per CU) shows the loader wave's trip to the
+// HBM for one block's actions taking 2500-3300 cycles, longer than the integrator's 2-step block for every machine but the induction
+// machines behind a PolynomialStaticLoad.  Two blocks ahead (GEMX_PIPE_AHEAD2=1: a third action buffer, a fourth reference buffer, the loader
+// waits with `s_waitcnt vmcnt(NSTAGE)` for the OLDER block only) takes the loader's wait from ~2800 to ~600 cycles per block -- and the
+// launch time does not move: those launches are held by the rate limiter (1620 ns per block = the measured period; the calibration finds
+// nothing faster, paced or not), i.e. by the write path, not by this latency.  Same-box A/B over six rows x three sizes: +3 % on one row
+// (Cont-SC-PMSM 65536), -14 % on another (PermExDc cont 65536: the extra buffer costs a resident workgroup), the rest within 1 %
+// (profiles/r05h_ab_loader_two_ahead.md, r05h_pipe_probe.txt).  Default off; the code stays as an A/B build.
+#ifndef GEMX_PIPE_AHEAD2  // 1: the shallow shapes (D <= 4) stage two blocks ahead (A/B builds)
+#define GEMX_PIPE_AHEAD2 0
+#endif
+constexpr int pipe_act_ahead(int D) { return (D <= 4 && GEMX_PIPE_AHEAD2) ? 2 : 1; }
+constexpr int pipe_act_bufs(int D) { return pipe_act_ahead(D) + 1; }
+constexpr int pipe_ref_bufs(int D) { return pipe_act_ahead(D) + 2; }  // (the output waves read a block's references one block behind the integrator)
 // rows of the pipelined kernel's per-lane action queue in LDS: `delay` (FIFO / carry rows), or D + delay where the queue of TRANSFORMED
 // actions behind a DqToAbcActionProcessor is kept as a row buffer indexed by the step of the block (deep shape only)
 __host__ __device__ constexpr int pipe_queue_rows(int D, int delay, bool dq_processor, bool full) {

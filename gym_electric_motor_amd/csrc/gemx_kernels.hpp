@@ -2531,13 +2531,14 @@ void advance_pipe_kernel(const KArgs<R> a) {
     // fused reward: reference rows [3][D][64 * n_ref] R, staged global -> LDS by the integrator wave one block ahead, read by the output
     // waves one block behind (hence three buffers).  The output waves thus issue NO global loads: a load would make them wait, through
     // the in-order vmcnt, for all their older observation stores once per block.
-    constexpr int ACTB_BYTES = PIPE_ACT_BUFS * ((D + 3) / 4 * 4) * BLOCK * (DISCRETE ? 1 : NACT * (int)sizeof(R));
+    constexpr int AHEAD = pipe_act_ahead(D), NBUF = pipe_act_bufs(D), NRBUF = pipe_ref_bufs(D);
+    constexpr int ACTB_BYTES = NBUF * ((D + 3) / 4 * 4) * BLOCK * (DISCRETE ? 1 : NACT * (int)sizeof(R));
     R *refb = reinterpret_cast<R *>(actb + ACTB_BYTES);
     const int n_ref = a.rw != nullptr ? a.rh.n_ref : 0;
     // per-action voltage table [NACTIONS][8] R of steppers that have one (ST::NVT > 0): written by the integrator wave before its first block, read by it and
     // (COMPACT rows, below) by the output waves
     constexpr bool USE_TAB = ST::NVT > 0 && DISCRETE && !FULL;  // (FULL: the supply voltage may differ per lane; the table is built from the uniform one)
-    R *vtab = refb + 3 * (size_t)D * BLOCK * n_ref;
+    R *vtab = refb + NRBUF * (size_t)D * BLOCK * n_ref;
     // COMPACT hand-off rows (synchronous machines behind a finite converter and a constant-speed load: the headline): the integrator's
     // time per step is dominated by its LDS instructions (~25 cycles of issue apiece against ~5 for a VALU instruction: six of them were
     // 150 of the step's 320 cycles), so the blocks that run on the voltage table and the one-step map hand over EIGHT values instead of
@@ -2562,7 +2563,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
     constexpr int U16 = ROWB / 16, NU16 = D * U16, NSTAGE = (NU16 + 63) / 64;
     auto stage_actions = [&](int b) {
         const int sb = steps_of(b);
-        unsigned char *dst = actb + (size_t)(b % PIPE_ACT_BUFS) * DP * ROWB;
+        unsigned char *dst = actb + (size_t)(b % NBUF) * DP * ROWB;
         const unsigned char *src = a.actions + ((int64_t)b * D * N + blk0) * ABYTES;
         if (!full_wg) {  // partial workgroup: this lane's own action of every row through a register; lanes beyond the batch stage zeros
             for (int s = 0; s < D; ++s) {
@@ -2595,7 +2596,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
     auto stage_refs = [&](int b) {  // rows of 64 * n_ref references, 64 consecutive dwords per instruction
         const int sb = steps_of(b);
         const int dwords = n_ref * (int)(sizeof(R) / 4);  // per env
-        R *dst = refb + (size_t)(b % 3) * D * BLOCK * n_ref;
+        R *dst = refb + (size_t)(b % NRBUF) * D * BLOCK * n_ref;
         if (!full_wg) {  // partial workgroup: lane by lane (see stage_actions)
             for (int s = 0; s < D; ++s) {
                 const int row = s < sb ? s : sb - 1;
@@ -2704,7 +2705,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
         }
 
         auto read_action = [&](int b, int s, R (&dst)[NACT], uint32_t &ddst) {
-            const unsigned char *row = actb + ((size_t)(b % PIPE_ACT_BUFS) * DP + s) * ROWB;
+            const unsigned char *row = actb + ((size_t)(b % NBUF) * DP + s) * ROWB;
             if (DISCRETE) ddst = row[tid];
             else {
 #pragma unroll
@@ -3159,20 +3160,34 @@ void advance_pipe_kernel(const KArgs<R> a) {
         // (Staging TWO blocks ahead through a third buffer was tried in round 2 -- the s_memtime probe shows this wave's loads taking longer
         // than the integrator's block in the shallow shapes -- and changed nothing, same box, over all motor families:
         // profiles/r02h_loader_depth.md; and again in round 4 for action tensors too large for the Infinity Cache: PIPE_ACT_BUFS.)
+        // ... which round 5 did for the shallow shapes after all (AHEAD = 2, see pipe_act_ahead): block b + 2 is issued, block b + 1 awaited
+        if (AHEAD == 2 && 1 < nb) {
+            stage_actions(1);
+            if (n_ref > 0) stage_refs(1);
+        }
         for (int b = 0; b < nb; ++b) {
 #ifdef GEMX_TIMING
             const unsigned long long l0 = clock64();
 #endif
-            if (b + 1 < nb) {
-                stage_actions(b + 1);
-                if (n_ref > 0) stage_refs(b + 1);
+            const bool issued = b + AHEAD < nb;
+            if (issued) {
+                stage_actions(b + AHEAD);
+                if (n_ref > 0) stage_refs(b + AHEAD);
             }
             if (DISCRETE) {
-                const unsigned char *rows = actb + (size_t)(b % PIPE_ACT_BUFS) * DP * ROWB;
+                const unsigned char *rows = actb + (size_t)(b % NBUF) * DP * ROWB;
                 const int sb = steps_of(b);
                 for (int s = 0; s < sb; ++s) bad |= (uint32_t)rows[(size_t)s * ROWB + tid] >= (uint32_t)ConvTraits<CONV>::NACTIONS;  // (lanes beyond the batch: staged as 0)
             }
-            if (b + 1 < nb) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): landed in LDS before the barrier publishes it
+            // block b + 1 has landed in LDS before the barrier publishes it.  vmcnt retires in order: with block b + 2's NSTAGE staging
+            // instructions just issued, "at most NSTAGE outstanding" is "block b + 1 complete" (fused reward: the reference rows' instruction
+            // count is a run-time value, so those launches wait for everything)
+            if (b + 1 < nb) {
+                constexpr int VM_KEEP = 0x0F70 | (NSTAGE & 0xF) | ((NSTAGE >> 4) << 14);
+                static_assert(NSTAGE < 64, "vmcnt immediate");
+                if (AHEAD == 2 && issued && n_ref == 0 && full_wg) __builtin_amdgcn_s_waitcnt(VM_KEEP);
+                else __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            }
 #ifdef GEMX_TIMING
             const unsigned long long l1 = clock64();
 #endif
@@ -3288,7 +3303,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
                 RewardRegs<R> WR;
                 WR.load(a.rh);
                 R rv[RPW][GEMX_MAX_REF];
-                const R *rb = refb + ((size_t)(pb % 3) * D + r0) * BLOCK * n_ref + (size_t)tid * n_ref;
+                const R *rb = refb + ((size_t)(pb % NRBUF) * D + r0) * BLOCK * n_ref + (size_t)tid * n_ref;
                 // unconditional loads from clamped addresses + selects: a conditional load compiles to one scalar branch per element
                 auto fetch_refs = [&](int nrr) {
 #pragma unroll
@@ -4126,8 +4141,8 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         auto smem_of = [&](int D) {
             size_t b = (size_t)D * BLOCK * h->nout * sizeof(R) + (size_t)D * BLOCK + 2 * (size_t)D * BLOCK * NHT * sizeof(R);
             b += (size_t)pipe_queue_rows(D, delay, conv_dq<CONV>() && h->pf.dq_processor != 0, need_full) * BLOCK * conv_nact_c<CONV>() * sizeof(R);  // DeadTimeProcessor queue
-            b += PIPE_ACT_BUFS * (size_t)((D + 3) / 4 * 4) * BLOCK * ABYTES;  // action staging (global -> LDS direct, one block ahead)
-            if (h->cur_reward != nullptr) b += 3 * (size_t)D * BLOCK * h->rw_n_ref * sizeof(R);  // reference staging for the fused reward
+            b += pipe_act_bufs(D) * (size_t)((D + 3) / 4 * 4) * BLOCK * ABYTES;  // action staging (global -> LDS direct, one or two blocks ahead)
+            if (h->cur_reward != nullptr) b += pipe_ref_bufs(D) * (size_t)D * BLOCK * h->rw_n_ref * sizeof(R);  // reference staging for the fused reward
             if (ST::NVT > 0 && ConvTraits<CONV>::DISCRETE) b += (size_t)ConvTraits<CONV>::NACTIONS * 8 * sizeof(R);  // per-action voltage table
             return (b + 15) & ~(size_t)15;
         };
