@@ -533,7 +533,7 @@ struct gemx_handle {
     // completed launches the fastest (by its best time) is kept for the rest of the handle's life.  GEMX_PACE_CAL=0 / an explicit
     // GEMX_PACE_GBPS: no calibration.  Results are unaffected either way (the limiter only delays block starts).
     struct PaceCal {
-        static constexpr int NC = 5, SAMPLES = 3, RING = 16;
+        static constexpr int NC = 5, SAMPLES = 6, RING = 16;  // (six rounds: the first ones run while the clocks still ramp)
         long long sig = -1;        // launch signature the state belongs to
         int next = 0;              // launches handed out so far (candidate = next % NC)
         int chosen = -1;           // >= 0: calibration done, candidate index kept

@@ -2454,7 +2454,7 @@ def test_rate_limiter_closed_loop_calibrates_and_never_changes_results(monkeypat
             monkeypatch.delenv(k)
         return outs, descs, d2
 
-    outs, descs, d2 = run({}, 48)
+    outs, descs, d2 = run({}, 72)
     assert "limiter calibrating" in descs[0] and "1.00 x" in descs[0]
     assert any("limiter calibrated" in d for d in descs), descs[-1]
     assert "limiter calibrated" in descs[-1]

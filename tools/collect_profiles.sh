@@ -49,7 +49,8 @@ for K in 1000 3000 6000; do
 done
 # the records that go with them: the GPU suite, the parity report, two ranks on this one GPU (gloo control plane) with the chunk gather
 cd $R
-python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/${TAG}_gpu_tests.txt
-python tests/parity_report.py > $OUT/${TAG}_parity.md 2>&1
-python tests/solver_scan.py > $OUT/${TAG}_solver_scan.md 2>/dev/null
+python -m pytest tests -m gpu -q -n 4 2>&1 | tail -3 > $OUT/${TAG}_gpu_tests.txt
+# (round 5: both scripts exit non-zero on any failed comparison, and the collection records it -- a FAIL cell used to be swallowed)
+python tests/parity_report.py > $OUT/${TAG}_parity.md 2>&1; echo "parity_report.py exit status $?" >> $OUT/${TAG}_gpu_tests.txt
+python tests/solver_scan.py > $OUT/${TAG}_solver_scan.md 2>/dev/null; echo "solver_scan.py exit status $?" >> $OUT/${TAG}_gpu_tests.txt
 python bench.py --gpus 2 --oversubscribe --gather chunk --steps 5 --warmup 2 --no-extras --no-pmc 2>&1 | tail -1 > $OUT/${TAG}_bench_gpus2_oversubscribe.json
