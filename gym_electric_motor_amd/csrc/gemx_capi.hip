@@ -590,6 +590,10 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
             if (prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
             if (prop.sharedMemPerBlock >= 64 * 1024) h->lds_max = prop.sharedMemPerBlock;
+            // The rate limiter's built-in targets are GB/s figures of ONE part in ONE mode: a whole MI355X (gfx950, 256 CUs, ~8 TB/s).  On
+            // anything else -- another arch, a partitioned device (CPX / DPX: fewer CUs per logical device) -- they mean nothing: the
+            // limiter starts switched off there (advisor finding, round 4; GEMX_PACE_GBPS still turns it on with an explicit target).
+            if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 || prop.multiProcessorCount != 256) h->pace_gbps = 0.0;
         }
         // every switch below changes which kernel a PRODUCT call runs: whatever is set is recorded and shows up in gemx_last_launch(), so that
         // a stray variable cannot silently change a benchmark (round 3 verdict)

@@ -2504,7 +2504,10 @@ void advance_pipe_kernel(const KArgs<R> a) {
     // it every row address of the output waves (k0 = pb * D + ow * RPW) is 64-bit per-lane VALU arithmetic (v_mad_u64_u32 chains)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int tid = threadIdx.x & (BLOCK - 1);
-    const int64_t blk0 = (int64_t)blockIdx.x * BLOCK;
+    // Workgroups take the 64-env groups in REVERSE order: the group that may be partial (the last one) goes to workgroup 0, which is
+    // dispatched first.  A partial workgroup is 15-20 % slower than a full one (general I/O paths); as the last workgroup of the last round it
+    // ran alone at the end of the launch (100000 envs: 0.67 of the roofline against 0.75 at 100032), in the first round it hides behind the rest.
+    const int64_t blk0 = (int64_t)(gridDim.x - 1u - blockIdx.x) * BLOCK;
     const int64_t env = blk0 + tid;
     const int64_t N = a.N;
     const int K = a.K;
@@ -2515,6 +2518,12 @@ void advance_pipe_kernel(const KArgs<R> a) {
     // tail).  All three tests are wave-uniform and sit outside the step loops; every full workgroup runs the code it ran before.
     const bool full_wg = blk0 + BLOCK <= N;
     const int rows_n = full_wg ? BLOCK : (int)(N - blk0);  // envs of this workgroup
+    // A batch whose rows are NOT 16-byte aligned (N % 16 != 0 with one-byte actions / done bytes, n_envs * n_out % 4 != 0, a caller's
+    // unaligned tensor: KArgs::coop / obs_vec are 0) keeps the 16-byte units in its full workgroups all the same: gfx950 under ROCm's
+    // default alignment mode executes global_store_dwordx4, 16-byte stores at byte offsets and global_load_lds_dwordx4 from byte-misaligned
+    // addresses correctly (tools/microbench_unaligned.hip, profiles/r05j_unaligned_access.txt) -- such a batch used to run the single-wave
+    // fallback kernel at a sixth of the rate.  fast_io: this workgroup moves its rows in 16-byte units.
+    const bool fast_io = full_wg;
     const bool valid = env < N;
     const int64_t envc = valid ? env : N - 1;  // clamped env index for loads
     constexpr int S = D;              // the observation ring holds exactly one hand-off block
@@ -2565,7 +2574,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
         const int sb = steps_of(b);
         unsigned char *dst = actb + (size_t)(b % NBUF) * DP * ROWB;
         const unsigned char *src = a.actions + ((int64_t)b * D * N + blk0) * ABYTES;
-        if (!full_wg) {  // partial workgroup: this lane's own action of every row through a register; lanes beyond the batch stage zeros
+        if (!fast_io) {  // partial workgroup / unaligned rows: this lane's own action of every row through a register; lanes beyond the batch stage zeros
             for (int s = 0; s < D; ++s) {
                 const int row = s < sb ? s : sb - 1;
                 const unsigned char *g = src + ((int64_t)row * N + (envc - blk0)) * ABYTES;
@@ -3185,7 +3194,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
             if (b + 1 < nb) {
                 constexpr int VM_KEEP = 0x0F70 | (NSTAGE & 0xF) | ((NSTAGE >> 4) << 14);
                 static_assert(NSTAGE < 64, "vmcnt immediate");
-                if (AHEAD == 2 && issued && n_ref == 0 && full_wg) __builtin_amdgcn_s_waitcnt(VM_KEEP);
+                if (AHEAD == 2 && issued && n_ref == 0 && fast_io) __builtin_amdgcn_s_waitcnt(VM_KEEP);
                 else __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
             }
 #ifdef GEMX_TIMING
@@ -3323,7 +3332,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
                     reward_apply<NOUT, RPW, R>(a, WR, ring, donebuf, pb * D + r0, r0, nr, tid, env, valid, rv);
                 }
             }
-            if (aos && nr == RPW && full_wg) flush_rows_pipe<NOUT, RPW, R>(a, ring + (size_t)r0 * BLOCK * NOUT, donebuf + (size_t)r0 * BLOCK, pb * D + r0, tid, blk0);
+            if (aos && nr == RPW && fast_io) flush_rows_pipe<NOUT, RPW, R>(a, ring + (size_t)r0 * BLOCK * NOUT, donebuf + (size_t)r0 * BLOCK, pb * D + r0, tid, blk0);
             else flush_rings<NOUT, R>(a, ring + (size_t)r0 * BLOCK * NOUT, donebuf + (size_t)r0 * BLOCK, pb * D + r0, nr, tid, blk0, rows_n, full_wg,
                                       valid, env);
 #ifdef GEMX_TIMING
@@ -4083,9 +4092,10 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     smem += (size_t)delay * BLOCK * conv_nact_c<CONV>() * sizeof(R);  // DeadTimeProcessor FIFO
     const int64_t blocks = (h->n + BLOCK - 1) / BLOCK;
     // pipelined kernel (integrator / output / loader waves) whenever the launch qualifies
-    // (round 5: any batch size whose rows stay 16-byte aligned, i.e. N % 16 == 0 with one-byte actions / done bytes -- a last workgroup of
-    // fewer than 64 envs is handled inside the pipelined kernel; dc_stream_kernel still wants whole workgroups)
-    const bool pipe_ok = h->use_pipe != 0 && K >= 2 && obs_every && a.coop && a.obs_vec &&
+    // (round 5: ANY batch size -- a last workgroup of fewer than 64 envs is handled inside the pipelined kernel (advance_pipe_kernel:
+    // full_wg / fast_io), rows that are not 16-byte aligned are moved by the same instructions (unaligned 16-byte accesses are legal);
+    // dc_stream_kernel still wants whole workgroups and aligned rows)
+    const bool pipe_ok = h->use_pipe != 0 && K >= 2 && obs_every &&
                          params_of<R>(h).constr_kind <= 1 && h->cfg.solver_nsteps == 1;
     // RC supply / random initialisers: the FULL instantiation (shape <4, 2> only; see advance_pipe_kernel)
     const bool need_full = h->cfg.supply_kind != GEMX_SUPPLY_IDEAL || h->cfg.init_kind != GEMX_INIT_CONST;
@@ -4096,7 +4106,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     // PermExDc, us per 1000 steps at 4096 / 8192 / 12288 / 16384 envs: 39 / 41 / 88 / 94 against 71 / 72 / 72 / 72; tools/ab_dc_stream.py)
     if constexpr (sizeof(R) == 4 && LOAD == GEMX_LOAD_CONST_SPEED && !IL &&
                   (SYS == GEMX_SYS_DC_PERMEX || SYS == GEMX_SYS_DC_SERIES || SYS == GEMX_SYS_DC_SHUNT || SYS == GEMX_SYS_DC_EXTEX)) {
-        bool dcs_ok = pipe_ok && (h->n % BLOCK) == 0 && h->use_dc_stream != 0 && !need_full && delay == 0 && !(h->cfg.solver_flags & GEMX_SOLVER_ADAPTIVE) && h->cur_reward == nullptr && (h->omega_is_init || h->use_dc_stream >= 3) &&
+        bool dcs_ok = pipe_ok && (h->n % BLOCK) == 0 && a.coop && a.obs_vec && h->use_dc_stream != 0 && !need_full && delay == 0 && !(h->cfg.solver_flags & GEMX_SOLVER_ADAPTIVE) && h->cur_reward == nullptr && (h->omega_is_init || h->use_dc_stream >= 3) &&
                       params_of<R>(h).obs_layout == GEMX_OBS_AOS && params_of<R>(h).t_il == R(0) &&
                       (h->use_dc_stream > 1 || 2 * blocks <= (int64_t)h->n_cu) && dcs_smem_bytes<SYS, CONV>() <= h->lds_max &&
                       (int64_t)h->n * h->nout * 64 < ((int64_t)1 << 31);  // (SIGNED 32-bit store offsets: lane offsets across the rows of a (double)
@@ -4422,9 +4432,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         // A fused fp32 rollout that lands HERE runs the single-wave kernel, several times slower than the pipelined one at the same size
         // (round 4 verdict: nothing but gemx_last_launch() told).  Said once per handle, with the reason; GEMX_QUIET=1 silences it.
         h->warned_fallback = true;
-        const char *why = !a.coop ? "action / done rows are not 16-byte aligned (batch size not a multiple of 16, or an unaligned tensor)"
-                          : !a.obs_vec ? "observation rows are not 16-byte aligned (n_envs * n_out not a multiple of 4)"
-                          : params_of<R>(h).constr_kind > 1 ? "custom constraint set (only none / the env's default constraint are pipelined)"
+        const char *why = params_of<R>(h).constr_kind > 1 ? "custom constraint set (only none / the env's default constraint are pipelined)"
                           : h->cfg.solver_nsteps != 1 ? "solver sub-stepping (nsteps > 1)"
                                                        : "random initial states beyond 4 workgroups per CU, or the LDS footprint of this configuration";
         const char *q = getenv("GEMX_QUIET");

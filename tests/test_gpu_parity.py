@@ -910,13 +910,18 @@ def _install_reward(ps, meta):
 
 
 @pytest.mark.parametrize("name", REWARD_CASES)
-@pytest.mark.parametrize("n_envs", [70, 128])
+@pytest.mark.parametrize("n_envs", [70, 128, -70])
 def test_fused_reward_matches_reference_env_rewards(name, n_envs, monkeypatch):
     """WeightedSumOfErrors fused into the rollout (gemx_rollout_reward): rewards env.step() returned in the reference run, with
     the references its generator produced fed in as data.  fp32: |dr| <= 1e-4 * reward scale; the violation reward exact.
-    n_envs = 128 takes the pipelined kernel (reward computed by the output waves), 70 the single-wave kernel with a tail."""
+    n_envs = 128: the pipelined kernel's aligned paths (reward computed by the output waves); 70: its unaligned, partial-workgroup paths
+    (round 5; the single-wave kernel's reward code is compared through GEMX_PIPE=0 elsewhere)."""
     import torch
 
+    single_wave = n_envs < 0  # (-70: the same batch through the single-wave kernel, GEMX_PIPE=0)
+    n_envs = abs(n_envs)
+    if single_wave:
+        monkeypatch.setenv("GEMX_PIPE", "0")
     d, meta = _load(name)
     env = _make_from_meta(meta, n_envs, dtype="float32", auto_reset=True)
     ps = env.physical_system
@@ -929,7 +934,7 @@ def test_fused_reward_matches_reference_env_rewards(name, n_envs, monkeypatch):
     refs = torch.as_tensor(np.repeat(d["references"][:, None, cols], n_envs, axis=1))
     obs, done, rew = ps.rollout(a.cuda(), references=refs.cuda())
     torch.cuda.synchronize()
-    assert ("advance_pipe_kernel" in ps.last_launch()) == (n_envs == 128)
+    assert ("advance_kernel" if single_wave else "advance_pipe_kernel") in ps.last_launch()
     rew, done = rew.double().cpu().numpy(), done.cpu().numpy().astype(bool)
     assert np.array_equal(rew[:, 0], rew[:, n_envs - 1])
     ref_done = d["terminated"]
@@ -1368,11 +1373,12 @@ PARTIAL_CASES = ["pmsm_epi_held_tau1e-4_euler",            # finite B6: voltage 
 
 
 @pytest.mark.parametrize("name", PARTIAL_CASES)
-@pytest.mark.parametrize("n", [16, 80, 208])
+@pytest.mark.parametrize("n", [16, 80, 208, 70, 7, 203])
 def test_partial_last_workgroup_of_the_pipelined_kernel(name, n, monkeypatch):
     """A batch that is not a multiple of 64 envs no longer falls back to the single-wave kernel (round 4: 6-8 x slower, silently): the
     pipelined kernel's last workgroup takes the remaining envs (clamped loads, masked stores, lane-by-lane staging, row stores over
-    the valid span).  Every shape, bit for bit against the single-wave kernel: all observation rows and done bytes of all envs, a
+    the valid span), and batches whose rows are not 16-byte aligned (n = 70, 7, 203) take those general I/O paths in every workgroup.
+    Every shape, bit for bit against the single-wave kernel: all observation rows and done bytes of all envs, a
     second launch from the stored state, and the final ODE / leg / supply state -- and the memory right behind every output tensor
     untouched (the partial workgroup's lanes beyond the batch store nothing)."""
     import torch
@@ -1518,26 +1524,28 @@ def test_random_initialiser_counters_after_create():
     env.close()
 
 
-def test_unaligned_batch_sizes_say_that_they_take_the_fallback(capfd):
-    """Batch sizes whose rows are not 16-byte aligned (n_envs not a multiple of 16) still run the single-wave kernel -- and now SAY so,
-    once per handle, on stderr (GEMX_QUIET=1 silences it)."""
+def test_the_single_wave_fallback_says_so_and_unaligned_batches_no_longer_take_it(capfd):
+    """Since round 5 EVERY batch size runs the pipelined kernel (rows that are not 16-byte aligned -- n_envs not a multiple of 16 -- go
+    lane by lane through its general I/O paths instead of falling back, 6-8 x slower, to the single-wave kernel).  What still lands on
+    the fallback -- here: a custom constraint set -- says so, once per handle, on stderr (GEMX_QUIET=1 silences it)."""
     import torch
 
     import gym_electric_motor_amd as ga
 
-    env = ga.make("Finite-CC-PMSM-v0", n_envs=70)
-    acts = torch.zeros((8, 70), dtype=torch.uint8, device="cuda")
+    for n in (70, 7, 1000):
+        env = ga.make("Finite-CC-PMSM-v0", n_envs=n)
+        env.rollout(torch.zeros((8, n), dtype=torch.uint8, device="cuda"))
+        assert "advance_pipe_kernel" in env.physical_system.last_launch(), n
+        env.close()
+    assert "fallback" not in capfd.readouterr().err
+    env = ga.make("Finite-CC-PMSM-v0", n_envs=128, constraints=("i_sq",))
+    acts = torch.zeros((8, 128), dtype=torch.uint8, device="cuda")
     env.rollout(acts)
     env.rollout(acts)
     assert "advance_kernel" in env.physical_system.last_launch()
     env.close()
     err = capfd.readouterr().err
-    assert err.count("single-wave fallback kernel") == 1 and "multiple of 16" in err
-    env = ga.make("Finite-CC-PMSM-v0", n_envs=80)
-    env.rollout(torch.zeros((8, 80), dtype=torch.uint8, device="cuda"))
-    assert "advance_pipe_kernel" in env.physical_system.last_launch()
-    env.close()
-    assert "fallback" not in capfd.readouterr().err
+    assert err.count("single-wave fallback kernel") == 1 and "custom constraint set" in err
 
 
 @pytest.mark.parametrize("env_id, delay, kw", [
