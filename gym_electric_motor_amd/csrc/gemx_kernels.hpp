@@ -271,9 +271,12 @@ __device__ __forceinline__ double pow_m01(double x) { return pow(x, -0.1); }
 __device__ __forceinline__ float rcp_r(float x) { return __builtin_amdgcn_rcpf(x); }  // V_RCP_F32, 1 ulp: the error norm is compared with 1
 __device__ __forceinline__ double rcp_r(double x) { return 1.0 / x; }
 // first try of a segment of length hs with the carried proposal hc: hs / ceil(hs / hc), the whole segment without a proposal
-template <class R> __device__ __forceinline__ R dp5_first_try(R hs, const R *hc) {
+// (Segments shorter than half a control step -- the dead-time segment of a switching leg, t_il << tau -- neither use nor update the carried
+// size: the proposal after a 1-us segment is at most 10 us and would cut the 99 us behind it into nine pieces.)
+template <class R> __device__ __forceinline__ bool dp5_carries(const DevParams<R> &P, R hs, const R *hc) { return hc != nullptr && !(hs < R(0.5) * P.tau); }
+template <class R> __device__ __forceinline__ R dp5_first_try(const DevParams<R> &P, R hs, const R *hc) {
     // (the proposal carries the controller's safety factor 0.9: a sub-step of proposal / 0.9 is the largest the last estimate would have let pass)
-    if (hc == nullptr || !(*hc > R(0)) || !(*hc < R(0.9) * hs)) return hs;
+    if (!dp5_carries<R>(P, hs, hc) || !(*hc > R(0)) || !(*hc < R(0.9) * hs)) return hs;
     const R n = fmin(ceil(R(0.9) * hs / *hc), R(1024));
     return hs / n;
 }
@@ -281,7 +284,7 @@ template <int NZ, class R, class F>
 __device__ __forceinline__ R dp5_adaptive(const DevParams<R> &P, R (&z)[NZ], R hs, F &&rhs, R *hc = nullptr) {
     R k1[NZ];
     rhs(z, k1);
-    R t = R(0), h = dp5_first_try<R>(hs, hc), integral = R(0), hprop = R(0);
+    R t = R(0), h = dp5_first_try<R>(P, hs, hc), integral = R(0), hprop = R(0);
     const R hmin = hs * R(1.0 / 1024.0);
     bool gave_up = false;
 #pragma nounroll
@@ -346,7 +349,7 @@ __device__ __forceinline__ R dp5_adaptive(const DevParams<R> &P, R (&z)[NZ], R h
         hprop = accept ? fmax(hprop, h) : hprop;  // (the controller's proposal after an accepted sub-step)
     }
     if (gave_up && P.errw != nullptr) atomicOr(P.errw, (uint32_t)GEMX_ERRFLAG_TOLERANCE);
-    if (hc != nullptr) *hc = hprop;
+    if (dp5_carries<R>(P, hs, hc)) *hc = hprop;
     return integral;
 }
 
@@ -602,7 +605,7 @@ __device__ __forceinline__ float dp5_adaptive_pk(const DevParams<float> &P, floa
     for (int j = 0; j < NP; ++j) z.p[j] = f2_t{y[1 + 2 * j], y[2 + 2 * j]};
     auto rhs = [&](const V &zz, V &dz) { dz.w = poly_load_ode<float>(P, zz.w, E.rhs(P, zz, dz)); };
     rhs(z, k1);
-    float t = 0.0f, h = dp5_first_try<float>(hs, hc), integral = 0.0f, hprop = 0.0f;
+    float t = 0.0f, h = dp5_first_try<float>(P, hs, hc), integral = 0.0f, hprop = 0.0f;
     const float hmin = hs * (1.0f / 1024.0f);
     bool gave_up = false;
 #pragma nounroll
@@ -658,7 +661,7 @@ __device__ __forceinline__ float dp5_adaptive_pk(const DevParams<float> &P, floa
         hprop = accept ? fmaxf(hprop, h) : hprop;
     }
     if (gave_up && P.errw != nullptr) atomicOr(P.errw, (uint32_t)GEMX_ERRFLAG_TOLERANCE);
-    if (hc != nullptr) *hc = hprop;
+    if (dp5_carries<float>(P, hs, hc)) *hc = hprop;
     y[0] = z.w;
 #pragma unroll
     for (int j = 0; j < NP; ++j) { y[1 + 2 * j] = z.p[j].x; y[2 + 2 * j] = z.p[j].y; }

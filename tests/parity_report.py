@@ -84,8 +84,8 @@ def main():
           "oracle with the SAME integrator on 62-64 sampled envs (trajectories episode by episode, done masks exact), all envs checked for finiteness "
           "and termination rate, step-by-step simulate() == fused rollout bit for bit:")
     print()
-    for env_id, n, solver in (("Cont-CC-PermExDc-v0", 4096, "euler"), ("Finite-CC-PMSM-v0", 16384, "rk4"), ("Cont-SC-SCIM-v0", 65536, "rk4"),
-                              ("Cont-SC-SCIM-v0:constspeed", 65536, "rk4")):
+    for env_id, n, solver in (("Cont-CC-PermExDc-v0", 4096, "euler"), ("Finite-CC-PMSM-v0", 16384, "rk4"), ("Finite-CC-PMSM-v0", 32768, "default"),
+                              ("Cont-SC-SCIM-v0", 65536, "default"), ("Cont-SC-SCIM-v0", 65536, "rk4"), ("Cont-SC-SCIM-v0:constspeed", 65536, "rk4")):
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):
             T.test_full_size_configs_against_oracle(env_id, n, solver)

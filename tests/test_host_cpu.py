@@ -447,6 +447,19 @@ def test_dead_time_processor_reset_action_is_folded_into_the_config():
         ga.make("Finite-CC-PMSM-v0", n_envs=2, _defer_create=True, physical_system_wrappers=(ga.DeadTimeProcessor(2, reset_action=lambda: [5, 3]),))
     with pytest.raises(ValueError, match="for a dead time of 2 steps"):
         ga.make("Finite-CC-PMSM-v0", n_envs=2, _defer_create=True, physical_system_wrappers=(ga.DeadTimeProcessor(2, reset_action=lambda: [5]),))
+    # round 5 (advisor finding): the row is validated against the WRAPPED system's action space -- length, bounds, per-component ranges
+    with pytest.raises(ValueError, match="not an element"):  # a short continuous row used to be zero-padded in silence
+        ga.make("Cont-CC-PMSM-v0", n_envs=2, _defer_create=True, physical_system_wrappers=(ga.DeadTimeProcessor(2, reset_action=lambda: [np.array([0.4, -0.3])] * 2),))
+    with pytest.raises(ValueError, match="not an element"):  # beyond the bounds
+        ga.make("Cont-CC-PMSM-v0", n_envs=2, _defer_create=True, physical_system_wrappers=(ga.DeadTimeProcessor(2, reset_action=lambda: [np.array([0.4, -1.3, 0.0])] * 2),))
+    with pytest.raises(ValueError, match="not an element"):  # [4, 0] of MultiDiscrete([4, 4]) used to alias the flat index of [0, 1]
+        ga.make("Finite-CC-ExtExDc-v0", n_envs=2, _defer_create=True, physical_system_wrappers=(ga.DeadTimeProcessor(3, reset_action=lambda: [[4, 0]] * 3),))
+    with pytest.raises(ValueError, match="not an element"):  # Discrete(8)
+        ga.make("Finite-CC-PMSM-v0", n_envs=2, _defer_create=True, physical_system_wrappers=(ga.DeadTimeProcessor(2, reset_action=lambda: [8, 8]),))
+    # behind a DqToAbcActionProcessor the DeadTimeProcessor wraps the abc system: three duty cycles, not the outer (u_d, u_q)
+    ps3 = ga.make("Cont-CC-PMSM-v0", n_envs=2, _defer_create=True,
+                  physical_system_wrappers=(ga.DeadTimeProcessor(2, reset_action=lambda: [np.array([0.1, 0.2, -0.3])] * 2), ga.DqToAbcActionProcessor.make("PMSM"))).physical_system
+    assert list(ps3._cfg.action_delay_reset)[:3] == [0.1, 0.2, -0.3]
     L = _lib.load()
     h = C.c_void_p()
     bad = _lib.GemxConfig.from_buffer_copy(ps._cfg)
