@@ -862,6 +862,43 @@ def extras(torch, dist, ga, args, w, n_local, spl, device, dev_index, out, tele)
             out["configs"]["scim_error_controlled"], _ = leg(torch, dist, ga, args, key, device, dev_index, spl, tele, error_controlled=True, steps=5, sustained=False)
         if key == "permexdc":
             out["configs"][key]["launch_model"] = launch_model(torch, dist, ga, args, key, device, dev_index, out["configs"][key])
+    # "actions ... can be generated on-device".  Config 4's launches once more with the loader wave GENERATING the random
+    # duty cycles (gemx_rollout_synthetic: no action tensor is read; 57 instead of 69 algorithmic bytes per env-step).  An extra beside
+    # `configs.scim`, whose actions stay a tensor in HBM as a policy's would be.
+    def device_actions_leg():
+        wc = dict(WORKLOADS["scim"], key="scim")
+        env_s = make_env(ga, wc, wc["envs"], dev_index)
+        try:
+            ps = env_s.physical_system
+            obs = torch.empty((spl, wc["envs"], ps._n_out), dtype=torch.float32, device=device)
+            done = torch.empty((spl, wc["envs"]), dtype=torch.uint8, device=device)
+            t_end = time.perf_counter() + args.settle_ms * 1e-3
+            while time.perf_counter() < t_end:
+                for _ in range(4):
+                    ps.rollout_synthetic(spl, seed=11, step0=0, obs_out=obs, done_out=done)
+                torch.cuda.synchronize()
+            walls = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(10):
+                    ps.rollout_synthetic(spl, seed=11, step0=i * spl, obs_out=obs, done_out=done)
+                torch.cuda.synchronize()
+                walls.append((time.perf_counter() - t0) / 10)
+            assert torch.isfinite(obs).all()
+            wall = sorted(walls)[1]
+            b_step = 4 * wc["s_out"] + 1  # no action bytes
+            gbs = wc["envs"] * (spl * b_step + 2 * 4 * wc["s_ode"]) / wall / 1e9
+            return {"workload": wc["desc"] + ", actions generated on the device (gemx_rollout_synthetic)", "envs": wc["envs"], "steps_per_launch": spl,
+                    "value": wc["envs"] * spl / wall, "unit": "env-steps/s", "launch_ms": wall * 1e3, "bytes_per_env_step": b_step,
+                    "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBPS, "frac_of_measured": gbs / HBM_MEASURED_COPY_GBPS, "kernel": ps.last_launch(),
+                    "note": "informational: BASELINE config 4 stays `configs.scim` (actions = a tensor resident in HBM)"}
+        finally:
+            env_s.close()
+    try:
+        out["configs"]["scim_device_actions"] = device_actions_leg()
+    except Exception as e:  # (an informational leg must not cost the line)
+        out["configs"]["scim_device_actions"] = {"error": repr(e)}
     if args.workload == "pmsm":  # BASELINE config 5 = 8 x 32768 envs: its shard on this one GPU
         out["configs"]["pmsm_c5_shard"], _ = leg(torch, dist, ga, args, "pmsm", device, dev_index, spl, tele, envs=32768)
     # the headline kernel with the chip full

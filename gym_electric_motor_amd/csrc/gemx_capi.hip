@@ -118,6 +118,18 @@ __global__ void reset_kernel(R *state, typename Angle<R>::T *angle, const uint8_
     }
 }
 
+// gemx_synthetic_actions: the synthetic action stream (gemx_common.hpp: synth_u32) written out, [K][N][A] R or [K][N] uint8
+template <class R>
+__global__ void synth_actions_kernel(unsigned char *out, int64_t N, int K, int nact, int n_actions, uint64_t seed, uint32_t step0) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (k, env)
+    if (idx >= (int64_t)K * N) return;
+    const int64_t env = idx % N;
+    const uint32_t t = step0 + (uint32_t)(idx / N);
+    if (n_actions > 0) out[idx] = (unsigned char)synth_index(synth_u32(seed, env, t, 0u), (uint32_t)n_actions);
+    else
+        for (int i = 0; i < nact; ++i) reinterpret_cast<R *>(out)[idx * nact + i] = (R)synth_unit(synth_u32(seed, env, t, (uint32_t)i));
+}
+
 template <class R>
 __global__ void get_state_kernel(const R *state, const typename Angle<R>::T *angle, R *out, int64_t N, int nd, int has_angle) {
     int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -857,6 +869,45 @@ int gemx_rollout(gemx_handle *h, const void *actions_dev, int32_t K, void *obs_o
     gemx::DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
     return launch_advance(h, actions_dev, K, obs_out_dev, done_out_dev, obs_every ? 1 : 0, st);
+}
+
+// number of discrete actions of the handle's converter (0: continuous)
+static int n_discrete_actions(const gemx_handle *h) {
+    switch (h->cfg.converter_kind) {
+        case GEMX_CONV_FINITE_B6: return 8;
+        case GEMX_CONV_FINITE_4QC: return 4;
+        case GEMX_CONV_FINITE_2X4QC: return 16;
+        case GEMX_CONV_FINITE_B6_4QC: return 32;
+        case GEMX_CONV_FINITE_2XB6: return 64;
+        default: return 0;
+    }
+}
+int gemx_synthetic_actions(gemx_handle *h, uint64_t seed, uint32_t step0, int32_t K, void *actions_out_dev, void *stream) {
+    if (!h || !actions_out_dev) return fail(GEMX_ERR_ARG, "null argument");
+    if (K < 1) return fail(GEMX_ERR_ARG, "K must be >= 1");
+    gemx::DeviceGuard guard(h->device);
+    const int64_t total = (int64_t)K * h->n;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (h->cfg.dtype == GEMX_F64)
+        hipLaunchKernelGGL(synth_actions_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned char *)actions_out_dev, h->n, K, h->nact, n_discrete_actions(h), seed, step0);
+    else
+        hipLaunchKernelGGL(synth_actions_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned char *)actions_out_dev, h->n, K, h->nact, n_discrete_actions(h), seed, step0);
+    HIP_TRY(hipGetLastError());
+    return GEMX_OK;
+}
+int gemx_rollout_synthetic(gemx_handle *h, uint64_t seed, uint32_t step0, int32_t K, void *obs_out_dev, uint8_t *done_out_dev, void *stream) {
+    if (!h) return fail(GEMX_ERR_ARG, "null handle");
+    if (!obs_out_dev) return fail(GEMX_ERR_ARG, "obs_out_dev must not be null");
+    if (K < 2) return fail(GEMX_ERR_ARG, "gemx_rollout_synthetic: K must be >= 2 (a single step takes gemx_synthetic_actions + gemx_step)");
+    if (((uintptr_t)obs_out_dev & 15u) != 0) return fail(GEMX_ERR_ARG, "obs_out_dev must be 16-byte aligned");
+    if (h->cfg.dtype == GEMX_F64) return fail(GEMX_ERR_ARG, "gemx_rollout_synthetic: fp32 handles only (the fp64 build runs gemx_synthetic_actions + gemx_rollout)");
+    gemx::DeviceGuard guard(h->device);
+    h->cur_synth = true;
+    h->cur_seed = seed;
+    h->cur_step0 = step0;
+    const int rc = launch_advance(h, nullptr, K, obs_out_dev, done_out_dev, 1, (hipStream_t)stream);
+    h->cur_synth = false;
+    return rc;
 }
 
 int gemx_set_reward(gemx_handle *h, const gemx_reward_config *rc) {

@@ -343,6 +343,24 @@ __device__ __forceinline__ void init_draw_all(const InitDev *I, int64_t env, uin
 }
 
 // ------------------------------------------------------------------------------------------------
+// SYNTHETIC ACTIONS (round 5; SURVEY.md 8e: "actions ... can be generated on-device").  A counter-based stream: the action of env e at
+// control step t (position in the stream) is a pure function of (seed, e, t, component) -- no state, the same bits on the host, in the
+// generator kernel (gemx_synthetic_actions) and in the pipelined kernel's loader wave (gemx_rollout_synthetic), which then reads NO action
+// tensor at all: random-action rollouts of the continuous converters lose the 8-24 B per env-step whose trip from the HBM between the row
+// stores costs them 15-20 % of their rate.  One 32-bit mix per value (lowbias32: two 32-bit multiplies, three xor-shifts;
+// the ten rounds of Philox used for the initial states would be 80 quarter-rate multiplies per env-step on a wave that shares its SIMD).
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t synth_u32(uint64_t seed, int64_t env, uint32_t t, uint32_t comp) {
+    uint32_t x = (uint32_t)env * 0x9E3779B9u + t * 0x85EBCA6Bu + comp * 0xC2B2AE35u + (uint32_t)seed;
+    x ^= (uint32_t)(seed >> 32) ^ ((uint32_t)((uint64_t)env >> 32) * 0x27D4EB2Fu);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+// continuous: uniform on the 2^24 midpoints of (-1, 1), exact in fp32 and fp64; discrete: the top bits (every action count is a power of two)
+__host__ __device__ __forceinline__ float synth_unit(uint32_t x) { return (float)(x >> 8) * 1.1920928955078125e-7f + (-1.0f + 5.9604644775390625e-8f); }
+__host__ __device__ __forceinline__ uint32_t synth_index(uint32_t x, uint32_t n_actions) { return (uint32_t)(((uint64_t)x * n_actions) >> 32); }
+
+// ------------------------------------------------------------------------------------------------
 // fused reward (WeightedSumOfErrors): device-resident description, read through scalar loads when a reward is requested
 // ------------------------------------------------------------------------------------------------
 template <class R> struct RewardDev {
@@ -419,6 +437,11 @@ template <class R> struct KArgs {
     uint32_t pace_block_ticks;
     uint32_t pace_tail_ticks;       // ... of the workgroups from index pace_tail_from on: the LAST round, which has the chip to itself with fewer
     uint32_t pace_tail_from;        //     workgroups than a full one and may run that much faster each
+    // synthetic actions (gemx_rollout_synthetic): act_synth != 0 -> `actions` is not read; the loader wave generates synth_u32(act_seed, env,
+    // act_step0 + k, component) instead
+    uint64_t act_seed;
+    uint32_t act_step0;
+    int32_t act_synth;
 };
 
 // FIFO slot of this launch's first step (0 without a DeadTimeProcessor) / its advance by the last workgroup to finish: every workgroup
@@ -507,6 +530,9 @@ struct gemx_handle {
     gemx::RewardHot<float> rh_f = {};   // its first terms by value (kernel argument)
     gemx::RewardHot<double> rh_d = {};
     int rw_n_ref = -1;       // -1: no reward installed
+    bool cur_synth = false;          // set by gemx_rollout_synthetic around the launch: actions come from synth_u32(cur_seed, env, cur_step0 + k, i)
+    uint64_t cur_seed = 0;
+    uint32_t cur_step0 = 0;
     const void *cur_refs = nullptr;  // set by gemx_rollout_reward around the launch
     void *cur_reward = nullptr;
     void *ring = nullptr;    // DeadTimeProcessor FIFO [delay][n][nact_conv] R | [delay][n] uint8

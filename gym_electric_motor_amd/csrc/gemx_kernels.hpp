@@ -2576,6 +2576,18 @@ void advance_pipe_kernel(const KArgs<R> a) {
     auto stage_actions = [&](int b) {
         const int sb = steps_of(b);
         unsigned char *dst = actb + (size_t)(b % NBUF) * DP * ROWB;
+        if (a.act_synth) {  // synthetic actions: this lane's own values of every row, generated (gemx_common.hpp: synth_u32); no memory read
+            for (int s = 0; s < D; ++s) {
+                const uint32_t t = a.act_step0 + (uint32_t)(b * D + (s < sb ? s : sb - 1));
+                if constexpr (DISCRETE) {
+                    dst[(size_t)s * ROWB + tid] = (unsigned char)synth_index(synth_u32(a.act_seed, envc, t, 0u), (uint32_t)ConvTraits<CONV>::NACTIONS);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NACT; ++i) reinterpret_cast<R *>(dst + (size_t)s * ROWB)[tid * NACT + i] = (R)synth_unit(synth_u32(a.act_seed, envc, t, (uint32_t)i));
+                }
+            }
+            return;
+        }
         const unsigned char *src = a.actions + ((int64_t)b * D * N + blk0) * ABYTES;
         if (!fast_io) {  // partial workgroup / unaligned rows: this lane's own action of every row through a register; lanes beyond the batch stage zeros
             for (int s = 0; s < D; ++s) {
@@ -4034,6 +4046,9 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     a.angle = (typename Angle<R>::T *)h->angle;
     a.sw = h->sw;
     a.actions = (const unsigned char *)actions;
+    a.act_synth = h->cur_synth ? 1 : 0;
+    a.act_seed = h->cur_seed;
+    a.act_step0 = h->cur_step0;
     a.obs = (R *)obs;
     a.done = done;
     a.ring = (unsigned char *)h->ring;
@@ -4109,7 +4124,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     // PermExDc, us per 1000 steps at 4096 / 8192 / 12288 / 16384 envs: 39 / 41 / 88 / 94 against 71 / 72 / 72 / 72; tools/ab_dc_stream.py)
     if constexpr (sizeof(R) == 4 && LOAD == GEMX_LOAD_CONST_SPEED && !IL &&
                   (SYS == GEMX_SYS_DC_PERMEX || SYS == GEMX_SYS_DC_SERIES || SYS == GEMX_SYS_DC_SHUNT || SYS == GEMX_SYS_DC_EXTEX)) {
-        bool dcs_ok = pipe_ok && (h->n % BLOCK) == 0 && a.coop && a.obs_vec && h->use_dc_stream != 0 && !need_full && delay == 0 && !(h->cfg.solver_flags & GEMX_SOLVER_ADAPTIVE) && h->cur_reward == nullptr && (h->omega_is_init || h->use_dc_stream >= 3) &&
+        bool dcs_ok = pipe_ok && !h->cur_synth && (h->n % BLOCK) == 0 && a.coop && a.obs_vec && h->use_dc_stream != 0 && !need_full && delay == 0 && !(h->cfg.solver_flags & GEMX_SOLVER_ADAPTIVE) && h->cur_reward == nullptr && (h->omega_is_init || h->use_dc_stream >= 3) &&
                       params_of<R>(h).obs_layout == GEMX_OBS_AOS && params_of<R>(h).t_il == R(0) &&
                       (h->use_dc_stream > 1 || 2 * blocks <= (int64_t)h->n_cu) && dcs_smem_bytes<SYS, CONV>() <= h->lds_max &&
                       (int64_t)h->n * h->nout * 64 < ((int64_t)1 << 31);  // (SIGNED 32-bit store offsets: lane offsets across the rows of a (double)
@@ -4412,6 +4427,8 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             return GEMX_OK;
         }
     }
+    if (h->cur_synth)  // (only the pipelined kernel's loader wave generates actions; gemx_synthetic_actions writes the same stream for any other path)
+        return fail(GEMX_ERR_ARG, "gemx_rollout_synthetic needs the pipelined kernel: fp32, K >= 2, every step's observations, no custom constraint set, one solver sub-step");
     if (K == 1 && h->cur_reward == nullptr && h->use_step_kernel != 0) {  // the closed-loop path: see step_kernel
         // one launch per control step is bound by the HOST's launch path: the function handle is resolved once per handle and the
         // arguments go as one buffer -- 3.36 against 3.55 us per launch through hipLaunchKernelGGL (tools/microbench_launch.hip)

@@ -165,6 +165,10 @@ class BatchedElectricMotorEnv:
     def rollout(self, actions, **kw):
         return self.physical_system.rollout(actions, **kw)
 
+    def rollout_synthetic(self, K, **kw):
+        """K fused steps on random actions generated on the device (PhysicalSystem.rollout_synthetic)."""
+        return self.physical_system.rollout_synthetic(K, **kw)
+
     def bind_rollout(self, actions, obs_out, done_out, stream=None):
         """-> zero-argument launch(): the pre-bound `gemx_rollout` call for fixed tensors (PhysicalSystem.bind_rollout)."""
         return self.physical_system.bind_rollout(actions, obs_out, done_out, stream=stream)

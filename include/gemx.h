@@ -29,7 +29,8 @@ extern "C" {
 #endif
 
 #define GEMX_ABI_VERSION 6 /* 2: GEMX_MAX_OUT 16 -> 24 (DFIM system, 24 states); 3: gemx_config.solver_flags; 4: solver_rtol / solver_atol; 5: init_flux_mode / init_flux;
-                            * 6: gemx_get_aux_state / gemx_set_aux_state / gemx_aux_state_bytes, gemx_reset_again; reset counters stay at 1 after gemx_create */
+                            * 6: gemx_get_aux_state / gemx_set_aux_state / gemx_aux_state_bytes, gemx_reset_again; reset counters stay at 1 after gemx_create;
+                            *    + gemx_rollout_synthetic / gemx_synthetic_actions (new entry points only) */
 #define GEMX_MAX_ODE 8  /* ODE state length incl. omega and the angle      */
 #define GEMX_MAX_OUT 24 /* system-state (observation) length               */
 #define GEMX_MODEL_ROWS 5
@@ -246,6 +247,14 @@ typedef struct gemx_reward_config {
 } gemx_reward_config;
 /* Install (rc != NULL) or remove (NULL) the reward function of a handle. */
 int gemx_set_reward(gemx_handle *h, const gemx_reward_config *rc);
+/* SYNTHETIC random-action rollouts without an action tensor ("actions ... can be generated on-device"): the action of env e at
+ * stream position t = step0 + k is a pure function of (seed, e, t, component) -- continuous entries uniform on (-1, 1), discrete indices
+ * uniform over the converter's action set (the flat index for MultiDiscrete) -- generated inside the launch (fp32, K >= 2, the conditions
+ * of the pipelined kernel; GEMX_ERR_ARG otherwise).  gemx_synthetic_actions writes the SAME stream into a tensor ([K, N, A] R | [K, N] uint8),
+ * for policies / tests / the paths gemx_rollout_synthetic does not serve: gemx_rollout on that tensor gives the same bits. */
+int gemx_rollout_synthetic(gemx_handle *h, uint64_t seed, uint32_t step0, int32_t K, void *obs_out_dev, uint8_t *done_out_dev, void *stream);
+int gemx_synthetic_actions(gemx_handle *h, uint64_t seed, uint32_t step0, int32_t K, void *actions_out_dev, void *stream);
+
 /* gemx_rollout (obs_every = 1) that additionally reads refs_dev [K, N, n_ref] (R) and writes reward_out_dev [K, N] (R). */
 int gemx_rollout_reward(gemx_handle *h, const void *actions_dev, int32_t K, const void *refs_dev, void *obs_out_dev,
                         uint8_t *done_out_dev, void *reward_out_dev, void *stream);

@@ -2736,3 +2736,57 @@ def test_replay_of_the_reference_env_shell_transcript(name):
     assert n_sim == doc["steps"] and n_reset >= 1
     rel, ab = _rel_err(np.asarray(got), np.asarray(ref), list(ps.state_names))
     assert rel < 1e-4, (rel, ab)
+
+
+@pytest.mark.parametrize("env_id, n", [("Cont-SC-SCIM-v0", 4096), ("Cont-CC-PMSM-v0", 200), ("Finite-CC-PMSM-v0", 16384), ("Finite-CC-DFIM-v0", 1000),
+                                       ("Cont-CC-DFIM-v0", 70), ("Finite-CC-ExtExDc-v0", 4160), ("Cont-CC-PermExDc-v0", 8256)])
+def test_synthetic_actions_generated_in_the_launch_equal_the_same_stream_from_a_tensor(env_id, n):
+    """gemx_rollout_synthetic (actions generated on-device -- the loader wave computes every env's action of every step from
+    (seed, env, step, component) and no action tensor is read) against gemx_rollout on the tensor gemx_synthetic_actions writes for the
+    same stream: observations, done bytes and final state bit for bit, over two chunked launches that continue the stream, partial
+    workgroups and unaligned batch sizes included; the stream itself is uniform (continuous: on (-1, 1), mean / variance / range;
+    discrete: every index of the action set, equally often) and differs between envs, steps, components and seeds."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    K1, K2, seed = 96, 37, 0xC0FFEE1234
+    ea, eb = ga.make(env_id, n_envs=n), ga.make(env_id, n_envs=n)
+    pa, pb = ea.physical_system, eb.physical_system
+    acts = pb.synthetic_actions(K1 + K2, seed=seed, step0=0)
+    o1, d1 = ea.rollout_synthetic(K1, seed=seed)
+    assert "advance_pipe_kernel" in pa.last_launch()
+    o2, d2 = ea.rollout_synthetic(K2, seed=seed)  # (step0 defaults to the step count: the stream continues)
+    r1, q1 = eb.rollout(acts[:K1])
+    r2, q2 = eb.rollout(acts[K1:])
+    assert torch.equal(o1, r1) and torch.equal(d1, q1) and torch.equal(o2, r2) and torch.equal(d2, q2)
+    assert torch.equal(pa.get_state(), pb.get_state()) and pa.k == pb.k == K1 + K2
+    a = acts.double().cpu().numpy()
+    if pa._discrete:
+        nflat = int(np.prod(pa.action_space.nvec)) if hasattr(pa.action_space, "nvec") else int(pa.action_space.n)
+        counts = np.bincount(a.astype(np.int64).ravel(), minlength=nflat)
+        assert len(counts) == nflat and counts.min() > 0.9 * a.size / nflat and counts.max() < 1.1 * a.size / nflat
+    else:
+        assert -1.0 < a.min() < -1.0 + 20.0 / a.size and 1.0 - 20.0 / a.size < a.max() < 1.0
+        assert abs(a.mean()) < 5.0 * 0.5774 / np.sqrt(a.size) + 1e-4 and abs(a.var() - 1.0 / 3.0) < 5.0 * 0.3 / np.sqrt(a.size) + 1e-4
+        if a.shape[2] > 1:
+            assert abs(np.corrcoef(a[..., 0].ravel(), a[..., 1].ravel())[0, 1]) < 5.0 / np.sqrt(a[..., 0].size)  # (5 sigma of an uncorrelated sample)
+    assert abs(np.corrcoef(a[:-1].ravel(), a[1:].ravel())[0, 1]) < 5.0 / np.sqrt(a[1:].size)          # step to step
+    assert abs(np.corrcoef(a[:, :-1].ravel(), a[:, 1:].ravel())[0, 1]) < 5.0 / np.sqrt(a[:, 1:].size)    # env to env
+    other = pb.synthetic_actions(4, seed=seed + 1, step0=0)
+    assert not torch.equal(other, acts[:4])
+    assert torch.equal(pb.synthetic_actions(5, seed=seed, step0=K1), acts[K1:K1 + 5])
+    ea.close(), eb.close()
+
+
+def test_synthetic_rollout_refuses_what_the_pipelined_kernel_does_not_serve():
+    import gym_electric_motor_amd as ga
+
+    env = ga.make("Finite-CC-PMSM-v0", n_envs=128, constraints=("i_sq",))  # custom constraint set: single-wave kernel
+    with pytest.raises(ValueError, match="pipelined kernel"):
+        env.rollout_synthetic(16)
+    env.close()
+    env = ga.make("Finite-CC-PMSM-v0", n_envs=128, dtype="float64")
+    with pytest.raises(ValueError, match="fp32"):
+        env.rollout_synthetic(16)
+    env.close()

@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--solver", choices=["rk4", "default"], default="rk4")
     ap.add_argument("--shape", default=None, help="GEMX_PIPE_SHAPE for every row (0: <12,3>, 1: <4,2>, 2: <2,2>, 3: <12,6>)")
     ap.add_argument("--only", nargs="*", default=None, help="substrings: run the rows whose label contains one of them")
+    ap.add_argument("--device-actions", action="store_true", help="actions generated on the device (rollout_synthetic): no action tensor, B/env-step without the action bytes")
     args = ap.parse_args()
     if args.shape is not None:
         os.environ["GEMX_PIPE_SHAPE"] = args.shape
@@ -97,8 +98,13 @@ def main():
                 rew = torch.empty((K, n), device="cuda")
                 b += 4 * int(rc.n_ref) + 4
 
+            if args.device_actions and not with_reward:
+                b -= a_bytes
+
             def launch():
-                if with_reward:
+                if args.device_actions and not with_reward:
+                    ps.rollout_synthetic(K, seed=1, step0=0, obs_out=obs, done_out=done)
+                elif with_reward:
                     ps.rollout(acts, obs_out=obs, done_out=done, references=refs, reward_out=rew)
                 else:
                     ps.rollout(acts, obs_out=obs, done_out=done)
