@@ -561,6 +561,9 @@ struct gemx_handle {
     struct PaceCal {
         static constexpr int NC = 5, SAMPLES = 6, RING = 16;  // (six rounds: the first ones run while the clocks still ramp)
         long long sig = -1;        // launch signature the state belongs to
+        float center = 1.0f;       // the candidates are center x {1, 0.93, 1.07, 0.86} (+ unpaced): re-centred when the winner sits at an edge
+        int recenters = 0;         //   ... at most MAX_RECENTER times (a hill climb from the built-in target)
+        static constexpr int MAX_RECENTER = 4;
         int next = 0;              // launches handed out so far (candidate = next % NC)
         int chosen = -1;           // >= 0: calibration done, candidate index kept
         float best[NC] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f};

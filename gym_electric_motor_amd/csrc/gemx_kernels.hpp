@@ -4318,7 +4318,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                 // a softer landing beyond it (back to the unpaced level, not below): 65536 / 131072 envs PMSM cont 0.66 / 0.63 unpaced -> 0.68 / 0.63
                 // at 6000 / 5600, EESM cont 0.62 / 0.59 -> 0.73 / 0.66, DFIM cont 0.60 / 0.70 -> 0.72 / 0.69, control_space='dq' 0.62 / 0.62 -> 0.68 /
                 // 0.65, ExtExDc cont 0.72 / 0.64 -> 0.77 / 0.64 at 6400 (profiles/r04p_pace_sweep3.txt).
-                const bool reads = ABYTES >= 8;
+                const bool reads = ABYTES >= 8 && !h->cur_synth;  // (synthetic actions are generated in the launch: nothing is read)
                 const double dflt = h->nout <= 8 ? (reads ? (few ? 7000.0 : 6400.0) : (some ? 7000.0 : 6600.0))
                                     : reads      ? (few ? 6400.0 : (some ? 6000.0 : 5800.0))
                                                  : (few ? 6800.0 : (some ? 6600.0 : 6400.0));
@@ -4331,9 +4331,9 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                 if (cal_eligible) {
                     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
                     (void)hipStreamIsCapturing(st, &capturing);
-                    const long long sig = ((long long)K << 40) ^ ((long long)blocks << 8) ^ (long long)shape ^ (h->cur_reward != nullptr ? 0x80 : 0);
+                    const long long sig = ((long long)K << 40) ^ ((long long)blocks << 8) ^ (long long)shape ^ (h->cur_reward != nullptr ? 0x80 : 0) ^ (h->cur_synth ? 0x40 : 0);
                     if (pc.sig != sig) {  // a new kind of launch: start over (events are kept)
-                        pc.sig = sig; pc.next = 0; pc.chosen = -1;
+                        pc.sig = sig; pc.next = 0; pc.chosen = -1; pc.center = 1.0f; pc.recenters = 0;
                         for (int c = 0; c < gemx_handle::PaceCal::NC; ++c) { pc.best[c] = 1e30f; pc.count[c] = 0; pc.issued[c] = 0; }
                         if (pc.ev_init) for (int i = 0; i < gemx_handle::PaceCal::RING; ++i) pc.ev_cand[i] = -1;
                     }
@@ -4366,7 +4366,17 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                                 int bi = 0;
                                 for (int c = 1; c < gemx_handle::PaceCal::NC; ++c) if (pc.best[c] < pc.best[bi]) bi = c;
                                 // (a candidate must beat the starting point by more than 1 % to replace it: timing noise)
-                                pc.chosen = pc.best[bi] < 0.99f * pc.best[0] ? bi : 0;
+                                const int win = pc.best[bi] < 0.99f * pc.best[0] ? bi : 0;
+                                // the winner at an EDGE of the bracket (x 1.07 or x 0.86): the optimum may lie beyond -- move the bracket there
+                                // and calibrate again (the built-in targets are one box's knees; a launch that reads nothing, e.g. with
+                                // synthetic actions, peaks well above them)
+                                if ((win == 2 || win == 3) && pc.recenters < gemx_handle::PaceCal::MAX_RECENTER) {
+                                    pc.center *= (float)CAL_SCALE[win];
+                                    pc.recenters++;
+                                    for (int c = 0; c < gemx_handle::PaceCal::NC; ++c) { pc.best[c] = 1e30f; pc.count[c] = 0; pc.issued[c] = 0; }
+                                } else {
+                                    pc.chosen = win;
+                                }
                             } else {
                                 for (int i = 0; i < gemx_handle::PaceCal::RING; ++i)
                                     if (pc.ev_cand[i] < 0) { cal_slot = i; break; }
@@ -4383,8 +4393,8 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                         }
                     }
                     const int use = pc.chosen >= 0 ? pc.chosen : (cal_slot >= 0 ? cal_cand : 0);
-                    target *= CAL_SCALE[use];
-                    pace_scale_used = CAL_SCALE[use];
+                    target *= CAL_SCALE[use] * pc.center;
+                    pace_scale_used = CAL_SCALE[use] * pc.center;
                 }
                 int64_t res = shape == 4 ? 2 * (int64_t)h->n_cu : resident(D, OW);
                 // More than four workgroups per CU (the DC machines' small rows) and a launch that needs the LAST slot of every CU to be one round:
@@ -4396,7 +4406,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                 if (res > 4 * (int64_t)h->n_cu && blocks <= res && blocks > res - (int64_t)h->n_cu) res -= (int64_t)h->n_cu;
                 pace_res = res;
                 if (target > 0.0 && (blocks > (int64_t)h->n_cu || h->pace_gbps > 0.0 || long_one) && K >= 64 && shape != 3) {  // (<12, 6> carries no limiter: see the kernel)
-                    const double wg_step_bytes = (double)BLOCK * (ABYTES + h->nout * sizeof(R) + 1 + (h->cur_reward != nullptr ? (h->rw_n_ref + 1) * sizeof(R) : 0));
+                    const double wg_step_bytes = (double)BLOCK * ((h->cur_synth ? 0 : ABYTES) + h->nout * sizeof(R) + 1 + (h->cur_reward != nullptr ? (h->rw_n_ref + 1) * sizeof(R) : 0));
                     auto ticks_for = [&](double active) {
                         const double t = wg_step_bytes * active / target * D / 10.0;  // bytes / (GB/s) = ns; 10 ns per tick; D rows per block
                         return t < 1.0 ? 1u : (t > 4.0e9 ? 0u : (uint32_t)(t + 0.5));

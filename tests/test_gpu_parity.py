@@ -2447,12 +2447,17 @@ def test_rate_limiter_closed_loop_calibrates_and_never_changes_results(monkeypat
         env = ga.make("Finite-CC-PMSM-v0", n_envs=n, tau=1e-4)
         ps = env.physical_system
         outs, descs = [], []
+        o = torch.empty((K, n, ps._n_out), device="cuda")
+        d = torch.empty((K, n), dtype=torch.uint8, device="cuda")
         for i in range(launches):
             env.reset()
-            o, d = env.rollout(acts)
+            env.rollout(acts, obs_out=o, done_out=d)
             if i % 8 == 7:
                 torch.cuda.synchronize()  # (completed launches are harvested at later launches)
-            outs.append((o.clone(), d.clone()))
+            if i == 0:
+                outs.append((o.clone(), d.clone()))
+            else:  # (every launch -- whatever candidate it ran -- against the first: compared on the spot, 235 MB a piece)
+                assert torch.equal(o, outs[0][0]) and torch.equal(d, outs[0][1]), i
             descs.append(ps.last_launch())
         torch.cuda.synchronize()
         o2, _ = env.rollout(acts[: K // 2])  # another signature
@@ -2462,13 +2467,11 @@ def test_rate_limiter_closed_loop_calibrates_and_never_changes_results(monkeypat
             monkeypatch.delenv(k)
         return outs, descs, d2
 
-    outs, descs, d2 = run({}, 72)
+    outs, descs, d2 = run({}, 240)  # (30 launches per bracket, up to five brackets when the winner keeps sitting at an edge)
     assert "limiter calibrating" in descs[0] and "1.00 x" in descs[0]
     assert any("limiter calibrated" in d for d in descs), descs[-1]
     assert "limiter calibrated" in descs[-1]
     assert "limiter calibrating" in d2  # K changed: a new calibration
-    for o, d in outs[1:]:
-        assert torch.equal(o, outs[0][0]) and torch.equal(d, outs[0][1])
     ref, rdesc, _ = run({"GEMX_PACE_CAL": "0"}, 2)
     assert "limiter" not in rdesc[0] and "rate limit" in rdesc[0]
     assert torch.equal(ref[0][0], outs[0][0]) and torch.equal(ref[0][1], outs[0][1])

@@ -114,6 +114,12 @@ def main():
                 for _ in range(4):
                     launch()
                 torch.cuda.synchronize()
+            for _ in range(50):  # (the closed-loop rate limiter calibrates during the first paced launches: wait for it, bounded)
+                if "limiter calibrating" not in ps.last_launch():
+                    break
+                for _ in range(8):
+                    launch()
+                torch.cuda.synchronize()
             for _ in range(2):
                 launch()
             torch.cuda.synchronize()
