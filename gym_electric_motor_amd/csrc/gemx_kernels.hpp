@@ -2486,11 +2486,16 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs<R> a) {
 #ifndef GEMX_PACE_DEFAULT_ON
 #define GEMX_PACE_DEFAULT_ON 1
 #endif
-template <int SYS, int SOLVER, bool IL, int D, bool FULL> constexpr int pipe_waves_per_eu() {
-    return (D <= 4 && !FULL && SYS != GEMX_SYS_DFIM && !(SOLVER == GEMX_SOLVER_DP5 && IL)) ? 4 : 1;
+template <int SYS, int SOLVER, bool IL, int D, bool FULL, bool SLOW = false> constexpr int pipe_waves_per_eu() {
+    return (D <= 4 && !FULL && !SLOW && SYS != GEMX_SYS_DFIM && !(SOLVER == GEMX_SOLVER_DP5 && IL)) ? 4 : 1;
 }
-template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R, int D, int OW, bool FULL = false>
-__global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) __attribute__((amdgpu_waves_per_eu(pipe_waves_per_eu<SYS, SOLVER, IL, D, FULL>())))
+// SLOW (round 5; <4, 2> only): the instantiation for solver sub-steps (nsteps > 1) and CUSTOM constraint sets (constr_kind 2).  Every
+// block of such a launch takes the rolled, run-time-checked copy of the step, which here also loops over the sub-steps and evaluates the
+// weighted Limit / Squared constraint on an observation row it computes for that purpose.  A separate instantiation because that code
+// inside the common kernels cost them registers (config 4's <4, 2>: 119 VGPRs -> 128 with 10 spills); with SLOW = false the kernel
+// is what it was.
+template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R, int D, int OW, bool FULL = false, bool SLOW = false>
+__global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) __attribute__((amdgpu_waves_per_eu(pipe_waves_per_eu<SYS, SOLVER, IL, D, FULL, SLOW>())))
 void advance_pipe_kernel(const KArgs<R> a) {
     constexpr int LW = pipe_loader_waves(D);  // 1: a loader wave stages actions / references instead of the integrator
     constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
@@ -2690,7 +2695,11 @@ void advance_pipe_kernel(const KArgs<R> a) {
         lin_preload<SYS, R>(P, LINABLE && lin_ok, linc);
         constexpr bool CAN_DELAY = D == PIPE_D && !FULL;
         const uint32_t delay_u = (uint32_t)P.delay;
-        const bool delayed_any = CAN_DELAY && P.delay > 0 && (!LINABLE || lin_ok);                          // wave-uniform
+        // SLOW: solver sub-steps and custom constraint sets -- every block takes mode 1 (see the kernel's head)
+        const bool ns1 = !SLOW || P.nsteps == 1;
+        const bool generic_constr = SLOW && P.constr_kind == 2;
+        const bool slow_path = !ns1 || generic_constr;                                                       // wave-uniform
+        const bool delayed_any = CAN_DELAY && P.delay > 0 && (!LINABLE || lin_ok) && !slow_path;            // wave-uniform
         const bool delayed_t = delayed_any && conv_dq<CONV>() && P.dq_processor;  // queue of TRANSFORMED actions (row buffer, see one_step)
         const bool delayed = delayed_any && !delayed_t;                           // delayed read of the staged raw rows
         uint32_t since = delay_u;  // DELAYED: control steps since this env's last reset, saturating at `delay` (the HBM ring holds zeros already)
@@ -2715,7 +2724,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
         R qpre[NACTC], tprev[NACTC];
 #pragma unroll
         for (int i = 0; i < NACTC; ++i) { qpre[i] = delayed_t ? fifo[(size_t)tid * NACTC + i] : R(0); tprev[i] = qpre[i]; }
-        const bool check_default = P.constr_kind == 1;
+        const bool check_default = SLOW ? P.constr_kind >= 1 : P.constr_kind == 1;  // (SLOW: the default constraint or a custom set -- the same thresholds)
         const bool auto_reset = P.auto_reset != 0;
         const R thr_done = check_default ? R(1) : R(INFINITY), thr_reset = (check_default && auto_reset) ? R(1) : R(INFINITY);
         uint32_t bad_action = 0;
@@ -2800,8 +2809,28 @@ void advance_pipe_kernel(const KArgs<R> a) {
                 if constexpr (TAB) {
                     ST::template advance<true, LINABLE, true>(Q, y, ang, sw, act, dact, ho, tab, linc, &hcar);
                 } else {
+                    if constexpr (FIFO && SLOW) {
+                        if (!ns1) { ST::template advance<false, false>(Q, y, ang, sw, act, dact, ho, nullptr, nullptr, &hcar); return; }  // sub-steps
+                    }
                     if (LINABLE && (!FIFO || lin_ok)) ST::template advance<true, LINABLE>(Q, y, ang, sw, act, dact, ho, nullptr, linc);
                     else ST::template advance<true, false>(Q, y, ang, sw, act, dact, ho, nullptr, nullptr, &hcar);
+                }
+            };
+            // custom constraint set (mode 1): constraint_done()'s expressions on the row observe() gives for THIS lane's parameters
+            R gviol = R(0);
+            auto generic_violation = [&](const DevParams<R> &Q) {
+                if constexpr (FIFO && SLOW) {
+                    if (generic_constr) {
+                        R ob[NOUT];
+                        ST::observe(Q, y, ang, ho, ob);
+                        R lim = R(0), sq = R(0);
+#pragma unroll
+                        for (int i = 0; i < NOUT; ++i) {
+                            lim = fmax(lim, P.cw[i] * fabs(ob[i]));  // (wave-uniform addresses: scalar loads)
+                            sq += (P.cw[GEMX_MAX_OUT + i] * ob[i]) * ob[i];
+                        }
+                        gviol = fmax(lim, sq);
+                    }
                 }
             };
             R usup_lane = P.u_sup;
@@ -2816,13 +2845,16 @@ void advance_pipe_kernel(const KArgs<R> a) {
                 }
                 usup_lane = PL.u_sup;
                 run_advance(PL);
+                generic_violation(PL);
                 if (!IL && conv_has_legs<CONV>() && P.rc_supply) sw = ST::legs_of(dact);
             } else {
                 run_advance(P);
+                generic_violation(P);
             }
             // (the wave-uniform switches "default constraint on" / "auto-reset on" live in the two thresholds, not in scalar ANDs of the
             // compare mask: VALU compare -> SALU and -> VALU select sat twice on every step's dependency chain; probe: -3 % integrator cycles)
-            const R viol = ST::state_violation(P, y, ho);
+            R viol = ST::state_violation(P, y, ho);
+            if constexpr (FIFO && SLOW) viol = generic_constr ? gviol : viol;
             const bool done = viol > thr_done;
             constexpr bool COMPACT_ROW = COMPACT_K && TAB;  // (the table-driven copies: modes 0 and 2)
             if constexpr (COMPACT_ROW) {
@@ -3004,7 +3036,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
             // tail blocks of 4 / 8 steps through the unrolled code: deep shape, synchronous machines (the headline's family, where the rolled
             // tail was 1.6 % of a 1000-step launch; every system would gain its 1-1.5 %, at +24 % compile time for the library -- not taken)
             constexpr bool TAIL48 = D == PIPE_D && PIPE_D == 12 && SYS == GEMX_SYS_SYNC;
-            if ((sb == D || (TAIL48 && (sb == 4 || sb == 8))) && P.delay == 0 && (!LINABLE || lin_ok)) {
+            if ((sb == D || (TAIL48 && (sb == 4 || sb == 8))) && P.delay == 0 && (!LINABLE || lin_ok) && !slow_path) {
                 if (sb == D) run_block(std::false_type{}, WholeBlock{});
                 else if constexpr (TAIL48) {
                     if (sb == 8) run_block(std::false_type{}, std::integral_constant<int, 8>{});
@@ -3996,7 +4028,7 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
 // roofline whatever the hand-off depth, their twelve-step unrolled blocks were the most expensive code of the library to compile (a fifth
 // of its build time for 8 of each unit's 60 pipelined instantiations), and <4, 2> / <2, 2> / the FULL form serve every batch size.
 template <int SOLVER> constexpr bool pipe_deep_built() { return SOLVER != GEMX_SOLVER_DP5; }
-// shape index -> kernel (0: <12, 3>, 1: <4, 2>, 2: <2, 2>, 3: <12, 6>, 4: <4, 2> FULL); nullptr for a shape that is not built
+// shape index -> kernel (0: <12, 3>, 1: <4, 2>, 2: <2, 2>, 3: <12, 6>, 4: <4, 2> FULL, 5 / 6: <4, 2> / <4, 2> FULL, SLOW); nullptr for a shape that is not built
 template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> inline void (*pipe_kernel_of(int shape))(const KArgs<R>) {
     if constexpr (pipe_deep_built<SOLVER>()) {
         if (shape == 0) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES>;
@@ -4005,6 +4037,8 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> inline void
     if (shape == 1) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2>;
     if (shape == 2) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D3, PIPE_OUT_WAVES3>;
     if (shape == 4) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2, true>;
+    if (shape == 5) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2, false, true>;
+    if (shape == 6) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2, true, true>;
     return nullptr;
 }
 
@@ -4113,8 +4147,8 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     // (round 5: ANY batch size -- a last workgroup of fewer than 64 envs is handled inside the pipelined kernel (advance_pipe_kernel:
     // full_wg / fast_io), rows that are not 16-byte aligned are moved by the same instructions (unaligned 16-byte accesses are legal);
     // dc_stream_kernel still wants whole workgroups and aligned rows)
-    const bool pipe_ok = h->use_pipe != 0 && K >= 2 && obs_every &&
-                         params_of<R>(h).constr_kind <= 1 && h->cfg.solver_nsteps == 1;
+    const bool pipe_ok = h->use_pipe != 0 && K >= 2 && obs_every;
+    const bool fast_step = params_of<R>(h).constr_kind <= 1 && h->cfg.solver_nsteps == 1;  // (else: the pipelined kernel's rolled copy of the step)
     // RC supply / random initialisers: the FULL instantiation (shape <4, 2> only; see advance_pipe_kernel)
     const bool need_full = h->cfg.supply_kind != GEMX_SUPPLY_IDEAL || h->cfg.init_kind != GEMX_INIT_CONST;
     // (fp32 only: the fp64 build is a diagnostic of the same device functions and takes the single-wave kernel, which keeps its
@@ -4124,7 +4158,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     // PermExDc, us per 1000 steps at 4096 / 8192 / 12288 / 16384 envs: 39 / 41 / 88 / 94 against 71 / 72 / 72 / 72; tools/ab_dc_stream.py)
     if constexpr (sizeof(R) == 4 && LOAD == GEMX_LOAD_CONST_SPEED && !IL &&
                   (SYS == GEMX_SYS_DC_PERMEX || SYS == GEMX_SYS_DC_SERIES || SYS == GEMX_SYS_DC_SHUNT || SYS == GEMX_SYS_DC_EXTEX)) {
-        bool dcs_ok = pipe_ok && !h->cur_synth && (h->n % BLOCK) == 0 && a.coop && a.obs_vec && h->use_dc_stream != 0 && !need_full && delay == 0 && !(h->cfg.solver_flags & GEMX_SOLVER_ADAPTIVE) && h->cur_reward == nullptr && (h->omega_is_init || h->use_dc_stream >= 3) &&
+        bool dcs_ok = pipe_ok && fast_step && !h->cur_synth && (h->n % BLOCK) == 0 && a.coop && a.obs_vec && h->use_dc_stream != 0 && !need_full && delay == 0 && !(h->cfg.solver_flags & GEMX_SOLVER_ADAPTIVE) && h->cur_reward == nullptr && (h->omega_is_init || h->use_dc_stream >= 3) &&
                       params_of<R>(h).obs_layout == GEMX_OBS_AOS && params_of<R>(h).t_il == R(0) &&
                       (h->use_dc_stream > 1 || 2 * blocks <= (int64_t)h->n_cu) && dcs_smem_bytes<SYS, CONV>() <= h->lds_max &&
                       (int64_t)h->n * h->nout * 64 < ((int64_t)1 << 31);  // (SIGNED 32-bit store offsets: lane offsets across the rows of a (double)
@@ -4293,6 +4327,10 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             if (smem_of(PIPE_D2) <= h->lds_max && fits_n) { D = PIPE_D2; OW = PIPE_OUT_WAVES2; shape = 4; }
             else D = 0;
         }
+        if (!fast_step && D != 0) {  // solver sub-steps / a custom constraint set: the SLOW instantiations of <4, 2> (no limiter: integrator-bound)
+            if (smem_of(PIPE_D2) <= h->lds_max) { D = PIPE_D2; OW = PIPE_OUT_WAVES2; shape = need_full ? 6 : 5; }
+            else D = 0;
+        }
         if (D != 0) {
             a.S = D;
             a.D = D;
@@ -4327,7 +4365,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                 constexpr double CAL_SCALE[gemx_handle::PaceCal::NC] = {1.0, 0.93, 1.07, 0.86, 0.0};  // (0: unpaced)
                 auto &pc = h->pcal;
                 cal_slot = -1;
-                const bool cal_eligible = h->pace_cal_on != 0 && h->pace_gbps < 0.0 && target > 0.0 && (blocks > (int64_t)h->n_cu || long_one) && K >= 64 && shape != 3;
+                const bool cal_eligible = h->pace_cal_on != 0 && h->pace_gbps < 0.0 && target > 0.0 && (blocks > (int64_t)h->n_cu || long_one) && K >= 64 && shape != 3 && shape < 5;
                 if (cal_eligible) {
                     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
                     (void)hipStreamIsCapturing(st, &capturing);
@@ -4396,7 +4434,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                     target *= CAL_SCALE[use] * pc.center;
                     pace_scale_used = CAL_SCALE[use] * pc.center;
                 }
-                int64_t res = shape == 4 ? 2 * (int64_t)h->n_cu : resident(D, OW);
+                int64_t res = shape >= 4 ? 2 * (int64_t)h->n_cu : resident(D, OW);
                 // More than four workgroups per CU (the DC machines' small rows) and a launch that needs the LAST slot of every CU to be one round:
                 // count one slot less.  Registers, LDS, wave slots and the occupancy API said seven of the ShuntDc <4, 2> kernel; 114688 envs = 1792
                 // workgroups were priced as one round of 1792 -- and ran 0.41 of the roofline against 0.63 unpaced: whichever workgroups do not
@@ -4405,7 +4443,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                 // with six; profiles/r04final_odd_sizes.txt, r04final_dc_residency.txt.)
                 if (res > 4 * (int64_t)h->n_cu && blocks <= res && blocks > res - (int64_t)h->n_cu) res -= (int64_t)h->n_cu;
                 pace_res = res;
-                if (target > 0.0 && (blocks > (int64_t)h->n_cu || h->pace_gbps > 0.0 || long_one) && K >= 64 && shape != 3) {  // (<12, 6> carries no limiter: see the kernel)
+                if (target > 0.0 && (blocks > (int64_t)h->n_cu || h->pace_gbps > 0.0 || long_one) && K >= 64 && shape != 3 && shape < 5) {  // (<12, 6> carries no limiter: see the kernel; nor do the SLOW ones)
                     const double wg_step_bytes = (double)BLOCK * ((h->cur_synth ? 0 : ABYTES) + h->nout * sizeof(R) + 1 + (h->cur_reward != nullptr ? (h->rw_n_ref + 1) * sizeof(R) : 0));
                     auto ticks_for = [&](double active) {
                         const double t = wg_step_bytes * active / target * D / 10.0;  // bytes / (GB/s) = ns; 10 ns per tick; D rows per block
@@ -4438,7 +4476,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         }
     }
     if (h->cur_synth)  // (only the pipelined kernel's loader wave generates actions; gemx_synthetic_actions writes the same stream for any other path)
-        return fail(GEMX_ERR_ARG, "gemx_rollout_synthetic needs the pipelined kernel: fp32, K >= 2, every step's observations, no custom constraint set, one solver sub-step");
+        return fail(GEMX_ERR_ARG, "gemx_rollout_synthetic needs the pipelined kernel: fp32, K >= 2 (and, with random initial states, at most 4 workgroups per CU)");
     if (K == 1 && h->cur_reward == nullptr && h->use_step_kernel != 0) {  // the closed-loop path: see step_kernel
         // one launch per control step is bound by the HOST's launch path: the function handle is resolved once per handle and the
         // arguments go as one buffer -- 3.36 against 3.55 us per launch through hipLaunchKernelGGL (tools/microbench_launch.hip)
@@ -4462,9 +4500,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         // A fused fp32 rollout that lands HERE runs the single-wave kernel, several times slower than the pipelined one at the same size
         // (round 4 verdict: nothing but gemx_last_launch() told).  Said once per handle, with the reason; GEMX_QUIET=1 silences it.
         h->warned_fallback = true;
-        const char *why = params_of<R>(h).constr_kind > 1 ? "custom constraint set (only none / the env's default constraint are pipelined)"
-                          : h->cfg.solver_nsteps != 1 ? "solver sub-stepping (nsteps > 1)"
-                                                       : "random initial states beyond 4 workgroups per CU, or the LDS footprint of this configuration";
+        const char *why = "random initial states beyond 4 workgroups per CU, or the LDS footprint of this configuration";
         const char *q = getenv("GEMX_QUIET");
         if (q == nullptr || atoi(q) == 0)
             fprintf(stderr, "gemx: note: this handle's fused rollouts run the single-wave fallback kernel (%s); expect a fraction of the pipelined kernel's rate\n", why);

@@ -1526,8 +1526,9 @@ def test_random_initialiser_counters_after_create():
 
 def test_the_single_wave_fallback_says_so_and_unaligned_batches_no_longer_take_it(capfd):
     """Since round 5 EVERY batch size runs the pipelined kernel (rows that are not 16-byte aligned -- n_envs not a multiple of 16 -- go
-    lane by lane through its general I/O paths instead of falling back, 6-8 x slower, to the single-wave kernel).  What still lands on
-    the fallback -- here: a custom constraint set -- says so, once per handle, on stderr (GEMX_QUIET=1 silences it)."""
+    lane by lane through its general I/O paths instead of falling back, 6-8 x slower, to the single-wave kernel), and so do custom
+    constraint sets and solver sub-steps (its rolled copy of the step).  What still lands on the fallback -- random initial states at
+    more than 4 workgroups per CU -- says so, once per handle, on stderr (GEMX_QUIET=1 silences it)."""
     import torch
 
     import gym_electric_motor_amd as ga
@@ -1537,15 +1538,86 @@ def test_the_single_wave_fallback_says_so_and_unaligned_batches_no_longer_take_i
         env.rollout(torch.zeros((8, n), dtype=torch.uint8, device="cuda"))
         assert "advance_pipe_kernel" in env.physical_system.last_launch(), n
         env.close()
+    for kw in (dict(constraints=("i_sq",)), dict(ode_solver=ga.RK4Solver(nsteps=3))):
+        env = ga.make("Finite-CC-PMSM-v0", n_envs=128, **kw)
+        env.rollout(torch.zeros((8, 128), dtype=torch.uint8, device="cuda"))
+        assert "advance_pipe_kernel" in env.physical_system.last_launch(), kw
+        env.close()
     assert "fallback" not in capfd.readouterr().err
-    env = ga.make("Finite-CC-PMSM-v0", n_envs=128, constraints=("i_sq",))
-    acts = torch.zeros((8, 128), dtype=torch.uint8, device="cuda")
+    n = 65600  # 1025 workgroups: one more than 4 per CU
+    env = _init_env("pmsm_sc_uniform", n, seed=3)[0]
+    acts = torch.zeros((8, n, env.physical_system._n_act), dtype=torch.float32, device="cuda")
     env.rollout(acts)
     env.rollout(acts)
     assert "advance_kernel" in env.physical_system.last_launch()
     env.close()
     err = capfd.readouterr().err
-    assert err.count("single-wave fallback kernel") == 1 and "custom constraint set" in err
+    assert err.count("single-wave fallback kernel") == 1 and "random initial states" in err
+
+
+SLOW_STEP_CASES = [
+    # (env id, make kwargs): custom constraint sets and solver sub-steps on the pipelined kernel's rolled copy of the step
+    ("Finite-CC-PMSM-v0", dict(constraints=("i_sq",))),
+    ("Finite-CC-PMSM-v0", dict(constraints=("i_sd", "omega"), solver="rk4x3")),
+    ("Cont-CC-PMSM-v0", dict(solver="euler4")),
+    ("Cont-SC-SCIM-v0", dict(constraints=("i_sa", "i_sb"), solver="rk4x2")),
+    ("Finite-CC-DFIM-v0", dict(solver="rk4x2")),
+    ("Cont-CC-ExtExDc-v0", dict(constraints=("i_a",), solver="dp5")),
+    ("Finite-CC-ShuntDc-v0", dict(solver="euler4", delay=2)),
+    ("Cont-CC-EESM-v0", dict(constraints=("i_e", "i_sq"), delay=1)),
+    ("Cont-TC-SeriesDc-v0", dict(constraints=("i", "torque"), rc=True)),
+    ("Cont-SC-PermExDc-v0", dict(solver="rk4x3", load="poly")),
+]
+
+
+@pytest.mark.parametrize("env_id, opts", SLOW_STEP_CASES, ids=[f"{e}-{'-'.join(f'{k}' for k in o)}" for e, o in SLOW_STEP_CASES])
+@pytest.mark.parametrize("n", [128, 70])
+def test_sub_steps_and_custom_constraints_on_the_pipelined_kernel_bit_for_bit(env_id, opts, n, monkeypatch):
+    """Round 5: solver sub-steps (nsteps > 1) and custom constraint sets run the pipelined kernel (before: the single-wave fallback,
+    6-8 x slower).  Its rolled copy of the step must give the single-wave kernel's bits: observations, terminations, auto-resets,
+    final state -- through dead time, an RC supply, a kinked load, whole and partial workgroups."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    K = 150
+    sol = {"rk4x3": lambda: ga.RK4Solver(nsteps=3), "rk4x2": lambda: ga.RK4Solver(nsteps=2), "euler4": lambda: ga.EulerSolver(nsteps=4),
+           "dp5": lambda: ga.DormandPrince5Solver(nsteps=2)}
+
+    def run(pipe):
+        monkeypatch.setenv("GEMX_PIPE", pipe)
+        kw = dict(n_envs=n)
+        if "constraints" in opts:
+            kw["constraints"] = opts["constraints"]
+        if "solver" in opts:
+            kw["ode_solver"] = sol[opts["solver"]]()
+        if opts.get("rc"):
+            kw["supply"] = ga.RCVoltageSupply(u_nominal=420.0, supply_parameter=dict(R=0.05, C=4e-3))
+        if opts.get("load") == "poly":
+            kw["load"] = ga.PolynomialStaticLoad(load_parameter=dict(a=0.01, b=0.01, c=0.0, j_load=1e-4))
+        if "delay" in opts:
+            kw["physical_system_wrappers"] = (ga.DeadTimeProcessor(steps=opts["delay"]),)
+        env = ga.make(env_id, **kw)
+        ps = env.physical_system
+        g = torch.Generator(device="cuda").manual_seed(17)
+        if ps._discrete:
+            nflat = int(np.prod(ps.action_space.nvec)) if hasattr(ps.action_space, "nvec") else int(ps.action_space.n)
+            acts = torch.randint(0, nflat, (K, n), device="cuda", generator=g, dtype=torch.uint8)
+        else:
+            acts = (torch.rand((K, n, ps._n_act), device="cuda", generator=g, dtype=torch.float64) * 2 - 1).to(ps._tdtype)
+        acts[40:] = acts[40]  # (held from step 40 on: the currents run into their limits, so that the constraint sets terminate episodes)
+        obs, done = env.rollout(acts)
+        assert ("advance_pipe_kernel" in ps.last_launch()) == (pipe == "1"), ps.last_launch()
+        obs2, done2 = env.rollout(acts)  # a second launch: carried state, queue, supply
+        res = (obs.clone(), done.clone(), obs2.clone(), done2.clone(), ps.get_state())
+        env.close()
+        return res
+
+    a, b = run("1"), run("0")
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    if "constraints" in opts:
+        assert a[1].any() or a[3].any(), "no termination in the run: the custom constraint set was not exercised"
 
 
 @pytest.mark.parametrize("env_id, delay, kw", [
@@ -2785,9 +2857,9 @@ def test_synthetic_actions_generated_in_the_launch_equal_the_same_stream_from_a_
 def test_synthetic_rollout_refuses_what_the_pipelined_kernel_does_not_serve():
     import gym_electric_motor_amd as ga
 
-    env = ga.make("Finite-CC-PMSM-v0", n_envs=128, constraints=("i_sq",))  # custom constraint set: single-wave kernel
-    with pytest.raises(ValueError, match="pipelined kernel"):
-        env.rollout_synthetic(16)
+    env = ga.make("Finite-CC-PMSM-v0", n_envs=128, constraints=("i_sq",))  # (a custom constraint set is served since round 5)
+    env.rollout_synthetic(16)
+    assert "advance_pipe_kernel" in env.physical_system.last_launch()
     env.close()
     env = ga.make("Finite-CC-PMSM-v0", n_envs=128, dtype="float64")
     with pytest.raises(ValueError, match="fp32"):

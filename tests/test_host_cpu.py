@@ -683,11 +683,11 @@ def test_register_budget_of_the_bench_kernels():
         for name, vgpr, spilled, scratch, _sg in vr.kernels_of(o):
             found[name.strip("`")] = (vgpr, spilled, scratch)
     budget = {  # kernel -> (VGPRs <=, spilled VGPRs <=, scratch bytes <=)
-        "advance_pipe_kernel<1, 1, 0, 1, false, float, 12, 6, false>": (128, 0, 32),   # headline
-        "advance_pipe_kernel<1, 1, 0, 1, false, float, 12, 3, false>": (168, 0, 32),   # headline, long launches (paced)
-        "advance_pipe_kernel<1, 1, 0, 1, false, float, 4, 2, false>": (128, 0, 0),     # config 5's shard, 1M envs
-        "advance_pipe_kernel<2, 2, 1, 1, false, float, 2, 2, false>": (128, 0, 0),     # config 4
-        "advance_pipe_kernel<2, 2, 1, 2, false, float, 2, 2, false>": (128, 8, 64),    # config 4, error-controlled
+        "advance_pipe_kernel<1, 1, 0, 1, false, float, 12, 6, false, false>": (128, 0, 32),   # headline
+        "advance_pipe_kernel<1, 1, 0, 1, false, float, 12, 3, false, false>": (168, 0, 32),   # headline, long launches (paced)
+        "advance_pipe_kernel<1, 1, 0, 1, false, float, 4, 2, false, false>": (128, 0, 0),     # config 5's shard, 1M envs
+        "advance_pipe_kernel<2, 2, 1, 1, false, float, 2, 2, false, false>": (128, 0, 0),     # config 4
+        "advance_pipe_kernel<2, 2, 1, 2, false, float, 2, 2, false, false>": (128, 8, 64),    # config 4, error-controlled
         "dc_stream_kernel<0, 0, 0, float, 32>": (128, 0, 0),                           # config 2
     }
     for k, (v_max, sp_max, sc_max) in budget.items():
