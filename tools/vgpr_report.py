@@ -47,7 +47,7 @@ def main():
         unit = os.path.basename(obj)[10:-2]
         for name, v, sp, sc, sg in kernels_of(obj):
             n_all += 1
-            shallow = bool(re.search(r"advance_pipe_kernel<.*, (4|2), 2, (false|true)>", name))
+            shallow = bool(re.search(r"advance_pipe_kernel<.*, (4|2), 2, (false|true)(, (false|true))?>", name))
             cliff = 128 < v <= 136 or 168 < v <= 176
             note = []
             if cliff:
