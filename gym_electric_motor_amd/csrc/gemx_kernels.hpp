@@ -2556,6 +2556,15 @@ void advance_pipe_kernel(const KArgs<R> a) {
     // (COMPACT rows, below) by the output waves
     constexpr bool USE_TAB = ST::NVT > 0 && DISCRETE && !FULL;  // (FULL: the supply voltage may differ per lane; the table is built from the uniform one)
     R *vtab = refb + NRBUF * (size_t)D * BLOCK * n_ref;
+    // PREPARED DRAWS (FULL, random initialisers; round 5).  Under random actions some lane of a wave terminates in most control steps, and
+    // the fp64 draw of its fresh initial state (two Philox blocks + the transforms: ~2000 cycles) sat, exec-masked, on the integrator's
+    // instruction stream almost every step.  The draw is a pure function of (env, reset count), so the LOADER wave computes every lane's
+    // NEXT one ahead of time: prep[0 .. ND] = the states (+ angle bits) of count `tag`, written before the tag; the integrator takes the
+    // entry when its tag is rcount + 1 and publishes the new count (`cnt`), else draws inline as before (two resets of a lane within one
+    // loader pass).  One wave's LDS operations complete in order and an entry is rewritten only after its count was consumed, so the
+    // integrator never sees a torn entry; both routes give the same bits.  [ND + 1][64] values | tag[64] | cnt[64]
+    volatile uint32_t *prep = reinterpret_cast<volatile uint32_t *>(vtab + ((ST::NVT > 0 && DISCRETE) ? ConvTraits<CONV>::NACTIONS * 8 : 0));
+    volatile uint32_t *prep_tag = prep + (ND + 1) * BLOCK, *prep_cnt = prep_tag + BLOCK;
     // COMPACT hand-off rows (synchronous machines behind a finite converter and a constant-speed load: the headline): the integrator's
     // time per step is dominated by its LDS instructions (~25 cycles of issue apiece against ~5 for a VALU instruction: six of them were
     // 150 of the step's 320 cycles), so the blocks that run on the voltage table and the one-step map hand over EIGHT values instead of
@@ -2679,7 +2688,11 @@ void advance_pipe_kernel(const KArgs<R> a) {
                 sup[0] = a.state[(int64_t)ND * N + envc];
                 sup[1] = a.state[(int64_t)(ND + 1) * N + envc];
             }
-            if (P.init_kind) rcount = a.rcnt[envc];
+            if (P.init_kind) {
+                rcount = a.rcnt[envc];
+                prep_cnt[tid] = rcount;
+                prep_tag[tid] = 0u;  // (counts start at 1: no entry)
+            }
         }
         R hcar = R(0);  // error-controlled solver: the step size its controller proposed last (state row ND + 2), see dp5_adaptive
         if (SOLVER == GEMX_SOLVER_DP5 && P.adaptive) hcar = a.state[(int64_t)(ND + 2) * N + envc];
@@ -2698,7 +2711,8 @@ void advance_pipe_kernel(const KArgs<R> a) {
         // SLOW: solver sub-steps and custom constraint sets -- every block takes mode 1 (see the kernel's head)
         const bool ns1 = !SLOW || P.nsteps == 1;
         const bool generic_constr = SLOW && P.constr_kind == 2;
-        const bool slow_path = !ns1 || generic_constr;                                                       // wave-uniform
+        constexpr bool slow_path = SLOW;  // (the launcher takes a SLOW instantiation exactly when nsteps != 1 or constr_kind == 2: its unrolled
+                                          // copies of the step are never run and, behind this constant, never compiled)
         const bool delayed_any = CAN_DELAY && P.delay > 0 && (!LINABLE || lin_ok) && !slow_path;            // wave-uniform
         const bool delayed_t = delayed_any && conv_dq<CONV>() && P.dq_processor;  // queue of TRANSFORMED actions (row buffer, see one_step)
         const bool delayed = delayed_any && !delayed_t;                           // delayed read of the staged raw rows
@@ -2887,7 +2901,17 @@ void advance_pipe_kernel(const KArgs<R> a) {
             ang = rs ? init_ang_v : ang;
             if constexpr (SOLVER == GEMX_SOLVER_DP5) hcar = rs ? R(0) : hcar;
             if constexpr (FULL) {
-                if (rs && P.init_kind) draw_initial_state_cnt<SYS, R>(a.rinit, envc, rcount, y, ang);  // (rare: exec-masked, skipped wave-wide)
+                if (rs && P.init_kind) {  // (exec-masked, skipped wave-wide)
+                    if (prep_tag[tid] == rcount + 1u) {  // the loader wave's prepared draw of this count
+#pragma unroll
+                        for (int j = 0; j < ND; ++j) { const uint32_t w = prep[j * BLOCK + tid]; memcpy(&y[j], &w, sizeof(R)); }
+                        if (HAS_ANGLE) { const uint32_t w = prep[ND * BLOCK + tid]; memcpy(&ang, &w, sizeof(R)); }
+                        rcount += 1u;
+                    } else {
+                        draw_initial_state_cnt<SYS, R>(a.rinit, envc, rcount, y, ang);
+                    }
+                    prep_cnt[tid] = rcount;
+                }
                 sup[0] = rs ? P.u_sup : sup[0];  // RCVoltageSupply.reset: the capacitor is loaded again, the supply's clock restarts
                 sup[1] = rs ? R(0) : sup[1];
             }
@@ -3229,6 +3253,21 @@ void advance_pipe_kernel(const KArgs<R> a) {
             if (issued) {
                 stage_actions(b + AHEAD);
                 if (n_ref > 0) stage_refs(b + AHEAD);
+            }
+            if constexpr (FULL) {
+                if (P.init_kind) {  // prepared draws (see `prep`): the next initial state of every lane whose entry was consumed
+                    const uint32_t c = prep_cnt[tid];
+                    if (prep_tag[tid] != c + 1u) {
+                        R yd[ND];
+                        AngT angd = AngT(0);
+                        uint32_t cc = c;
+                        draw_initial_state_cnt<SYS, R>(a.rinit, envc, cc, yd, angd);
+#pragma unroll
+                        for (int j = 0; j < ND; ++j) { uint32_t w; memcpy(&w, &yd[j], sizeof(R)); prep[j * BLOCK + tid] = w; }
+                        if (HAS_ANGLE) { uint32_t w; memcpy(&w, &angd, sizeof(R)); prep[ND * BLOCK + tid] = w; }
+                        prep_tag[tid] = cc;
+                    }
+                }
             }
             if (DISCRETE) {
                 const unsigned char *rows = actb + (size_t)(b % NBUF) * DP * ROWB;
@@ -4206,6 +4245,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             b += pipe_act_bufs(D) * (size_t)((D + 3) / 4 * 4) * BLOCK * ABYTES;  // action staging (global -> LDS direct, one or two blocks ahead)
             if (h->cur_reward != nullptr) b += pipe_ref_bufs(D) * (size_t)D * BLOCK * h->rw_n_ref * sizeof(R);  // reference staging for the fused reward
             if (ST::NVT > 0 && ConvTraits<CONV>::DISCRETE) b += (size_t)ConvTraits<CONV>::NACTIONS * 8 * sizeof(R);  // per-action voltage table
+            if (need_full) b += (size_t)(SysTraits<SYS>::ND + 3) * BLOCK * sizeof(uint32_t);                         // prepared draws (random initialisers)
             return (b + 15) & ~(size_t)15;
         };
         // workgroups of a shape one CU holds: LDS, wave slots -- and REGISTERS (round 4: the arithmetic used to stop at the first two and

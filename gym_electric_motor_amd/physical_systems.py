@@ -938,7 +938,7 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         solvers.py:44-45, converters.py:193-197, dead_time_processor.py:63-72, voltage_supplies.py:100-123."""
         torch = _torch()
         nb = int(self._L.gemx_aux_state_bytes(self._handle))
-        aux = torch.empty(nb, dtype=torch.uint8, device=self._tdev)
+        aux = torch.zeros(nb, dtype=torch.uint8, device=self._tdev)  # (zeros: the sections' padding is not written -- equal states, equal blobs)
         _lib.check(self._L.gemx_get_aux_state(self._handle, C.c_void_p(aux.data_ptr()), self._stream()))
         return {"state": self.get_state(), "switch_state": self.get_switch_state(), "aux": aux, "k": int(self._k)}
 

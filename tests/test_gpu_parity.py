@@ -1555,6 +1555,41 @@ def test_the_single_wave_fallback_says_so_and_unaligned_batches_no_longer_take_i
     assert err.count("single-wave fallback kernel") == 1 and "random initial states" in err
 
 
+@pytest.mark.parametrize("case", ["pmsm_sc_uniform", "permexdc_sc_gauss", "extex_cc_uniform_interval", "eesm_sc_uniform", "scim_sc_uniform",
+                                  "scim_cc_negspeed_uniform", "dfim_cc_negspeed_interval_uniform"])
+@pytest.mark.parametrize("n", [70, 4096])
+def test_prepared_draws_of_the_loader_wave_give_the_inline_draws_bits(case, n, monkeypatch):
+    """Round 5: in the FULL pipelined kernel the loader wave computes every lane's NEXT random initial state ahead of time (a pure function
+    of (env, reset count)); the integrator takes the prepared entry at a reset and draws inline only when a lane resets again before the
+    loader's next pass.  Either way the bits are those of the single-wave kernel, which always draws inline: observations, terminations,
+    states and reset counters, over launches with many terminations (held actions drive the currents into their limits)."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    K = 400
+
+    def run(pipe):
+        monkeypatch.setenv("GEMX_PIPE", pipe)
+        env = _init_env(case, n, seed=13)[0]
+        ps = env.physical_system
+        g = torch.Generator(device="cuda").manual_seed(23)
+        acts = (torch.rand((K, n, ps._n_act), device="cuda", generator=g, dtype=torch.float64) * 2 - 1).to(ps._tdtype)
+        acts[20:] = acts[20]  # held: every env runs into a limit again and again
+        obs, done = env.rollout(acts)
+        assert ("advance_pipe_kernel" in ps.last_launch()) == (pipe == "1"), ps.last_launch()
+        obs2, done2 = env.rollout(acts[:37])  # (a launch whose last block is partial)
+        res = (obs.clone(), done.clone(), obs2.clone(), done2.clone(), ps.get_state(), ps.get_checkpoint()["aux"].clone())  # (aux: the reset counters)
+        env.close()
+        return res
+
+    a, b = run("1"), run("0")
+    for x, y in zip(a, b):
+        assert torch.equal(x.cpu(), y.cpu())
+    per_env = a[1].sum(dim=0)
+    assert int(per_env.max()) >= 3 and float((per_env > 0).float().mean()) > 0.2, "too few terminations to exercise the reset path"
+
+
 SLOW_STEP_CASES = [
     # (env id, make kwargs): custom constraint sets and solver sub-steps on the pipelined kernel's rolled copy of the step
     ("Finite-CC-PMSM-v0", dict(constraints=("i_sq",))),

@@ -19,5 +19,6 @@ for n in (16384, 32768, 65536, 131072):
             for _ in range(5): ps.rollout(acts, obs_out=obs, done_out=done)
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1)/5
-            print(f"{label:6s} N={n:7d} GEMX_PIPE={pipe}: {n*K/ms/1e6:7.1f} G env-steps/s  {ps.last_launch().split(' grid')[0]}", flush=True)
+            dr = float(done.float().mean())  # terminations per env-step; per wave-step: 1 - (1 - dr)^64
+            print(f"{label:6s} N={n:7d} GEMX_PIPE={pipe}: {n*K/ms/1e6:7.1f} G env-steps/s  done rate {dr:.4f} (a wave resets in {1 - (1 - dr) ** 64:.2f} of its steps)  {ps.last_launch().split(' grid')[0]}", flush=True)
             env.close()
