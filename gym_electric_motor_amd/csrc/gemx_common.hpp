@@ -291,13 +291,18 @@ __device__ __forceinline__ double init_state_from_uniform(const InitDev *I, int 
     const double x = I->mu[j] + I->sigma[j] * inv_norm_cdf(I->cdf_lo[j] + (I->cdf_hi[j] - I->cdf_lo[j]) * u);
     return fmin(fmax(x, I->lo[j]), I->hi[j]);
 }
-// all (<= 8) uniforms of one (env, reset count): two Philox blocks
-__device__ __forceinline__ void init_uniforms(const InitDev *I, int64_t env, uint32_t count, double (&u)[GEMX_MAX_ODE]) {
-    uint32_t r0[4], r1[4];
-    Philox::block(I->seed, (uint64_t)env, count, 0u, r0);
-    Philox::block(I->seed, (uint64_t)env, count, 1u, r1);
+// all (<= 8) uniforms of one (env, reset count): two Philox blocks -- the second one only where something reads it (more than four ODE
+// states, or the induction machines' field angle, uniform 7); wave-uniform
+__device__ __forceinline__ bool init_needs_block1(const InitDev *I) { return I->n > 4 || I->flux_mode != 0; }
+__device__ __forceinline__ void init_uniforms_from(const uint32_t (&r0)[4], const uint32_t (&r1)[4], double (&u)[GEMX_MAX_ODE]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { u[i] = Philox::u01(r0[i]); u[4 + i] = Philox::u01(r1[i]); }
+}
+__device__ __forceinline__ void init_uniforms(const InitDev *I, int64_t env, uint32_t count, double (&u)[GEMX_MAX_ODE]) {
+    uint32_t r0[4], r1[4] = {0u, 0u, 0u, 0u};
+    Philox::block(I->seed, (uint64_t)env, count, 0u, r0);
+    if (init_needs_block1(I)) Philox::block(I->seed, (uint64_t)env, count, 1u, r1);
+    init_uniforms_from(r0, r1, u);
 }
 // one state from its uniform with explicit bounds (the induction machines' per-reset flux bounds)
 __device__ __forceinline__ double init_draw_bounded(const InitDev *I, int j, double lo, double hi, double u) {
@@ -314,10 +319,11 @@ __device__ __forceinline__ double init_draw_bounded(const InitDev *I, int j, dou
 // PREVIOUS reset's draw (the reference reads the motor's stale _initial_states; the counter-based stream lets the kernel recompute
 // them instead of storing them) --, flux bounds +-psi_d_max (|cos|, |sin|) clipped to the user's interval.
 // FLUX: compiled in for the induction-machine systems only (the code sits in every kernel's auto-reset path).
-template <bool FLUX>
-__device__ __forceinline__ void init_draw_all(const InitDev *I, int64_t env, uint32_t count, double (&out)[GEMX_MAX_ODE]) {
-    double u[GEMX_MAX_ODE];
-    init_uniforms(I, env, count, u);
+// `init_draw_from`: the draw from its uniforms -- `u` of (env, count) and, where the induction machines read the previous reset's currents
+// (count > 1, omega != 0), `up` of (env, count - 1), fetched through `prev` only then.  The pipelined kernel's loader wave computes the
+// Philox blocks one per pass and finishes with this (prepared draws); init_draw_all is the draw in one go.
+template <bool FLUX, class Prev>
+__device__ __forceinline__ void init_draw_from(const InitDev *I, uint32_t count, const double (&u)[GEMX_MAX_ODE], Prev prev, double (&out)[GEMX_MAX_ODE]) {
     for (int j = 0; j < I->n && j < GEMX_MAX_ODE; ++j) out[j] = init_state_from_uniform(I, j, u[j]);
     if (FLUX && I->flux_mode) {
         const int fs = I->flux_slot;  // slots fs - 2, fs - 1: i_s alpha, i_s beta
@@ -328,7 +334,7 @@ __device__ __forceinline__ void init_draw_all(const InitDev *I, int64_t env, uin
             double ia = I->constant[fs - 2], ib = I->constant[fs - 1];
             if (count > 1u) {
                 double up[GEMX_MAX_ODE];
-                init_uniforms(I, env, count - 1u, up);
+                prev(up);
                 ia = init_state_from_uniform(I, fs - 2, up[fs - 2]);
                 ib = init_state_from_uniform(I, fs - 1, up[fs - 1]);
             }
@@ -340,6 +346,12 @@ __device__ __forceinline__ void init_draw_all(const InitDev *I, int64_t env, uin
         out[fs] = init_draw_bounded(I, fs, fmax(-ha, I->lo[fs]), fmin(ha, I->hi[fs]), u[fs]);
         out[fs + 1] = init_draw_bounded(I, fs + 1, fmax(-hb, I->lo[fs + 1]), fmin(hb, I->hi[fs + 1]), u[fs + 1]);
     }
+}
+template <bool FLUX>
+__device__ __forceinline__ void init_draw_all(const InitDev *I, int64_t env, uint32_t count, double (&out)[GEMX_MAX_ODE]) {
+    double u[GEMX_MAX_ODE];
+    init_uniforms(I, env, count, u);
+    init_draw_from<FLUX>(I, count, u, [&](double (&up)[GEMX_MAX_ODE]) { init_uniforms(I, env, count - 1u, up); }, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -576,9 +588,9 @@ struct gemx_handle {
     int pace_cal_on = 1;  // GEMX_PACE_CAL
     double pace_scale_last = 1.0;  // factor on the built-in target the last paced launch ran at (0: unpaced)
     int pace_cal_state = 0;        // of the last launch: 0 no calibration, 1 a calibration launch, 2 calibrated
-    size_t pipe_occ_smem[4] = {0, 0, 0, 0};
-    int pipe_occ[4] = {0, 0, 0, 0};   // ... and the workgroups per CU the runtime reports for it with this handle's LDS bytes (occupancy API, once)
-    int pipe_regs[4] = {0, 0, 0, 0};  // VGPRs of the pipelined kernel's shape k (hipFuncGetAttributes, once): the launcher's residency arithmetic
+    size_t pipe_occ_smem[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int pipe_occ[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ... and the workgroups per CU the runtime reports for it with this handle's LDS bytes (occupancy API, once)
+    int pipe_regs[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // VGPRs of the pipelined kernel's shape k (hipFuncGetAttributes, once): the launcher's residency arithmetic
     unsigned pipe_attr_set = 0;  // bit k: hipFuncSetAttribute(max dynamic LDS) done for pipelined shape k (per handle = per device:
     bool attr_set = false;       //   the attribute is per device, and a handle is bound to one device and one kernel instantiation)
     int wg_per_cu = 0;           // single-wave kernel: resident workgroups per CU from its VGPR count (0: not queried yet)

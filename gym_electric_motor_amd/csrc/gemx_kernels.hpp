@@ -2486,6 +2486,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs<R> a) {
 #ifndef GEMX_PACE_DEFAULT_ON
 #define GEMX_PACE_DEFAULT_ON 1
 #endif
+constexpr int PREP_Q = 4;  // prepared draws per lane (FULL pipelined kernel, random initialisers)
+#ifndef GEMX_PREP_DRAWS
+#define GEMX_PREP_DRAWS 1  // (0: A/B builds -- every reset draws inline)
+#endif
 template <int SYS, int SOLVER, bool IL, int D, bool FULL, bool SLOW = false> constexpr int pipe_waves_per_eu() {
     return (D <= 4 && !FULL && !SLOW && SYS != GEMX_SYS_DFIM && !(SOLVER == GEMX_SOLVER_DP5 && IL)) ? 4 : 1;
 }
@@ -2494,7 +2498,9 @@ template <int SYS, int SOLVER, bool IL, int D, bool FULL, bool SLOW = false> con
 // weighted Limit / Squared constraint on an observation row it computes for that purpose.  A separate instantiation because that code
 // inside the common kernels cost them registers (config 4's <4, 2>: 119 VGPRs -> 128 with 10 spills); with SLOW = false the kernel
 // is what it was.
-template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R, int D, int OW, bool FULL = false, bool SLOW = false>
+// RINIT (round 5; with FULL only): random initial states.  The FULL kernel without it serves the RC supply alone and carries no draw code
+// at all (the prepared-draw code inside one shared kernel cost the RC-supply launches 15 % of their rate, same box).
+template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R, int D, int OW, bool FULL = false, bool SLOW = false, bool RINIT = false>
 __global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) __attribute__((amdgpu_waves_per_eu(pipe_waves_per_eu<SYS, SOLVER, IL, D, FULL, SLOW>())))
 void advance_pipe_kernel(const KArgs<R> a) {
     constexpr int LW = pipe_loader_waves(D);  // 1: a loader wave stages actions / references instead of the integrator
@@ -2556,15 +2562,23 @@ void advance_pipe_kernel(const KArgs<R> a) {
     // (COMPACT rows, below) by the output waves
     constexpr bool USE_TAB = ST::NVT > 0 && DISCRETE && !FULL;  // (FULL: the supply voltage may differ per lane; the table is built from the uniform one)
     R *vtab = refb + NRBUF * (size_t)D * BLOCK * n_ref;
-    // PREPARED DRAWS (FULL, random initialisers; round 5).  Under random actions some lane of a wave terminates in most control steps, and
-    // the fp64 draw of its fresh initial state (two Philox blocks + the transforms: ~2000 cycles) sat, exec-masked, on the integrator's
-    // instruction stream almost every step.  The draw is a pure function of (env, reset count), so the LOADER wave computes every lane's
-    // NEXT one ahead of time: prep[0 .. ND] = the states (+ angle bits) of count `tag`, written before the tag; the integrator takes the
-    // entry when its tag is rcount + 1 and publishes the new count (`cnt`), else draws inline as before (two resets of a lane within one
-    // loader pass).  One wave's LDS operations complete in order and an entry is rewritten only after its count was consumed, so the
-    // integrator never sees a torn entry; both routes give the same bits.  [ND + 1][64] values | tag[64] | cnt[64]
-    volatile uint32_t *prep = reinterpret_cast<volatile uint32_t *>(vtab + ((ST::NVT > 0 && DISCRETE) ? ConvTraits<CONV>::NACTIONS * 8 : 0));
-    volatile uint32_t *prep_tag = prep + (ND + 1) * BLOCK, *prep_cnt = prep_tag + BLOCK;
+    // PREPARED DRAWS (FULL, random initialisers; round 5).  Under random actions some lane of a wave terminates in most control steps (PMSM,
+    // 2.3 % of the env-steps: 78 % of a wave's steps), and the fp64 draw of its fresh initial state (Philox blocks + the transforms: 1100-
+    // 3500 cycles) sat, exec-masked, on the integrator's instruction stream nearly every step.  The draw is a pure function of (env,
+    // reset count), so the LOADER wave computes every lane's next PREP_Q draws ahead of time into a per-lane queue: entry of count c in
+    // slot c % PREP_Q = eight dwords [states.., angle bits, .., tag = c], the tag written last.  The integrator keeps the entry of
+    // rcount + 1 in registers (read at every block start and after every consumption -- tag half first; LDS operations of a wave complete
+    // in order and the loader rewrites a slot only after its count was consumed, so no torn entry is ever taken), takes it at a reset and
+    // publishes the new count (`prep_cnt`); a lane that outruns its queue draws inline as before.  Both routes give the same bits.
+    // [PREP_Q][64][8] dwords | cnt[64]
+    // (pointers in the LDS address space, explicitly: address-space inference does not rewrite VOLATILE accesses, and as flat_load /
+    // flat_store -- which count on vmcnt AND lgkmcnt -- these cost the RC-supply launches of the same kernel 15 % of their rate)
+    typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+    typedef volatile __attribute__((address_space(3))) uint32_t lds_u32_t;
+    typedef volatile __attribute__((address_space(3))) u4_t lds_u4_t;
+    lds_u32_t *prep = (lds_u32_t *)reinterpret_cast<uint32_t *>(vtab + ((ST::NVT > 0 && DISCRETE) ? ConvTraits<CONV>::NACTIONS * 8 : 0));
+    lds_u32_t *prep_cnt = prep + (size_t)PREP_Q * BLOCK * 8;
+    static_assert(ND + 1 <= 7, "a prepared draw is eight dwords: states, angle, tag");
     // COMPACT hand-off rows (synchronous machines behind a finite converter and a constant-speed load: the headline): the integrator's
     // time per step is dominated by its LDS instructions (~25 cycles of issue apiece against ~5 for a VALU instruction: six of them were
     // 150 of the step's 320 cycles), so the blocks that run on the voltage table and the one-step map hand over EIGHT values instead of
@@ -2688,10 +2702,11 @@ void advance_pipe_kernel(const KArgs<R> a) {
                 sup[0] = a.state[(int64_t)ND * N + envc];
                 sup[1] = a.state[(int64_t)(ND + 1) * N + envc];
             }
-            if (P.init_kind) {
+            if constexpr (RINIT) {
                 rcount = a.rcnt[envc];
                 prep_cnt[tid] = rcount;
-                prep_tag[tid] = 0u;  // (counts start at 1: no entry)
+#pragma unroll
+                for (int q = 0; q < PREP_Q; ++q) prep[((size_t)q * BLOCK + tid) * 8 + 7] = 0u;  // (counts start at 1: tag 0 = no entry)
             }
         }
         R hcar = R(0);  // error-controlled solver: the step size its controller proposed last (state row ND + 2), see dp5_adaptive
@@ -2742,6 +2757,15 @@ void advance_pipe_kernel(const KArgs<R> a) {
         const bool auto_reset = P.auto_reset != 0;
         const R thr_done = check_default ? R(1) : R(INFINITY), thr_reset = (check_default && auto_reset) ? R(1) : R(INFINITY);
         uint32_t bad_action = 0;
+        // prepared draws (FULL, random initialisers): the queue entry of rcount + 1, tag in pre_hi.w (see `prep`)
+        u4_t pre_lo = {0u, 0u, 0u, 0u}, pre_hi = {0u, 0u, 0u, 0u};
+        auto prefetch_draw = [&]() {
+            if constexpr (FULL && RINIT && GEMX_PREP_DRAWS != 0) {
+                lds_u4_t *e = (lds_u4_t *)(prep + ((size_t)((rcount + 1u) % PREP_Q) * BLOCK + tid) * 8);
+                pre_hi = e[1];  // (the tag's half first: a valid tag implies the other half was written before it)
+                pre_lo = e[0];
+            }
+        };
         if constexpr (USE_TAB) {  // (written and read by this wave only: LDS operations of one wave complete in order)
             if (tid < ConvTraits<CONV>::NACTIONS) {
                 R e[8];
@@ -2901,16 +2925,18 @@ void advance_pipe_kernel(const KArgs<R> a) {
             ang = rs ? init_ang_v : ang;
             if constexpr (SOLVER == GEMX_SOLVER_DP5) hcar = rs ? R(0) : hcar;
             if constexpr (FULL) {
-                if (rs && P.init_kind) {  // (exec-masked, skipped wave-wide)
-                    if (prep_tag[tid] == rcount + 1u) {  // the loader wave's prepared draw of this count
+                if constexpr (RINIT) if (rs) {  // (exec-masked, skipped wave-wide)
+                    if (GEMX_PREP_DRAWS != 0 && pre_hi.w == rcount + 1u) {  // the loader wave's prepared draw of this count, in registers since the block's start
+                        const uint32_t w8[8] = {pre_lo.x, pre_lo.y, pre_lo.z, pre_lo.w, pre_hi.x, pre_hi.y, pre_hi.z, pre_hi.w};
 #pragma unroll
-                        for (int j = 0; j < ND; ++j) { const uint32_t w = prep[j * BLOCK + tid]; memcpy(&y[j], &w, sizeof(R)); }
-                        if (HAS_ANGLE) { const uint32_t w = prep[ND * BLOCK + tid]; memcpy(&ang, &w, sizeof(R)); }
+                        for (int j = 0; j < ND; ++j) memcpy(&y[j], &w8[j], sizeof(R));
+                        if (HAS_ANGLE) memcpy(&ang, &w8[ND], sizeof(R));
                         rcount += 1u;
                     } else {
                         draw_initial_state_cnt<SYS, R>(a.rinit, envc, rcount, y, ang);
                     }
-                    prep_cnt[tid] = rcount;
+                    if (GEMX_PREP_DRAWS != 0) prep_cnt[tid] = rcount;
+                    prefetch_draw();  // the next count's entry (its latency ends long before the next step's reset test)
                 }
                 sup[0] = rs ? P.u_sup : sup[0];  // RCVoltageSupply.reset: the capacitor is loaded again, the supply's clock restarts
                 sup[1] = rs ? R(0) : sup[1];
@@ -2965,6 +2991,9 @@ void advance_pipe_kernel(const KArgs<R> a) {
 #ifdef GEMX_TIMING
             t0 = clock64();
 #endif
+            if constexpr (FULL) {
+                if constexpr (RINIT) prefetch_draw();  // (what the loader wave has prepared since)
+            }
             const int sb = steps_of(b);
             R *hb = hand + (size_t)(b & 1) * D * BLOCK * NHT + (size_t)tid * NHT;
             // block b's actions (and, the first time, the state) have landed: staged a whole block ago.  Only THEN issue the next
@@ -3198,7 +3227,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
                     a.state[(int64_t)ND * N + env] = sup[0];
                     a.state[(int64_t)(ND + 1) * N + env] = sup[1];
                 }
-                if (P.init_kind) a.rcnt[env] = rcount;
+                if constexpr (RINIT) a.rcnt[env] = rcount;
             }
             if (SOLVER == GEMX_SOLVER_DP5 && P.adaptive) a.state[(int64_t)(ND + 2) * N + env] = hcar;
             int phase_end = 0;
@@ -3236,6 +3265,10 @@ void advance_pipe_kernel(const KArgs<R> a) {
         unsigned long long tl = 0, tb = 0;
 #endif
         uint32_t bad = 0;
+        // prepared draws (FULL, random initialisers): the Philox blocks of the draw in progress, its count, the lanes it is for
+        uint32_t pq0[4] = {0u, 0u, 0u, 0u}, pq1[4] = {0u, 0u, 0u, 0u}, pp0[4] = {0u, 0u, 0u, 0u}, pp1[4] = {0u, 0u, 0u, 0u}, prep_c = 0u;
+        bool prep_act = false;
+        int prep_phase = 0;  // wave-uniform
         if (DISCRETE) __syncthreads();
         // (Staging TWO blocks ahead through a third buffer was tried in round 2 -- the s_memtime probe shows this wave's loads taking longer
         // than the integrator's block in the shallow shapes -- and changed nothing, same box, over all motor families:
@@ -3254,18 +3287,53 @@ void advance_pipe_kernel(const KArgs<R> a) {
                 stage_actions(b + AHEAD);
                 if (n_ref > 0) stage_refs(b + AHEAD);
             }
-            if constexpr (FULL) {
-                if (P.init_kind) {  // prepared draws (see `prep`): the next initial state of every lane whose entry was consumed
-                    const uint32_t c = prep_cnt[tid];
-                    if (prep_tag[tid] != c + 1u) {
-                        R yd[ND];
-                        AngT angd = AngT(0);
-                        uint32_t cc = c;
-                        draw_initial_state_cnt<SYS, R>(a.rinit, envc, cc, yd, angd);
+            if constexpr (FULL && RINIT && GEMX_PREP_DRAWS != 0) {
+                {
+                    // prepared draws (see `prep`): the next initial state of every lane whose entry was consumed -- ONE Philox block per pass
+                    // (~900 cycles: forty quarter-rate multiplies), so that this wave still reaches the block's barrier before the
+                    // integrator does; the whole draw in one pass (~2000-3500 cycles) made it the slowest wave of a block wherever the
+                    // integrator runs on its one-step map (PMSM, 32768 envs: 41 G env-steps/s against 89 G without random initial states).
+                    constexpr bool FLUX = SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM;
+                    const InitDev *I = a.rinit;
+                    const bool blk1 = init_needs_block1(I), fprev = FLUX && I->flux_mode != 0;
+                    if (prep_phase == 0) {  // scan: the first of the next PREP_Q counts whose slot does not hold it; lanes with a full queue sit out
+                        const uint32_t c = prep_cnt[tid];
+                        prep_act = false;
+                        prep_c = c;
 #pragma unroll
-                        for (int j = 0; j < ND; ++j) { uint32_t w; memcpy(&w, &yd[j], sizeof(R)); prep[j * BLOCK + tid] = w; }
-                        if (HAS_ANGLE) { uint32_t w; memcpy(&w, &angd, sizeof(R)); prep[ND * BLOCK + tid] = w; }
-                        prep_tag[tid] = cc;
+                        for (int q = PREP_Q; q >= 1; --q) {
+                            const uint32_t w = c + (uint32_t)q;
+                            if (prep[((size_t)(w % PREP_Q) * BLOCK + tid) * 8 + 7] != w) { prep_act = true; prep_c = w - 1u; }
+                        }
+                        if (__any(prep_act)) prep_phase = 1;
+                    }
+                    if (prep_phase == 1) {
+                        Philox::block(I->seed, (uint64_t)envc, prep_c + 1u, 0u, pq0);
+                        prep_phase = blk1 ? 2 : (fprev ? 3 : 5);
+                    } else if (prep_phase == 2) {
+                        Philox::block(I->seed, (uint64_t)envc, prep_c + 1u, 1u, pq1);
+                        prep_phase = fprev ? 3 : 5;
+                    } else if (prep_phase == 3) {  // the induction machines' previous draw (its stator currents bound this one's flux)
+                        Philox::block(I->seed, (uint64_t)envc, prep_c, 0u, pp0);
+                        prep_phase = I->flux_slot > 4 ? 4 : 5;  // (the currents' uniforms, slots flux_slot - 2 and - 1, sit in block 0 for every machine built)
+                    } else if (prep_phase == 4) {
+                        Philox::block(I->seed, (uint64_t)envc, prep_c, 1u, pp1);
+                        prep_phase = 5;
+                    } else if (prep_phase == 5) {
+                        if (prep_act) {
+                            double u[GEMX_MAX_ODE], v[GEMX_MAX_ODE];
+                            init_uniforms_from(pq0, pq1, u);
+                            init_draw_from<FLUX>(I, prep_c + 1u, u, [&](double (&up)[GEMX_MAX_ODE]) { init_uniforms_from(pp0, pp1, up); }, v);
+                            uint32_t w8[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+                            for (int j = 0; j < ND; ++j) { const R x = (R)v[j]; memcpy(&w8[j], &x, sizeof(R)); }
+                            if (HAS_ANGLE) { const AngT ad = Angle<R>::from_rad(v[ND]); memcpy(&w8[ND], &ad, sizeof(R)); }
+                            w8[7] = prep_c + 1u;
+                            lds_u4_t *e = (lds_u4_t *)(prep + ((size_t)((prep_c + 1u) % PREP_Q) * BLOCK + tid) * 8);
+                            e[0] = u4_t{w8[0], w8[1], w8[2], w8[3]};
+                            e[1] = u4_t{w8[4], w8[5], w8[6], w8[7]};  // (the tag's half last)
+                        }
+                        prep_phase = 0;
                     }
                 }
             }
@@ -4067,7 +4135,8 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
 // roofline whatever the hand-off depth, their twelve-step unrolled blocks were the most expensive code of the library to compile (a fifth
 // of its build time for 8 of each unit's 60 pipelined instantiations), and <4, 2> / <2, 2> / the FULL form serve every batch size.
 template <int SOLVER> constexpr bool pipe_deep_built() { return SOLVER != GEMX_SOLVER_DP5; }
-// shape index -> kernel (0: <12, 3>, 1: <4, 2>, 2: <2, 2>, 3: <12, 6>, 4: <4, 2> FULL, 5 / 6: <4, 2> / <4, 2> FULL, SLOW); nullptr for a shape that is not built
+// shape index -> kernel (0: <12, 3>, 1: <4, 2>, 2: <2, 2>, 3: <12, 6>, 4: <4, 2> FULL, 5 / 6: <4, 2> / <4, 2> FULL, SLOW, 7: <4, 2> FULL RINIT); nullptr for a
+// shape that is not built
 template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> inline void (*pipe_kernel_of(int shape))(const KArgs<R>) {
     if constexpr (pipe_deep_built<SOLVER>()) {
         if (shape == 0) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES>;
@@ -4078,6 +4147,7 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> inline void
     if (shape == 4) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2, true>;
     if (shape == 5) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2, false, true>;
     if (shape == 6) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2, true, true>;
+    if (shape == 7) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2, true, false, true>;
     return nullptr;
 }
 
@@ -4245,7 +4315,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             b += pipe_act_bufs(D) * (size_t)((D + 3) / 4 * 4) * BLOCK * ABYTES;  // action staging (global -> LDS direct, one or two blocks ahead)
             if (h->cur_reward != nullptr) b += pipe_ref_bufs(D) * (size_t)D * BLOCK * h->rw_n_ref * sizeof(R);  // reference staging for the fused reward
             if (ST::NVT > 0 && ConvTraits<CONV>::DISCRETE) b += (size_t)ConvTraits<CONV>::NACTIONS * 8 * sizeof(R);  // per-action voltage table
-            if (need_full) b += (size_t)(SysTraits<SYS>::ND + 3) * BLOCK * sizeof(uint32_t);                         // prepared draws (random initialisers)
+            if (h->cfg.init_kind != GEMX_INIT_CONST) b += (size_t)(PREP_Q * 8 + 1) * BLOCK * sizeof(uint32_t);       // prepared draws (random initialisers)
             return (b + 15) & ~(size_t)15;
         };
         // workgroups of a shape one CU holds: LDS, wave slots -- and REGISTERS (round 4: the arithmetic used to stop at the first two and
@@ -4282,11 +4352,11 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             }
             return (int64_t)h->pipe_occ[shape_];
         };
-        auto resident = [&](int D, int OW) {
+        auto resident = [&](int D, int OW, int shape_full = -1) {  // (shape_full: one of the FULL / SLOW instantiations of <4, 2>, shapes 4-7)
             int64_t w = (int64_t)(h->lds_max / smem_of(D));
             const int waves_per_wg = 1 + OW + pipe_loader_waves(D);
             const int64_t wmax = 32 / waves_per_wg;
-            const int shape_ = D == PIPE_D ? (OW == PIPE_OUT_WAVES ? 0 : 3) : (D == PIPE_D2 ? 1 : 2);
+            const int shape_ = shape_full >= 0 ? shape_full : (D == PIPE_D ? (OW == PIPE_OUT_WAVES ? 0 : 3) : (D == PIPE_D2 ? 1 : 2));
             const int64_t wreg = regs_limit(shape_, waves_per_wg);
             w = w > wmax ? wmax : w;
             w = w > wreg ? wreg : w;
@@ -4363,13 +4433,15 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             // 52 vs 14 G env-steps/s at 16384 envs, 89 vs 26 at 32768, 89 vs 47 at 65536).  Random initialisers (the fp64 draw sits in the
             // integrator's reset path): ahead up to 32768 envs (28 vs 16), level at 65536, behind beyond (28 vs 43 at 131072) --
             // tools/ab_full_variant.py
-            const bool fits_n = h->cfg.init_kind == GEMX_INIT_CONST || blocks <= 4 * (int64_t)h->n_cu;
-            if (smem_of(PIPE_D2) <= h->lds_max && fits_n) { D = PIPE_D2; OW = PIPE_OUT_WAVES2; shape = 4; }
+            // Round 5: random initialisers have their own instantiation (RINIT) whose loader wave prepares the draws; same box, PMSM finite:
+            // 21 -> 54-57 G env-steps/s at 32768 / 65536 envs, and 57 against the single-wave kernel's 32 at 131072 -- the size rule
+            // ("at most four workgroups per CU") is gone (profiles/r05r_ab_prep.txt).
+            if (smem_of(PIPE_D2) <= h->lds_max) { D = PIPE_D2; OW = PIPE_OUT_WAVES2; shape = h->cfg.init_kind != GEMX_INIT_CONST ? 7 : 4; }
             else D = 0;
         }
         if (!fast_step && D != 0) {  // solver sub-steps / a custom constraint set: the SLOW instantiations of <4, 2> (no limiter: integrator-bound)
-            if (smem_of(PIPE_D2) <= h->lds_max) { D = PIPE_D2; OW = PIPE_OUT_WAVES2; shape = need_full ? 6 : 5; }
-            else D = 0;
+            if (smem_of(PIPE_D2) <= h->lds_max && h->cfg.init_kind == GEMX_INIT_CONST) { D = PIPE_D2; OW = PIPE_OUT_WAVES2; shape = need_full ? 6 : 5; }
+            else D = 0;  // (together with random initialisers: the single-wave kernel)
         }
         if (D != 0) {
             a.S = D;
@@ -4474,7 +4546,9 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                     target *= CAL_SCALE[use] * pc.center;
                     pace_scale_used = CAL_SCALE[use] * pc.center;
                 }
-                int64_t res = shape >= 4 ? 2 * (int64_t)h->n_cu : resident(D, OW);
+                // (round 5: the FULL instantiations are priced with their own registers and occupancy too -- without the draw code the RC-supply
+                // kernel went from 207 to 118 VGPRs, four workgroups per CU instead of the two that used to be written here)
+                int64_t res = shape >= 4 ? resident(D, OW, shape) : resident(D, OW);
                 // More than four workgroups per CU (the DC machines' small rows) and a launch that needs the LAST slot of every CU to be one round:
                 // count one slot less.  Registers, LDS, wave slots and the occupancy API said seven of the ShuntDc <4, 2> kernel; 114688 envs = 1792
                 // workgroups were priced as one round of 1792 -- and ran 0.41 of the roofline against 0.63 unpaced: whichever workgroups do not
@@ -4516,7 +4590,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         }
     }
     if (h->cur_synth)  // (only the pipelined kernel's loader wave generates actions; gemx_synthetic_actions writes the same stream for any other path)
-        return fail(GEMX_ERR_ARG, "gemx_rollout_synthetic needs the pipelined kernel: fp32, K >= 2 (and, with random initial states, at most 4 workgroups per CU)");
+        return fail(GEMX_ERR_ARG, "gemx_rollout_synthetic needs the pipelined kernel: fp32, K >= 2 (and no random initial states together with solver sub-steps / a custom constraint set)");
     if (K == 1 && h->cur_reward == nullptr && h->use_step_kernel != 0) {  // the closed-loop path: see step_kernel
         // one launch per control step is bound by the HOST's launch path: the function handle is resolved once per handle and the
         // arguments go as one buffer -- 3.36 against 3.55 us per launch through hipLaunchKernelGGL (tools/microbench_launch.hip)
@@ -4540,7 +4614,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         // A fused fp32 rollout that lands HERE runs the single-wave kernel, several times slower than the pipelined one at the same size
         // (round 4 verdict: nothing but gemx_last_launch() told).  Said once per handle, with the reason; GEMX_QUIET=1 silences it.
         h->warned_fallback = true;
-        const char *why = "random initial states beyond 4 workgroups per CU, or the LDS footprint of this configuration";
+        const char *why = "random initial states together with solver sub-steps or a custom constraint set, or the LDS footprint of this configuration";
         const char *q = getenv("GEMX_QUIET");
         if (q == nullptr || atoi(q) == 0)
             fprintf(stderr, "gemx: note: this handle's fused rollouts run the single-wave fallback kernel (%s); expect a fraction of the pipelined kernel's rate\n", why);

@@ -1527,8 +1527,9 @@ def test_random_initialiser_counters_after_create():
 def test_the_single_wave_fallback_says_so_and_unaligned_batches_no_longer_take_it(capfd):
     """Since round 5 EVERY batch size runs the pipelined kernel (rows that are not 16-byte aligned -- n_envs not a multiple of 16 -- go
     lane by lane through its general I/O paths instead of falling back, 6-8 x slower, to the single-wave kernel), and so do custom
-    constraint sets and solver sub-steps (its rolled copy of the step).  What still lands on the fallback -- random initial states at
-    more than 4 workgroups per CU -- says so, once per handle, on stderr (GEMX_QUIET=1 silences it)."""
+    constraint sets and solver sub-steps (its rolled copy of the step), and random initial states at any size (the loader wave prepares
+    the draws).  What still lands on the fallback -- random initial states TOGETHER with a custom constraint set -- says so, once per
+    handle, on stderr (GEMX_QUIET=1 silences it)."""
     import torch
 
     import gym_electric_motor_amd as ga
@@ -1544,9 +1545,15 @@ def test_the_single_wave_fallback_says_so_and_unaligned_batches_no_longer_take_i
         assert "advance_pipe_kernel" in env.physical_system.last_launch(), kw
         env.close()
     assert "fallback" not in capfd.readouterr().err
-    n = 65600  # 1025 workgroups: one more than 4 per CU
+    n = 65600  # 1025 workgroups: one more than 4 per CU (the FULL instantiation's old size rule)
     env = _init_env("pmsm_sc_uniform", n, seed=3)[0]
     acts = torch.zeros((8, n, env.physical_system._n_act), dtype=torch.float32, device="cuda")
+    env.rollout(acts)
+    assert "advance_pipe_kernel" in env.physical_system.last_launch()
+    env.close()
+    assert "fallback" not in capfd.readouterr().err
+    env = _init_env("pmsm_sc_uniform", 128, seed=3, constraints=("i_sq",))[0]
+    acts = torch.zeros((8, 128, env.physical_system._n_act), dtype=torch.float32, device="cuda")
     env.rollout(acts)
     env.rollout(acts)
     assert "advance_kernel" in env.physical_system.last_launch()

@@ -669,6 +669,7 @@ def test_register_budget_of_the_bench_kernels():
     lost a leg twice to an edit elsewhere in the kernel: four pinned registers took the error-controlled <2, 2> SCIM kernel across the
     128-register line (0.148 -> 0.076 of the roofline), and a rolled tail loop put 1.2 KB of scratch into it (0.146 -> 0.05)."""
     import importlib.util
+    import re
 
     readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
     build = os.path.join(REPO, "gym_electric_motor_amd", "build")
@@ -681,13 +682,13 @@ def test_register_budget_of_the_bench_kernels():
     found = {}
     for u, o in units.items():
         for name, vgpr, spilled, scratch, _sg in vr.kernels_of(o):
-            found[name.strip("`")] = (vgpr, spilled, scratch)
+            found[re.sub(r"(, false)+>$", ">", name.strip("`"))] = (vgpr, spilled, scratch)  # (trailing defaulted template flags dropped)
     budget = {  # kernel -> (VGPRs <=, spilled VGPRs <=, scratch bytes <=)
-        "advance_pipe_kernel<1, 1, 0, 1, false, float, 12, 6, false, false>": (128, 0, 32),   # headline
-        "advance_pipe_kernel<1, 1, 0, 1, false, float, 12, 3, false, false>": (168, 0, 32),   # headline, long launches (paced)
-        "advance_pipe_kernel<1, 1, 0, 1, false, float, 4, 2, false, false>": (128, 0, 0),     # config 5's shard, 1M envs
-        "advance_pipe_kernel<2, 2, 1, 1, false, float, 2, 2, false, false>": (128, 0, 0),     # config 4
-        "advance_pipe_kernel<2, 2, 1, 2, false, float, 2, 2, false, false>": (128, 8, 64),    # config 4, error-controlled
+        "advance_pipe_kernel<1, 1, 0, 1, false, float, 12, 6>": (128, 0, 32),   # headline
+        "advance_pipe_kernel<1, 1, 0, 1, false, float, 12, 3>": (168, 0, 32),   # headline, long launches (paced)
+        "advance_pipe_kernel<1, 1, 0, 1, false, float, 4, 2>": (128, 0, 0),     # config 5's shard, 1M envs
+        "advance_pipe_kernel<2, 2, 1, 1, false, float, 2, 2>": (128, 0, 0),     # config 4
+        "advance_pipe_kernel<2, 2, 1, 2, false, float, 2, 2>": (128, 8, 64),    # config 4, error-controlled
         "dc_stream_kernel<0, 0, 0, float, 32>": (128, 0, 0),                           # config 2
     }
     for k, (v_max, sp_max, sc_max) in budget.items():
