@@ -2490,7 +2490,16 @@ constexpr int PREP_Q = 4;  // prepared draws per lane (FULL pipelined kernel, ra
 #ifndef GEMX_PREP_DRAWS
 #define GEMX_PREP_DRAWS 1  // (0: A/B builds -- every reset draws inline)
 #endif
-template <int SYS, int SOLVER, bool IL, int D, bool FULL, bool SLOW = false> constexpr int pipe_waves_per_eu() {
+// RINIT: waves per SIMD the instantiation is compiled for.  Left alone the induction machines' kernels took 286 VGPRs (one workgroup
+// per CU): at most 256, two per CU, SCIM 13.4 -> 22.6 G env-steps/s.  The others: at most 168, three per CU, with the inline draw marked
+// as the cold side of its branch so that the spills land THERE (PMSM at 131072 envs 59 -> 68 G, level elsewhere; without the hint 57 ->
+// 50, and 39 at four waves; the induction machines lose 20-35 % at three or four).  profiles/r05t_ab_rinit_waves.txt, r05u_ab_rinit_expect.txt
+#define GEMX_EXPECT_PREPARED(x) __builtin_expect((x), 1)
+#ifndef GEMX_RINIT_WAVES
+#define GEMX_RINIT_WAVES 0  // (A/B builds: one figure for every system)
+#endif
+template <int SYS, int SOLVER, bool IL, int D, bool FULL, bool SLOW = false, bool RINIT = false> constexpr int pipe_waves_per_eu() {
+    if (RINIT) return GEMX_RINIT_WAVES != 0 ? GEMX_RINIT_WAVES : ((SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM) ? 2 : 3);
     return (D <= 4 && !FULL && !SLOW && SYS != GEMX_SYS_DFIM && !(SOLVER == GEMX_SOLVER_DP5 && IL)) ? 4 : 1;
 }
 // SLOW (round 5; <4, 2> only): the instantiation for solver sub-steps (nsteps > 1) and CUSTOM constraint sets (constr_kind 2).  Every
@@ -2501,7 +2510,7 @@ template <int SYS, int SOLVER, bool IL, int D, bool FULL, bool SLOW = false> con
 // RINIT (round 5; with FULL only): random initial states.  The FULL kernel without it serves the RC supply alone and carries no draw code
 // at all (the prepared-draw code inside one shared kernel cost the RC-supply launches 15 % of their rate, same box).
 template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R, int D, int OW, bool FULL = false, bool SLOW = false, bool RINIT = false>
-__global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) __attribute__((amdgpu_waves_per_eu(pipe_waves_per_eu<SYS, SOLVER, IL, D, FULL, SLOW>())))
+__global__ __launch_bounds__((1 + OW + pipe_loader_waves(D)) * BLOCK) __attribute__((amdgpu_waves_per_eu(pipe_waves_per_eu<SYS, SOLVER, IL, D, FULL, SLOW, RINIT>())))
 void advance_pipe_kernel(const KArgs<R> a) {
     constexpr int LW = pipe_loader_waves(D);  // 1: a loader wave stages actions / references instead of the integrator
     constexpr int ND = SysTraits<SYS>::ND, NOUT = SysTraits<SYS>::NOUT, NACT = ConvTraits<CONV>::NACT;
@@ -2926,7 +2935,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
             if constexpr (SOLVER == GEMX_SOLVER_DP5) hcar = rs ? R(0) : hcar;
             if constexpr (FULL) {
                 if constexpr (RINIT) if (rs) {  // (exec-masked, skipped wave-wide)
-                    if (GEMX_PREP_DRAWS != 0 && pre_hi.w == rcount + 1u) {  // the loader wave's prepared draw of this count, in registers since the block's start
+                    if (GEMX_PREP_DRAWS != 0 && GEMX_EXPECT_PREPARED(pre_hi.w == rcount + 1u)) {  // the loader wave's prepared draw of this count, in registers since the block's start
                         const uint32_t w8[8] = {pre_lo.x, pre_lo.y, pre_lo.z, pre_lo.w, pre_hi.x, pre_hi.y, pre_hi.z, pre_hi.w};
 #pragma unroll
                         for (int j = 0; j < ND; ++j) memcpy(&y[j], &w8[j], sizeof(R));
@@ -4200,11 +4209,14 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     h->steps_total += (unsigned long long)K;
     a.err = h->err;
     if (h->linmap_state == 0) {  // once per handle: the electrical subsystem's one-step map (constant-speed loads)
-        // (random initialisers may draw omega per episode: those handles keep the stage-by-stage solver)
+        // (random initialisers that draw OMEGA per episode keep the stage-by-stage solver.  Round 5: only those -- a random MOTOR initialiser
+        // beside a constant-speed load leaves omega at init[0], the map stays valid, and the kernels check every lane's omega at launch
+        // anyway (lin_usable); until then every random-initialiser handle ran the full Runge-Kutta stages, 2.2 x the integrator time)
         if constexpr (linable<SYS, LOAD, SOLVER, IL, R>()) {
             hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
             (void)hipStreamIsCapturing(st, &capturing);
-            if (h->cfg.init_kind != GEMX_INIT_CONST || (h->cfg.solver_flags & GEMX_SOLVER_ADAPTIVE) || h->cfg.solver_nsteps != 1) {  // (error control, sub-steps: stage by stage)
+            const bool omega_drawn = h->cfg.init_kind != GEMX_INIT_CONST && h->cfg.init_lo[0] < h->cfg.init_hi[0];
+            if (omega_drawn || (h->cfg.solver_flags & GEMX_SOLVER_ADAPTIVE) || h->cfg.solver_nsteps != 1) {  // (error control, sub-steps: stage by stage)
                 h->linmap_state = -1;
             } else if (capturing == hipStreamCaptureStatusNone) {
                 // built and COMPLETED here, so that later launches on any stream (or from a captured graph) find it; a first launch

@@ -40,6 +40,9 @@ CASES = [
     ("PMSM cont DqToAbc + DeadTime(1)", "Cont-CC-PMSM-v0", {"wrappers": ("dead1", "dq")}, False),
     ("PMSM finite DeadTime(2)", "Finite-CC-PMSM-v0", {"wrappers": ("dead2",)}, False),
     ("PMSM finite + RC supply", "Finite-CC-PMSM-v0", {"rc": True}, False),
+    ("PMSM finite + random initial states", "Finite-CC-PMSM-v0", {"rinit": "PMSM"}, False),  # (round 5: prepared draws, RINIT instantiation)
+    ("PMSM cont SC + random initial states", "Cont-SC-PMSM-v0", {"rinit": "PMSM", "rinit_load": True}, False),
+    ("SCIM cont + random initial states", "Cont-CC-SCIM-v0", {"rinit": "SCIM"}, False),
     ("PMSM finite + fused reward", "Finite-CC-PMSM-v0", {}, True),
     ("SCIM cont SC + fused reward", "Cont-SC-SCIM-v0", {}, True),
 ]
@@ -73,6 +76,12 @@ def main():
             kw2 = dict(kw)
             if kw2.pop("rc", False):
                 kw2["supply"] = ga.RCVoltageSupply(u_nominal=420.0, supply_parameter=dict(R=0.5, C=2e-3))
+            rinit = kw2.pop("rinit", None)
+            if rinit:
+                kw2["motor"] = {"PMSM": ga.PermanentMagnetSynchronousMotor, "SCIM": ga.SquirrelCageInductionMotor}[rinit](motor_initializer=dict(random_init="uniform"))
+                kw2["seed"] = 3
+                if kw2.pop("rinit_load", False):
+                    kw2["load"] = ga.PolynomialStaticLoad(load_initializer=dict(random_init="uniform"))
             ws = []
             for wname in kw2.pop("wrappers", ()):
                 ws.append(ga.DeadTimeProcessor(int(wname[4:])) if wname.startswith("dead") else ga.DqToAbcActionProcessor.make("PMSM"))

@@ -9,7 +9,12 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 env_id = sys.argv[3] if len(sys.argv) > 3 else "Finite-CC-PMSM-v0"
 solver = ga.EulerSolver() if os.environ.get("PROBE_SOLVER", "rk4") == "euler" else ga.RK4Solver()
-env = ga.make(env_id, n_envs=n, device="cuda:0") if os.environ.get("PROBE_SOLVER") == "default" else ga.make(env_id, n_envs=n, device="cuda:0", ode_solver=solver, tau=1e-4)
+extra = {}
+if os.environ.get("PROBE_RINIT"):  # random initial states (the RINIT instantiation: prepared draws)
+    extra = dict(motor=ga.PermanentMagnetSynchronousMotor(motor_initializer=dict(random_init="uniform")), seed=3)
+if os.environ.get("PROBE_RC"):
+    extra = dict(supply=ga.RCVoltageSupply(u_nominal=420.0, supply_parameter=dict(R=0.5, C=2e-3)))
+env = ga.make(env_id, n_envs=n, device="cuda:0", **extra) if os.environ.get("PROBE_SOLVER") == "default" else ga.make(env_id, n_envs=n, device="cuda:0", ode_solver=solver, tau=1e-4, **extra)
 ps = env.physical_system
 env.reset()
 if "Finite" in env_id:
