@@ -2768,6 +2768,9 @@ void advance_pipe_kernel(const KArgs<R> a) {
         uint32_t bad_action = 0;
         // prepared draws (FULL, random initialisers): the queue entry of rcount + 1, tag in pre_hi.w (see `prep`)
         u4_t pre_lo = {0u, 0u, 0u, 0u}, pre_hi = {0u, 0u, 0u, 0u};
+#ifdef GEMX_TIMING
+        uint32_t n_prepared = 0u, n_inline = 0u;  // resets served from the queue / drawn inline (debug words 500, 501: tools/probe_prepared_draws.py)
+#endif
         auto prefetch_draw = [&]() {
             if constexpr (FULL && RINIT && GEMX_PREP_DRAWS != 0) {
                 lds_u4_t *e = (lds_u4_t *)(prep + ((size_t)((rcount + 1u) % PREP_Q) * BLOCK + tid) * 8);
@@ -2941,8 +2944,14 @@ void advance_pipe_kernel(const KArgs<R> a) {
                         for (int j = 0; j < ND; ++j) memcpy(&y[j], &w8[j], sizeof(R));
                         if (HAS_ANGLE) memcpy(&ang, &w8[ND], sizeof(R));
                         rcount += 1u;
+#ifdef GEMX_TIMING
+                        n_prepared += 1u;
+#endif
                     } else {
                         draw_initial_state_cnt<SYS, R>(a.rinit, envc, rcount, y, ang);
+#ifdef GEMX_TIMING
+                        n_inline += 1u;
+#endif
                     }
                     if (GEMX_PREP_DRAWS != 0) prep_cnt[tid] = rcount;
                     prefetch_draw();  // the next count's entry (its latency ends long before the next step's reset test)
@@ -3237,6 +3246,13 @@ void advance_pipe_kernel(const KArgs<R> a) {
                     a.state[(int64_t)(ND + 1) * N + env] = sup[1];
                 }
                 if constexpr (RINIT) a.rcnt[env] = rcount;
+#ifdef GEMX_TIMING
+                if constexpr (RINIT) {
+                    unsigned long long *dbgc = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64);
+                    atomicAdd(&dbgc[500], (unsigned long long)n_prepared);
+                    atomicAdd(&dbgc[501], (unsigned long long)n_inline);
+                }
+#endif
             }
             if (SOLVER == GEMX_SOLVER_DP5 && P.adaptive) a.state[(int64_t)(ND + 2) * N + env] = hcar;
             int phase_end = 0;
