@@ -11,6 +11,7 @@ CASES = (
     ("rinit", "Finite-CC-PMSM-v0", lambda: dict(motor=ga.PermanentMagnetSynchronousMotor(motor_initializer=dict(random_init="uniform")), seed=3)),
     ("rinit_sc", "Cont-SC-PMSM-v0", lambda: dict(motor=ga.PermanentMagnetSynchronousMotor(motor_initializer=dict(random_init="uniform")),
                                                  load=ga.PolynomialStaticLoad(load_initializer=dict(random_init="uniform")), seed=3)),
+    ("scim_plain", "Cont-CC-SCIM-v0", lambda: dict()),
     ("rinit_scim", "Cont-CC-SCIM-v0", lambda: dict(motor=ga.SquirrelCageInductionMotor(motor_initializer=dict(random_init="uniform")), seed=3)),
     ("rinit_gauss", "Cont-CC-PermExDc-v0", lambda: dict(motor=ga.DcPermanentlyExcitedMotor(motor_initializer=dict(random_init="gaussian", random_params=(30.0, 40.0))), seed=3)),
 )
