@@ -1597,6 +1597,56 @@ def test_prepared_draws_of_the_loader_wave_give_the_inline_draws_bits(case, n, m
     assert int(per_env.max()) >= 3 and float((per_env > 0).float().mean()) > 0.2, "too few terminations to exercise the reset path"
 
 
+@pytest.mark.parametrize("combo", ["dead_time", "rc_supply", "dead_time+rc_supply", "reward", "synthetic"])
+def test_prepared_draws_beside_the_other_per_lane_features(combo, monkeypatch):
+    """Random initial states (RINIT instantiation, prepared draws) together with what else lives in the FULL kernel or its loader wave: a
+    DeadTimeProcessor queue (refilled at every reset), the RC supply's per-lane state, the fused reward's reference rows, synthetic
+    actions generated by the same loader wave.  Bit for bit the single-wave kernel's results (synthetic actions: the same stream fed
+    as a tensor)."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    n, K = 200, 300
+
+    def run(pipe):
+        monkeypatch.setenv("GEMX_PIPE", pipe)
+        kw = dict(motor=ga.PermanentMagnetSynchronousMotor(motor_initializer=dict(random_init="uniform")), seed=31, n_envs=n, ode_solver=ga.RK4Solver(), tau=1e-4)
+        if "dead_time" in combo:
+            kw["physical_system_wrappers"] = (ga.DeadTimeProcessor(steps=2),)
+        if "rc_supply" in combo:
+            kw["supply"] = ga.RCVoltageSupply(u_nominal=420.0, supply_parameter=dict(R=0.5, C=2e-3))
+        env = ga.make("Cont-CC-PMSM-v0", **kw)
+        ps = env.physical_system
+        g = torch.Generator(device="cuda").manual_seed(41)
+        acts = (torch.rand((K, n, ps._n_act), device="cuda", generator=g, dtype=torch.float64) * 2 - 1).to(ps._tdtype)
+        acts[30:] = acts[30]
+        extra = ()
+        if combo == "reward":
+            rc = ps.set_reward(reward_weights=dict(i_sd=0.5, i_sq=0.5), referenced_states=("i_sd", "i_sq"))
+            refs = torch.rand((K, n, int(rc.n_ref)), device="cuda", generator=g) - 0.5
+            rew = torch.empty((K, n), device="cuda")
+            obs, done = ps.rollout(acts, references=refs, reward_out=rew)[:2]
+            extra = (rew.clone(),)
+        elif combo == "synthetic":
+            if pipe == "1":
+                obs, done = ps.rollout_synthetic(K, seed=5, step0=0)
+            else:
+                obs, done = ps.rollout(ps.synthetic_actions(K, seed=5, step0=0))
+        else:
+            obs, done = ps.rollout(acts)
+        if pipe == "1":
+            assert "advance_pipe_kernel" in ps.last_launch(), ps.last_launch()
+        res = (obs.clone(), done.clone(), ps.get_state(), ps.get_checkpoint()["aux"].clone()) + extra
+        env.close()
+        return res
+
+    a, b = run("1"), run("0")
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert int(a[1].sum()) > n, "too few terminations to exercise the reset path"
+
+
 SLOW_STEP_CASES = [
     # (env id, make kwargs): custom constraint sets and solver sub-steps on the pipelined kernel's rolled copy of the step
     ("Finite-CC-PMSM-v0", dict(constraints=("i_sq",))),
