@@ -298,10 +298,10 @@ __device__ __forceinline__ void init_uniforms_from(const uint32_t (&r0)[4], cons
 #pragma unroll
     for (int i = 0; i < 4; ++i) { u[i] = Philox::u01(r0[i]); u[4 + i] = Philox::u01(r1[i]); }
 }
-__device__ __forceinline__ void init_uniforms(const InitDev *I, int64_t env, uint32_t count, double (&u)[GEMX_MAX_ODE]) {
+__device__ __forceinline__ void init_uniforms(const InitDev *I, int64_t env, uint32_t count, double (&u)[GEMX_MAX_ODE], bool block1 = true) {
     uint32_t r0[4], r1[4] = {0u, 0u, 0u, 0u};
     Philox::block(I->seed, (uint64_t)env, count, 0u, r0);
-    if (init_needs_block1(I)) Philox::block(I->seed, (uint64_t)env, count, 1u, r1);
+    if (block1 && init_needs_block1(I)) Philox::block(I->seed, (uint64_t)env, count, 1u, r1);
     init_uniforms_from(r0, r1, u);
 }
 // one state from its uniform with explicit bounds (the induction machines' per-reset flux bounds)
@@ -351,7 +351,8 @@ template <bool FLUX>
 __device__ __forceinline__ void init_draw_all(const InitDev *I, int64_t env, uint32_t count, double (&out)[GEMX_MAX_ODE]) {
     double u[GEMX_MAX_ODE];
     init_uniforms(I, env, count, u);
-    init_draw_from<FLUX>(I, count, u, [&](double (&up)[GEMX_MAX_ODE]) { init_uniforms(I, env, count - 1u, up); }, out);
+    // (of the previous draw only the stator currents' uniforms are read, slots flux_slot - 2 and - 1: block 1 only if they reach into it)
+    init_draw_from<FLUX>(I, count, u, [&](double (&up)[GEMX_MAX_ODE]) { init_uniforms(I, env, count - 1u, up, I->flux_slot > 4); }, out);
 }
 
 // ------------------------------------------------------------------------------------------------

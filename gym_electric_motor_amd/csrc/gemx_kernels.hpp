@@ -3292,6 +3292,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
         uint32_t bad = 0;
         // prepared draws (FULL, random initialisers): the Philox blocks of the draw in progress, its count, the lanes it is for
         uint32_t pq0[4] = {0u, 0u, 0u, 0u}, pq1[4] = {0u, 0u, 0u, 0u}, pp0[4] = {0u, 0u, 0u, 0u}, pp1[4] = {0u, 0u, 0u, 0u}, prep_c = 0u;
+        uint32_t lq0[4] = {0u, 0u, 0u, 0u}, prep_lastw = 0u;  // Philox block 0 of the draw this lane got last, and its count
         bool prep_act = false;
         int prep_phase = 0;  // wave-uniform
         if (DISCRETE) __syncthreads();
@@ -3332,13 +3333,24 @@ void advance_pipe_kernel(const KArgs<R> a) {
                         }
                         if (__any(prep_act)) prep_phase = 1;
                     }
+                    // the induction machines' previous draw (its stator currents bound this one's flux): filling a queue count by count, that
+                    // is the draw this lane got last -- its block 0 was kept, and the draw takes three passes instead of four
+                    auto after_own_blocks = [&]() {
+                        if (!fprev) return 5;
+                        if (I->flux_slot <= 4 && !__any(prep_act && prep_lastw != prep_c)) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) pp0[i] = lq0[i];
+                            return 5;
+                        }
+                        return 3;
+                    };
                     if (prep_phase == 1) {
                         Philox::block(I->seed, (uint64_t)envc, prep_c + 1u, 0u, pq0);
-                        prep_phase = blk1 ? 2 : (fprev ? 3 : 5);
+                        prep_phase = blk1 ? 2 : after_own_blocks();
                     } else if (prep_phase == 2) {
                         Philox::block(I->seed, (uint64_t)envc, prep_c + 1u, 1u, pq1);
-                        prep_phase = fprev ? 3 : 5;
-                    } else if (prep_phase == 3) {  // the induction machines' previous draw (its stator currents bound this one's flux)
+                        prep_phase = after_own_blocks();
+                    } else if (prep_phase == 3) {
                         Philox::block(I->seed, (uint64_t)envc, prep_c, 0u, pp0);
                         prep_phase = I->flux_slot > 4 ? 4 : 5;  // (the currents' uniforms, slots flux_slot - 2 and - 1, sit in block 0 for every machine built)
                     } else if (prep_phase == 4) {
@@ -3357,6 +3369,9 @@ void advance_pipe_kernel(const KArgs<R> a) {
                             lds_u4_t *e = (lds_u4_t *)(prep + ((size_t)((prep_c + 1u) % PREP_Q) * BLOCK + tid) * 8);
                             e[0] = u4_t{w8[0], w8[1], w8[2], w8[3]};
                             e[1] = u4_t{w8[4], w8[5], w8[6], w8[7]};  // (the tag's half last)
+                            prep_lastw = prep_c + 1u;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) lq0[i] = pq0[i];
                         }
                         prep_phase = 0;
                     }
