@@ -84,7 +84,7 @@ EXPORTS = (
     "gemx_n_envs", "gemx_n_ode", "gemx_n_out", "gemx_n_action", "gemx_action_itemsize", "gemx_n_switch_bytes", "gemx_reset_observation", "gemx_set_reward", "gemx_rollout_reward", "gemx_refgen_create", "gemx_refgen_destroy", "gemx_refgen_reset",
     "gemx_refgen_rollout", "gemx_refgen_get_state",
     "gemx_reset", "gemx_step", "gemx_rollout", "gemx_get_state", "gemx_set_state", "gemx_get_switch_state",
-    "gemx_set_switch_state", "gemx_aux_state_bytes", "gemx_get_aux_state", "gemx_set_aux_state", "gemx_reset_again", "gemx_rollout_synthetic", "gemx_synthetic_actions", "gemx_set_steps_per_block", "gemx_last_launch", "gemx_error_flags", "gemx_debug_read",
+    "gemx_set_switch_state", "gemx_aux_state_bytes", "gemx_get_aux_state", "gemx_set_aux_state", "gemx_reset_again", "gemx_rollout_synthetic", "gemx_synthetic_actions", "gemx_set_rate_limiter", "gemx_set_steps_per_block", "gemx_last_launch", "gemx_error_flags", "gemx_debug_read",
 )
 
 
@@ -122,6 +122,7 @@ def load():
     L.gemx_aux_state_bytes.argtypes = [vp]
     L.gemx_aux_state_bytes.restype = i64
     L.gemx_rollout_synthetic.argtypes = [vp, C.c_uint64, C.c_uint32, i32, vp, vp, vp]
+    L.gemx_set_rate_limiter.argtypes = [vp, i32, C.c_double]
     L.gemx_synthetic_actions.argtypes = [vp, C.c_uint64, C.c_uint32, i32, vp, vp]
     L.gemx_get_aux_state.argtypes = [vp, vp, vp]
     L.gemx_set_aux_state.argtypes = [vp, vp, vp]

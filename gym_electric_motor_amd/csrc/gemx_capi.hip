@@ -895,6 +895,26 @@ int gemx_synthetic_actions(gemx_handle *h, uint64_t seed, uint32_t step0, int32_
     HIP_TRY(hipGetLastError());
     return GEMX_OK;
 }
+int gemx_set_rate_limiter(gemx_handle *h, int32_t mode, double target_gbps) {
+    if (!h) return fail(GEMX_ERR_ARG, "null handle");
+    if (mode < 0 || mode > 2) return fail(GEMX_ERR_ARG, "gemx_set_rate_limiter: mode must be 0 (off), 1 (open loop) or 2 (closed loop)");
+    if (!(target_gbps == target_gbps) || target_gbps > 1.0e6) return fail(GEMX_ERR_ARG, "gemx_set_rate_limiter: target_gbps out of range");
+    // pace_gbps: < 0 the built-in target, 0 off, > 0 an explicit target; calibration only around the built-in one (launch_advance)
+    h->pace_gbps = mode == 0 ? 0.0 : (target_gbps > 0.0 ? target_gbps : -1.0);
+    h->pace_cal_on = mode == 2 ? 1 : 0;
+    {
+        gemx::DeviceGuard guard(h->device);
+        for (int i = 0; i < gemx_handle::PaceCal::RING; ++i) {  // (recreated on demand)
+            if (h->pcal.ev0[i]) (void)hipEventDestroy((hipEvent_t)h->pcal.ev0[i]);
+            if (h->pcal.ev1[i]) (void)hipEventDestroy((hipEvent_t)h->pcal.ev1[i]);
+        }
+        (void)hipGetLastError();
+    }
+    h->pcal = gemx_handle::PaceCal();
+    h->pace_cal_state = 0;
+    h->pace_scale_last = 1.0;
+    return GEMX_OK;
+}
 int gemx_rollout_synthetic(gemx_handle *h, uint64_t seed, uint32_t step0, int32_t K, void *obs_out_dev, uint8_t *done_out_dev, void *stream) {
     if (!h) return fail(GEMX_ERR_ARG, "null handle");
     if (!obs_out_dev) return fail(GEMX_ERR_ARG, "obs_out_dev must not be null");

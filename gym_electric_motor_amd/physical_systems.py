@@ -736,6 +736,16 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         self._k += K
         return obs_out, done_out
 
+    def set_rate_limiter(self, mode="closed", target_gbps=None):
+        """The large-batch rate limiter of the fused rollout (include/gemx.h, gemx_set_rate_limiter) for THIS system: mode 'off' |
+        'open' (the built-in target of the launch's family and size) | 'closed' (the default on a whole gfx950: the handle times its own
+        launches and keeps the best of a bracket around that target); `target_gbps` replaces the built-in target (open loop).  Results
+        never depend on it.  Turn it off for systems that share the chip with other work."""
+        modes = {"off": 0, "open": 1, "closed": 2}
+        if mode not in modes:
+            raise ValueError(f"mode must be one of {sorted(modes)}, not {mode!r}")
+        _lib.check(self._L.gemx_set_rate_limiter(self._handle, modes[mode], float(target_gbps) if target_gbps else 0.0))
+
     # ------------------------------------------------------------------ fused reward (SURVEY.md 8f rank 3)
     def synthetic_actions(self, K, seed=0, step0=None):
         """The device's synthetic action stream as a tensor: [K, N, A] (continuous, uniform on (-1, 1)) or [K, N] uint8 (uniform over the

@@ -30,7 +30,7 @@ extern "C" {
 
 #define GEMX_ABI_VERSION 6 /* 2: GEMX_MAX_OUT 16 -> 24 (DFIM system, 24 states); 3: gemx_config.solver_flags; 4: solver_rtol / solver_atol; 5: init_flux_mode / init_flux;
                             * 6: gemx_get_aux_state / gemx_set_aux_state / gemx_aux_state_bytes, gemx_reset_again; reset counters stay at 1 after gemx_create;
-                            *    + gemx_rollout_synthetic / gemx_synthetic_actions (new entry points only) */
+                            *    + gemx_rollout_synthetic / gemx_synthetic_actions, gemx_set_rate_limiter (new entry points only) */
 #define GEMX_MAX_ODE 8  /* ODE state length incl. omega and the angle      */
 #define GEMX_MAX_OUT 24 /* system-state (observation) length               */
 #define GEMX_MODEL_ROWS 5
@@ -254,6 +254,15 @@ int gemx_set_reward(gemx_handle *h, const gemx_reward_config *rc);
  * for policies / tests / the paths gemx_rollout_synthetic does not serve: gemx_rollout on that tensor gives the same bits. */
 int gemx_rollout_synthetic(gemx_handle *h, uint64_t seed, uint32_t step0, int32_t K, void *obs_out_dev, uint8_t *done_out_dev, void *stream);
 int gemx_synthetic_actions(gemx_handle *h, uint64_t seed, uint32_t step0, int32_t K, void *actions_out_dev, void *stream);
+
+/* The large-batch RATE LIMITER of the fused rollout (more workgroups than CUs: every workgroup is held to one block of rows per interval,
+ * because this chip's write path delivers more when it is offered slightly less than it can take -- DESIGN.md 4.1).  Results never depend
+ * on it, only the rate.  mode 0: off; 1: open loop at the built-in target of the launch's family and size; 2: closed loop (the default on a
+ * whole gfx950: each handle times its own launches with HIP events and keeps the best of a bracket around that target, or none).
+ * target_gbps > 0 replaces the built-in target (algorithmic GB/s, chip-wide; then open loop); <= 0 keeps it.  The environment variables
+ * GEMX_PACE_GBPS / GEMX_PACE_CAL set the same two things for every handle at gemx_create; this call overrides them for one handle
+ * (e.g. several handles sharing the chip, a partitioned device: mode 0).  Forgets the handle's calibration. */
+int gemx_set_rate_limiter(gemx_handle *h, int32_t mode, double target_gbps);
 
 /* gemx_rollout (obs_every = 1) that additionally reads refs_dev [K, N, n_ref] (R) and writes reward_out_dev [K, N] (R). */
 int gemx_rollout_reward(gemx_handle *h, const void *actions_dev, int32_t K, const void *refs_dev, void *obs_out_dev,

@@ -1647,6 +1647,36 @@ def test_prepared_draws_beside_the_other_per_lane_features(combo, monkeypatch):
     assert int(a[1].sum()) > n, "too few terminations to exercise the reset path"
 
 
+def test_rate_limiter_per_handle_switch_changes_the_launch_not_the_results():
+    """gemx_set_rate_limiter / system.set_rate_limiter (advisor finding of round 4: a per-handle switch beside the environment variables):
+    off, open loop, an explicit target, closed loop -- the launch line says what ran, the bits are the same."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    n, K = 65536, 128
+    acts = torch.randint(0, 8, (K, n), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    ref = None
+    for mode, kw in (("off", {}), ("open", {}), ("open", dict(target_gbps=5000.0)), ("closed", {})):
+        env = ga.make("Finite-CC-PMSM-v0", n_envs=n)
+        ps = env.physical_system
+        ps.set_rate_limiter(mode, **kw)
+        obs, done = env.rollout(acts)
+        line = ps.last_launch()
+        if mode != "closed":  # (a closed-loop launch may be the bracket's unpaced candidate)
+            assert ("rate limit" in line) == (mode == "open"), line
+        assert ("limiter calibrat" in line) == (mode == "closed"), line
+        if ref is None:
+            ref = (obs.clone(), done.clone())
+        else:
+            assert torch.equal(obs, ref[0]) and torch.equal(done, ref[1])
+        env.close()
+    env = ga.make("Finite-CC-PMSM-v0", n_envs=64)
+    with pytest.raises(ValueError):
+        env.physical_system.set_rate_limiter("sometimes")
+    env.close()
+
+
 SLOW_STEP_CASES = [
     # (env id, make kwargs): custom constraint sets and solver sub-steps on the pipelined kernel's rolled copy of the step
     ("Finite-CC-PMSM-v0", dict(constraints=("i_sq",))),
