@@ -54,7 +54,12 @@ Round 5: `roofline` carries both roofs SURVEY.md 8(d) names (`frac` against the 
 launches of more workgroups than CUs run under the CLOSED-LOOP rate limiter (each handle calibrates its interval with HIP events during
 its first ~30 paced launches: every leg's `--settle-ms` covers that, and `roofline.kernel` says `limiter calibrated at x`).
 
-Extra objects in the JSON line (rank 0):
+Round 6: stdout carries ONE COMPACT line (< 6 KB: the contract's keys, `roofline`, `cpu_baseline`, `legs` = {name: {frac, launch_ms}} for
+BASELINE configs 2 / 4 / 4 with the ConstantSpeedLoad / 5's shard / 1M envs / the error-controlled solver, and for N > 1 `gather`, `rccl`,
+`config5`), printed LAST; the full record described below goes to `bench_extras.json` beside this script (`--extras-file`; a copy under
+gpurun_out/ when that directory exists).  Round 5 printed the full record as the line, it grew to 20 KB and the driver could not parse it.
+
+Objects of the full record (rank 0; the stdout line keeps the numbers of `roofline`, `cpu_baseline`, `legs` only):
   roofline            HBM roofline of the dominant kernel: algorithmic bytes per launch / mean launch duration measured HERE with HIP
                       events on the launch stream around the K timed launches; peak = 8000 GB/s (MI355X spec); traffic = HBM bytes
                       per launch MEASURED IN THIS RUN: two child runs of this script under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE`
@@ -524,7 +529,7 @@ def cpu_baseline(w, budget_s=12.0):
             ref = json.load(open(ref_path))
             out["reference"] = {"source": "profiles/cpu_reference.json (oracle/cpu_reference_bench.py: the reference's own Python path, "
                                           "timed in the build container, which has /root/reference; the GPU box has not)",
-                                "host": ref.get("host"), "env_steps_per_s": ref.get("results", {}).get(w["env_id"])}
+                                "same_host": False, "host": ref.get("host"), "env_steps_per_s": ref.get("results", {}).get(w["env_id"])}
         except Exception as e:  # a malformed record must not kill the bench line
             out["reference"] = {"error": repr(e)}
     return out
@@ -712,7 +717,7 @@ def worker(args, rank, world, local_rank, backend):
                 cb["note"] = f"timed on rank 0's host while the other {world - 1} rank(s) wait; identical at every N"
             out["cpu_baseline"] = cb
         out["overrides"] = {k: v for k, v in os.environ.items() if k.startswith("GEMX_")}  # A/B switches active in THIS run (normally none)
-        print(json.dumps(out), flush=True)
+        emit(out, args)
 
     if dist_on:
         try:
@@ -720,6 +725,115 @@ def worker(args, rank, world, local_rank, backend):
             dist.destroy_process_group()
         except Exception as e:  # (the line is out already)
             print(f"bench.py: rank {rank}: shutdown barrier failed: {e!r}", file=sys.stderr)
+
+
+LINE_LIMIT = 6000  # bytes of the ONE stdout line (round 5's 20-KB line was more than the driver parses: BENCH_r05.json parsed = null)
+LEGS = ("permexdc", "scim", "scim_constspeed", "scim_plain_rk4", "scim_error_controlled", "scim_device_actions", "pmsm_c5_shard")
+
+
+def _r(x, nd=4):
+    """numbers of the stdout line: 4-5 significant digits are what the measurement carries"""
+    if isinstance(x, float):
+        return float(f"{x:.{nd + 1}g}") if x == x and abs(x) != float("inf") else None
+    return x
+
+
+def _cut(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[: n - 3] + "..."
+
+
+def compact_line(out, extras_file=None):
+    """The stdout line: the contract's keys + `roofline` + `cpu_baseline` + `legs` {name: {frac, launch_ms}}, numbers only, < LINE_LIMIT
+    bytes whatever the legs returned (tests/test_host_cpu.py asserts it on a full record).  Everything else -- repeats, telemetry,
+    sustained seconds, cold start, single-step legs, notes, tracebacks of failed legs -- is the side file `extras_file`."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: out.get(k) for k in keep}  # (full precision: value x bytes per env-step == roofline.achieved is checked to 1e-9)
+    c = out.get("config") or {}
+    line["config"] = {"workload": _cut(c.get("workload", ""), 300), **{k: c.get(k) for k in ("env_id", "envs_per_gpu", "solver", "tau", "steps_per_launch",
+                                                                                           "parallelism", "world_size", "backend", "oversubscribed") if k in c}}
+    ro = out.get("roofline") or {}
+    line["roofline"] = {k: ro.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_of_measured", "launch_ms",
+                                               "launch_ms_hip_events", "algorithmic_bytes_per_launch", "bytes_per_env_step")}
+    line["roofline"]["kernel"] = _cut(ro.get("kernel", ""), 200)
+    rp = out.get("repeats") or {}
+    if "roofline_frac_min" in rp:
+        line["roofline"]["frac_min"], line["roofline"]["frac_max"] = _r(rp["roofline_frac_min"]), _r(rp["roofline_frac_max"])
+    s1 = out.get("sustained_1s") or {}
+    if "roofline_frac" in s1:
+        line["roofline"]["frac_sustained_1s"] = _r(s1["roofline_frac"])
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict) and "error" not in cb:
+        cl = {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"), "sample": _cut(cb.get("sample", ""), 200)}
+        ac = cb.get("all_cores") or {}
+        if "value" in ac:
+            cl["all_cores"] = {"value": _r(ac["value"]), "cores": ac.get("cores")}
+        ref = (cb.get("reference") or {}).get("env_steps_per_s") or {}
+        if ref:  # the reference's own Python path, env-steps/s on ONE core (episodic), recorded on the build host: another machine
+            cl["reference"] = {"same_host": False, "unit": "env-steps/s on 1 core", **{k: _r(v.get("episodic_1core")) for k, v in ref.items() if isinstance(v, dict)},
+                               "all_cores_dopri5": _r((ref.get("dopri5") or {}).get("episodic_all_cores")),
+                               "cores": ((cb.get("reference") or {}).get("host") or {}).get("cores")}
+        line["cpu_baseline"] = cl
+    elif cb is not None:
+        line["cpu_baseline"] = {"error": _cut((cb or {}).get("error", "failed"), 200)}
+    legs = {}
+    for name in LEGS:
+        v = (out.get("configs") or {}).get(name)
+        if not isinstance(v, dict):
+            continue
+        if "error" in v:
+            legs[name] = {"error": _cut(v["error"], 120)}
+            continue
+        lm = (v.get("roofline") or {}).get("launch_ms", v.get("launch_ms"))
+        legs[name] = {"frac": _r(v.get("frac")), "launch_ms": _r(lm)}
+        fl = (v.get("launch_model") or {}).get("frac_of_latency_bound")
+        if fl is not None:
+            legs[name]["frac_of_latency_bound"] = _r(fl)
+    a = out.get("at_scale")
+    if isinstance(a, dict) and "frac_of_peak" in a:
+        legs["at_scale"] = {"frac": _r(min(a.get("frac_of_peak_repeats") or [a["frac_of_peak"]])), "launch_ms": _r(a.get("launch_ms")), "envs": a.get("envs")}
+    if legs:
+        line["legs"] = legs
+    # multi-GPU lines: the one collective of the path and config 5, numbers only
+    g = (out.get("gather") or {}).get("chunk")
+    if isinstance(g, dict):
+        line["gather"] = {"chunk": {"value": _r(g.get("value"), 6), "ms_per_step": _r(g.get("ms_per_step"))} if "error" not in g else {"error": _cut(g["error"], 120)}}
+    rc = out.get("rccl")
+    if isinstance(rc, dict):
+        line["rccl"] = {k: _r(rc.get(k)) for k in ("world_seen", "backend", "bytes_per_rank", "ms", "GB_per_s", "own_slot_bit_identical") if k in rc} or {"error": _cut(rc.get("error"), 120)}
+    c5 = out.get("config5")
+    if isinstance(c5, dict):
+        line["config5"] = {k: _r(c5.get(k), 6) for k in ("envs_per_gpu", "envs_total", "value", "ms_per_step", "roofline_frac_per_gpu") if k in c5} or {"error": _cut(c5.get("error"), 120)}
+    cs = out.get("cold_start")
+    if isinstance(cs, dict):
+        line["cold_start_value"] = _r(cs.get("value"), 6)
+    if out.get("extras_error"):
+        line["extras_error"] = _cut(out["extras_error"].get("error"), 160)
+    line["overrides"] = {k: _cut(v, 40) for k, v in list((out.get("overrides") or {}).items())[:8]}  # (normally {})
+    if extras_file:
+        line["extras_file"] = extras_file
+    txt = json.dumps(line, separators=(",", ":"))
+    if len(txt) >= LINE_LIMIT:  # cannot happen with the fields above (every string is cut); if it ever does, the contract's keys still go out
+        for k in ("legs", "gather", "rccl", "config5", "overrides", "extras_error", "cold_start_value"):
+            line.pop(k, None)
+        txt = json.dumps(line, separators=(",", ":"))
+    return txt
+
+
+def emit(out, args):
+    """Full record -> the side file (`--extras-file`, default bench_extras.json beside this script; a copy under gpurun_out/ when that
+    directory exists, so that a gpurun call brings it home); ONE compact line -> stdout, last."""
+    path = args.extras_file or os.path.join(REPO, "bench_extras.json")
+    written = None
+    for p in [path] + ([os.path.join(REPO, "gpurun_out", os.path.basename(path))] if os.path.isdir(os.path.join(REPO, "gpurun_out")) else []):
+        try:
+            with open(p, "w") as fh:
+                json.dump(out, fh, indent=1)
+            written = written or os.path.relpath(p, REPO)
+        except OSError as e:  # a read-only checkout: the line still goes out
+            print(f"bench.py: could not write {p}: {e!r}", file=sys.stderr)
+    sys.stdout.flush()
+    print(compact_line(out, written), flush=True)
 
 
 def guarded_pair(fn):
@@ -985,6 +1099,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child runs (N = 1 only)")
     ap.add_argument("--config5", choices=["auto", "on", "off"], default="auto",
                     help="also measure BASELINE config 5's shard (32768 envs per GPU) on every rank and report it as `config5` (auto: at --gpus 8)")
+    ap.add_argument("--extras-file", default=None, help="where the full record goes (default: bench_extras.json beside this script); stdout carries "
+                                                         "one compact line (< 6 KB)")
     ap.add_argument("--dist-timeout", type=float, default=300.0, help="torch.distributed timeout in seconds (rendezvous, barriers, collectives)")
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0 or args.steps_per_launch < 2 or args.settle_ms < 0:

@@ -6,7 +6,7 @@ import os
 from . import build as _build
 
 MAX_ODE, MAX_OUT, MODEL_ROWS, MODEL_COLS = 8, 24, 5, 11
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 SYS_DC_PERMEX, SYS_SYNC, SYS_SCIM, SYS_DC_SERIES, SYS_DC_SHUNT, SYS_DC_EXTEX, SYS_EESM, SYS_DFIM = 0, 1, 2, 3, 4, 5, 6, 7
 CONV_CONT_4QC, CONV_FINITE_B6, CONV_CONT_B6, CONV_FINITE_4QC = 0, 1, 2, 3
@@ -34,7 +34,7 @@ class GemxConfig(C.Structure):
         ("limit_mask", C.c_uint32), ("squared_mask", C.c_uint32),
         ("action_frame", C.c_int32), ("action_delay", C.c_int32),
         ("supply_kind", C.c_int32), ("init_kind", C.c_int32), ("init_flux_mode", C.c_int32), ("init_flux", C.c_double * 8),
-        ("seed", C.c_uint64),
+        ("seed", C.c_uint64), ("env_base", C.c_int64),
         ("init_lo", C.c_double * MAX_ODE), ("init_hi", C.c_double * MAX_ODE), ("init_mu", C.c_double * MAX_ODE),
         ("init_sigma", C.c_double * MAX_ODE),
         ("supply_r", C.c_double), ("supply_c", C.c_double), ("action_delay_reset", C.c_double * 6), ("solver_rtol", C.c_double), ("solver_atol", C.c_double),
@@ -71,7 +71,7 @@ class GemxRefgenConfig(C.Structure):
     """Mirror of `gemx_refgen_config` (include/gemx.h)."""
 
     _fields_ = [
-        ("struct_size", C.c_int32), ("n_ref", C.c_int32), ("seed", C.c_uint64),
+        ("struct_size", C.c_int32), ("n_ref", C.c_int32), ("seed", C.c_uint64), ("env_base", C.c_int64),
         ("episode_len_lo", C.c_int32), ("episode_len_hi", C.c_int32),
         ("sigma_lo", C.c_double * MAX_REF), ("sigma_hi", C.c_double * MAX_REF),
         ("margin_lo", C.c_double * MAX_REF), ("margin_hi", C.c_double * MAX_REF),

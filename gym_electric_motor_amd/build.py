@@ -1,13 +1,16 @@
-"""Build the in-tree HIP library `libgemx.so` for gfx950 (explicit hipcc, no JIT cache).
+"""Build the in-tree HIP libraries for gfx950 (explicit hipcc, no JIT cache).
 
 Sources (gym_electric_motor_amd/csrc):
     gemx_common.hpp, gemx_kernels.hpp   device templates
-    gemx_inst.hip                       ONE instantiation unit, compiled once per (system, converter, dtype)
-    gemx_capi.hip                       C ABI (include/gemx.h), validation, small kernels, dispatch
-    gemx_refgen.hip                     device-side Wiener-process reference generation (gemx_refgen_*)
-The 38 instantiation units (19 system/converter pairs x fp32, fp64) + the C-ABI and refgen units are compiled in parallel and linked with `hipcc -shared`.
+    gemx_inst.hip                       ONE kernel unit, compiled once per (system, converter unit, dtype) into its OWN shared object
+                                        libgemx_u<S>_<C>_<F>.so, which gemx_create loads with dlopen (round 6: a handle maps the C ABI and
+                                        the one unit it runs, not all 38)
+    gemx_capi.hip                       C ABI (include/gemx.h), validation, small kernels, unit loader  } libgemx.so
+    gemx_refgen.hip                     device-side Wiener-process reference generation (gemx_refgen_*) }
+The 38 units (19 system/converter pairs x fp32, fp64) and the two objects of libgemx.so are compiled in parallel.
 """
 import concurrent.futures as cf
+import glob
 import hashlib
 import os
 import shutil
@@ -19,6 +22,13 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 SOURCES = [os.path.join(CSRC, f) for f in ("gemx_common.hpp", "gemx_kernels.hpp", "gemx_inst.hip", "gemx_capi.hip", "gemx_refgen.hip")]
 HEADER = os.path.join(REPO, "include", "gemx.h")
 LIB = os.path.join(PKG_DIR, "libgemx.so")
+
+
+def unit_lib(s, c, f64):
+    """the shared object of one kernel unit (beside libgemx.so: gemx_capi.hip's load_unit looks there)"""
+    return os.path.join(PKG_DIR, f"libgemx_u{s}_{c}_{int(f64)}.so")
+
+
 OBJ_DIR = os.path.join(PKG_DIR, "build")
 STAMP = LIB + ".sha256"  # next to the library (the object directory does not travel to the GPU box: .gpurunignore)
 
@@ -49,8 +59,12 @@ _DEPS = {"inst": ["gemx_common.hpp", "gemx_kernels.hpp", "gemx_inst.hip"], "capi
 _COST = {7: 6.0, 2: 5.3, 6: 4.9, 1: 4.5, 5: 4.0, 4: 3.9, 3: 3.5, 0: 3.5}
 
 
+def all_libs():
+    return [LIB] + [unit_lib(s, c, f) for s, c in UNITS for f in (0, 1)]
+
+
 def is_stale():
-    if not os.path.exists(LIB) or not os.path.exists(STAMP):
+    if not os.path.exists(STAMP) or not all(os.path.exists(p) for p in all_libs()):
         return True
     return open(STAMP).read().strip() != _digest()
 
@@ -88,12 +102,12 @@ def _build_locked(hipcc, force, verbose, jobs):
     snap_header = os.path.join(snap, os.path.basename(HEADER))
     csrc = snap
     inc = ["-I" + snap]
-    cmds = []  # (object, command, kind, cost)
+    cmds = []  # (output, command, kind, cost)
     for s, c in UNITS:
         for f64 in (0, 1):
-            obj = os.path.join(OBJ_DIR, f"gemx_inst_{s}_{c}_{f64}.o")
-            cmds.append((obj, [hipcc] + FLAGS + inc + [f"-DGEMX_INST_SYS={s}", f"-DGEMX_INST_CONV={c}", f"-DGEMX_INST_F64={f64}",
-                                                      "-c", os.path.join(csrc, "gemx_inst.hip"), "-o", obj], "inst", _COST[s] * (0.15 if f64 else 1.0)))
+            out = unit_lib(s, c, f64)
+            cmds.append((out, [hipcc] + FLAGS + inc + [f"-DGEMX_INST_SYS={s}", f"-DGEMX_INST_CONV={c}", f"-DGEMX_INST_F64={f64}", "-fvisibility=hidden",
+                                                      "-shared", os.path.join(csrc, "gemx_inst.hip"), "-o", out], "inst", _COST[s] * (0.15 if f64 else 1.0)))
     capi_obj = os.path.join(OBJ_DIR, "gemx_capi.o")
     cmds.append((capi_obj, [hipcc] + FLAGS + inc + ["-c", os.path.join(csrc, "gemx_capi.hip"), "-o", capi_obj], "capi", 0.3))
     refgen_obj = os.path.join(OBJ_DIR, "gemx_refgen.o")
@@ -107,7 +121,7 @@ def _build_locked(hipcc, force, verbose, jobs):
 
     def compile_one(job):  # skipped when the object was built from the same sources with the same flags
         obj, cmd, kind, _ = job
-        stamp = obj + ".sha256"
+        stamp = os.path.join(OBJ_DIR, os.path.basename(obj) + ".sha256")
         if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == digests[kind]:
             return
         run(cmd)
@@ -117,7 +131,10 @@ def _build_locked(hipcc, force, verbose, jobs):
     jobs = jobs or min(len(cmds), os.cpu_count() or 4)
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:  # longest first: the big induction-machine units do not end up as the tail
         list(ex.map(compile_one, sorted(cmds, key=lambda j: -j[3])))
-    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [j[0] for j in cmds])
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, capi_obj, refgen_obj, "-ldl"])
+    for stale in glob.glob(os.path.join(PKG_DIR, "libgemx_u*.so")):  # a unit that is no longer in UNITS must not be found by dlopen
+        if stale not in [j[0] for j in cmds]:
+            os.remove(stale)
     with open(STAMP, "w") as fh:
         fh.write(_digest(snap_sources, snap_header))  # (of what was compiled: an edit made meanwhile leaves the library stale, as it should)
     return LIB

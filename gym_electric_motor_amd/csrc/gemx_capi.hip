@@ -1,9 +1,15 @@
 // gemx_capi.hip -- C ABI of libgemx.so (include/gemx.h): handle management, validation, reset / state access
 // kernels, dispatch to the kernel instantiation units (gemx_inst.hip).  No CPU fallback.
+#include <dlfcn.h>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <new>
+#include <set>
+#include <string>
 
 #include "gemx_common.hpp"
 
@@ -120,10 +126,10 @@ __global__ void reset_kernel(R *state, typename Angle<R>::T *angle, const uint8_
 
 // gemx_synthetic_actions: the synthetic action stream (gemx_common.hpp: synth_u32) written out, [K][N][A] R or [K][N] uint8
 template <class R>
-__global__ void synth_actions_kernel(unsigned char *out, int64_t N, int K, int nact, int n_actions, uint64_t seed, uint32_t step0) {
+__global__ void synth_actions_kernel(unsigned char *out, int64_t N, int K, int nact, int n_actions, uint64_t seed, uint32_t step0, int64_t env_base) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (k, env)
     if (idx >= (int64_t)K * N) return;
-    const int64_t env = idx % N;
+    const int64_t env = env_base + idx % N;  // the stream's env word is the GLOBAL index (gemx_config.env_base)
     const uint32_t t = step0 + (uint32_t)(idx / N);
     if (n_actions > 0) out[idx] = (unsigned char)synth_index(synth_u32(seed, env, t, 0u), (uint32_t)n_actions);
     else
@@ -152,6 +158,8 @@ __global__ void set_state_kernel(R *state, typename Angle<R>::T *angle, const R 
 // =================================================================================================
 using namespace gemx;
 
+void gemx_cov_note(const char *key);  // instantiation coverage (below): a process with GEMX_COVERAGE_FILE set lists every distinct kernel it launches
+#define GEMX_COV(name) gemx_cov_note(name)
 static thread_local char g_err[512] = "";
 namespace gemx {
 int fail(int code, const char *fmt, ...) {
@@ -361,6 +369,7 @@ template <class R> static int launch_reset(gemx_handle *h, const uint8_t *mask, 
     using AngT = typename Angle<R>::T;
     const DevParams<R> &P = params_of<R>(h);
     int64_t blocks = (h->n + 255) / 256;
+    GEMX_COV(sizeof(R) == 4 ? "reset_kernel<float>" : "reset_kernel<double>");
     hipLaunchKernelGGL(reset_kernel<R>, dim3((unsigned)blocks), dim3(256), 0, st, (R *)h->state, (AngT *)h->angle, mask, (R *)obs, h->n,
                        h->nd, h->nout, h->has_angle, h->cfg.obs_layout, P, (const R *)h->reset_obs_dev, (unsigned char *)h->ring,
                        h->cfg.action_delay > 0 ? (int)(h->ring_bytes / ((size_t)h->cfg.action_delay * (size_t)h->n)) : 0, h->cfg.system_kind,
@@ -380,7 +389,8 @@ struct AuxHeader {
     uint64_t steps_total, rc_bytes, ring_bytes, rcnt_bytes;
     uint32_t system_kind, converter_kind;
     uint64_t angle_bytes;
-    unsigned char pad[128 - 88];
+    int64_t env_base;  // version 2: the shard's global env offset (the counter-based streams continue where they were only on the same shard)
+    unsigned char pad[128 - 96];
 };
 static_assert(sizeof(AuxHeader) == 128, "aux header is 128 bytes");
 constexpr uint32_t AUX_MAGIC = 0x55415847u;  // "GXAU"
@@ -399,42 +409,95 @@ __global__ void aux_header_kernel(AuxHeader hd, const uint32_t *fifo_phase, AuxH
     }
 }
 
-namespace gemx {
-#define GEMX_DECL_UNIT(S, C, F) int launch_unit_##S##_##C##_##F(gemx_handle *, const void *, int, void *, uint8_t *, int, hipStream_t);
-GEMX_DECL_UNIT(0, 0, 0) GEMX_DECL_UNIT(0, 0, 1)
-GEMX_DECL_UNIT(1, 1, 0) GEMX_DECL_UNIT(1, 1, 1)
-GEMX_DECL_UNIT(1, 2, 0) GEMX_DECL_UNIT(1, 2, 1)
-GEMX_DECL_UNIT(2, 1, 0) GEMX_DECL_UNIT(2, 1, 1)
-GEMX_DECL_UNIT(2, 2, 0) GEMX_DECL_UNIT(2, 2, 1)
-GEMX_DECL_UNIT(0, 3, 0) GEMX_DECL_UNIT(0, 3, 1)
-GEMX_DECL_UNIT(3, 0, 0) GEMX_DECL_UNIT(3, 0, 1)
-GEMX_DECL_UNIT(3, 3, 0) GEMX_DECL_UNIT(3, 3, 1)
-GEMX_DECL_UNIT(4, 0, 0) GEMX_DECL_UNIT(4, 0, 1)
-GEMX_DECL_UNIT(4, 3, 0) GEMX_DECL_UNIT(4, 3, 1)
-GEMX_DECL_UNIT(5, 4, 0) GEMX_DECL_UNIT(5, 4, 1)
-GEMX_DECL_UNIT(5, 5, 0) GEMX_DECL_UNIT(5, 5, 1)
-GEMX_DECL_UNIT(6, 6, 0) GEMX_DECL_UNIT(6, 6, 1)
-GEMX_DECL_UNIT(6, 7, 0) GEMX_DECL_UNIT(6, 7, 1)
-GEMX_DECL_UNIT(7, 8, 0) GEMX_DECL_UNIT(7, 8, 1)
-GEMX_DECL_UNIT(7, 9, 0) GEMX_DECL_UNIT(7, 9, 1)
-GEMX_DECL_UNIT(1, 10, 0) GEMX_DECL_UNIT(1, 10, 1)
-GEMX_DECL_UNIT(2, 10, 0) GEMX_DECL_UNIT(2, 10, 1)
-GEMX_DECL_UNIT(6, 11, 0) GEMX_DECL_UNIT(6, 11, 1)
-#undef GEMX_DECL_UNIT
-}  // namespace gemx
+// ---- kernel units -----------------------------------------------------------------------------------------------------------------
+// Round 6: the stepping kernels of ONE (system, converter unit, dtype) live in their own shared object, libgemx_u<S>_<C>_<F>.so beside this
+// library (gemx_inst.hip; gym_electric_motor_amd/build.py), loaded by gemx_create with dlopen -- a handle maps this library (C ABI, reset /
+// state access / reference generators: ~2 MB) and the one unit it runs (2-6 MB) instead of 144 MB of all 38.  GEMX_UNIT_DIR names another
+// directory.  A unit exports gemx_unit_init (checks that it was compiled against THIS handle layout and receives the error sink) and
+// gemx_unit_launch (what gemx::launch_unit_S_C_F used to be).
+typedef int (*gemx_unit_launch_fn)(gemx_handle *, const void *, int, void *, uint8_t *, int, hipStream_t);
+typedef int (*gemx_unit_init_fn)(unsigned long long handle_bytes, int abi, void (*set_error)(const char *));
+struct UnitLib { void *dl = nullptr; gemx_unit_launch_fn launch = nullptr; };
+static UnitLib g_units[8][12][2];
+static std::mutex g_units_mu;
+static void unit_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
+static int load_unit(int s, int c, int f, gemx_unit_launch_fn *out) {
+    if (s < 0 || s >= 8 || c < 0 || c >= 12) return fail(GEMX_ERR_ARG, "unsupported system/converter combination %d/%d", s, c);
+    std::lock_guard<std::mutex> lock(g_units_mu);
+    UnitLib &u = g_units[s][c][f];
+    if (u.launch == nullptr) {
+        char dir[1024] = "";
+        const char *ud = getenv("GEMX_UNIT_DIR");
+        if (ud != nullptr && ud[0] != 0) snprintf(dir, sizeof(dir), "%s", ud);
+        else {
+            Dl_info info;
+            if (dladdr((const void *)&gemx_abi_version, &info) == 0 || info.dli_fname == nullptr) return fail(GEMX_ERR_DEVICE, "dladdr failed: cannot locate libgemx.so's directory");
+            snprintf(dir, sizeof(dir), "%s", info.dli_fname);
+            char *slash = strrchr(dir, '/');
+            if (slash != nullptr) *slash = 0;
+            else snprintf(dir, sizeof(dir), ".");
+        }
+        char path[1200];
+        snprintf(path, sizeof(path), "%s/libgemx_u%d_%d_%d.so", dir, s, c, f);
+        void *dl = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (dl == nullptr) {
+            const char *e = dlerror();
+            return fail(GEMX_ERR_ARG, "kernel unit %s cannot be loaded (%s): system/converter combination %d/%d is not built, or the package's build is incomplete "
+                                      "(python -m gym_electric_motor_amd.build)", path, e ? e : "?", s, c);
+        }
+        auto init = (gemx_unit_init_fn)dlsym(dl, "gemx_unit_init");
+        auto launch = (gemx_unit_launch_fn)dlsym(dl, "gemx_unit_launch");
+        if (init == nullptr || launch == nullptr) { dlclose(dl); return fail(GEMX_ERR_ARG, "%s exports no gemx_unit_init / gemx_unit_launch", path); }
+        const int rc = init((unsigned long long)sizeof(gemx_handle), GEMX_ABI_VERSION, unit_set_error);
+        if (rc != GEMX_OK) { dlclose(dl); return fail(GEMX_ERR_ARG, "%s was built from other sources than libgemx.so (handle layout / ABI differ): rebuild the package", path); }
+        u.dl = dl;
+        u.launch = launch;
+    }
+    *out = u.launch;
+    return GEMX_OK;
+}
+
+// ---- instantiation coverage (tools/instantiation_coverage.py): with GEMX_COVERAGE_FILE set, every DISTINCT kernel instantiation a process
+// launches is appended to that file once, as the template arguments of the kernel symbol ("advance_pipe_kernel<1, 1, 0, 1, false, float, 12,
+// 6, false, false, false>") -- diffed against the kernel symbols of the built libraries.  Off (one getenv per process) otherwise.
+static std::mutex g_cov_mu;
+static std::set<std::string> *g_cov_seen = nullptr;
+static const char *g_cov_path = nullptr;
+static bool g_cov_init = false;
+void gemx_cov_note(const char *key) {
+    std::lock_guard<std::mutex> lock(g_cov_mu);
+    if (!g_cov_init) {
+        g_cov_init = true;
+        const char *p = getenv("GEMX_COVERAGE_FILE");
+        if (p != nullptr && p[0] != 0) { g_cov_path = strdup(p); g_cov_seen = new std::set<std::string>(); }
+    }
+    if (g_cov_path == nullptr || !g_cov_seen->insert(key).second) return;
+    FILE *fh = fopen(g_cov_path, "a");
+    if (fh != nullptr) { fprintf(fh, "%s\n", key); fclose(fh); }
+}
+static void cov_note_launch(const gemx_handle *h, bool linmap_built) {
+    const auto &l = h->ll;
+    const char *R = l.real_size == 4 ? "float" : "double", *il = l.il ? "true" : "false";
+    char key[256];
+    if (l.pipe == 3) snprintf(key, sizeof(key), "dc_stream_kernel<%d, %d, %d, float, %d>", l.sys, l.conv, l.solver, l.shape);
+    else if (l.pipe == 2) snprintf(key, sizeof(key), "step_kernel<%d, %d, %d, %d, %s, %s>", l.sys, l.conv, l.load, l.solver, il, R);
+    else if (l.pipe == 1) {
+        static const char *SH[8] = {"12, 3, false, false, false", "4, 2, false, false, false", "2, 2, false, false, false", "12, 6, false, false, false",
+                                    "4, 2, true, false, false", "4, 2, false, true, false", "4, 2, true, true, false", "4, 2, true, false, true"};
+        snprintf(key, sizeof(key), "advance_pipe_kernel<%d, %d, %d, %d, %s, %s, %s>", l.sys, l.conv, l.load, l.solver, il, R, SH[l.shape & 7]);
+    } else snprintf(key, sizeof(key), "advance_kernel<%d, %d, %d, %d, %s, %s>", l.sys, l.conv, l.load, l.solver, il, R);
+    gemx_cov_note(key);
+    if (linmap_built) { snprintf(key, sizeof(key), "linmap_kernel<%d, %d, %s>", l.sys, l.solver, R); gemx_cov_note(key); }
+}
 
 static int launch_advance(gemx_handle *h, const void *actions, int K, void *obs, uint8_t *done, int obs_every, hipStream_t st) {
-    const int s = h->cfg.system_kind, c = h->conv_unit, f = h->cfg.dtype == GEMX_F64;
-#define GEMX_UNIT(S, C)                                                                                     \
-    if (s == S && c == C)                                                                                   \
-        return f ? gemx::launch_unit_##S##_##C##_1(h, actions, K, obs, done, obs_every, st)                 \
-                 : gemx::launch_unit_##S##_##C##_0(h, actions, K, obs, done, obs_every, st);
-    GEMX_UNIT(0, 0) GEMX_UNIT(1, 1) GEMX_UNIT(1, 2) GEMX_UNIT(2, 1) GEMX_UNIT(2, 2)
-    GEMX_UNIT(0, 3) GEMX_UNIT(3, 0) GEMX_UNIT(3, 3) GEMX_UNIT(4, 0) GEMX_UNIT(4, 3)
-    GEMX_UNIT(5, 4) GEMX_UNIT(5, 5) GEMX_UNIT(6, 6) GEMX_UNIT(6, 7) GEMX_UNIT(7, 8) GEMX_UNIT(7, 9)
-    GEMX_UNIT(1, 10) GEMX_UNIT(2, 10) GEMX_UNIT(6, 11)
-#undef GEMX_UNIT
-    return fail(GEMX_ERR_ARG, "unsupported system/converter combination %d/%d", s, c);
+    if (h->unit_launch == nullptr) return fail(GEMX_ERR_ARG, "internal: the handle's kernel unit is not loaded");
+    const int lin_before = h->linmap_state;
+    const int rc = ((gemx_unit_launch_fn)h->unit_launch)(h, actions, K, obs, done, obs_every, st);
+    if (rc != GEMX_OK) return rc;
+    h->steps_total += (unsigned long long)K;  // (only what was launched: a refused launch leaves the count the checkpoint header carries alone)
+    cov_note_launch(h, lin_before == 0 && h->linmap_state == 1);
+    return GEMX_OK;
 }
 
 static int elem_size(const gemx_handle *h) { return h->cfg.dtype == GEMX_F64 ? 8 : 4; }
@@ -481,6 +544,7 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         return fail(GEMX_ERR_ARG, "gemx_config ABI mismatch (struct_size %d vs %d, abi %d vs %d)", cfg->struct_size,
                     (int)sizeof(gemx_config), cfg->abi_version, GEMX_ABI_VERSION);
     if (n_envs <= 0) return fail(GEMX_ERR_ARG, "n_envs must be positive");
+    if (cfg->env_base < 0 || cfg->env_base > INT64_MAX - n_envs) return fail(GEMX_ERR_ARG, "env_base must be >= 0 (the global index of this handle's env 0)");
     if (!(cfg->tau > 0)) return fail(GEMX_ERR_ARG, "tau must be positive");
     if (cfg->interlocking_time < 0 || cfg->interlocking_time >= cfg->tau)
         return fail(GEMX_ERR_ARG, "interlocking_time must be in [0, tau)");
@@ -595,6 +659,12 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
     }
     if (device < 0 || device >= ndev) { delete h; return fail(GEMX_ERR_ARG, "device %d out of range (0..%d)", device, ndev - 1); }
     gemx::DeviceGuard guard(device);  // the caller's current device is restored on every return path
+    {  // this handle's kernel unit (dlopen on first use in the process)
+        gemx_unit_launch_fn fn = nullptr;
+        rc = load_unit(cfg->system_kind, h->conv_unit, cfg->dtype == GEMX_F64 ? 1 : 0, &fn);
+        if (rc != GEMX_OK) { delete h; return rc; }
+        h->unit_launch = (void *)fn;
+    }
     {
         int cur = -1;
         if (hipGetDevice(&cur) != hipSuccess || cur != device) { delete h; return fail(GEMX_ERR_DEVICE, "hipSetDevice(%d) failed", device); }
@@ -661,6 +731,7 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
         I.kind = cfg->init_kind;
         I.n = h->nd + h->has_angle;
         I.seed = cfg->seed;
+        I.env_base = cfg->env_base;
         for (int j = 0; j < I.n; ++j) {
             I.lo[j] = cfg->init_lo[j]; I.hi[j] = cfg->init_hi[j]; I.mu[j] = cfg->init_mu[j]; I.sigma[j] = cfg->init_sigma[j];
             I.constant[j] = cfg->init_state[j];
@@ -810,10 +881,14 @@ int gemx_get_aux_state(gemx_handle *h, void *blob_out_dev, void *stream) {
     AuxHeader hd;
     memset(&hd, 0, sizeof(hd));
     hd.angle_bytes = ang_b;
-    hd.magic = AUX_MAGIC; hd.version = 1; hd.n = h->n; hd.elem_size = (uint32_t)elem_size(h); hd.delay = (uint32_t)h->cfg.action_delay;
+    hd.magic = AUX_MAGIC; hd.version = 2; hd.env_base = h->cfg.env_base; hd.n = h->n; hd.elem_size = (uint32_t)elem_size(h); hd.delay = (uint32_t)h->cfg.action_delay;
     hd.nact_conv = (uint32_t)h->nact_conv; hd.supply_rc = h->cfg.supply_kind == GEMX_SUPPLY_RC; hd.init_kind = (uint32_t)h->cfg.init_kind;
     hd.steps_total = h->steps_total; hd.rc_bytes = rc_b; hd.ring_bytes = ring_b; hd.rcnt_bytes = rcnt_b;
     hd.system_kind = (uint32_t)h->cfg.system_kind; hd.converter_kind = (uint32_t)h->cfg.converter_kind;
+    // (the 16-byte padding between the sections is part of the blob: zeroed here, so that blobs of equal states are equal bytes for a C
+    // caller that hashes or compares them -- advisor finding, round 5; the Python binding used to pre-zero its buffer for that)
+    HIP_TRY(hipMemsetAsync(blob_out_dev, 0, (size_t)gemx_aux_state_bytes(h), st));
+    GEMX_COV("aux_header_kernel");
     hipLaunchKernelGGL(aux_header_kernel, dim3(1), dim3(64), 0, st, hd, (const uint32_t *)h->fifo_phase, (AuxHeader *)blob_out_dev);
     HIP_TRY(hipGetLastError());
     unsigned char *p = (unsigned char *)blob_out_dev + sizeof(AuxHeader);
@@ -838,12 +913,12 @@ int gemx_set_aux_state(gemx_handle *h, const void *blob_in_dev, void *stream) {
     HIP_TRY(hipStreamSynchronize(st));
     size_t rc_b, ring_b, rcnt_b, ang_b;
     aux_sections(h, rc_b, ring_b, rcnt_b, ang_b);
-    if (hd.magic != AUX_MAGIC || hd.version != 1) return fail(GEMX_ERR_ARG, "not a gemx aux-state blob (magic %08x, version %u)", hd.magic, hd.version);
+    if (hd.magic != AUX_MAGIC || hd.version != 2) return fail(GEMX_ERR_ARG, "not a gemx aux-state blob (magic %08x, version %u)", hd.magic, hd.version);
     if (hd.n != h->n || hd.elem_size != (uint32_t)elem_size(h) || hd.delay != (uint32_t)h->cfg.action_delay || hd.nact_conv != (uint32_t)h->nact_conv ||
         hd.supply_rc != (uint32_t)(h->cfg.supply_kind == GEMX_SUPPLY_RC) || hd.init_kind != (uint32_t)h->cfg.init_kind || hd.rc_bytes != rc_b ||
-        hd.ring_bytes != ring_b || hd.rcnt_bytes != rcnt_b || hd.angle_bytes != ang_b || hd.system_kind != (uint32_t)h->cfg.system_kind || hd.converter_kind != (uint32_t)h->cfg.converter_kind)
-        return fail(GEMX_ERR_ARG, "aux-state blob was taken from a handle of another configuration (n_envs %lld vs %lld, dtype, DeadTimeProcessor steps, supply or initialiser kind differ)",
-                    (long long)hd.n, (long long)h->n);
+        hd.ring_bytes != ring_b || hd.rcnt_bytes != rcnt_b || hd.angle_bytes != ang_b || hd.system_kind != (uint32_t)h->cfg.system_kind || hd.converter_kind != (uint32_t)h->cfg.converter_kind || hd.env_base != h->cfg.env_base)
+        return fail(GEMX_ERR_ARG, "aux-state blob was taken from a handle of another configuration (n_envs %lld vs %lld, env_base %lld vs %lld, dtype, DeadTimeProcessor steps, supply or initialiser kind differ)",
+                    (long long)hd.n, (long long)h->n, (long long)hd.env_base, (long long)h->cfg.env_base);
     if (h->cfg.action_delay > 0 && hd.fifo_phase >= (uint32_t)h->cfg.action_delay) return fail(GEMX_ERR_ARG, "aux-state blob: FIFO phase %u out of range", hd.fifo_phase);
     const unsigned char *p = (const unsigned char *)blob_in_dev + sizeof(AuxHeader);
     if (rc_b) HIP_TRY(hipMemcpyAsync((unsigned char *)h->state + (size_t)h->nd * (size_t)h->n * elem_size(h), p, rc_b, hipMemcpyDeviceToDevice, st));
@@ -888,10 +963,11 @@ int gemx_synthetic_actions(gemx_handle *h, uint64_t seed, uint32_t step0, int32_
     gemx::DeviceGuard guard(h->device);
     const int64_t total = (int64_t)K * h->n;
     const unsigned blocks = (unsigned)((total + 255) / 256);
+    GEMX_COV(h->cfg.dtype == GEMX_F64 ? "synth_actions_kernel<double>" : "synth_actions_kernel<float>");
     if (h->cfg.dtype == GEMX_F64)
-        hipLaunchKernelGGL(synth_actions_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned char *)actions_out_dev, h->n, K, h->nact, n_discrete_actions(h), seed, step0);
+        hipLaunchKernelGGL(synth_actions_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned char *)actions_out_dev, h->n, K, h->nact, n_discrete_actions(h), seed, step0, h->cfg.env_base);
     else
-        hipLaunchKernelGGL(synth_actions_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned char *)actions_out_dev, h->n, K, h->nact, n_discrete_actions(h), seed, step0);
+        hipLaunchKernelGGL(synth_actions_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned char *)actions_out_dev, h->n, K, h->nact, n_discrete_actions(h), seed, step0, h->cfg.env_base);
     HIP_TRY(hipGetLastError());
     return GEMX_OK;
 }
@@ -981,6 +1057,7 @@ int gemx_get_state(gemx_handle *h, void *soa_out_dev, void *stream) {
     gemx::DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
     int64_t blocks = (h->n + 255) / 256;
+    GEMX_COV(h->cfg.dtype == GEMX_F64 ? "get_state_kernel<double>" : "get_state_kernel<float>");
     if (h->cfg.dtype == GEMX_F64)
         hipLaunchKernelGGL(get_state_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st, (const double *)h->state, (const double *)h->angle,
                            (double *)soa_out_dev, h->n, h->nd, h->has_angle);
@@ -995,6 +1072,7 @@ int gemx_set_state(gemx_handle *h, const void *soa_in_dev, void *stream) {
     gemx::DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
     int64_t blocks = (h->n + 255) / 256;
+    GEMX_COV(h->cfg.dtype == GEMX_F64 ? "set_state_kernel<double>" : "set_state_kernel<float>");
     if (h->cfg.dtype == GEMX_F64)
         hipLaunchKernelGGL(set_state_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st, (double *)h->state, (double *)h->angle,
                            (const double *)soa_in_dev, h->n, h->nd, h->has_angle);

@@ -220,7 +220,7 @@ template <class R> __device__ __forceinline__ void t32(R al, R be, R &a, R &b, R
 
 // ------------------------------------------------------------------------------------------------
 // random initial states: Philox4x32-10 (Salmon et al., SC'11), counter = (env lo, env hi, reset count, block), key = seed.
-// Counter-based, so a reset needs no RNG state beyond the env's reset count.
+// Counter-based, so a reset needs no RNG state beyond the env's reset count.  env = the GLOBAL env index (gemx_config.env_base + i).
 // ------------------------------------------------------------------------------------------------
 struct Philox {
     static __host__ __device__ __forceinline__ void round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
@@ -245,6 +245,7 @@ struct Philox {
 struct InitDev {
     int32_t kind, n;  // gemx_init_kind; number of ODE states incl. the angle
     uint64_t seed;
+    int64_t env_base;  // gemx_config.env_base: the streams are keyed by the GLOBAL env index env_base + i (a shard draws what the unsharded job draws)
     double lo[GEMX_MAX_ODE], hi[GEMX_MAX_ODE], mu[GEMX_MAX_ODE], sigma[GEMX_MAX_ODE], constant[GEMX_MAX_ODE];
     double cdf_lo[GEMX_MAX_ODE], cdf_hi[GEMX_MAX_ODE];  // gaussian: Phi((lo - mu) / sigma), Phi((hi - mu) / sigma), computed on the host
     // induction machines (gemx_config.init_flux_mode): the two flux states' bounds are re-derived at every reset from a random field
@@ -300,8 +301,9 @@ __device__ __forceinline__ void init_uniforms_from(const uint32_t (&r0)[4], cons
 }
 __device__ __forceinline__ void init_uniforms(const InitDev *I, int64_t env, uint32_t count, double (&u)[GEMX_MAX_ODE], bool block1 = true) {
     uint32_t r0[4], r1[4] = {0u, 0u, 0u, 0u};
-    Philox::block(I->seed, (uint64_t)env, count, 0u, r0);
-    if (block1 && init_needs_block1(I)) Philox::block(I->seed, (uint64_t)env, count, 1u, r1);
+    const uint64_t genv = (uint64_t)(I->env_base + env);  // global env index
+    Philox::block(I->seed, genv, count, 0u, r0);
+    if (block1 && init_needs_block1(I)) Philox::block(I->seed, genv, count, 1u, r1);
     init_uniforms_from(r0, r1, u);
 }
 // one state from its uniform with explicit bounds (the induction machines' per-reset flux bounds)
@@ -453,6 +455,7 @@ template <class R> struct KArgs {
     // synthetic actions (gemx_rollout_synthetic): act_synth != 0 -> `actions` is not read; the loader wave generates synth_u32(act_seed, env,
     // act_step0 + k, component) instead
     uint64_t act_seed;
+    int64_t act_env_base;  // gemx_config.env_base: the stream is keyed by the global env index
     uint32_t act_step0;
     int32_t act_synth;
 };
@@ -552,6 +555,7 @@ struct gemx_handle {
     size_t ring_bytes = 0;
     int nact_conv = 1;       // converter-side action width (== nact unless a dq action frame is configured)
     int conv_unit = 0;       // converter kind of the kernel unit (internal dq kinds included)
+    void *unit_launch = nullptr;  // gemx_unit_launch of libgemx_u<system>_<conv_unit>_<dtype>.so, loaded by gemx_create (gemx_capi.hip: load_unit)
     unsigned long long steps_total = 0;  // control steps launched since creation (informational; the FIFO phase lives on the device)
     uint32_t *fifo_phase = nullptr;      // device words [phase, ticket] of the DeadTimeProcessor FIFO (KArgs::fifo_phase)
     uint32_t *err = nullptr;
@@ -561,7 +565,7 @@ struct gemx_handle {
     int n_cu = 256;
     size_t lds_max = 160 * 1024;
     int steps_per_block = 0;  // 0 = heuristic
-    struct LastLaunch { int pipe, sys, conv, load, solver, il, real_size, d, threads, k, s; long long blocks; size_t lds; unsigned pace, pace_tail; long long pace_res; };
+    struct LastLaunch { int pipe, sys, conv, load, solver, il, real_size, d, threads, k, s; long long blocks; size_t lds; unsigned pace, pace_tail; long long pace_res; int shape; };  // shape: pipelined kernel: pipe_kernel_of's index; dc_stream_kernel: envs per workgroup
     LastLaunch ll = {};            // most recent advance launch (formatted lazily by gemx_last_launch)
     mutable char last_launch[512] = "";
     char overrides[192] = "";  // the GEMX_* environment switches that were set when the handle was created ("NAME=value ..."): gemx_last_launch() names them

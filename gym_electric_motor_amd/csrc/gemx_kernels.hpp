@@ -2617,10 +2617,10 @@ void advance_pipe_kernel(const KArgs<R> a) {
             for (int s = 0; s < D; ++s) {
                 const uint32_t t = a.act_step0 + (uint32_t)(b * D + (s < sb ? s : sb - 1));
                 if constexpr (DISCRETE) {
-                    dst[(size_t)s * ROWB + tid] = (unsigned char)synth_index(synth_u32(a.act_seed, envc, t, 0u), (uint32_t)ConvTraits<CONV>::NACTIONS);
+                    dst[(size_t)s * ROWB + tid] = (unsigned char)synth_index(synth_u32(a.act_seed, a.act_env_base + envc, t, 0u), (uint32_t)ConvTraits<CONV>::NACTIONS);
                 } else {
 #pragma unroll
-                    for (int i = 0; i < NACT; ++i) reinterpret_cast<R *>(dst + (size_t)s * ROWB)[tid * NACT + i] = (R)synth_unit(synth_u32(a.act_seed, envc, t, (uint32_t)i));
+                    for (int i = 0; i < NACT; ++i) reinterpret_cast<R *>(dst + (size_t)s * ROWB)[tid * NACT + i] = (R)synth_unit(synth_u32(a.act_seed, a.act_env_base + envc, t, (uint32_t)i));
                 }
             }
             return;
@@ -3344,17 +3344,18 @@ void advance_pipe_kernel(const KArgs<R> a) {
                         }
                         return 3;
                     };
+                    const uint64_t prep_genv = (uint64_t)(I->env_base + envc);  // the streams' env word is the GLOBAL index
                     if (prep_phase == 1) {
-                        Philox::block(I->seed, (uint64_t)envc, prep_c + 1u, 0u, pq0);
+                        Philox::block(I->seed, prep_genv, prep_c + 1u, 0u, pq0);
                         prep_phase = blk1 ? 2 : after_own_blocks();
                     } else if (prep_phase == 2) {
-                        Philox::block(I->seed, (uint64_t)envc, prep_c + 1u, 1u, pq1);
+                        Philox::block(I->seed, prep_genv, prep_c + 1u, 1u, pq1);
                         prep_phase = after_own_blocks();
                     } else if (prep_phase == 3) {
-                        Philox::block(I->seed, (uint64_t)envc, prep_c, 0u, pp0);
+                        Philox::block(I->seed, prep_genv, prep_c, 0u, pp0);
                         prep_phase = I->flux_slot > 4 ? 4 : 5;  // (the currents' uniforms, slots flux_slot - 2 and - 1, sit in block 0 for every machine built)
                     } else if (prep_phase == 4) {
-                        Philox::block(I->seed, (uint64_t)envc, prep_c, 1u, pp1);
+                        Philox::block(I->seed, prep_genv, prep_c, 1u, pp1);
                         prep_phase = 5;
                     } else if (prep_phase == 5) {
                         if (prep_act) {
@@ -4231,13 +4232,13 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     a.actions = (const unsigned char *)actions;
     a.act_synth = h->cur_synth ? 1 : 0;
     a.act_seed = h->cur_seed;
+    a.act_env_base = h->cfg.env_base;
     a.act_step0 = h->cur_step0;
     a.obs = (R *)obs;
     a.done = done;
     a.ring = (unsigned char *)h->ring;
     const int delay = h->cfg.action_delay;
     a.fifo_phase = h->fifo_phase;
-    h->steps_total += (unsigned long long)K;
     a.err = h->err;
     if (h->linmap_state == 0) {  // once per handle: the electrical subsystem's one-step map (constant-speed loads)
         // (random initialisers that draw OMEGA per episode keep the stage-by-stage solver.  Round 5: only those -- a random MOTOR initialiser
@@ -4345,6 +4346,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             hipLaunchKernelGGL(dkern, dim3((unsigned)dblocks), dim3(dcs_waves<SYS>() * BLOCK), dsmem, st, a);
             GEMX_HIP_TRY(hipGetLastError());
             h->ll = {3, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), dd, dcs_waves<SYS>() * BLOCK, K, dd, dblocks, dsmem};
+            h->ll.shape = epw32 ? BLOCK / 2 : BLOCK;  // (the kernel's envs-per-workgroup template argument)
             return GEMX_OK;
         }
     }
@@ -4629,6 +4631,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             h->pace_scale_last = pace_scale_used;
             h->pace_cal_state = h->pcal.chosen >= 0 ? 2 : (cal_slot >= 0 ? 1 : 0);
             h->ll = {1, SYS, CONV, LOAD, SOLVER, (int)IL, (int)sizeof(R), D, threads, K, D, (long long)blocks, psmem, a.pace_block_ticks, a.pace_tail_ticks, (long long)pace_res};
+            h->ll.shape = shape;
             return GEMX_OK;
         }
     }

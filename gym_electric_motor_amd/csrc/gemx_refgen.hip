@@ -14,6 +14,8 @@
 // (env, generator) walks its K steps sequentially: scale by the sub-episode's sigma, accumulate, clip, restart on `done`.
 #include "gemx_common.hpp"
 
+void gemx_cov_note(const char *key);  // gemx_capi.hip: instantiation coverage (GEMX_COVERAGE_FILE)
+
 struct gemx_refgen {
     gemx_refgen_config cfg;
     int64_t n;
@@ -44,7 +46,7 @@ __device__ inline void refgen_block(uint64_t seed, int64_t env, int gen, int kin
 
 // (1) standard normals for steps t0 .. t0+K-1 of every (env, generator): Box-Muller on two Philox words
 template <class R>
-__global__ void refgen_normals_kernel(R *out, int64_t N, int n_ref, int K, uint64_t seed, uint64_t t0) {
+__global__ void refgen_normals_kernel(R *out, int64_t N, int n_ref, int K, uint64_t seed, uint64_t t0, int64_t env_base) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)K * N * n_ref;
     if (idx >= total) return;
@@ -52,7 +54,7 @@ __global__ void refgen_normals_kernel(R *out, int64_t N, int n_ref, int K, uint6
     const int64_t env = (idx / n_ref) % N;
     const int64_t k = idx / ((int64_t)n_ref * N);
     uint32_t r[4];
-    refgen_block(seed, env, g, DRAW_STEP, t0 + (uint64_t)k, r);
+    refgen_block(seed, env_base + env, g, DRAW_STEP, t0 + (uint64_t)k, r);  // (the GLOBAL env index keys the stream)
     const double u1 = gemx::Philox::u01(r[0]), u2 = gemx::Philox::u01(r[1]);
     out[idx] = (R)(sqrt(-2.0 * log(u1)) * cos(gemx::kTwoPi * u2));
 }
@@ -60,13 +62,14 @@ __global__ void refgen_normals_kernel(R *out, int64_t N, int n_ref, int K, uint6
 struct RefgenDev {
     int32_t n_ref, len_lo, len_hi;
     uint64_t seed;
+    int64_t env_base;  // gemx_refgen_config.env_base
     double log_sig_lo[GEMX_MAX_REF], log_sig_hi[GEMX_MAX_REF], m_lo[GEMX_MAX_REF], m_hi[GEMX_MAX_REF], i_lo[GEMX_MAX_REF], i_hi[GEMX_MAX_REF];
 };
 
 // SubepisodedReferenceGenerator.get_reference_observation, lines 104-111: a new sub-episode draws its length and its sigma
 __device__ inline void new_subepisode(const RefgenDev &G, int64_t env, int g, uint32_t &n_sub, int32_t &left, double &sigma) {
     uint32_t r[4];
-    refgen_block(G.seed, env, g, DRAW_SUB, n_sub++, r);
+    refgen_block(G.seed, G.env_base + env, g, DRAW_SUB, n_sub++, r);
     // int((hi - lo) * U + lo), _get_current_value lines 116-119; then 10 ** U(log10 sigma_range), wiener ... line 31
     left = (int32_t)((double)(G.len_hi - G.len_lo) * gemx::Philox::u01(r[0]) + (double)G.len_lo);
     sigma = pow(10.0, (G.log_sig_hi[g] - G.log_sig_lo[g]) * gemx::Philox::u01(r[1]) + G.log_sig_lo[g]);
@@ -75,7 +78,7 @@ __device__ inline void new_subepisode(const RefgenDev &G, int64_t env, int g, ui
 __device__ inline void reset_generator(const RefgenDev &G, int64_t env, int g, uint32_t &n_reset, uint32_t &n_sub, int32_t &left, double &sigma,
                                        double &value) {
     uint32_t r[4];
-    refgen_block(G.seed, env, g, DRAW_RESET, n_reset++, r);
+    refgen_block(G.seed, G.env_base + env, g, DRAW_RESET, n_reset++, r);
     value = (G.i_hi[g] - G.i_lo[g]) * gemx::Philox::u01(r[0]) + G.i_lo[g];
     left = 0;  // `_current_episode_length = -1`: the next get_reference_observation starts a sub-episode
     (void)n_sub; (void)sigma;
@@ -118,7 +121,7 @@ __global__ void refgen_walk_kernel(R *out, const uint8_t *done, const uint8_t *r
 RefgenDev make_dev(const gemx_refgen_config &c) {
     RefgenDev G;
     memset(&G, 0, sizeof(G));
-    G.n_ref = c.n_ref; G.len_lo = c.episode_len_lo; G.len_hi = c.episode_len_hi; G.seed = c.seed;
+    G.n_ref = c.n_ref; G.len_lo = c.episode_len_lo; G.len_hi = c.episode_len_hi; G.seed = c.seed; G.env_base = c.env_base;
     for (int g = 0; g < c.n_ref; ++g) {
         G.log_sig_lo[g] = log10(c.sigma_lo[g]); G.log_sig_hi[g] = log10(c.sigma_hi[g]);
         G.m_lo[g] = c.margin_lo[g]; G.m_hi[g] = c.margin_hi[g]; G.i_lo[g] = c.initial_lo[g]; G.i_hi[g] = c.initial_hi[g];
@@ -128,6 +131,7 @@ RefgenDev make_dev(const gemx_refgen_config &c) {
 
 template <class R> int walk(gemx_refgen *r, void *out, const uint8_t *done, const uint8_t *mask, int reset_all, int K, hipStream_t st) {
     const int64_t lanes = r->n * r->cfg.n_ref;
+    gemx_cov_note(sizeof(R) == 4 ? "refgen_walk_kernel<float>" : "refgen_walk_kernel<double>");
     hipLaunchKernelGGL(refgen_walk_kernel<R>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, (R *)out, done, mask, reset_all, r->n, K, make_dev(r->cfg),
                        r->value, r->sigma, r->left, r->n_sub, r->n_reset);
     GEMX_HIP_TRY(hipGetLastError());
@@ -142,6 +146,7 @@ int gemx_refgen_create(const gemx_refgen_config *cfg, int64_t n_envs, int device
     if (!cfg || !out) return gemx::fail(GEMX_ERR_ARG, "null argument");
     *out = nullptr;
     if (cfg->struct_size != (int32_t)sizeof(gemx_refgen_config)) return gemx::fail(GEMX_ERR_ARG, "gemx_refgen_config size mismatch");
+    if (cfg->env_base < 0) return gemx::fail(GEMX_ERR_ARG, "env_base must be >= 0");
     if (cfg->n_ref < 1 || cfg->n_ref > GEMX_MAX_REF) return gemx::fail(GEMX_ERR_ARG, "n_ref must be in [1, %d]", GEMX_MAX_REF);
     if (n_envs <= 0) return gemx::fail(GEMX_ERR_ARG, "n_envs must be positive");
     if (cfg->episode_len_lo < 1 || cfg->episode_len_hi < cfg->episode_len_lo) return gemx::fail(GEMX_ERR_ARG, "episode lengths must satisfy 1 <= lo <= hi");
@@ -198,12 +203,13 @@ int gemx_refgen_rollout(gemx_refgen *r, const uint8_t *done_dev, int32_t K, void
     gemx::DeviceGuard guard(r->device);
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)K * r->n * r->cfg.n_ref;
+    gemx_cov_note(r->f64 ? "refgen_normals_kernel<double>" : "refgen_normals_kernel<float>");
     if (r->f64)
         hipLaunchKernelGGL(refgen_normals_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (double *)refs_out_dev, r->n, r->cfg.n_ref, K,
-                           r->cfg.seed, (uint64_t)r->t_total);
+                           r->cfg.seed, (uint64_t)r->t_total, r->cfg.env_base);
     else
         hipLaunchKernelGGL(refgen_normals_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (float *)refs_out_dev, r->n, r->cfg.n_ref, K,
-                           r->cfg.seed, (uint64_t)r->t_total);
+                           r->cfg.seed, (uint64_t)r->t_total, r->cfg.env_base);
     GEMX_HIP_TRY(hipGetLastError());
     r->t_total += (unsigned long long)K;
     return r->f64 ? walk<double>(r, refs_out_dev, done_dev, nullptr, 0, K, st) : walk<float>(r, refs_out_dev, done_dev, nullptr, 0, K, st);

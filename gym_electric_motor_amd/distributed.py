@@ -145,10 +145,14 @@ def gather_rollout(obs_chunk, done_chunk=None, group=None, force=False, out=None
 
 
 def make_sharded(env_id, n_envs_total, rank, world, device, **kwargs):
-    """This rank's shard of a `n_envs_total`-env batched environment."""
+    """This rank's shard of a `n_envs_total`-env batched environment: envs [lo, hi) of the job, with `env_base = lo`, so that every
+    device-side random stream (random initial states, `rollout_synthetic` actions, the Wiener reference generators that are given this
+    system) is keyed by the env's GLOBAL index -- W shards draw exactly what one unsharded system of n_envs_total envs draws (round 5
+    keyed them by the local index: every rank replayed rank 0's draws)."""
     from .envs import make
 
     lo, hi = shard_range(n_envs_total, rank, world)
+    kwargs.setdefault("env_base", lo)
     env = make(env_id, n_envs=hi - lo, device=device, **kwargs)
     env.shard = (lo, hi)
     env.n_envs_total = n_envs_total

@@ -100,7 +100,7 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
 
     def __init__(self, converter, motor, load, supply, ode_solver, tau=1e-4, calc_jacobian=None, n_envs=1, device=0,
                  dtype="float32", constraints=(), auto_reset=None, obs_layout="aos", control_space="abc", action_frame=None,
-                 action_delay=0, action_delay_reset=None, seed=0, _defer_create=False):
+                 action_delay=0, action_delay_reset=None, seed=0, env_base=0, _defer_create=False):
         """
         Args (first six as in SCMLSystem.__init__, physical_systems.py:54-65):
             converter, motor, load, supply: component instances (this package's or the reference's).
@@ -124,6 +124,11 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
                 `action_delay` steps earlier (the reset action right after a reset).
             action_delay_reset: the ONE action every reset refills that queue with (DeadTimeProcessor(reset_action=...)), in the
                 action space of the system the processor wraps; None = zeros, the reference's default.
+            seed(int): key of every device-side random stream (random initialisers; `rollout_synthetic` takes its own).
+            env_base(int): GLOBAL index of this system's env 0.  The streams are keyed by (seed, env_base + i, ...), so the shards of
+                one job (`distributed.make_sharded` sets env_base to the shard's first env) draw, env by env, what one unsharded
+                system draws -- the reference gives every env object its own branch of the seed sequence (core.py:373-385,
+                physical_systems.py:164-169, random_component.py:60-87).
         """
         if control_space not in ("abc", "dq"):
             raise ValueError(f"control_space must be 'abc' or 'dq', got {control_space!r}")
@@ -132,6 +137,9 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         if action_frame not in ("abc", "dq", "dq_processor"):
             raise ValueError(f"action_frame must be 'abc', 'dq' or 'dq_processor', got {action_frame!r}")
         self._seed = int(seed) & (2**64 - 1)
+        self._env_base = int(env_base)
+        if self._env_base < 0:
+            raise ValueError(f"env_base must be >= 0, got {env_base!r}")
         self._action_frame = action_frame
         self._action_delay = int(action_delay)
         if not 0 <= self._action_delay <= _lib.MAX_DELAY:
@@ -187,6 +195,7 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
     electrical_motor = property(lambda self: self._electrical_motor)
     mechanical_load = property(lambda self: self._mechanical_load)
     n_envs = property(lambda self: self._n_envs)
+    env_base = property(lambda self: self._env_base, doc="global index of env 0 (the key of every device random stream is env_base + i)")
     device = property(lambda self: self._device)
     dead_time = property(lambda self: self._action_delay)  # DeadTimeProcessor.dead_time (dead_time_processor.py:43-46)
 
@@ -486,6 +495,7 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             raise ValueError("motor and load initialisers must use the same distribution on the accelerated path")
         cfg.init_kind = {"uniform": _lib.INIT_UNIFORM, "gaussian": _lib.INIT_GAUSSIAN}[kinds.pop()] if kinds else _lib.INIT_CONST
         cfg.seed = self._seed
+        cfg.env_base = self._env_base
         if induction and (getattr(mot, "initializer", None) or {}).get("random_init") is not None:
             names = list(((mot.initializer or {}).get("states") or {}).keys())
             if names[:4] != ["i_salpha", "i_sbeta", "psi_ralpha", "psi_rbeta"]:
@@ -771,8 +781,11 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             obs_out = torch.empty(oshape, dtype=self._tdtype, device=self._tdev)
         if done_out is None:
             done_out = torch.empty(dshape, dtype=torch.uint8, device=self._tdev)
-        assert tuple(obs_out.shape) == oshape and obs_out.is_contiguous() and obs_out.dtype == self._tdtype
-        assert tuple(done_out.shape) == dshape and done_out.is_contiguous() and done_out.dtype == torch.uint8
+        # (the checks of bind_rollout -- incl. the DEVICE: a host or other-GPU tensor would hand the kernel a foreign pointer; advisor, round 5)
+        if not (torch.is_tensor(obs_out) and tuple(obs_out.shape) == oshape and obs_out.is_contiguous() and obs_out.dtype == self._tdtype and obs_out.device == self._tdev):
+            raise ValueError(f"rollout_synthetic: obs_out must be a contiguous {self._tdtype} tensor of shape {oshape} on {self._tdev}")
+        if not (torch.is_tensor(done_out) and tuple(done_out.shape) == dshape and done_out.is_contiguous() and done_out.dtype == torch.uint8 and done_out.device == self._tdev):
+            raise ValueError(f"rollout_synthetic: done_out must be a contiguous uint8 tensor of shape {dshape} on {self._tdev}")
         _lib.check(self._L.gemx_rollout_synthetic(self._handle, int(seed) & (2**64 - 1), s0, K, C.c_void_p(obs_out.data_ptr()),
                                                   C.c_void_p(done_out.data_ptr()), self._stream()))
         self._k += K
@@ -948,7 +961,7 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         solvers.py:44-45, converters.py:193-197, dead_time_processor.py:63-72, voltage_supplies.py:100-123."""
         torch = _torch()
         nb = int(self._L.gemx_aux_state_bytes(self._handle))
-        aux = torch.zeros(nb, dtype=torch.uint8, device=self._tdev)  # (zeros: the sections' padding is not written -- equal states, equal blobs)
+        aux = torch.empty(nb, dtype=torch.uint8, device=self._tdev)  # (gemx_get_aux_state zeroes the sections' padding itself: equal states, equal blobs)
         _lib.check(self._L.gemx_get_aux_state(self._handle, C.c_void_p(aux.data_ptr()), self._stream()))
         return {"state": self.get_state(), "switch_state": self.get_switch_state(), "aux": aux, "k": int(self._k)}
 

@@ -23,7 +23,7 @@ from . import _lib
 
 class BatchedWienerProcessReferenceGenerator:
     def __init__(self, reference_states=("omega",), sigma_range=(1e-3, 1e-1), episode_lengths=(500, 2000), limit_margin=None,
-                 initial_range=None, seed=0):
+                 initial_range=None, seed=0, env_base=None):
         self._reference_states = tuple(s.lower() for s in ([reference_states] if isinstance(reference_states, str) else reference_states))
         if not 1 <= len(self._reference_states) <= _lib.MAX_REF:
             raise ValueError(f"1..{_lib.MAX_REF} reference states")
@@ -32,6 +32,7 @@ class BatchedWienerProcessReferenceGenerator:
         self._limit_margin = limit_margin
         self._initial_range = initial_range
         self._seed = int(seed) & (2**64 - 1)
+        self._env_base = None if env_base is None else int(env_base)  # None: the physical system's (a shard's generators follow its envs)
         self._handle = None
 
     reference_names = property(lambda self: self._ordered)
@@ -59,6 +60,7 @@ class BatchedWienerProcessReferenceGenerator:
         cfg.struct_size = C.sizeof(_lib.GemxRefgenConfig)
         cfg.n_ref = len(self._ordered)
         cfg.seed = self._seed
+        cfg.env_base = self._env_base if self._env_base is not None else int(getattr(ps, "env_base", 0))
         cfg.episode_len_lo, cfg.episode_len_hi = self._episode_lengths
         for j, name in enumerate(self._ordered):
             lo, hi = self._margins(ps, name)

@@ -28,9 +28,12 @@
 extern "C" {
 #endif
 
-#define GEMX_ABI_VERSION 6 /* 2: GEMX_MAX_OUT 16 -> 24 (DFIM system, 24 states); 3: gemx_config.solver_flags; 4: solver_rtol / solver_atol; 5: init_flux_mode / init_flux;
+#define GEMX_ABI_VERSION 7 /* 2: GEMX_MAX_OUT 16 -> 24 (DFIM system, 24 states); 3: gemx_config.solver_flags; 4: solver_rtol / solver_atol; 5: init_flux_mode / init_flux;
                             * 6: gemx_get_aux_state / gemx_set_aux_state / gemx_aux_state_bytes, gemx_reset_again; reset counters stay at 1 after gemx_create;
-                            *    + gemx_rollout_synthetic / gemx_synthetic_actions, gemx_set_rate_limiter (new entry points only) */
+                            *    + gemx_rollout_synthetic / gemx_synthetic_actions, gemx_set_rate_limiter (new entry points only);
+                            * 7: gemx_config.env_base / gemx_refgen_config.env_base: every device random stream is keyed by the GLOBAL env index
+                            *    env_base + i (shards of one job draw what the unsharded job draws); narrow action tensors (gemx_rollout_q);
+                            *    one unit library per (system, converter, dtype), loaded by gemx_create */
 #define GEMX_MAX_ODE 8  /* ODE state length incl. omega and the angle      */
 #define GEMX_MAX_OUT 24 /* system-state (observation) length               */
 #define GEMX_MODEL_ROWS 5
@@ -87,8 +90,9 @@ typedef enum { GEMX_SOLVER_EULER = 0, GEMX_SOLVER_RK4 = 1, GEMX_SOLVER_DP5 = 2 }
  * (ScipyOdeSolver('dopri5'), solvers.py:139-184: scipy's DOPRI5 with rtol 1e-6, atol 1e-12).  Every integration segment is tried as one
  * Dormand-Prince 5(4) step; where the embedded error estimate, in scipy's norm sqrt(mean((err_i / (solver_atol + solver_rtol
  * max(|y_i|, |y_i new|)))^2)), exceeds 1 the lane cuts its step (h <- h clamp(0.9 err^-1/5, 0.2, 1)) and goes on with steps chosen the same
- * way until the segment is through; the other lanes of its wave wait.  Not scipy's step sequence (no step size carried between control
- * steps, no PI term), so not its bits -- the same tolerance.  Floor: a step of 1/1024 of the segment is taken whatever its estimate and
+ * way until the segment is through; the other lanes of its wave wait.  The step size a lane ends a control step with is CARRIED to its next
+ * one (a state row, like DOPRI5's WORK(7); cleared by a reset, part of the checkpoint blob).  Still not scipy's step sequence (no PI term,
+ * fp32 error estimates), so not its bits -- the same tolerance.  Floor: a step of 1/1024 of the segment is taken whatever its estimate and
  * raises GEMX_ERRFLAG_TOLERANCE.  Takes precedence over GEMX_SOLVER_SPLIT_KINKS and over solver_nsteps; the one-step map and the
  * small-batch DC kernel are not used. */
 #define GEMX_SOLVER_ADAPTIVE 2
@@ -152,6 +156,12 @@ typedef struct gemx_config {
     int32_t init_flux_mode;
     double init_flux[8];
     uint64_t seed;
+    /* GLOBAL index of this handle's env 0 (ABI 7).  Every device-side random stream -- the initialisers above, the synthetic actions of
+     * gemx_rollout_synthetic / gemx_synthetic_actions -- is a pure function of (seed, env_base + i, ...): a job sharded over W handles
+     * (ranks / GPUs) with env_base = the shard's first env draws, env by env, exactly what ONE handle over all envs draws, as every env
+     * object of the reference owns its own branch of the seed sequence (core.py:373-385, physical_systems.py:164-169,
+     * random_component.py:60-87).  0 for a lone handle; >= 0. */
+    int64_t env_base;
     double init_lo[GEMX_MAX_ODE], init_hi[GEMX_MAX_ODE], init_mu[GEMX_MAX_ODE], init_sigma[GEMX_MAX_ODE];
     double supply_r, supply_c;
     /* DeadTimeProcessor reset action, in the action space of the system the processor wraps: continuous converter actions
@@ -281,6 +291,7 @@ typedef struct gemx_refgen_config {
     int32_t struct_size; /* = sizeof(gemx_refgen_config) */
     int32_t n_ref;       /* 1..GEMX_MAX_REF sub-generators */
     uint64_t seed;
+    int64_t env_base;    /* global index of env 0 (ABI 7; see gemx_config.env_base): streams are keyed by (seed, env_base + i, generator, ...) */
     int32_t episode_len_lo, episode_len_hi; /* episode_lengths, default (500, 2000) */
     double sigma_lo[GEMX_MAX_REF], sigma_hi[GEMX_MAX_REF];     /* sigma_range, default (1e-3, 1e-1) */
     double margin_lo[GEMX_MAX_REF], margin_hi[GEMX_MAX_REF];   /* limit_margin in normalised units */
@@ -297,7 +308,7 @@ int gemx_refgen_get_state(gemx_refgen *r, double *value_out_dev, double *sigma_o
  * angle as a 32-bit fraction of a turn internally, so a get/set round trip rounds it to fp32 radians, ~1e-7 rad), plus the
  * per-env packed converter switching state, 2 bits per half-bridge: [N] uint8, or [2][N] uint8 (row 0 = bits 0..7,
  * row 1 = bits 8..11) for the 6 half-bridges of GEMX_CONV_FINITE_2XB6; gemx_n_switch_bytes() = bytes per env.
- * Step counters are not exported.
+ * (There is no per-env step counter: PhysicalSystem.k belongs to the binding; the handle's launched-steps count is in the blob below.)
  * Everything else a resumed handle needs is ONE opaque device blob (gemx_aux_state_bytes() bytes, 16-byte aligned): the
  * RCVoltageSupply's two rows (capacitor voltage, time since its last update; voltage_supplies.py:100-123), the DeadTimeProcessor's
  * action queue and its phase (dead_time_processor.py:63-85), the per-env reset counters of the random initialisers (the counter-based

@@ -50,7 +50,7 @@ enum { ORC_CONV_CONT_4QC = 0, ORC_CONV_FINITE_B6 = 1, ORC_CONV_CONT_B6 = 2, ORC_
 #define ORC_IS_DC(s) ((s) == ORC_SYS_DC_PERMEX || (s) == ORC_SYS_DC_SERIES || (s) == ORC_SYS_DC_SHUNT || (s) == ORC_SYS_DC_EXTEX)
 enum { ORC_LOAD_CONST_SPEED = 0, ORC_LOAD_POLY_STATIC = 1 };
 enum { ORC_SOLVER_EULER = 0, ORC_SOLVER_RK4 = 1, ORC_SOLVER_DOPRI5 = 2, ORC_SOLVER_DP5_FIXED = 3, ORC_SOLVER_IVP_RK45 = 4,
-       ORC_SOLVER_RK4_KINK = 5, ORC_SOLVER_DP5_KINK = 6 };
+       ORC_SOLVER_RK4_KINK = 5, ORC_SOLVER_DP5_KINK = 6, ORC_SOLVER_DEV_ADAPTIVE = 7 };
 
 #define ORC_MAX_ODE 8
 #define ORC_MAX_OUT 24
@@ -539,8 +539,55 @@ static void integrate_kink(const orc_params *p, orc_env *e, int dp5, double t_en
     e->t = t_end;
 }
 
+/* ORC_SOLVER_DEV_ADAPTIVE -- a DIAGNOSTIC, not a restatement of the reference: the error controller of the HIP kernels' ScipyOdeSolver()
+ * (gym_electric_motor_amd/csrc/gemx_kernels.hpp: dp5_adaptive / dp5_first_try) in fp64, one lane at a time, so that the statistics of a
+ * 64-lane wave (attempts per control step of every lane, of the slowest lane) can be taken on the CPU: tools/wave_step_statistics.py,
+ * orc_wave_attempts below.  Norm over the states without the angle, rtol 1e-6, atol 1e-9 (the device's defaults), the carried proposal in
+ * e->dp_h, first try = hs / ceil(0.9 hs / proposal), a rejected step cut by clamp(0.9 err^-1/5, 0.2, 1), floor hs / 1024.
+ * g_dev_first_try > 0 replaces the first try of the next segment (the wave-shared proposal under test). */
+static __thread double g_dev_first_try = 0.0;
+static __thread int g_dev_attempts = 0;
+static double dev_first_try(const orc_params *p, double hs, double hc) {
+    if (hs < 0.5 * p->tau || !(hc > 0.0) || !(hc < 0.9 * hs)) return hs;
+    return hs / fmin(ceil(0.9 * hs / hc), 1024.0);
+}
+static void dev_adaptive(const orc_params *p, orc_env *e, double t_end) {
+    const double RTOL = 1e-6, ATOL = 1e-9;
+    const int n = n_ode(p), nz = ORC_IS_DC(p->system) ? n : n - 1; /* the angle is integrated alongside, outside the error norm */
+    double k1[ORC_MAX_ODE], k2[ORC_MAX_ODE], k3[ORC_MAX_ODE], k4[ORC_MAX_ODE], k5[ORC_MAX_ODE], k6[ORC_MAX_ODE], y1[ORC_MAX_ODE];
+    const double hs = t_end - e->t, hmin = hs / 1024.0;
+    const int carries = !(hs < 0.5 * p->tau);
+    double t = 0.0, h = g_dev_first_try > 0.0 ? fmin(g_dev_first_try, hs) : dev_first_try(p, hs, e->dp_h), hprop = 0.0;
+    g_dev_first_try = 0.0;
+    system_equation(p, e, e->y, k1);
+    for (int guard = 0; guard < 4096 && t < hs; ++guard) {
+        const int fin = !(h < hs - t);
+        const double hh = fin ? hs - t : h;
+        g_dev_attempts++;
+        dp5_stages(p, e, n, e->y, hh, k1, k2, k3, k4, k5, k6, y1); /* k2 <- f(y1) (FSAL), k4 <- the error estimate */
+        double e2 = 0.0;
+        for (int i = 0; i < nz; ++i) {
+            const double r = k4[i] / (ATOL + RTOL * fmax(fabs(e->y[i]), fabs(y1[i])));
+            e2 += r * r;
+        }
+        const double en2 = e2 / nz;
+        const int floor_hit = !(hh > hmin), accept = !(en2 > 1.0) || floor_hit;
+        double fac = en2 > 1e-20 ? 0.9 * pow(en2, -0.1) : 10.0;
+        fac = fmin(fmax(fac, 0.2), accept ? 10.0 : 1.0);
+        if (accept) {
+            for (int i = 0; i < n; ++i) { e->y[i] = y1[i]; k1[i] = k2[i]; }
+            t = fin ? hs : t + hh;
+        }
+        h = fmax(hh * fac, hmin);
+        if (accept) hprop = fmax(hprop, h);
+    }
+    if (carries) e->dp_h = hprop;
+    e->t = t_end;
+}
+
 static void integrate(const orc_params *p, orc_env *e, double t_end) {
     int n = n_ode(p);
+    if (p->solver == ORC_SOLVER_DEV_ADAPTIVE) { dev_adaptive(p, e, t_end); return; }
     if (p->solver == ORC_SOLVER_DOPRI5) { dopri5_adaptive(p, e, t_end); return; }
     if (p->solver == ORC_SOLVER_IVP_RK45) { ivp_rk45(p, e, t_end); return; }
     if (p->solver == ORC_SOLVER_RK4_KINK || p->solver == ORC_SOLVER_DP5_KINK) { integrate_kink(p, e, p->solver == ORC_SOLVER_DP5_KINK, t_end); return; }
@@ -1148,6 +1195,37 @@ void orc_rollout_many(const orc_params *p, int n_env, const double *actions, int
         }
     }
     if (n_done) *n_done = nd;
+}
+
+/* Diagnostic (tools/wave_step_statistics.py): `lanes` envs advanced in LOCKSTEP under ORC_SOLVER_DEV_ADAPTIVE, as one wave of the HIP kernel
+ * is.  hist_lane[a] = (lane, control step) pairs that took a attempts; hist_wave[a] = control steps whose slowest lane took a (what the
+ * wave pays: lanes that are through ride along).  shared = 1: every lane's first try of a control step is the MINIMUM of the lanes' own
+ * first tries (the wave-shared proposal of the round-5 verdict, item 5); rejected lanes still cut their own steps.  Histograms of 32 bins
+ * (last = that many or more).  actions [K][lanes][A]. */
+void orc_wave_attempts(const orc_params *p, int lanes, const double *actions, int n_act, int K, int shared, int64_t *hist_lane, int64_t *hist_wave) {
+    if (lanes > 64) lanes = 64;
+    orc_env e[64];
+    double obs[ORC_MAX_OUT], scratch[ORC_MAX_OUT];
+    for (int j = 0; j < lanes; ++j) { orc_init(p, &e[j]); orc_reset(p, &e[j], scratch); }
+    for (int k = 0; k < K; ++k) {
+        double first = 0.0;
+        if (shared) {
+            first = p->tau;
+            for (int j = 0; j < lanes; ++j) first = fmin(first, dev_first_try(p, p->tau, e[j].dp_h));
+        }
+        int worst = 0;
+        for (int j = 0; j < lanes; ++j) {
+            g_dev_first_try = first;
+            g_dev_attempts = 0;
+            orc_step(p, &e[j], actions + ((size_t)k * lanes + j) * n_act, obs);
+            g_dev_first_try = 0.0;
+            const int a = g_dev_attempts < 31 ? g_dev_attempts : 31;
+            hist_lane[a]++;
+            worst = a > worst ? a : worst;
+            if (orc_done(p, obs)) orc_reset(p, &e[j], scratch);
+        }
+        hist_wave[worst]++;
+    }
 }
 
 /* WeightedSumOfErrors.reward, reward_functions/weighted_sum_of_errors.py:125-129:

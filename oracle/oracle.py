@@ -82,7 +82,9 @@ _SOLVER = {"euler": (SOLVER_EULER, 1), "euler4": (SOLVER_EULER, 4), "rk4": (SOLV
            # scipy.integrate.solve_ivp(method="RK45") as ScipySolveIvpSolver drives it (solvers.py:187-219); tolerances below
            "ivp": (SOLVER_IVP_RK45, 1), "ivp_tight": (SOLVER_IVP_RK45, 1),
            # what the HIP kernels do for a PolynomialStaticLoad: a fixed step corrected for the load's kinks in closed form (no reference counterpart)
-           "rk4_kink": (SOLVER_RK4_KINK, 1), "dp5_kink": (SOLVER_DP5_KINK, 1)}
+           "rk4_kink": (SOLVER_RK4_KINK, 1), "dp5_kink": (SOLVER_DP5_KINK, 1),
+           # DIAGNOSTIC: the HIP kernels' error controller (ScipyOdeSolver() on the device) in fp64, for wave statistics on the CPU
+           "dev_adaptive": (7, 1)}
 _IVP_TOL = {"ivp": (1e-3, 1e-6), "ivp_tight": (1e-10, 1e-12)}  # solve_ivp defaults | oracle/make_golden.py:make_solver("ivp_tight")
 _MP_KEYS = {SYS_DC: ("r_a", "l_a", "psi_e"), SYS_PMSM: ("p", "l_d", "l_q", "r_s", "psi_p"),
             SYS_SCIM: ("p", "l_m", "l_sigs", "l_sigr", "r_s", "r_r"),
@@ -274,6 +276,17 @@ def rollout_many(params, actions, auto_reset=True):
     L.orc_rollout_many(C.byref(params), C.c_int(n_env), a.ctypes.data_as(C.c_void_p), C.c_int(A), C.c_int(K),
                        C.c_int(int(auto_reset)), last.ctypes.data_as(C.c_void_p), C.byref(nd))
     return last, nd.value
+
+
+def wave_attempts(params, actions, shared=False):
+    """orc_wave_attempts: actions [K, lanes <= 64, A] -> (hist_lane[32], hist_wave[32]) of attempts per control step under the device's
+    error controller (params.solver must be "dev_adaptive")."""
+    a = np.ascontiguousarray(np.asarray(actions, dtype=np.float64))
+    K, lanes, A = a.shape
+    hl, hw = np.zeros(32, dtype=np.int64), np.zeros(32, dtype=np.int64)
+    lib().orc_wave_attempts(C.byref(params), C.c_int(lanes), a.ctypes.data_as(C.c_void_p), C.c_int(A), C.c_int(K), C.c_int(int(shared)),
+                            hl.ctypes.data_as(C.c_void_p), hw.ctypes.data_as(C.c_void_p))
+    return hl, hw
 
 
 def load_golden(name, golden_dir=None):

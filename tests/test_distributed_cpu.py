@@ -48,7 +48,14 @@ def _worker(rank, world, port, n_total, out_dir):
         dc = ((torch.arange(K).reshape(K, 1) + torch.arange(lo, hi).reshape(1, -1)) % 2).to(torch.uint8).contiguous()
         chunk = gdd.gather_rollout(oc, dc)
         assert chunk[0].shape == (w, K, hi - lo, S) and chunk[0].dtype == torch.float32 and chunk[1].shape == (w, K, hi - lo) and chunk[1].dtype == torch.uint8
-    torch.save((all_obs, all_done, all_obs2, chunk), os.path.join(out_dir, f"r{rank}.pt"))
+    # this rank's shard of a sharded env (host-side configuration only: no GPU here).  Every device random stream is keyed by the
+    # GLOBAL env index: the shard's first env goes into the physical system's config AND into a reference generator given that system
+    import gym_electric_motor_amd as ga
+
+    env = gdd.make_sharded("Finite-CC-PMSM-v0", n_total, r, w, device=0, seed=5, _defer_create=True)
+    gen = ga.BatchedWienerProcessReferenceGenerator(reference_states=("i_sd",), seed=5).set_modules(env.physical_system, _defer_create=True)
+    bases = (env.shard, int(env.physical_system._cfg.env_base), env.physical_system.env_base, int(gen._cfg.env_base), env.physical_system.n_envs)
+    torch.save((all_obs, all_done, all_obs2, chunk, bases), os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -62,7 +69,9 @@ def test_gather_observations_gloo_world2(tmp_path, n_total):
     mp.spawn(_worker, args=(2, port, n_total, str(tmp_path)), nprocs=2, join=True)
     expect = torch.arange(n_total, dtype=torch.float32).reshape(-1, 1).repeat(1, 14)
     for r in range(2):
-        all_obs, all_done, all_obs2, chunk = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
+        all_obs, all_done, all_obs2, chunk, bases = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
+        lo, hi = gd.shard_range(n_total, r, 2)
+        assert bases == ((lo, hi), lo, lo, lo, hi - lo)  # make_sharded: env_base = the shard's first env, on every rank
         assert torch.equal(all_obs, expect) and torch.equal(all_obs2, expect)
         assert torch.equal(all_done, (torch.arange(n_total) % 3 == 0).to(torch.uint8))
         if n_total % 2 == 0:  # rank-major chunk gather: [W, K, n_local, S_out] -> [K, n_total, S_out] must be the global batch

@@ -1902,6 +1902,83 @@ def test_random_initialisers_streams_and_auto_reset():
         e.close()
 
 
+@pytest.mark.parametrize("n", [8192, 8192 + 2 * 37])  # (second: N/2 % 64 != 0 -- every half ends in a partial workgroup, and starts inside one of the whole)
+@pytest.mark.parametrize("what", ["pmsm_sc_uniform", "scim_sc_uniform", "dfim_cc_negspeed_interval_uniform", "synthetic", "synthetic_cont", "wiener"])
+def test_two_half_size_shards_equal_one_whole_bit_for_bit(what, n):
+    """Every device-side random stream is keyed by the GLOBAL env index (gemx_config.env_base, ABI 7): two handles of N/2 envs with bases 0
+    and N/2 produce, concatenated, exactly what one handle of N envs produces -- random initial states (uniform; the induction machines'
+    flux mode with its look-back at the previous draw) through create, reset and the in-kernel auto-resets of a fused rollout (prepared
+    draws of the loader wave), `rollout_synthetic`'s actions, and the Wiener reference generators.  Round 5 keyed them by the local index:
+    every shard of a multi-GPU job replayed shard 0's draws (the reference: one seed-sequence branch per env object, core.py:373-385,
+    physical_systems.py:164-169, random_component.py:60-87).  Also: a shard with another base draws OTHER states."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    h = n // 2
+    K = 192
+
+    def cat(parts, dim):
+        return torch.cat([p_.cpu() for p_ in parts], dim=dim)
+
+    if what == "wiener":
+        envs = [ga.make("Cont-CC-PMSM-v0", n_envs=m, env_base=b) for m, b in ((n, 0), (h, 0), (h, h))]
+        gens = [ga.BatchedWienerProcessReferenceGenerator(reference_states=("i_sd", "i_sq"), seed=31).set_modules(e.physical_system) for e in envs]
+        assert [int(g._cfg.env_base) for g in gens] == [0, 0, h]  # (taken from the physical system)
+        for g in gens:
+            g.reset()
+        d = (torch.rand((K, n), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)) < 0.01).to(torch.uint8)
+        whole = gens[0].rollout(K, done=d)
+        halves = cat([gens[1].rollout(K, done=d[:, :h].contiguous()), gens[2].rollout(K, done=d[:, h:].contiguous())], 1)
+        assert torch.equal(whole.cpu(), halves)
+        assert not torch.equal(whole[:, :h].cpu(), whole[:, h:].cpu())
+        st = [g.state() for g in gens]
+        for j in range(3):
+            assert torch.equal(st[0][j].cpu(), cat([st[1][j], st[2][j]], 1))
+        for e in envs:
+            e.close()
+        return
+    if what.startswith("synthetic"):
+        env_id = "Finite-CC-PMSM-v0" if what == "synthetic" else "Cont-SC-SCIM-v0"
+        envs = [ga.make(env_id, n_envs=m, env_base=b, tau=1e-4) for m, b in ((n, 0), (h, 0), (h, h))]
+        outs = []
+        for e in envs:
+            ps = e.physical_system
+            a = ps.synthetic_actions(K, seed=9, step0=5)
+            o, d = ps.rollout_synthetic(K, seed=9, step0=5)
+            assert "advance_pipe_kernel" in ps.last_launch()
+            outs.append((a.clone(), o.clone(), d.clone()))
+        for j in range(3):
+            assert torch.equal(outs[0][j].cpu(), cat([outs[1][j], outs[2][j]], 1)), j
+        assert not torch.equal(outs[1][0].cpu(), outs[2][0].cpu())  # the second shard's actions are not the first shard's
+        for e in envs:
+            e.close()
+        return
+    envs = [_init_env(what, m, seed=13, env_base=b)[0] for m, b in ((n, 0), (h, 0), (h, h))]
+    pss = [e.physical_system for e in envs]
+    y = [ps.get_state() for ps in pss]  # draw #1 (create)
+    assert torch.equal(y[0].cpu(), cat(y[1:], 1)) and not torch.equal(y[1].cpu(), y[2].cpu())
+    r = [ps.reset() for ps in pss]  # draw #2
+    assert torch.equal(r[0].cpu(), cat(r[1:], 0))
+    g = torch.Generator(device="cuda").manual_seed(23)
+    acts = (torch.rand((K, n, pss[0]._n_act), device="cuda", generator=g, dtype=torch.float64) * 2 - 1).to(pss[0]._tdtype)
+    acts[20:] = acts[20]  # held: every env runs into a limit again and again (auto-resets: prepared and inline draws)
+    res = []
+    for ps, sl in zip(pss, (slice(0, n), slice(0, h), slice(h, n))):
+        o, d = ps.rollout(acts[:, sl].contiguous())
+        assert "advance_pipe_kernel" in ps.last_launch()
+        res.append((o.clone(), d.clone(), ps.get_state(), ps.get_checkpoint()["aux"].clone()))
+    assert torch.equal(res[0][0].cpu(), cat([res[1][0], res[2][0]], 1)) and torch.equal(res[0][1].cpu(), cat([res[1][1], res[2][1]], 1))
+    assert torch.equal(res[0][2].cpu(), cat([res[1][2], res[2][2]], 1))
+    per_env = res[0][1].sum(dim=0)
+    assert int(per_env.max()) >= 3 and float((per_env > 0).float().mean()) > 0.2, "too few terminations to exercise the reset path"
+    # the checkpoint blob names its shard: restoring shard 1's blob into shard 0's handle is refused
+    with pytest.raises(ValueError, match="env_base"):
+        pss[1].set_checkpoint(dict(pss[1].get_checkpoint(), aux=res[2][3]))
+    for e in envs:
+        e.close()
+
+
 def test_random_gaussian_initialiser_is_a_truncated_normal():
     """random_init='gaussian': normal(mue, sigma) truncated to the bounds (scipy.stats.truncnorm, electric_motor.py:236-249).
     (The reference passes a CONSTANT random_state to truncnorm.rvs, so it returns the same draw at every reset -- visible in
@@ -2605,11 +2682,18 @@ def test_bench_multi_gpu_code_path_through_rccl_in_a_world_of_one():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    import tempfile
+
+    side = os.path.join(tempfile.mkdtemp(prefix="gemx_bench_"), "extras.json")
     cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--gather", "chunk", "--config5", "on",
-           "--no-extras", "--no-pmc", "--settle-ms", "5", "--repeats", "1", "--steps-per-launch", "200"]
+           "--no-extras", "--no-pmc", "--settle-ms", "5", "--repeats", "1", "--steps-per-launch", "200", "--extras-file", side]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    last = r.stdout.rstrip("\n").splitlines()[-1]
+    assert last.startswith("{") and len(last) < 6000, len(last)  # ONE compact line, last on stdout (round 5's 20 KB were not parsed)
+    line = json.loads(last)
+    full = json.load(open(side))  # the full record went to the side file
+    assert full["value"] == line["value"] and "repeats" in full and "telemetry" in full and "repeats" not in line
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["backend"] == "nccl"
     rf = line["roofline"]
     # one clock: value (env-steps/s) x algorithmic bytes per env-step of a launch == roofline.achieved

@@ -553,7 +553,7 @@ def test_config_struct_header_binding_and_docs_agree():
     spec.loader.exec_module(gen)
     header = open(os.path.join(REPO, "include", "gemx.h")).read()
     fields = gen.parse_struct(header)
-    ct = {"int32_t": C.c_int32, "uint32_t": C.c_uint32, "uint64_t": C.c_uint64, "double": C.c_double}
+    ct = {"int32_t": C.c_int32, "uint32_t": C.c_uint32, "uint64_t": C.c_uint64, "int64_t": C.c_int64, "double": C.c_double}
     want = [(name, ct[t] * n if n else ct[t]) for t, name, n in fields]
     got = list(_lib.GemxConfig._fields_)
     assert [g[0] for g in got] == [w[0] for w in want]
@@ -586,6 +586,26 @@ def test_bench_cli_contract_without_a_gpu():
 
     assert [bench.bytes_per_env_step_fused(dict(w)) for w in (bench.WORKLOADS["permexdc"], bench.WORKLOADS["pmsm"], bench.WORKLOADS["scim"])] == [25, 58, 69]
     assert [bench.bytes_per_env_step_single(dict(w)) for w in (bench.WORKLOADS["permexdc"], bench.WORKLOADS["pmsm"], bench.WORKLOADS["scim"])] == [41, 90, 117]
+    # the stdout line stays small enough for the driver to parse (round 5's 20-KB line was recorded as parsed = null): the compact form
+    # of a COMPLETE record (last round's collection: every leg present) and of one whose every optional leg failed with a long message
+    import json
+
+    full = json.load(open(os.path.join(REPO, "profiles", "r05_bench.json")))
+    txt = bench.compact_line(full, "bench_extras.json")
+    assert len(txt) < 4096 < bench.LINE_LIMIT == 6000 and "\n" not in txt
+    line = json.loads(txt)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "legs"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["roofline"]["achieved"] == full["roofline"]["achieved"] and line["roofline"]["frac"] == full["roofline"]["frac"]
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and "model" not in line["config"]
+    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and line["cpu_baseline"]["reference"]["same_host"] is False
+    assert set(line["legs"]) >= {"permexdc", "scim", "scim_constspeed", "scim_error_controlled", "pmsm_c5_shard", "at_scale"}
+    assert all(set(v) >= {"frac", "launch_ms"} for v in line["legs"].values())
+    bad = dict(full, configs={k: {"error": "x" * 5000} for k in bench.LEGS}, extras_error={"error": "y" * 9000}, overrides={f"GEMX_{i}": "z" * 100 for i in range(30)},
+               gather={"chunk": {"error": "q" * 3000}}, rccl={"error": "q" * 3000}, config5={"error": "e" * 3000}, cpu_baseline={"error": "c" * 3000})
+    txt = bench.compact_line(bad, "bench_extras.json")
+    assert len(txt) < bench.LINE_LIMIT and json.loads(txt)["value"] == full["value"]
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "0"], capture_output=True, text=True, env=env)
@@ -665,15 +685,14 @@ def test_reference_env_shell_reads_are_answered_identically(name):
 
 def test_register_budget_of_the_bench_kernels():
     """The kernels behind bench.py's legs keep their occupancy line and stay out of scratch memory: VGPR count, spilled VGPRs and private
-    segment of the built code objects (llvm-readelf on gym_electric_motor_amd/build/*.o, as tools/vgpr_report.py reads them).  Round 4
+    segment of the built code objects (llvm-readelf on the code objects of gym_electric_motor_amd/libgemx_u*.so, as tools/vgpr_report.py reads them).  Round 4
     lost a leg twice to an edit elsewhere in the kernel: four pinned registers took the error-controlled <2, 2> SCIM kernel across the
     128-register line (0.148 -> 0.076 of the roofline), and a rolled tail loop put 1.2 KB of scratch into it (0.146 -> 0.05)."""
     import importlib.util
     import re
 
     readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
-    build = os.path.join(REPO, "gym_electric_motor_amd", "build")
-    units = {u: os.path.join(build, f"gemx_inst_{u}.o") for u in ("0_0_0", "1_1_0", "2_2_0")}
+    units = {u: os.path.join(REPO, "gym_electric_motor_amd", f"libgemx_u{u}.so") for u in ("0_0_0", "1_1_0", "2_2_0")}
     if not os.path.exists(readelf) or not all(os.path.exists(o) for o in units.values()):
         pytest.skip("no built objects / llvm-readelf here")
     spec = importlib.util.spec_from_file_location("vgpr_report", os.path.join(REPO, "tools", "vgpr_report.py"))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Register report of the built kernels: VGPRs, spilled VGPRs and scratch bytes of every kernel in gym_electric_motor_amd/build/*.o
+"""Register report of the built kernels: VGPRs, spilled VGPRs and scratch bytes of every kernel in gym_electric_motor_amd/libgemx_u*.so
 (llvm-readelf --notes of the gfx950 code objects), and the kernels that sit just ABOVE an occupancy line.
 
     python tools/vgpr_report.py [--units 2_2_0,1_1_0] [--all] > profiles/<round>_vgpr_report.md
@@ -20,10 +20,22 @@ BUILD = os.path.join(REPO, "gym_electric_motor_amd", "build")
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
+def code_object_of(lib):
+    """the gfx950 code object of a built library / object file, extracted into gym_electric_motor_amd/build (never beside a shipped .so)"""
+    os.makedirs(BUILD, exist_ok=True)
+    co = os.path.join(BUILD, os.path.basename(lib) + ".0.hipv4-amdgcn-amd-amdhsa--gfx950")
+    if not os.path.exists(co) or os.path.getmtime(co) < os.path.getmtime(lib):
+        link = os.path.join(BUILD, os.path.basename(lib))
+        if os.path.abspath(link) != os.path.abspath(lib):  # llvm-objdump --offloading writes next to its input: give it one inside build/
+            if os.path.lexists(link):
+                os.remove(link)
+            os.symlink(os.path.abspath(lib), link)
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", os.path.basename(lib)], cwd=BUILD, capture_output=True)
+    return co
+
+
 def kernels_of(obj):
-    co = obj + ".0.hipv4-amdgcn-amd-amdhsa--gfx950"
-    if not os.path.exists(co) or os.path.getmtime(co) < os.path.getmtime(obj):
-        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", obj], cwd=os.path.dirname(obj), capture_output=True)
+    co = code_object_of(obj)
     txt = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True).stdout
     out = []
     for b in txt.split("- .agpr_count")[1:]:
@@ -31,7 +43,12 @@ def kernels_of(obj):
         g = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", b).group(1))  # noqa: E731
         out.append((name, g("vgpr_count"), g("vgpr_spill_count"), g("private_segment_fixed_size"), g("sgpr_count")))
     names = subprocess.run(["c++filt"], input="\n".join(k[0] for k in out), capture_output=True, text=True).stdout.splitlines()
-    return [(n.replace("gemx::", "").replace("(KArgs<float>)", "").replace("(KArgs<double>)", "").replace("void ", ""),) + k[1:] for n, k in zip(names, out)]
+    return [(re.sub(r"\((gemx::)?KArgs<(float|double)>\)$", "", n.replace("gemx::", "").replace("void ", "")),) + k[1:] for n, k in zip(names, out)]
+
+
+def unit_path(u):
+    """u = '<sys>_<conv>_<f64>' -> the unit's shared object (round 6: one per unit, beside libgemx.so)"""
+    return os.path.join(REPO, "gym_electric_motor_amd", f"libgemx_u{u}.so")
 
 
 def main():
@@ -39,12 +56,12 @@ def main():
     ap.add_argument("--units", default=None, help="comma-separated sys_conv_f64 units (default: every fp32 unit)")
     ap.add_argument("--all", action="store_true", help="list every kernel, not only cliffs / spills")
     args = ap.parse_args()
-    objs = sorted(glob.glob(os.path.join(BUILD, "gemx_inst_*_0.o"))) if args.units is None else [os.path.join(BUILD, f"gemx_inst_{u}.o") for u in args.units.split(",")]
+    objs = sorted(glob.glob(unit_path("*_0"))) if args.units is None else [unit_path(u) for u in args.units.split(",")]
     print("| unit | kernel | VGPRs | spilled | scratch B | note |")
     print("|---|---|---|---|---|---|")
     n_all = n_cliff = n_spill = 0
     for obj in objs:
-        unit = os.path.basename(obj)[10:-2]
+        unit = os.path.basename(obj)[len("libgemx_u"):-3]
         for name, v, sp, sc, sg in kernels_of(obj):
             n_all += 1
             shallow = bool(re.search(r"advance_pipe_kernel<.*, (4|2), 2, (false|true)(, (false|true))?>", name))

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Error-controlled solver: what does a WAVE pay per control step, and would a wave-shared first try change it?  (round 5 verdict, item 5)
+
+CPU statistics through oracle/gemx_oracle.c's diagnostic restatement of the device's controller (ORC_SOLVER_DEV_ADAPTIVE: the carried
+proposal, first try = tau / ceil(0.9 tau / proposal), rejections cut by clamp(0.9 err^-1/5, 0.2, 1)), 64 lock-stepped lanes per wave,
+BASELINE config 4's env (Cont-SC-SCIM-v0, PolynomialStaticLoad, default constraint + auto-reset, tau = 1e-4) under i.i.d. uniform random
+duty cycles -- the workload of bench.py's `scim_error_controlled` leg -- and under held actions (piecewise constant over 50 steps).
+
+  per lane : mean attempts per control step of one env (what an env-by-env solver pays)
+  per wave : mean over control steps of the SLOWEST of the 64 lanes (what the lock-stepped wave pays)
+  shared   : every lane's first try = the minimum of the wave's own first tries (one DPP min-reduction on the device); rejected lanes
+             still cut their own steps
+
+    python tools/wave_step_statistics.py [--waves 8] [--steps 2000] > profiles/r06_wave_step_statistics.md
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as orc  # noqa: E402
+
+
+def stats(h):
+    n = h.sum()
+    a = np.arange(len(h))
+    mean = float((h * a).sum() / n)
+    tail = {k: float(h[k:].sum() / n) for k in (2, 3, 4, 5, 6)}
+    return mean, tail
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--waves", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--golden", default="scim_epi_uniform_euler")
+    args = ap.parse_args()
+    orc.build()
+    _, meta = orc.load_golden(args.golden)
+    meta = dict(meta, tau=1e-4)
+    p = orc.params_from_meta(meta, solver="dev_adaptive", episodic=True)
+    rng = np.random.default_rng(1234)
+    print("# Error-controlled solver: attempts per control step, per lane and per 64-lane wave (CPU statistics, device controller in fp64)\n")
+    print(f"Env: {meta.get('env_id', args.golden)}, tau 1e-4, rtol 1e-6 / atol 1e-9, {args.waves} waves x 64 lanes x {args.steps} control steps, episodic.\n")
+    print("| actions | first try | per lane: mean | P(>=2) | P(>=3) | P(>=4) | per wave (slowest of 64): mean | P(>=3) | P(>=4) | P(>=5) | P(>=6) |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
+    rows = {}
+    for label, held in (("i.i.d. uniform per step", 1), ("held for 50 steps", 50)):
+        for shared in (False, True):
+            hl, hw = np.zeros(32, dtype=np.int64), np.zeros(32, dtype=np.int64)
+            r2 = np.random.default_rng(1234)
+            for _ in range(args.waves):
+                a = r2.uniform(-1, 1, ((args.steps + held - 1) // held, 64, 3))
+                a = np.repeat(a, held, axis=0)[: args.steps]
+                l, w = orc.wave_attempts(p, a, shared=shared)
+                hl += l
+                hw += w
+            ml, tl = stats(hl)
+            mw, tw = stats(hw)
+            rows[(label, shared)] = (ml, mw)
+            print(f"| {label} | {'wave-shared minimum' if shared else 'per lane (product)'} | {ml:.2f} | {tl[2]:.3f} | {tl[3]:.3f} | {tl[4]:.4f} | "
+                  f"{mw:.2f} | {tw[3]:.3f} | {tw[4]:.3f} | {tw[5]:.3f} | {tw[6]:.4f} |")
+    print()
+    for label in ("i.i.d. uniform per step", "held for 50 steps"):
+        a, b = rows[(label, False)][1], rows[(label, True)][1]
+        print(f"- {label}: the wave pays {a:.2f} attempts per control step with per-lane first tries, {b:.2f} with the wave-shared minimum "
+              f"({(a / b - 1) * 100:+.0f} % rate at an attempt-bound launch).")
+
+
+if __name__ == "__main__":
+    main()
