@@ -716,15 +716,34 @@ def worker(args, rank, world, local_rank, backend):
             if isinstance(cb, dict) and "error" not in cb:
                 cb["note"] = f"timed on rank 0's host while the other {world - 1} rank(s) wait; identical at every N"
             out["cpu_baseline"] = cb
-        out["overrides"] = {k: v for k, v in os.environ.items() if k.startswith("GEMX_")}  # A/B switches active in THIS run (normally none)
-        emit(out, args)
+        out["overrides"] = {k: v for k, v in os.environ.items() if k.startswith("GEMX_") and k != "GEMX_COVERAGE_FILE"}  # A/B switches active in THIS run (normally none)
+        line = emit(out, args, defer=dist_on)
 
     if dist_on:
+        # RCCL writes to the C library's stdout ("Librccl path : ..."), block-buffered on a pipe and flushed when the process EXITS -- i.e.
+        # after a line printed here: the driver's "last stdout line" of every multi-GPU run would be RCCL's.  So with a process group the
+        # line goes out AFTER the teardown, behind a flush of the C streams; a watchdog prints it anyway if the teardown hangs.
+        timer = None
+        if rank == 0:
+            import threading
+
+            def late():
+                flush_c_streams()
+                print(line, flush=True)
+                os._exit(0)
+
+            timer = threading.Timer(60.0, late)
+            timer.daemon = True
+            timer.start()
         try:
             dist.barrier()
             dist.destroy_process_group()
-        except Exception as e:  # (the line is out already)
+        except Exception as e:
             print(f"bench.py: rank {rank}: shutdown barrier failed: {e!r}", file=sys.stderr)
+        if rank == 0:
+            timer.cancel()
+            flush_c_streams()
+            print(line, flush=True)
 
 
 LINE_LIMIT = 6000  # bytes of the ONE stdout line (round 5's 20-KB line was more than the driver parses: BENCH_r05.json parsed = null)
@@ -820,9 +839,20 @@ def compact_line(out, extras_file=None):
     return txt
 
 
-def emit(out, args):
+def flush_c_streams():
+    """fflush(NULL): whatever native libraries (RCCL) have buffered on the C stdout goes out NOW, ahead of the line"""
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
+def emit(out, args, defer=False):
     """Full record -> the side file (`--extras-file`, default bench_extras.json beside this script; a copy under gpurun_out/ when that
-    directory exists, so that a gpurun call brings it home); ONE compact line -> stdout, last."""
+    directory exists, so that a gpurun call brings it home); ONE compact line -> stdout, last (defer: returned, the caller prints it
+    after the process group's teardown)."""
     path = args.extras_file or os.path.join(REPO, "bench_extras.json")
     written = None
     for p in [path] + ([os.path.join(REPO, "gpurun_out", os.path.basename(path))] if os.path.isdir(os.path.join(REPO, "gpurun_out")) else []):
@@ -832,8 +862,12 @@ def emit(out, args):
             written = written or os.path.relpath(p, REPO)
         except OSError as e:  # a read-only checkout: the line still goes out
             print(f"bench.py: could not write {p}: {e!r}", file=sys.stderr)
-    sys.stdout.flush()
-    print(compact_line(out, written), flush=True)
+    line = compact_line(out, written)
+    if not defer:
+        flush_c_streams()
+        sys.stdout.flush()
+        print(line, flush=True)
+    return line
 
 
 def guarded_pair(fn):

@@ -209,12 +209,17 @@ class ScipyOdeSolver(DormandPrince5Solver):
     tolerance semantics, not scipy's step sequence.  Keyword arguments as `scipy.integrate.ode.set_integrator('dopri5', ...)` takes
     them: `rtol`, `atol` (absolute, in state units; default 1e-9 -- scipy's 1e-12 is below fp32 resolution and changes nothing); others
     (`nsteps`, `first_step`, `safety`, ...) are accepted and ignored.  A step at the floor of 1/1024 of a segment that still misses the
-    tolerance raises a warning through `check_errors()`."""
+    tolerance raises a warning through `check_errors()`.
+    split_kinks (default True; round 6): behind a PolynomialStaticLoad every attempt integrates the smooth model system of the kink
+    correction (RK4Solver.split_kinks) and the kink's defect is added in closed form -- the error estimate then never sees the kink of the
+    load torque at |omega| = a tau_decay / J, whose crossing costs the plain controller five to eight attempts, and the 64 lanes of a wave
+    wait for the one that crosses: BASELINE config 4 under random actions, 4.7 -> 1.8 attempts per control step and wave, same accuracy
+    against the reference's dopri5 runs (profiles/r06_wave_step_statistics.md).  False: the plain controller of rounds 4-5."""
 
-    def __init__(self, integrator="dopri5", rtol=1e-6, atol=1e-9, **kwargs):
+    def __init__(self, integrator="dopri5", rtol=1e-6, atol=1e-9, split_kinks=True, **kwargs):
         if integrator != "dopri5":
             raise ValueError(f"integrator {integrator!r}: the accelerated path restates 'dopri5' (the reference's default) only")
-        super().__init__(nsteps=1, split_kinks=False)
+        super().__init__(nsteps=1, split_kinks=split_kinks)
         self._adaptive = True
         self._rtol, self._atol = float(rtol), float(atol)
         self._ignored = dict(kwargs)

@@ -265,7 +265,7 @@ template <class R> static void fill_params(const gemx_handle &h, const double *m
     P.rtol = (R)(c.solver_rtol > 0 ? c.solver_rtol : 1e-6);
     P.atol = (R)(c.solver_atol > 0 ? c.solver_atol : 1e-9);
     P.errw = nullptr;  // (set per launch: launch_advance_t)
-    if (P.adaptive) P.kink_split = 0;
+    // (round 6: the error-controlled solver honours GEMX_SOLVER_SPLIT_KINKS -- every attempt on the smooth model system, dp5_adaptive)
     P.auto_reset = c.auto_reset;
     P.obs_layout = c.obs_layout;
     P.dc_thr[0] = P.dc_thr[1] = (R)INFINITY;

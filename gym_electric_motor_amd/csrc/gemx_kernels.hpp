@@ -280,79 +280,6 @@ template <class R> __device__ __forceinline__ R dp5_first_try(const DevParams<R>
     const R n = fmin(ceil(R(0.9) * hs / *hc), R(1024));
     return hs / n;
 }
-template <int NZ, class R, class F>
-__device__ __forceinline__ R dp5_adaptive(const DevParams<R> &P, R (&z)[NZ], R hs, F &&rhs, R *hc = nullptr) {
-    R k1[NZ];
-    rhs(z, k1);
-    R t = R(0), h = dp5_first_try<R>(P, hs, hc), integral = R(0), hprop = R(0);
-    const R hmin = hs * R(1.0 / 1024.0);
-    bool gave_up = false;
-#pragma nounroll
-    for (int guard = 0; guard < 4096; ++guard) {
-        const bool active = t < hs;
-        if (!__any(active)) break;
-        const bool fin = !(h < hs - t);  // this attempt reaches the end of the segment
-        const R hh = active ? (fin ? hs - t : h) : R(0);
-        R k2[NZ], k3[NZ], k4[NZ], k5[NZ], k6[NZ], k7[NZ], zt[NZ], zn[NZ];
-        R q = R(35.0 / 384.0) * z[0];
-#pragma unroll
-        for (int i = 0; i < NZ; ++i) zt[i] = z[i] + hh * (R(1.0 / 5.0) * k1[i]);
-        rhs(zt, k2);
-#pragma unroll
-        for (int i = 0; i < NZ; ++i) zt[i] = z[i] + hh * (R(3.0 / 40.0) * k1[i] + R(9.0 / 40.0) * k2[i]);
-        rhs(zt, k3);
-        q += R(500.0 / 1113.0) * zt[0];
-#pragma unroll
-        for (int i = 0; i < NZ; ++i) zt[i] = z[i] + hh * (R(44.0 / 45.0) * k1[i] - R(56.0 / 15.0) * k2[i] + R(32.0 / 9.0) * k3[i]);
-        rhs(zt, k4);
-        q += R(125.0 / 192.0) * zt[0];
-#pragma unroll
-        for (int i = 0; i < NZ; ++i)
-            zt[i] = z[i] + hh * (R(19372.0 / 6561.0) * k1[i] - R(25360.0 / 2187.0) * k2[i] + R(64448.0 / 6561.0) * k3[i] -
-                                 R(212.0 / 729.0) * k4[i]);
-        rhs(zt, k5);
-        q -= R(2187.0 / 6784.0) * zt[0];
-#pragma unroll
-        for (int i = 0; i < NZ; ++i)
-            zt[i] = z[i] + hh * (R(9017.0 / 3168.0) * k1[i] - R(355.0 / 33.0) * k2[i] + R(46732.0 / 5247.0) * k3[i] +
-                                 R(49.0 / 176.0) * k4[i] - R(5103.0 / 18656.0) * k5[i]);
-        rhs(zt, k6);
-        q += R(11.0 / 84.0) * zt[0];
-#pragma unroll
-        for (int i = 0; i < NZ; ++i)
-            zn[i] = z[i] + hh * (R(35.0 / 384.0) * k1[i] + R(500.0 / 1113.0) * k3[i] + R(125.0 / 192.0) * k4[i] -
-                                 R(2187.0 / 6784.0) * k5[i] + R(11.0 / 84.0) * k6[i]);
-        rhs(zn, k7);
-        R e2 = R(0);
-#pragma unroll
-        for (int i = 0; i < NZ; ++i) {
-            const R err = hh * (R(71.0 / 57600.0) * k1[i] - R(71.0 / 16695.0) * k3[i] + R(71.0 / 1920.0) * k4[i] -
-                                R(17253.0 / 339200.0) * k5[i] + R(22.0 / 525.0) * k6[i] - R(1.0 / 40.0) * k7[i]);
-            const R sk = P.atol + P.rtol * fmax(fabs(z[i]), fabs(zn[i]));
-            const R r = err * rcp_r(sk);
-            e2 += r * r;
-        }
-        const R en2 = e2 * R(1.0 / NZ);  // the norm squared: err <= 1 <=> en2 <= 1, err^-1/5 = en2^-1/10
-        const bool floor_hit = !(hh > hmin);
-        const bool accept = active && (!(en2 > R(1)) || floor_hit);
-        gave_up |= active && floor_hit && en2 > R(1);
-        R fac = en2 > R(1e-20) ? R(0.9) * pow_m01(en2) : R(10);
-        fac = fmin(fmax(fac, R(0.2)), accept ? R(10) : R(1));
-#pragma unroll
-        for (int i = 0; i < NZ; ++i) {
-            z[i] = accept ? zn[i] : z[i];
-            k1[i] = accept ? k7[i] : k1[i];
-        }
-        integral += accept ? hh * q : R(0);
-        t = accept ? (fin ? hs : t + hh) : t;
-        h = active ? fmax(hh * fac, hmin) : h;
-        hprop = accept ? fmax(hprop, h) : hprop;  // (the controller's proposal after an accepted sub-step)
-    }
-    if (gave_up && P.errw != nullptr) atomicOr(P.errw, (uint32_t)GEMX_ERRFLAG_TOLERANCE);
-    if (dp5_carries<R>(P, hs, hc)) *hc = hprop;
-    return integral;
-}
-
 // GEMX_SOLVER_SPLIT_KINKS (integrate<>): the model system's omega path over one step as the cubic Hermite interpolant in th = t / h,
 // s(th) = w + V0 th + c2 th^2 + c3 th^3 (V0, V1 = h x the end slopes), and its ramp integrals U(c) = int_0^1 (s - c)_+ dth.
 __device__ __forceinline__ float sqrt_r(float x) { return __builtin_amdgcn_sqrtf(x); }  // V_SQRT_F32, 1 ulp
@@ -372,6 +299,146 @@ template <class R> struct KinkPath {
         return (a0 & a1) ? Mc : ((a0 | a1) ? (up ? Mc - Q : Q) : R(0));
     }
 };
+
+// KINKS (round 6; GEMX_SOLVER_ADAPTIVE together with GEMX_SOLVER_SPLIT_KINKS, a PolynomialStaticLoad whose torque has kinks; z[0] = omega):
+// under random actions the plain controller spends 4.7 attempts per control step and WAVE on BASELINE config 4 -- not because the lanes
+// need them (1.1 per lane) but because some lane of 64 crosses the load's kink at |omega| = a tau_decay / J in most steps, where the error
+// estimate of a step across the kink demands five to eight cuts (tools/wave_step_statistics.py; without the kink every step of every
+// lane is ONE accepted attempt).  So every attempt integrates the SMOOTH model system of the fixed-step kink correction (integrate<>: the
+// saturation replaced by the affine piece c0 + c1 omega of the region the mid-step omega is predicted in; `rhs_m(z, dz, c0, c1)`), its
+// error estimate never sees the kink, and an accepted sub-step adds the kink's defect to omega in closed form (kink_defect).  The first
+// stage of the next sub-step is the last of this one (FSAL) unless the sub-step touched a kink: then the TRUE right-hand side is evaluated
+// at the corrected state (behind a wave ballot).  1.8 attempts per control step and wave; 9e-7 / 6e-6 against scipy's dopri5 on i.i.d. /
+// held actions where the plain controller has 7e-7 / 3e-6 (fp64, oracle/gemx_oracle.c: ORC_SOLVER_DEV_ADAPTIVE_KINK follows these steps).
+template <class R>
+__device__ __forceinline__ R kink_defect(const DevParams<R> &P, R w, R w1, R V0, R V1, R wmid, bool band, bool needs, R hh) {
+    // integrate<>'s closed forms (documented there): the defect of omega over a sub-step of length hh whose model path is the cubic
+    // through (w, w1) with the end slopes V0 / hh, V1 / hh
+    const R lim = P.omega_lim, phi_lim = copysign(lim, wmid), dl = w1 - w;
+    const R c2 = R(3) * dl - R(2) * V0 - V1, c3 = V0 + V1 - R(2) * dl;
+    const KinkPath<R> kp{w, w1, V0, V0 * V0, R(4) * (dl - V0), c2 * R(1.0 / 3.0), c3 * R(0.25), R(0.5) * V0,
+                         w + R(0.5) * V0 + c2 * R(1.0 / 3.0) + c3 * R(0.25), w1 > w};
+    const R lev = (kp.up ? (w < -lim) : !(w > lim)) ? -lim : lim, oth = -lev;
+    const R U1 = kp.ramp(lev);
+    const bool o0 = w >= oth, o1 = w1 >= oth, full = o0 != o1;
+    R U2 = (o0 & o1) ? kp.M - oth : R(0);
+    if (__any(full)) {
+        const R uf = kp.ramp(oth);
+        U2 = full ? uf : U2;
+    }
+    const R Up = lev > R(0) ? U1 : U2, Um = lev > R(0) ? U2 : U1;
+    const R D = -(hh * P.inv_tau_decay) * ((Um - Up - lim) - (band ? kp.M : phi_lim));
+    return needs ? D : R(0);
+}
+struct NoModel {};
+template <int NZ, class R, class F, class FM = NoModel>
+__device__ __forceinline__ R dp5_adaptive(const DevParams<R> &P, R (&z)[NZ], R hs, F &&rhs, R *hc = nullptr, FM &&rhs_m = FM{}) {
+    constexpr bool HAS_M = !std::is_same<typename std::decay<FM>::type, NoModel>::value;
+    bool kink = false;  // wave-uniform
+    if constexpr (HAS_M) kink = P.kink_split != 0;
+    R k1t[NZ];  // the TRUE right-hand side at z
+    rhs(z, k1t);
+    R t = R(0), h = dp5_first_try<R>(P, hs, hc), integral = R(0), hprop = R(0);
+    const R hmin = hs * R(1.0 / 1024.0);
+    bool gave_up = false;
+#pragma nounroll
+    for (int guard = 0; guard < 4096; ++guard) {
+        const bool active = t < hs;
+        if (!__any(active)) break;
+        const bool fin = !(h < hs - t);  // this attempt reaches the end of the segment
+        const R hh = active ? (fin ? hs - t : h) : R(0);
+        R k1[NZ], k2[NZ], k3[NZ], k4[NZ], k5[NZ], k6[NZ], k7[NZ], zt[NZ], zn[NZ];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) k1[i] = k1t[i];
+        [[maybe_unused]] R kc0 = R(0), kc1 = R(0), wmid = R(0);
+        [[maybe_unused]] bool band = false;
+        if constexpr (HAS_M) {
+            if (kink) {  // this attempt's model: the region of the Euler-predicted mid-step omega
+                wmid = fma(R(0.5) * hh, k1t[0], z[0]);
+                band = fabs(wmid) < P.omega_lim;
+                kc1 = band ? P.lin_factor : R(0);
+                kc0 = band ? R(0) : copysign(P.la, wmid);
+                k1[0] = fma(med3_r(P.lin_factor * z[0], -P.la, P.la) - fma(kc1, z[0], kc0), P.inv_j, k1t[0]);  // first stage of the model system
+            }
+        }
+        auto ev = [&](const R (&zz)[NZ], R (&dz)[NZ]) {
+            if constexpr (HAS_M) {
+                if (kink) { rhs_m(zz, dz, kc0, kc1); return; }
+            }
+            rhs(zz, dz);
+        };
+        R q = R(35.0 / 384.0) * z[0];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) zt[i] = z[i] + hh * (R(1.0 / 5.0) * k1[i]);
+        ev(zt, k2);
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) zt[i] = z[i] + hh * (R(3.0 / 40.0) * k1[i] + R(9.0 / 40.0) * k2[i]);
+        ev(zt, k3);
+        q += R(500.0 / 1113.0) * zt[0];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) zt[i] = z[i] + hh * (R(44.0 / 45.0) * k1[i] - R(56.0 / 15.0) * k2[i] + R(32.0 / 9.0) * k3[i]);
+        ev(zt, k4);
+        q += R(125.0 / 192.0) * zt[0];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i)
+            zt[i] = z[i] + hh * (R(19372.0 / 6561.0) * k1[i] - R(25360.0 / 2187.0) * k2[i] + R(64448.0 / 6561.0) * k3[i] -
+                                 R(212.0 / 729.0) * k4[i]);
+        ev(zt, k5);
+        q -= R(2187.0 / 6784.0) * zt[0];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i)
+            zt[i] = z[i] + hh * (R(9017.0 / 3168.0) * k1[i] - R(355.0 / 33.0) * k2[i] + R(46732.0 / 5247.0) * k3[i] +
+                                 R(49.0 / 176.0) * k4[i] - R(5103.0 / 18656.0) * k5[i]);
+        ev(zt, k6);
+        q += R(11.0 / 84.0) * zt[0];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i)
+            zn[i] = z[i] + hh * (R(35.0 / 384.0) * k1[i] + R(500.0 / 1113.0) * k3[i] + R(125.0 / 192.0) * k4[i] -
+                                 R(2187.0 / 6784.0) * k5[i] + R(11.0 / 84.0) * k6[i]);
+        ev(zn, k7);
+        R e2 = R(0);
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) {
+            const R err = hh * (R(71.0 / 57600.0) * k1[i] - R(71.0 / 16695.0) * k3[i] + R(71.0 / 1920.0) * k4[i] -
+                                R(17253.0 / 339200.0) * k5[i] + R(22.0 / 525.0) * k6[i] - R(1.0 / 40.0) * k7[i]);
+            const R sk = P.atol + P.rtol * fmax(fabs(z[i]), fabs(zn[i]));
+            const R r = err * rcp_r(sk);
+            e2 += r * r;
+        }
+        const R en2 = e2 * R(1.0 / NZ);  // the norm squared: err <= 1 <=> en2 <= 1, err^-1/5 = en2^-1/10
+        const bool floor_hit = !(hh > hmin);
+        const bool accept = active && (!(en2 > R(1)) || floor_hit);
+        gave_up |= active && floor_hit && en2 > R(1);
+        R fac = en2 > R(1e-20) ? R(0.9) * pow_m01(en2) : R(10);
+        fac = fmin(fmax(fac, R(0.2)), accept ? R(10) : R(1));
+        [[maybe_unused]] const R w0 = z[0];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) {
+            z[i] = accept ? zn[i] : z[i];
+            k1t[i] = accept ? k7[i] : k1t[i];  // (FSAL: where the sub-step touched no kink the model's slope at the end IS the true one)
+        }
+        if constexpr (HAS_M) {
+            if (kink) {
+                const R lim = P.omega_lim, phi_lim = copysign(lim, wmid), w1 = zn[0];
+                const bool needs = accept && ((med3_r(w0, -lim, lim) != (band ? w0 : phi_lim)) | (med3_r(w1, -lim, lim) != (band ? w1 : phi_lim)));
+                if (__any(needs)) {  // wave-uniform: the closed forms, and the true slope at the corrected state
+                    z[0] = z[0] + kink_defect<R>(P, w0, w1, hh * k1[0], hh * k7[0], wmid, band, needs, hh);
+                    R kt[NZ];
+                    rhs(z, kt);
+#pragma unroll
+                    for (int i = 0; i < NZ; ++i) k1t[i] = needs ? kt[i] : k1t[i];
+                }
+            }
+        }
+        integral += accept ? hh * q : R(0);
+        t = accept ? (fin ? hs : t + hh) : t;
+        h = active ? fmax(hh * fac, hmin) : h;
+        hprop = accept ? fmax(hprop, h) : hprop;  // (the controller's proposal after an accepted sub-step)
+    }
+    if (gave_up && P.errw != nullptr) atomicOr(P.errw, (uint32_t)GEMX_ERRFLAG_TOLERANCE);
+    if (dp5_carries<R>(P, hs, hc)) *hc = hprop;
+    return integral;
+}
 
 // ------------------------------------------------------------------------------------------------
 // PACKED fp32 (round 5).  gfx950's VALU takes two fp32 operations per lane and issue slot (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32), and a
@@ -604,7 +671,9 @@ __device__ __forceinline__ float dp5_adaptive_pk(const DevParams<float> &P, floa
 #pragma unroll
     for (int j = 0; j < NP; ++j) z.p[j] = f2_t{y[1 + 2 * j], y[2 + 2 * j]};
     auto rhs = [&](const V &zz, V &dz) { dz.w = poly_load_ode<float>(P, zz.w, E.rhs(P, zz, dz)); };
-    rhs(z, k1);
+    const bool kink = P.kink_split != 0;  // wave-uniform: every attempt on the smooth model system, the kink's defect in closed form (dp5_adaptive: KINKS)
+    V k1t;  // the TRUE right-hand side at z
+    rhs(z, k1t);
     float t = 0.0f, h = dp5_first_try<float>(P, hs, hc), integral = 0.0f, hprop = 0.0f;
     const float hmin = hs * (1.0f / 1024.0f);
     bool gave_up = false;
@@ -615,26 +684,41 @@ __device__ __forceinline__ float dp5_adaptive_pk(const DevParams<float> &P, floa
         const bool fin = !(h < hs - t);
         const float hh = active ? (fin ? hs - t : h) : 0.0f;
         V k2, k3, k4, k5, k6, k7, zt, zn;
+        k1 = k1t;
+        float kc0 = 0.0f, kc1 = 0.0f, wmid = 0.0f;
+        bool band = false;
+        if (kink) {  // this attempt's model: the region of the Euler-predicted mid-step omega
+            wmid = fmaf(0.5f * hh, k1t.w, z.w);
+            band = fabsf(wmid) < P.omega_lim;
+            kc1 = band ? P.lin_factor : 0.0f;
+            kc0 = band ? 0.0f : copysignf(P.la, wmid);
+            k1.w = fmaf(med3_r(P.lin_factor * z.w, -P.la, P.la) - fmaf(kc1, z.w, kc0), P.inv_j, k1t.w);  // first stage of the model system
+        }
+        auto ev = [&](const V &zz, V &dz) {
+            const float tq = E.rhs(P, zz, dz);
+            const float om = zz.w;
+            dz.w = kink ? (tq - (P.lc * (om * fabsf(om)) + P.lb * om + fmaf(kc1, om, kc0))) * P.inv_j : poly_load_ode<float>(P, om, tq);
+        };
         float q = (float)(35.0 / 384.0) * z.w;
         zt = pk_axpy(z, hh, pk_scale((float)(1.0 / 5.0), k1));
-        rhs(zt, k2);
+        ev(zt, k2);
         zt = pk_axpy(z, hh, pk_acc(pk_scale((float)(3.0 / 40.0), k1), (float)(9.0 / 40.0), k2));
-        rhs(zt, k3);
+        ev(zt, k3);
         q += (float)(500.0 / 1113.0) * zt.w;
         zt = pk_axpy(z, hh, pk_acc(pk_acc(pk_scale((float)(44.0 / 45.0), k1), -(float)(56.0 / 15.0), k2), (float)(32.0 / 9.0), k3));
-        rhs(zt, k4);
+        ev(zt, k4);
         q += (float)(125.0 / 192.0) * zt.w;
         zt = pk_axpy(z, hh, pk_acc(pk_acc(pk_acc(pk_scale((float)(19372.0 / 6561.0), k1), -(float)(25360.0 / 2187.0), k2), (float)(64448.0 / 6561.0), k3),
                                    -(float)(212.0 / 729.0), k4));
-        rhs(zt, k5);
+        ev(zt, k5);
         q -= (float)(2187.0 / 6784.0) * zt.w;
         zt = pk_axpy(z, hh, pk_acc(pk_acc(pk_acc(pk_acc(pk_scale((float)(9017.0 / 3168.0), k1), -(float)(355.0 / 33.0), k2), (float)(46732.0 / 5247.0), k3),
                                           (float)(49.0 / 176.0), k4), -(float)(5103.0 / 18656.0), k5));
-        rhs(zt, k6);
+        ev(zt, k6);
         q += (float)(11.0 / 84.0) * zt.w;
         zn = pk_axpy(z, hh, pk_acc(pk_acc(pk_acc(pk_acc(pk_scale((float)(35.0 / 384.0), k1), (float)(500.0 / 1113.0), k3), (float)(125.0 / 192.0), k4),
                                           -(float)(2187.0 / 6784.0), k5), (float)(11.0 / 84.0), k6));
-        rhs(zn, k7);
+        ev(zn, k7);
         // error estimate hh (e1 k1 + e3 k3 + e4 k4 + e5 k5 + e6 k6 + e7 k7), scaled per component by atol + rtol max(|z|, |z new|)
         const V er = pk_scale(hh, pk_acc(pk_acc(pk_acc(pk_acc(pk_acc(pk_scale((float)(71.0 / 57600.0), k1), -(float)(71.0 / 16695.0), k3), (float)(71.0 / 1920.0), k4),
                                                         -(float)(17253.0 / 339200.0), k5), (float)(22.0 / 525.0), k6), -(float)(1.0 / 40.0), k7));
@@ -648,12 +732,25 @@ __device__ __forceinline__ float dp5_adaptive_pk(const DevParams<float> &P, floa
         gave_up |= active && floor_hit && en2 > 1.0f;
         float fac = en2 > 1e-20f ? 0.9f * pow_m01(en2) : 10.0f;
         fac = fminf(fmaxf(fac, 0.2f), accept ? 10.0f : 1.0f);
+        const float w0 = z.w;
         z.w = accept ? zn.w : z.w;
-        k1.w = accept ? k7.w : k1.w;
+        k1t.w = accept ? k7.w : k1t.w;  // (FSAL: where the sub-step touched no kink the model's slope at the end IS the true one)
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             z.p[j] = accept ? zn.p[j] : z.p[j];
-            k1.p[j] = accept ? k7.p[j] : k1.p[j];
+            k1t.p[j] = accept ? k7.p[j] : k1t.p[j];
+        }
+        if (kink) {
+            const float lim = P.omega_lim, phi_lim = copysignf(lim, wmid), w1 = zn.w;
+            const bool needs = accept && ((med3_r(w0, -lim, lim) != (band ? w0 : phi_lim)) | (med3_r(w1, -lim, lim) != (band ? w1 : phi_lim)));
+            if (__any(needs)) {  // wave-uniform: the closed forms, and the true slope at the corrected state
+                z.w = z.w + kink_defect<float>(P, w0, w1, hh * k1.w, hh * k7.w, wmid, band, needs, hh);
+                V kt;
+                rhs(z, kt);
+                k1t.w = needs ? kt.w : k1t.w;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) k1t.p[j] = needs ? kt.p[j] : k1t.p[j];
+            }
         }
         integral += accept ? hh * q : 0.0f;
         t = accept ? (fin ? hs : t + hh) : t;
@@ -783,7 +880,20 @@ __device__ __forceinline__ R integrate(const DevParams<R> &P, R (&y)[SysTraits<S
 #pragma unroll
             for (int i = 0; i < NM; ++i) dz[1 + i] = dx[i];
         };
-        if (SOLVER == GEMX_SOLVER_DP5 && P.adaptive) return P.pole * dp5_adaptive<NM + 1, R>(P, y, h, rhs, hc);
+        if (SOLVER == GEMX_SOLVER_DP5 && P.adaptive) {
+            // (with GEMX_SOLVER_SPLIT_KINKS: every attempt on the smooth model system c0 + c1 omega of the load's saturation, see dp5_adaptive)
+            auto rhs_mc = [&](const R (&z)[NM + 1], R (&dz)[NM + 1], R c0, R c1) {
+                R x[NM], dx[NM];
+#pragma unroll
+                for (int i = 0; i < NM; ++i) x[i] = z[1 + i];
+                const typename E::Pre pre = E::prep(P, z[0], u);
+                E::f(P, pre, x, dx);
+                dz[0] = (E::torque(P, x) - (P.lc * (z[0] * fabs(z[0])) + P.lb * z[0] + fma(c1, z[0], c0))) * P.inv_j;
+#pragma unroll
+                for (int i = 0; i < NM; ++i) dz[1 + i] = dx[i];
+            };
+            return P.pole * dp5_adaptive<NM + 1, R>(P, y, h, rhs, hc, rhs_mc);
+        }
         if (!P.kink_split) {
             R wsum = R(0);
             if (NS1 || ns == 1) {
@@ -4171,22 +4281,32 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
     }
 }
 
-// Which shapes of the pipelined kernel exist for a solver: the two DEEP shapes (<12, 3>, <12, 6>) are not built for the Dormand-Prince
-// kernels (fixed-step DP5 and the error-controlled ScipyOdeSolver()).  Those launches are bound by the integrator at 0.1-0.3 of the
-// roofline whatever the hand-off depth, their twelve-step unrolled blocks were the most expensive code of the library to compile (a fifth
-// of its build time for 8 of each unit's 60 pipelined instantiations), and <4, 2> / <2, 2> / the FULL form serve every batch size.
-template <int SOLVER> constexpr bool pipe_deep_built() { return SOLVER != GEMX_SOLVER_DP5; }
-// shape index -> kernel (0: <12, 3>, 1: <4, 2>, 2: <2, 2>, 3: <12, 6>, 4: <4, 2> FULL, 5 / 6: <4, 2> / <4, 2> FULL, SLOW, 7: <4, 2> FULL RINIT); nullptr for a
-// shape that is not built
+// Which shapes of the pipelined kernel exist.  Round 6, from the instantiation-coverage record (tools/instantiation_coverage.py,
+// profiles/r06_instantiation_coverage.md: of 2455 compiled kernels the whole GPU suite, bench.py and the throughput matrix launched 473):
+//   * <4, 2> and its FULL / FULL + SLOW / FULL + RINIT forms serve EVERY (load, solver, dead time) combination at every batch size;
+//   * the two DEEP shapes (<12, 3>, <12, 6>: one workgroup per CU, small batches) exist for the default fixed-step solver (RK4) without
+//     converter dead time only -- the configurations every bench leg, matrix row and `make(env_id)` default runs at 16384 envs.  Euler, the
+//     Dormand-Prince kernels (integrator-bound at 0.1-0.3 of the roofline whatever the hand-off depth) and the dead-time code (IL) take
+//     <4, 2> there; their twelve-step unrolled blocks were the most expensive code of the library to compile;
+//   * <2, 2> (one resident round where <4, 2> would run a round plus a short tail) exists without dead time for RK4 and Dormand-Prince
+//     (BASELINE config 4 runs it under both);
+//   * SLOW without FULL is gone: solver sub-steps and custom constraint sets take FULL + SLOW (a per-lane supply row they do not need:
+//     those launches are integrator-bound).
+// Every shape that IS built is launched by tests/test_gpu_instantiations.py and compared bit for bit with the single-wave kernel.
+template <int SOLVER, bool IL> constexpr bool pipe_deep_built() { return SOLVER == GEMX_SOLVER_RK4 && !IL; }
+template <int SOLVER, bool IL> constexpr bool pipe_d3_built() { return SOLVER != GEMX_SOLVER_EULER && !IL; }
+// shape index -> kernel (0: <12, 3>, 1: <4, 2>, 2: <2, 2>, 3: <12, 6>, 4: <4, 2> FULL, 6: <4, 2> FULL SLOW, 7: <4, 2> FULL RINIT; 5 (SLOW without
+// FULL) is no longer built); nullptr for a shape that is not built
 template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> inline void (*pipe_kernel_of(int shape))(const KArgs<R>) {
-    if constexpr (pipe_deep_built<SOLVER>()) {
+    if constexpr (pipe_deep_built<SOLVER, IL>()) {
         if (shape == 0) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES>;
         if (shape == 3) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES_RW>;
     }
+    if constexpr (pipe_d3_built<SOLVER, IL>()) {
+        if (shape == 2) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D3, PIPE_OUT_WAVES3>;
+    }
     if (shape == 1) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2>;
-    if (shape == 2) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D3, PIPE_OUT_WAVES3>;
     if (shape == 4) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2, true>;
-    if (shape == 5) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2, false, true>;
     if (shape == 6) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2, true, true>;
     if (shape == 7) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2, true, false, true>;
     return nullptr;
@@ -4303,7 +4423,8 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     const bool pipe_ok = h->use_pipe != 0 && K >= 2 && obs_every;
     const bool fast_step = params_of<R>(h).constr_kind <= 1 && h->cfg.solver_nsteps == 1;  // (else: the pipelined kernel's rolled copy of the step)
     // RC supply / random initialisers: the FULL instantiation (shape <4, 2> only; see advance_pipe_kernel)
-    const bool need_full = h->cfg.supply_kind != GEMX_SUPPLY_IDEAL || h->cfg.init_kind != GEMX_INIT_CONST;
+    // (round 6: also solver sub-steps / custom constraint sets -- the SLOW copy of the step exists in its FULL form only, pipe_kernel_of)
+    const bool need_full = h->cfg.supply_kind != GEMX_SUPPLY_IDEAL || h->cfg.init_kind != GEMX_INIT_CONST || !fast_step;
     // (fp32 only: the fp64 build is a diagnostic of the same device functions and takes the single-wave kernel, which keeps its
     // translation units three times smaller)
     // small batches of the DC machines behind a constant-speed load: dc_stream_kernel, up to one workgroup per TWO CUs (8192 envs): there it
@@ -4433,7 +4554,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         // (round 4: only while the rate limiter is OFF.  With it the shallow shapes hold 0.79 at every size from 32768 envs on, the deep shape in
         // rounds 0.64-0.77: profiles/r04m_pace_shapes.txt)
         const bool pacing_on = (h->pace_gbps < 0.0 ? GEMX_PACE_DEFAULT_ON != 0 : h->pace_gbps > 0.0) && K >= 64;
-        if (pipe_deep_built<SOLVER>() && compact_l && !pacing_on && K >= 400 && delay == 0 && h->cur_reward == nullptr && smem_of(PIPE_D) <= h->lds_max) {
+        if (pipe_deep_built<SOLVER, IL>() && compact_l && !pacing_on && K >= 400 && delay == 0 && h->cur_reward == nullptr && smem_of(PIPE_D) <= h->lds_max) {
             const int64_t res0 = resident(PIPE_D, PIPE_OUT_WAVES_RW), rounds = (blocks + res0 - 1) / res0;
             deep_rounds = blocks > res0 && 100 * blocks >= 85 * rounds * res0;
         }
@@ -4449,12 +4570,12 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         const bool long_one = pacing_on && h->pace_gbps < 0.0 && K >= 1200 && SYS == GEMX_SYS_SYNC && h->pf.lin_on != 0 && !need_full && h->cur_reward == nullptr &&
                               blocks <= (int64_t)h->n_cu;
         const int64_t deep_max = pacing_on && resident(PIPE_D, PIPE_OUT_WAVES) > 2 * (int64_t)h->n_cu ? 2 * (int64_t)h->n_cu : resident(PIPE_D, PIPE_OUT_WAVES);
-        if (pipe_deep_built<SOLVER>() && smem_of(PIPE_D) <= h->lds_max && (blocks <= deep_max || deep_rounds)) {
+        if (pipe_deep_built<SOLVER, IL>() && smem_of(PIPE_D) <= h->lds_max && (blocks <= deep_max || deep_rounds)) {
             D = PIPE_D; OW = PIPE_OUT_WAVES; shape = 0;
             // (long launches of the synchronous machines' one-step-map rows: <12, 3>, which carries the rate limiter -- see `long_one` below)
             if (h->cur_reward != nullptr || (compact_l && !long_one)) { OW = PIPE_OUT_WAVES_RW; shape = 3; }
         }
-        else if (smem_of(PIPE_D3) <= h->lds_max && blocks <= resident(PIPE_D3, PIPE_OUT_WAVES3) &&
+        else if (pipe_d3_built<SOLVER, IL>() && smem_of(PIPE_D3) <= h->lds_max && blocks <= resident(PIPE_D3, PIPE_OUT_WAVES3) &&
                  blocks > resident(PIPE_D2, PIPE_OUT_WAVES2) && 2 * blocks <= 3 * resident(PIPE_D2, PIPE_OUT_WAVES2)) {
             // (round 4: EVERY system.  Rounds 2-3 kept this to the induction machines on one sample -- ExtExDc at 131072 envs, which is not
             // this case at all (two full rounds of <4, 2>) -- but where <4, 2> runs a round plus a tail of at most half a round and <2, 2>
@@ -4471,7 +4592,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         } else if (smem_of(PIPE_D2) <= h->lds_max) { D = PIPE_D2; OW = PIPE_OUT_WAVES2; shape = 1; }
         if (h->pipe_shape >= 0 && h->pipe_shape <= 3) {  // forced shape (tests)
             const int fd[4] = {PIPE_D, PIPE_D2, PIPE_D3, PIPE_D}, fo[4] = {PIPE_OUT_WAVES, PIPE_OUT_WAVES2, PIPE_OUT_WAVES3, PIPE_OUT_WAVES_RW};
-            if (smem_of(fd[h->pipe_shape]) <= h->lds_max && (pipe_deep_built<SOLVER>() || fd[h->pipe_shape] != PIPE_D)) { shape = h->pipe_shape; D = fd[shape]; OW = fo[shape]; }
+            if (smem_of(fd[h->pipe_shape]) <= h->lds_max && pipe_kernel_of<SYS, CONV, LOAD, SOLVER, IL, R>(h->pipe_shape) != nullptr) { shape = h->pipe_shape; D = fd[shape]; OW = fo[shape]; }
         }
         if (need_full) {  // one instantiation serves these handles
             // ~180 VGPRs = two resident workgroups per CU.  RC supply: ahead of the single-wave kernel at every size (PMSM finite, same box:
@@ -4485,7 +4606,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             else D = 0;
         }
         if (!fast_step && D != 0) {  // solver sub-steps / a custom constraint set: the SLOW instantiations of <4, 2> (no limiter: integrator-bound)
-            if (smem_of(PIPE_D2) <= h->lds_max && h->cfg.init_kind == GEMX_INIT_CONST) { D = PIPE_D2; OW = PIPE_OUT_WAVES2; shape = need_full ? 6 : 5; }
+            if (smem_of(PIPE_D2) <= h->lds_max && h->cfg.init_kind == GEMX_INIT_CONST) { D = PIPE_D2; OW = PIPE_OUT_WAVES2; shape = 6; }
             else D = 0;  // (together with random initialisers: the single-wave kernel)
         }
         if (D != 0) {
@@ -4683,9 +4804,12 @@ int launch_advance_unit(gemx_handle *h, const void *actions, int K, void *obs, u
     // keeps them too, from Stepper::legs_of -- so an RC supply no longer forces the slower IL code)
     const bool il = sizeof(R) == 8 || h->cfg.interlocking_time > 0.0;
     const int ld = h->cfg.load_kind, sv = h->cfg.solver_kind;
+    // (gemx_create refuses interlocking_time > 0 for the EESM -- the reference's dead-time branch for that system cannot execute,
+    // physical_systems.py:634 -- so its fp32 units carry no dead-time code)
+    constexpr bool IL_BUILT = sizeof(R) == 8 || SYS != GEMX_SYS_EESM;
 #define GEMX_CASE(LD, SV)                                                                                                  \
     if (ld == LD && sv == SV) {                                                                                            \
-        if (il) return launch_advance_t<SYS, CONV, LD, SV, true, R>(h, actions, K, obs, done, obs_every, st);              \
+        if constexpr (IL_BUILT) if (il) return launch_advance_t<SYS, CONV, LD, SV, true, R>(h, actions, K, obs, done, obs_every, st); \
         if constexpr (sizeof(R) == 4) return launch_advance_t<SYS, CONV, LD, SV, false, R>(h, actions, K, obs, done, obs_every, st); \
     }
     GEMX_CASE(GEMX_LOAD_CONST_SPEED, GEMX_SOLVER_EULER)

@@ -93,8 +93,11 @@ typedef enum { GEMX_SOLVER_EULER = 0, GEMX_SOLVER_RK4 = 1, GEMX_SOLVER_DP5 = 2 }
  * way until the segment is through; the other lanes of its wave wait.  The step size a lane ends a control step with is CARRIED to its next
  * one (a state row, like DOPRI5's WORK(7); cleared by a reset, part of the checkpoint blob).  Still not scipy's step sequence (no PI term,
  * fp32 error estimates), so not its bits -- the same tolerance.  Floor: a step of 1/1024 of the segment is taken whatever its estimate and
- * raises GEMX_ERRFLAG_TOLERANCE.  Takes precedence over GEMX_SOLVER_SPLIT_KINKS and over solver_nsteps; the one-step map and the
- * small-batch DC kernel are not used. */
+ * raises GEMX_ERRFLAG_TOLERANCE.  Takes precedence over solver_nsteps; the one-step map and the small-batch DC kernel are not used.
+ * Together with GEMX_SOLVER_SPLIT_KINKS (ABI 7; PolynomialStaticLoad): every attempt integrates the smooth model system of the kink
+ * correction above and an accepted sub-step adds the kink's defect to omega in closed form, so that the error estimate never sees the
+ * kink.  Without it a lane that crosses |omega| = a tau_decay / J cuts its step five to eight times, and under random actions some lane of
+ * a 64-lane wave does in most control steps: 4.7 attempts per control step and wave against 1.8 (profiles/r06_wave_step_statistics.md). */
 #define GEMX_SOLVER_ADAPTIVE 2
 typedef enum { GEMX_F32 = 0, GEMX_F64 = 1 } gemx_dtype;
 /* observation layout: [N, S_out] rows per env (the reference contract) or [S_out, N] */

@@ -50,7 +50,7 @@ enum { ORC_CONV_CONT_4QC = 0, ORC_CONV_FINITE_B6 = 1, ORC_CONV_CONT_B6 = 2, ORC_
 #define ORC_IS_DC(s) ((s) == ORC_SYS_DC_PERMEX || (s) == ORC_SYS_DC_SERIES || (s) == ORC_SYS_DC_SHUNT || (s) == ORC_SYS_DC_EXTEX)
 enum { ORC_LOAD_CONST_SPEED = 0, ORC_LOAD_POLY_STATIC = 1 };
 enum { ORC_SOLVER_EULER = 0, ORC_SOLVER_RK4 = 1, ORC_SOLVER_DOPRI5 = 2, ORC_SOLVER_DP5_FIXED = 3, ORC_SOLVER_IVP_RK45 = 4,
-       ORC_SOLVER_RK4_KINK = 5, ORC_SOLVER_DP5_KINK = 6, ORC_SOLVER_DEV_ADAPTIVE = 7 };
+       ORC_SOLVER_RK4_KINK = 5, ORC_SOLVER_DP5_KINK = 6, ORC_SOLVER_DEV_ADAPTIVE = 7, ORC_SOLVER_DEV_ADAPTIVE_KINK = 8 };
 
 #define ORC_MAX_ODE 8
 #define ORC_MAX_OUT 24
@@ -486,6 +486,33 @@ static void fixed_step_m(const orc_params *p, orc_env *e, int dp5, double h, con
         e->y[i] = e->y[i] + h * (35.0 / 384.0 * k1[i] + 500.0 / 1113.0 * k3[i] + 125.0 / 192.0 * k4[i] - 2187.0 / 6784.0 * k5[i] +
                                  11.0 / 84.0 * k6[i]);
 }
+/* dp5_stages on the model system (system_equation_m): k6[0] keeps the last stage's d omega / dt */
+static void dp5_stages_m(const orc_params *p, const orc_env *e, int n, const double *y, double h, double *k1, double *k2,
+                       double *k3, double *k4, double *k5, double *k6, double *y1, int model, double c0, double c1) {
+    double yt[ORC_MAX_ODE];
+    for (int i = 0; i < n; ++i) yt[i] = y[i] + h * (1.0 / 5.0) * k1[i];
+    system_equation_m(p, e, yt, k2, model, c0, c1);
+    for (int i = 0; i < n; ++i) yt[i] = y[i] + h * (3.0 / 40.0 * k1[i] + 9.0 / 40.0 * k2[i]);
+    system_equation_m(p, e, yt, k3, model, c0, c1);
+    for (int i = 0; i < n; ++i) yt[i] = y[i] + h * (44.0 / 45.0 * k1[i] - 56.0 / 15.0 * k2[i] + 32.0 / 9.0 * k3[i]);
+    system_equation_m(p, e, yt, k4, model, c0, c1);
+    for (int i = 0; i < n; ++i)
+        yt[i] = y[i] + h * (19372.0 / 6561.0 * k1[i] - 25360.0 / 2187.0 * k2[i] + 64448.0 / 6561.0 * k3[i] -
+                            212.0 / 729.0 * k4[i]);
+    system_equation_m(p, e, yt, k5, model, c0, c1);
+    for (int i = 0; i < n; ++i)
+        yt[i] = y[i] + h * (9017.0 / 3168.0 * k1[i] - 355.0 / 33.0 * k2[i] + 46732.0 / 5247.0 * k3[i] +
+                            49.0 / 176.0 * k4[i] - 5103.0 / 18656.0 * k5[i]);
+    system_equation_m(p, e, yt, k6, model, c0, c1);
+    for (int i = 0; i < n; ++i)
+        y1[i] = y[i] + h * (35.0 / 384.0 * k1[i] + 500.0 / 1113.0 * k3[i] + 125.0 / 192.0 * k4[i] -
+                            2187.0 / 6784.0 * k5[i] + 11.0 / 84.0 * k6[i]);
+    system_equation_m(p, e, y1, k2, model, c0, c1);
+    for (int i = 0; i < n; ++i)
+        k4[i] = (71.0 / 57600.0 * k1[i] - 71.0 / 16695.0 * k3[i] + 71.0 / 1920.0 * k4[i] - 17253.0 / 339200.0 * k5[i] +
+                 22.0 / 525.0 * k6[i] - 1.0 / 40.0 * k2[i]) * h;
+}
+
 static double clamp3(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 /* KinkPath::ramp: U(c) = int_0^1 (s(th) - c)_+ dth along s = w + V0 th + c2 th^2 + c3 th^3; the crossing instant from the quadratic
  * through both ends with the start slope (U is stationary in it) */
@@ -553,6 +580,11 @@ static double dev_first_try(const orc_params *p, double hs, double hc) {
 }
 static void dev_adaptive(const orc_params *p, orc_env *e, double t_end) {
     const double RTOL = 1e-6, ATOL = 1e-9;
+    /* ORC_SOLVER_DEV_ADAPTIVE_KINK: the same controller on the SMOOTH model system of every attempt (the load's saturation replaced by the
+     * affine piece of the region the mid-step omega is predicted in), the kink's defect added to omega in closed form after an accepted
+     * sub-step -- the error estimate then never sees the kink, whose crossing costs the plain controller 5-8 attempts (round 6). */
+    const int kink = p->solver == ORC_SOLVER_DEV_ADAPTIVE_KINK && p->load == ORC_LOAD_POLY_STATIC && p->load_a / p->j_total * p->tau_decay > 0.0;
+    const double lim = kink ? p->load_a / p->j_total * p->tau_decay : 0.0, kap = p->j_total / p->tau_decay, inv_j = 1.0 / p->j_total, la = p->load_a;
     const int n = n_ode(p), nz = ORC_IS_DC(p->system) ? n : n - 1; /* the angle is integrated alongside, outside the error norm */
     double k1[ORC_MAX_ODE], k2[ORC_MAX_ODE], k3[ORC_MAX_ODE], k4[ORC_MAX_ODE], k5[ORC_MAX_ODE], k6[ORC_MAX_ODE], y1[ORC_MAX_ODE];
     const double hs = t_end - e->t, hmin = hs / 1024.0;
@@ -564,6 +596,17 @@ static void dev_adaptive(const orc_params *p, orc_env *e, double t_end) {
         const int fin = !(h < hs - t);
         const double hh = fin ? hs - t : h;
         g_dev_attempts++;
+        double k1m[ORC_MAX_ODE], c0 = 0.0, c1 = 0.0, wmid = 0.0;
+        int band = 0;
+        for (int i = 0; i < n; ++i) k1m[i] = k1[i];
+        if (kink) {
+            const double w = e->y[0];
+            wmid = 0.5 * hh * k1[0] + w;
+            band = fabs(wmid) < lim;
+            c1 = band ? kap : 0.0; c0 = band ? 0.0 : copysign(la, wmid);
+            k1m[0] = (clamp3(kap * w, -la, la) - (c1 * w + c0)) * inv_j + k1[0];
+            dp5_stages_m(p, e, n, e->y, hh, k1m, k2, k3, k4, k5, k6, y1, 1, c0, c1);
+        } else
         dp5_stages(p, e, n, e->y, hh, k1, k2, k3, k4, k5, k6, y1); /* k2 <- f(y1) (FSAL), k4 <- the error estimate */
         double e2 = 0.0;
         for (int i = 0; i < nz; ++i) {
@@ -575,7 +618,26 @@ static void dev_adaptive(const orc_params *p, orc_env *e, double t_end) {
         double fac = en2 > 1e-20 ? 0.9 * pow(en2, -0.1) : 10.0;
         fac = fmin(fmax(fac, 0.2), accept ? 10.0 : 1.0);
         if (accept) {
+            const double w = e->y[0], w1 = y1[0];
             for (int i = 0; i < n; ++i) { e->y[i] = y1[i]; k1[i] = k2[i]; }
+            if (kink) {
+                const double phi_lim = copysign(lim, wmid);
+                const int needs = (clamp3(w, -lim, lim) != (band ? w : phi_lim)) | (clamp3(w1, -lim, lim) != (band ? w1 : phi_lim));
+                if (needs) { /* integrate_kink_substep's defect, end slope = the model's f(y1) */
+                    const double V0 = hh * k1m[0], V1 = hh * k2[0], dl = w1 - w;
+                    const double c2 = 3.0 * dl - 2.0 * V0 - V1, c3 = V0 + V1 - 2.0 * dl;
+                    const kink_path kp = {w, w1, V0, V0 * V0, 4.0 * (dl - V0), c2 * (1.0 / 3.0), c3 * 0.25, 0.5 * V0,
+                                          w + 0.5 * V0 + c2 * (1.0 / 3.0) + c3 * 0.25, w1 > w};
+                    const double lev = (kp.up ? (w < -lim) : !(w > lim)) ? -lim : lim, oth = -lev;
+                    const double U1 = kink_ramp(&kp, lev);
+                    const int o0 = w >= oth, o1 = w1 >= oth;
+                    double U2 = (o0 & o1) ? kp.M - oth : 0.0;
+                    if (o0 != o1) U2 = kink_ramp(&kp, oth);
+                    const double Up = lev > 0.0 ? U1 : U2, Um = lev > 0.0 ? U2 : U1;
+                    e->y[0] = w1 - (hh * (1.0 / p->tau_decay)) * ((Um - Up - lim) - (band ? kp.M : phi_lim));
+                    system_equation(p, e, e->y, k1); /* the TRUE system's slope at the corrected state (no FSAL across a crossing) */
+                }
+            }
             t = fin ? hs : t + hh;
         }
         h = fmax(hh * fac, hmin);
@@ -587,7 +649,7 @@ static void dev_adaptive(const orc_params *p, orc_env *e, double t_end) {
 
 static void integrate(const orc_params *p, orc_env *e, double t_end) {
     int n = n_ode(p);
-    if (p->solver == ORC_SOLVER_DEV_ADAPTIVE) { dev_adaptive(p, e, t_end); return; }
+    if (p->solver == ORC_SOLVER_DEV_ADAPTIVE || p->solver == ORC_SOLVER_DEV_ADAPTIVE_KINK) { dev_adaptive(p, e, t_end); return; }
     if (p->solver == ORC_SOLVER_DOPRI5) { dopri5_adaptive(p, e, t_end); return; }
     if (p->solver == ORC_SOLVER_IVP_RK45) { ivp_rk45(p, e, t_end); return; }
     if (p->solver == ORC_SOLVER_RK4_KINK || p->solver == ORC_SOLVER_DP5_KINK) { integrate_kink(p, e, p->solver == ORC_SOLVER_DP5_KINK, t_end); return; }

@@ -84,7 +84,7 @@ _SOLVER = {"euler": (SOLVER_EULER, 1), "euler4": (SOLVER_EULER, 4), "rk4": (SOLV
            # what the HIP kernels do for a PolynomialStaticLoad: a fixed step corrected for the load's kinks in closed form (no reference counterpart)
            "rk4_kink": (SOLVER_RK4_KINK, 1), "dp5_kink": (SOLVER_DP5_KINK, 1),
            # DIAGNOSTIC: the HIP kernels' error controller (ScipyOdeSolver() on the device) in fp64, for wave statistics on the CPU
-           "dev_adaptive": (7, 1)}
+           "dev_adaptive": (7, 1), "dev_adaptive_kink": (8, 1)}
 _IVP_TOL = {"ivp": (1e-3, 1e-6), "ivp_tight": (1e-10, 1e-12)}  # solve_ivp defaults | oracle/make_golden.py:make_solver("ivp_tight")
 _MP_KEYS = {SYS_DC: ("r_a", "l_a", "psi_e"), SYS_PMSM: ("p", "l_d", "l_q", "r_s", "psi_p"),
             SYS_SCIM: ("p", "l_m", "l_sigs", "l_sigr", "r_s", "r_r"),

@@ -2704,7 +2704,7 @@ def test_bench_multi_gpu_code_path_through_rccl_in_a_world_of_one():
     assert rc["world_seen"] == 1 and rc["backend"] == "nccl" and rc["own_slot_bit_identical"] is True
     assert rc["bytes_per_rank"] == 16384 * 200 * 57 and rc["GB_per_s"] > 0 and rc["ms"] > 0
     assert line["gather"]["chunk"]["value"] > 0 and "error" not in line["config5"] and line["config5"]["envs_per_gpu"] == 32768
-    assert line["overrides"] == {k: v for k, v in os.environ.items() if k.startswith("GEMX_")}
+    assert line["overrides"] == {k: v for k, v in os.environ.items() if k.startswith("GEMX_") and k != "GEMX_COVERAGE_FILE"}
 
 
 def test_rate_limiter_closed_loop_calibrates_and_never_changes_results(monkeypatch):
