@@ -309,7 +309,7 @@ template <class R> struct KinkPath {
 // error estimate never sees the kink, and an accepted sub-step adds the kink's defect to omega in closed form (kink_defect).  The first
 // stage of the next sub-step is the last of this one (FSAL) unless the sub-step touched a kink: then the TRUE right-hand side is evaluated
 // at the corrected state (behind a wave ballot).  1.8 attempts per control step and wave; 9e-7 / 6e-6 against scipy's dopri5 on i.i.d. /
-// held actions where the plain controller has 7e-7 / 3e-6 (fp64, oracle/gemx_oracle.c: ORC_SOLVER_DEV_ADAPTIVE_KINK follows these steps).
+// held actions where the plain controller has 7e-7 / 3e-6 (fp64: the test suite's CPU restatement of these steps, tools/wave_step_statistics.py).
 template <class R>
 __device__ __forceinline__ R kink_defect(const DevParams<R> &P, R w, R w1, R V0, R V1, R wmid, bool band, bool needs, R hh) {
     // integrate<>'s closed forms (documented there): the defect of omega over a sub-step of length hh whose model path is the cubic

@@ -379,7 +379,9 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         cfg.solver_flags = _lib.SOLVER_SPLIT_KINKS if getattr(self._ode_solver, "_split_kinks", False) else 0
         tol = self._adaptive_tolerances()
         if tol is not None:  # ScipyOdeSolver: error-controlled DP5
-            cfg.solver_flags = _lib.SOLVER_ADAPTIVE | (cfg.solver_flags & _lib.SOLVER_SPLIT_KINKS)
+            # (kinks in closed form unless the caller opts out -- ScipyOdeSolver(split_kinks=False); the reference's own instance has no such
+            # attribute and gets the default.  Ignored by the library for loads without a kink.)
+            cfg.solver_flags = _lib.SOLVER_ADAPTIVE | (_lib.SOLVER_SPLIT_KINKS if getattr(self._ode_solver, "_split_kinks", True) else 0)
             cfg.solver_rtol, cfg.solver_atol = tol
         cfg.dtype = _lib.F64 if self._dtype_name == "float64" else _lib.F32
         cfg.obs_layout = {"aos": _lib.OBS_AOS, "soa": _lib.OBS_SOA}[self._obs_layout]

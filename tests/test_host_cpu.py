@@ -187,9 +187,10 @@ def test_error_controlled_solver_config():
     both select the device's error-controlled Dormand-Prince: GEMX_SOLVER_DP5 + GEMX_SOLVER_ADAPTIVE with the caller's tolerances (scipy's
     atol 1e-12 is raised to the device's floor 1e-9); the flag is refused with another scheme."""
     cfg = ga.make("Cont-SC-SCIM-v0", n_envs=2, ode_solver=ga.ScipyOdeSolver(), _defer_create=True).physical_system._cfg
-    assert (cfg.solver_kind, cfg.solver_nsteps, cfg.solver_flags) == (_lib.SOLVER_DP5, 1, _lib.SOLVER_ADAPTIVE)
+    AK = _lib.SOLVER_ADAPTIVE | _lib.SOLVER_SPLIT_KINKS  # (round 6: the load's kinks in closed form by default; split_kinks=False opts out)
+    assert (cfg.solver_kind, cfg.solver_nsteps, cfg.solver_flags) == (_lib.SOLVER_DP5, 1, AK)
     assert (cfg.solver_rtol, cfg.solver_atol) == (1e-6, 1e-9)
-    cfg = ga.make("Cont-SC-SCIM-v0", n_envs=2, ode_solver=ga.ScipyOdeSolver(rtol=1e-5, atol=1e-7, nsteps=500), _defer_create=True).physical_system._cfg
+    cfg = ga.make("Cont-SC-SCIM-v0", n_envs=2, ode_solver=ga.ScipyOdeSolver(rtol=1e-5, atol=1e-7, nsteps=500, split_kinks=False), _defer_create=True).physical_system._cfg
     assert (cfg.solver_flags, cfg.solver_rtol, cfg.solver_atol) == (_lib.SOLVER_ADAPTIVE, 1e-5, 1e-7)
     with pytest.raises(ValueError):
         ga.ScipyOdeSolver("lsoda")
@@ -199,7 +200,7 @@ def test_error_controlled_solver_config():
             self._integrator, self._solver_args = integrator, kwargs
 
     cfg = ga.make("Cont-SC-SCIM-v0", n_envs=2, ode_solver=ScipyOdeSolver(), _defer_create=True).physical_system._cfg
-    assert (cfg.solver_kind, cfg.solver_flags, cfg.solver_rtol, cfg.solver_atol) == (_lib.SOLVER_DP5, _lib.SOLVER_ADAPTIVE, 1e-6, 1e-9)
+    assert (cfg.solver_kind, cfg.solver_flags, cfg.solver_rtol, cfg.solver_atol) == (_lib.SOLVER_DP5, AK, 1e-6, 1e-9)
     cfg = ga.make("Cont-SC-SCIM-v0", n_envs=2, ode_solver=ScipyOdeSolver(rtol=1e-4, atol=1e-5), _defer_create=True).physical_system._cfg
     assert (cfg.solver_rtol, cfg.solver_atol) == (1e-4, 1e-5)
     if os.path.isdir("/root/reference/src"):  # the live class, in a child process (its imports stay out of this session)
@@ -210,7 +211,7 @@ def test_error_controlled_solver_config():
                 "from gym_electric_motor.physical_systems.solvers import ScipyOdeSolver\n"
                 "import gym_electric_motor_amd as ga\nfrom gym_electric_motor_amd import _lib\n"
                 "c = ga.make('Cont-SC-SCIM-v0', n_envs=2, ode_solver=ScipyOdeSolver(), _defer_create=True).physical_system._cfg\n"
-                "assert (c.solver_kind, c.solver_flags, c.solver_rtol) == (_lib.SOLVER_DP5, _lib.SOLVER_ADAPTIVE, 1e-6)\nprint('OK')\n"
+                "assert (c.solver_kind, c.solver_flags, c.solver_rtol) == (_lib.SOLVER_DP5, _lib.SOLVER_ADAPTIVE | _lib.SOLVER_SPLIT_KINKS, 1e-6)\nprint('OK')\n"
                 % (os.path.join(REPO, "oracle", "gymnasium_standin"), "/root/reference/src", REPO))
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-3000:]

@@ -30,7 +30,7 @@ def _vr():
 
 def norm(name):
     """one spelling for a kernel: no namespace, no argument list, no `void`"""
-    n = name.strip().replace("gemx::", "").replace("void ", "")
+    n = name.strip().replace("gemx::", "").replace("(anonymous namespace)::", "").replace("void ", "")
     n = re.sub(r"\(.*\)$", "", n)
     return re.sub(r"\s+", " ", n)
 

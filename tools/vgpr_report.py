@@ -20,28 +20,51 @@ BUILD = os.path.join(REPO, "gym_electric_motor_amd", "build")
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
-def code_object_of(lib):
-    """the gfx950 code object of a built library / object file, extracted into gym_electric_motor_amd/build (never beside a shipped .so)"""
+def code_objects_of(lib):
+    """the gfx950 code objects of a built library (one per translation unit), extracted into gym_electric_motor_amd/build (never beside a
+    shipped .so): .hip_fatbin section -> its bundles (a library linked from several objects carries several, back to back) ->
+    clang-offload-bundler --unbundle, which also inflates --offload-compress bundles (llvm-objdump --offloading writes those out still
+    compressed)"""
     os.makedirs(BUILD, exist_ok=True)
-    co = os.path.join(BUILD, os.path.basename(lib) + ".0.hipv4-amdgcn-amd-amdhsa--gfx950")
-    if not os.path.exists(co) or os.path.getmtime(co) < os.path.getmtime(lib):
-        link = os.path.join(BUILD, os.path.basename(lib))
-        if os.path.abspath(link) != os.path.abspath(lib):  # llvm-objdump --offloading writes next to its input: give it one inside build/
-            if os.path.lexists(link):
-                os.remove(link)
-            os.symlink(os.path.abspath(lib), link)
-        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", os.path.basename(lib)], cwd=BUILD, capture_output=True)
-    return co
+    base = os.path.join(BUILD, os.path.basename(lib))
+    done = sorted(glob.glob(base + ".*.gfx950.co"))
+    if done and all(os.path.getmtime(c) >= os.path.getmtime(lib) for c in done):
+        return done
+    for c in done:
+        os.remove(c)
+    fb = base + ".fatbin"
+    subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fb, lib, os.devnull], check=True, capture_output=True)
+    blob = open(fb, "rb").read()
+    os.remove(fb)
+    starts = sorted(m.start() for magic in (b"CCOB", b"__CLANG_OFFLOAD_BUNDLE__") for m in re.finditer(re.escape(magic), blob))
+    # (a compressed bundle's payload may contain the magic by chance: keep the starts that unbundle)
+    out = []
+    for i, a in enumerate(starts):
+        part, co = base + f".{i}.bundle", base + f".{len(out)}.gfx950.co"
+        seg = blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)]
+        if seg[:4] == b"CCOB":  # compressed bundle: its header carries the exact size (the section pads every bundle to 4 KB, which the inflater refuses)
+            ver = int.from_bytes(seg[4:6], "little")
+            size = int.from_bytes(seg[8:16], "little") if ver >= 3 else (int.from_bytes(seg[8:12], "little") if ver == 2 else len(seg))
+            seg = seg[:size] if 0 < size <= len(seg) else seg
+        open(part, "wb").write(seg)
+        r = subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + part,
+                            "--output=" + co, "--unbundle"], capture_output=True)
+        os.remove(part)
+        if r.returncode == 0 and os.path.exists(co) and os.path.getsize(co) > 0:
+            out.append(co)
+        elif os.path.exists(co):
+            os.remove(co)
+    return out
 
 
 def kernels_of(obj):
-    co = code_object_of(obj)
-    txt = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True).stdout
     out = []
-    for b in txt.split("- .agpr_count")[1:]:
-        name = re.search(r"\.name:\s+(\S+)", b).group(1)
-        g = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", b).group(1))  # noqa: E731
-        out.append((name, g("vgpr_count"), g("vgpr_spill_count"), g("private_segment_fixed_size"), g("sgpr_count")))
+    for co in code_objects_of(obj):
+        txt = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True).stdout
+        for b in txt.split("- .agpr_count")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", b).group(1)
+            g = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", b).group(1))  # noqa: E731
+            out.append((name, g("vgpr_count"), g("vgpr_spill_count"), g("private_segment_fixed_size"), g("sgpr_count")))
     names = subprocess.run(["c++filt"], input="\n".join(k[0] for k in out), capture_output=True, text=True).stdout.splitlines()
     return [(re.sub(r"\((gemx::)?KArgs<(float|double)>\)$", "", n.replace("gemx::", "").replace("void ", "")),) + k[1:] for n, k in zip(names, out)]
 
