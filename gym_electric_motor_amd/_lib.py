@@ -37,7 +37,7 @@ class GemxConfig(C.Structure):
         ("seed", C.c_uint64), ("env_base", C.c_int64),
         ("init_lo", C.c_double * MAX_ODE), ("init_hi", C.c_double * MAX_ODE), ("init_mu", C.c_double * MAX_ODE),
         ("init_sigma", C.c_double * MAX_ODE),
-        ("supply_r", C.c_double), ("supply_c", C.c_double), ("action_delay_reset", C.c_double * 6), ("solver_rtol", C.c_double), ("solver_atol", C.c_double),
+        ("supply_r", C.c_double), ("supply_c", C.c_double), ("action_delay_reset", C.c_double * 6), ("solver_rtol", C.c_double), ("solver_atol", C.c_double), ("solver_atol_omega", C.c_double),
         ("tau", C.c_double), ("interlocking_time", C.c_double), ("u_nominal", C.c_double),
         ("model", C.c_double * (MODEL_ROWS * MODEL_COLS)),
         ("torque_coef", C.c_double * 4),

@@ -216,12 +216,16 @@ class ScipyOdeSolver(DormandPrince5Solver):
     wait for the one that crosses: BASELINE config 4 under random actions, 4.7 -> 1.8 attempts per control step and wave, same accuracy
     against the reference's dopri5 runs (profiles/r06_wave_step_statistics.md).  False: the plain controller of rounds 4-5."""
 
-    def __init__(self, integrator="dopri5", rtol=1e-6, atol=1e-9, split_kinks=True, **kwargs):
+    def __init__(self, integrator="dopri5", rtol=1e-6, atol=1e-9, split_kinks=True, atol_omega=None, **kwargs):
+        """atol_omega: absolute tolerance of omega in rad/s; None = atol x the speed limit, i.e. `atol` in NORMALISED units (1e-9 of the
+        speed range instead of 1e-9 rad/s: a speed-control episode starts at omega = 0, where a physical-unit atol makes lanes cut steps
+        that no observation can show, and the 64 lanes of a wave wait for them -- include/gemx.h: solver_atol_omega)."""
         if integrator != "dopri5":
             raise ValueError(f"integrator {integrator!r}: the accelerated path restates 'dopri5' (the reference's default) only")
         super().__init__(nsteps=1, split_kinks=split_kinks)
         self._adaptive = True
         self._rtol, self._atol = float(rtol), float(atol)
+        self._atol_omega = 0.0 if atol_omega is None else float(atol_omega)
         self._ignored = dict(kwargs)
 
 

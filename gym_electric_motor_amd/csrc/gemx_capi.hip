@@ -264,6 +264,7 @@ template <class R> static void fill_params(const gemx_handle &h, const double *m
     P.adaptive = (c.solver_flags & GEMX_SOLVER_ADAPTIVE) ? 1 : 0;
     P.rtol = (R)(c.solver_rtol > 0 ? c.solver_rtol : 1e-6);
     P.atol = (R)(c.solver_atol > 0 ? c.solver_atol : 1e-9);
+    P.atol_w = (R)(c.solver_atol_omega > 0 ? c.solver_atol_omega : (double)P.atol * c.limits[0]);  // (omega is state 0 and observation 0 of every system)
     P.errw = nullptr;  // (set per launch: launch_advance_t)
     // (round 6: the error-controlled solver honours GEMX_SOLVER_SPLIT_KINKS -- every attempt on the smooth model system, dp5_adaptive)
     P.auto_reset = c.auto_reset;
@@ -553,8 +554,8 @@ int gemx_create(const gemx_config *cfg, int64_t n_envs, int device, gemx_handle 
     if (cfg->solver_flags & ~(GEMX_SOLVER_SPLIT_KINKS | GEMX_SOLVER_ADAPTIVE)) return fail(GEMX_ERR_ARG, "unknown solver_flags 0x%x", cfg->solver_flags);
     if ((cfg->solver_flags & GEMX_SOLVER_ADAPTIVE) && cfg->solver_kind != GEMX_SOLVER_DP5)
         return fail(GEMX_ERR_ARG, "GEMX_SOLVER_ADAPTIVE needs solver_kind GEMX_SOLVER_DP5 (the embedded error estimate is Dormand-Prince's)");
-    if ((cfg->solver_flags & GEMX_SOLVER_ADAPTIVE) && (cfg->solver_rtol < 0 || cfg->solver_atol < 0 || cfg->solver_rtol > 0.1))
-        return fail(GEMX_ERR_ARG, "solver_rtol must be in [0, 0.1] and solver_atol >= 0 (0 = default)");
+    if ((cfg->solver_flags & GEMX_SOLVER_ADAPTIVE) && (cfg->solver_rtol < 0 || cfg->solver_atol < 0 || cfg->solver_rtol > 0.1 || cfg->solver_atol_omega < 0))
+        return fail(GEMX_ERR_ARG, "solver_rtol must be in [0, 0.1], solver_atol >= 0 and solver_atol_omega >= 0 (0 = default)");
     if (cfg->dtype != GEMX_F32 && cfg->dtype != GEMX_F64) return fail(GEMX_ERR_ARG, "unknown dtype");
     if (cfg->obs_layout != GEMX_OBS_AOS && cfg->obs_layout != GEMX_OBS_SOA) return fail(GEMX_ERR_ARG, "unknown obs_layout");
     if (cfg->load_kind != GEMX_LOAD_CONST_SPEED && cfg->load_kind != GEMX_LOAD_POLY_STATIC) return fail(GEMX_ERR_ARG, "unknown load_kind");

@@ -95,6 +95,7 @@ template <class R> struct DevParams {
     int32_t kink_split;     // GEMX_SOLVER_SPLIT_KINKS: the PolynomialStaticLoad's kinks are corrected for in closed form (integrate<>)
     int32_t adaptive;       // GEMX_SOLVER_ADAPTIVE (DP5 only): error-controlled sub-stepping, dp5_adaptive()
     R rtol, atol;           //   its tolerances (gemx_config.solver_rtol / solver_atol)
+    R atol_w;               //   ... and omega's absolute tolerance (gemx_config.solver_atol_omega; default solver_atol x limits[omega])
     uint32_t *errw;         //   the handle's device error word (GEMX_ERRFLAG_TOLERANCE)
     // DC machines: the default LimitConstraint on current c as a threshold in AMPERES, dc_thr[c] = the smallest R with
     // fl(dc_thr[c] * inv_lim[2 + c]) > 1 (viol_threshold(), host): |i| >= dc_thr[c]  <=>  |i * inv_lim| > 1 for EVERY i, because

@@ -401,7 +401,7 @@ __device__ __forceinline__ R dp5_adaptive(const DevParams<R> &P, R (&z)[NZ], R h
         for (int i = 0; i < NZ; ++i) {
             const R err = hh * (R(71.0 / 57600.0) * k1[i] - R(71.0 / 16695.0) * k3[i] + R(71.0 / 1920.0) * k4[i] -
                                 R(17253.0 / 339200.0) * k5[i] + R(22.0 / 525.0) * k6[i] - R(1.0 / 40.0) * k7[i]);
-            const R sk = P.atol + P.rtol * fmax(fabs(z[i]), fabs(zn[i]));
+            const R sk = ((HAS_M && i == 0) ? P.atol_w : P.atol) + P.rtol * fmax(fabs(z[i]), fabs(zn[i]));  // (HAS_M: z[0] is omega)
             const R r = err * rcp_r(sk);
             e2 += r * r;
         }
@@ -722,10 +722,10 @@ __device__ __forceinline__ float dp5_adaptive_pk(const DevParams<float> &P, floa
         // error estimate hh (e1 k1 + e3 k3 + e4 k4 + e5 k5 + e6 k6 + e7 k7), scaled per component by atol + rtol max(|z|, |z new|)
         const V er = pk_scale(hh, pk_acc(pk_acc(pk_acc(pk_acc(pk_acc(pk_scale((float)(71.0 / 57600.0), k1), -(float)(71.0 / 16695.0), k3), (float)(71.0 / 1920.0), k4),
                                                         -(float)(17253.0 / 339200.0), k5), (float)(22.0 / 525.0), k6), -(float)(1.0 / 40.0), k7));
-        auto sq = [&](float e, float a0, float a1) { const float r = e * rcp_r(P.atol + P.rtol * fmaxf(fabsf(a0), fabsf(a1))); return r * r; };
-        float e2 = sq(er.w, z.w, zn.w);
+        auto sq = [&](float e, float a0, float a1, float at) { const float r = e * rcp_r(at + P.rtol * fmaxf(fabsf(a0), fabsf(a1))); return r * r; };
+        float e2 = sq(er.w, z.w, zn.w, P.atol_w);  // (omega: its own absolute tolerance, gemx_config.solver_atol_omega)
 #pragma unroll
-        for (int j = 0; j < NP; ++j) e2 += sq(er.p[j].x, z.p[j].x, zn.p[j].x) + sq(er.p[j].y, z.p[j].y, zn.p[j].y);
+        for (int j = 0; j < NP; ++j) e2 += sq(er.p[j].x, z.p[j].x, zn.p[j].x, P.atol) + sq(er.p[j].y, z.p[j].y, zn.p[j].y, P.atol);
         const float en2 = e2 * (1.0f / NZ);
         const bool floor_hit = !(hh > hmin);
         const bool accept = active && (!(en2 > 1.0f) || floor_hit);
@@ -4293,12 +4293,15 @@ __global__ __launch_bounds__(dcs_waves<SYS>() * BLOCK) void dc_stream_kernel(con
 //   * SLOW without FULL is gone: solver sub-steps and custom constraint sets take FULL + SLOW (a per-lane supply row they do not need:
 //     those launches are integrator-bound).
 // Every shape that IS built is launched by tests/test_gpu_instantiations.py and compared bit for bit with the single-wave kernel.
-template <int SOLVER, bool IL> constexpr bool pipe_deep_built() { return SOLVER == GEMX_SOLVER_RK4 && !IL; }
+// (the DFIM's 24-value rows leave no room for twelve-step blocks in 160 KB of LDS: its deep shapes could never be launched;
+// the finite EESM converter is not available behind an RC supply, the one user of the plain FULL form)
+template <int SYS, int SOLVER, bool IL> constexpr bool pipe_deep_built() { return SOLVER == GEMX_SOLVER_RK4 && !IL && SYS != GEMX_SYS_DFIM; }
+template <int SYS, int CONV> constexpr bool pipe_full_built() { return !(SYS == GEMX_SYS_EESM && CONV == GEMX_CONV_FINITE_B6_4QC); }
 template <int SOLVER, bool IL> constexpr bool pipe_d3_built() { return SOLVER != GEMX_SOLVER_EULER && !IL; }
 // shape index -> kernel (0: <12, 3>, 1: <4, 2>, 2: <2, 2>, 3: <12, 6>, 4: <4, 2> FULL, 6: <4, 2> FULL SLOW, 7: <4, 2> FULL RINIT; 5 (SLOW without
 // FULL) is no longer built); nullptr for a shape that is not built
 template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> inline void (*pipe_kernel_of(int shape))(const KArgs<R>) {
-    if constexpr (pipe_deep_built<SOLVER, IL>()) {
+    if constexpr (pipe_deep_built<SYS, SOLVER, IL>()) {
         if (shape == 0) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES>;
         if (shape == 3) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D, PIPE_OUT_WAVES_RW>;
     }
@@ -4306,7 +4309,9 @@ template <int SYS, int CONV, int LOAD, int SOLVER, bool IL, class R> inline void
         if (shape == 2) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D3, PIPE_OUT_WAVES3>;
     }
     if (shape == 1) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2>;
-    if (shape == 4) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2, true>;
+    if constexpr (pipe_full_built<SYS, CONV>()) {
+        if (shape == 4) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2, true>;
+    }
     if (shape == 6) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2, true, true>;
     if (shape == 7) return advance_pipe_kernel<SYS, CONV, LOAD, SOLVER, IL, R, PIPE_D2, PIPE_OUT_WAVES2, true, false, true>;
     return nullptr;
@@ -4554,7 +4559,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         // (round 4: only while the rate limiter is OFF.  With it the shallow shapes hold 0.79 at every size from 32768 envs on, the deep shape in
         // rounds 0.64-0.77: profiles/r04m_pace_shapes.txt)
         const bool pacing_on = (h->pace_gbps < 0.0 ? GEMX_PACE_DEFAULT_ON != 0 : h->pace_gbps > 0.0) && K >= 64;
-        if (pipe_deep_built<SOLVER, IL>() && compact_l && !pacing_on && K >= 400 && delay == 0 && h->cur_reward == nullptr && smem_of(PIPE_D) <= h->lds_max) {
+        if (pipe_deep_built<SYS, SOLVER, IL>() && compact_l && !pacing_on && K >= 400 && delay == 0 && h->cur_reward == nullptr && smem_of(PIPE_D) <= h->lds_max) {
             const int64_t res0 = resident(PIPE_D, PIPE_OUT_WAVES_RW), rounds = (blocks + res0 - 1) / res0;
             deep_rounds = blocks > res0 && 100 * blocks >= 85 * rounds * res0;
         }
@@ -4570,7 +4575,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
         const bool long_one = pacing_on && h->pace_gbps < 0.0 && K >= 1200 && SYS == GEMX_SYS_SYNC && h->pf.lin_on != 0 && !need_full && h->cur_reward == nullptr &&
                               blocks <= (int64_t)h->n_cu;
         const int64_t deep_max = pacing_on && resident(PIPE_D, PIPE_OUT_WAVES) > 2 * (int64_t)h->n_cu ? 2 * (int64_t)h->n_cu : resident(PIPE_D, PIPE_OUT_WAVES);
-        if (pipe_deep_built<SOLVER, IL>() && smem_of(PIPE_D) <= h->lds_max && (blocks <= deep_max || deep_rounds)) {
+        if (pipe_deep_built<SYS, SOLVER, IL>() && smem_of(PIPE_D) <= h->lds_max && (blocks <= deep_max || deep_rounds)) {
             D = PIPE_D; OW = PIPE_OUT_WAVES; shape = 0;
             // (long launches of the synchronous machines' one-step-map rows: <12, 3>, which carries the rate limiter -- see `long_one` below)
             if (h->cur_reward != nullptr || (compact_l && !long_one)) { OW = PIPE_OUT_WAVES_RW; shape = 3; }

@@ -383,6 +383,7 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             # attribute and gets the default.  Ignored by the library for loads without a kink.)
             cfg.solver_flags = _lib.SOLVER_ADAPTIVE | (_lib.SOLVER_SPLIT_KINKS if getattr(self._ode_solver, "_split_kinks", True) else 0)
             cfg.solver_rtol, cfg.solver_atol = tol
+            cfg.solver_atol_omega = float(getattr(self._ode_solver, "_atol_omega", 0.0))  # (0: atol x the speed limit)
         cfg.dtype = _lib.F64 if self._dtype_name == "float64" else _lib.F32
         cfg.obs_layout = {"aos": _lib.OBS_AOS, "soa": _lib.OBS_SOA}[self._obs_layout]
         cfg.auto_reset = int(self._auto_reset)

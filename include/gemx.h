@@ -171,6 +171,13 @@ typedef struct gemx_config {
      * [0 .. A_conv - 1] (A_conv = 2 for control_space='dq'), or [0] = the flat index of a discrete action */
     double action_delay_reset[6];
     double solver_rtol, solver_atol; /* GEMX_SOLVER_ADAPTIVE: relative / absolute (state units) tolerance; 0 = 1e-6 / 1e-9 */
+    /* GEMX_SOLVER_ADAPTIVE, systems whose omega is a state (PolynomialStaticLoad): the absolute tolerance of OMEGA in rad/s (ABI 7).
+     * 0 = solver_atol x limits[omega], i.e. solver_atol in NORMALISED units -- 1e-9 of the speed range (4e-7 rad/s), not 1e-9 rad/s: a
+     * speed-control episode starts at omega = 0, where the relative term vanishes and an absolute tolerance of 1e-9 rad/s (2e-12 of the
+     * range, below anything an observation can show) makes lanes cut steps that no result depends on -- with 64 lock-stepped lanes some lane
+     * does so in most control steps (BASELINE config 4: 1.7 attempts per control step and wave instead of 1.0; against scipy's dopri5 runs
+     * 4e-6 either way: profiles/r06_wave_step_statistics.md).  solver_atol itself restores the behaviour of ABI <= 6. */
+    double solver_atol_omega;
     double tau;               /* control step, PhysicalSystem.tau */
     double interlocking_time; /* converter dead time, converters.py:35-41; must be < tau */
     double u_nominal;         /* IdealVoltageSupply.u_nominal, voltage_supplies.py:60-72 */

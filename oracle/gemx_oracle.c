@@ -574,6 +574,11 @@ static void integrate_kink(const orc_params *p, orc_env *e, int dp5, double t_en
  * g_dev_first_try > 0 replaces the first try of the next segment (the wave-shared proposal under test). */
 static __thread double g_dev_first_try = 0.0;
 static __thread int g_dev_attempts = 0;
+int g_dev_atol_omega_scaled = 0;
+void orc_dev_set_atol_omega_scaled(int on) { g_dev_atol_omega_scaled = on; }
+static __thread double g_dev_en2_first = 0.0; /* error norm squared of the first attempt of the last segment (diagnostic) */
+int orc_dev_attempts(void) { int a = g_dev_attempts; g_dev_attempts = 0; return a; }
+double orc_dev_en2_first(void) { return g_dev_en2_first; }
 static double dev_first_try(const orc_params *p, double hs, double hc) {
     if (hs < 0.5 * p->tau || !(hc > 0.0) || !(hc < 0.9 * hs)) return hs;
     return hs / fmin(ceil(0.9 * hs / hc), 1024.0);
@@ -610,10 +615,13 @@ static void dev_adaptive(const orc_params *p, orc_env *e, double t_end) {
         dp5_stages(p, e, n, e->y, hh, k1, k2, k3, k4, k5, k6, y1); /* k2 <- f(y1) (FSAL), k4 <- the error estimate */
         double e2 = 0.0;
         for (int i = 0; i < nz; ++i) {
-            const double r = k4[i] / (ATOL + RTOL * fmax(fabs(e->y[i]), fabs(y1[i])));
+            /* g_dev_atol_omega_scaled (experiment): omega's absolute tolerance in NORMALISED units, atol x limits[0] */
+            const double at = (i == 0 && g_dev_atol_omega_scaled) ? ATOL * p->limits[0] : ATOL;
+            const double r = k4[i] / (at + RTOL * fmax(fabs(e->y[i]), fabs(y1[i])));
             e2 += r * r;
         }
         const double en2 = e2 / nz;
+        if (guard == 0) g_dev_en2_first = en2;
         const int floor_hit = !(hh > hmin), accept = !(en2 > 1.0) || floor_hit;
         double fac = en2 > 1e-20 ? 0.9 * pow(en2, -0.1) : 10.0;
         fac = fmin(fmax(fac, 0.2), accept ? 10.0 : 1.0);

@@ -120,7 +120,8 @@ def test_every_fp32_instantiation_of_a_unit_is_launched_and_bit_identical(unit, 
                 env.close()
                 # -- the pipelined shapes (the dispatcher ignores a forced shape that is not built and takes <4, 2>)
                 monkeypatch.setenv("GEMX_DC_STREAM", "0")
-                built = {1: "D=4", 0: "D=12" if (solver == "rk4" and not il) else None, 3: "D=12" if (solver == "rk4" and not il) else None,
+                deep = solver == "rk4" and not il and sys_kind != 7  # (the DFIM's 24-value rows leave no LDS for twelve-step blocks)
+                built = {1: "D=4", 0: "D=12" if deep else None, 3: "D=12" if deep else None,
                          2: "D=2" if (solver != "euler" and not il) else None}
                 for shape, want in built.items():
                     if want is None:

@@ -242,7 +242,8 @@ def _check_done(meta, d, got_done, ref_states_full=None):
     assert margin[first] < 1e-5, f"done mask differs at step {first} with margin {margin[first]:.3e}"
 
 
-FLUX_FLOOR = 0.05  # field-oriented columns: the 1e-4 contract holds as it stands while |psi_r| >= 5 % of its range over the run
+from parity_contract import FLUX_FLOOR, SIGN_MARGIN  # noqa: E402  (0.05: the 1e-4 contract holds as it stands while |psi_r| >= 5 % of its range over the run;
+#                                                               2e-5: see below.  One place for both: tests/parity_contract.py, pinned against DESIGN.md section 2)
 
 
 def compare_trajectory(meta, d, obs, done, min_fraction=0.0, psi=None, stop=None, per_step=False):
@@ -308,7 +309,7 @@ def compare_trajectory(meta, d, obs, done, min_fraction=0.0, psi=None, stop=None
     return float(per_col[j]), float(diff.max()), names[j], dmsg
 
 
-SIGN_MARGIN = 2e-5  # dead-time lanes: a current-sign decision is "within rounding of zero" below this fraction of the current limit
+# SIGN_MARGIN (tests/parity_contract.py: 2e-5): dead-time lanes -- a current-sign decision is "within rounding of zero" below this fraction of the current limit
 
 
 def _lanes_against_oracle(name, meta, a_np, obs, done, lanes, sol_obj, dtype, acts_ndim):
