@@ -198,3 +198,37 @@ def test_every_fp64_instantiation_of_a_unit_is_launched_and_bit_identical(unit):
             env.close()
             assert "advance_kernel" in a[3] and "f64" in a[3] and "step_kernel" in b[3], (a[3], b[3])
             _same(torch, a, b, f"{unit} fp64 load={load} solver={solver}")
+
+
+def test_the_fp64_forms_of_the_small_kernels():
+    """libgemx.so's own kernels in their fp64 instantiations (the diagnostic build's state access, synthetic action stream and Wiener
+    reference generators): get_state / set_state round trip, the synthetic stream equal to the fp32 one value for value (the stream is
+    exact in both types), chunked reference generation equal to one-shot generation."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    env = ga.make("Cont-CC-PMSM-v0", n_envs=N, tau=1e-4, dtype="float64")
+    ps = env.physical_system
+    acts = _actions(torch, ps)
+    env.rollout(acts)
+    y = ps.get_state().clone()
+    twin = ga.make("Cont-CC-PMSM-v0", n_envs=N, tau=1e-4, dtype="float64")
+    twin.physical_system.set_state(y)
+    assert torch.equal(twin.physical_system.get_state(), y)
+    a = env.rollout(acts[:7])
+    b = twin.rollout(acts[:7])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    s64 = ps.synthetic_actions(K, seed=4, step0=9)
+    e32 = ga.make("Cont-CC-PMSM-v0", n_envs=N, tau=1e-4)
+    s32 = e32.physical_system.synthetic_actions(K, seed=4, step0=9)
+    assert s64.dtype == torch.float64 and torch.equal(s64, s32.double())
+    g1 = ga.BatchedWienerProcessReferenceGenerator(reference_states=("i_sd", "i_sq"), seed=2).set_modules(ps)
+    g2 = ga.BatchedWienerProcessReferenceGenerator(reference_states=("i_sd", "i_sq"), seed=2).set_modules(ps)
+    g1.reset()
+    g2.reset()
+    whole = g1.rollout(60)
+    parts = torch.cat([g2.rollout(1), g2.rollout(25), g2.rollout(34)])
+    assert whole.dtype == torch.float64 and torch.equal(whole, parts)
+    for e in (env, twin, e32):
+        e.close()

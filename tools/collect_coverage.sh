@@ -9,7 +9,7 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 rm -f $OUT/${TAG}_cov_*.txt
 cd $R
-GEMX_COVERAGE_FILE=$OUT/${TAG}_cov_tests.txt timeout 2400 python -m pytest tests -m gpu -q -x -n 4 > $OUT/${TAG}_gpu_tests_full.txt 2>&1
+GEMX_COVERAGE_FILE=$OUT/${TAG}_cov_tests.txt timeout 2400 python -m pytest tests -m gpu -q -n 4 > $OUT/${TAG}_gpu_tests_full.txt 2>&1
 tail -15 $OUT/${TAG}_gpu_tests_full.txt > $OUT/${TAG}_gpu_tests.txt
 GEMX_COVERAGE_FILE=$OUT/${TAG}_cov_bench.txt timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench.log 2>&1
 tail -1 $OUT/${TAG}_bench.log > $OUT/${TAG}_bench_line.json
