@@ -220,7 +220,8 @@ template <class R> __device__ __forceinline__ void t32(R al, R be, R &a, R &b, R
 
 
 // ------------------------------------------------------------------------------------------------
-// random initial states: Philox4x32-10 (Salmon et al., SC'11), counter = (env lo, env hi, reset count, block), key = seed.
+// Philox4x32-10 (Salmon et al., SC'11), counter = (env lo, env hi, reset count, block), key = seed: the reference generators' streams
+// (gemx_refgen.hip); the random INITIAL STATES used it until round 5 and take InitRng below since.
 // Counter-based, so a reset needs no RNG state beyond the env's reset count.  env = the GLOBAL env index (gemx_config.env_base + i).
 // ------------------------------------------------------------------------------------------------
 struct Philox {
@@ -241,6 +242,37 @@ struct Philox {
     }
     // uniform in the open interval (0, 1), 32 bits of resolution
     static __host__ __device__ __forceinline__ double u01(uint32_t x) { return ((double)x + 0.5) * (1.0 / 4294967296.0); }
+};
+// INITIAL-STATE streams since round 6: Threefry-4x32 with 12 rounds (the add-rotate-xor generator of the same paper; counter = (env lo, env hi,
+// reset count, block), key = (seed lo, seed hi, 0, 0)).  Philox's rounds are two 32 x 32 -> 64-bit multiplies each, quarter-rate instructions
+// on gfx950 (~900 cycles per block of four values for a wave); Threefry's are adds, rotates and xors at full rate (~340).  That matters twice:
+// the pipelined kernel's LOADER wave prepares every lane's next draws while the integrators of the other workgroups on its SIMD compete for
+// the same issue slots (Cont-SC-PMSM with random initial states at 131072 envs was bound by the loader's 6000 cycles per block), and a lane
+// that outruns its queue draws INLINE on the integrator's own stream (SCIM: 7.7 % of the resets, 7000 of the integrator's 10000 cycles per
+// block: profiles/r06_rinit_probe.md).  The reference generators (gemx_refgen.hip) keep Philox.
+struct InitRng {
+    static __host__ __device__ __forceinline__ uint32_t rotl(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+    static __host__ __device__ __forceinline__ void block(uint64_t seed, uint64_t env, uint32_t count, uint32_t blk, uint32_t (&out)[4]) {
+        const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), k2 = 0u, k3 = 0u;
+        const uint32_t ks[5] = {k0, k1, k2, k3, 0x1BD11BDAu ^ k0 ^ k1 ^ k2 ^ k3};
+        uint32_t x0 = (uint32_t)env + ks[0], x1 = (uint32_t)(env >> 32) + ks[1], x2 = count + ks[2], x3 = blk + ks[3];
+        constexpr int R0[8] = {10, 11, 13, 23, 6, 17, 25, 18}, R1[8] = {26, 21, 27, 5, 20, 11, 10, 20};
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            if ((r & 1) == 0) {
+                x0 += x1; x1 = rotl(x1, R0[r & 7]); x1 ^= x0;
+                x2 += x3; x3 = rotl(x3, R1[r & 7]); x3 ^= x2;
+            } else {
+                x0 += x3; x3 = rotl(x3, R0[r & 7]); x3 ^= x0;
+                x2 += x1; x1 = rotl(x1, R1[r & 7]); x1 ^= x2;
+            }
+            if ((r & 3) == 3) {  // key injection after every fourth round
+                const int s_ = (r + 1) >> 2;
+                x0 += ks[s_ % 5]; x1 += ks[(s_ + 1) % 5]; x2 += ks[(s_ + 2) % 5]; x3 += ks[(s_ + 3) % 5] + (uint32_t)s_;
+            }
+        }
+        out[0] = x0; out[1] = x1; out[2] = x2; out[3] = x3;
+    }
 };
 // per-state sampling description (device array read in the rare reset path only)
 struct InitDev {
@@ -289,7 +321,7 @@ __host__ __device__ inline double inv_norm_cdf(double p) {
 // the j-th initial state from its uniform u in (0, 1): uniform in [lo, hi], or normal(mu, sigma) truncated to [lo, hi] by inverse CDF
 __device__ __forceinline__ double init_state_from_uniform(const InitDev *I, int j, double u) {
     if (!(I->lo[j] < I->hi[j])) return I->constant[j];
-    if (I->kind == GEMX_INIT_UNIFORM) return I->lo[j] + (I->hi[j] - I->lo[j]) * u;
+    if (I->kind == GEMX_INIT_UNIFORM) return fma(I->hi[j] - I->lo[j], u, I->lo[j]);  // (one rounding, spelled out: the same bits from every call site)
     const double x = I->mu[j] + I->sigma[j] * inv_norm_cdf(I->cdf_lo[j] + (I->cdf_hi[j] - I->cdf_lo[j]) * u);
     return fmin(fmax(x, I->lo[j]), I->hi[j]);
 }
@@ -303,14 +335,14 @@ __device__ __forceinline__ void init_uniforms_from(const uint32_t (&r0)[4], cons
 __device__ __forceinline__ void init_uniforms(const InitDev *I, int64_t env, uint32_t count, double (&u)[GEMX_MAX_ODE], bool block1 = true) {
     uint32_t r0[4], r1[4] = {0u, 0u, 0u, 0u};
     const uint64_t genv = (uint64_t)(I->env_base + env);  // global env index
-    Philox::block(I->seed, genv, count, 0u, r0);
-    if (block1 && init_needs_block1(I)) Philox::block(I->seed, genv, count, 1u, r1);
+    InitRng::block(I->seed, genv, count, 0u, r0);
+    if (block1 && init_needs_block1(I)) InitRng::block(I->seed, genv, count, 1u, r1);
     init_uniforms_from(r0, r1, u);
 }
 // one state from its uniform with explicit bounds (the induction machines' per-reset flux bounds)
 __device__ __forceinline__ double init_draw_bounded(const InitDev *I, int j, double lo, double hi, double u) {
     if (!(lo < hi)) return lo;  // (upper - lower) * u + lower of a degenerate interval
-    if (I->kind == GEMX_INIT_UNIFORM) return lo + (hi - lo) * u;
+    if (I->kind == GEMX_INIT_UNIFORM) return fma(hi - lo, u, lo);
     // electric_motor.py:236-249: mue = random_params[0] or the middle of the interval, sigma = random_params[1] or 1 (mu[j] = NaN: middle)
     const double mu = I->mu[j] == I->mu[j] ? I->mu[j] : 0.5 * (hi - lo) + lo, sg = I->sigma[j];
     const double cl = 0.5 * erfc(-(lo - mu) / sg * 0.70710678118654752440), ch = 0.5 * erfc(-(hi - mu) / sg * 0.70710678118654752440);
@@ -325,13 +357,24 @@ __device__ __forceinline__ double init_draw_bounded(const InitDev *I, int j, dou
 // `init_draw_from`: the draw from its uniforms -- `u` of (env, count) and, where the induction machines read the previous reset's currents
 // (count > 1, omega != 0), `up` of (env, count - 1), fetched through `prev` only then.  The pipelined kernel's loader wave computes the
 // Philox blocks one per pass and finishes with this (prepared draws); init_draw_all is the draw in one go.
-template <bool FLUX, class Prev>
+// NS: the number of ODE states incl. the angle where the caller knows it at compile time (the kernels of one system: the loop unrolls, and a
+// descriptor the caller copied into registers -- the pipelined kernel's loader wave -- is never indexed dynamically); 0: I->n.
+template <bool FLUX, int NS = 0, class Prev>
 __device__ __forceinline__ void init_draw_from(const InitDev *I, uint32_t count, const double (&u)[GEMX_MAX_ODE], Prev prev, double (&out)[GEMX_MAX_ODE]) {
-    for (int j = 0; j < I->n && j < GEMX_MAX_ODE; ++j) out[j] = init_state_from_uniform(I, j, u[j]);
+    if constexpr (NS > 0) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) out[j] = init_state_from_uniform(I, j, u[j]);
+    } else {
+        for (int j = 0; j < I->n && j < GEMX_MAX_ODE; ++j) out[j] = init_state_from_uniform(I, j, u[j]);
+    }
     if (FLUX && I->flux_mode) {
-        const int fs = I->flux_slot;  // slots fs - 2, fs - 1: i_s alpha, i_s beta
-        const double eps = 6.283185307179586476925286766559 * u[7] - 3.141592653589793238462643383279;
-        const double ce = cos(eps), se = sin(eps), om = out[0];
+        constexpr int FS_STATIC = 3;  // (gemx_create: [omega, i_s alpha, i_s beta, psi_r alpha, psi_r beta, epsilon] for both induction machines)
+        const int fs = NS > 0 ? FS_STATIC : I->flux_slot;  // slots fs - 2, fs - 1: i_s alpha, i_s beta
+        // eps_mag = 2 pi u7 - pi ~ U(-pi, pi): cos / sin through the fp32 hardware functions, which take their argument in TURNS
+        // (cos(2 pi u - pi) = -cos(2 pi u)); 1e-6 absolute is all a random field angle needs (round 5: the fp64 library sincos, a few
+        // hundred instructions on the integrator's stream whenever a lane drew inline).  The draw is distributional by contract (KS tests).
+        const float u7 = (float)u[7];
+        const double ce = -(double)__builtin_amdgcn_cosf(u7), se = -(double)__builtin_amdgcn_sinf(u7), om = out[0];
         double psi = I->flux[0];
         if (om != 0.0) {
             double ia = I->constant[fs - 2], ib = I->constant[fs - 1];
@@ -350,12 +393,12 @@ __device__ __forceinline__ void init_draw_from(const InitDev *I, uint32_t count,
         out[fs + 1] = init_draw_bounded(I, fs + 1, fmax(-hb, I->lo[fs + 1]), fmin(hb, I->hi[fs + 1]), u[fs + 1]);
     }
 }
-template <bool FLUX>
+template <bool FLUX, int NS = 0>
 __device__ __forceinline__ void init_draw_all(const InitDev *I, int64_t env, uint32_t count, double (&out)[GEMX_MAX_ODE]) {
     double u[GEMX_MAX_ODE];
     init_uniforms(I, env, count, u);
     // (of the previous draw only the stator currents' uniforms are read, slots flux_slot - 2 and - 1: block 1 only if they reach into it)
-    init_draw_from<FLUX>(I, count, u, [&](double (&up)[GEMX_MAX_ODE]) { init_uniforms(I, env, count - 1u, up, I->flux_slot > 4); }, out);
+    init_draw_from<FLUX, NS>(I, count, u, [&](double (&up)[GEMX_MAX_ODE]) { init_uniforms(I, env, count - 1u, up, I->flux_slot > 4); }, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -457,6 +500,7 @@ template <class R> struct KArgs {
     // act_step0 + k, component) instead
     uint64_t act_seed;
     int64_t act_env_base;  // gemx_config.env_base: the stream is keyed by the global env index
+    int32_t prep_phases;   // random initial states: phases of the loader's prepared-draw state machine per hand-off block (launch_advance_t)
     uint32_t act_step0;
     int32_t act_synth;
 };

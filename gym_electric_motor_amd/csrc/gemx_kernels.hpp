@@ -1714,23 +1714,43 @@ __device__ __forceinline__ void draw_initial_state(const KArgs<R> &a, int64_t en
     const uint32_t count = a.rcnt[env] + 1u;
     a.rcnt[env] = count;
     double v[GEMX_MAX_ODE];
-    init_draw_all<SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM>(a.rinit, env, count, v);
+    init_draw_all<SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM, SysTraits<SYS>::ND + (SysTraits<SYS>::HAS_ANGLE ? 1 : 0)>(a.rinit, env, count, v);
 #pragma unroll
     for (int j = 0; j < ND; ++j) y[j] = (R)v[j];
     if (SysTraits<SYS>::HAS_ANGLE) ang = Angle<R>::from_rad(v[ND]);
 }
 
-// the same draw with the env's reset counter held in a register (pipelined kernel: no global memory traffic besides the description)
+// the same draw with the env's reset counter held in a register (pipelined kernel: no global memory traffic besides the description).
+// A REAL CALL since round 6 (the pipelined kernel's integrator only; the single-wave kernels keep the inline form, see above): inlined into
+// every unrolled copy of the step, the draw -- generator blocks, the induction machines' flux bounds, the truncated normal's erfc and inverse
+// CDF in fp64 -- was 13 600 of the SCIM kernel's 38 000 instructions, and a lane that outran its queue of prepared draws (2-7 % of the SCIM's
+// resets) sent its wave through ~1500 instructions that are never in the instruction cache: ~12 000 cycles per event, 7000 of the
+// integrator's 10 000 cycles per block (profiles/r06_rinit_probe.md).  One copy per kernel, the result in registers.
+template <int SYS, class R> struct DrawnState {
+    R y[SysTraits<SYS>::ND];
+    typename Angle<R>::T ang;
+};
+template <int SYS, class R>
+__device__ __attribute__((noinline)) DrawnState<SYS, R> draw_initial_state_call(const InitDev *rinit, int64_t env, uint32_t count) {
+    constexpr int ND = SysTraits<SYS>::ND;
+    DrawnState<SYS, R> o;
+    double v[GEMX_MAX_ODE];
+    init_draw_all<SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM, SysTraits<SYS>::ND + (SysTraits<SYS>::HAS_ANGLE ? 1 : 0)>(rinit, env, count, v);
+#pragma unroll
+    for (int j = 0; j < ND; ++j) o.y[j] = (R)v[j];
+    o.ang = typename Angle<R>::T(0);
+    if (SysTraits<SYS>::HAS_ANGLE) o.ang = Angle<R>::from_rad(v[ND]);
+    return o;
+}
 template <int SYS, class R>
 __device__ __forceinline__ void draw_initial_state_cnt(const InitDev *rinit, int64_t env, uint32_t &count, R (&y)[SysTraits<SYS>::ND],
                                                        typename Angle<R>::T &ang) {
     constexpr int ND = SysTraits<SYS>::ND;
     count += 1u;
-    double v[GEMX_MAX_ODE];
-    init_draw_all<SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM>(rinit, env, count, v);
+    const DrawnState<SYS, R> o = draw_initial_state_call<SYS, R>(rinit, env, count);
 #pragma unroll
-    for (int j = 0; j < ND; ++j) y[j] = (R)v[j];
-    if (SysTraits<SYS>::HAS_ANGLE) ang = Angle<R>::from_rad(v[ND]);
+    for (int j = 0; j < ND; ++j) y[j] = o.y[j];
+    if (SysTraits<SYS>::HAS_ANGLE) ang = o.ang;
 }
 
 // step() for the single-wave kernel
@@ -2596,7 +2616,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs<R> a) {
 #ifndef GEMX_PACE_DEFAULT_ON
 #define GEMX_PACE_DEFAULT_ON 1
 #endif
-constexpr int PREP_Q = 4;  // prepared draws per lane (FULL pipelined kernel, random initialisers)
+// prepared draws per lane (FULL pipelined kernel, random initialisers): four; eight for the induction machines, whose episodes under random
+// initial states are short (a third of them a few steps) and whose draw takes the loader three to four passes -- with four entries 7.7 % of
+// the SCIM's resets found the queue empty and drew inline (round 5 A/B: +10 % for the SCIM, -5 to -15 % for the PMSM, hence per system)
+template <int SYS> constexpr int prep_q() { return (SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM) ? 8 : 4; }
 #ifndef GEMX_PREP_DRAWS
 #define GEMX_PREP_DRAWS 1  // (0: A/B builds -- every reset draws inline)
 #endif
@@ -2605,6 +2628,13 @@ constexpr int PREP_Q = 4;  // prepared draws per lane (FULL pipelined kernel, ra
 // as the cold side of its branch so that the spills land THERE (PMSM at 131072 envs 59 -> 68 G, level elsewhere; without the hint 57 ->
 // 50, and 39 at four waves; the induction machines lose 20-35 % at three or four).  profiles/r05t_ab_rinit_waves.txt, r05u_ab_rinit_expect.txt
 #define GEMX_EXPECT_PREPARED(x) __builtin_expect((x), 1)
+// Phases of the loader's prepared-draw state machine (scan + generator block | generator block | ... | finish) per hand-off block
+// (KArgs::prep_phases).  Round 5: one -- a pass cost 1450-6600 cycles (Philox, and every field of the description re-read from global memory)
+// and more per pass made the loader the slowest wave of a block.  Round 6 (Threefry, the description in registers: 560 / 870-2500 cycles):
+// TWO where a workgroup has its CU to itself (the induction machines, whose draw takes three phases and whose lanes drain their queues
+// fastest: resets that find the queue empty 7.4 % -> 2.4 %, SCIM cont at 16384 envs 420 -> 370 us per 500 steps), ONE where four
+// workgroups share a CU and the loaders' arithmetic competes with the integrators' (131072 envs: SCIM 2120 against 2285 us, PMSM speed
+// control 1445 against 1670).  GEMX_PREP_PHASES overrides (A/B builds).  profiles/r06_rinit_probe.md.
 #ifndef GEMX_RINIT_WAVES
 #define GEMX_RINIT_WAVES 0  // (A/B builds: one figure for every system)
 #endif
@@ -2695,6 +2725,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
     typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
     typedef volatile __attribute__((address_space(3))) uint32_t lds_u32_t;
     typedef volatile __attribute__((address_space(3))) u4_t lds_u4_t;
+    constexpr int PREP_Q = prep_q<SYS>();
     lds_u32_t *prep = (lds_u32_t *)reinterpret_cast<uint32_t *>(vtab + ((ST::NVT > 0 && DISCRETE) ? ConvTraits<CONV>::NACTIONS * 8 : 0));
     lds_u32_t *prep_cnt = prep + (size_t)PREP_Q * BLOCK * 8;
     static_assert(ND + 1 <= 7, "a prepared draw is eight dwords: states, angle, tag");
@@ -3047,8 +3078,16 @@ void advance_pipe_kernel(const KArgs<R> a) {
             ang = rs ? init_ang_v : ang;
             if constexpr (SOLVER == GEMX_SOLVER_DP5) hcar = rs ? R(0) : hcar;
             if constexpr (FULL) {
+#if defined(GEMX_AB_NO_RINIT_BLOCK)  // timing-only A/B build: a reset restores the constant state (results are WRONG)
+                if constexpr (false) if (rs) {
+#else
                 if constexpr (RINIT) if (rs) {  // (exec-masked, skipped wave-wide)
+#endif
+#if defined(GEMX_AB_NO_INLINE)  // timing-only A/B build: every reset takes whatever the registers hold (results are WRONG where the queue was empty)
+                    if (true) {
+#else
                     if (GEMX_PREP_DRAWS != 0 && GEMX_EXPECT_PREPARED(pre_hi.w == rcount + 1u)) {  // the loader wave's prepared draw of this count, in registers since the block's start
+#endif
                         const uint32_t w8[8] = {pre_lo.x, pre_lo.y, pre_lo.z, pre_lo.w, pre_hi.x, pre_hi.y, pre_hi.z, pre_hi.w};
 #pragma unroll
                         for (int j = 0; j < ND; ++j) memcpy(&y[j], &w8[j], sizeof(R));
@@ -3397,7 +3436,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
         // It also validates discrete actions (converters.py:204-206: an index outside the action space is an error): block b's rows
         // are in LDS -- block 0 behind the initial barrier, the others staged and awaited here one iteration earlier.
 #ifdef GEMX_TIMING
-        unsigned long long tl = 0, tb = 0;
+        unsigned long long tl = 0, tb = 0, tph[6] = {0, 0, 0, 0, 0, 0}, nph[6] = {0, 0, 0, 0, 0, 0};
 #endif
         uint32_t bad = 0;
         // prepared draws (FULL, random initialisers): the Philox blocks of the draw in progress, its count, the lanes it is for
@@ -3405,6 +3444,13 @@ void advance_pipe_kernel(const KArgs<R> a) {
         uint32_t lq0[4] = {0u, 0u, 0u, 0u}, prep_lastw = 0u;  // Philox block 0 of the draw this lane got last, and its count
         bool prep_act = false;
         int prep_phase = 0;  // wave-uniform
+        // The initialiser's description, copied ONCE into this wave's registers (round 6).  Read through the pointer, every field was loaded
+        // from global memory again in every pass -- the compiler may not keep a global load across the block's barrier and the volatile
+        // LDS traffic -- and a pass that computes one generator block (~340 cycles of arithmetic) took 1450, the finishing pass 3000-6600
+        // (dependent scalar loads of lo / hi / constant per state, then fp64 arithmetic; profiles/r06_rinit_probe.md): with four
+        // workgroups per CU the loader, not the integrator, set the block time of PMSM speed control with random initial states.
+        InitDev prep_desc;
+        if constexpr (FULL && RINIT && GEMX_PREP_DRAWS != 0) prep_desc = *a.rinit;
         if (DISCRETE) __syncthreads();
         // (Staging TWO blocks ahead through a third buffer was tried in round 2 -- the s_memtime probe shows this wave's loads taking longer
         // than the integrator's block in the shallow shapes -- and changed nothing, same box, over all motor families:
@@ -3424,13 +3470,18 @@ void advance_pipe_kernel(const KArgs<R> a) {
                 if (n_ref > 0) stage_refs(b + AHEAD);
             }
             if constexpr (FULL && RINIT && GEMX_PREP_DRAWS != 0) {
-                {
+#pragma unroll 1
+                for (int prep_rep = 0; prep_rep < a.prep_phases; ++prep_rep) {  // (phases of the state machine below per pass: see launch_advance_t)
+#ifdef GEMX_TIMING
+                    const unsigned long long pt0 = clock64();
+                    const int pt_phase = prep_phase;
+#endif
                     // prepared draws (see `prep`): the next initial state of every lane whose entry was consumed -- ONE Philox block per pass
                     // (~900 cycles: forty quarter-rate multiplies), so that this wave still reaches the block's barrier before the
                     // integrator does; the whole draw in one pass (~2000-3500 cycles) made it the slowest wave of a block wherever the
                     // integrator runs on its one-step map (PMSM, 32768 envs: 41 G env-steps/s against 89 G without random initial states).
                     constexpr bool FLUX = SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM;
-                    const InitDev *I = a.rinit;
+                    const InitDev *I = &prep_desc;  // (the copy made before the block loop: see there)
                     const bool blk1 = init_needs_block1(I), fprev = FLUX && I->flux_mode != 0;
                     if (prep_phase == 0) {  // scan: the first of the next PREP_Q counts whose slot does not hold it; lanes with a full queue sit out
                         const uint32_t c = prep_cnt[tid];
@@ -3456,22 +3507,22 @@ void advance_pipe_kernel(const KArgs<R> a) {
                     };
                     const uint64_t prep_genv = (uint64_t)(I->env_base + envc);  // the streams' env word is the GLOBAL index
                     if (prep_phase == 1) {
-                        Philox::block(I->seed, prep_genv, prep_c + 1u, 0u, pq0);
+                        InitRng::block(I->seed, prep_genv, prep_c + 1u, 0u, pq0);
                         prep_phase = blk1 ? 2 : after_own_blocks();
                     } else if (prep_phase == 2) {
-                        Philox::block(I->seed, prep_genv, prep_c + 1u, 1u, pq1);
+                        InitRng::block(I->seed, prep_genv, prep_c + 1u, 1u, pq1);
                         prep_phase = after_own_blocks();
                     } else if (prep_phase == 3) {
-                        Philox::block(I->seed, prep_genv, prep_c, 0u, pp0);
+                        InitRng::block(I->seed, prep_genv, prep_c, 0u, pp0);
                         prep_phase = I->flux_slot > 4 ? 4 : 5;  // (the currents' uniforms, slots flux_slot - 2 and - 1, sit in block 0 for every machine built)
                     } else if (prep_phase == 4) {
-                        Philox::block(I->seed, prep_genv, prep_c, 1u, pp1);
+                        InitRng::block(I->seed, prep_genv, prep_c, 1u, pp1);
                         prep_phase = 5;
                     } else if (prep_phase == 5) {
                         if (prep_act) {
                             double u[GEMX_MAX_ODE], v[GEMX_MAX_ODE];
                             init_uniforms_from(pq0, pq1, u);
-                            init_draw_from<FLUX>(I, prep_c + 1u, u, [&](double (&up)[GEMX_MAX_ODE]) { init_uniforms_from(pp0, pp1, up); }, v);
+                            init_draw_from<FLUX, ND + (HAS_ANGLE ? 1 : 0)>(I, prep_c + 1u, u, [&](double (&up)[GEMX_MAX_ODE]) { init_uniforms_from(pp0, pp1, up); }, v);
                             uint32_t w8[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
                             for (int j = 0; j < ND; ++j) { const R x = (R)v[j]; memcpy(&w8[j], &x, sizeof(R)); }
@@ -3486,6 +3537,9 @@ void advance_pipe_kernel(const KArgs<R> a) {
                         }
                         prep_phase = 0;
                     }
+#ifdef GEMX_TIMING
+                    tph[pt_phase] += clock64() - pt0; nph[pt_phase] += 1ull;
+#endif
                 }
             }
             if (DISCRETE) {
@@ -3519,6 +3573,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
         if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 37)) {
             unsigned long long *dbg = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.err) + 64) + (blockIdx.x ? 16 : 0);
             dbg[12] = tl; dbg[13] = tb;
+            if (blockIdx.x == 0) for (int i = 0; i < 6; ++i) { dbg[484 + i] = tph[i]; dbg[490 + i] = nph[i]; }  // loader: cycles / passes per prepared-draw phase
         }
 #endif
     } else {
@@ -4358,6 +4413,11 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     a.act_synth = h->cur_synth ? 1 : 0;
     a.act_seed = h->cur_seed;
     a.act_env_base = h->cfg.env_base;
+#ifdef GEMX_PREP_PHASES
+    a.prep_phases = GEMX_PREP_PHASES;
+#else
+    a.prep_phases = ((SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM) && (h->n + BLOCK - 1) / BLOCK <= (int64_t)h->n_cu) ? 2 : 1;
+#endif
     a.act_step0 = h->cur_step0;
     a.obs = (R *)obs;
     a.done = done;
@@ -4486,7 +4546,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             b += pipe_act_bufs(D) * (size_t)((D + 3) / 4 * 4) * BLOCK * ABYTES;  // action staging (global -> LDS direct, one or two blocks ahead)
             if (h->cur_reward != nullptr) b += pipe_ref_bufs(D) * (size_t)D * BLOCK * h->rw_n_ref * sizeof(R);  // reference staging for the fused reward
             if (ST::NVT > 0 && ConvTraits<CONV>::DISCRETE) b += (size_t)ConvTraits<CONV>::NACTIONS * 8 * sizeof(R);  // per-action voltage table
-            if (h->cfg.init_kind != GEMX_INIT_CONST) b += (size_t)(PREP_Q * 8 + 1) * BLOCK * sizeof(uint32_t);       // prepared draws (random initialisers)
+            if (h->cfg.init_kind != GEMX_INIT_CONST) b += (size_t)(prep_q<SYS>() * 8 + 1) * BLOCK * sizeof(uint32_t);       // prepared draws (random initialisers)
             return (b + 15) & ~(size_t)15;
         };
         // workgroups of a shape one CU holds: LDS, wave slots -- and REGISTERS (round 4: the arithmetic used to stop at the first two and
@@ -4812,11 +4872,18 @@ int launch_advance_unit(gemx_handle *h, const void *actions, int K, void *obs, u
     // (gemx_create refuses interlocking_time > 0 for the EESM -- the reference's dead-time branch for that system cannot execute,
     // physical_systems.py:634 -- so its fp32 units carry no dead-time code)
     constexpr bool IL_BUILT = sizeof(R) == 8 || SYS != GEMX_SYS_EESM;
+#ifdef GEMX_DEV_ONLY  // tools/dev_build.py --only LOAD,SOLVER,IL: ONE combination of the unit (a variant build for probes: seconds, not minutes)
+#define GEMX_CASE(LD, SV)                                                                                                  \
+    if constexpr (LD == GEMX_DEV_LOAD && SV == GEMX_DEV_SOLVER)                                                             \
+        if (ld == LD && sv == SV && il == (GEMX_DEV_IL != 0))                                                              \
+            return launch_advance_t<SYS, CONV, LD, SV, GEMX_DEV_IL != 0, R>(h, actions, K, obs, done, obs_every, st);
+#else
 #define GEMX_CASE(LD, SV)                                                                                                  \
     if (ld == LD && sv == SV) {                                                                                            \
         if constexpr (IL_BUILT) if (il) return launch_advance_t<SYS, CONV, LD, SV, true, R>(h, actions, K, obs, done, obs_every, st); \
         if constexpr (sizeof(R) == 4) return launch_advance_t<SYS, CONV, LD, SV, false, R>(h, actions, K, obs, done, obs_every, st); \
     }
+#endif
     GEMX_CASE(GEMX_LOAD_CONST_SPEED, GEMX_SOLVER_EULER)
     GEMX_CASE(GEMX_LOAD_CONST_SPEED, GEMX_SOLVER_RK4)
     GEMX_CASE(GEMX_LOAD_CONST_SPEED, GEMX_SOLVER_DP5)

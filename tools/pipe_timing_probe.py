@@ -60,6 +60,10 @@ for base in (0, 16):
     print(f"   integrator: {nlong} of {nb} barrier waits > 1000 cycles; out wave 0: longest block {v >> 40} cycles, {v & 0xFFFFF} blocks > 2000, {(v >> 20) & 0xFFFFF} > 3000")
     print(f"   loader: stage+wait={buf[base+12]/nb:.0f} barrier={buf[base+13]/nb:.0f}")
 
+if os.environ.get("PROBE_RINIT"):  # loader: cycles per prepared-draw phase (scan | block 0 | block 1 | previous block 0 | previous block 1 | finish)
+    ph = (C.c_ulonglong * 504)()
+    L.gemx_debug_read(ps._handle, ph, 504)
+    print("   loader prepared-draw phases (cycles per execution x executions): " + "  ".join(f"{i}: {ph[484 + i] / max(1, ph[490 + i]):.0f} x {ph[490 + i]}" for i in range(6)))
 if b"dc_stream" in L.gemx_last_launch(ps._handle):  # every wave of workgroup 0 (dc_stream_kernel, -DGEMX_TIMING): work / barrier cycles per block
     allw = (C.c_ulonglong * 96)()
     L.gemx_debug_read(ps._handle, allw, 96)
