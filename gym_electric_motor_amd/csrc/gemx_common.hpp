@@ -253,6 +253,10 @@ struct Philox {
 struct InitRng {
     static __host__ __device__ __forceinline__ uint32_t rotl(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
     static __host__ __device__ __forceinline__ void block(uint64_t seed, uint64_t env, uint32_t count, uint32_t blk, uint32_t (&out)[4]) {
+#ifdef GEMX_INIT_RNG_PHILOX  // A/B builds: round 5's generator
+        Philox::block(seed, env, count, blk, out);
+        return;
+#endif
         const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), k2 = 0u, k3 = 0u;
         const uint32_t ks[5] = {k0, k1, k2, k3, 0x1BD11BDAu ^ k0 ^ k1 ^ k2 ^ k3};
         uint32_t x0 = (uint32_t)env + ks[0], x1 = (uint32_t)(env >> 32) + ks[1], x2 = count + ks[2], x3 = blk + ks[3];

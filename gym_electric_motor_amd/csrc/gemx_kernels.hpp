@@ -1704,6 +1704,9 @@ __device__ __forceinline__ R supply_current(const DevParams<R> &P, const R (&y)[
     return tot;
 }
 
+#ifndef GEMX_DRAW_NS  // 0: the number of states read from the description at run time, as rounds 4-5 did (A/B builds)
+#define GEMX_DRAW_NS 1
+#endif
 // in-kernel auto-reset with random initialisers: a fresh initial state for this env, its reset counter advanced (rare path).
 // (Round 4 tried this as a real call, `noinline`: advance_kernel's spills went from 41-55 to 2-27 registers -- not to zero, the 256-VGPR
 // cap is the blocked I/O's prefetch and flush registers, not this path -- while step_kernel, which calls it too, went from no scratch
@@ -1714,7 +1717,7 @@ __device__ __forceinline__ void draw_initial_state(const KArgs<R> &a, int64_t en
     const uint32_t count = a.rcnt[env] + 1u;
     a.rcnt[env] = count;
     double v[GEMX_MAX_ODE];
-    init_draw_all<SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM, SysTraits<SYS>::ND + (SysTraits<SYS>::HAS_ANGLE ? 1 : 0)>(a.rinit, env, count, v);
+    init_draw_all<SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM, GEMX_DRAW_NS * (SysTraits<SYS>::ND + (SysTraits<SYS>::HAS_ANGLE ? 1 : 0))>(a.rinit, env, count, v);
 #pragma unroll
     for (int j = 0; j < ND; ++j) y[j] = (R)v[j];
     if (SysTraits<SYS>::HAS_ANGLE) ang = Angle<R>::from_rad(v[ND]);
@@ -1730,12 +1733,20 @@ template <int SYS, class R> struct DrawnState {
     R y[SysTraits<SYS>::ND];
     typename Angle<R>::T ang;
 };
+#ifndef GEMX_DRAW_CALL  // 0: the inline form of rounds 4-5 (A/B builds)
+#define GEMX_DRAW_CALL 1
+#endif
+#if GEMX_DRAW_CALL
+#define GEMX_DRAW_CALL_ATTR __attribute__((noinline))
+#else
+#define GEMX_DRAW_CALL_ATTR __forceinline__
+#endif
 template <int SYS, class R>
-__device__ __attribute__((noinline)) DrawnState<SYS, R> draw_initial_state_call(const InitDev *rinit, int64_t env, uint32_t count) {
+__device__ GEMX_DRAW_CALL_ATTR DrawnState<SYS, R> draw_initial_state_call(const InitDev *rinit, int64_t env, uint32_t count) {
     constexpr int ND = SysTraits<SYS>::ND;
     DrawnState<SYS, R> o;
     double v[GEMX_MAX_ODE];
-    init_draw_all<SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM, SysTraits<SYS>::ND + (SysTraits<SYS>::HAS_ANGLE ? 1 : 0)>(rinit, env, count, v);
+    init_draw_all<SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM, GEMX_DRAW_NS * (SysTraits<SYS>::ND + (SysTraits<SYS>::HAS_ANGLE ? 1 : 0))>(rinit, env, count, v);
 #pragma unroll
     for (int j = 0; j < ND; ++j) o.y[j] = (R)v[j];
     o.ang = typename Angle<R>::T(0);
@@ -2729,6 +2740,30 @@ void advance_pipe_kernel(const KArgs<R> a) {
     lds_u32_t *prep = (lds_u32_t *)reinterpret_cast<uint32_t *>(vtab + ((ST::NVT > 0 && DISCRETE) ? ConvTraits<CONV>::NACTIONS * 8 : 0));
     lds_u32_t *prep_cnt = prep + (size_t)PREP_Q * BLOCK * 8;
     static_assert(ND + 1 <= 7, "a prepared draw is eight dwords: states, angle, tag");
+    // The initialiser's description in LDS (round 6; GEMX_PREP_DESC_COPY = 2).  Read through the global pointer, every field was loaded
+    // again in every pass of the loader (nothing may stay in registers across the block's barrier and the volatile LDS traffic): a pass
+    // that computes one generator block -- ~340 cycles of arithmetic -- took 1450, the finishing pass 3000-6600.  Copied into the loader's
+    // REGISTERS (= 1) the passes are fast where a workgroup has its CU to itself, but the ~140 dwords live across the whole kernel cost
+    // the heavier integrators their registers at four workgroups per CU (same box, 131072 envs: PMSM speed control 0.40 -> 0.30 of the
+    // roofline, SCIM 0.30 -> 0.26; PMSM finite 0.69 -> 0.75; profiles/r06_rinit_probe.md).  In LDS it costs neither: the waves that draw
+    // (integrator: inline draws; loader: prepared draws) each write the same 552 bytes before their first use -- no barrier needed, LDS
+    // operations of one wave complete in order and both write identical values.
+#ifndef GEMX_PREP_DESC_COPY  // 0: through the pointer (round 5), 1: the loader's registers, 2: LDS
+#define GEMX_PREP_DESC_COPY 2
+#endif
+    InitDev *desc_lds = reinterpret_cast<InitDev *>(gemx_smem);  // (unused unless FULL && RINIT)
+    if constexpr (FULL && RINIT) {
+        desc_lds = reinterpret_cast<InitDev *>(reinterpret_cast<uint32_t *>(vtab + ((ST::NVT > 0 && DISCRETE) ? ConvTraits<CONV>::NACTIONS * 8 : 0)) +
+                                              (size_t)(PREP_Q * 8 + 1) * BLOCK);
+    }
+    auto copy_desc_to_lds = [&]() {
+        if constexpr (FULL && RINIT && GEMX_PREP_DESC_COPY == 2) {
+            static_assert(sizeof(InitDev) % 4 == 0, "dword copy");
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(a.rinit);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(desc_lds);
+            for (int i = tid; i < (int)(sizeof(InitDev) / 4); i += BLOCK) dst[i] = src[i];
+        }
+    };
     // COMPACT hand-off rows (synchronous machines behind a finite converter and a constant-speed load: the headline): the integrator's
     // time per step is dominated by its LDS instructions (~25 cycles of issue apiece against ~5 for a VALU instruction: six of them were
     // 150 of the step's 320 cycles), so the blocks that run on the voltage table and the one-step map hand over EIGHT values instead of
@@ -2853,6 +2888,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
                 sup[1] = a.state[(int64_t)(ND + 1) * N + envc];
             }
             if constexpr (RINIT) {
+                copy_desc_to_lds();
                 rcount = a.rcnt[envc];
                 prep_cnt[tid] = rcount;
 #pragma unroll
@@ -3097,7 +3133,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
                         n_prepared += 1u;
 #endif
                     } else {
-                        draw_initial_state_cnt<SYS, R>(a.rinit, envc, rcount, y, ang);
+                        draw_initial_state_cnt<SYS, R>(GEMX_PREP_DESC_COPY == 2 ? desc_lds : a.rinit, envc, rcount, y, ang);
 #ifdef GEMX_TIMING
                         n_inline += 1u;
 #endif
@@ -3444,13 +3480,10 @@ void advance_pipe_kernel(const KArgs<R> a) {
         uint32_t lq0[4] = {0u, 0u, 0u, 0u}, prep_lastw = 0u;  // Philox block 0 of the draw this lane got last, and its count
         bool prep_act = false;
         int prep_phase = 0;  // wave-uniform
-        // The initialiser's description, copied ONCE into this wave's registers (round 6).  Read through the pointer, every field was loaded
-        // from global memory again in every pass -- the compiler may not keep a global load across the block's barrier and the volatile
-        // LDS traffic -- and a pass that computes one generator block (~340 cycles of arithmetic) took 1450, the finishing pass 3000-6600
-        // (dependent scalar loads of lo / hi / constant per state, then fp64 arithmetic; profiles/r06_rinit_probe.md): with four
-        // workgroups per CU the loader, not the integrator, set the block time of PMSM speed control with random initial states.
+        // (the initialiser's description: see GEMX_PREP_DESC_COPY at the kernel's LDS layout)
         InitDev prep_desc;
-        if constexpr (FULL && RINIT && GEMX_PREP_DRAWS != 0) prep_desc = *a.rinit;
+        if constexpr (FULL && RINIT && GEMX_PREP_DRAWS != 0 && GEMX_PREP_DESC_COPY == 1) prep_desc = *a.rinit;
+        copy_desc_to_lds();
         if (DISCRETE) __syncthreads();
         // (Staging TWO blocks ahead through a third buffer was tried in round 2 -- the s_memtime probe shows this wave's loads taking longer
         // than the integrator's block in the shallow shapes -- and changed nothing, same box, over all motor families:
@@ -3481,7 +3514,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
                     // integrator does; the whole draw in one pass (~2000-3500 cycles) made it the slowest wave of a block wherever the
                     // integrator runs on its one-step map (PMSM, 32768 envs: 41 G env-steps/s against 89 G without random initial states).
                     constexpr bool FLUX = SYS == GEMX_SYS_SCIM || SYS == GEMX_SYS_DFIM;
-                    const InitDev *I = &prep_desc;  // (the copy made before the block loop: see there)
+                    const InitDev *I = GEMX_PREP_DESC_COPY == 2 ? desc_lds : (GEMX_PREP_DESC_COPY == 1 ? &prep_desc : a.rinit);  // (see GEMX_PREP_DESC_COPY)
                     const bool blk1 = init_needs_block1(I), fprev = FLUX && I->flux_mode != 0;
                     if (prep_phase == 0) {  // scan: the first of the next PREP_Q counts whose slot does not hold it; lanes with a full queue sit out
                         const uint32_t c = prep_cnt[tid];
@@ -3522,7 +3555,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
                         if (prep_act) {
                             double u[GEMX_MAX_ODE], v[GEMX_MAX_ODE];
                             init_uniforms_from(pq0, pq1, u);
-                            init_draw_from<FLUX, ND + (HAS_ANGLE ? 1 : 0)>(I, prep_c + 1u, u, [&](double (&up)[GEMX_MAX_ODE]) { init_uniforms_from(pp0, pp1, up); }, v);
+                            init_draw_from<FLUX, GEMX_DRAW_NS * (ND + (HAS_ANGLE ? 1 : 0))>(I, prep_c + 1u, u, [&](double (&up)[GEMX_MAX_ODE]) { init_uniforms_from(pp0, pp1, up); }, v);
                             uint32_t w8[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
                             for (int j = 0; j < ND; ++j) { const R x = (R)v[j]; memcpy(&w8[j], &x, sizeof(R)); }
@@ -4546,7 +4579,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             b += pipe_act_bufs(D) * (size_t)((D + 3) / 4 * 4) * BLOCK * ABYTES;  // action staging (global -> LDS direct, one or two blocks ahead)
             if (h->cur_reward != nullptr) b += pipe_ref_bufs(D) * (size_t)D * BLOCK * h->rw_n_ref * sizeof(R);  // reference staging for the fused reward
             if (ST::NVT > 0 && ConvTraits<CONV>::DISCRETE) b += (size_t)ConvTraits<CONV>::NACTIONS * 8 * sizeof(R);  // per-action voltage table
-            if (h->cfg.init_kind != GEMX_INIT_CONST) b += (size_t)(prep_q<SYS>() * 8 + 1) * BLOCK * sizeof(uint32_t);       // prepared draws (random initialisers)
+            if (h->cfg.init_kind != GEMX_INIT_CONST) b += (size_t)(prep_q<SYS>() * 8 + 1) * BLOCK * sizeof(uint32_t) + ((sizeof(InitDev) + 15) & ~(size_t)15);  // prepared draws (random initialisers) + the description
             return (b + 15) & ~(size_t)15;
         };
         // workgroups of a shape one CU holds: LDS, wave slots -- and REGISTERS (round 4: the arithmetic used to stop at the first two and

@@ -32,8 +32,9 @@ extern "C" {
                             * 6: gemx_get_aux_state / gemx_set_aux_state / gemx_aux_state_bytes, gemx_reset_again; reset counters stay at 1 after gemx_create;
                             *    + gemx_rollout_synthetic / gemx_synthetic_actions, gemx_set_rate_limiter (new entry points only);
                             * 7: gemx_config.env_base / gemx_refgen_config.env_base: every device random stream is keyed by the GLOBAL env index
-                            *    env_base + i (shards of one job draw what the unsharded job draws); narrow action tensors (gemx_rollout_q);
-                            *    one unit library per (system, converter, dtype), loaded by gemx_create */
+                            *    env_base + i (shards of one job draw what the unsharded job draws); gemx_config.solver_atol_omega; GEMX_SOLVER_ADAPTIVE
+                            *    honours GEMX_SOLVER_SPLIT_KINKS; the initial-state streams are Threefry-4x32-12 (were Philox4x32-10: other draws from
+                            *    the same seed, same distributions); one unit library per (system, converter, dtype), loaded by gemx_create */
 #define GEMX_MAX_ODE 8  /* ODE state length incl. omega and the angle      */
 #define GEMX_MAX_OUT 24 /* system-state (observation) length               */
 #define GEMX_MODEL_ROWS 5
@@ -143,8 +144,9 @@ typedef struct gemx_config {
     /* Initial ODE state (electric_motor.py:150-257, mechanical_load.py:100-160).  GEMX_INIT_CONST: init_state below.
      * GEMX_INIT_UNIFORM / GEMX_INIT_GAUSSIAN: every reset (gemx_reset and the in-kernel auto-reset) draws each ODE state j with
      * init_lo[j] < init_hi[j] anew -- uniformly in [lo, hi], or from a normal(init_mu[j], init_sigma[j]) truncated to [lo, hi]
-     * (scipy.stats.truncnorm in the reference) -- from a counter-based Philox4x32-10 stream keyed by `seed` and indexed by
-     * (env, number of resets of that env, j); states with lo == hi keep init_state[j].  numpy's PCG64 streams of the reference
+     * (scipy.stats.truncnorm in the reference) -- from a counter-based stream (Threefry-4x32 with 12 rounds since ABI 7, Philox4x32-10
+     * before: Salmon et al., SC'11) keyed by `seed` and indexed by (env_base + env, number of resets of that env, j); states with lo == hi
+     * keep init_state[j].  numpy's PCG64 streams of the reference
      * cannot be reproduced on a device: parity is distributional (tests/test_gpu_parity.py), and exact for the state -> reset
      * observation map.  Every system; the load's omega for any system with a PolynomialStaticLoad.
      * Induction machines (SCIM, DFIM; ABI 5): init_flux_mode = 1 re-derives the bounds of the two flux states at EVERY reset as the

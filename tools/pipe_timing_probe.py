@@ -14,6 +14,8 @@ if os.environ.get("PROBE_RINIT"):  # random initial states (the RINIT instantiat
     extra = dict(motor=ga.PermanentMagnetSynchronousMotor(motor_initializer=dict(random_init="uniform")), seed=3)
 if os.environ.get("PROBE_RINIT") == "SCIM":
     extra = dict(motor=ga.SquirrelCageInductionMotor(motor_initializer=dict(random_init="uniform")), seed=3)
+if os.environ.get("PROBE_RINIT_LOAD"):  # ... and the load's omega drawn as well (bench_matrix.py's "PMSM cont SC + random initial states")
+    extra["load"] = ga.PolynomialStaticLoad(load_initializer=dict(random_init="uniform"))
 if os.environ.get("PROBE_RC"):
     extra = dict(supply=ga.RCVoltageSupply(u_nominal=420.0, supply_parameter=dict(R=0.5, C=2e-3)))
 env = ga.make(env_id, n_envs=n, device="cuda:0", **extra) if os.environ.get("PROBE_SOLVER") == "default" else ga.make(env_id, n_envs=n, device="cuda:0", ode_solver=solver, tau=1e-4, **extra)
