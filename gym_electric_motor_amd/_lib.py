@@ -83,7 +83,7 @@ EXPORTS = (
     "gemx_abi_version", "gemx_sizeof_config", "gemx_last_error", "gemx_device_count", "gemx_create", "gemx_destroy",
     "gemx_n_envs", "gemx_n_ode", "gemx_n_out", "gemx_n_action", "gemx_action_itemsize", "gemx_n_switch_bytes", "gemx_reset_observation", "gemx_set_reward", "gemx_rollout_reward", "gemx_refgen_create", "gemx_refgen_destroy", "gemx_refgen_reset",
     "gemx_refgen_rollout", "gemx_refgen_get_state",
-    "gemx_reset", "gemx_step", "gemx_rollout", "gemx_get_state", "gemx_set_state", "gemx_get_switch_state",
+    "gemx_reset", "gemx_step", "gemx_rollout", "gemx_rollout_half", "gemx_get_state", "gemx_set_state", "gemx_get_switch_state",
     "gemx_set_switch_state", "gemx_aux_state_bytes", "gemx_get_aux_state", "gemx_set_aux_state", "gemx_reset_again", "gemx_rollout_synthetic", "gemx_synthetic_actions", "gemx_set_rate_limiter", "gemx_set_steps_per_block", "gemx_last_launch", "gemx_error_flags", "gemx_debug_read",
 )
 
@@ -128,6 +128,7 @@ def load():
     L.gemx_set_aux_state.argtypes = [vp, vp, vp]
     L.gemx_step.argtypes = [vp, vp, vp, vp, vp]
     L.gemx_rollout.argtypes = [vp, vp, i32, vp, vp, i32, vp]
+    L.gemx_rollout_half.argtypes = [vp, vp, i32, vp, vp, vp]
     L.gemx_set_reward.argtypes = [vp, C.POINTER(GemxRewardConfig)]
     L.gemx_refgen_create.argtypes = [C.POINTER(GemxRefgenConfig), i64, C.c_int, C.c_int, C.POINTER(vp)]
     L.gemx_refgen_destroy.argtypes = [vp]

@@ -1007,6 +1007,21 @@ int gemx_rollout_synthetic(gemx_handle *h, uint64_t seed, uint32_t step0, int32_
     return rc;
 }
 
+int gemx_rollout_half(gemx_handle *h, const void *actions_half_dev, int32_t K, void *obs_out_dev, uint8_t *done_out_dev, void *stream) {
+    if (!h) return fail(GEMX_ERR_ARG, "null handle");
+    if (!actions_half_dev || !obs_out_dev) return fail(GEMX_ERR_ARG, "actions_half_dev and obs_out_dev must not be null");
+    if (K < 2) return fail(GEMX_ERR_ARG, "gemx_rollout_half: K must be >= 2");
+    if (((uintptr_t)obs_out_dev & 15u) != 0) return fail(GEMX_ERR_ARG, "obs_out_dev must be 16-byte aligned");
+    if (((uintptr_t)actions_half_dev & 1u) != 0) return fail(GEMX_ERR_ARG, "actions_half_dev must be 2-byte aligned");
+    if (h->cfg.dtype == GEMX_F64) return fail(GEMX_ERR_ARG, "gemx_rollout_half: fp32 handles only");
+    if (n_discrete_actions(h) > 0) return fail(GEMX_ERR_ARG, "gemx_rollout_half: continuous converters only (a discrete action is one byte already)");
+    gemx::DeviceGuard guard(h->device);
+    h->cur_half = true;
+    const int rc = launch_advance(h, actions_half_dev, K, obs_out_dev, done_out_dev, 1, (hipStream_t)stream);
+    h->cur_half = false;
+    return rc;
+}
+
 int gemx_set_reward(gemx_handle *h, const gemx_reward_config *rc) {
     if (!h) return fail(GEMX_ERR_ARG, "null handle");
     if (!rc) { h->rw_n_ref = -1; return GEMX_OK; }

@@ -505,6 +505,7 @@ template <class R> struct KArgs {
     uint64_t act_seed;
     int64_t act_env_base;  // gemx_config.env_base: the stream is keyed by the global env index
     int32_t prep_phases;   // random initial states: phases of the loader's prepared-draw state machine per hand-off block (launch_advance_t)
+    int32_t act_half;      // gemx_rollout_half: `actions` is [K][N][A] IEEE half (continuous converters, fp32 kernels): widened while staged
     uint32_t act_step0;
     int32_t act_synth;
 };
@@ -595,6 +596,7 @@ struct gemx_handle {
     gemx::RewardHot<float> rh_f = {};   // its first terms by value (kernel argument)
     gemx::RewardHot<double> rh_d = {};
     int rw_n_ref = -1;       // -1: no reward installed
+    bool cur_half = false;           // set by gemx_rollout_half around the launch: the action tensor holds IEEE halves
     bool cur_synth = false;          // set by gemx_rollout_synthetic around the launch: actions come from synth_u32(cur_seed, env, cur_step0 + k, i)
     uint64_t cur_seed = 0;
     uint32_t cur_step0 = 0;

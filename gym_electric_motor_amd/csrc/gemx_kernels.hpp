@@ -2641,11 +2641,11 @@ template <int SYS> constexpr int prep_q() { return (SYS == GEMX_SYS_SCIM || SYS 
 #define GEMX_EXPECT_PREPARED(x) __builtin_expect((x), 1)
 // Phases of the loader's prepared-draw state machine (scan + generator block | generator block | ... | finish) per hand-off block
 // (KArgs::prep_phases).  Round 5: one -- a pass cost 1450-6600 cycles (Philox, and every field of the description re-read from global memory)
-// and more per pass made the loader the slowest wave of a block.  Round 6 (Threefry, the description in registers: 560 / 870-2500 cycles):
-// TWO where a workgroup has its CU to itself (the induction machines, whose draw takes three phases and whose lanes drain their queues
-// fastest: resets that find the queue empty 7.4 % -> 2.4 %, SCIM cont at 16384 envs 420 -> 370 us per 500 steps), ONE where four
-// workgroups share a CU and the loaders' arithmetic competes with the integrators' (131072 envs: SCIM 2120 against 2285 us, PMSM speed
-// control 1445 against 1670).  GEMX_PREP_PHASES overrides (A/B builds).  profiles/r06_rinit_probe.md.
+// and more per pass made the loader the slowest wave of a block.  Round 6 (Threefry, the description in LDS: ~560 cycles per generator block,
+// 870-2500 for the finish): TWO for the induction machines, whose draw takes three phases and whose lanes drain their queues fastest
+// (resets that find the queue empty 7.4 % -> 2.4 %; same box, product builds, SCIM cont at 131072 envs 0.373 -> 0.430 of the roofline, 16384
+// envs 0.216 -> 0.250; three phases: 0.360 / 0.196), ONE for the others (PMSM finite at 16384 envs 0.411 -> 0.336 with two, speed control
+// level).  GEMX_PREP_PHASES overrides (A/B builds).  profiles/r06_rinit_probe.md.
 #ifndef GEMX_RINIT_WAVES
 #define GEMX_RINIT_WAVES 0  // (A/B builds: one figure for every system)
 #endif
@@ -2800,6 +2800,24 @@ void advance_pipe_kernel(const KArgs<R> a) {
                 }
             }
             return;
+        }
+        if constexpr (!DISCRETE && sizeof(R) == 4) {
+            if (a.act_half) {  // NARROW action tensor (gemx_rollout_half, round 6): [K][N][A] halves, 2 A bytes per env-step from the HBM instead
+                               // of 4 A.  Each lane loads its own env's values and widens them into the SAME fp32 rows the direct
+                               // global -> LDS loads write for an fp32 tensor: everything downstream (integrator, delayed reads of the
+                               // DeadTimeProcessor, dq stage) is untouched, and a half tensor gives the bits of its values fed as fp32.
+                const _Float16 *srch = reinterpret_cast<const _Float16 *>(a.actions) + (int64_t)b * D * N * NACT;
+                for (int s = 0; s < D; ++s) {
+                    const int row = s < sb ? s : sb - 1;
+                    const _Float16 *g = srch + ((int64_t)row * N + envc) * NACT;
+#pragma unroll
+                    for (int i = 0; i < NACT; ++i) {
+                        const float v = (float)g[i];
+                        reinterpret_cast<float *>(dst + (size_t)s * ROWB)[tid * NACT + i] = valid ? v : 0.0f;
+                    }
+                }
+                return;
+            }
         }
         const unsigned char *src = a.actions + ((int64_t)b * D * N + blk0) * ABYTES;
         if (!fast_io) {  // partial workgroup / unaligned rows: this lane's own action of every row through a register; lanes beyond the batch stage zeros
@@ -3586,7 +3604,7 @@ void advance_pipe_kernel(const KArgs<R> a) {
             if (b + 1 < nb) {
                 constexpr int VM_KEEP = 0x0F70 | (NSTAGE & 0xF) | ((NSTAGE >> 4) << 14);
                 static_assert(NSTAGE < 64, "vmcnt immediate");
-                if (AHEAD == 2 && issued && n_ref == 0 && fast_io) __builtin_amdgcn_s_waitcnt(VM_KEEP);
+                if (AHEAD == 2 && issued && n_ref == 0 && fast_io && !a.act_half) __builtin_amdgcn_s_waitcnt(VM_KEEP);
                 else __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
             }
 #ifdef GEMX_TIMING
@@ -4446,6 +4464,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     a.act_synth = h->cur_synth ? 1 : 0;
     a.act_seed = h->cur_seed;
     a.act_env_base = h->cfg.env_base;
+    a.act_half = h->cur_half ? 1 : 0;
 #ifdef GEMX_PREP_PHASES
     a.prep_phases = GEMX_PREP_PHASES;
 #else
@@ -4530,7 +4549,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
     // PermExDc, us per 1000 steps at 4096 / 8192 / 12288 / 16384 envs: 39 / 41 / 88 / 94 against 71 / 72 / 72 / 72; tools/ab_dc_stream.py)
     if constexpr (sizeof(R) == 4 && LOAD == GEMX_LOAD_CONST_SPEED && !IL &&
                   (SYS == GEMX_SYS_DC_PERMEX || SYS == GEMX_SYS_DC_SERIES || SYS == GEMX_SYS_DC_SHUNT || SYS == GEMX_SYS_DC_EXTEX)) {
-        bool dcs_ok = pipe_ok && fast_step && !h->cur_synth && (h->n % BLOCK) == 0 && a.coop && a.obs_vec && h->use_dc_stream != 0 && !need_full && delay == 0 && !(h->cfg.solver_flags & GEMX_SOLVER_ADAPTIVE) && h->cur_reward == nullptr && (h->omega_is_init || h->use_dc_stream >= 3) &&
+        bool dcs_ok = pipe_ok && fast_step && !h->cur_synth && !h->cur_half && (h->n % BLOCK) == 0 && a.coop && a.obs_vec && h->use_dc_stream != 0 && !need_full && delay == 0 && !(h->cfg.solver_flags & GEMX_SOLVER_ADAPTIVE) && h->cur_reward == nullptr && (h->omega_is_init || h->use_dc_stream >= 3) &&
                       params_of<R>(h).obs_layout == GEMX_OBS_AOS && params_of<R>(h).t_il == R(0) &&
                       (h->use_dc_stream > 1 || 2 * blocks <= (int64_t)h->n_cu) && dcs_smem_bytes<SYS, CONV>() <= h->lds_max &&
                       (int64_t)h->n * h->nout * 64 < ((int64_t)1 << 31);  // (SIGNED 32-bit store offsets: lane offsets across the rows of a (double)
@@ -4732,7 +4751,8 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                 // a softer landing beyond it (back to the unpaced level, not below): 65536 / 131072 envs PMSM cont 0.66 / 0.63 unpaced -> 0.68 / 0.63
                 // at 6000 / 5600, EESM cont 0.62 / 0.59 -> 0.73 / 0.66, DFIM cont 0.60 / 0.70 -> 0.72 / 0.69, control_space='dq' 0.62 / 0.62 -> 0.68 /
                 // 0.65, ExtExDc cont 0.72 / 0.64 -> 0.77 / 0.64 at 6400 (profiles/r04p_pace_sweep3.txt).
-                const bool reads = ABYTES >= 8 && !h->cur_synth;  // (synthetic actions are generated in the launch: nothing is read)
+                const int abytes_eff = h->cur_half ? ABYTES / 2 : ABYTES;  // (gemx_rollout_half: two bytes per value)
+                const bool reads = abytes_eff >= 8 && !h->cur_synth;  // (synthetic actions are generated in the launch: nothing is read)
                 const double dflt = h->nout <= 8 ? (reads ? (few ? 7000.0 : 6400.0) : (some ? 7000.0 : 6600.0))
                                     : reads      ? (few ? 6400.0 : (some ? 6000.0 : 5800.0))
                                                  : (few ? 6800.0 : (some ? 6600.0 : 6400.0));
@@ -4745,7 +4765,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                 if (cal_eligible) {
                     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
                     (void)hipStreamIsCapturing(st, &capturing);
-                    const long long sig = ((long long)K << 40) ^ ((long long)blocks << 8) ^ (long long)shape ^ (h->cur_reward != nullptr ? 0x80 : 0) ^ (h->cur_synth ? 0x40 : 0);
+                    const long long sig = ((long long)K << 40) ^ ((long long)blocks << 8) ^ (long long)shape ^ (h->cur_reward != nullptr ? 0x80 : 0) ^ (h->cur_synth ? 0x40 : 0) ^ (h->cur_half ? 0x20 : 0);
                     if (pc.sig != sig) {  // a new kind of launch: start over (events are kept)
                         pc.sig = sig; pc.next = 0; pc.chosen = -1; pc.center = 1.0f; pc.recenters = 0;
                         for (int c = 0; c < gemx_handle::PaceCal::NC; ++c) { pc.best[c] = 1e30f; pc.count[c] = 0; pc.issued[c] = 0; }
@@ -4822,7 +4842,7 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                 if (res > 4 * (int64_t)h->n_cu && blocks <= res && blocks > res - (int64_t)h->n_cu) res -= (int64_t)h->n_cu;
                 pace_res = res;
                 if (target > 0.0 && (blocks > (int64_t)h->n_cu || h->pace_gbps > 0.0 || long_one) && K >= 64 && shape != 3 && shape < 5) {  // (<12, 6> carries no limiter: see the kernel; nor do the SLOW ones)
-                    const double wg_step_bytes = (double)BLOCK * ((h->cur_synth ? 0 : ABYTES) + h->nout * sizeof(R) + 1 + (h->cur_reward != nullptr ? (h->rw_n_ref + 1) * sizeof(R) : 0));
+                    const double wg_step_bytes = (double)BLOCK * ((h->cur_synth ? 0 : abytes_eff) + h->nout * sizeof(R) + 1 + (h->cur_reward != nullptr ? (h->rw_n_ref + 1) * sizeof(R) : 0));
                     auto ticks_for = [&](double active) {
                         const double t = wg_step_bytes * active / target * D / 10.0;  // bytes / (GB/s) = ns; 10 ns per tick; D rows per block
                         return t < 1.0 ? 1u : (t > 4.0e9 ? 0u : (uint32_t)(t + 0.5));
@@ -4854,6 +4874,8 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
             return GEMX_OK;
         }
     }
+    if (h->cur_half)
+        return fail(GEMX_ERR_ARG, "gemx_rollout_half needs the pipelined kernel: fp32, K >= 2, a continuous converter (and no random initial states together with solver sub-steps / a custom constraint set)");
     if (h->cur_synth)  // (only the pipelined kernel's loader wave generates actions; gemx_synthetic_actions writes the same stream for any other path)
         return fail(GEMX_ERR_ARG, "gemx_rollout_synthetic needs the pipelined kernel: fp32, K >= 2 (and no random initial states together with solver sub-steps / a custom constraint set)");
     if (K == 1 && h->cur_reward == nullptr && h->use_step_kernel != 0) {  // the closed-loop path: see step_kernel

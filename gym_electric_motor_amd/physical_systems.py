@@ -701,8 +701,9 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             raise ValueError("bind_rollout needs a device tensor of actions [K, N, A] / [K, N]")
         K = int(actions.shape[0])
         a = actions
-        if not (a.device == self._tdev and a.is_contiguous() and a.dtype is self._want_dtype and a.numel() == K * self._act_numel):
-            raise ValueError(f"bind_rollout needs a contiguous {self._want_dtype} tensor of {K} x {self._act_numel} elements on {self._tdev}")
+        half = a.dtype is torch.float16 and not self._discrete and self._tdtype == torch.float32 and K >= 2  # (narrow action tensor: gemx_rollout_half)
+        if not (a.device == self._tdev and a.is_contiguous() and (a.dtype is self._want_dtype or half) and a.numel() == K * self._act_numel):
+            raise ValueError(f"bind_rollout needs a contiguous {self._want_dtype} (continuous converters, fp32: or float16) tensor of {K} x {self._act_numel} elements on {self._tdev}")
         oshape, dshape = (K,) + tuple(self._obs.shape), (K, self._n_envs)
         if not (torch.is_tensor(obs_out) and tuple(obs_out.shape) == oshape and obs_out.is_contiguous() and obs_out.dtype == self._tdtype and obs_out.device == self._tdev):
             raise ValueError(f"bind_rollout: obs_out must be a contiguous {self._tdtype} tensor of shape {oshape} on {self._tdev}")
@@ -710,8 +711,8 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             raise ValueError(f"bind_rollout: done_out must be a contiguous uint8 tensor of shape {dshape} on {self._tdev}")
         stream = stream if stream is not None else torch.cuda.current_stream(self._tdev)  # (the Stream OBJECT is kept: its raw handle must not dangle)
         st = stream.cuda_stream
-        call, check = self._L.gemx_rollout, _lib.check
-        args = (C.c_void_p(a.data_ptr()), K, C.c_void_p(obs_out.data_ptr()), C.c_void_p(done_out.data_ptr()), 1, C.c_void_p(st))
+        call, check = (self._L.gemx_rollout_half if half else self._L.gemx_rollout), _lib.check
+        args = (C.c_void_p(a.data_ptr()), K, C.c_void_p(obs_out.data_ptr()), C.c_void_p(done_out.data_ptr())) + (() if half else (1,)) + (C.c_void_p(st),)
         keep = (a, obs_out, done_out, stream)  # the buffers and the stream behind the raw pointers stay alive as long as the launcher does
         out = (obs_out, done_out)
 
@@ -732,7 +733,15 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
         K = int(actions.shape[0])
         if references is not None or reward_out is not None:
             return self._rollout_reward(actions, K, obs_out, done_out, references, reward_out)
-        a = self._actions_to_device(actions, (K, self._n_envs))
+        # a HALF action tensor (continuous converters, fp32 systems): taken as it is -- gemx_rollout_half widens the values while they are
+        # staged (6 instead of 12 bytes per env-step for three duty cycles; the results are those of the same values fed as fp32)
+        half = (torch.is_tensor(actions) and actions.dtype == torch.float16 and not self._discrete and self._tdtype == torch.float32 and not last_only)
+        if half:
+            if not (actions.device == self._tdev and actions.is_contiguous() and actions.numel() == K * self._act_numel and K >= 2):
+                raise ValueError(f"rollout: a float16 action tensor must be a contiguous device tensor of {K} x {self._act_numel} elements on {self._tdev}, K >= 2")
+            a = actions
+        else:
+            a = self._actions_to_device(actions, (K, self._n_envs))
         if last_only:
             oshape, dshape = tuple(self._obs.shape), (self._n_envs,)
         else:
@@ -744,8 +753,12 @@ class BatchedSCMLSystem(_PhysicalSystemBase):
             done_out = torch.empty(dshape, dtype=torch.uint8, device=self._tdev)
         assert tuple(obs_out.shape) == oshape and obs_out.is_contiguous() and obs_out.dtype == self._tdtype
         assert tuple(done_out.shape) == dshape and done_out.is_contiguous() and done_out.dtype == torch.uint8
-        _lib.check(self._L.gemx_rollout(self._handle, C.c_void_p(a.data_ptr()), K, C.c_void_p(obs_out.data_ptr()),
-                                        C.c_void_p(done_out.data_ptr()), 0 if last_only else 1, self._stream()))
+        if half:
+            _lib.check(self._L.gemx_rollout_half(self._handle, C.c_void_p(a.data_ptr()), K, C.c_void_p(obs_out.data_ptr()),
+                                                 C.c_void_p(done_out.data_ptr()), self._stream()))
+        else:
+            _lib.check(self._L.gemx_rollout(self._handle, C.c_void_p(a.data_ptr()), K, C.c_void_p(obs_out.data_ptr()),
+                                            C.c_void_p(done_out.data_ptr()), 0 if last_only else 1, self._stream()))
         self._k += K
         return obs_out, done_out
 

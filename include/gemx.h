@@ -32,7 +32,7 @@ extern "C" {
                             * 6: gemx_get_aux_state / gemx_set_aux_state / gemx_aux_state_bytes, gemx_reset_again; reset counters stay at 1 after gemx_create;
                             *    + gemx_rollout_synthetic / gemx_synthetic_actions, gemx_set_rate_limiter (new entry points only);
                             * 7: gemx_config.env_base / gemx_refgen_config.env_base: every device random stream is keyed by the GLOBAL env index
-                            *    env_base + i (shards of one job draw what the unsharded job draws); gemx_config.solver_atol_omega; GEMX_SOLVER_ADAPTIVE
+                            *    env_base + i (shards of one job draw what the unsharded job draws); gemx_rollout_half; gemx_config.solver_atol_omega; GEMX_SOLVER_ADAPTIVE
                             *    honours GEMX_SOLVER_SPLIT_KINKS; the initial-state streams are Threefry-4x32-12 (were Philox4x32-10: other draws from
                             *    the same seed, same distributions); one unit library per (system, converter, dtype), loaded by gemx_create */
 #define GEMX_MAX_ODE 8  /* ODE state length incl. omega and the angle      */
@@ -276,6 +276,14 @@ int gemx_set_reward(gemx_handle *h, const gemx_reward_config *rc);
  * for policies / tests / the paths gemx_rollout_synthetic does not serve: gemx_rollout on that tensor gives the same bits. */
 int gemx_rollout_synthetic(gemx_handle *h, uint64_t seed, uint32_t step0, int32_t K, void *obs_out_dev, uint8_t *done_out_dev, void *stream);
 int gemx_synthetic_actions(gemx_handle *h, uint64_t seed, uint32_t step0, int32_t K, void *actions_out_dev, void *stream);
+
+/* gemx_rollout with a NARROW action tensor (ABI 7): actions_half_dev [K, N, A] IEEE half (continuous converters, fp32 handles, K >= 2;
+ * observations of every step).  A policy's duty cycles need no more than eleven bits; from 32768 envs on the launches of the continuous
+ * converters are bound by the write path's tolerance for the action stream read between the row stores, and half the read
+ * bytes is the one lever a tensor-fed rollout has.  The values are widened to fp32 while they are staged: the results are, bit for bit, those
+ * of gemx_rollout on the same values as fp32 (the reference clips and uses float64 duty cycles: converters.py:144-158, 888-903; the
+ * quantisation of a half, 2^-11 relative, is the caller's to accept). */
+int gemx_rollout_half(gemx_handle *h, const void *actions_half_dev, int32_t K, void *obs_out_dev, uint8_t *done_out_dev, void *stream);
 
 /* The large-batch RATE LIMITER of the fused rollout (more workgroups than CUs: every workgroup is held to one block of rows per interval,
  * because this chip's write path delivers more when it is offered slightly less than it can take -- DESIGN.md 4.1).  Results never depend

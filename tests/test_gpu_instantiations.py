@@ -232,3 +232,69 @@ def test_the_fp64_forms_of_the_small_kernels():
     assert whole.dtype == torch.float64 and torch.equal(whole, parts)
     for e in (env, twin, e32):
         e.close()
+
+
+@pytest.mark.parametrize("env_id, n, kw", [("Cont-CC-PMSM-v0", 200, {}), ("Cont-CC-PMSM-v0", 65536, {}), ("Cont-SC-SCIM-v0", 32768 + 64 + 7, {}),
+                                            ("Cont-CC-EESM-v0", 4096, {}), ("Cont-CC-DFIM-v0", 1000, {}), ("Cont-CC-PermExDc-v0", 16384, {}),
+                                            ("Cont-CC-PMSM-v0", 4096, {"control_space": "dq"}), ("Cont-CC-PMSM-v0", 16384, {"action_delay": 2})])
+def test_half_action_tensor_gives_the_bits_of_its_values_fed_as_fp32(env_id, n, kw):
+    """gemx_rollout_half (ABI 7): a [K, N, A] float16 action tensor is widened while it is staged -- observations, done bytes and the final
+    state are those of `rollout(actions.float())`, bit for bit, in every pipelined shape incl. partial workgroups, the DeadTimeProcessor's
+    delayed reads and control_space='dq'; through `rollout()` and through `bind_rollout()`.  What a half costs against unrounded duty
+    cycles is the caller's quantisation (2^-11 relative on [-1, 1]); the kernel adds nothing to it."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+
+    Kh = 53
+    env = ga.make(env_id, n_envs=n, tau=1e-4, **kw)
+    ps = env.physical_system
+    g = torch.Generator(device="cuda").manual_seed(17)
+    a16 = (torch.rand((Kh, n, ps._n_act), device="cuda", generator=g) * 2.2 - 1.1).to(torch.float16)  # (beyond [-1, 1] too: clipped by the converter)
+    env.reset()
+    ref = env.rollout(a16.float())
+    ref = (ref[0].clone(), ref[1].clone(), ps.get_state().clone(), ps.last_launch())
+    env.reset()
+    got = env.rollout(a16)
+    got = (got[0].clone(), got[1].clone(), ps.get_state().clone(), ps.last_launch())
+    assert "advance_pipe_kernel" in got[3], got[3]
+    _same(torch, ref, got, f"{env_id} n={n} half action tensor")
+    obs = torch.empty_like(ref[0])
+    done = torch.empty_like(ref[1])
+    env.reset()
+    launch = env.bind_rollout(a16, obs, done)
+    launch()
+    assert torch.equal(obs, ref[0]) and torch.equal(done, ref[1])
+    with pytest.raises(ValueError):  # a single step has no fused launch to widen in
+        env.rollout(a16[:1])
+    env.close()
+
+
+def test_half_action_tensor_is_refused_where_it_has_no_meaning():
+    """The C entry point refuses what it cannot serve, with a message: discrete converters (one byte per action already), fp64 handles,
+    a single step (no fused launch to widen in)."""
+    import ctypes as C
+
+    import torch
+
+    import gym_electric_motor_amd as ga
+    from gym_electric_motor_amd import _lib
+
+    L = _lib.load()
+    buf = torch.zeros(8 * 128 * 3, dtype=torch.float16, device="cuda")
+    obs = torch.zeros(8 * 128 * 16, dtype=torch.float64, device="cuda")
+    done = torch.zeros(8 * 128, dtype=torch.uint8, device="cuda")
+
+    def call(env, K):
+        return L.gemx_rollout_half(env.physical_system._handle, C.c_void_p(buf.data_ptr()), K, C.c_void_p(obs.data_ptr()), C.c_void_p(done.data_ptr()), None)
+
+    e = ga.make("Finite-CC-PMSM-v0", n_envs=128)
+    assert call(e, 8) == -1 and b"continuous converters only" in L.gemx_last_error()
+    e.close()
+    e = ga.make("Cont-CC-PMSM-v0", n_envs=128, dtype="float64")
+    assert call(e, 8) == -1 and b"fp32 handles only" in L.gemx_last_error()
+    e.close()
+    e = ga.make("Cont-CC-PMSM-v0", n_envs=128)
+    assert call(e, 1) == -1 and b"K must be >= 2" in L.gemx_last_error()
+    assert call(e, 8) == 0
+    e.close()

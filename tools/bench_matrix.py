@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--shape", default=None, help="GEMX_PIPE_SHAPE for every row (0: <12,3>, 1: <4,2>, 2: <2,2>, 3: <12,6>)")
     ap.add_argument("--only", nargs="*", default=None, help="substrings: run the rows whose label contains one of them")
     ap.add_argument("--device-actions", action="store_true", help="actions generated on the device (rollout_synthetic): no action tensor, B/env-step without the action bytes")
+    ap.add_argument("--half-actions", action="store_true", help="continuous rows: the action tensor as float16 (gemx_rollout_half): 2 instead of 4 bytes per duty cycle")
     args = ap.parse_args()
     if args.shape is not None:
         os.environ["GEMX_PIPE_SHAPE"] = args.shape
@@ -97,6 +98,9 @@ def main():
             else:
                 acts = torch.rand((K, n, ps._n_act), device="cuda", generator=g) * 2 - 1
                 a_bytes = 4 * ps._n_act
+                if args.half_actions and not with_reward:
+                    acts = acts.to(torch.float16)
+                    a_bytes = 2 * ps._n_act
             obs = torch.empty((K, n, ps._n_out), device="cuda")
             done = torch.empty((K, n), dtype=torch.uint8, device="cuda")
             refs = rew = None
