@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--shape", default=None, help="GEMX_PIPE_SHAPE for every row (0: <12,3>, 1: <4,2>, 2: <2,2>, 3: <12,6>)")
     ap.add_argument("--only", nargs="*", default=None, help="substrings: run the rows whose label contains one of them")
     ap.add_argument("--device-actions", action="store_true", help="actions generated on the device (rollout_synthetic): no action tensor, B/env-step without the action bytes")
+    ap.add_argument("--chunks", type=int, default=1, help="rotating action tensors (C x K steps): with C x K x N x bytes beyond the 256 MB Infinity Cache the "
+                                                          "actions of every launch come from the HBM, as behind a policy (one re-read chunk can sit in the cache)")
     ap.add_argument("--half-actions", action="store_true", help="continuous rows: the action tensor as float16 (gemx_rollout_half): 2 instead of 4 bytes per duty cycle")
     args = ap.parse_args()
     if args.shape is not None:
@@ -114,7 +116,12 @@ def main():
             if args.device_actions and not with_reward:
                 b -= a_bytes
 
+            chunks = [acts] + [acts.clone() for _ in range(max(1, args.chunks) - 1)]
+            turn = [0]
+
             def launch():
+                turn[0] += 1
+                acts = chunks[turn[0] % len(chunks)]
                 if args.device_actions and not with_reward:
                     ps.rollout_synthetic(K, seed=1, step0=0, obs_out=obs, done_out=done)
                 elif with_reward:

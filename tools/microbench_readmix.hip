@@ -7,6 +7,7 @@
 //     1  the reference's [K][N][A]: 768 B per step at a stride of N * 12 B
 //     2  group-major [N/64][K][64][A]: the workgroup's own stream, 768 B per step, contiguous from step to step
 //     3  group-major, 16 steps (12 KB) at once every eighth block
+//     4  (round 6) the reference layout with HALF-precision values: 384 B per step -- what a narrow action tensor (gemx_rollout_half) could buy at best
 // pace_ns > 0: block b starts no earlier than b * pace_ns after the workgroup's start (the rate limiter).
 //   hipcc --offload-arch=gfx950 -O3 tools/microbench_readmix.hip -o tools/microbench_readmix && tools/microbench_readmix
 #include <hip/hip_runtime.h>
@@ -49,6 +50,10 @@ __global__ __launch_bounds__(256) void mix(vf4 *out, const vf4 *act, vf4 *sink, 
             } else if (mode == 2) {
                 if (lane < 48 && kb < K) f0 = act[((long long)w * K + kb) * 48 + lane];
                 if (lane < 48 && kb + 1 < K) f1 = act[((long long)w * K + kb + 1) * 48 + lane];
+            } else if (mode == 4) {  // round 6: a NARROW action tensor, [K][N][A] halves -- 384 B per workgroup and step (24 sixteen-byte units)
+                const long long hrow_v = (long long)N * 6 / 16;
+                if (lane < 24 && kb < K) f0 = act[(long long)kb * hrow_v + (long long)w * 24 + lane];
+                if (lane < 24 && kb + 1 < K) f1 = act[(long long)(kb + 1) * hrow_v + (long long)w * 24 + lane];
             } else if (mode == 3) {
                 if ((b & 7) == 0)
                     for (int j = lane; j < 16 * 48 && kb + j / 48 < K; j += 64) f0 += act[((long long)w * K + kb) * 48 + j];
@@ -71,9 +76,9 @@ int main() {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     printf("| action reads | pace (ns per 2-step block) | us per launch | bytes moved | GB/s | of 8 TB/s |\n|---|---|---|---|---|---|\n");
-    const char *names[4] = {"none", "[K][N][A] (reference)", "group-major, per step", "group-major, 12 KB every 8 blocks"};
+    const char *names[5] = {"none", "[K][N][A] (reference)", "group-major, per step", "group-major, 12 KB every 8 blocks", "[K][N][A] as HALVES (6 B per env-step)"};
     for (unsigned pace : {0u, 150u, 162u, 175u}) {
-        for (int mode = 0; mode < 4; ++mode) {
+        for (int mode = 0; mode < 5; ++mode) {
             auto launch = [&]() { hipLaunchKernelGGL(mix, dim3(N / 64), dim3(256), 0, 0, out, act, sink, K, N, mode, pace); };
             for (int r = 0; r < 10; ++r) launch();
             hipDeviceSynchronize();
@@ -87,7 +92,7 @@ int main() {
                 ts.push_back(ms / 10);
             }
             std::sort(ts.begin(), ts.end());
-            const double bytes = (double)ob + (mode ? (double)ab : 0.0), gbs = bytes / (ts[1] * 1e-3) / 1e9;
+            const double bytes = (double)ob + (mode == 4 ? (double)ab / 2 : (mode ? (double)ab : 0.0)), gbs = bytes / (ts[1] * 1e-3) / 1e9;
             printf("| %s | %u | %.1f | %.0f MB | %.0f | %.3f |\n", names[mode], pace * 10, ts[1] * 1e3, bytes / 1e6, gbs, gbs / 8000.0);
             fflush(stdout);
         }
