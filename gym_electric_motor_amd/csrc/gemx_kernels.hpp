@@ -4765,7 +4765,12 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                 if (cal_eligible) {
                     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
                     (void)hipStreamIsCapturing(st, &capturing);
-                    const long long sig = ((long long)K << 40) ^ ((long long)blocks << 8) ^ (long long)shape ^ (h->cur_reward != nullptr ? 0x80 : 0) ^ (h->cur_synth ? 0x40 : 0) ^ (h->cur_half ? 0x20 : 0);
+                    // (the interval per hand-off block does not depend on the launch's length: K enters only through its class -- short launches,
+                    // whose fixed costs weigh on the timings, and the long launches at one workgroup per CU, which pace a different shape.  A
+                    // training loop that varies K within a class keeps its calibration; round 5 keyed it by K itself and re-calibrated, up to 240
+                    // launches, at every change.)
+                    const int k_class = long_one ? 2 : (K < 256 ? 0 : 1);
+                    const long long sig = ((long long)k_class << 40) ^ ((long long)blocks << 8) ^ (long long)shape ^ (h->cur_reward != nullptr ? 0x80 : 0) ^ (h->cur_synth ? 0x40 : 0) ^ (h->cur_half ? 0x20 : 0);
                     if (pc.sig != sig) {  // a new kind of launch: start over (events are kept)
                         pc.sig = sig; pc.next = 0; pc.chosen = -1; pc.center = 1.0f; pc.recenters = 0;
                         for (int c = 0; c < gemx_handle::PaceCal::NC; ++c) { pc.best[c] = 1e30f; pc.count[c] = 0; pc.issued[c] = 0; }
@@ -4808,6 +4813,9 @@ int launch_advance_t(gemx_handle *h, const void *actions, int K, void *obs, uint
                                     pc.center *= (float)CAL_SCALE[win];
                                     pc.recenters++;
                                     for (int c = 0; c < gemx_handle::PaceCal::NC; ++c) { pc.best[c] = 1e30f; pc.count[c] = 0; pc.issued[c] = 0; }
+                                    // (pairs still in flight were timed at the OLD centre: they must not be harvested into the new bracket --
+                                    // best[] keeps the minimum, one stale fast sample could pick the wrong candidate for good; advisor, round 5)
+                                    for (int i = 0; i < gemx_handle::PaceCal::RING; ++i) pc.ev_cand[i] = -1;
                                 } else {
                                     pc.chosen = win;
                                 }

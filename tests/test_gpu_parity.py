@@ -2712,7 +2712,8 @@ def test_rate_limiter_closed_loop_calibrates_and_never_changes_results(monkeypat
     """The large-batch rate limiter is closed loop since round 5: a handle's first paced launches take turns at the built-in target x
     {1, 0.93, 1.07, 0.86} and unpaced, each timed with HIP events on the launch stream, and the fastest is kept (gemx_last_launch() says
     `calibrating` / `calibrated` and at what factor).  The limiter only delays block starts, so every launch -- calibrating, calibrated,
-    GEMX_PACE_CAL=0, GEMX_PACE_GBPS=0 -- produces the same bits; a launch with another signature (K) starts a new calibration."""
+    GEMX_PACE_CAL=0, GEMX_PACE_GBPS=0 -- produces the same bits; the calibration belongs to (workgroups, shape, reward / action source, and
+    the CLASS of the launch length: < 256 steps | longer | the long launches at one workgroup per CU), so that a loop that varies K keeps it."""
     import torch
 
     import gym_electric_motor_amd as ga
@@ -2739,8 +2740,10 @@ def test_rate_limiter_closed_loop_calibrates_and_never_changes_results(monkeypat
                 assert torch.equal(o, outs[0][0]) and torch.equal(d, outs[0][1]), i
             descs.append(ps.last_launch())
         torch.cuda.synchronize()
-        o2, _ = env.rollout(acts[: K // 2])  # another signature
-        d2 = ps.last_launch()
+        env.rollout(acts[: K // 2])  # another length of the same class (< 256 steps): the calibration is kept (round 6)
+        d_same = ps.last_launch()
+        env.rollout(torch.cat([acts, acts, acts]))  # 384 steps: the other class -- a new calibration
+        d2 = (d_same, ps.last_launch())
         env.close()
         for k in env_kw:
             monkeypatch.delenv(k)
@@ -2750,7 +2753,8 @@ def test_rate_limiter_closed_loop_calibrates_and_never_changes_results(monkeypat
     assert "limiter calibrating" in descs[0] and "1.00 x" in descs[0]
     assert any("limiter calibrated" in d for d in descs), descs[-1]
     assert "limiter calibrated" in descs[-1]
-    assert "limiter calibrating" in d2  # K changed: a new calibration
+    assert "limiter calibrated" in d2[0]  # K changed within its class (short launches): no new calibration -- a training loop may vary K
+    assert "limiter calibrating" in d2[1]  # ... across the classes (K >= 256): fixed costs no longer weigh on the timings, a new one
     ref, rdesc, _ = run({"GEMX_PACE_CAL": "0"}, 2)
     assert "limiter" not in rdesc[0] and "rate limit" in rdesc[0]
     assert torch.equal(ref[0][0], outs[0][0]) and torch.equal(ref[0][1], outs[0][1])
