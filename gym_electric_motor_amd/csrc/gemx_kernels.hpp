@@ -697,7 +697,8 @@ __device__ __forceinline__ float dp5_adaptive_pk(const DevParams<float> &P, floa
         auto ev = [&](const V &zz, V &dz) {
             const float tq = E.rhs(P, zz, dz);
             const float om = zz.w;
-            dz.w = kink ? (tq - (P.lc * (om * fabsf(om)) + P.lb * om + fmaf(kc1, om, kc0))) * P.inv_j : poly_load_ode<float>(P, om, tq);
+            if (kink) dz.w = (tq - (P.lc * (om * fabsf(om)) + P.lb * om + fmaf(kc1, om, kc0))) * P.inv_j;  // (a wave-uniform branch: not both sides)
+            else dz.w = poly_load_ode<float>(P, om, tq);
         };
         float q = (float)(35.0 / 384.0) * z.w;
         zt = pk_axpy(z, hh, pk_scale((float)(1.0 / 5.0), k1));

@@ -10,7 +10,8 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/${TAG}_bench.log 2>&1   # exactly what the driver runs (HBM traffic measured in-run by its own --pmc child passes)
-tail -1 $OUT/${TAG}_bench.log > $OUT/${TAG}_bench.json
+tail -1 $OUT/${TAG}_bench.log > $OUT/${TAG}_bench.json          # the compact stdout line (round 6: < 6 KB, printed last)
+cp $R/bench_extras.json $OUT/${TAG}_bench_extras.json 2>/dev/null  # ... and the full record beside it
 # (the runs under rocprofv3 below pass --no-pmc: no profiler inside the profiler)
 ksub() { [ "$1" = permexdc ] && echo dc_stream || echo advance; }  # the dominant kernel of a workload (config 2: dc_stream_kernel)
 for WL in pmsm permexdc scim scim_constspeed; do
@@ -49,7 +50,11 @@ for K in 1000 3000 6000; do
 done
 # the records that go with them: the GPU suite, the parity report, two ranks on this one GPU (gloo control plane) with the chunk gather
 cd $R
-python -m pytest tests -m gpu -q -n 4 2>&1 | tail -3 > $OUT/${TAG}_gpu_tests.txt
+rm -f $OUT/${TAG}_cov_tests.txt
+GEMX_COVERAGE_FILE=$OUT/${TAG}_cov_tests.txt python -m pytest tests -m gpu -q -n 4 2>&1 | tail -3 > $OUT/${TAG}_gpu_tests.txt   # (+ the instantiation-coverage record)
+python tools/latency_bound_rows.py > $OUT/${TAG}_latency_bound_rows.md 2>/dev/null   # needs variants/lat_a, lat_b (python tools/latency_bound_rows.py --build)
+python tools/bench_matrix.py --solver default --chunks 4 --only "PMSM cont" "EESM cont" "DFIM cont" "ExtExDc cont" > $OUT/${TAG}_matrix_actions_from_hbm.md 2>/dev/null
+python tools/bench_matrix.py --solver default --chunks 4 --half-actions --only "PMSM cont" "EESM cont" "DFIM cont" "ExtExDc cont" > $OUT/${TAG}_matrix_half_actions_from_hbm.md 2>/dev/null
 # (round 5: both scripts exit non-zero on any failed comparison, and the collection records it -- a FAIL cell used to be swallowed)
 python tests/parity_report.py > $OUT/${TAG}_parity.md 2>&1; echo "parity_report.py exit status $?" >> $OUT/${TAG}_gpu_tests.txt
 python tests/solver_scan.py > $OUT/${TAG}_solver_scan.md 2>/dev/null; echo "solver_scan.py exit status $?" >> $OUT/${TAG}_gpu_tests.txt
