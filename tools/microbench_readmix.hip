@@ -50,6 +50,16 @@ __global__ __launch_bounds__(256) void mix(vf4 *out, const vf4 *act, vf4 *sink, 
             } else if (mode == 2) {
                 if (lane < 48 && kb < K) f0 = act[((long long)w * K + kb) * 48 + lane];
                 if (lane < 48 && kb + 1 < K) f1 = act[((long long)w * K + kb + 1) * 48 + lane];
+            } else if (mode == 5) {  // round 6: mode 1 with NON-TEMPORAL loads (the action stream is read once)
+                if (lane < 48 && kb < K) f0 = __builtin_nontemporal_load(&act[(long long)kb * act_row_v + (long long)w * 48 + lane]);
+                if (lane < 48 && kb + 1 < K) f1 = __builtin_nontemporal_load(&act[(long long)(kb + 1) * act_row_v + (long long)w * 48 + lane]);
+            } else if (mode == 6) {  // round 6: mode 1, but BOTH steps' rows fetched by one instruction's 64 lanes where they fit (2 x 48 = 96 units: two instructions of 48 -> 64 + 32)
+                const long long u = (long long)lane;
+                if (kb + 1 < K) {
+                    const long long r0 = (long long)kb * act_row_v + (long long)w * 48, r1 = (long long)(kb + 1) * act_row_v + (long long)w * 48;
+                    f0 = act[u < 48 ? r0 + u : r1 + (u - 48)];
+                    if (lane < 32) f1 = act[r1 + 16 + lane];
+                }
             } else if (mode == 4) {  // round 6: a NARROW action tensor, [K][N][A] halves -- 384 B per workgroup and step (24 sixteen-byte units)
                 const long long hrow_v = (long long)N * 6 / 16;
                 if (lane < 24 && kb < K) f0 = act[(long long)kb * hrow_v + (long long)w * 24 + lane];
@@ -76,9 +86,10 @@ int main() {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     printf("| action reads | pace (ns per 2-step block) | us per launch | bytes moved | GB/s | of 8 TB/s |\n|---|---|---|---|---|---|\n");
-    const char *names[5] = {"none", "[K][N][A] (reference)", "group-major, per step", "group-major, 12 KB every 8 blocks", "[K][N][A] as HALVES (6 B per env-step)"};
+    const char *names[7] = {"none", "[K][N][A] (reference)", "group-major, per step", "group-major, 12 KB every 8 blocks", "[K][N][A] as HALVES (6 B per env-step)",
+                            "[K][N][A], non-temporal loads", "[K][N][A], two rows per 64-lane instruction"};
     for (unsigned pace : {0u, 150u, 162u, 175u}) {
-        for (int mode = 0; mode < 5; ++mode) {
+        for (int mode = 0; mode < 7; ++mode) {
             auto launch = [&]() { hipLaunchKernelGGL(mix, dim3(N / 64), dim3(256), 0, 0, out, act, sink, K, N, mode, pace); };
             for (int r = 0; r < 10; ++r) launch();
             hipDeviceSynchronize();
