@@ -501,6 +501,30 @@ def test_parity_contract_constants_match_the_design_document():
     assert "from parity_contract import FLUX_FLOOR, SIGN_MARGIN" in gpu and not re.search(r"^(FLUX_FLOOR|SIGN_MARGIN)\s*=", gpu, re.M)
 
 
+def test_unit_libraries_are_complete_small_and_self_contained():
+    """Round 6: one shared object per kernel unit, loaded by gemx_create.  All 38 exist beside libgemx.so, each exports gemx_unit_init /
+    gemx_unit_launch (and nothing of libgemx.so is needed to load one: no DT_NEEDED on it), what a handle maps -- the C ABI + ONE unit --
+    stays far below 20 MB on disk, and the whole set below half of round 5's 144 MB library."""
+    import subprocess
+
+    from gym_electric_motor_amd import build as b
+
+    libs = b.all_libs()
+    assert len(libs) == 39 and all(os.path.exists(p) for p in libs), [p for p in libs if not os.path.exists(p)]
+    sizes = {os.path.basename(p): os.path.getsize(p) for p in libs}
+    assert sizes["libgemx.so"] < 2 << 20 and max(v for k, v in sizes.items() if k != "libgemx.so") + sizes["libgemx.so"] < 20 << 20, sizes
+    assert sum(sizes.values()) < 72 << 20, sum(sizes.values())
+    for p in libs[1:4] + libs[-2:]:
+        dyn = subprocess.run(["nm", "-D", "--defined-only", p], capture_output=True, text=True).stdout
+        assert " T gemx_unit_init" in dyn and " T gemx_unit_launch" in dyn, p
+        needed = subprocess.run(["readelf", "-d", p], capture_output=True, text=True).stdout
+        assert "libgemx.so" not in needed, p
+    # a unit compiled against another handle layout / ABI refuses to serve (what gemx_create reports as "rebuild the package")
+    u = C.CDLL(libs[1])
+    u.gemx_unit_init.argtypes = [C.c_ulonglong, C.c_int, C.c_void_p]
+    assert u.gemx_unit_init(1, _lib.ABI_VERSION, None) == -1 and u.gemx_unit_init(0, _lib.ABI_VERSION + 1, None) == -1
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(REPO, "gym_electric_motor_amd")
     for root, _, files in os.walk(pkg):
