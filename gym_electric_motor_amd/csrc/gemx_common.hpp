@@ -322,12 +322,25 @@ __host__ __device__ inline double inv_norm_cdf(double p) {
     }
     return q < 0 ? -val : val;
 }
+// The truncated normal's arithmetic -- the inverse CDF's three rational polynomials, erfc for per-reset bounds: ~600 fp64 instructions -- as
+// REAL CALLS (round 6).  Inlined, it sat in the middle of every draw, also the uniform ones that never execute it, and a draw on the
+// integrator's stream (a lane that outran its queue of prepared draws) fetched its way through all of it from a cold instruction cache:
+// ~13 000 cycles per event for a PMSM draw of ~200 executed instructions (profiles/r06_rinit_probe.md).
+__device__ __attribute__((noinline)) double init_gauss_state(double mu, double sigma, double cdf_lo, double cdf_hi, double lo, double hi, double u) {
+    const double x = mu + sigma * inv_norm_cdf(cdf_lo + (cdf_hi - cdf_lo) * u);
+    return fmin(fmax(x, lo), hi);
+}
+__device__ __attribute__((noinline)) double init_gauss_bounded(double mu_cfg, double sg, double lo, double hi, double u) {
+    // electric_motor.py:236-249: mue = random_params[0] or the middle of the interval, sigma = random_params[1] or 1 (mu = NaN: middle)
+    const double mu = mu_cfg == mu_cfg ? mu_cfg : 0.5 * (hi - lo) + lo;
+    const double cl = 0.5 * erfc(-(lo - mu) / sg * 0.70710678118654752440), ch = 0.5 * erfc(-(hi - mu) / sg * 0.70710678118654752440);
+    return fmin(fmax(mu + sg * inv_norm_cdf(cl + (ch - cl) * u), lo), hi);
+}
 // the j-th initial state from its uniform u in (0, 1): uniform in [lo, hi], or normal(mu, sigma) truncated to [lo, hi] by inverse CDF
 __device__ __forceinline__ double init_state_from_uniform(const InitDev *I, int j, double u) {
     if (!(I->lo[j] < I->hi[j])) return I->constant[j];
     if (I->kind == GEMX_INIT_UNIFORM) return fma(I->hi[j] - I->lo[j], u, I->lo[j]);  // (one rounding, spelled out: the same bits from every call site)
-    const double x = I->mu[j] + I->sigma[j] * inv_norm_cdf(I->cdf_lo[j] + (I->cdf_hi[j] - I->cdf_lo[j]) * u);
-    return fmin(fmax(x, I->lo[j]), I->hi[j]);
+    return init_gauss_state(I->mu[j], I->sigma[j], I->cdf_lo[j], I->cdf_hi[j], I->lo[j], I->hi[j], u);
 }
 // all (<= 8) uniforms of one (env, reset count): two Philox blocks -- the second one only where something reads it (more than four ODE
 // states, or the induction machines' field angle, uniform 7); wave-uniform
@@ -347,10 +360,7 @@ __device__ __forceinline__ void init_uniforms(const InitDev *I, int64_t env, uin
 __device__ __forceinline__ double init_draw_bounded(const InitDev *I, int j, double lo, double hi, double u) {
     if (!(lo < hi)) return lo;  // (upper - lower) * u + lower of a degenerate interval
     if (I->kind == GEMX_INIT_UNIFORM) return fma(hi - lo, u, lo);
-    // electric_motor.py:236-249: mue = random_params[0] or the middle of the interval, sigma = random_params[1] or 1 (mu[j] = NaN: middle)
-    const double mu = I->mu[j] == I->mu[j] ? I->mu[j] : 0.5 * (hi - lo) + lo, sg = I->sigma[j];
-    const double cl = 0.5 * erfc(-(lo - mu) / sg * 0.70710678118654752440), ch = 0.5 * erfc(-(hi - mu) / sg * 0.70710678118654752440);
-    return fmin(fmax(mu + sg * inv_norm_cdf(cl + (ch - cl) * u), lo), hi);
+    return init_gauss_bounded(I->mu[j], I->sigma[j], lo, hi, u);
 }
 // THE draw of one reset: out[0 .. n-1] = the ODE states (+ the angle in slot n - 1 when the system has one) of (env, reset count).
 // Induction machines (flux_mode; induction_motor.py:174-185, 250-285, squirrel_cage_induction_motor.py:146-157): a field angle
