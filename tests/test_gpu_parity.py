@@ -473,6 +473,48 @@ def test_error_controlled_solver_fp64_against_the_reference_default_solver(name)
     assert rel < 2e-5, (rel, col, dmsg)
 
 
+@pytest.mark.parametrize("name", ["scim_epi_uniform_euler", "pmsm_sc_free_held_dopri5", "scim_free_held_dopri5", "permexdc_sc_free_held_dopri5"])
+@pytest.mark.parametrize("split_kinks", [True, False])
+def test_error_controlled_solver_fp64_equals_its_cpu_restatement(name, split_kinks):
+    """Round 6: the device's error controller -- carried proposal, first try = segment / ceil(0.9 segment / proposal), rejections cut by
+    clamp(0.9 err^-1/5, 0.2, 1), omega's absolute tolerance in normalised units and, with split_kinks, every attempt on the smooth model
+    system with the kink's defect in closed form -- is restated step for step in the test infrastructure (ORC_SOLVER_DEV_ADAPTIVE[_KINK]),
+    which is where its wave statistics come from (tools/wave_step_statistics.py).  The fp64 build must reproduce that restatement:
+    same accept / reject decisions, same sub-steps -- 1e-9 absolute over per-lane random action streams with auto-resets, done masks equal."""
+    import torch
+
+    import gym_electric_motor_amd as ga
+    from oracle import oracle as orc
+
+    d, meta = _load(name)
+    n, K = 6, min(1200, d["actions"].shape[0])
+    env = _make_from_meta(meta, n, solver=ga.ScipyOdeSolver(split_kinks=split_kinks), dtype="float64", auto_reset=True)
+    ps = env.physical_system
+    rng = np.random.default_rng(11)
+    a = rng.uniform(-1.0, 1.0, (K, n, ps._n_act))
+    a[K // 2:] = a[K // 2]  # (second half held: long smooth stretches, the carried proposal at work)
+    obs, done = env.rollout(torch.as_tensor(a, device="cuda"))
+    ps.check_errors()
+    obs, done = obs.cpu().numpy(), done.cpu().numpy().astype(bool)
+    env.close()
+    L = orc.lib()
+    L.orc_dev_set_atol_omega_scaled(1)
+    try:
+        p = orc.params_from_meta(meta, solver="dev_adaptive_kink" if split_kinks else "dev_adaptive")
+        for j in range(n):
+            e = orc.OracleEnv(p)
+            e.reset()
+            ro, rd = e.rollout(a[:, j], auto_reset=True)
+            diff = np.abs(obs[:, j] - ro)
+            k_eps = list(meta["state_names"]).index("epsilon") if "epsilon" in meta["state_names"] else None
+            if k_eps is not None:
+                diff[:, k_eps] = np.minimum(diff[:, k_eps], 2.0 - diff[:, k_eps])
+            assert (rd == done[:, j]).all(), (name, j)
+            assert diff.max() < 1e-9, (name, split_kinks, j, float(diff.max()), int(np.argmax(diff.max(axis=1))))
+    finally:
+        L.orc_dev_set_atol_omega_scaled(0)
+
+
 def test_error_controlled_solver_is_the_same_in_every_kernel_and_chunking():
     """One fused rollout == the same steps in uneven chunks == step by step (gemx_step), and the pipelined kernel == the single-wave
     kernel: the step-size decisions are per control step and per lane, so nothing may depend on how the steps are batched."""
